@@ -1,0 +1,130 @@
+/*
+ * sis_hip.h -- C ABI of libsis_hip.so: the MI355X (gfx950) kernels behind the
+ * synthesis-in-style hot path (StyleGAN2 generator forward + segmentation training step).
+ *
+ * Drop-in boundary.  Every entry point takes plain device pointers, sizes and a HIP stream
+ * (passed as void*, i.e. a hipStream_t; NULL = the legacy default stream).  No torch types.
+ * Inputs are borrowed and must be contiguous; outputs are caller-allocated.  Nothing here
+ * synchronises the host.  Return value: 0 on success, non-zero on error (message from
+ * sis_last_error(), thread-local).  The reference interface each function replaces is cited
+ * as file:line relative to /root/reference/stylegan_code_finder/.
+ *
+ * dtype codes: 0 = float32, 1 = float64, 2 = float16, 3 = bfloat16.
+ */
+#ifndef SIS_HIP_H
+#define SIS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIS_F32 0
+#define SIS_F64 1
+#define SIS_F16 2
+#define SIS_BF16 3
+
+/* library version (major*1000 + minor) and last error text of the calling thread */
+int sis_version(void);
+const char* sis_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  fused bias + activation.
+ * Replaces the pybind entry `fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)`
+ *   networks/stylegan2/op/fused_bias_act.cpp:11-21, launcher fused_bias_act_kernel.cu:52-99,
+ *   element formula fused_bias_act_kernel.cu:25-47.
+ * out[i] = f(x[i] + bias[(i / step_b) % size_b]) * scale, mode = act*10+grad:
+ *   10/11 linear; 30 leaky-relu(alpha); 31 leaky-relu gradient gated on ref[i] > 0; 12/32 zero.
+ * bias == NULL (or size_b == 0) means "no bias", ref == NULL means "no ref" (the reference
+ * passes empty tensors, fused_bias_act_kernel.cu:62-63).  step_b = product of dims[2:].
+ */
+int sis_fused_bias_act(void* out, const void* x, const void* bias, const void* ref, int dtype,
+                       int64_t numel, int64_t step_b, int64_t size_b, int act, int grad,
+                       float alpha, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  upfirdn2d: zero-insert upsample, pad/crop, 2-D FIR with the flipped taps, decimate.
+ * Replaces the pybind entry `upfirdn2d_op.upfirdn2d(input, kernel, up_x, up_y, down_x, down_y,
+ *   pad_x0, pad_x1, pad_y0, pad_y1)`  networks/stylegan2/op/upfirdn2d.cpp:12-23,
+ *   launcher/dispatch upfirdn2d_kernel.cu:140-272, kernel :52-137.
+ * in  [major, in_h, in_w, minor], taps [kh, kw] (same dtype as in), out [major, out_h, out_w, minor]
+ * with out = (in*up + pad0 + pad1 - k + down) / down  (upfirdn2d_kernel.cu:167-168).
+ * Unlike the reference (which silently returns uninitialised memory for an up/down/tap
+ * combination outside its 6 modes, upfirdn2d_kernel.cu:172-175) every combination is computed.
+ */
+int sis_upfirdn2d_out_size(int in_size, int up, int down, int pad0, int pad1, int k);
+int sis_upfirdn2d(void* out, const void* in, const void* taps, int dtype, int major, int in_h,
+                  int in_w, int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                  int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Generator building blocks (float32).  Together they replace the composite PyTorch code of
+ * networks/stylegan2/model.py cited per function.
+ */
+
+/* PixelNorm, model.py:19-20: out[b,:] = x[b,:] * rsqrt(mean(x[b,:]^2) + 1e-8). */
+int sis_pixel_norm(float* out, const float* x, int batch, int dim, void* stream);
+
+/* EqualLinear, model.py:152-162: out[b,o] = sum_i x[b,i] * w[o,i] * scale + bias[o]*lr_mul, then
+ * (activation != 0) leaky-relu(0.2) * sqrt(2) as fused_leaky_relu does (fused_act.py:85-86).
+ * x rows are x_row_stride floats apart (lets a [B, n_latent, D] latent be indexed in place). */
+int sis_equal_linear(float* out, const float* x, int64_t x_row_stride, const float* w,
+                     const float* bias, int batch, int in_dim, int out_dim, float scale,
+                     float lr_mul, int activation, void* stream);
+
+/* Truncation trick, model.py:502-510: out = mean + psi * (w - mean); mean is [dim]. */
+int sis_truncate(float* out, const float* w, const float* mean, float psi, int batch, int dim,
+                 void* stream);
+
+/* Weight prepack for the modulated convolution (once per checkpoint):
+ *   wpk[ci][tap][co] = w[co][ci][tap]            (tap = kh*ks + kw)
+ *   wsq[co][ci]      = sum_tap w[co][ci][tap]^2  (feeds the demodulation, model.py:243-245)
+ * w is the ModulatedConv2d.weight parameter [1, Cout, Cin, ks, ks] (model.py:223-225). */
+int sis_modconv_prepack(float* wpk, float* wsq, const float* w, int cout, int cin, int ksize,
+                        void* stream);
+
+/* dscale[b,co] = scale * rsqrt(scale^2 * sum_ci s[b,ci]^2 * wsq[co,ci] + 1e-8) when demodulate,
+ * else scale  (model.py:241-245 with the style factored out of the weights; scale = 1/sqrt(Cin*ks^2),
+ * model.py:219-220). */
+int sis_modconv_demod(float* dscale, const float* s, const float* wsq, int batch, int cin,
+                      int cout, float scale, int demodulate, void* stream);
+
+/* Modulated convolution, stride 1, "same" padding, ks in {1,3}: model.py:272-276 (+ :287-292,
+ * fused_act.py:85-86 when fuse_act != 0):
+ *   y[b,co,h,w] = dscale[b,co] * sum_{ci,kh,kw} wpk[ci][kh*ks+kw][co] * s[b,ci] * x[b,ci,h+kh-p,w+kw-p]
+ *   fuse_act:  y = lrelu_{0.2}(y + noise_weight[0]*noise[nb,0,h,w] + bias[co]) * sqrt(2)
+ * noise is [1,1,H,W] (noise_batch_stride 0) or [B,1,H,W] (stride H*W) or NULL; noise_weight is a
+ * DEVICE pointer to one float (the NoiseInjection.weight parameter).  MFMA fp32 (v_mfma_f32_32x32x2_f32). */
+int sis_modconv2d(float* out, const float* x, const float* wpk, const float* s,
+                  const float* dscale, const float* noise, int64_t noise_batch_stride,
+                  const float* noise_weight, const float* bias, int batch, int cin, int cout,
+                  int h, int w, int ksize, int fuse_act, void* stream);
+
+/* Modulated transposed convolution, stride 2, no padding, ks = 3: model.py:251-261 up to (not
+ * including) the Blur: t[b,co,p,q] = dscale[b,co] * sum_{ci, 2h+kh=p, 2w+kw=q} wpk[ci][kh*3+kw][co]
+ * * s[b,ci] * x[b,ci,h,w];  t is [B, Cout, 2H+1, 2W+1]. */
+int sis_modconv2d_up(float* t, const float* x, const float* wpk, const float* s,
+                     const float* dscale, int batch, int cin, int cout, int h, int w,
+                     void* stream);
+
+/* Blur (upfirdn2d up=1 down=1, model.py:89-92 / :262) fused with NoiseInjection + FusedLeakyReLU
+ * (model.py:338-340): in [B,C,IH,IW] -> out [B,C,OH,OW], OH = IH + pad0 + pad1 - kh + 1.
+ * fuse_act == 0 gives the plain blur. taps [kh,kw] float32 device pointer. */
+int sis_blur_noise_act(float* out, const float* in, const float* taps, const float* noise,
+                       int64_t noise_batch_stride, const float* noise_weight, const float* bias,
+                       int batch, int channels, int in_h, int in_w, int kh, int kw, int pad0,
+                       int pad1, int fuse_act, void* stream);
+
+/* ToRGB, model.py:355-364: out[b,c,y,x] = scale * sum_ci w[c,ci]*s[b,ci]*x[b,ci,y,x] + bias[c]
+ * + upfirdn2d(skip, taps, up=2, pad=(pad0,pad1))[b,c,y,x]   (skip == NULL: first ToRGB).
+ * w is the [1,3,Cin,1,1] parameter, skip is [B,3,H/2,W/2], taps [kh,kw]. out channels fixed to
+ * `cout` <= 4. */
+int sis_to_rgb(float* out, const float* x, const float* w, const float* s, const float* bias,
+               const float* skip, const float* taps, int batch, int cin, int cout, int h, int width,
+               int kh, int kw, int pad0, int pad1, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIS_HIP_H */

@@ -1,0 +1,94 @@
+"""ORACLE (test infrastructure, not product): import the UNMODIFIED reference
+modules by file path, in THIS container only.
+
+``/root/reference`` does not exist on the GPU box, so nothing that runs there
+(``-m gpu`` tests, ``smoke()``, ``bench.py``) may call into this file; it is used
+by ``tests/golden/make_golden.py`` and by the CPU tests that pin the oracle, and
+those tests skip when the reference tree is absent.
+
+Recipe: ``networks/stylegan2/model.py`` has one relative import,
+``from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d`` (model.py:12).
+We register a synthetic package ``refpkg`` whose ``refpkg.op`` is
+``oracle.ops_ref`` (the reference's own ops are CUDA-only), then exec model.py as
+``refpkg.model``.  Everything else -- ModulatedConv2d, Blur pads, ToRGB, forward
+control flow, truncation, noise handling, parameter init -- is the reference's
+own code.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+REFERENCE_ROOT = "/root/reference/stylegan_code_finder"
+
+
+def reference_available():
+    return os.path.isfile(os.path.join(REFERENCE_ROOT, "networks", "stylegan2", "model.py"))
+
+
+def load_reference_stylegan2():
+    """Returns the reference ``networks.stylegan2.model`` module object."""
+    if "refpkg.model" in sys.modules:
+        return sys.modules["refpkg.model"]
+    from oracle import ops_ref
+
+    pkg = types.ModuleType("refpkg")
+    pkg.__path__ = []
+    sys.modules["refpkg"] = pkg
+    sys.modules["refpkg.op"] = ops_ref
+    path = os.path.join(REFERENCE_ROOT, "networks", "stylegan2", "model.py")
+    spec = importlib.util.spec_from_file_location("refpkg.model", path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["refpkg.model"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _stub_modules():
+    """cv2 (only used by BaseSegmenter post-processing) and ml_collections (a config
+    attribute-dict) are absent from this image; neither takes part in forward/backward."""
+    if "cv2" not in sys.modules:
+        try:
+            import cv2  # noqa: F401
+        except Exception:
+            sys.modules["cv2"] = types.ModuleType("cv2")
+    if "ml_collections" not in sys.modules:
+        try:
+            import ml_collections  # noqa: F401
+        except Exception:
+            m = types.ModuleType("ml_collections")
+
+            class ConfigDict(dict):
+                def __getattr__(self, k):
+                    try:
+                        return self[k]
+                    except KeyError as e:
+                        raise AttributeError(k) from e
+
+                def __setattr__(self, k, v):
+                    self[k] = v
+
+            m.ConfigDict = ConfigDict
+            sys.modules["ml_collections"] = m
+
+
+def load_reference_segmenters():
+    """Returns (ema_net.network, trans_u_net.vit_seg_modeling, trans_u_net.utils, ema_net.utils)
+    of the reference, imported with a bare ``networks`` package (skipping networks/__init__.py,
+    which needs skimage / pytorch_training)."""
+    _stub_modules()
+    if "networks" not in sys.modules or not getattr(sys.modules["networks"], "_sis_ref_stub", False):
+        if "networks" in sys.modules:
+            raise RuntimeError("a different top-level 'networks' package is already imported; "
+                               "import the reference segmenters in a fresh process")
+        pkg = types.ModuleType("networks")
+        pkg.__path__ = [os.path.join(REFERENCE_ROOT, "networks")]
+        pkg._sis_ref_stub = True
+        sys.modules["networks"] = pkg
+    import importlib
+
+    ema = importlib.import_module("networks.ema_net.network")
+    ema_utils = importlib.import_module("networks.ema_net.utils")
+    vit = importlib.import_module("networks.trans_u_net.vit_seg_modeling")
+    tu_utils = importlib.import_module("networks.trans_u_net.utils")
+    return ema, vit, tu_utils, ema_utils

@@ -1,0 +1,267 @@
+// Small generator-side kernels (fp32): mapping network pieces, weight prepack, demodulation
+// coefficients and the ToRGB / skip accumulation.  None of these is on the MFMA roofline; they
+// are latency- or HBM-bound and written so that each reads its operands exactly once.
+#include "sis_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// PixelNorm (model.py:19-20): one wave per row.
+__global__ __launch_bounds__(256) void pixel_norm_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                         int batch, int dim) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= batch) return;
+    const float* xr = x + (int64_t)row * dim;
+    float ss = 0.f;
+    for (int i = lane; i < dim; i += 64) { const float v = xr[i]; ss += v * v; }
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss / (float)dim + 1e-8f);
+    for (int i = lane; i < dim; i += 64) out[(int64_t)row * dim + i] = xr[i] * r;
+}
+
+// EqualLinear (model.py:152-162).  One wave per output feature; the wave keeps its weight row in
+// registers (in_dim <= 64*ELW floats) and walks the batch, so the [out,in] matrix is read once.
+constexpr int ELW = 16;  // supports in_dim up to 1024
+__global__ __launch_bounds__(256) void equal_linear_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                           int64_t x_row_stride, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, int batch, int in_dim,
+                                                           int out_dim, float scale, float lr_mul, int activation) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (o >= out_dim) return;
+    float wr[ELW];
+#pragma unroll
+    for (int j = 0; j < ELW; ++j) {
+        const int i = lane + 64 * j;
+        wr[j] = (i < in_dim) ? w[(int64_t)o * in_dim + i] : 0.f;
+    }
+    const float b = bias ? bias[o] * lr_mul : 0.f;
+    for (int r = 0; r < batch; ++r) {
+        const float* xr = x + (int64_t)r * x_row_stride;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < ELW; ++j) {
+            const int i = lane + 64 * j;
+            if (i < in_dim) acc += xr[i] * wr[j];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            float v = acc * scale + b;
+            if (activation) v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
+            out[(int64_t)r * out_dim + o] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void truncate_kernel(float* __restrict__ out, const float* __restrict__ w,
+                                                       const float* __restrict__ mean, float psi, int64_t n, int dim) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const float m = mean[i % dim]; out[i] = m + psi * (w[i] - m); }
+}
+
+// wpk[ci][tap][co] = w[co][ci][tap];  wsq[co][ci] = sum_tap w^2.  One lane per (co, ci).
+__global__ __launch_bounds__(256) void prepack_kernel(float* __restrict__ wpk, float* __restrict__ wsq,
+                                                      const float* __restrict__ w, int cout, int cin, int taps) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // i = ci * cout + co  (co fastest -> coalesced writes)
+    if (i >= (int64_t)cout * cin) return;
+    const int co = (int)(i % cout), ci = (int)(i / cout);
+    const float* src = w + ((int64_t)co * cin + ci) * taps;
+    float ss = 0.f;
+    for (int t = 0; t < taps; ++t) {
+        const float v = src[t];
+        ss += v * v;
+        wpk[((int64_t)ci * taps + t) * cout + co] = v;
+    }
+    wsq[(int64_t)co * cin + ci] = ss;
+}
+
+// dscale[b,co] = scale * rsqrt(scale^2 * sum_ci s^2 * wsq + 1e-8): one wave per (b, co).
+__global__ __launch_bounds__(256) void demod_kernel(float* __restrict__ dscale, const float* __restrict__ s,
+                                                    const float* __restrict__ wsq, int batch, int cin, int cout,
+                                                    float scale, int demodulate) {
+    const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (idx >= (int64_t)batch * cout) return;
+    const int b = (int)(idx / cout), co = (int)(idx % cout);
+    if (!demodulate) { if (lane == 0) dscale[idx] = scale; return; }
+    const float* sr = s + (int64_t)b * cin;
+    const float* wr = wsq + (int64_t)co * cin;
+    float acc = 0.f;
+    for (int i = lane; i < cin; i += 64) { const float sv = sr[i] * scale; acc += sv * sv * wr[i]; }
+    acc = wave_sum(acc);
+    if (lane == 0) dscale[idx] = scale * rsqrtf(acc + 1e-8f);
+}
+
+// ToRGB (model.py:355-364): 1x1 modulated conv to <=4 channels + bias + upsampled skip.
+// HBM-bound: reads x once (Cin planes), 4 pixels per lane (float4 when W % 4 == 0).
+struct RgbParams {
+    int batch, cin, cout, h, w, kh, kw, pad0, sh, sw;
+    float scale;
+};
+constexpr int RGB_MAXC = 4;
+
+__device__ __forceinline__ float skip_up2(const float* __restrict__ sp, const float* __restrict__ taps,
+                                          const RgbParams& p, int y, int x) {
+    // upfirdn2d with up=2, down=1 at output (y,x): polyphase walk of upfirdn2d_kernel.cu:112-129
+    const int mid_x = x + 1 - p.pad0, mid_y = y + 1 - p.pad0;
+    const int ix0 = (mid_x >= 0) ? mid_x / 2 : -((1 - mid_x) / 2);
+    const int iy0 = (mid_y >= 0) ? mid_y / 2 : -((1 - mid_y) / 2);
+    const int kx0 = (ix0 + 1) * 2 - mid_x - 1, ky0 = (iy0 + 1) * 2 - mid_y - 1;
+    float v = 0.f;
+    for (int fy = ky0, iy = iy0; fy < p.kh; fy += 2, ++iy) {
+        if (iy < 0 || iy >= p.sh) continue;
+        for (int fx = kx0, ix = ix0; fx < p.kw; fx += 2, ++ix) {
+            if (ix < 0 || ix >= p.sw) continue;
+            v += sp[iy * p.sw + ix] * taps[(p.kh - 1 - fy) * p.kw + (p.kw - 1 - fx)];
+        }
+    }
+    return v;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void to_rgb_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                     const float* __restrict__ w, const float* __restrict__ s,
+                                                     const float* __restrict__ bias, const float* __restrict__ skip,
+                                                     const float* __restrict__ taps, RgbParams p) {
+    extern __shared__ __attribute__((aligned(16))) float weff[];  // [cout][cin]: scale * w[c,ci] * s[b,ci]
+    const int hw = p.h * p.w;
+    const int groups = (hw + 256 * VEC - 1) / (256 * VEC);
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    for (int e = threadIdx.x; e < p.cout * p.cin; e += 256) {
+        const int ci = e % p.cin;
+        weff[e] = p.scale * w[e] * s[(int64_t)b * p.cin + ci];
+    }
+    __syncthreads();
+    const int pix = (g * 256 + threadIdx.x) * VEC;
+    if (pix >= hw) return;
+    float acc[RGB_MAXC][VEC];
+#pragma unroll
+    for (int c = 0; c < RGB_MAXC; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[c][v] = 0.f;
+    const float* xb = x + (int64_t)b * p.cin * hw + pix;
+#pragma unroll 4
+    for (int ci = 0; ci < p.cin; ++ci) {
+        float xv[4];
+        if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(xb + (int64_t)ci * hw);
+            xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+        } else {
+            xv[0] = xb[(int64_t)ci * hw];
+        }
+#pragma unroll
+        for (int c = 0; c < RGB_MAXC; ++c) {
+            if (c < p.cout) {
+                const float wv = weff[c * p.cin + ci];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[c][v] += wv * xv[v];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < RGB_MAXC; ++c) {
+        if (c >= p.cout) continue;
+        const float bb = bias ? bias[c] : 0.f;
+        float* o = out + ((int64_t)b * p.cout + c) * hw + pix;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float r = acc[c][v] + bb;
+            if (skip) {
+                const int y = (pix + v) / p.w, xx = (pix + v) % p.w;
+                r += skip_up2(skip + ((int64_t)b * p.cout + c) * p.sh * p.sw, taps, p, y, xx);
+            }
+            o[v] = r;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sis_pixel_norm(float* out, const float* x, int batch, int dim, void* stream) {
+    if (batch <= 0 || dim <= 0) return 0;
+    SIS_REQUIRE(out && x, "sis_pixel_norm: null pointer");
+    hipLaunchKernelGGL(pixel_norm_kernel, dim3(sis_cdiv(batch, 4)), dim3(256), 0, (hipStream_t)stream, out, x, batch, dim);
+    SIS_CHECK_LAUNCH("sis_pixel_norm");
+    return 0;
+}
+
+extern "C" int sis_equal_linear(float* out, const float* x, int64_t x_row_stride, const float* w, const float* bias,
+                                int batch, int in_dim, int out_dim, float scale, float lr_mul, int activation,
+                                void* stream) {
+    if (batch <= 0 || out_dim <= 0) return 0;
+    SIS_REQUIRE(out && x && w, "sis_equal_linear: null pointer");
+    SIS_REQUIRE(in_dim > 0 && in_dim <= 64 * ELW, "sis_equal_linear: in_dim %d outside 1..%d", in_dim, 64 * ELW);
+    hipLaunchKernelGGL(equal_linear_kernel, dim3(sis_cdiv(out_dim, 4)), dim3(256), 0, (hipStream_t)stream, out, x,
+                       x_row_stride, w, bias, batch, in_dim, out_dim, scale, lr_mul, activation);
+    SIS_CHECK_LAUNCH("sis_equal_linear");
+    return 0;
+}
+
+extern "C" int sis_truncate(float* out, const float* w, const float* mean, float psi, int batch, int dim,
+                            void* stream) {
+    const int64_t n = (int64_t)batch * dim;
+    if (n <= 0) return 0;
+    SIS_REQUIRE(out && w && mean, "sis_truncate: null pointer");
+    hipLaunchKernelGGL(truncate_kernel, dim3(sis_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out, w, mean, psi, n, dim);
+    SIS_CHECK_LAUNCH("sis_truncate");
+    return 0;
+}
+
+extern "C" int sis_modconv_prepack(float* wpk, float* wsq, const float* w, int cout, int cin, int ksize,
+                                   void* stream) {
+    SIS_REQUIRE(wpk && wsq && w, "sis_modconv_prepack: null pointer");
+    SIS_REQUIRE(cout > 0 && cin > 0 && ksize > 0, "sis_modconv_prepack: bad sizes");
+    const int64_t n = (int64_t)cout * cin;
+    hipLaunchKernelGGL(prepack_kernel, dim3(sis_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, wpk, wsq, w, cout, cin,
+                       ksize * ksize);
+    SIS_CHECK_LAUNCH("sis_modconv_prepack");
+    return 0;
+}
+
+extern "C" int sis_modconv_demod(float* dscale, const float* s, const float* wsq, int batch, int cin, int cout,
+                                 float scale, int demodulate, void* stream) {
+    if (batch <= 0 || cout <= 0) return 0;
+    SIS_REQUIRE(dscale && (!demodulate || (s && wsq)), "sis_modconv_demod: null pointer");
+    hipLaunchKernelGGL(demod_kernel, dim3(sis_cdiv((int64_t)batch * cout, 4)), dim3(256), 0, (hipStream_t)stream, dscale, s,
+                       wsq, batch, cin, cout, scale, demodulate);
+    SIS_CHECK_LAUNCH("sis_modconv_demod");
+    return 0;
+}
+
+extern "C" int sis_to_rgb(float* out, const float* x, const float* w, const float* s, const float* bias,
+                          const float* skip, const float* taps, int batch, int cin, int cout, int h, int wd, int kh,
+                          int kw, int pad0, int pad1, float scale, void* stream) {
+    if (batch <= 0 || h <= 0 || wd <= 0) return 0;
+    SIS_REQUIRE(out && x && w && s, "sis_to_rgb: null pointer");
+    SIS_REQUIRE(cout >= 1 && cout <= RGB_MAXC, "sis_to_rgb: cout %d outside 1..%d", cout, RGB_MAXC);
+    SIS_REQUIRE(cin >= 1 && (size_t)cin * cout * 4 <= 48 * 1024, "sis_to_rgb: cin too large");
+    RgbParams p;
+    p.batch = batch; p.cin = cin; p.cout = cout; p.h = h; p.w = wd; p.kh = kh; p.kw = kw; p.pad0 = pad0;
+    p.sh = 0; p.sw = 0; p.scale = scale;
+    if (skip) {
+        SIS_REQUIRE(taps && kh >= 1 && kw >= 1, "sis_to_rgb: skip given without taps");
+        SIS_REQUIRE(h % 2 == 0 && wd % 2 == 0, "sis_to_rgb: skip path needs even output size");
+        p.sh = h / 2; p.sw = wd / 2;
+        SIS_REQUIRE(sis_upfirdn2d_out_size(p.sh, 2, 1, pad0, pad1, kh) == h &&
+                        sis_upfirdn2d_out_size(p.sw, 2, 1, pad0, pad1, kw) == wd,
+                    "sis_to_rgb: upsampled skip would not match the %dx%d output", h, wd);
+    }
+    const int hw = h * wd;
+    const size_t lds = (size_t)cin * cout * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (hw % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+        const int groups = sis_cdiv(hw, 1024);
+        hipLaunchKernelGGL(to_rgb_kernel<4>, dim3(batch * groups), dim3(256), lds, st, out, x, w, s, bias, skip, taps, p);
+    } else {
+        const int groups = sis_cdiv(hw, 256);
+        hipLaunchKernelGGL(to_rgb_kernel<1>, dim3(batch * groups), dim3(256), lds, st, out, x, w, s, bias, skip, taps, p);
+    }
+    SIS_CHECK_LAUNCH("sis_to_rgb");
+    return 0;
+}

@@ -1,0 +1,372 @@
+"""StyleGAN2 generator for MI355X: the reference's module surface on hand-written HIP kernels.
+
+Drop-in for /root/reference/stylegan_code_finder/networks/stylegan2/model.py (generator half):
+same class names, constructor signatures, attribute names and -- checked by the test-suite --
+the same 135-key ``state_dict`` schema, so ``load_state_dict(torch.load(ckpt)['g_ema'], strict=True)``
+(networks/__init__.py:22-29,422) works unchanged, as do the callers in utils/dataset_creation.py.
+
+What is different is how a layer executes.  The reference materialises
+per-sample weights ``[B,Cout,Cin,k,k]`` and runs a grouped cuDNN convolution (model.py:237-278),
+followed by separate noise, bias/activation and clone kernels.  Here, under ``torch.no_grad()`` on
+a HIP device, every StyledConv is one or two launches of ``libsis_hip.so``:
+
+  conv (stride 1)   sis_modconv2d      MFMA fp32; style applied to the input tile on load; demod, noise,
+                                       bias, leaky-ReLU*sqrt2 in the epilogue
+  conv (upsample)   sis_modconv2d_up   MFMA fp32 transposed conv in 4-phase gather form -> (2H+1)^2
+                    sis_blur_noise_act 4x4 FIR + noise + bias + leaky-ReLU*sqrt2
+  ToRGB             sis_to_rgb         1x1 modulated conv + bias + polyphase-upsampled skip, one pass
+  mapping network   sis_pixel_norm, sis_equal_linear (bias + leaky-ReLU fused), sis_truncate
+
+Weights are shared by the whole batch and prepacked once per checkpoint ([Cin][tap][Cout] plus the
+per-(Cout,Cin) squared sums that give the demodulation coefficients from a [B,Cin]x[Cin,Cout]
+product).  Requested intermediate activations are the layer outputs themselves (never written
+in place afterwards), not extra ``detach().clone()`` copies (model.py:532-549).
+
+With autograd enabled (GAN training / latent projection -- outside the synthesis path) the layers
+fall back to differentiable device code: the reference's grouped-convolution formulation on ATen,
+with ``upfirdn2d`` / ``fused_leaky_relu`` still running on the HIP kernels through their autograd
+Functions.  CPU tensors are rejected with ``RuntimeError`` like the reference's extension does.
+"""
+import math
+import random
+import typing
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+import sis_hip
+from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
+
+
+def _needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def make_kernel(k):
+    """Normalised 2-D FIR taps from a 1-D (outer product) or 2-D list (model.py:23-31)."""
+    taps = torch.tensor(k, dtype=torch.float32)
+    if taps.ndim == 1:
+        taps = torch.outer(taps, taps)
+    return taps / taps.sum()
+
+
+class PixelNorm(nn.Module):
+    def forward(self, input):
+        if _needs_grad(input) or input.dim() != 2:
+            return input * torch.rsqrt(input.pow(2).mean(dim=1, keepdim=True) + 1e-8)
+        return sis_hip.pixel_norm(input)
+
+
+class Upsample(nn.Module):
+    """x2 upsampling FIR of the RGB skip branch: taps * factor^2, pad ((p+1)//2 + f - 1, p//2)."""
+
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer('kernel', make_kernel(kernel) * (factor ** 2))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2 + factor - 1, p // 2)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, up=self.factor, down=1, pad=self.pad)
+
+
+class Blur(nn.Module):
+    def __init__(self, kernel, pad, upsample_factor=1):
+        super().__init__()
+        taps = make_kernel(kernel)
+        if upsample_factor > 1:
+            taps = taps * (upsample_factor ** 2)
+        self.register_buffer('kernel', taps)
+        self.pad = pad
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, pad=self.pad)
+
+
+class EqualLinear(nn.Module):
+    """Linear layer with equalised learning rate: weights stored / lr_mul, scaled by lr_mul/sqrt(in)."""
+
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.full((out_dim,), float(bias_init))) if bias else None
+        self.activation = activation
+        self.lr_mul = lr_mul
+        self.scale = lr_mul / math.sqrt(in_dim)
+
+    def forward(self, input):
+        if _needs_grad(input, self.weight, self.bias) or input.dim() != 2:
+            bias = None if self.bias is None else self.bias * self.lr_mul
+            if self.activation:
+                return fused_leaky_relu(F.linear(input, self.weight * self.scale), bias)
+            return F.linear(input, self.weight * self.scale, bias=bias)
+        if input.is_contiguous():
+            return sis_hip.equal_linear(input, self.weight, self.bias, self.scale, self.lr_mul, self.activation)
+        # a latent[:, i] view of [B, n_latent, D]: rows are a fixed stride apart, read it in place
+        if input.stride(1) != 1:
+            input = input.contiguous()
+            return sis_hip.equal_linear(input, self.weight, self.bias, self.scale, self.lr_mul, self.activation)
+        return sis_hip.equal_linear(input, self.weight, self.bias, self.scale, self.lr_mul, self.activation,
+                                    row_stride=input.stride(0), batch=input.shape[0])
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})'
+
+
+class ModulatedConv2d(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False,
+                 downsample=False, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        self.eps = 1e-8
+        self.kernel_size = kernel_size
+        self.in_channel = in_channel
+        self.out_channel = out_channel
+        self.upsample = upsample
+        self.downsample = downsample
+        self.demodulate = demodulate
+        if upsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) - (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1), upsample_factor=factor)
+        if downsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) + (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2, p // 2))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
+        self._pack = None
+        self._pack_key = None
+
+    def __repr__(self):
+        return (f'{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, '
+                f'upsample={self.upsample}, downsample={self.downsample})')
+
+    # ---- MI355X path -----------------------------------------------------------------------
+    def packed_weights(self):
+        """(wpk [Cin, k*k, Cout], wsq [Cout, Cin]); rebuilt when the parameter changes."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if self._pack_key != key:
+            self._pack = sis_hip.modconv_prepack(w.detach())
+            self._pack_key = key
+        return self._pack
+
+    def hip_supported(self):
+        return (not self.downsample) and (self.kernel_size == 3 or (self.kernel_size == 1 and not self.upsample))
+
+    def modulate(self, style):
+        """s [B, Cin] and the epilogue factor scale * demod [B, Cout]."""
+        wpk, wsq = self.packed_weights()
+        s = self.modulation(style)
+        return wpk, s, sis_hip.modconv_demod(s, wsq, self.scale, self.demodulate)
+
+    def forward(self, input, style):
+        if _needs_grad(input, style, self.weight, self.modulation.weight) or not self.hip_supported():
+            return self._forward_autograd(input, style)
+        sis_hip.require_device(input, "input")
+        wpk, s, dscale = self.modulate(style)
+        if self.upsample:
+            return self.blur(sis_hip.modconv2d_up(input, wpk, s, dscale))
+        return sis_hip.modconv2d(input, wpk, s, dscale, self.kernel_size)
+
+    # ---- differentiable path (training only; reference formulation, model.py:237-278) --------
+    def _forward_autograd(self, input, style):
+        b, cin, h, w = input.shape
+        k, cout = self.kernel_size, self.out_channel
+        mod = self.modulation(style).view(b, 1, cin, 1, 1)
+        wt = self.scale * self.weight * mod
+        if self.demodulate:
+            wt = wt * torch.rsqrt(wt.pow(2).sum([2, 3, 4], keepdim=True) + 1e-8)
+        x = input.reshape(1, b * cin, h, w)
+        if self.upsample:
+            out = F.conv_transpose2d(x, wt.transpose(1, 2).reshape(b * cin, cout, k, k), stride=2, groups=b)
+            return self.blur(out.view(b, cout, out.shape[2], out.shape[3]))
+        if self.downsample:
+            x = self.blur(input)
+            x = x.reshape(1, b * cin, x.shape[2], x.shape[3])
+            out = F.conv2d(x, wt.view(b * cout, cin, k, k), stride=2, groups=b)
+        else:
+            out = F.conv2d(x, wt.view(b * cout, cin, k, k), padding=self.padding, groups=b)
+        return out.view(b, cout, out.shape[2], out.shape[3])
+
+
+class NoiseInjection(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+    @staticmethod
+    def fresh(image):
+        b, _, h, w = image.shape
+        return image.new_empty(b, 1, h, w).normal_()
+
+    def forward(self, image, noise=None):
+        if noise is None:
+            noise = self.fresh(image)
+        return image + self.weight * noise
+
+
+class ConstantInput(nn.Module):
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.input = nn.Parameter(torch.randn(1, channel, size, size))
+
+    def forward(self, input):
+        return self.input.repeat(input.shape[0], 1, 1, 1)
+
+
+class StyledConv(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False, blur_kernel=[1, 3, 3, 1],
+                 demodulate=True):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample,
+                                    blur_kernel=blur_kernel, demodulate=demodulate)
+        self.noise = NoiseInjection()
+        self.activate = FusedLeakyReLU(out_channel)
+
+    def forward(self, input, style, noise=None):
+        conv, act = self.conv, self.activate
+        fused_ok = (conv.hip_supported() and act.negative_slope == 0.2 and abs(act.scale - 2 ** 0.5) < 1e-12
+                    and not _needs_grad(input, style, conv.weight, conv.modulation.weight, self.noise.weight, act.bias))
+        if not fused_ok:
+            return act(self.noise(conv(input, style), noise=noise))
+        sis_hip.require_device(input, "input")
+        wpk, s, dscale = conv.modulate(style)
+        b, _, h, w = input.shape
+        if conv.upsample:
+            t = sis_hip.modconv2d_up(input, wpk, s, dscale)
+            pad = conv.blur.pad
+            oh = t.shape[2] + pad[0] + pad[1] - conv.blur.kernel.shape[0] + 1
+            ow = t.shape[3] + pad[0] + pad[1] - conv.blur.kernel.shape[1] + 1
+            if noise is None:
+                noise = input.new_empty(b, 1, oh, ow).normal_()
+            return sis_hip.blur_noise_act(t, conv.blur.kernel, pad, noise, self.noise.weight, act.bias, fuse_act=True)
+        if noise is None:
+            noise = input.new_empty(b, 1, h, w).normal_()
+        return sis_hip.modconv2d(input, wpk, s, dscale, conv.kernel_size, noise, self.noise.weight, act.bias,
+                                 fuse_act=True)
+
+
+class ToRGB(nn.Module):
+    def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        if upsample:
+            self.upsample = Upsample(blur_kernel)
+        self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+
+    def forward(self, input, style, skip=None):
+        conv = self.conv
+        if _needs_grad(input, style, skip, conv.weight, conv.modulation.weight, self.bias):
+            out = conv(input, style) + self.bias
+            return out if skip is None else out + self.upsample(skip)
+        sis_hip.require_device(input, "input")
+        s = conv.modulation(style)
+        if skip is None:
+            return sis_hip.to_rgb(input, conv.weight, s, self.bias, conv.scale)
+        up = self.upsample
+        if up.factor != 2:
+            return sis_hip.to_rgb(input, conv.weight, s, self.bias, conv.scale) + up(skip)
+        return sis_hip.to_rgb(input, conv.weight, s, self.bias, conv.scale, skip, up.kernel, up.pad)
+
+
+class Generator(nn.Module):
+    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01):
+        super().__init__()
+        self.size = size
+        self.style_dim = style_dim
+        self.style = nn.Sequential(PixelNorm(), *[
+            EqualLinear(style_dim, style_dim, lr_mul=lr_mlp, activation='fused_lrelu') for _ in range(n_mlp)])
+        self.channels = self.get_channels(channel_multiplier)
+        self.input = ConstantInput(self.channels[4])
+        self.conv1 = StyledConv(self.channels[4], self.channels[4], 3, style_dim, blur_kernel=blur_kernel)
+        self.to_rgb1 = ToRGB(self.channels[4], style_dim, upsample=False)
+        self.log_size = int(math.log(size, 2))
+        self.num_layers = (self.log_size - 2) * 2 + 1
+        self.n_latent = self.log_size * 2 - 2
+
+        self.convs = nn.ModuleList()
+        self.upsamples = nn.ModuleList()
+        self.to_rgbs = nn.ModuleList()
+        self.noises = nn.Module()
+        for layer_idx in range(self.num_layers):
+            res = 2 ** ((layer_idx + 5) // 2)
+            self.noises.register_buffer(f'noise_{layer_idx}', torch.randn(1, 1, res, res))
+        in_channel = self.channels[4]
+        for i in range(3, self.log_size + 1):
+            out_channel = self.channels[2 ** i]
+            self.convs.append(StyledConv(in_channel, out_channel, 3, style_dim, upsample=True, blur_kernel=blur_kernel))
+            self.convs.append(StyledConv(out_channel, out_channel, 3, style_dim, blur_kernel=blur_kernel))
+            self.to_rgbs.append(ToRGB(out_channel, style_dim))
+            in_channel = out_channel
+
+    @staticmethod
+    def get_channels(channel_multiplier=2) -> typing.Dict[int, int]:
+        cm = channel_multiplier
+        return {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * cm, 128: 128 * cm, 256: 64 * cm, 512: 32 * cm,
+                1024: 16 * cm}
+
+    def make_noise(self) -> typing.List[torch.Tensor]:
+        device = self.input.input.device
+        sizes = [4] + [2 ** i for i in range(3, self.log_size + 1) for _ in range(2)]
+        return [torch.randn(1, 1, s, s, device=device) for s in sizes]
+
+    def mean_latent(self, n_latent):
+        latent_in = torch.randn(n_latent, self.style_dim, device=self.input.input.device)
+        return self.style(latent_in).mean(0, keepdim=True)
+
+    def get_latent(self, input):
+        return self.style(input)
+
+    def _truncate(self, style, truncation, truncation_latent):
+        if _needs_grad(style, truncation_latent) or not style.is_cuda or truncation_latent.numel() != style.shape[-1]:
+            return truncation_latent + truncation * (style - truncation_latent)
+        return sis_hip.truncate(style, truncation_latent, truncation)
+
+    def forward(self, styles, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
+                input_is_latent=False, noise=None, randomize_noise=True, return_intermediate_activations=False):
+        if not input_is_latent:
+            styles = [self.style(s) for s in styles]
+        if noise is None:
+            noise = [None] * self.num_layers if randomize_noise else [
+                getattr(self.noises, f'noise_{i}') for i in range(self.num_layers)]
+        if truncation < 1:
+            styles = [self._truncate(s, truncation, truncation_latent) for s in styles]
+
+        if len(styles) < 2:
+            inject_index = self.n_latent
+            latent = styles[0].unsqueeze(1).repeat(1, inject_index, 1) if styles[0].ndim < 3 else styles[0]
+        else:
+            if inject_index is None:
+                inject_index = random.randint(1, self.n_latent - 1)
+            latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
+                                styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
+
+        acts = {} if return_intermediate_activations else None
+
+        def tap(idx, t):
+            if acts is not None:
+                acts[idx] = t.detach()
+
+        out = self.input(latent)
+        tap(0, out)
+        out = self.conv1(out, latent[:, 0], noise=noise[0])
+        tap(1, out)
+        skip = self.to_rgb1(out, latent[:, 1])
+        for r in range(self.log_size - 2):
+            i = 1 + 2 * r
+            out = self.convs[2 * r](out, latent[:, i], noise=noise[1 + 2 * r])
+            tap(i + 1, out)
+            out = self.convs[2 * r + 1](out, latent[:, i + 1], noise=noise[2 + 2 * r])
+            tap(i + 2, out)
+            skip = self.to_rgbs[r](out, latent[:, i + 2], skip)
+        image = skip
+        if return_latents:
+            return image, latent
+        if return_intermediate_activations:
+            return image, acts
+        return image, None

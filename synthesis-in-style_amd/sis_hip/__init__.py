@@ -1,0 +1,283 @@
+"""ctypes binding of ``libsis_hip.so`` (C ABI declared in ``include/sis_hip.h``).
+
+This is the only place where Python touches the native library.  There is NO fallback: when the
+shared object is missing, or a tensor is not on a HIP device, the wrappers raise ``RuntimeError``
+(the reference's ops raise ``RuntimeError("... must be a CUDA tensor")`` in the same situations,
+networks/stylegan2/op/fused_bias_act.cpp:13-14, upfirdn2d.cpp:15-16).
+
+PyTorch is used for device memory and streams only: every wrapper takes ``torch.Tensor``s,
+passes ``data_ptr()`` and the current HIP stream, and returns freshly allocated tensors, mirroring
+the ownership rules of the reference extension (outputs owned by the caller, inputs borrowed and
+made contiguous, kernels enqueued on the current stream, no host sync).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsis_hip.so")
+
+_lib = None
+
+F32, F64, F16, BF16 = 0, 1, 2, 3
+_DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.bfloat16: BF16}
+
+_vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+_SIGNATURES = {
+    "sis_version": ([], _i),
+    "sis_last_error": ([], ctypes.c_char_p),
+    "sis_fused_bias_act": ([_vp, _vp, _vp, _vp, _i, _i64, _i64, _i64, _i, _i, _f, _f, _vp], _i),
+    "sis_upfirdn2d_out_size": ([_i] * 6, _i),
+    "sis_upfirdn2d": ([_vp, _vp, _vp] + [_i] * 15 + [_vp], _i),
+    "sis_pixel_norm": ([_vp, _vp, _i, _i, _vp], _i),
+    "sis_equal_linear": ([_vp, _vp, _i64, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp], _i),
+    "sis_truncate": ([_vp, _vp, _vp, _f, _i, _i, _vp], _i),
+    "sis_modconv_prepack": ([_vp, _vp, _vp, _i, _i, _i, _vp], _i),
+    "sis_modconv_demod": ([_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp], _i),
+    "sis_modconv2d": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 7 + [_vp], _i),
+    "sis_modconv2d_up": ([_vp] * 5 + [_i] * 5 + [_vp], _i),
+    "sis_blur_noise_act": ([_vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 9 + [_vp], _i),
+    "sis_to_rgb": ([_vp] * 7 + [_i] * 9 + [_f, _vp], _i),
+}
+
+
+def exported_symbols():
+    """Every symbol include/sis_hip.h declares (checked by the CPU test-suite)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"libsis_hip.so is not built ({LIB_PATH}); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C synthesis-in-style_amd/csrc`.  There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = L
+    return _lib
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {lib().sis_last_error().decode()}")
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")  # same text as the reference CHECK_CUDA
+
+
+def dtype_code(t):
+    try:
+        return _DTYPE_CODE[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"unsupported dtype {t.dtype} (float32/float64/float16/bfloat16)") from None
+
+
+# ------------------------------------------------------------------------------------------ K1
+
+
+def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
+    """Same argument order as the reference pybind entry (fused_bias_act.cpp:11-21); empty tensors
+    mean "absent" (fused_bias_act_kernel.cu:62-63)."""
+    require_device(input, "input")
+    require_device(bias, "bias")
+    x = input.contiguous()
+    b = bias.contiguous() if bias.numel() else None
+    r = refer.contiguous() if refer.numel() else None
+    if b is not None and b.dtype != x.dtype:
+        b = b.to(x.dtype)
+    if r is not None:
+        require_device(r, "refer")
+        if r.dtype != x.dtype:
+            r = r.to(x.dtype)
+    step_b = 1
+    for d in x.shape[2:]:
+        step_b *= d
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_fused_bias_act(_ptr(out), _ptr(x), _ptr(b), _ptr(r), dtype_code(x), x.numel(), step_b,
+                                        b.numel() if b is not None else 0, int(act), int(grad), float(alpha),
+                                        float(scale), _stream()), "sis_fused_bias_act")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ K2
+
+
+def upfirdn2d_out_size(in_size, up, down, pad0, pad1, k):
+    return (in_size * up + pad0 + pad1 - k + down) // down
+
+
+def upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
+    """Same signature as the reference pybind entry (upfirdn2d.cpp:12-23): input
+    [major, in_h, in_w, minor], kernel [kh, kw] -> [major, out_h, out_w, minor]."""
+    require_device(input, "input")
+    require_device(kernel, "kernel")
+    x = input.contiguous()
+    k = kernel.contiguous()
+    if k.dtype != x.dtype:
+        k = k.to(x.dtype)
+    major, in_h, in_w, minor = x.shape
+    kh, kw = k.shape
+    out_h = upfirdn2d_out_size(in_h, up_y, down_y, pad_y0, pad_y1, kh)
+    out_w = upfirdn2d_out_size(in_w, up_x, down_x, pad_x0, pad_x1, kw)
+    if out_h < 0 or out_w < 0:
+        raise RuntimeError(f"upfirdn2d: negative output size {out_h}x{out_w}")
+    out = torch.empty((major, out_h, out_w, minor), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_upfirdn2d(_ptr(out), _ptr(x), _ptr(k), dtype_code(x), major, in_h, in_w, minor, kh, kw,
+                                   up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, _stream()),
+               "sis_upfirdn2d")
+    return out
+
+
+# ------------------------------------------------------------------------------ generator blocks
+
+
+def _f32(t, name):
+    require_device(t, name)
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: the generator kernels are float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def pixel_norm(x):
+    x = _f32(x, "input")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_pixel_norm(_ptr(out), _ptr(x), x.shape[0], x.shape[1], _stream()), "sis_pixel_norm")
+    return out
+
+
+def equal_linear(x, weight, bias, scale, lr_mul, activation, row_stride=None, batch=None):
+    """x is [B, in] (or any tensor whose rows are ``row_stride`` floats apart, e.g. latent[:, i])."""
+    require_device(x, "input")
+    w = _f32(weight, "weight")
+    b = _f32(bias, "bias") if bias is not None else None
+    if row_stride is None:
+        x = _f32(x, "input")
+        row_stride, batch = x.shape[1], x.shape[0]
+    out = torch.empty((batch, w.shape[0]), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _check(lib().sis_equal_linear(_ptr(out), _ptr(x), row_stride, _ptr(w), _ptr(b), batch, w.shape[1], w.shape[0],
+                                      float(scale), float(lr_mul), int(bool(activation)), _stream()),
+               "sis_equal_linear")
+    return out
+
+
+def truncate(w, mean, psi):
+    w = _f32(w, "style")
+    mean = _f32(mean, "truncation_latent").reshape(-1)
+    dim = w.shape[-1]
+    if mean.numel() != dim:
+        raise RuntimeError("truncation_latent must hold one latent vector")
+    out = torch.empty_like(w)
+    with torch.cuda.device(w.device):
+        _check(lib().sis_truncate(_ptr(out), _ptr(w), _ptr(mean), float(psi), w.numel() // dim, dim, _stream()),
+               "sis_truncate")
+    return out
+
+
+def modconv_prepack(weight):
+    """weight: ModulatedConv2d.weight [1, Cout, Cin, k, k] -> (wpk [Cin, k*k, Cout], wsq [Cout, Cin])."""
+    w = _f32(weight, "weight")
+    _, cout, cin, k, _ = w.shape
+    wpk = torch.empty((cin, k * k, cout), dtype=torch.float32, device=w.device)
+    wsq = torch.empty((cout, cin), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _check(lib().sis_modconv_prepack(_ptr(wpk), _ptr(wsq), _ptr(w), cout, cin, k, _stream()),
+               "sis_modconv_prepack")
+    return wpk, wsq
+
+
+def modconv_demod(s, wsq, scale, demodulate):
+    s = _f32(s, "style")
+    cout, cin = wsq.shape
+    out = torch.empty((s.shape[0], cout), dtype=torch.float32, device=s.device)
+    with torch.cuda.device(s.device):
+        _check(lib().sis_modconv_demod(_ptr(out), _ptr(s), _ptr(wsq), s.shape[0], cin, cout, float(scale),
+                                       int(bool(demodulate)), _stream()), "sis_modconv_demod")
+    return out
+
+
+def _noise_args(noise, batch, h, w):
+    if noise is None:
+        return None, 0
+    noise = _f32(noise, "noise")
+    if noise.numel() == h * w:
+        return noise, 0
+    if noise.numel() == batch * h * w:
+        return noise, h * w
+    raise RuntimeError(f"noise shape {tuple(noise.shape)} does not broadcast over [{batch}, C, {h}, {w}]")
+
+
+def modconv2d(x, wpk, s, dscale, ksize, noise=None, noise_weight=None, bias=None, fuse_act=False):
+    x = _f32(x, "input")
+    batch, cin, h, w = x.shape
+    cout = wpk.shape[2]
+    noise, nbs = _noise_args(noise, batch, h, w)
+    out = torch.empty((batch, cout, h, w), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_modconv2d(_ptr(out), _ptr(x), _ptr(wpk), _ptr(s), _ptr(dscale), _ptr(noise), nbs,
+                                   _ptr(noise_weight), _ptr(bias), batch, cin, cout, h, w, ksize, int(bool(fuse_act)),
+                                   _stream()), "sis_modconv2d")
+    return out
+
+
+def modconv2d_up(x, wpk, s, dscale):
+    x = _f32(x, "input")
+    batch, cin, h, w = x.shape
+    cout = wpk.shape[2]
+    out = torch.empty((batch, cout, 2 * h + 1, 2 * w + 1), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_modconv2d_up(_ptr(out), _ptr(x), _ptr(wpk), _ptr(s), _ptr(dscale), batch, cin, cout, h, w,
+                                      _stream()), "sis_modconv2d_up")
+    return out
+
+
+def blur_noise_act(x, taps, pad, noise=None, noise_weight=None, bias=None, fuse_act=False):
+    x = _f32(x, "input")
+    taps = _f32(taps, "kernel")
+    batch, ch, ih, iw = x.shape
+    kh, kw = taps.shape
+    oh, ow = ih + pad[0] + pad[1] - kh + 1, iw + pad[0] + pad[1] - kw + 1
+    noise, nbs = _noise_args(noise, batch, oh, ow)
+    out = torch.empty((batch, ch, oh, ow), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_blur_noise_act(_ptr(out), _ptr(x), _ptr(taps), _ptr(noise), nbs, _ptr(noise_weight),
+                                        _ptr(bias), batch, ch, ih, iw, kh, kw, pad[0], pad[1], int(bool(fuse_act)),
+                                        _stream()), "sis_blur_noise_act")
+    return out
+
+
+def to_rgb(x, weight, s, bias, scale, skip=None, taps=None, pad=(0, 0)):
+    x = _f32(x, "input")
+    w = _f32(weight, "weight")
+    batch, cin, h, wd = x.shape
+    cout = w.numel() // cin
+    kh = kw = 0
+    if skip is not None:
+        skip = _f32(skip, "skip")
+        taps = _f32(taps, "kernel")
+        kh, kw = taps.shape
+    out = torch.empty((batch, cout, h, wd), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_to_rgb(_ptr(out), _ptr(x), _ptr(w), _ptr(s), _ptr(bias), _ptr(skip), _ptr(taps), batch, cin,
+                                cout, h, wd, kh, kw, pad[0], pad[1], float(scale), _stream()), "sis_to_rgb")
+    return out

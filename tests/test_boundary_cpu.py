@@ -1,0 +1,85 @@
+"""CPU suite, part 2: the drop-in boundary (no compute calls -- there is no GPU here).
+
+* libsis_hip.so loads and exports every symbol include/sis_hip.h declares;
+* the Python operator surface has the reference's names and rejects CPU tensors with RuntimeError
+  (reference: fused_bias_act.cpp:13-14, upfirdn2d.cpp:15-16), i.e. there is no CPU fallback;
+* Generator has the reference's 135-key state_dict schema and loads a g_ema checkpoint strictly;
+* the product sources never import the oracle.
+"""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sis_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sis_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import sis_hip
+    assert os.path.exists(sis_hip.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(sis_hip.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/sis_hip.h but not exported"
+    assert sorted(sis_hip.exported_symbols()) == declared
+    assert sis_hip.lib().sis_version() >= 1000
+
+
+def test_out_size_helper_matches_reference_formula():
+    import sis_hip
+    L = sis_hip.lib()
+    for (n, up, down, p0, p1, k) in [(9, 1, 1, 1, 1, 4), (4, 2, 1, 2, 1, 4), (8, 1, 2, 1, 1, 4), (5, 3, 2, 2, 3, 5)]:
+        assert L.sis_upfirdn2d_out_size(n, up, down, p0, p1, k) == (n * up + p0 + p1 - k) // down + 1
+
+
+def test_ops_reject_cpu_tensors():
+    from networks.stylegan2.op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        fused_leaky_relu(torch.randn(2, 3, 4, 4), torch.zeros(3))
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        upfirdn2d(torch.randn(1, 2, 8, 8), torch.ones(4, 4) / 16, pad=(1, 1))
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        FusedLeakyReLU(3)(torch.randn(2, 3))
+
+
+def test_generator_schema_and_strict_load():
+    from networks.stylegan2.model import Generator
+    from oracle import stylegan2_ref as R
+    for size, sdim, n_mlp, cm in [(16, 64, 3, 1), (256, 512, 8, 2)]:
+        with torch.device("meta"):
+            g = Generator(size, sdim, n_mlp, channel_multiplier=cm)
+        schema = R.state_dict_schema(size, sdim, n_mlp, cm)
+        sd = g.state_dict()
+        assert list(sd.keys()) == [n for n, _ in schema]
+        for n, shape in schema:
+            assert tuple(sd[n].shape) == tuple(shape), n
+    g = Generator(16, 64, 3, channel_multiplier=1)
+    g.load_state_dict(R.seeded_state_dict(16, 64, 3, 1, seed=5), strict=True)
+    assert g.n_latent == 6 and g.num_layers == 5 and g.log_size == 4 and g.size == 16
+    assert [tuple(n.shape) for n in g.make_noise()] == [(1, 1, 4, 4), (1, 1, 8, 8), (1, 1, 8, 8), (1, 1, 16, 16),
+                                                         (1, 1, 16, 16)]
+
+
+def test_generator_on_cpu_raises_instead_of_falling_back():
+    from networks.stylegan2.model import Generator
+    g = Generator(16, 64, 2, channel_multiplier=1).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError):
+        g([torch.randn(2, 64)])
+
+
+def test_product_never_imports_oracle():
+    src = os.path.join(ROOT, "synthesis-in-style_amd")
+    for dirpath, _, files in os.walk(src):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(dirpath, f)
