@@ -1,0 +1,195 @@
+"""Headline benchmark: StyleGAN2 256x256 synthesis (Generator.forward) images/s on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 the driver launches one
+rank per GPU through torch.distributed.run.  W untimed warm-up steps, then exactly K timed steps
+bracketed by barrier + torch.cuda.synchronize() on both sides, MAX over ranks, ONE JSON line from
+rank 0.
+
+Workload (BASELINE.json configs[1]): Generator(256, 512, 8, channel_multiplier=2).forward on a batch of
+32 latents per GPU, explicit noise maps, ``return_intermediate_activations=True`` (the mode
+create_dataset_for_segmentation.py runs, utils/dataset_creation.py:50-57), fp32, synthetic seeded
+weights (default init, noise weights ~N(0, 0.1^2) so the noise path is live), inputs resident in HBM.
+A "step" is one such forward.  Synthesis shards by image with no collective, so N GPUs
+= N independent batches per step: weak scaling; value = N * 32 * K / time.
+
+Two extra objects on the JSON line:
+  roofline      dominant kernel (by summed device time) measured live with HIP events on the launch
+                stream: algorithmic FLOPs per launch / average launch duration vs the fp32 MFMA peak.
+  cpu_baseline  the oracle (CPU restatement of the reference's own grouped-conv formulation,
+                oracle/stylegan2_ref.py) timed on the host cores of this box on a bounded sample
+                (batch 4), rank 0 / N = 1 only.  A reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "synthesis-in-style_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+METRIC = "StyleGAN2 synth images/sec + seg-train images/sec @256², 1/2/4/8 MI355X"
+PEAK_MFMA_F32_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0
+BATCH = 32
+SIZE = 256
+
+
+def build_generator(device, seed=0):
+    from networks.stylegan2.model import Generator
+    torch.manual_seed(seed)
+    g = Generator(SIZE, 512, 8, channel_multiplier=2)
+    with torch.no_grad():
+        for name, p in g.named_parameters():
+            if name.endswith("noise.weight"):
+                p.normal_(0.0, 0.1)
+    return g.to(device).eval()
+
+
+def synth_inputs(g, batch, device, seed):
+    gen = torch.Generator().manual_seed(seed)
+    z = torch.randn(batch, 512, generator=gen).to(device)
+    sizes = [4] + [2 ** i for i in range(3, g.log_size + 1) for _ in range(2)]
+    noise = [torch.randn(1, 1, s, s, generator=gen).to(device) for s in sizes]
+    return z, noise
+
+
+def step(g, z, noise):
+    with torch.no_grad():
+        return g([z], noise=noise, return_intermediate_activations=True)
+
+
+def kernel_profile(g, z, noise, steps):
+    """Per-kernel device time from HIP events recorded on the launch stream around every launch."""
+    import sis_hip
+    records = []
+    sis_hip.set_profiler(records)
+    try:
+        for _ in range(steps):
+            step(g, z, noise)
+        torch.cuda.synchronize()
+    finally:
+        sis_hip.set_profiler(None)
+    agg = {}
+    for name, flops, nbytes, e0, e1 in records:
+        a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        a["launches"] += 1
+        a["ms"] += e0.elapsed_time(e1)
+        a["flops"] += flops
+        a["bytes"] += nbytes
+    return agg
+
+
+def cpu_baseline(g, seed):
+    """Oracle on the host cores: B=4 (BASELINE.json configs[0]), 1 warm-up + 2 timed iterations."""
+    from oracle import stylegan2_ref as R
+    sd = {k: v.detach().cpu() for k, v in g.state_dict().items()}
+    z, noise = synth_inputs(g, 4, "cpu", seed)
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    with torch.no_grad():
+        img, _ = R.generator_forward(sd, [z], noise=noise, return_intermediate_activations=True)
+        t = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            img, _ = R.generator_forward(sd, [z], noise=noise, return_intermediate_activations=True)
+            t.append(time.perf_counter() - t0)
+    sec = sorted(t)[0]
+    return {"value": round(4 / sec, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"Generator(256,512,8,cm=2) forward with activations, batch 4, fp32, {threads} torch threads, "
+                      f"best of 2 after 1 warm-up ({sec:.2f} s/iter)"}, img, (z, noise)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    g = build_generator(device)
+    z, noise = synth_inputs(g, args.batch, device, seed=1 + rank)
+
+    for _ in range(args.warmup):
+        step(g, z, noise)
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(g, z, noise)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    assert torch.isfinite(out[0]).all()
+
+    result = None
+    if rank == 0:
+        n_gpus = world
+        total_images = args.batch * args.steps * n_gpus
+        agg = kernel_profile(g, z, noise, min(args.steps, 5))
+        dom_name = max(agg, key=lambda k: agg[k]["ms"])
+        dom = agg[dom_name]
+        per_launch_ms = dom["ms"] / dom["launches"]
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        roofline = {"kernel": dom_name, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": dom["launches"] // min(args.steps, 5),
+                    "avg_launch_ms": round(per_launch_ms, 4),
+                    "flops_per_launch": dom["flops"] / dom["launches"],
+                    "kernels": {k: {"ms_per_step": round(v["ms"] / min(args.steps, 5), 4),
+                                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                                    "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
+                                for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}}
+        result = {
+            "metric": METRIC, "value": round(total_images / elapsed, 2), "unit": "images/s", "n_gpus": n_gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "StyleGAN2 Generator(256,512,8,cm=2).forward, batch 32 per GPU, explicit noise, "
+                                   "return_intermediate_activations=True (BASELINE.json configs[1])",
+                       "batch_per_gpu": args.batch, "image_size": SIZE, "parallelism": f"replicated x{n_gpus}, "
+                       "images sharded, no collective"},
+            "roofline": roofline,
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            cb, img_cpu, (z4, noise4) = cpu_baseline(g, seed=1234)
+            with torch.no_grad():
+                img_gpu, _ = g([z4.to(device)], noise=[n.to(device) for n in noise4])
+            cb["gpu_vs_cpu_image_max_rel_err"] = float(
+                (img_gpu.cpu() - img_cpu).abs().max() / img_cpu.abs().max())
+            result["cpu_baseline"] = cb
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if result is not None:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

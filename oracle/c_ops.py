@@ -62,5 +62,5 @@ def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
     fn.restype = None
     fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_long] + [ctypes.c_int] * 6 + [cty, cty]
     fn(_ptr(out), _ptr(x), _ptr(b), _ptr(r), x.size, step_b, max(b.size, 1), use_bias, use_ref,
-       act, grad, alpha, scale)
+       act, grad, float(np.float32(alpha)), float(np.float32(scale)))  # C float at the pybind boundary
     return out

@@ -17,6 +17,7 @@ tests use as the gradient oracle for the HIP backward kernels.
 """
 import math
 
+import numpy as np
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -55,8 +56,15 @@ def upfirdn2d_out_size(in_size, up, down, pad0, pad1, k):
     return (in_size * up + pad0 + pad1 - k) // down + 1
 
 
+def _as_c_float(v):
+    """The pybind entry takes ``float alpha, float scale`` (fused_bias_act.cpp:11-12): Python doubles are
+    rounded to binary32 before the kernel widens them to scalar_t, also for float64 tensors."""
+    return float(np.float32(v))
+
+
 def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
     """Element formula of fused_bias_act_kernel.cu:25-47; empty tensors mean absent."""
+    alpha, scale = _as_c_float(alpha), _as_c_float(scale)
     y = x
     if bias is not None and bias.numel() > 0:
         shape = [1, -1] + [1] * (x.dim() - 2)
@@ -74,7 +82,7 @@ def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
 
 def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):
     shape = [1, -1] + [1] * (input.dim() - 2)
-    return F.leaky_relu(input + bias.reshape(shape), negative_slope) * scale
+    return F.leaky_relu(input + bias.reshape(shape), _as_c_float(negative_slope)) * _as_c_float(scale)
 
 
 class FusedLeakyReLU(nn.Module):

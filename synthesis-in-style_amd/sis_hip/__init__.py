@@ -64,6 +64,27 @@ def lib():
     return _lib
 
 
+_prof = None
+
+
+def set_profiler(records):
+    """bench.py hook: when ``records`` is a list, every kernel launch below is bracketed by HIP events on
+    the launch stream and appended as (kernel, algorithmic_flops, algorithmic_bytes, ev0, ev1)."""
+    global _prof
+    _prof = records
+
+
+def _launch(kernel, flops, nbytes, call):
+    if _prof is None:
+        return call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = call()
+    e1.record()
+    _prof.append((kernel, flops, nbytes, e0, e1))
+    return rc
+
+
 def _check(rc, name):
     if rc != 0:
         raise RuntimeError(f"{name} failed: {lib().sis_last_error().decode()}")
@@ -234,9 +255,11 @@ def modconv2d(x, wpk, s, dscale, ksize, noise=None, noise_weight=None, bias=None
     noise, nbs = _noise_args(noise, batch, h, w)
     out = torch.empty((batch, cout, h, w), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(lib().sis_modconv2d(_ptr(out), _ptr(x), _ptr(wpk), _ptr(s), _ptr(dscale), _ptr(noise), nbs,
-                                   _ptr(noise_weight), _ptr(bias), batch, cin, cout, h, w, ksize, int(bool(fuse_act)),
-                                   _stream()), "sis_modconv2d")
+        _check(_launch(f"modconv_mfma_kernel<0,{ksize}>", 2.0 * batch * cout * cin * ksize * ksize * h * w,
+                       4.0 * (x.numel() + out.numel() + wpk.numel()),
+                       lambda: lib().sis_modconv2d(_ptr(out), _ptr(x), _ptr(wpk), _ptr(s), _ptr(dscale), _ptr(noise),
+                                                   nbs, _ptr(noise_weight), _ptr(bias), batch, cin, cout, h, w, ksize,
+                                                   int(bool(fuse_act)), _stream())), "sis_modconv2d")
     return out
 
 
@@ -246,8 +269,10 @@ def modconv2d_up(x, wpk, s, dscale):
     cout = wpk.shape[2]
     out = torch.empty((batch, cout, 2 * h + 1, 2 * w + 1), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(lib().sis_modconv2d_up(_ptr(out), _ptr(x), _ptr(wpk), _ptr(s), _ptr(dscale), batch, cin, cout, h, w,
-                                      _stream()), "sis_modconv2d_up")
+        _check(_launch("modconv_mfma_kernel<1,3>", 2.0 * batch * cout * cin * 9 * h * w,
+                       4.0 * (x.numel() + out.numel() + wpk.numel()),
+                       lambda: lib().sis_modconv2d_up(_ptr(out), _ptr(x), _ptr(wpk), _ptr(s), _ptr(dscale), batch, cin,
+                                                      cout, h, w, _stream())), "sis_modconv2d_up")
     return out
 
 
@@ -260,9 +285,11 @@ def blur_noise_act(x, taps, pad, noise=None, noise_weight=None, bias=None, fuse_
     noise, nbs = _noise_args(noise, batch, oh, ow)
     out = torch.empty((batch, ch, oh, ow), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(lib().sis_blur_noise_act(_ptr(out), _ptr(x), _ptr(taps), _ptr(noise), nbs, _ptr(noise_weight),
-                                        _ptr(bias), batch, ch, ih, iw, kh, kw, pad[0], pad[1], int(bool(fuse_act)),
-                                        _stream()), "sis_blur_noise_act")
+        _check(_launch("blur_tile_kernel", 0.0, 4.0 * (x.numel() + out.numel()),
+                       lambda: lib().sis_blur_noise_act(_ptr(out), _ptr(x), _ptr(taps), _ptr(noise), nbs,
+                                                        _ptr(noise_weight), _ptr(bias), batch, ch, ih, iw, kh, kw,
+                                                        pad[0], pad[1], int(bool(fuse_act)), _stream())),
+               "sis_blur_noise_act")
     return out
 
 
@@ -278,6 +305,8 @@ def to_rgb(x, weight, s, bias, scale, skip=None, taps=None, pad=(0, 0)):
         kh, kw = taps.shape
     out = torch.empty((batch, cout, h, wd), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(lib().sis_to_rgb(_ptr(out), _ptr(x), _ptr(w), _ptr(s), _ptr(bias), _ptr(skip), _ptr(taps), batch, cin,
-                                cout, h, wd, kh, kw, pad[0], pad[1], float(scale), _stream()), "sis_to_rgb")
+        _check(_launch("to_rgb_kernel", 0.0, 4.0 * (x.numel() + out.numel() + (skip.numel() if skip is not None else 0)),
+                       lambda: lib().sis_to_rgb(_ptr(out), _ptr(x), _ptr(w), _ptr(s), _ptr(bias), _ptr(skip),
+                                                _ptr(taps), batch, cin, cout, h, wd, kh, kw, pad[0], pad[1],
+                                                float(scale), _stream())), "sis_to_rgb")
     return out
