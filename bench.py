@@ -84,12 +84,26 @@ def kernel_profile(g, z, noise, steps):
     return agg
 
 
+def host_cores():
+    """CPU share of this process: min(affinity mask, cgroup quota); the GPU box exposes 256 logical CPUs
+    but grants a 16-core share per GPU, and oversubscribing torch's intra-op pool makes the baseline
+    slower, not faster."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, int(os.environ.get("SIS_BENCH_CPU_THREADS", "16")))
+
+
 def cpu_baseline(g, seed):
     """Oracle on the host cores: B=4 (BASELINE.json configs[0]), 1 warm-up + 2 timed iterations."""
     from oracle import stylegan2_ref as R
     sd = {k: v.detach().cpu() for k, v in g.state_dict().items()}
     z, noise = synth_inputs(g, 4, "cpu", seed)
-    threads = os.cpu_count() or 1
+    threads = host_cores()
     torch.set_num_threads(threads)
     with torch.no_grad():
         img, _ = R.generator_forward(sd, [z], noise=noise, return_intermediate_activations=True)

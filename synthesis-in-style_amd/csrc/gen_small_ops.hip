@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(float* __restrict__ out
 // EqualLinear (model.py:152-162).  One wave per output feature; the wave keeps its weight row in
 // registers (in_dim <= 64*ELW floats) and walks the batch, so the [out,in] matrix is read once.
 constexpr int ELW = 16;  // supports in_dim up to 1024
+constexpr int EL_ROWS = 4;  // batch rows per workgroup (blockIdx.y walks the batch)
 __global__ __launch_bounds__(256) void equal_linear_kernel(float* __restrict__ out, const float* __restrict__ x,
                                                            int64_t x_row_stride, const float* __restrict__ w,
                                                            const float* __restrict__ bias, int batch, int in_dim,
@@ -42,19 +43,32 @@ __global__ __launch_bounds__(256) void equal_linear_kernel(float* __restrict__ o
         wr[j] = (i < in_dim) ? w[(int64_t)o * in_dim + i] : 0.f;
     }
     const float b = bias ? bias[o] * lr_mul : 0.f;
-    for (int r = 0; r < batch; ++r) {
-        const float* xr = x + (int64_t)r * x_row_stride;
-        float acc = 0.f;
+    const int r0 = blockIdx.y * EL_ROWS;
+    float acc[EL_ROWS];
 #pragma unroll
-        for (int j = 0; j < ELW; ++j) {
-            const int i = lane + 64 * j;
-            if (i < in_dim) acc += xr[i] * wr[j];
+    for (int rr = 0; rr < EL_ROWS; ++rr) {
+        acc[rr] = 0.f;
+        const int r = r0 + rr;
+        if (r < batch) {
+            const float* xr = x + (int64_t)r * x_row_stride;
+#pragma unroll
+            for (int j = 0; j < ELW; ++j) {
+                const int i = lane + 64 * j;
+                if (i < in_dim) acc[rr] += xr[i] * wr[j];
+            }
         }
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            float v = acc * scale + b;
-            if (activation) v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
-            out[(int64_t)r * out_dim + o] = v;
+    }
+#pragma unroll
+    for (int rr = 0; rr < EL_ROWS; ++rr) acc[rr] = wave_sum(acc[rr]);
+    if (lane == 0) {
+#pragma unroll
+        for (int rr = 0; rr < EL_ROWS; ++rr) {
+            const int r = r0 + rr;
+            if (r < batch) {
+                float v = acc[rr] * scale + b;
+                if (activation) v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
+                out[(int64_t)r * out_dim + o] = v;
+            }
         }
     }
 }
@@ -197,7 +211,7 @@ extern "C" int sis_equal_linear(float* out, const float* x, int64_t x_row_stride
     if (batch <= 0 || out_dim <= 0) return 0;
     SIS_REQUIRE(out && x && w, "sis_equal_linear: null pointer");
     SIS_REQUIRE(in_dim > 0 && in_dim <= 64 * ELW, "sis_equal_linear: in_dim %d outside 1..%d", in_dim, 64 * ELW);
-    hipLaunchKernelGGL(equal_linear_kernel, dim3(sis_cdiv(out_dim, 4)), dim3(256), 0, (hipStream_t)stream, out, x,
+    hipLaunchKernelGGL(equal_linear_kernel, dim3(sis_cdiv(out_dim, 4), sis_cdiv(batch, EL_ROWS)), dim3(256), 0, (hipStream_t)stream, out, x,
                        x_row_stride, w, bias, batch, in_dim, out_dim, scale, lr_mul, activation);
     SIS_CHECK_LAUNCH("sis_equal_linear");
     return 0;

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_kernel(const ConvParams p
         // ---- stage weights: rows (ci, tap) of MBLK contiguous floats
         constexpr int WV4 = C::WFLOATS / 4;
         if (p.cout_vec4) {
-#pragma unroll 3
+#pragma unroll
             for (int i = 0; i < (WV4 + 255) / 256; ++i) {
                 const int e = tid + 256 * i;
                 if (e < WV4) {
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_kernel(const ConvParams p
             }
         }
         // ---- stage the style-modulated input tile (zero padded), 4 channels at a time
-#pragma unroll 1
+#pragma unroll
         for (int j0 = 0; j0 < CC; j0 += 4) {
             float xv[4][XI];
 #pragma unroll
