@@ -95,18 +95,21 @@ int sis_modconv_demod(float* dscale, const float* s, const float* wsq, int batch
  *   y[b,co,h,w] = dscale[b,co] * sum_{ci,kh,kw} wpk[ci][kh*ks+kw][co] * s[b,ci] * x[b,ci,h+kh-p,w+kw-p]
  *   fuse_act:  y = lrelu_{0.2}(y + noise_weight[0]*noise[nb,0,h,w] + bias[co]) * sqrt(2)
  * noise is [1,1,H,W] (noise_batch_stride 0) or [B,1,H,W] (stride H*W) or NULL; noise_weight is a
- * DEVICE pointer to one float (the NoiseInjection.weight parameter).  MFMA fp32 (v_mfma_f32_32x32x2_f32). */
+ * DEVICE pointer to one float (the NoiseInjection.weight parameter).  MFMA fp32 (v_mfma_f32_32x32x2_f32).
+ * workspace (optional, may be NULL): device scratch for split-K partial sums of launch-starved small
+ * layers; without it those layers run unsplit.  Contents need not be preserved between calls. */
 int sis_modconv2d(float* out, const float* x, const float* wpk, const float* s,
                   const float* dscale, const float* noise, int64_t noise_batch_stride,
                   const float* noise_weight, const float* bias, int batch, int cin, int cout,
-                  int h, int w, int ksize, int fuse_act, void* stream);
+                  int h, int w, int ksize, int fuse_act, void* workspace, int64_t workspace_bytes,
+                  void* stream);
 
 /* Modulated transposed convolution, stride 2, no padding, ks = 3: model.py:251-261 up to (not
  * including) the Blur: t[b,co,p,q] = dscale[b,co] * sum_{ci, 2h+kh=p, 2w+kw=q} wpk[ci][kh*3+kw][co]
  * * s[b,ci] * x[b,ci,h,w];  t is [B, Cout, 2H+1, 2W+1]. */
 int sis_modconv2d_up(float* t, const float* x, const float* wpk, const float* s,
                      const float* dscale, int batch, int cin, int cout, int h, int w,
-                     void* stream);
+                     void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Blur (upfirdn2d up=1 down=1, model.py:89-92 / :262) fused with NoiseInjection + FusedLeakyReLU
  * (model.py:338-340): in [B,C,IH,IW] -> out [B,C,OH,OW], OH = IH + pad0 + pad1 - kh + 1.

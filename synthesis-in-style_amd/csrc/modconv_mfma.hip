@@ -30,48 +30,17 @@
 // Occupancy plan: 2 workgroups per CU (<= 256 VGPRs, ~48 KB LDS each); while one stages its next
 // K chunk the other one's MFMAs keep the matrix pipe busy (f32 MFMA issues one 32x32x2 per 64
 // cycles per SIMD, so LDS reads -- 12-22 ds_read_b32 per 18-24 MFMAs -- are nowhere near a limit).
-#include "sis_common.h"
+#include "modconv_common.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int MAX_CLS = 4;
+constexpr int MAX_CLS = MC_MAX_CLS;
 constexpr int CC = 8;   // input channels per K chunk
-constexpr int XI = 3;   // staged x elements per lane per channel (covers xt <= 768)
-
-struct TileClass {
-    int th_log2, tw_log2, nb;  // tile = nb samples x 2^th_log2 rows x 2^tw_log2 cols
-    int h0, w0, h1, w1;        // region of positions this class owns: [h0,h1) x [w0,w1)
-    int nth, ntw;              // tiles per sample
-    int first_block;           // first position-tile index of this class
-    int xt;                    // floats per channel of the staged input tile
-};
-
-struct ConvParams {
-    const float* x; const float* wpk; const float* s; const float* dscale;
-    const float* noise; const float* noise_w; const float* bias;
-    float* out;
-    int64_t noise_bstride;
-    int B, Cin, Cout, H, W, OH, OW;
-    int fuse;
-    int npos_tiles, ncls;
-    int cout_vec4;
-    TileClass cls[MAX_CLS];
-};
+constexpr int XI = MC_XI;
 
 template <int MODE, int KS>
-struct Cfg {
-    static constexpr int NTAPS = KS * KS;
-    static constexpr int MBLK = MODE == 0 ? 128 : 64;
-    static constexpr int NPOS = MODE == 0 ? 256 : 128;
-    static constexpr int WAVES_N = MODE == 0 ? 2 : 4;
-    static constexpr int MT = 2;
-    static constexpr int NT = MODE == 0 ? 4 : 1;
-    static constexpr int NACC = MODE == 0 ? 4 : 4;
-    static constexpr int PAD_LO = MODE == 0 ? KS / 2 : 1;
-    static constexpr int EXT = MODE == 0 ? KS - 1 : 1;
-    static constexpr int WFLOATS = CC * NTAPS * MBLK;
+struct Cfg : ConvCfg<MODE, KS> {
+    static constexpr int WFLOATS = CC * ConvCfg<MODE, KS>::NTAPS * ConvCfg<MODE, KS>::MBLK;
 };
 
 template <int MODE, int KS>
@@ -245,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_kernel(const ConvParams p
             const int pp = (wn * C::NT + t) * 32 + l31;
             const int n = pp >> (thl + twl), rem = pp & ((1 << (thl + twl)) - 1);
             const int b = b0 + n, h = h0 + (rem >> twl), w = w0 + (rem & (tw - 1));
-            if (b >= p.B || h >= p.H || w >= p.W) continue;
+            if (n >= tc.nb || b >= p.B || h >= p.H || w >= p.W) continue;
             float nz = 0.f;
             if (p.fuse && p.noise) nz = nw * p.noise[(int64_t)b * p.noise_bstride + h * p.W + w];
             float* ob = p.out + (int64_t)b * p.Cout * HW + h * p.W + w;
@@ -270,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_kernel(const ConvParams p
         const int pp = wn * 32 + l31;
         const int n = pp >> (thl + twl), rem = pp & ((1 << (thl + twl)) - 1);
         const int b = b0 + n, h = h0 + (rem >> twl), w = w0 + (rem & (tw - 1));
-        if (b < p.B && h < tc.h1 && w < tc.w1) {
+        if (n < tc.nb && b < p.B && h < tc.h1 && w < tc.w1) {
             const int OHW = p.OH * p.OW;
             float* ob = p.out + (int64_t)b * p.Cout * OHW;
             const float* db = p.dscale + (int64_t)b * p.Cout;
@@ -291,28 +260,6 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_kernel(const ConvParams p
                 }
         }
     }
-}
-
-int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
-
-// Adds a tile class covering positions [h0,h1) x [w0,w1) with tiles of npos positions.
-void add_class(ConvParams& p, int npos, int ext, int batch, int h0, int h1, int w0, int w1, int tw_cap) {
-    const int hh = h1 - h0, ww = w1 - w0;
-    if (hh <= 0 || ww <= 0) return;
-    TileClass& c = p.cls[p.ncls];
-    int twl = ilog2_ceil(ww);
-    const int capl = ilog2_ceil(tw_cap);
-    if (twl > capl) twl = capl;
-    const int npl = ilog2_ceil(npos);
-    int thl = ilog2_ceil(hh);
-    if (thl > npl - twl) thl = npl - twl;
-    c.th_log2 = thl; c.tw_log2 = twl; c.nb = npos >> (thl + twl);
-    c.h0 = h0; c.w0 = w0; c.h1 = h1; c.w1 = w1;
-    c.nth = sis_cdiv(hh, 1 << thl); c.ntw = sis_cdiv(ww, 1 << twl);
-    c.first_block = p.npos_tiles;
-    c.xt = c.nb * ((1 << thl) + ext) * ((1 << twl) + ext);
-    p.npos_tiles += c.nth * c.ntw * sis_cdiv(batch, c.nb);
-    p.ncls++;
 }
 
 template <int MODE, int KS>
@@ -340,39 +287,54 @@ int check_common(const char* name, const void* out, const void* x, const void* w
 
 }  // namespace
 
+int modconv_v2_launch(ConvParams& p, int mode, int ks, hipStream_t st, void* workspace, int64_t workspace_bytes);
+
+static void init_params(ConvParams& p) {
+    p.slab = nullptr; p.ksplit = 1; p.npos_tiles = 0; p.ncls = 0; p.nb_max = 0;
+}
+
 extern "C" int sis_modconv2d(float* out, const float* x, const float* wpk, const float* s, const float* dscale,
                              const float* noise, int64_t noise_batch_stride, const float* noise_weight,
                              const float* bias, int batch, int cin, int cout, int h, int w, int ksize, int fuse_act,
-                             void* stream) {
+                             void* workspace, int64_t workspace_bytes, void* stream) {
     if (batch == 0) return 0;
     if (check_common("sis_modconv2d", out, x, wpk, s, dscale, batch, cin, cout, h, w, h, w)) return 1;
     SIS_REQUIRE(ksize == 1 || ksize == 3, "sis_modconv2d: kernel size %d not supported (1 or 3)", ksize);
     if (noise) SIS_REQUIRE(noise_weight, "sis_modconv2d: noise given without noise_weight");
     ConvParams p;
+    init_params(p);
     p.x = x; p.wpk = wpk; p.s = s; p.dscale = dscale; p.noise = noise; p.noise_w = noise_weight; p.bias = bias;
     p.out = out; p.noise_bstride = noise_batch_stride;
     p.B = batch; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w; p.OH = h; p.OW = w; p.fuse = fuse_act != 0;
-    p.npos_tiles = 0; p.ncls = 0;
+    p.kchunk = cin;
     p.cout_vec4 = (cout % 4 == 0) && (((uintptr_t)wpk & 15) == 0);
-    add_class(p, 256, ksize - 1, batch, 0, h, 0, w, 32);
+    mc_add_class(p, 256, ksize - 1, batch, 0, h, 0, w, 32, 16);
+    const int rc = modconv_v2_launch(p, 0, ksize, (hipStream_t)stream, workspace, workspace_bytes);
+    if (rc >= 0) return rc;
+    p.ksplit = 1; p.kchunk = cin; p.slab = nullptr;
     if (ksize == 3) return launch<0, 3>(p, (hipStream_t)stream);
     return launch<0, 1>(p, (hipStream_t)stream);
 }
 
 extern "C" int sis_modconv2d_up(float* t, const float* x, const float* wpk, const float* s, const float* dscale,
-                                int batch, int cin, int cout, int h, int w, void* stream) {
+                                int batch, int cin, int cout, int h, int w, void* workspace, int64_t workspace_bytes,
+                                void* stream) {
     if (batch == 0) return 0;
     const int oh = 2 * h + 1, ow = 2 * w + 1;
     if (check_common("sis_modconv2d_up", t, x, wpk, s, dscale, batch, cin, cout, h, w, oh, ow)) return 1;
     ConvParams p;
+    init_params(p);
     p.x = x; p.wpk = wpk; p.s = s; p.dscale = dscale; p.noise = nullptr; p.noise_w = nullptr; p.bias = nullptr;
     p.out = t; p.noise_bstride = 0;
     p.B = batch; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w; p.OH = oh; p.OW = ow; p.fuse = 0;
-    p.npos_tiles = 0; p.ncls = 0;
+    p.kchunk = cin;
     p.cout_vec4 = (cout % 4 == 0) && (((uintptr_t)wpk & 15) == 0);
-    add_class(p, 128, 1, batch, 0, h, 0, w, 32);          // interior positions
-    add_class(p, 128, 1, batch, h, h + 1, 0, w, 128);     // last row  (T[2H, 0..2W-1])
-    add_class(p, 128, 1, batch, 0, h, w, w + 1, 1);       // last col  (T[0..2H-1, 2W])
-    add_class(p, 128, 1, batch, h, h + 1, w, w + 1, 1);   // corner    (T[2H, 2W])
+    mc_add_class(p, 128, 1, batch, 0, h, 0, w, 32, 8);          // interior positions
+    mc_add_class(p, 128, 1, batch, h, h + 1, 0, w, 128, 8);     // last row  (T[2H, 0..2W-1])
+    mc_add_class(p, 128, 1, batch, 0, h, w, w + 1, 1, 8);       // last col  (T[0..2H-1, 2W])
+    mc_add_class(p, 128, 1, batch, h, h + 1, w, w + 1, 1, 8);   // corner    (T[2H, 2W])
+    const int rc = modconv_v2_launch(p, 1, 3, (hipStream_t)stream, workspace, workspace_bytes);
+    if (rc >= 0) return rc;
+    p.ksplit = 1; p.kchunk = cin; p.slab = nullptr;
     return launch<1, 3>(p, (hipStream_t)stream);
 }

@@ -1,0 +1,340 @@
+// Fast path of the modulated convolution: LDS-DMA (global_load_lds) staging, double-buffered
+// LDS, one barrier per K chunk, optional split-K for the launch-starved low-resolution layers.
+//
+// Same GEMM mapping as modconv_mfma.hip (see its header); what changes is how operands arrive:
+//   * weights   global_load_lds_dwordx4: one wave instruction moves two 512-byte rows
+//               [ci][tap][co0..co0+127] straight into LDS (no VGPRs, no ds_write);
+//   * input     global_load_lds_dword, EXEC-masked: halo / out-of-image positions are never
+//               written, they keep the zeros stored once before the K loop (the set of padded
+//               positions of a tile is the same for every channel chunk);
+//   * style     s[b, :] of the tile's samples sits in LDS for the whole kernel and multiplies
+//               the B operand after its ds_read (one v_mul per operand, hidden under the MFMAs),
+//               so staging is a pure copy and needs no arithmetic.
+// While chunk c is multiplied out of buffer c&1, the DMA for chunk c+1 fills the other buffer;
+// `__syncthreads()` (s_waitcnt vmcnt(0) + s_barrier) at the end of the chunk both retires this
+// wave's DMA and frees the buffer just read.  Two workgroups per CU (<= 256 VGPRs, ~50 KB LDS)
+// still overlap each other's barriers.
+//
+// Split-K (ksplit > 1): blockIdx.y owns a slice of input channels and writes raw partial sums to
+// slab[slice]; modconv_splitk_finish adds the slices in fixed order (bitwise reproducible, no
+// atomics) and applies the epilogue.  Used when position-tiles x oc-blocks < ~2 per CU (4^2..16^2).
+#include "modconv_common.h"
+
+namespace {
+
+template <int MODE>
+struct V2 {
+    static constexpr int CC = MODE == 0 ? 4 : 8;  // input channels per chunk
+};
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 4, 0, 0);
+}
+
+template <int MODE, int KS>
+__global__ __launch_bounds__(256, 2) void modconv_v2_kernel(const ConvParams p, const int xt_max) {
+    typedef ConvCfg<MODE, KS> C;
+    constexpr int CC = V2<MODE>::CC;
+    constexpr int WF = CC * C::NTAPS * C::MBLK;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Wl = lds;                   // [2][WF]
+    float* Xl = lds + 2 * WF;          // [2][CC * xt]
+    float* Sl = Xl + 2 * CC * xt_max;  // [nb][Cin]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = MODE == 0 ? (wave >> 1) : 0;
+    const int wn = MODE == 0 ? (wave & 1) : wave;
+    const int wbase = tid & ~63;  // wave-uniform: LDS-DMA destinations are base + lane * size
+
+    int pt = blockIdx.x % p.npos_tiles;
+    const int o0 = (blockIdx.x / p.npos_tiles) * C::MBLK;
+    int ci_cls = 0;
+#pragma unroll
+    for (int c = 1; c < MC_MAX_CLS; ++c)
+        if (c < p.ncls && pt >= p.cls[c].first_block) ci_cls = c;
+    const TileClass tc = p.cls[ci_cls];
+    pt -= tc.first_block;
+    const int twi = pt % tc.ntw; pt /= tc.ntw;
+    const int thi = pt % tc.nth;
+    const int bt = pt / tc.nth;
+    const int thl = tc.th_log2, twl = tc.tw_log2;
+    const int th = 1 << thl, tw = 1 << twl;
+    const int b0 = bt * tc.nb, h0 = tc.h0 + (thi << thl), w0 = tc.w0 + (twi << twl);
+    const int eh = th + C::EXT, ew = tw + C::EXT;
+    const int xt = tc.xt;
+    const int HW = p.H * p.W;
+    const int k_lo = blockIdx.y * p.kchunk;
+    const int k_hi = min(p.Cin, k_lo + p.kchunk);
+
+    // ---- one-time LDS init: zeros under the input tiles, style rows of this tile's samples
+    for (int e = tid; e < 2 * CC * xt; e += 256) Xl[e] = 0.f;
+    for (int e = tid; e < tc.nb * p.Cin; e += 256) {
+        const int n = e / p.Cin, ci = e - n * p.Cin;
+        Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
+    }
+
+    // ---- per-lane DMA source offsets for the input tile (-1: padded position, never written)
+    int st_goff[MC_XI];
+#pragma unroll
+    for (int i = 0; i < MC_XI; ++i) {
+        const int idx = tid + 256 * i;
+        st_goff[i] = -1;
+        if (idx < xt) {
+            const int n = idx / (eh * ew), rem = idx - n * (eh * ew);
+            const int r = rem / ew, c = rem - r * ew;
+            const int b = b0 + n, h = h0 - C::PAD_LO + r, w = w0 - C::PAD_LO + c;
+            if (b < p.B && h >= 0 && h < p.H && w >= 0 && w < p.W) st_goff[i] = b * p.Cin * HW + h * p.W + w;
+        }
+    }
+    // weight DMA: float4 e = it*256 + tid of the chunk's [CC*NTAPS][MBLK] slab
+    constexpr int WV4 = WF / 4, WIT = (WV4 + 255) / 256;
+    int w_goff[WIT];
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+        const int e = it * 256 + tid;
+        const int row = e / (C::MBLK / 4), q = e - row * (C::MBLK / 4);
+        w_goff[it] = (e < WV4 && o0 + q * 4 < p.Cout) ? row * p.Cout + o0 + q * 4 : -1;
+    }
+
+    auto stage = [&](int ci0, int buf) {
+        const float* wsrc = p.wpk + (int64_t)ci0 * C::NTAPS * p.Cout;
+        float* wdst = Wl + buf * WF + wbase * 4;
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            if (w_goff[it] >= 0) glds16(wsrc + w_goff[it], wdst + it * 1024);
+        const float* xsrc = p.x + (int64_t)ci0 * HW;
+        float* xdst = Xl + buf * CC * xt + wbase;
+#pragma unroll
+        for (int j = 0; j < CC; ++j)
+#pragma unroll
+            for (int i = 0; i < MC_XI; ++i)
+                if (st_goff[i] >= 0) glds4(xsrc + st_goff[i] + j * HW, xdst + j * xt + i * 256);
+    };
+
+    // ---- per-lane operand offsets
+    int xo[C::NT], so[C::NT];
+#pragma unroll
+    for (int t = 0; t < C::NT; ++t) {
+        const int pp = (wn * C::NT + t) * 32 + l31;
+        const int n = pp >> (thl + twl), rem = pp & ((1 << (thl + twl)) - 1);
+        const int r = rem >> twl, c = rem & (tw - 1);
+        xo[t] = n * eh * ew + r * ew + c + half * xt;
+        so[t] = min(n, tc.nb - 1) * p.Cin + half;
+    }
+    const int aoff = half * C::NTAPS * C::MBLK + wm * 64 + l31;
+
+    f32x16 acc[C::MT][C::NACC];
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+        for (int a = 0; a < C::NACC; ++a)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[m][a][j] = 0.f;
+
+    __syncthreads();  // zeros and style rows are in LDS before any DMA may land on them
+    stage(k_lo, 0);
+    __syncthreads();  // vmcnt(0) + barrier: chunk 0 landed
+
+    int buf = 0;
+    for (int ci0 = k_lo; ci0 < k_hi; ci0 += CC, buf ^= 1) {
+        if (ci0 + CC < k_hi) stage(ci0 + CC, buf ^ 1);
+        const float* Wb = Wl + buf * WF;
+        const float* Xb = Xl + buf * CC * xt;
+        float sv[CC / 2][C::NT];
+#pragma unroll
+        for (int cp = 0; cp < CC / 2; ++cp)
+#pragma unroll
+            for (int t = 0; t < C::NT; ++t) sv[cp][t] = Sl[so[t] + ci0 + 2 * cp];
+
+        if (MODE == 0) {
+#pragma unroll
+            for (int tap = 0; tap < C::NTAPS; ++tap) {
+                const int toff = (tap / KS) * ew + (tap % KS);
+#pragma unroll
+                for (int cp = 0; cp < CC / 2; ++cp) {
+                    float a[C::MT], bv[C::NT];
+#pragma unroll
+                    for (int m = 0; m < C::MT; ++m) a[m] = Wb[(2 * cp * C::NTAPS + tap) * C::MBLK + aoff + m * 32];
+#pragma unroll
+                    for (int t = 0; t < C::NT; ++t) bv[t] = Xb[2 * cp * xt + xo[t] + toff] * sv[cp][t];
+#pragma unroll
+                    for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                        for (int t = 0; t < C::NT; ++t)
+                            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[t], acc[m][t], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int cp = 0; cp < CC / 2; ++cp) {
+                const float* xb = Xb + 2 * cp * xt + xo[0];
+                const float s0 = sv[cp][0];
+                const float x_ul = xb[0] * s0, x_u = xb[1] * s0, x_l = xb[ew] * s0, x_c = xb[ew + 1] * s0;
+#pragma unroll
+                for (int m = 0; m < C::MT; ++m) {
+                    const float* wb = Wb + 2 * cp * C::NTAPS * C::MBLK + aoff + m * 32;
+                    float a[9];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) a[t] = wb[t * C::MBLK];
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], x_c, acc[m][0], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[6], x_u, acc[m][0], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], x_l, acc[m][0], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8], x_ul, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], x_c, acc[m][1], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[7], x_u, acc[m][1], 0, 0, 0);
+                    acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], x_c, acc[m][2], 0, 0, 0);
+                    acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[5], x_l, acc[m][2], 0, 0, 0);
+                    acc[m][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4], x_c, acc[m][3], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();  // next chunk's DMA retired (vmcnt 0) and everyone is done with this buffer
+    }
+
+    // ---- epilogue (ksplit > 1: raw partial sums to this slice's slab)
+    const bool partial = p.ksplit > 1;
+    if (MODE == 0) {
+        float nw = 0.f;
+        if (!partial && p.fuse && p.noise) nw = p.noise_w[0];
+        float* obase = partial ? p.slab + (int64_t)blockIdx.y * p.B * p.Cout * HW : p.out;
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t) {
+            const int pp = (wn * C::NT + t) * 32 + l31;
+            const int n = pp >> (thl + twl), rem = pp & ((1 << (thl + twl)) - 1);
+            const int b = b0 + n, h = h0 + (rem >> twl), w = w0 + (rem & (tw - 1));
+            if (n >= tc.nb || b >= p.B || h >= p.H || w >= p.W) continue;
+            float nz = 0.f;
+            if (!partial && p.fuse && p.noise) nz = nw * p.noise[(int64_t)b * p.noise_bstride + h * p.W + w];
+            float* ob = obase + (int64_t)b * p.Cout * HW + h * p.W + w;
+            const float* db = p.dscale + (int64_t)b * p.Cout;
+#pragma unroll
+            for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int co = o0 + wm * 64 + m * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
+                    if (co < p.Cout) {
+                        float v = acc[m][t][j];
+                        if (!partial) {
+                            v *= db[co];
+                            if (p.fuse) {
+                                v += nz;
+                                if (p.bias) v += p.bias[co];
+                                v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
+                            }
+                        }
+                        ob[(int64_t)co * HW] = v;
+                    }
+                }
+        }
+    } else {
+        const int pp = wn * 32 + l31;
+        const int n = pp >> (thl + twl), rem = pp & ((1 << (thl + twl)) - 1);
+        const int b = b0 + n, h = h0 + (rem >> twl), w = w0 + (rem & (tw - 1));
+        if (n < tc.nb && b < p.B && h < tc.h1 && w < tc.w1) {
+            const int OHW = p.OH * p.OW;
+            float* ob = (partial ? p.slab + (int64_t)blockIdx.y * p.B * p.Cout * OHW : p.out) + (int64_t)b * p.Cout * OHW;
+            const float* db = p.dscale + (int64_t)b * p.Cout;
+#pragma unroll
+            for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int co = o0 + m * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
+                    if (co < p.Cout) {
+                        const float d = partial ? 1.f : db[co];
+                        float* oc = ob + (int64_t)co * OHW;
+#pragma unroll
+                        for (int ph = 0; ph < 4; ++ph) {
+                            const int oy = 2 * h + (ph >> 1), ox = 2 * w + (ph & 1);
+                            if (oy < p.OH && ox < p.OW) oc[oy * p.OW + ox] = acc[m][ph][j] * d;
+                        }
+                    }
+                }
+        }
+    }
+}
+
+// Adds the K slices in slice order and applies demodulation (+ noise, bias, leaky-ReLU when fused).
+__global__ __launch_bounds__(256) void modconv_splitk_finish(const ConvParams p, int64_t plane_elems, int64_t total) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t ohw = (int64_t)p.OH * p.OW;
+    float nw = 0.f;
+    if (p.fuse && p.noise) nw = p.noise_w[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        float v = 0.f;
+        for (int k = 0; k < p.ksplit; ++k) v += p.slab[k * plane_elems + i];
+        const int64_t bc = i / ohw, hw = i - bc * ohw;
+        const int b = (int)(bc / p.Cout), co = (int)(bc - (int64_t)b * p.Cout);
+        v *= p.dscale[bc];
+        if (p.fuse) {
+            if (p.noise) v += nw * p.noise[(int64_t)b * p.noise_bstride + hw];
+            if (p.bias) v += p.bias[co];
+            v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
+        }
+        p.out[i] = v;
+    }
+}
+
+template <int MODE, int KS>
+int launch_v2(ConvParams& p, hipStream_t st) {
+    typedef ConvCfg<MODE, KS> C;
+    constexpr int CC = V2<MODE>::CC;
+    int xt_max = 0;
+    for (int c = 0; c < p.ncls; ++c) xt_max = p.cls[c].xt > xt_max ? p.cls[c].xt : xt_max;
+    if (xt_max > 256 * MC_XI) return -1;
+    const size_t lds = (size_t)(2 * CC * C::NTAPS * C::MBLK + 2 * CC * xt_max + p.nb_max * p.Cin) * sizeof(float);
+    if (lds > 160 * 1024) return -1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_v2_kernel<MODE, KS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return sis_fail("modconv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int64_t bx = (int64_t)p.npos_tiles * sis_cdiv(p.Cout, C::MBLK);
+    SIS_REQUIRE(bx > 0 && bx < ((int64_t)1 << 31), "modconv: bad grid");
+    hipLaunchKernelGGL((modconv_v2_kernel<MODE, KS>), dim3((unsigned)bx, p.ksplit), dim3(256), lds, st, p, xt_max);
+    SIS_CHECK_LAUNCH("modconv_v2_kernel");
+    if (p.ksplit > 1) {
+        const int64_t total = (int64_t)p.B * p.Cout * p.OH * p.OW;
+        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(modconv_splitk_finish, dim3(blocks), dim3(256), 0, st, p, total, total);
+        SIS_CHECK_LAUNCH("modconv_splitk_finish");
+    }
+    return 0;
+}
+
+}  // namespace
+
+// Chooses the K split: enough (tile x oc-block x slice) workgroups to give every CU ~2, slices a
+// multiple of the chunk size, and the slabs must fit the caller's workspace.
+static void plan_splitk(ConvParams& p, int mblk, int cc, int64_t workspace_bytes) {
+    p.ksplit = 1; p.kchunk = p.Cin; p.slab = nullptr;
+    const int64_t blocks = (int64_t)p.npos_tiles * sis_cdiv(p.Cout, mblk);
+    if (blocks >= 384 || p.Cin < 4 * cc) return;
+    int want = (int)((512 + blocks - 1) / blocks);
+    const int max_split = p.Cin / (2 * cc);
+    if (want > max_split) want = max_split;
+    const int64_t out_bytes = (int64_t)p.B * p.Cout * p.OH * p.OW * 4;
+    if ((int64_t)want * out_bytes > workspace_bytes) want = (int)(workspace_bytes / out_bytes);
+    if (want < 2) return;
+    int kchunk = sis_cdiv(sis_cdiv(p.Cin, want), cc) * cc;
+    p.kchunk = kchunk;
+    p.ksplit = sis_cdiv(p.Cin, kchunk);
+}
+
+int modconv_v2_launch(ConvParams& p, int mode, int ks, hipStream_t st, void* workspace, int64_t workspace_bytes) {
+    const int cc = mode == 0 ? V2<0>::CC : V2<1>::CC;
+    if (p.Cin % cc != 0 || !p.cout_vec4 || (((uintptr_t)p.x | (uintptr_t)p.wpk) & 15) != 0) return -1;
+    plan_splitk(p, mode == 0 ? 128 : 64, cc, workspace ? workspace_bytes : 0);
+    if (p.ksplit > 1) p.slab = (float*)workspace;
+    if (mode == 0 && ks == 3) return launch_v2<0, 3>(p, st);
+    if (mode == 0 && ks == 1) return launch_v2<0, 1>(p, st);
+    if (mode == 1 && ks == 3) return launch_v2<1, 3>(p, st);
+    return -1;
+}

@@ -36,8 +36,8 @@ _SIGNATURES = {
     "sis_truncate": ([_vp, _vp, _vp, _f, _i, _i, _vp], _i),
     "sis_modconv_prepack": ([_vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "sis_modconv_demod": ([_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp], _i),
-    "sis_modconv2d": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 7 + [_vp], _i),
-    "sis_modconv2d_up": ([_vp] * 5 + [_i] * 5 + [_vp], _i),
+    "sis_modconv2d": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 7 + [_vp, _i64, _vp], _i),
+    "sis_modconv2d_up": ([_vp] * 5 + [_i] * 5 + [_vp, _i64, _vp], _i),
     "sis_blur_noise_act": ([_vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 9 + [_vp], _i),
     "sis_to_rgb": ([_vp] * 7 + [_i] * 9 + [_f, _vp], _i),
 }
@@ -237,6 +237,19 @@ def modconv_demod(s, wsq, scale, demodulate):
     return out
 
 
+WORKSPACE_BYTES = 128 << 20
+_workspaces = {}
+
+
+def _workspace(device):
+    """Per-device scratch for split-K partial sums (stream-ordered reuse: one stream per device at a time)."""
+    ws = _workspaces.get(device)
+    if ws is None:
+        ws = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
 def _noise_args(noise, batch, h, w):
     if noise is None:
         return None, 0
@@ -254,12 +267,14 @@ def modconv2d(x, wpk, s, dscale, ksize, noise=None, noise_weight=None, bias=None
     cout = wpk.shape[2]
     noise, nbs = _noise_args(noise, batch, h, w)
     out = torch.empty((batch, cout, h, w), dtype=torch.float32, device=x.device)
+    ws = _workspace(x.device)
     with torch.cuda.device(x.device):
         _check(_launch(f"modconv_mfma_kernel<0,{ksize}>", 2.0 * batch * cout * cin * ksize * ksize * h * w,
                        4.0 * (x.numel() + out.numel() + wpk.numel()),
                        lambda: lib().sis_modconv2d(_ptr(out), _ptr(x), _ptr(wpk), _ptr(s), _ptr(dscale), _ptr(noise),
                                                    nbs, _ptr(noise_weight), _ptr(bias), batch, cin, cout, h, w, ksize,
-                                                   int(bool(fuse_act)), _stream())), "sis_modconv2d")
+                                                   int(bool(fuse_act)), _ptr(ws), ws.numel(), _stream())),
+               "sis_modconv2d")
     return out
 
 
@@ -268,11 +283,13 @@ def modconv2d_up(x, wpk, s, dscale):
     batch, cin, h, w = x.shape
     cout = wpk.shape[2]
     out = torch.empty((batch, cout, 2 * h + 1, 2 * w + 1), dtype=torch.float32, device=x.device)
+    ws = _workspace(x.device)
     with torch.cuda.device(x.device):
         _check(_launch("modconv_mfma_kernel<1,3>", 2.0 * batch * cout * cin * 9 * h * w,
                        4.0 * (x.numel() + out.numel() + wpk.numel()),
                        lambda: lib().sis_modconv2d_up(_ptr(out), _ptr(x), _ptr(wpk), _ptr(s), _ptr(dscale), batch, cin,
-                                                      cout, h, w, _stream())), "sis_modconv2d_up")
+                                                      cout, h, w, _ptr(ws), ws.numel(), _stream())),
+               "sis_modconv2d_up")
     return out
 
 
