@@ -287,8 +287,6 @@ int check_common(const char* name, const void* out, const void* x, const void* w
 
 }  // namespace
 
-int modconv_v2_launch(ConvParams& p, int mode, int ks, hipStream_t st, void* workspace, int64_t workspace_bytes);
-
 static void init_params(ConvParams& p) {
     p.slab = nullptr; p.ksplit = 1; p.npos_tiles = 0; p.ncls = 0; p.nb_max = 0;
 }
@@ -329,12 +327,20 @@ extern "C" int sis_modconv2d_up(float* t, const float* x, const float* wpk, cons
     p.B = batch; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w; p.OH = oh; p.OW = ow; p.fuse = 0;
     p.kchunk = cin;
     p.cout_vec4 = (cout % 4 == 0) && (((uintptr_t)wpk & 15) == 0);
-    mc_add_class(p, 128, 1, batch, 0, h, 0, w, 32, 8);          // interior positions
-    mc_add_class(p, 128, 1, batch, h, h + 1, 0, w, 128, 8);     // last row  (T[2H, 0..2W-1])
-    mc_add_class(p, 128, 1, batch, 0, h, w, w + 1, 1, 8);       // last col  (T[0..2H-1, 2W])
-    mc_add_class(p, 128, 1, batch, h, h + 1, w, w + 1, 1, 8);   // corner    (T[2H, 2W])
-    const int rc = modconv_v2_launch(p, 1, 3, (hipStream_t)stream, workspace, workspace_bytes);
-    if (rc >= 0) return rc;
+    int mblk, npos;
+    modconv_v2_tile(1, &mblk, &npos);
+    for (int pass = 0; pass < 2; ++pass) {
+        const int np = pass == 0 ? npos : 128;
+        p.npos_tiles = 0; p.ncls = 0; p.nb_max = 0;
+        mc_add_class(p, np, 1, batch, 0, h, 0, w, 32, 8);          // interior positions
+        mc_add_class(p, np, 1, batch, h, h + 1, 0, w, np, 8);      // last row  (T[2H, 0..2W-1])
+        mc_add_class(p, np, 1, batch, 0, h, w, w + 1, 1, 8);       // last col  (T[0..2H-1, 2W])
+        mc_add_class(p, np, 1, batch, h, h + 1, w, w + 1, 1, 8);   // corner    (T[2H, 2W])
+        if (pass == 0) {
+            const int rc = modconv_v2_launch(p, 1, 3, (hipStream_t)stream, workspace, workspace_bytes);
+            if (rc >= 0) return rc;
+        }
+    }
     p.ksplit = 1; p.kchunk = cin; p.slab = nullptr;
     return launch<1, 3>(p, (hipStream_t)stream);
 }

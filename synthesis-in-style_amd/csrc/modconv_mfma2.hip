@@ -27,6 +27,21 @@ struct V2 {
     static constexpr int CC = MODE == 0 ? 4 : 8;  // input channels per chunk
 };
 
+// Wave layout of a workgroup: WM x WN waves, each owning MT x NT 32x32 accumulator tiles
+// (MODE 1: NT = 1 and the 4 output phases take the place of the N tiles).
+template <int MODE, int KS, int WM_, int WN_, int MT_, int NT_, int OCC_>
+struct V2Cfg {
+    static constexpr int NTAPS = KS * KS;
+    static constexpr int WM = WM_, WN = WN_, MT = MT_, NT = NT_, OCC = OCC_;
+    static constexpr int THREADS = 64 * WM * WN;
+    static constexpr int MBLK = 32 * WM * MT;
+    static constexpr int NPOS = 32 * WN * NT;
+    static constexpr int NACC = MODE == 0 ? NT : 4;
+    static constexpr int PAD_LO = MODE == 0 ? KS / 2 : 1;
+    static constexpr int EXT = MODE == 0 ? KS - 1 : 1;
+    static constexpr int XI = (768 + THREADS - 1) / THREADS;  // covers xt <= 768
+};
+
 __device__ __forceinline__ void glds16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -36,10 +51,11 @@ __device__ __forceinline__ void glds4(const float* g, float* l) {
                                      (__attribute__((address_space(3))) void*)l, 4, 0, 0);
 }
 
-template <int MODE, int KS>
-__global__ __launch_bounds__(256, 2) void modconv_v2_kernel(const ConvParams p, const int xt_max) {
-    typedef ConvCfg<MODE, KS> C;
+template <int MODE, int KS, typename C>
+__global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const ConvParams p, const int xt_max) {
     constexpr int CC = V2<MODE>::CC;
+    constexpr int NTHR = C::THREADS;
+    constexpr int XI = C::XI;
     constexpr int WF = CC * C::NTAPS * C::MBLK;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Wl = lds;                   // [2][WF]
@@ -48,8 +64,8 @@ __global__ __launch_bounds__(256, 2) void modconv_v2_kernel(const ConvParams p, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int wm = MODE == 0 ? (wave >> 1) : 0;
-    const int wn = MODE == 0 ? (wave & 1) : wave;
+    const int wm = wave / C::WN;
+    const int wn = wave % C::WN;
     const int wbase = tid & ~63;  // wave-uniform: LDS-DMA destinations are base + lane * size
 
     int pt = blockIdx.x % p.npos_tiles;
@@ -73,17 +89,17 @@ __global__ __launch_bounds__(256, 2) void modconv_v2_kernel(const ConvParams p, 
     const int k_hi = min(p.Cin, k_lo + p.kchunk);
 
     // ---- one-time LDS init: zeros under the input tiles, style rows of this tile's samples
-    for (int e = tid; e < 2 * CC * xt; e += 256) Xl[e] = 0.f;
-    for (int e = tid; e < tc.nb * p.Cin; e += 256) {
+    for (int e = tid; e < 2 * CC * xt; e += NTHR) Xl[e] = 0.f;
+    for (int e = tid; e < tc.nb * p.Cin; e += NTHR) {
         const int n = e / p.Cin, ci = e - n * p.Cin;
         Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
     }
 
     // ---- per-lane DMA source offsets for the input tile (-1: padded position, never written)
-    int st_goff[MC_XI];
+    int st_goff[XI];
 #pragma unroll
-    for (int i = 0; i < MC_XI; ++i) {
-        const int idx = tid + 256 * i;
+    for (int i = 0; i < XI; ++i) {
+        const int idx = tid + NTHR * i;
         st_goff[i] = -1;
         if (idx < xt) {
             const int n = idx / (eh * ew), rem = idx - n * (eh * ew);
@@ -93,11 +109,11 @@ __global__ __launch_bounds__(256, 2) void modconv_v2_kernel(const ConvParams p, 
         }
     }
     // weight DMA: float4 e = it*256 + tid of the chunk's [CC*NTAPS][MBLK] slab
-    constexpr int WV4 = WF / 4, WIT = (WV4 + 255) / 256;
+    constexpr int WV4 = WF / 4, WIT = (WV4 + NTHR - 1) / NTHR;
     int w_goff[WIT];
 #pragma unroll
     for (int it = 0; it < WIT; ++it) {
-        const int e = it * 256 + tid;
+        const int e = it * NTHR + tid;
         const int row = e / (C::MBLK / 4), q = e - row * (C::MBLK / 4);
         w_goff[it] = (e < WV4 && o0 + q * 4 < p.Cout) ? row * p.Cout + o0 + q * 4 : -1;
     }
@@ -107,14 +123,14 @@ __global__ __launch_bounds__(256, 2) void modconv_v2_kernel(const ConvParams p, 
         float* wdst = Wl + buf * WF + wbase * 4;
 #pragma unroll
         for (int it = 0; it < WIT; ++it)
-            if (w_goff[it] >= 0) glds16(wsrc + w_goff[it], wdst + it * 1024);
+            if (w_goff[it] >= 0) glds16(wsrc + w_goff[it], wdst + it * NTHR * 4);
         const float* xsrc = p.x + (int64_t)ci0 * HW;
         float* xdst = Xl + buf * CC * xt + wbase;
 #pragma unroll
         for (int j = 0; j < CC; ++j)
 #pragma unroll
-            for (int i = 0; i < MC_XI; ++i)
-                if (st_goff[i] >= 0) glds4(xsrc + st_goff[i] + j * HW, xdst + j * xt + i * 256);
+            for (int i = 0; i < XI; ++i)
+                if (st_goff[i] >= 0) glds4(xsrc + st_goff[i] + j * HW, xdst + j * xt + i * NTHR);
     };
 
     // ---- per-lane operand offsets
@@ -127,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void modconv_v2_kernel(const ConvParams p, 
         xo[t] = n * eh * ew + r * ew + c + half * xt;
         so[t] = min(n, tc.nb - 1) * p.Cin + half;
     }
-    const int aoff = half * C::NTAPS * C::MBLK + wm * 64 + l31;
+    const int aoff = half * C::NTAPS * C::MBLK + wm * C::MT * 32 + l31;
 
     f32x16 acc[C::MT][C::NACC];
 #pragma unroll
@@ -217,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void modconv_v2_kernel(const ConvParams p, 
             for (int m = 0; m < C::MT; ++m)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    const int co = o0 + wm * 64 + m * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
+                    const int co = o0 + (wm * C::MT + m) * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
                     if (co < p.Cout) {
                         float v = acc[m][t][j];
                         if (!partial) {
@@ -244,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void modconv_v2_kernel(const ConvParams p, 
             for (int m = 0; m < C::MT; ++m)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    const int co = o0 + m * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
+                    const int co = o0 + (wm * C::MT + m) * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
                     if (co < p.Cout) {
                         const float d = partial ? 1.f : db[co];
                         float* oc = ob + (int64_t)co * OHW;
@@ -280,25 +296,24 @@ __global__ __launch_bounds__(256) void modconv_splitk_finish(const ConvParams p,
     }
 }
 
-template <int MODE, int KS>
+template <int MODE, int KS, typename C>
 int launch_v2(ConvParams& p, hipStream_t st) {
-    typedef ConvCfg<MODE, KS> C;
     constexpr int CC = V2<MODE>::CC;
     int xt_max = 0;
     for (int c = 0; c < p.ncls; ++c) xt_max = p.cls[c].xt > xt_max ? p.cls[c].xt : xt_max;
-    if (xt_max > 256 * MC_XI) return -1;
+    if (xt_max > C::THREADS * C::XI) return -1;
     const size_t lds = (size_t)(2 * CC * C::NTAPS * C::MBLK + 2 * CC * xt_max + p.nb_max * p.Cin) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_v2_kernel<MODE, KS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_v2_kernel<MODE, KS, C>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return sis_fail("modconv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int64_t bx = (int64_t)p.npos_tiles * sis_cdiv(p.Cout, C::MBLK);
     SIS_REQUIRE(bx > 0 && bx < ((int64_t)1 << 31), "modconv: bad grid");
-    hipLaunchKernelGGL((modconv_v2_kernel<MODE, KS>), dim3((unsigned)bx, p.ksplit), dim3(256), lds, st, p, xt_max);
+    hipLaunchKernelGGL((modconv_v2_kernel<MODE, KS, C>), dim3((unsigned)bx, p.ksplit), dim3(C::THREADS), lds, st, p, xt_max);
     SIS_CHECK_LAUNCH("modconv_v2_kernel");
     if (p.ksplit > 1) {
         const int64_t total = (int64_t)p.B * p.Cout * p.OH * p.OW;
@@ -328,13 +343,37 @@ static void plan_splitk(ConvParams& p, int mblk, int cc, int64_t workspace_bytes
     p.ksplit = sis_cdiv(p.Cin, kchunk);
 }
 
+// Wave layouts (SIS_CONV_CFG=<mode0><mode1> digits select experiments; default "11": the 8-wave layouts,
+// 4 waves per SIMD, measured 3-10 % faster than the 4-wave ones: more waves to cover barrier skew).
+typedef V2Cfg<0, 3, 2, 2, 2, 4, 2> Conv3A;   // 256 thr, 128 co x 256 px, wave 64x128, 2 WG/CU
+typedef V2Cfg<0, 3, 2, 4, 2, 2, 4> Conv3B;   // 512 thr, 128 co x 256 px, wave 64x64,  2 WG/CU (4 waves/SIMD)
+typedef V2Cfg<0, 1, 2, 2, 2, 4, 2> Conv1A;
+typedef V2Cfg<1, 3, 1, 4, 2, 1, 2> UpA;      // 256 thr, 64 co x 128 pos, wave 64 co x 32 pos x 4 phases
+typedef V2Cfg<1, 3, 2, 4, 1, 1, 4> UpB;      // 512 thr, 64 co x 128 pos, wave 32 co x 32 pos x 4 phases
+typedef V2Cfg<1, 3, 1, 8, 2, 1, 2> UpC;      // 512 thr, 64 co x 256 pos, wave 64 co x 32 pos x 4 phases
+
+int modconv_v2_tile(int mode, int* mblk, int* npos) {
+    static int cfg = -1;
+    if (cfg < 0) {
+        const char* e = getenv("SIS_CONV_CFG");
+        cfg = (e && e[0] >= '0' && e[0] <= '9' && e[1] >= '0' && e[1] <= '9') ? (e[0] - '0') * 10 + (e[1] - '0') : 11;
+    }
+    const int c = mode == 0 ? cfg / 10 : cfg % 10;
+    if (mode == 0) { *mblk = 128; *npos = 256; }
+    else { *mblk = 64; *npos = c == 2 ? 256 : 128; }
+    return c;
+}
+
 int modconv_v2_launch(ConvParams& p, int mode, int ks, hipStream_t st, void* workspace, int64_t workspace_bytes) {
     const int cc = mode == 0 ? V2<0>::CC : V2<1>::CC;
     if (p.Cin % cc != 0 || !p.cout_vec4 || (((uintptr_t)p.x | (uintptr_t)p.wpk) & 15) != 0) return -1;
-    plan_splitk(p, mode == 0 ? 128 : 64, cc, workspace ? workspace_bytes : 0);
+    int mblk, npos;
+    const int c = modconv_v2_tile(mode, &mblk, &npos);
+    plan_splitk(p, mblk, cc, workspace ? workspace_bytes : 0);
     if (p.ksplit > 1) p.slab = (float*)workspace;
-    if (mode == 0 && ks == 3) return launch_v2<0, 3>(p, st);
-    if (mode == 0 && ks == 1) return launch_v2<0, 1>(p, st);
-    if (mode == 1 && ks == 3) return launch_v2<1, 3>(p, st);
+    if (mode == 0 && ks == 3) return c == 1 ? launch_v2<0, 3, Conv3B>(p, st) : launch_v2<0, 3, Conv3A>(p, st);
+    if (mode == 0 && ks == 1) return launch_v2<0, 1, Conv1A>(p, st);
+    if (mode == 1 && ks == 3)
+        return c == 1 ? launch_v2<1, 3, UpB>(p, st) : c == 2 ? launch_v2<1, 3, UpC>(p, st) : launch_v2<1, 3, UpA>(p, st);
     return -1;
 }

@@ -269,7 +269,7 @@ def modconv2d(x, wpk, s, dscale, ksize, noise=None, noise_weight=None, bias=None
     out = torch.empty((batch, cout, h, w), dtype=torch.float32, device=x.device)
     ws = _workspace(x.device)
     with torch.cuda.device(x.device):
-        _check(_launch(f"modconv_mfma_kernel<0,{ksize}>", 2.0 * batch * cout * cin * ksize * ksize * h * w,
+        _check(_launch(f"modconv_v2_kernel<0, {ksize}>", 2.0 * batch * cout * cin * ksize * ksize * h * w,
                        4.0 * (x.numel() + out.numel() + wpk.numel()),
                        lambda: lib().sis_modconv2d(_ptr(out), _ptr(x), _ptr(wpk), _ptr(s), _ptr(dscale), _ptr(noise),
                                                    nbs, _ptr(noise_weight), _ptr(bias), batch, cin, cout, h, w, ksize,
@@ -285,7 +285,7 @@ def modconv2d_up(x, wpk, s, dscale):
     out = torch.empty((batch, cout, 2 * h + 1, 2 * w + 1), dtype=torch.float32, device=x.device)
     ws = _workspace(x.device)
     with torch.cuda.device(x.device):
-        _check(_launch("modconv_mfma_kernel<1,3>", 2.0 * batch * cout * cin * 9 * h * w,
+        _check(_launch("modconv_v2_kernel<1, 3>", 2.0 * batch * cout * cin * 9 * h * w,
                        4.0 * (x.numel() + out.numel() + wpk.numel()),
                        lambda: lib().sis_modconv2d_up(_ptr(out), _ptr(x), _ptr(wpk), _ptr(s), _ptr(dscale), batch, cin,
                                                       cout, h, w, _ptr(ws), ws.numel(), _stream())),
