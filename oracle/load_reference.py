@@ -81,10 +81,14 @@ def load_reference_segmenters():
         if "networks" in sys.modules:
             raise RuntimeError("a different top-level 'networks' package is already imported; "
                                "import the reference segmenters in a fresh process")
-        pkg = types.ModuleType("networks")
-        pkg.__path__ = [os.path.join(REFERENCE_ROOT, "networks")]
-        pkg._sis_ref_stub = True
-        sys.modules["networks"] = pkg
+        for name in ("networks", "utils"):  # bare packages: skip their __init__.py (skimage, pytorch_training)
+            if name in sys.modules and not getattr(sys.modules[name], "_sis_ref_stub", False):
+                raise RuntimeError(f"a different top-level '{name}' package is already imported; "
+                                   "import the reference segmenters in a fresh process")
+            pkg = types.ModuleType(name)
+            pkg.__path__ = [os.path.join(REFERENCE_ROOT, name)]
+            pkg._sis_ref_stub = True
+            sys.modules[name] = pkg
     import importlib
 
     ema = importlib.import_module("networks.ema_net.network")

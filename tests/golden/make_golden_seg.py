@@ -1,0 +1,87 @@
+"""Generates tests/golden/ema_net_step.npz (and trans_u_net_step.npz) by running the UNMODIFIED reference
+segmentation networks (imported by file path, oracle/load_reference.py) through one training iteration in
+the order of updater/segmentation_updater.py:47-73 / :83-106 with torch.optim.SGD built as
+training_builder/ema_net_train_builder.py:27-48 / trans_u_net_train_builder.py:39-40.
+
+Run in the build container, in its own process (the reference's top-level ``networks`` package name clashes
+with the product's).  Weights / batches are re-derived anywhere from the seeded numpy streams in
+oracle/ema_net_ref.py / oracle/trans_u_net_ref.py; only outputs are stored.  Dropout layers are set to p = 0
+(device RNG streams can never match across vendors, SURVEY.md §7 "hard parts").
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import load_reference  # noqa: E402
+from oracle import ema_net_ref as E  # noqa: E402
+
+
+def make_ema_net(ema, ema_utils):
+    torch.manual_seed(0)
+    net = ema.EMANet(3, 50, use_pretrained_resnet=False)
+    schema = E.state_dict_schema(50, 3)
+    assert [k for k, _ in schema] == list(net.state_dict().keys())
+    for (k, s), v in zip(schema, net.state_dict().values()):
+        assert tuple(s) == tuple(v.shape), k
+    net.load_state_dict(E.seeded_state_dict(50, 3, seed=7), strict=True)
+    net.fc1[1].p = 0.0
+    net.train()
+    lr, wd, mom, em_mom = 0.009, 1e-4, 0.9, 0.9  # configs/segmenter/stylegan2_ema_net_segmenter.yaml:17-26
+    opt = torch.optim.SGD([
+        {"params": ema_utils.get_params(net, key="1x"), "lr": lr, "weight_decay": wd},
+        {"params": ema_utils.get_params(net, key="1y"), "lr": lr, "weight_decay": 0},
+        {"params": ema_utils.get_params(net, key="2x"), "lr": 2 * lr, "weight_decay": 0.0}], momentum=mom)
+    out = {"cfg": np.array([50, 3, 7, 8, 2, 256])}
+    # label maps: forward without labels on the initial state (batch-statistics BN: with running stats at their
+    # init values an eval-mode forward of a random net overflows to 1e4-sized logits and says nothing)
+    with torch.no_grad():
+        batch = E.seeded_batch(2, 256, 3, seed=10)
+        pred = net(batch["images"])
+        out["pred_slice"] = pred[:, :, ::16, ::16].numpy()
+        out["pred_labels"] = net.predict_classes(batch["images"]).numpy().astype(np.uint8)
+        top2 = pred.topk(2, dim=1).values
+        out["pred_margin"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float16)
+    net.load_state_dict(E.seeded_state_dict(50, 3, seed=7), strict=True)  # undo the running-stat updates
+    for it in range(2):
+        batch = E.seeded_batch(2, 256, 3, seed=8 + it)
+        loss, mu = net(batch["images"], torch.squeeze(batch["segmented"], dim=1))
+        with torch.no_grad():
+            mu_mean = mu.mean(dim=0, keepdim=True)
+            net.emau.mu *= em_mom
+            net.emau.mu += mu_mean * (1 - em_mom)
+        total = loss.mean()
+        opt.zero_grad()
+        total.backward()
+        if it == 0:
+            out["loss"] = loss.detach().numpy()
+            out["mu_slice"] = mu.detach()[:, ::32, ::8].numpy()
+            out["mu_abs_sum"] = mu.detach().abs().sum().double().numpy()
+            names = [n for n, p in net.named_parameters()]
+            out["grad_norms"] = np.array([-1.0 if p.grad is None else p.grad.double().norm().item()
+                                          for _, p in net.named_parameters()])  # -1: no gradient reaches it
+            out["grad_names"] = np.array(names)
+            out["grad_fc2_weight"] = net.fc2.weight.grad.numpy()
+            out["grad_stem0_slice"] = net.extractor[0][0].weight.grad[::8].numpy()
+        opt.step()
+        out[f"loss_mean_{it}"] = total.detach().numpy()
+    sd = net.state_dict()
+    out["after_names"] = np.array(list(sd.keys()))
+    out["after_abs_sums"] = np.array([v.double().abs().sum().item() for v in sd.values()])
+    out["after_emau_mu_slice"] = sd["emau.mu"][0, ::32, ::8].numpy()
+    out["after_bn_running_var_fc0"] = sd["fc0.bn.running_var"].numpy()
+    np.savez_compressed(os.path.join(HERE, "ema_net_step.npz"), **out)
+
+
+if __name__ == "__main__":
+    assert load_reference.reference_available()
+    ema, vit, tu_utils, ema_utils = load_reference.load_reference_segmenters()
+    torch.set_num_threads(8)
+    make_ema_net(ema, ema_utils)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith("_step.npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

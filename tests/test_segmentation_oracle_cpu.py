@@ -1,0 +1,59 @@
+"""CPU suite, part 3: the segmentation-training oracle is pinned against golden outputs of the reference
+EMANet run through one-and-a-half updater iterations (tests/golden/make_golden_seg.py)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import ema_net_ref as E
+
+
+def test_ema_net_schema_counts():
+    schema = E.state_dict_schema(50, 3)
+    assert len(schema) == 353
+    n_params = sum(int(np.prod(s)) for n, s in schema if "running_" not in n and not n.endswith("tracked") and n != "emau.mu")
+    assert n_params == 34776771
+    sd = E.seeded_state_dict(50, 3, seed=1)
+    g1x, g1y, g2x = E.param_groups(sd)
+    assert (len(g1x), len(g1y), len(g2x)) == (60, 58, 60)
+
+
+def test_ema_net_train_step_vs_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ema_net_step.npz"))
+    n_layers, classes, wseed, bseed, batch, size = g["cfg"].tolist()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    sd = E.seeded_state_dict(n_layers, classes, seed=wseed)
+    bufs = {}
+    total, loss, mu, grads = E.train_step(sd, bufs, E.seeded_batch(batch, size, classes, seed=bseed))
+    np.testing.assert_allclose(loss.numpy(), g["loss"], rtol=2e-5)
+    np.testing.assert_allclose(total.numpy(), g["loss_mean_0"], rtol=2e-5)
+    np.testing.assert_allclose(mu[:, ::32, ::8].numpy(), g["mu_slice"], rtol=1e-4, atol=1e-6)
+    for name, ref in zip(g["grad_names"], g["grad_norms"]):
+        if ref < 0:
+            assert grads[str(name)] is None
+        else:
+            np.testing.assert_allclose(grads[str(name)].double().norm().item(), ref, rtol=2e-3, err_msg=str(name))
+    np.testing.assert_allclose(grads["fc2.weight"].numpy(), g["grad_fc2_weight"], rtol=1e-3, atol=1e-6)
+    total1, _, _, _ = E.train_step(sd, bufs, E.seeded_batch(batch, size, classes, seed=bseed + 1))
+    np.testing.assert_allclose(total1.numpy(), g["loss_mean_1"], rtol=1e-4)
+    # After the first update the state agrees with the reference to ~1e-7; the second forward/backward of this
+    # randomly initialised 50-layer net (BN over a batch of 2, hard EM assignments) amplifies that to a few
+    # percent in early-layer gradients, so the two-step state is held to a looser bound.
+    for name, ref in zip(g["after_names"], g["after_abs_sums"]):
+        np.testing.assert_allclose(sd[str(name)].double().abs().sum().item(), ref, rtol=3e-3, err_msg=str(name))
+    np.testing.assert_allclose(sd["emau.mu"][0, ::32, ::8].numpy(), g["after_emau_mu_slice"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(sd["fc0.bn.running_var"].numpy(), g["after_bn_running_var_fc0"], rtol=1e-3)
+
+
+def test_ema_net_label_maps_vs_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ema_net_step.npz"))
+    n_layers, classes, wseed, bseed, batch, size = g["cfg"].tolist()
+    sd = E.seeded_state_dict(n_layers, classes, seed=wseed)
+    with torch.no_grad():
+        pred, _ = E.forward(sd, E.seeded_batch(batch, size, classes, seed=10)["images"], training=True)
+    np.testing.assert_allclose(pred[:, :, ::16, ::16].numpy(), g["pred_slice"], rtol=1e-3, atol=1e-4)
+    labels = pred.argmax(1, keepdim=True).numpy().astype(np.uint8)
+    margin = g["pred_margin"].astype(np.float32)
+    decided = margin > 1e-3  # argmax must be bit-exact wherever the reference's top-2 margin is not a rounding tie
+    assert (labels[:, 0][decided] == g["pred_labels"][:, 0][decided]).all()
+    assert decided.mean() > 0.98
