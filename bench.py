@@ -118,12 +118,70 @@ def cpu_baseline(g, seed):
                       f"best of 2 after 1 warm-up ({sec:.2f} s/iter)"}, img, (z, noise)
 
 
+SEG_FLOPS_PER_IMAGE = {"emanet": 227.38e9, "transunet": 1007.79e9}  # fwd+bwd, SURVEY.md §8(d) (2*MAC)
+SEG_CONFIG = {"emanet": "configs/segmenter/ema_net_resnet50_256.yaml",
+              "transunet": "configs/segmenter/trans_u_net_r50_vit_b16_512.yaml"}
+
+
+def bench_training(args, workload, world, rank, device, distributed):
+    """Segmentation training images/s (BASELINE.json configs[3] / [4]): one step = one updater iteration
+    (forward, loss, backward with bucketed RCCL all-reduce, fused SGD step) on a synthetic batch resident in HBM."""
+    import yaml
+    import torch.distributed as dist
+    from training_builder.train_builder_selection import get_train_builder_class
+    from utils.synthetic_data import SyntheticSegmentationLoader
+    config = yaml.safe_load(open(os.path.join(ROOT, "synthesis-in-style_amd", SEG_CONFIG[workload])))
+    config["fine_tune"] = None
+    if args.batch:
+        config["batch_size"] = args.batch
+    loader = SyntheticSegmentationLoader(config["batch_size"], config["image_size"], config["num_classes"],
+                                         seed=1234 + rank, device=device)
+    torch.manual_seed(0)
+    builder = get_train_builder_class(config)(config, loader, None, rank=device.index, world_size=world)
+    updater = builder.get_updater()
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        updater.update()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        updater.update()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank != 0:
+        return None
+    images = config["batch_size"] * args.steps * world
+    tf = SEG_FLOPS_PER_IMAGE[workload] * images / elapsed / 1e12 / world
+    return {
+        "metric": METRIC, "value": round(images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{config['network']} training step, {config['image_size']}x{config['image_size']}, batch "
+                               f"{config['batch_size']} per GPU (BASELINE.json configs[{3 if workload == 'emanet' else 4}])",
+                   "batch_per_gpu": config["batch_size"], "image_size": config["image_size"],
+                   "parallelism": f"dp{world}, DDP bucketed all-reduce over RCCL"},
+        "roofline": {"kernel": "whole step (convolutions on ROCm libraries this round)", "bound": "mfma",
+                     "achieved": round(tf, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tf / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="synthesis", choices=["synthesis", "emanet", "transunet"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -139,6 +197,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
+
+    if args.workload != "synthesis":
+        result = bench_training(args, args.workload, world, rank, device, distributed)
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        if result is not None:
+            print(json.dumps(result))
+        return
+    args.batch = args.batch or BATCH
 
     g = build_generator(device)
     z, noise = synth_inputs(g, args.batch, device, seed=1 + rank)

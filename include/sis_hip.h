@@ -127,6 +127,38 @@ int sis_to_rgb(float* out, const float* x, const float* w, const float* s, const
                const float* skip, const float* taps, int batch, int cin, int cout, int h, int width,
                int kh, int kw, int pad0, int pad1, float scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Segmentation training step (float32): the non-convolution ends of EMANetUpdater.update_core /
+ * TransUNetUpdater.update_core (updater/segmentation_updater.py:47-73, :83-106).
+ */
+
+/* EMANet loss tail, networks/ema_net/network.py:305-311 + CrossEntropyLoss2d :319-327:
+ *   pred = bilinear(logits [B,C,h,w] -> [B,C,out_h,out_w], align_corners=True)
+ *   loss[b] = mean_{y,x} NLL(log_softmax(pred)[b,:,y,x], labels[b,y,x]), ignore_index pixels count as 0.
+ * workspace: sis_upsample_ce_workspace(batch, out_h, out_w) floats.  labels are int64 [B,out_h,out_w]. */
+int sis_upsample_ce_workspace(int batch, int out_h, int out_w);
+int sis_upsample_ce_fwd(float* loss, float* workspace, const float* logits, const int64_t* labels,
+                        int batch, int classes, int h, int w, int out_h, int out_w,
+                        int64_t ignore_index, void* stream);
+/* grad_logits[b,c,i,j] = d(sum_b grad_loss[b] * loss[b]) / d logits[b,c,i,j] (deterministic gather). */
+int sis_upsample_ce_bwd(float* grad_logits, const float* grad_loss, const float* logits,
+                        const int64_t* labels, int batch, int classes, int h, int w, int out_h,
+                        int out_w, int64_t ignore_index, void* stream);
+
+/* torch.optim.SGD(momentum, dampening 0, no nesterov) for every tensor of an optimizer in one launch
+ * (training_builder/ema_net_train_builder.py:27-48).  `table` is a device array of n_chunks rows of four
+ * int64: {param ptr, grad ptr, momentum-buffer ptr, count | (group << 48)}, count <= sis_sgd_chunk_elems().
+ *   d = grad + wd[group]*p;  buf = first_step ? d : momentum*buf + d;  p -= lr[group]*buf
+ * lr / weight_decay are HOST arrays of n_groups (<= 4) floats. */
+int sis_sgd_chunk_elems(void);
+int sis_sgd_momentum(const int64_t* table, int n_chunks, const float* lr, const float* weight_decay,
+                     int n_groups, float momentum, int first_step, void* stream);
+
+/* emau.mu[i] = mu[i]*momentum + mean_b(mu_batch[b,i])*one_minus_momentum
+ * (updater/segmentation_updater.py:56-66; in-place on the buffer, outside autograd). */
+int sis_ema_update(float* mu, const float* mu_batch, float momentum, float one_minus_momentum,
+                   int batch, int numel, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,253 @@
+"""EMANet (dilated ResNet backbone + Expectation-Maximisation Attention Unit) for MI355X.
+
+Drop-in for /root/reference/stylegan_code_finder/networks/ema_net/network.py: same constructor, same
+``forward(img, lbl=None, size=None)`` contract (``(loss[B], mu)`` when training with labels, logits otherwise),
+same ``state_dict`` keys (353 for ResNet-50: ``extractor.{0..7}...``, ``fc0``, ``emau``, ``fc1``, ``fc2``;
+checked against the reference's key list in the test-suite), same initialisation statistics.
+
+Differences in execution:
+* the loss tail -- bilinear upsampling of the stride-8 logits to label resolution, log-softmax, NLL with
+  ``ignore_label`` and the per-sample spatial mean (reference :305-311, :319-327) -- is ONE hand-written HIP
+  kernel each way (``sis_upsample_ce_fwd/bwd``); the full-resolution logits are never materialised;
+* "SynchronizedBatchNorm2d" is what it effectively is under the reference's DistributedDataParallel launch:
+  per-GPU ``F.batch_norm`` with momentum 3e-4 (bn_lib/nn/modules/batchnorm.py:51-56); the DataParallel-era
+  synchronisation machinery is not carried over (never active under train.py);
+* convolutions / batch norm / pooling / bmm run on the ROCm libraries through ATen for now (DESIGN.md lists
+  them as the next kernels to hand-write).
+"""
+import math
+import pathlib
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.nn.modules.batchnorm import _BatchNorm
+
+import sis_hip
+from networks.base_segmenter import BaseSegmenter
+
+BN_MOM = 3e-4
+RESNET_BLOCKS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+
+
+class SynchronizedBatchNorm2d(nn.BatchNorm2d):
+    """Per-process batch norm; always the functional call, so ``num_batches_tracked`` stays untouched exactly
+    as in the reference's code path."""
+
+    def forward(self, input):
+        return F.batch_norm(input, self.running_mean, self.running_var, self.weight, self.bias, self.training,
+                            self.momentum, self.eps)
+
+
+norm_layer = partial(SynchronizedBatchNorm2d, momentum=BN_MOM)
+
+
+def _init_weights(module):
+    """He-normal on fan-out for convolutions, unit scale / zero shift for norms (reference :88-98)."""
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+            m.weight.data.normal_(0, math.sqrt(2. / fan_out))
+        elif isinstance(m, _BatchNorm):
+            m.weight.data.fill_(1)
+            if m.bias is not None:
+                m.bias.data.zero_()
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, previous_dilation=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, dilation, dilation, bias=False)
+        self.bn2 = norm_layer(planes)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
+        self.bn3 = norm_layer(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.dilation = dilation
+        self.stride = stride
+
+    def forward(self, x):
+        shortcut = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return self.relu(y + shortcut)
+
+
+class ResNet(nn.Module):
+    """Deep-stem ResNet with output stride 8 or 16 (dilated layer3 / layer4, multi-grid [1,2,4] in layer4)."""
+
+    def __init__(self, block, layers, num_classes=1000, stride=8):
+        super().__init__()
+        self.inplanes = 128
+        self.conv1 = nn.Sequential(
+            nn.Conv2d(3, 64, 3, 2, 1, bias=False), norm_layer(64), nn.ReLU(inplace=True),
+            nn.Conv2d(64, 64, 3, 1, 1, bias=False), norm_layer(64), nn.ReLU(inplace=True),
+            nn.Conv2d(64, 128, 3, 1, 1, bias=False))
+        self.bn1 = norm_layer(self.inplanes)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        if stride == 16:
+            self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+            self.layer4 = self._make_layer(block, 512, layers[3], stride=1, dilation=2, grids=[1, 2, 4])
+        elif stride == 8:
+            self.layer3 = self._make_layer(block, 256, layers[2], stride=1, dilation=2)
+            self.layer4 = self._make_layer(block, 512, layers[3], stride=1, dilation=4, grids=[1, 2, 4])
+        else:
+            raise RuntimeError(f'=> unsupported output stride: {stride}')
+        self.avgpool = nn.AvgPool2d(7, stride=1)
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        _init_weights(self)
+
+    def _make_layer(self, block, planes, blocks, stride=1, dilation=1, grids=None):
+        grids = grids or [1] * blocks
+        if dilation not in (1, 2, 4):
+            raise RuntimeError(f'=> unknown dilation size: {dilation}')
+        out_planes = planes * block.expansion
+        downsample = None
+        if stride != 1 or self.inplanes != out_planes:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, out_planes, 1, stride, bias=False),
+                                       norm_layer(out_planes))
+        first_dilation = 2 if dilation == 4 else 1
+        units = [block(self.inplanes, planes, stride, dilation=first_dilation, downsample=downsample,
+                       previous_dilation=dilation)]
+        self.inplanes = out_planes
+        units += [block(out_planes, planes, dilation=dilation * grids[i], previous_dilation=dilation)
+                  for i in range(1, blocks)]
+        return nn.Sequential(*units)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = self.avgpool(x)
+        return self.fc(x.view(x.size(0), -1))
+
+
+def resnet(n_layers, stride, use_pretrained_resnet, pretrained_path):
+    net = ResNet(Bottleneck, layers=RESNET_BLOCKS[n_layers], stride=stride)
+    if use_pretrained_resnet:
+        path = pathlib.Path(pretrained_path)
+        assert path.exists(), f'There does not seem to be a pretrained model at {pretrained_path}. Make sure ' \
+                              f'you downloaded the correct model and saved it there.'
+        net.load_state_dict(torch.load(path), strict=False)
+    return net
+
+
+class ConvBNReLU(nn.Module):
+    def __init__(self, c_in, c_out, kernel_size, stride, padding, dilation):
+        super().__init__()
+        self.conv = nn.Conv2d(c_in, c_out, kernel_size, stride, padding, dilation, bias=False)
+        self.bn = norm_layer(c_out)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.relu(self.bn(self.conv(x)))
+
+
+class EMAU(nn.Module):
+    """Expectation-Maximisation Attention Unit: ``stage_num`` E/M rounds over ``k`` bases held in the buffer
+    ``mu`` [1, c, k]; the rounds run outside autograd, only the reconstruction ``mu z^T`` is differentiated
+    through (and, as in the reference, only w.r.t. nothing upstream: conv1 receives no gradient)."""
+
+    def __init__(self, c, k, stage_num=3):
+        super().__init__()
+        self.stage_num = stage_num
+        mu = torch.empty(1, c, k).normal_(0, math.sqrt(2. / k))
+        self.register_buffer('mu', self._l2norm(mu, dim=1))
+        self.conv1 = nn.Conv2d(c, c, 1)
+        self.conv2 = nn.Sequential(nn.Conv2d(c, c, 1, bias=False), norm_layer(c))
+        _init_weights(self)
+
+    def forward(self, x):
+        idn = x
+        x = self.conv1(x)
+        b, c, h, w = x.size()
+        x = x.view(b, c, h * w)
+        mu = self.mu.repeat(b, 1, 1)
+        with torch.no_grad():
+            x_t = x.permute(0, 2, 1)
+            for _ in range(self.stage_num):
+                z = F.softmax(torch.bmm(x_t, mu), dim=2)              # E: responsibilities  [b, n, k]
+                z_ = z / (1e-6 + z.sum(dim=1, keepdim=True))
+                mu = self._l2norm(torch.bmm(x, z_), dim=1)             # M: bases             [b, c, k]
+        x = F.relu(mu.matmul(z.permute(0, 2, 1)).view(b, c, h, w), inplace=True)
+        x = F.relu(self.conv2(x) + idn, inplace=True)
+        return x, mu
+
+    @staticmethod
+    def _l2norm(inp, dim):
+        return inp / (1e-6 + inp.norm(dim=dim, keepdim=True))
+
+
+class _UpsampleCrossEntropy(Function):
+    """loss[b] = mean_{y,x} NLL(log_softmax(bilinear_{align_corners}(logits))[b,:,y,x], labels[b,y,x])."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, size, ignore_index):
+        ctx.save_for_backward(logits, labels)
+        ctx.size, ctx.ignore_index = size, ignore_index
+        return sis_hip.upsample_ce_fwd(logits, labels, size, ignore_index)
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        logits, labels = ctx.saved_tensors
+        return sis_hip.upsample_ce_bwd(grad_loss.contiguous(), logits, labels, ctx.size, ctx.ignore_index), None, None, None
+
+
+class CrossEntropyLoss2d(nn.Module):
+    """Per-sample mean cross entropy over [B, C, H, W] logits (reference :319-327); kept for callers that hold
+    full-resolution predictions.  EMANet.forward itself uses the fused upsample + loss kernel."""
+
+    def __init__(self, weight=None, reduction='none', ignore_index=255):
+        super().__init__()
+        self.nll_loss = nn.NLLLoss(weight, reduction=reduction, ignore_index=ignore_index)
+        self.ignore_index = ignore_index
+
+    def forward(self, inputs, targets):
+        return self.nll_loss(F.log_softmax(inputs, dim=1), targets).mean(dim=2).mean(dim=1)
+
+
+class EMANet(BaseSegmenter):
+    def __init__(self, num_classes, n_layers, stride=8, stage_num=3, ignore_label=255, background_class_id: int = 0,
+                 min_confidence: float = 0.0, min_contour_area: int = 0, use_pretrained_resnet=True,
+                 pretrained_path: str = ""):
+        super().__init__(background_class_id, min_confidence, min_contour_area)
+        self.num_classes = num_classes
+        backbone = resnet(n_layers, stride, use_pretrained_resnet, pretrained_path)
+        self.extractor = nn.Sequential(backbone.conv1, backbone.bn1, backbone.relu, backbone.maxpool,
+                                       backbone.layer1, backbone.layer2, backbone.layer3, backbone.layer4)
+        self.fc0 = ConvBNReLU(2048, 512, 3, 1, 1, 1)
+        self.emau = EMAU(512, 64, stage_num)
+        self.fc1 = nn.Sequential(ConvBNReLU(512, 256, 3, 1, 1, 1), nn.Dropout2d(p=0.1))
+        self.fc2 = nn.Conv2d(256, num_classes, 1)
+        self.crit = CrossEntropyLoss2d(ignore_index=ignore_label, reduction='none')
+        self.ignore_label = ignore_label
+
+    def logits(self, img):
+        x = self.fc0(self.extractor(img))
+        x, mu = self.emau(x)
+        return self.fc2(self.fc1(x)), mu
+
+    def forward(self, img, lbl=None, size=None):
+        x, mu = self.logits(img)
+        if size is None:
+            size = img.size()[-2:]
+        if self.training and lbl is not None:
+            sis_hip.require_device(x, "img")  # the loss tail is a HIP kernel: no CPU fallback
+            if x.dtype == torch.float32 and x.shape[1] <= 32:
+                return _UpsampleCrossEntropy.apply(x, lbl, (int(size[0]), int(size[1])), self.ignore_label), mu
+            # > 32 classes or reduced precision: library composite on the device (same math, three passes)
+            pred = F.interpolate(x.float(), size=size, mode='bilinear', align_corners=True)
+            return self.crit(pred, lbl), mu
+        return F.interpolate(x, size=size, mode='bilinear', align_corners=True)
+
+    def predict_classes(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.argmax(self.forward(x), dim=1, keepdim=True)

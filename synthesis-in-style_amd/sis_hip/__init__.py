@@ -40,6 +40,12 @@ _SIGNATURES = {
     "sis_modconv2d_up": ([_vp] * 5 + [_i] * 5 + [_vp, _i64, _vp], _i),
     "sis_blur_noise_act": ([_vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 9 + [_vp], _i),
     "sis_to_rgb": ([_vp] * 7 + [_i] * 9 + [_f, _vp], _i),
+    "sis_upsample_ce_workspace": ([_i] * 3, _i),
+    "sis_upsample_ce_fwd": ([_vp] * 4 + [_i] * 6 + [_i64, _vp], _i),
+    "sis_upsample_ce_bwd": ([_vp] * 4 + [_i] * 6 + [_i64, _vp], _i),
+    "sis_sgd_chunk_elems": ([], _i),
+    "sis_sgd_momentum": ([_vp, _i, ctypes.POINTER(_f), ctypes.POINTER(_f), _i, _f, _i, _vp], _i),
+    "sis_ema_update": ([_vp, _vp, _f, _f, _i, _i, _vp], _i),
 }
 
 
@@ -327,3 +333,63 @@ def to_rgb(x, weight, s, bias, scale, skip=None, taps=None, pad=(0, 0)):
                                                 _ptr(taps), batch, cin, cout, h, wd, kh, kw, pad[0], pad[1],
                                                 float(scale), _stream())), "sis_to_rgb")
     return out
+
+
+# ------------------------------------------------------------------------------ segmentation training
+
+
+def upsample_ce_fwd(logits, labels, out_size, ignore_index):
+    """loss[B] of bilinear(align_corners) + log-softmax + NLL + spatial mean; labels int64 [B, H, W]."""
+    x = _f32(logits, "logits")
+    require_device(labels, "labels")
+    if labels.dtype != torch.int64:
+        raise RuntimeError(f"labels must be int64, got {labels.dtype}")
+    lab = labels.contiguous()
+    b, c, h, w = x.shape
+    oh, ow = out_size
+    if tuple(lab.shape) != (b, oh, ow):
+        raise RuntimeError(f"labels shape {tuple(lab.shape)} != {(b, oh, ow)}")
+    L = lib()
+    ws = torch.empty(L.sis_upsample_ce_workspace(b, oh, ow), dtype=torch.float32, device=x.device)
+    loss = torch.empty(b, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(L.sis_upsample_ce_fwd(_ptr(loss), _ptr(ws), _ptr(x), _ptr(lab), b, c, h, w, oh, ow, int(ignore_index),
+                                     _stream()), "sis_upsample_ce_fwd")
+    return loss
+
+
+def upsample_ce_bwd(grad_loss, logits, labels, out_size, ignore_index):
+    x = _f32(logits, "logits")
+    g = _f32(grad_loss, "grad_loss")
+    lab = labels.contiguous()
+    b, c, h, w = x.shape
+    gx = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_upsample_ce_bwd(_ptr(gx), _ptr(g), _ptr(x), _ptr(lab), b, c, h, w, out_size[0], out_size[1],
+                                         int(ignore_index), _stream()), "sis_upsample_ce_bwd")
+    return gx
+
+
+def sgd_chunk_elems():
+    return lib().sis_sgd_chunk_elems()
+
+
+def sgd_momentum(table, n_chunks, lrs, wds, momentum, first_step):
+    n = len(lrs)
+    arr = _f * n
+    with torch.cuda.device(table.device):
+        _check(lib().sis_sgd_momentum(_ptr(table), n_chunks, arr(*lrs), arr(*wds), n, float(momentum),
+                                      int(bool(first_step)), _stream()), "sis_sgd_momentum")
+
+
+def ema_update(mu, mu_batch, momentum):
+    """In place: mu <- mu*m + mean_b(mu_batch)*(1-m); (1-m) is formed in double like the reference's Python."""
+    require_device(mu, "mu")
+    mb = _f32(mu_batch, "mu_batch")
+    if not mu.is_contiguous() or mu.dtype != torch.float32:
+        raise RuntimeError("mu must be a contiguous float32 buffer")
+    n = mu.numel()
+    with torch.cuda.device(mu.device):
+        _check(lib().sis_ema_update(_ptr(mu), _ptr(mb), float(momentum), float(1 - momentum), mb.numel() // n, n,
+                                    _stream()), "sis_ema_update")
+    return mu

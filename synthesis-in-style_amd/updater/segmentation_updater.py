@@ -1,0 +1,77 @@
+"""One training iteration per segmentation model family.
+
+Mirrors updater/segmentation_updater.py:42-106 of the reference: same class names, constructor keywords
+(``em_mom`` / ``num_classes`` + the Updater dicts), batch contract (``batch['images']`` f32 [B,3,S,S] in
+[-1,1], ``batch['segmented']`` int64 [B,1,S,S]) and the same order of operations inside ``update_core``:
+
+  EMANet     forward -> EM bases moving average (no grad) -> loss.mean() -> zero_grad -> backward -> step
+  TransUNet  zero_grad -> forward -> 0.5 * CE + 0.5 * Dice(softmax) -> backward -> step
+
+MI355X specifics: the bases update is one HIP kernel (``sis_ema_update``), the EMANet loss tail is fused inside
+the network (networks/ema_net/network.py), the optimizer step is the one-launch ``FusedSGD`` the builders
+create, gradients are all-reduced by DistributedDataParallel over RCCL while backward is still running.
+"""
+import torch
+from torch import nn
+
+import sis_hip
+from networks.trans_u_net.utils import DiceLoss
+from training.loop import GradientApplier, Updater, get_current_reporter
+
+
+def _unwrap(network):
+    """The bare module behind a DistributedDataParallel wrapper (reference: try/except AttributeError, :58-66)."""
+    return network.module if hasattr(network, 'module') and not hasattr(network, 'emau') else network
+
+
+class EMANetUpdater(Updater):
+    def __init__(self, *args, **kwargs):
+        self.em_mom = kwargs.pop('em_mom')
+        super().__init__(*args, **kwargs)
+
+    def update_core(self):
+        batch = next(self.iterators['images'])
+        batch = {key: value.to(self.device, non_blocking=True) for key, value in batch.items()}
+        reporter = get_current_reporter()
+        network = self.networks['segmentation']
+        optimizer = self.optimizers['main']
+
+        loss, mu = network(batch['images'], torch.squeeze(batch['segmented'], dim=1))
+
+        with torch.no_grad():
+            bases = _unwrap(network).emau.mu
+            if bases.is_cuda:
+                sis_hip.ema_update(bases, mu, self.em_mom)
+            else:
+                raise RuntimeError("mu must be a CUDA tensor")
+
+        loss = loss.mean()
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        reporter.add_observation({'softmax': loss.detach()}, 'loss')
+
+
+class TransUNetUpdater(Updater):
+    def __init__(self, *args, **kwargs):
+        num_classes = kwargs.pop('num_classes')
+        super().__init__(*args, **kwargs)
+        self.ce_loss = nn.CrossEntropyLoss()
+        self.dice_loss = DiceLoss(num_classes)
+
+    def update_core(self):
+        batch = next(self.iterators['images'])
+        batch = {key: value.to(self.device, non_blocking=True) for key, value in batch.items()}
+        reporter = get_current_reporter()
+        network = self.networks['segmentation']
+
+        with GradientApplier([network], [self.optimizers['main']]):
+            prediction = network(batch['images'])
+            ground_truth = torch.squeeze(batch['segmented'], dim=1)
+            loss_ce = self.ce_loss(prediction, ground_truth.long())
+            loss_dice = self.dice_loss(prediction, ground_truth, softmax=True)
+            loss = 0.5 * loss_ce + 0.5 * loss_dice
+            loss.backward()
+
+        reporter.add_observation({'combined': loss.detach(), 'CE': loss_ce.detach(), 'Dice': loss_dice.detach()},
+                                 'loss')

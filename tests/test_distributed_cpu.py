@@ -1,0 +1,100 @@
+"""CPU suite, part 4: the N > 1 paths, rehearsed with the gloo backend and world_size 2.
+
+* synthesis shards by image id with no collective (utils/dataset_creation.shard_range);
+* segmentation training wraps the network exactly as the builder does (DistributedDataParallel,
+  broadcast_buffers=False, bucketed all-reduce): gradients on every rank equal the mean of the per-rank
+  gradients, parameters stay in lock-step after an optimizer step, buffers stay per-rank.
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_ids():
+    from utils.dataset_creation import shard_range
+    for n, world in [(100000, 8), (10, 3), (7, 8), (0, 4)]:
+        ranges = [shard_range(n, r, world) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        assert max(hi - lo for lo, hi in ranges) - min(hi - lo for lo, hi in ranges) <= 1
+    assert shard_range(100000, 3, 8) == (37500, 50000)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class _TinySegmenter(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(3, 4, 3, padding=1)
+        self.bn = nn.BatchNorm2d(4, momentum=3e-4)
+        self.head = nn.Conv2d(4, 3, 1)
+        self.register_buffer("mu", torch.zeros(1, 4))
+
+    def forward(self, x):
+        return self.head(torch.relu(self.bn(self.conv(x))))
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, "synthesis-in-style_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from training_builder.base_train_builder import BaseSingleNetworkTrainBuilder, strip_parallel_module
+        torch.manual_seed(0)
+        builder = BaseSingleNetworkTrainBuilder({"fine_tune": None, "bucket_cap_mb": 1}, rank=rank, world_size=world)
+        net = _TinySegmenter()
+        with torch.no_grad():
+            net.mu.fill_(float(rank))  # per-rank buffer must survive (broadcast_buffers=False)
+        ddp = builder._prepare_segmentation_network(net)
+        assert strip_parallel_module(ddp) is net
+        gen = torch.Generator().manual_seed(100 + rank)
+        x = torch.randn(2, 3, 8, 8, generator=gen)
+        y = torch.randint(0, 3, (2, 8, 8), generator=gen)
+        loss = nn.functional.cross_entropy(ddp(x), y)
+        loss.backward()
+        grads = torch.cat([p.grad.flatten() for p in net.parameters()])
+        # single-process replay of this rank's gradient, then average across ranks by hand
+        torch.manual_seed(0)
+        solo = _TinySegmenter()
+        nn.functional.cross_entropy(solo(x), y).backward()
+        local = torch.cat([p.grad.flatten() for p in solo.parameters()])
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        expect = torch.stack(gathered).mean(0)
+        opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9)
+        opt.step()
+        params = torch.cat([p.detach().flatten() for p in net.parameters()])
+        all_params = [torch.zeros_like(params) for _ in range(world)]
+        dist.all_gather(all_params, params)
+        out[rank] = (torch.allclose(grads, expect, atol=1e-6), all(torch.equal(all_params[0], q) for q in all_params),
+                     float(net.mu[0, 0]), float(net.bn.running_mean.abs().sum()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_wrap_world_size_2_gloo():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert len(out) == world
+    for rank in range(world):
+        grads_ok, params_ok, mu, bn_stat = out[rank]
+        assert grads_ok, "DDP gradients are not the mean of the per-rank gradients"
+        assert params_ok, "parameters diverged across ranks after one step"
+        assert mu == float(rank), "buffers were broadcast (must stay per-rank)"
+    assert out[0][3] != out[1][3], "batch-norm statistics must be per-rank"

@@ -1,0 +1,101 @@
+"""GPU parity, part 3: the segmentation-training kernels against stock torch on the host (fp64 / fp32).
+
+* sis_upsample_ce_fwd/bwd == F.interpolate(bilinear, align_corners=True) -> log_softmax -> NLL(ignore) -> mean
+  (networks/ema_net/network.py:305-311, :319-327 of the reference), values and gradients;
+* sis_sgd_momentum == torch.optim.SGD(momentum, weight_decay) over several steps, three groups;
+* sis_ema_update == the in-place mu update of updater/segmentation_updater.py:56-66.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_loss(logits, labels, size, ignore):
+    pred = F.interpolate(logits, size=size, mode="bilinear", align_corners=True)
+    nll = F.nll_loss(F.log_softmax(pred, dim=1), labels, ignore_index=ignore, reduction="none")
+    return nll.mean(dim=2).mean(dim=1)
+
+
+@pytest.mark.parametrize("b,c,h,w,H,W", [(2, 3, 32, 32, 256, 256), (3, 5, 7, 9, 40, 33), (1, 21, 16, 16, 16, 16),
+                                         (2, 2, 1, 1, 8, 8), (2, 4, 33, 33, 257, 257)])
+def test_upsample_ce_forward_backward(device, b, c, h, w, H, W):
+    import sis_hip
+    gen = torch.Generator().manual_seed(b + c + h + H)
+    logits = torch.randn(b, c, h, w, generator=gen) * 2
+    labels = torch.randint(0, c, (b, H, W), generator=gen)
+    labels[torch.rand(b, H, W, generator=gen) < 0.1] = 255
+    gl = torch.randn(b, generator=gen)
+    x64 = logits.double().requires_grad_(True)
+    ref = _ref_loss(x64, labels, (H, W), 255)
+    (gref,) = torch.autograd.grad(ref, x64, gl.double())
+    loss = sis_hip.upsample_ce_fwd(logits.to(device), labels.to(device), (H, W), 255)
+    assert torch.allclose(loss.cpu().double(), ref.detach(), rtol=2e-5, atol=1e-6)
+    gx = sis_hip.upsample_ce_bwd(gl.to(device), logits.to(device), labels.to(device), (H, W), 255)
+    scale = gref.abs().max().item()
+    assert (gx.cpu().double() - gref).abs().max().item() <= 2e-5 * scale + 1e-9
+    # determinism: no atomics anywhere
+    assert torch.equal(loss, sis_hip.upsample_ce_fwd(logits.to(device), labels.to(device), (H, W), 255))
+    assert torch.equal(gx, sis_hip.upsample_ce_bwd(gl.to(device), logits.to(device), labels.to(device), (H, W), 255))
+
+
+def test_upsample_ce_autograd_through_network_tail(device):
+    from networks.ema_net.network import _UpsampleCrossEntropy
+    gen = torch.Generator().manual_seed(3)
+    logits = torch.randn(2, 3, 32, 32, generator=gen)
+    labels = torch.randint(0, 3, (2, 256, 256), generator=gen)
+    xr = logits.clone().requires_grad_(True)
+    _ref_loss(xr, labels, (256, 256), 255).mean().backward()
+    xd = logits.to(device).requires_grad_(True)
+    _UpsampleCrossEntropy.apply(xd, labels.to(device), (256, 256), 255).mean().backward()
+    assert torch.allclose(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-9)
+
+
+def test_fused_sgd_matches_torch_sgd(device):
+    from training.fused_sgd import FusedSGD
+    gen = torch.Generator().manual_seed(5)
+    shapes = [(64, 3, 3, 3), (70000,), (128,), (3, 256, 1, 1), (1,), (200000,)]
+    ref_p = [torch.randn(*s, generator=gen).requires_grad_(True) for s in shapes]
+    dev_p = [p.detach().clone().to(device).requires_grad_(True) for p in ref_p]
+    groups = lambda ps: [{"params": ps[:2], "lr": 0.009, "weight_decay": 1e-4},
+                         {"params": ps[2:4], "lr": 0.009, "weight_decay": 0},
+                         {"params": ps[4:], "lr": 0.018, "weight_decay": 0.0}]
+    ref_opt = torch.optim.SGD(groups(ref_p), momentum=0.9)
+    dev_opt = FusedSGD(groups(dev_p), momentum=0.9)
+    for step in range(4):
+        for pr, pd in zip(ref_p, dev_p):
+            g = torch.randn(pr.shape, generator=gen)
+            pr.grad = g.clone()
+            if pd.grad is None:
+                pd.grad = g.to(device)
+            else:
+                pd.grad.copy_(g)
+        if step == 2:
+            for opt in (ref_opt, dev_opt):
+                for gr in opt.param_groups:
+                    gr["lr"] *= 0.5
+        ref_opt.step()
+        dev_opt.step()
+        for pr, pd in zip(ref_p, dev_p):
+            assert torch.allclose(pd.detach().cpu(), pr.detach(), rtol=1e-6, atol=1e-7), step
+    sd = dev_opt.state_dict()
+    assert all("momentum_buffer" in s for s in sd["state"].values())
+    # a parameter without gradient is skipped, like torch.optim.SGD
+    extra = torch.zeros(5, device=device, requires_grad=True)
+    opt = FusedSGD([extra, dev_p[0]], lr=0.1, momentum=0.9)
+    opt.step()
+    assert torch.equal(extra.detach().cpu(), torch.zeros(5))
+
+
+def test_ema_update(device):
+    import sis_hip
+    gen = torch.Generator().manual_seed(9)
+    mu = torch.randn(1, 512, 64, generator=gen)
+    mub = torch.randn(6, 512, 64, generator=gen)
+    ref = mu.clone()
+    ref *= 0.9
+    ref += mub.mean(dim=0, keepdim=True) * (1 - 0.9)
+    d = mu.to(device)
+    sis_hip.ema_update(d, mub.to(device), 0.9)
+    assert torch.allclose(d.cpu(), ref, rtol=1e-6, atol=1e-7)
