@@ -31,7 +31,10 @@ def make_ema_net(ema, ema_utils):
     net.load_state_dict(E.seeded_state_dict(50, 3, seed=7), strict=True)
     net.fc1[1].p = 0.0
     net.train()
-    lr, wd, mom, em_mom = 0.009, 1e-4, 0.9, 0.9  # configs/segmenter/stylegan2_ema_net_segmenter.yaml:17-26
+    # wd / momenta of configs/segmenter/stylegan2_ema_net_segmenter.yaml:17-26; lr 2e-5 instead of 0.009: on this
+    # randomly initialised net the first-step stem gradients are ~1000x the weights, so at lr 0.009 the second
+    # iteration is chaotic (1e-7 perturbations change its loss by tens of percent) and pins nothing
+    lr, wd, mom, em_mom = 2e-5, 1e-4, 0.9, 0.9
     opt = torch.optim.SGD([
         {"params": ema_utils.get_params(net, key="1x"), "lr": lr, "weight_decay": wd},
         {"params": ema_utils.get_params(net, key="1y"), "lr": lr, "weight_decay": 0},
@@ -73,6 +76,9 @@ def make_ema_net(ema, ema_utils):
     out["after_names"] = np.array(list(sd.keys()))
     out["after_abs_sums"] = np.array([v.double().abs().sum().item() for v in sd.values()])
     out["after_emau_mu_slice"] = sd["emau.mu"][0, ::32, ::8].numpy()
+    init = E.seeded_state_dict(50, 3, seed=7)
+    for k in ("fc2.weight", "fc2.bias", "fc1.0.bn.weight"):  # two-step parameter deltas
+        out["delta_" + k] = (sd[k] - init[k]).numpy()
     out["after_bn_running_var_fc0"] = sd["fc0.bn.running_var"].numpy()
     np.savez_compressed(os.path.join(HERE, "ema_net_step.npz"), **out)
 

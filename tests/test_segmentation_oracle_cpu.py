@@ -24,7 +24,7 @@ def test_ema_net_train_step_vs_golden(golden_dir):
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     sd = E.seeded_state_dict(n_layers, classes, seed=wseed)
     bufs = {}
-    total, loss, mu, grads = E.train_step(sd, bufs, E.seeded_batch(batch, size, classes, seed=bseed))
+    total, loss, mu, grads = E.train_step(sd, bufs, E.seeded_batch(batch, size, classes, seed=bseed), lr=2e-5)
     np.testing.assert_allclose(loss.numpy(), g["loss"], rtol=2e-5)
     np.testing.assert_allclose(total.numpy(), g["loss_mean_0"], rtol=2e-5)
     np.testing.assert_allclose(mu[:, ::32, ::8].numpy(), g["mu_slice"], rtol=1e-4, atol=1e-6)
@@ -34,15 +34,16 @@ def test_ema_net_train_step_vs_golden(golden_dir):
         else:
             np.testing.assert_allclose(grads[str(name)].double().norm().item(), ref, rtol=2e-3, err_msg=str(name))
     np.testing.assert_allclose(grads["fc2.weight"].numpy(), g["grad_fc2_weight"], rtol=1e-3, atol=1e-6)
-    total1, _, _, _ = E.train_step(sd, bufs, E.seeded_batch(batch, size, classes, seed=bseed + 1))
+    total1, _, _, _ = E.train_step(sd, bufs, E.seeded_batch(batch, size, classes, seed=bseed + 1), lr=2e-5)
     np.testing.assert_allclose(total1.numpy(), g["loss_mean_1"], rtol=1e-4)
-    # After the first update the state agrees with the reference to ~1e-7; the second forward/backward of this
-    # randomly initialised 50-layer net (BN over a batch of 2, hard EM assignments) amplifies that to a few
-    # percent in early-layer gradients, so the two-step state is held to a looser bound.
     for name, ref in zip(g["after_names"], g["after_abs_sums"]):
-        np.testing.assert_allclose(sd[str(name)].double().abs().sum().item(), ref, rtol=3e-3, err_msg=str(name))
-    np.testing.assert_allclose(sd["emau.mu"][0, ::32, ::8].numpy(), g["after_emau_mu_slice"], rtol=1e-3, atol=1e-5)
-    np.testing.assert_allclose(sd["fc0.bn.running_var"].numpy(), g["after_bn_running_var_fc0"], rtol=1e-3)
+        np.testing.assert_allclose(sd[str(name)].double().abs().sum().item(), ref, rtol=1e-5, err_msg=str(name))
+    np.testing.assert_allclose(sd["emau.mu"][0, ::32, ::8].numpy(), g["after_emau_mu_slice"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["fc0.bn.running_var"].numpy(), g["after_bn_running_var_fc0"], rtol=1e-4)
+    init = E.seeded_state_dict(n_layers, classes, seed=wseed)
+    for k in ("fc2.weight", "fc2.bias", "fc1.0.bn.weight"):
+        ref = g["delta_" + k]
+        np.testing.assert_allclose((sd[k] - init[k]).numpy(), ref, rtol=1e-2, atol=1e-3 * np.abs(ref).max(), err_msg=k)
 
 
 def test_ema_net_label_maps_vs_golden(golden_dir):
