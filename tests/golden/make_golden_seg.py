@@ -83,11 +83,58 @@ def make_ema_net(ema, ema_utils):
     np.savez_compressed(os.path.join(HERE, "ema_net_step.npz"), **out)
 
 
+def make_trans_u_net(vit, tu_utils):
+    from oracle import trans_u_net_ref as T
+    cfg = vit.VIT_CONFIGS["R50-ViT-B_16"]
+    cfg.n_classes, cfg.n_skip = 3, 3
+    cfg.patches.grid = (14, 14)
+    cfg.transformer.dropout_rate = 0.0  # stochastic layers off (embedding / MLP dropout 0.1 in the shipped config)
+    net = vit.VisionTransformer(cfg, img_size=224, num_classes=3)
+    schema = T.state_dict_schema(224, 3)
+    assert [k for k, _ in schema] == list(net.state_dict().keys())
+    for (k, s), v in zip(schema, net.state_dict().values()):
+        assert tuple(s) == tuple(v.shape), k
+    net.load_state_dict(T.seeded_state_dict(224, 3, seed=17), strict=True)
+    net.train()
+    # lr / momentum / weight decay of configs/segmenter/stylegan2_trans_u_net_segmenter.yaml:17-19 except lr
+    # (1e-4 instead of 0.01 for the same conditioning reason as the EMANet fixture)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-4, momentum=0.9, weight_decay=1e-4)
+    ce_loss, dice = torch.nn.CrossEntropyLoss(), tu_utils.DiceLoss(3)
+    out = {"cfg": np.array([224, 3, 17, 18, 2])}
+    for it in range(2):
+        batch = E.seeded_batch(2, 224, 3, seed=18 + it)
+        opt.zero_grad()
+        pred = net(batch["images"])
+        gt = torch.squeeze(batch["segmented"], dim=1)
+        loss_ce = ce_loss(pred, gt.long())
+        loss_dice = dice(pred, gt, softmax=True)
+        loss = 0.5 * loss_ce + 0.5 * loss_dice
+        loss.backward()
+        if it == 0:
+            out["losses"] = np.array([loss.item(), loss_ce.item(), loss_dice.item()])
+            out["logits_slice"] = pred.detach()[:, :, ::8, ::8].numpy()
+            out["labels"] = pred.detach().argmax(1).numpy().astype(np.uint8)
+            top2 = pred.detach().topk(2, dim=1).values
+            out["margin"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float16)
+            out["grad_names"] = np.array([n for n, _ in net.named_parameters()])
+            out["grad_norms"] = np.array([p.grad.double().norm().item() for _, p in net.named_parameters()])
+            out["grad_head"] = net.segmentation_head[0].weight.grad.numpy()
+        opt.step()
+        out[f"loss_{it}"] = np.array(loss.item())
+    sd = net.state_dict()
+    init = T.seeded_state_dict(224, 3, seed=17)
+    for k in ("segmentation_head.0.weight", "segmentation_head.0.bias", "decoder.blocks.3.conv2.1.weight",
+              "transformer.encoder.encoder_norm.weight"):
+        out["delta_" + k] = (sd[k] - init[k]).numpy()
+    np.savez_compressed(os.path.join(HERE, "trans_u_net_step.npz"), **out)
+
+
 if __name__ == "__main__":
     assert load_reference.reference_available()
     ema, vit, tu_utils, ema_utils = load_reference.load_reference_segmenters()
     torch.set_num_threads(8)
     make_ema_net(ema, ema_utils)
+    make_trans_u_net(vit, tu_utils)
     for f in sorted(os.listdir(HERE)):
         if f.endswith("_step.npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

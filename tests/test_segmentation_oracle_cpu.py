@@ -58,3 +58,36 @@ def test_ema_net_label_maps_vs_golden(golden_dir):
     decided = margin > 1e-3  # argmax must be bit-exact wherever the reference's top-2 margin is not a rounding tie
     assert (labels[:, 0][decided] == g["pred_labels"][:, 0][decided]).all()
     assert decided.mean() > 0.98
+
+
+def test_trans_u_net_schema_counts():
+    from oracle import trans_u_net_ref as T
+    schema = T.state_dict_schema(224, 3)
+    assert len(schema) == 409
+    n_params = sum(int(np.prod(s)) for n, s in schema if "running_" not in n and not n.endswith("tracked"))
+    assert n_params == 105276211  # R50-ViT-B_16 @224, 3 classes (105.9 M at 512^2 incl. larger pos-emb)
+
+
+def test_trans_u_net_train_step_vs_golden(golden_dir):
+    from oracle import trans_u_net_ref as T
+    g = np.load(os.path.join(golden_dir, "trans_u_net_step.npz"))
+    size, classes, wseed, bseed, batch = g["cfg"].tolist()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    sd = T.seeded_state_dict(size, classes, seed=wseed)
+    init = {k: v.clone() for k, v in sd.items()}
+    bufs = {}
+    loss, ce, dice, grads, logits = T.train_step(sd, bufs, E.seeded_batch(batch, size, classes, seed=bseed), lr=1e-4)
+    np.testing.assert_allclose([loss.item(), ce.item(), dice.item()], g["losses"], rtol=2e-5)
+    np.testing.assert_allclose(logits[:, :, ::8, ::8].numpy(), g["logits_slice"], rtol=1e-3, atol=1e-4)
+    decided = g["margin"].astype(np.float32) > 1e-3
+    assert (logits.argmax(1).numpy().astype(np.uint8)[decided] == g["labels"][decided]).all() and decided.mean() > 0.98
+    for name, ref in zip(g["grad_names"], g["grad_norms"]):
+        np.testing.assert_allclose(grads[str(name)].double().norm().item(), ref, rtol=2e-3, atol=1e-9, err_msg=str(name))
+    np.testing.assert_allclose(grads["segmentation_head.0.weight"].numpy(), g["grad_head"], rtol=1e-3,
+                               atol=1e-4 * np.abs(g["grad_head"]).max())
+    loss1, *_ = T.train_step(sd, bufs, E.seeded_batch(batch, size, classes, seed=bseed + 1), lr=1e-4)
+    np.testing.assert_allclose(loss1.item(), g["loss_1"], rtol=1e-3)
+    for k in ("segmentation_head.0.weight", "segmentation_head.0.bias", "decoder.blocks.3.conv2.1.weight",
+              "transformer.encoder.encoder_norm.weight"):
+        ref = g["delta_" + k]
+        np.testing.assert_allclose((sd[k] - init[k]).numpy(), ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max(), err_msg=k)
