@@ -73,6 +73,20 @@ int sis_equal_linear(float* out, const float* x, int64_t x_row_stride, const flo
                      const float* bias, int batch, int in_dim, int out_dim, float scale,
                      float lr_mul, int activation, void* stream);
 
+/* Every modulation EqualLinear of one Generator.forward in ONE launch (20 layers at 256^2; model.py:240 per
+ * layer): out_base[row.out_offset + b*out_dim + o] = scale * <latent[b, row.latent_index, :], w[o, :]> + bias[o].
+ * latent is [B, n_latent, dim]; table is a device array of n_layers rows of 8 int64:
+ * {weight ptr, bias ptr, out offset (floats), latent index, out_dim, first_block, 0, 0}, first_block = running
+ * sum of ceil(out_dim / 4); total_blocks = the final sum. */
+int sis_modulation_batch(float* out_base, const float* latent, const int64_t* table, int n_layers,
+                         int total_blocks, int batch, int n_latent, int dim, float scale, void* stream);
+
+/* Every demodulation-coefficient row of one forward in ONE launch (see sis_modconv_demod); table rows of 8
+ * int64: {wsq ptr, float bits of the conv scale, s offset, dscale offset, cout, first_block, cin, demodulate},
+ * first_block = running sum of ceil(batch * cout / 4). */
+int sis_demod_batch(float* dscale_base, const float* s_base, const int64_t* table, int n_layers,
+                    int total_blocks, int batch, void* stream);
+
 /* Truncation trick, model.py:502-510: out = mean + psi * (w - mean); mean is [dim]. */
 int sis_truncate(float* out, const float* w, const float* mean, float psi, int batch, int dim,
                  void* stream);
@@ -106,18 +120,21 @@ int sis_modconv2d(float* out, const float* x, const float* wpk, const float* s,
 
 /* Modulated transposed convolution, stride 2, no padding, ks = 3: model.py:251-261 up to (not
  * including) the Blur: t[b,co,p,q] = dscale[b,co] * sum_{ci, 2h+kh=p, 2w+kw=q} wpk[ci][kh*3+kw][co]
- * * s[b,ci] * x[b,ci,h,w];  t is [B, Cout, 2H+1, 2W+1]. */
+ * * s[b,ci] * x[b,ci,h,w];  t is [B, Cout, 2H+1, t_row_stride] with the first 2W+1 floats of every row
+ * meaningful (t_row_stride 0 = dense 2W+1; an even stride lets the kernel store output phase pairs as 8 bytes). */
 int sis_modconv2d_up(float* t, const float* x, const float* wpk, const float* s,
                      const float* dscale, int batch, int cin, int cout, int h, int w,
-                     void* workspace, int64_t workspace_bytes, void* stream);
+                     int t_row_stride, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Blur (upfirdn2d up=1 down=1, model.py:89-92 / :262) fused with NoiseInjection + FusedLeakyReLU
  * (model.py:338-340): in [B,C,IH,IW] -> out [B,C,OH,OW], OH = IH + pad0 + pad1 - kh + 1.
- * fuse_act == 0 gives the plain blur. taps [kh,kw] float32 device pointer. */
+ * fuse_act == 0 gives the plain blur. taps [kh,kw] float32 device pointer.  in_row_stride (floats, 0 = in_w)
+ * lets the input rows be padded; sis_modconv2d_up writes rows of 2W+4 floats so that the 4x4 / pad-1 case
+ * streams aligned 16-byte rows. */
 int sis_blur_noise_act(float* out, const float* in, const float* taps, const float* noise,
                        int64_t noise_batch_stride, const float* noise_weight, const float* bias,
-                       int batch, int channels, int in_h, int in_w, int kh, int kw, int pad0,
-                       int pad1, int fuse_act, void* stream);
+                       int batch, int channels, int in_h, int in_w, int in_row_stride, int kh, int kw,
+                       int pad0, int pad1, int fuse_act, void* stream);
 
 /* ToRGB, model.py:355-364: out[b,c,y,x] = scale * sum_ci w[c,ci]*s[b,ci]*x[b,ci,y,x] + bias[c]
  * + upfirdn2d(skip, taps, up=2, pad=(pad0,pad1))[b,c,y,x]   (skip == NULL: first ToRGB).

@@ -73,6 +73,83 @@ __global__ __launch_bounds__(256) void equal_linear_kernel(float* __restrict__ o
     }
 }
 
+// All modulation EqualLinears (20 at 256^2) + all demodulation coefficient rows (13) of one forward in two
+// launches.  table rows (8 x int64): {weight ptr, bias ptr, out offset (floats), latent index, out_dim,
+// first_block, aux ptr, aux int}.
+struct BatchHdr { int n_layers, batch, dim, n_latent; float scale; };
+
+__global__ __launch_bounds__(256) void modulation_batch_kernel(float* __restrict__ out_base,
+                                                               const float* __restrict__ latent,
+                                                               const int64_t* __restrict__ table, BatchHdr h) {
+    int layer = 0;
+    for (int l = 1; l < h.n_layers; ++l)
+        if ((int)blockIdx.x >= (int)table[l * 8 + 5]) layer = l;
+    const int64_t* row = table + layer * 8;
+    const float* w = reinterpret_cast<const float*>(row[0]);
+    const float* bias = reinterpret_cast<const float*>(row[1]);
+    float* out = out_base + row[2];
+    const int lat = (int)row[3], out_dim = (int)row[4];
+    const int o = ((int)blockIdx.x - (int)row[5]) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (o >= out_dim) return;
+    float wr[ELW];
+#pragma unroll
+    for (int j = 0; j < ELW; ++j) {
+        const int i = lane + 64 * j;
+        wr[j] = (i < h.dim) ? w[(int64_t)o * h.dim + i] : 0.f;
+    }
+    const float b = bias ? bias[o] : 0.f;
+    const int r0 = blockIdx.y * EL_ROWS;
+    float acc[EL_ROWS];
+#pragma unroll
+    for (int rr = 0; rr < EL_ROWS; ++rr) {
+        acc[rr] = 0.f;
+        const int r = r0 + rr;
+        if (r < h.batch) {
+            const float* xr = latent + ((int64_t)r * h.n_latent + lat) * h.dim;
+#pragma unroll
+            for (int j = 0; j < ELW; ++j) {
+                const int i = lane + 64 * j;
+                if (i < h.dim) acc[rr] += xr[i] * wr[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < EL_ROWS; ++rr) acc[rr] = wave_sum(acc[rr]);
+    if (lane == 0) {
+#pragma unroll
+        for (int rr = 0; rr < EL_ROWS; ++rr)
+            if (r0 + rr < h.batch) out[(int64_t)(r0 + rr) * out_dim + o] = acc[rr] * h.scale + b;
+    }
+}
+
+// table rows (8 x int64): {wsq ptr, unused, s offset, dscale offset, cout, first_block (units of 4 (b,co) pairs), cin, demodulate};
+// conv scale = 1/sqrt(cin * taps) is passed as a float bit pattern in row[1].
+__global__ __launch_bounds__(256) void demod_batch_kernel(float* __restrict__ dscale_base,
+                                                          const float* __restrict__ s_base,
+                                                          const int64_t* __restrict__ table, int n_layers, int batch) {
+    int layer = 0;
+    for (int l = 1; l < n_layers; ++l)
+        if ((int)blockIdx.x >= (int)table[l * 8 + 5]) layer = l;
+    const int64_t* row = table + layer * 8;
+    const float* wsq = reinterpret_cast<const float*>(row[0]);
+    const float scale = __int_as_float((int)row[1]);
+    const float* s = s_base + row[2];
+    float* dscale = dscale_base + row[3];
+    const int cout = (int)row[4], cin = (int)row[6], demodulate = (int)row[7];
+    const int64_t idx = ((int64_t)blockIdx.x - row[5]) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (idx >= (int64_t)batch * cout) return;
+    const int b = (int)(idx / cout), co = (int)(idx % cout);
+    if (!demodulate) { if (lane == 0) dscale[idx] = scale; return; }
+    const float* sr = s + (int64_t)b * cin;
+    const float* wr = wsq + (int64_t)co * cin;
+    float acc = 0.f;
+    for (int i = lane; i < cin; i += 64) { const float sv = sr[i] * scale; acc += sv * sv * wr[i]; }
+    acc = wave_sum(acc);
+    if (lane == 0) dscale[idx] = scale * rsqrtf(acc + 1e-8f);
+}
+
 __global__ __launch_bounds__(256) void truncate_kernel(float* __restrict__ out, const float* __restrict__ w,
                                                        const float* __restrict__ mean, float psi, int64_t n, int dim) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -160,7 +237,7 @@ __global__ __launch_bounds__(256) void to_rgb_kernel(float* __restrict__ out, co
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[c][v] = 0.f;
     const float* xb = x + (int64_t)b * p.cin * hw + pix;
-#pragma unroll 4
+#pragma unroll 8
     for (int ci = 0; ci < p.cin; ++ci) {
         float xv[4];
         if (VEC == 4) {
@@ -214,6 +291,29 @@ extern "C" int sis_equal_linear(float* out, const float* x, int64_t x_row_stride
     hipLaunchKernelGGL(equal_linear_kernel, dim3(sis_cdiv(out_dim, 4), sis_cdiv(batch, EL_ROWS)), dim3(256), 0, (hipStream_t)stream, out, x,
                        x_row_stride, w, bias, batch, in_dim, out_dim, scale, lr_mul, activation);
     SIS_CHECK_LAUNCH("sis_equal_linear");
+    return 0;
+}
+
+extern "C" int sis_modulation_batch(float* out_base, const float* latent, const int64_t* table, int n_layers,
+                                    int total_blocks, int batch, int n_latent, int dim, float scale, void* stream) {
+    if (n_layers <= 0 || batch <= 0) return 0;
+    SIS_REQUIRE(out_base && latent && table, "sis_modulation_batch: null pointer");
+    SIS_REQUIRE(dim > 0 && dim <= 64 * ELW, "sis_modulation_batch: style dim %d outside 1..%d", dim, 64 * ELW);
+    BatchHdr h;
+    h.n_layers = n_layers; h.batch = batch; h.dim = dim; h.n_latent = n_latent; h.scale = scale;
+    hipLaunchKernelGGL(modulation_batch_kernel, dim3(total_blocks, sis_cdiv(batch, EL_ROWS)), dim3(256), 0,
+                       (hipStream_t)stream, out_base, latent, table, h);
+    SIS_CHECK_LAUNCH("sis_modulation_batch");
+    return 0;
+}
+
+extern "C" int sis_demod_batch(float* dscale_base, const float* s_base, const int64_t* table, int n_layers,
+                               int total_blocks, int batch, void* stream) {
+    if (n_layers <= 0 || batch <= 0) return 0;
+    SIS_REQUIRE(dscale_base && s_base && table, "sis_demod_batch: null pointer");
+    hipLaunchKernelGGL(demod_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, dscale_base, s_base,
+                       table, n_layers, batch);
+    SIS_CHECK_LAUNCH("sis_demod_batch");
     return 0;
 }
 

@@ -26,6 +26,7 @@ struct ConvParams {
     float* slab;               // split-K partial sums [ksplit][B][Cout][OH][OW] or nullptr
     int64_t noise_bstride;
     int B, Cin, Cout, H, W, OH, OW;
+    int ORS;                   // output row stride in floats (>= OW)
     int fuse;
     int npos_tiles, ncls;
     int cout_vec4;

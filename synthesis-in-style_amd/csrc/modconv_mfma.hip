@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_kernel(const ConvParams p
         const int n = pp >> (thl + twl), rem = pp & ((1 << (thl + twl)) - 1);
         const int b = b0 + n, h = h0 + (rem >> twl), w = w0 + (rem & (tw - 1));
         if (n < tc.nb && b < p.B && h < tc.h1 && w < tc.w1) {
-            const int OHW = p.OH * p.OW;
+            const int OHW = p.OH * p.ORS;
             float* ob = p.out + (int64_t)b * p.Cout * OHW;
             const float* db = p.dscale + (int64_t)b * p.Cout;
 #pragma unroll
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_kernel(const ConvParams p
 #pragma unroll
                         for (int ph = 0; ph < 4; ++ph) {
                             const int oy = 2 * h + (ph >> 1), ox = 2 * w + (ph & 1);
-                            if (oy < p.OH && ox < p.OW) oc[oy * p.OW + ox] = acc[m][ph][j] * d;
+                            if (oy < p.OH && ox < p.OW) oc[oy * p.ORS + ox] = acc[m][ph][j] * d;
                         }
                     }
                 }
@@ -303,7 +303,7 @@ extern "C" int sis_modconv2d(float* out, const float* x, const float* wpk, const
     init_params(p);
     p.x = x; p.wpk = wpk; p.s = s; p.dscale = dscale; p.noise = noise; p.noise_w = noise_weight; p.bias = bias;
     p.out = out; p.noise_bstride = noise_batch_stride;
-    p.B = batch; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w; p.OH = h; p.OW = w; p.fuse = fuse_act != 0;
+    p.B = batch; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w; p.OH = h; p.OW = w; p.ORS = w; p.fuse = fuse_act != 0;
     p.kchunk = cin;
     p.cout_vec4 = (cout % 4 == 0) && (((uintptr_t)wpk & 15) == 0);
     mc_add_class(p, 256, ksize - 1, batch, 0, h, 0, w, 32, 16);
@@ -315,16 +315,18 @@ extern "C" int sis_modconv2d(float* out, const float* x, const float* wpk, const
 }
 
 extern "C" int sis_modconv2d_up(float* t, const float* x, const float* wpk, const float* s, const float* dscale,
-                                int batch, int cin, int cout, int h, int w, void* workspace, int64_t workspace_bytes,
-                                void* stream) {
+                                int batch, int cin, int cout, int h, int w, int t_row_stride, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
     if (batch == 0) return 0;
     const int oh = 2 * h + 1, ow = 2 * w + 1;
-    if (check_common("sis_modconv2d_up", t, x, wpk, s, dscale, batch, cin, cout, h, w, oh, ow)) return 1;
+    if (t_row_stride <= 0) t_row_stride = ow;
+    SIS_REQUIRE(t_row_stride >= ow, "sis_modconv2d_up: row stride %d smaller than 2W+1 = %d", t_row_stride, ow);
+    if (check_common("sis_modconv2d_up", t, x, wpk, s, dscale, batch, cin, cout, h, w, oh, t_row_stride)) return 1;
     ConvParams p;
     init_params(p);
     p.x = x; p.wpk = wpk; p.s = s; p.dscale = dscale; p.noise = nullptr; p.noise_w = nullptr; p.bias = nullptr;
     p.out = t; p.noise_bstride = 0;
-    p.B = batch; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w; p.OH = oh; p.OW = ow; p.fuse = 0;
+    p.B = batch; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w; p.OH = oh; p.OW = ow; p.ORS = t_row_stride; p.fuse = 0;
     p.kchunk = cin;
     p.cout_vec4 = (cout % 4 == 0) && (((uintptr_t)wpk & 15) == 0);
     int mblk, npos;

@@ -253,9 +253,10 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
         const int n = pp >> (thl + twl), rem = pp & ((1 << (thl + twl)) - 1);
         const int b = b0 + n, h = h0 + (rem >> twl), w = w0 + (rem & (tw - 1));
         if (n < tc.nb && b < p.B && h < tc.h1 && w < tc.w1) {
-            const int OHW = p.OH * p.OW;
+            const int OHW = p.OH * p.ORS;
             float* ob = (partial ? p.slab + (int64_t)blockIdx.y * p.B * p.Cout * OHW : p.out) + (int64_t)b * p.Cout * OHW;
             const float* db = p.dscale + (int64_t)b * p.Cout;
+            const bool pair = (p.ORS & 1) == 0 && 2 * w + 1 < p.OW;  // both column phases valid, 8-byte aligned
 #pragma unroll
             for (int m = 0; m < C::MT; ++m)
 #pragma unroll
@@ -265,9 +266,16 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
                         const float d = partial ? 1.f : db[co];
                         float* oc = ob + (int64_t)co * OHW;
 #pragma unroll
-                        for (int ph = 0; ph < 4; ++ph) {
-                            const int oy = 2 * h + (ph >> 1), ox = 2 * w + (ph & 1);
-                            if (oy < p.OH && ox < p.OW) oc[oy * p.OW + ox] = acc[m][ph][j] * d;
+                        for (int a = 0; a < 2; ++a) {
+                            const int oy = 2 * h + a;
+                            if (oy >= p.OH) continue;
+                            float* orow = oc + (int64_t)oy * p.ORS + 2 * w;
+                            if (pair) {
+                                *reinterpret_cast<float2*>(orow) = make_float2(acc[m][2 * a][j] * d, acc[m][2 * a + 1][j] * d);
+                            } else {
+                                orow[0] = acc[m][2 * a][j] * d;
+                                if (2 * w + 1 < p.OW) orow[1] = acc[m][2 * a + 1][j] * d;
+                            }
                         }
                     }
                 }
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
 // Adds the K slices in slice order and applies demodulation (+ noise, bias, leaky-ReLU when fused).
 __global__ __launch_bounds__(256) void modconv_splitk_finish(const ConvParams p, int64_t plane_elems, int64_t total) {
     const int64_t stride = (int64_t)gridDim.x * 256;
-    const int64_t ohw = (int64_t)p.OH * p.OW;
+    const int64_t ohw = (int64_t)p.OH * p.ORS;
     float nw = 0.f;
     if (p.fuse && p.noise) nw = p.noise_w[0];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
@@ -316,7 +324,7 @@ int launch_v2(ConvParams& p, hipStream_t st) {
     hipLaunchKernelGGL((modconv_v2_kernel<MODE, KS, C>), dim3((unsigned)bx, p.ksplit), dim3(C::THREADS), lds, st, p, xt_max);
     SIS_CHECK_LAUNCH("modconv_v2_kernel");
     if (p.ksplit > 1) {
-        const int64_t total = (int64_t)p.B * p.Cout * p.OH * p.OW;
+        const int64_t total = (int64_t)p.B * p.Cout * p.OH * p.ORS;
         const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
         hipLaunchKernelGGL(modconv_splitk_finish, dim3(blocks), dim3(256), 0, st, p, total, total);
         SIS_CHECK_LAUNCH("modconv_splitk_finish");
@@ -335,7 +343,7 @@ static void plan_splitk(ConvParams& p, int mblk, int cc, int64_t workspace_bytes
     int want = (int)((512 + blocks - 1) / blocks);
     const int max_split = p.Cin / (2 * cc);
     if (want > max_split) want = max_split;
-    const int64_t out_bytes = (int64_t)p.B * p.Cout * p.OH * p.OW * 4;
+    const int64_t out_bytes = (int64_t)p.B * p.Cout * p.OH * p.ORS * 4;
     if ((int64_t)want * out_bytes > workspace_bytes) want = (int)(workspace_bytes / out_bytes);
     if (want < 2) return;
     int kchunk = sis_cdiv(sis_cdiv(p.Cin, want), cc) * cc;

@@ -141,6 +141,127 @@ __global__ __launch_bounds__(256) void blur_tile_kernel(float* __restrict__ out,
     }
 }
 
+// Row-streaming blur for the generator's hot shape: 4x4 taps, up = down = 1, output width a multiple of 4,
+// input rows 16-byte aligned (row stride % 4 == 0; the transposed conv writes its (2H+1) x (2W+1) result
+// into rows padded to 2W+4 floats for exactly this).  One lane = 4 consecutive output columns x 8 rows:
+// per input row ONE aligned float4 load, the 3 halo values come from the neighbouring lanes by shuffle
+// (explicit loads only at row / wave edges), per output row one float4 store.  No LDS, no index division
+// in the loop.
+struct BlurRowParams {
+    int planes, channels, in_h, in_w, in_rs, out_h, out_w, pad_x0, pad_y0;
+    int cols4, row_groups;
+    int64_t noise_bstride, total;
+    float slope, ascale;
+};
+constexpr int BR_ROWS = 8;
+
+template <bool FUSE>
+__global__ __launch_bounds__(256) void blur_rows_kernel(float* __restrict__ out, const float* __restrict__ in,
+                                                        const float* __restrict__ taps, const float* __restrict__ noise,
+                                                        const float* __restrict__ noise_w, const float* __restrict__ bias,
+                                                        BlurRowParams p) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool active = g < p.total;
+    const int64_t gg = active ? g : p.total - 1;
+    const int xi = (int)(gg % p.cols4);
+    const int64_t r1 = gg / p.cols4;
+    const int rg = (int)(r1 % p.row_groups);
+    const int plane = (int)(r1 / p.row_groups);
+    const int lane = threadIdx.x & 63;
+    float k[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) k[a][b] = taps[(3 - a) * 4 + (3 - b)];  // flipped taps
+    const float* src = in + (int64_t)plane * p.in_h * p.in_rs;
+    const int x0 = 4 * xi - p.pad_x0;  // first input column of this lane's window (x0 .. x0+6)
+    const int oy0 = rg * BR_ROWS;
+    const bool left_edge = xi == 0, right_edge = xi == p.cols4 - 1;
+    // pad_x0 == 1: own aligned float4 covers window columns 1..4, left neighbour gives column 0, right one 5..6
+    float win[4][7];
+    auto load_row = [&](int iy, float* w) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool row_ok = iy >= 0 && iy < p.in_h;
+        const float* rowp = src + (int64_t)iy * p.in_rs;
+        if (row_ok) a = *reinterpret_cast<const float4*>(rowp + 4 * xi);
+        float l = __shfl_up(a.w, 1, 64);
+        float r0 = __shfl_down(a.x, 1, 64), r1v = __shfl_down(a.y, 1, 64);
+        if (left_edge) l = 0.f;
+        else if (lane == 0) l = row_ok ? rowp[4 * xi - 1] : 0.f;
+        if (right_edge) {
+            r0 = (row_ok && 4 * xi + 4 < p.in_w) ? rowp[4 * xi + 4] : 0.f;
+            r1v = (row_ok && 4 * xi + 5 < p.in_w) ? rowp[4 * xi + 5] : 0.f;
+        } else if (lane == 63) {
+            r0 = row_ok ? rowp[4 * xi + 4] : 0.f;
+            r1v = row_ok ? rowp[4 * xi + 5] : 0.f;
+        }
+        w[0] = l; w[1] = a.x; w[2] = a.y; w[3] = a.z; w[4] = a.w; w[5] = r0; w[6] = r1v;
+    };
+    (void)x0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) load_row(oy0 - p.pad_y0 + t, win[t + 1]);
+    float nw = 0.f, bb = 0.f;
+    const float* nz = nullptr;
+    if (FUSE) {
+        if (noise) { nw = noise_w[0]; nz = noise + (int64_t)(plane / p.channels) * p.noise_bstride; }
+        if (bias) bb = bias[plane % p.channels];
+    }
+    float* dst = out + (int64_t)plane * p.out_h * p.out_w;
+#pragma unroll
+    for (int j = 0; j < BR_ROWS; ++j) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int c = 0; c < 7; ++c) win[t][c] = win[t + 1][c];
+        load_row(oy0 - p.pad_y0 + j + 3, win[3]);
+        float o[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            float v = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) v += win[a][x + b] * k[a][b];
+            o[x] = v;
+        }
+        const int oy = oy0 + j;
+        if (active && oy < p.out_h) {
+            if (FUSE) {
+                float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (nz) n4 = *reinterpret_cast<const float4*>(nz + (int64_t)oy * p.out_w + 4 * xi);
+                const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    float v = o[x] + nw * nn[x] + bb;
+                    o[x] = (v > 0.f ? v : v * p.slope) * p.ascale;
+                }
+            }
+            *reinterpret_cast<float4*>(dst + (int64_t)oy * p.out_w + 4 * xi) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+int launch_blur_rows(float* out, const float* in, const float* taps, const float* noise, int64_t nbs,
+                     const float* noise_w, const float* bias, int planes, int channels, int in_h, int in_w, int in_rs,
+                     int out_h, int out_w, int pad0, bool fuse, hipStream_t st) {
+    BlurRowParams p;
+    p.planes = planes; p.channels = channels; p.in_h = in_h; p.in_w = in_w; p.in_rs = in_rs; p.out_h = out_h;
+    p.out_w = out_w; p.pad_x0 = pad0; p.pad_y0 = pad0;
+    p.cols4 = out_w / 4; p.row_groups = sis_cdiv(out_h, BR_ROWS);
+    p.noise_bstride = nbs; p.slope = 0.2f; p.ascale = 1.4142135623730951f;
+    p.total = (int64_t)planes * p.row_groups * p.cols4;
+    const int64_t blocks = (p.total + 255) / 256;
+    SIS_REQUIRE(blocks > 0 && blocks < ((int64_t)1 << 31), "blur: grid too large");
+    if (fuse)
+        hipLaunchKernelGGL(blur_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, out, in, taps, noise, noise_w,
+                           bias, p);
+    else
+        hipLaunchKernelGGL(blur_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, out, in, taps, noise,
+                           noise_w, bias, p);
+    SIS_CHECK_LAUNCH("blur_rows_kernel");
+    return 0;
+}
+
 template <typename T>
 int launch_direct(void* out, const void* in, const void* taps, const UpdnParams& p, hipStream_t st) {
     const int64_t total = (int64_t)p.major * p.out_h * p.out_w * p.minor;
@@ -212,14 +333,22 @@ extern "C" int sis_upfirdn2d(void* out, const void* in, const void* taps, int dt
 
 extern "C" int sis_blur_noise_act(float* out, const float* in, const float* taps, const float* noise,
                                   int64_t noise_batch_stride, const float* noise_weight, const float* bias, int batch,
-                                  int channels, int in_h, int in_w, int kh, int kw, int pad0, int pad1, int fuse_act,
-                                  void* stream) {
+                                  int channels, int in_h, int in_w, int in_row_stride, int kh, int kw, int pad0, int pad1,
+                                  int fuse_act, void* stream) {
     SIS_REQUIRE(kh >= 1 && kw >= 1 && kh <= BT_K && kw <= BT_K, "sis_blur_noise_act: taps must be at most %dx%d", BT_K, BT_K);
     const int out_h = in_h + pad0 + pad1 - kh + 1, out_w = in_w + pad0 + pad1 - kw + 1;
     SIS_REQUIRE(out_h >= 0 && out_w >= 0, "sis_blur_noise_act: negative output size");
     if ((int64_t)batch * channels * out_h * out_w == 0) return 0;
     SIS_REQUIRE(out && in && taps, "sis_blur_noise_act: null pointer");
     if (noise) SIS_REQUIRE(noise_weight, "sis_blur_noise_act: noise given without noise_weight");
+    if (in_row_stride <= 0) in_row_stride = in_w;
+    SIS_REQUIRE(in_row_stride >= in_w, "sis_blur_noise_act: row stride %d smaller than the row %d", in_row_stride, in_w);
+    const bool aligned = (((uintptr_t)in | (uintptr_t)out | (uintptr_t)noise) & 15) == 0;
+    if (kh == 4 && kw == 4 && pad0 == 1 && in_row_stride % 4 == 0 && out_w % 4 == 0 && out_w >= 8 && aligned &&
+        (!noise || (noise_batch_stride % 4) == 0))
+        return launch_blur_rows(out, in, taps, noise, noise_batch_stride, noise_weight, bias, batch * channels, channels,
+                                in_h, in_w, in_row_stride, out_h, out_w, pad0, fuse_act != 0, (hipStream_t)stream);
+    SIS_REQUIRE(in_row_stride == in_w, "sis_blur_noise_act: padded rows need 4x4 taps, pad0 = 1 and a 4-aligned width");
     return launch_blur_tile(out, in, taps, noise, noise_batch_stride, noise_weight, bias, batch * channels, channels,
                             in_h, in_w, out_h, out_w, kh, kw, pad0, pad0, fuse_act != 0, (hipStream_t)stream);
 }

@@ -29,6 +29,7 @@ Functions.  CPU tensors are rejected with ``RuntimeError`` like the reference's 
 """
 import math
 import random
+import struct
 import typing
 
 import torch
@@ -236,15 +237,22 @@ class StyledConv(nn.Module):
             return act(self.noise(conv(input, style), noise=noise))
         sis_hip.require_device(input, "input")
         wpk, s, dscale = conv.modulate(style)
+        return self.forward_s(input, wpk, s, dscale, noise)
+
+    def forward_s(self, input, wpk, s, dscale, noise=None):
+        """Fused layer given the already computed style vector ``s`` [B,Cin] and epilogue factors [B,Cout]."""
+        conv, act = self.conv, self.activate
         b, _, h, w = input.shape
         if conv.upsample:
-            t = sis_hip.modconv2d_up(input, wpk, s, dscale)
-            pad = conv.blur.pad
-            oh = t.shape[2] + pad[0] + pad[1] - conv.blur.kernel.shape[0] + 1
-            ow = t.shape[3] + pad[0] + pad[1] - conv.blur.kernel.shape[1] + 1
+            taps, pad = conv.blur.kernel, conv.blur.pad
+            padded = tuple(taps.shape) == (4, 4) and pad[0] == 1  # row-streaming blur wants 16-byte aligned rows
+            t = sis_hip.modconv2d_up(input, wpk, s, dscale, padded_rows=padded)
+            in_w = 2 * w + 1
+            oh = t.shape[2] + pad[0] + pad[1] - taps.shape[0] + 1
+            ow = in_w + pad[0] + pad[1] - taps.shape[1] + 1
             if noise is None:
                 noise = input.new_empty(b, 1, oh, ow).normal_()
-            return sis_hip.blur_noise_act(t, conv.blur.kernel, pad, noise, self.noise.weight, act.bias, fuse_act=True)
+            return sis_hip.blur_noise_act(t, taps, pad, noise, self.noise.weight, act.bias, fuse_act=True, in_w=in_w)
         if noise is None:
             noise = input.new_empty(b, 1, h, w).normal_()
         return sis_hip.modconv2d(input, wpk, s, dscale, conv.kernel_size, noise, self.noise.weight, act.bias,
@@ -265,7 +273,10 @@ class ToRGB(nn.Module):
             out = conv(input, style) + self.bias
             return out if skip is None else out + self.upsample(skip)
         sis_hip.require_device(input, "input")
-        s = conv.modulation(style)
+        return self.forward_s(input, conv.modulation(style), skip)
+
+    def forward_s(self, input, s, skip=None):
+        conv = self.conv
         if skip is None:
             return sis_hip.to_rgb(input, conv.weight, s, self.bias, conv.scale)
         up = self.upsample
@@ -322,6 +333,68 @@ class Generator(nn.Module):
     def get_latent(self, input):
         return self.style(input)
 
+    # ---- one-launch modulation / demodulation for the whole forward (MI355X fast path) ----------------
+    def _layer_sequence(self):
+        """(module, latent index) in execution order (model.py:534-552 of the reference)."""
+        seq = [(self.conv1, 0), (self.to_rgb1, 1)]
+        for r in range(self.log_size - 2):
+            i = 1 + 2 * r
+            seq += [(self.convs[2 * r], i), (self.convs[2 * r + 1], i + 1), (self.to_rgbs[r], i + 2)]
+        return seq
+
+    def _modulation_plan(self, batch, device):
+        seq = self._layer_sequence()
+        key = (batch, device) + tuple((m.conv.weight.data_ptr(), m.conv.weight._version, m.conv.modulation.weight.data_ptr(),
+                                       m.conv.modulation.bias.data_ptr()) for m, _ in seq)
+        if getattr(self, '_plan_key', None) == key:
+            return self._plan
+        mod_rows, dem_rows, s_off, d_off, mblocks, dblocks = [], [], 0, 0, 0, 0
+        s_slices, d_slices = [], []
+        for m, lat in seq:
+            conv = m.conv
+            cin, cout = conv.in_channel, conv.out_channel
+            lin = conv.modulation
+            mod_rows.append([lin.weight.data_ptr(), lin.bias.data_ptr(), s_off, lat, cin, mblocks, 0, 0])
+            s_slices.append((s_off, cin))
+            mblocks += (cin + 3) // 4
+            if isinstance(m, StyledConv):
+                _, wsq = conv.packed_weights()
+                bits = struct.unpack('<i', struct.pack('<f', conv.scale))[0]
+                dem_rows.append([wsq.data_ptr(), bits, s_off, d_off, cout, dblocks, cin, int(conv.demodulate)])
+                d_slices.append((d_off, cout))
+                dblocks += (batch * cout + 3) // 4
+                d_off += batch * cout
+            else:
+                d_slices.append(None)
+            s_off += batch * cin
+        self._plan = dict(mod=torch.tensor(mod_rows, dtype=torch.int64).to(device),
+                          dem=torch.tensor(dem_rows, dtype=torch.int64).to(device), n_mod=len(mod_rows),
+                          n_dem=len(dem_rows), mblocks=mblocks, dblocks=dblocks, s_total=s_off, d_total=d_off,
+                          s_slices=s_slices, d_slices=d_slices, lin_scale=seq[0][0].conv.modulation.scale)
+        self._plan_key = key
+        return self._plan
+
+    def _fast_path(self, latent):
+        if _needs_grad(latent) or any(p.requires_grad for p in self.parameters()) and torch.is_grad_enabled():
+            return False
+        if not latent.is_cuda or latent.dtype != torch.float32 or latent.dim() != 3 or latent.shape[-1] > 1024:
+            return False
+        return all(m.conv.hip_supported() and m.conv.modulation.lr_mul == 1 and m.conv.modulation.activation is None
+                   for m, _ in self._layer_sequence())
+
+    def _modulate_all(self, latent):
+        """Every layer's s [B,Cin] (and scale*demod [B,Cout] for the styled convs): two launches in total."""
+        latent = latent.contiguous()
+        b = latent.shape[0]
+        plan = self._modulation_plan(b, latent.device)
+        s_flat = torch.empty(plan['s_total'], dtype=torch.float32, device=latent.device)
+        d_flat = torch.empty(max(plan['d_total'], 1), dtype=torch.float32, device=latent.device)
+        sis_hip.modulation_batch(s_flat, latent, plan['mod'], plan['n_mod'], plan['mblocks'], plan['lin_scale'])
+        sis_hip.demod_batch(d_flat, s_flat, plan['dem'], plan['n_dem'], plan['dblocks'], b)
+        s_list = [s_flat[o:o + b * c].view(b, c) for o, c in plan['s_slices']]
+        d_list = [None if sl is None else d_flat[sl[0]:sl[0] + b * sl[1]].view(b, sl[1]) for sl in plan['d_slices']]
+        return s_list, d_list
+
     def _truncate(self, style, truncation, truncation_latent):
         if _needs_grad(style, truncation_latent) or not style.is_cuda or truncation_latent.numel() != style.shape[-1]:
             return truncation_latent + truncation * (style - truncation_latent)
@@ -354,6 +427,22 @@ class Generator(nn.Module):
 
         out = self.input(latent)
         tap(0, out)
+        if self._fast_path(latent):
+            s, d = self._modulate_all(latent)
+            out = self.conv1.forward_s(out, self.conv1.conv.packed_weights()[0], s[0], d[0], noise[0])
+            tap(1, out)
+            skip = self.to_rgb1.forward_s(out, s[1])
+            for r in range(self.log_size - 2):
+                i, j = 1 + 2 * r, 2 + 3 * r
+                up, conv, rgb = self.convs[2 * r], self.convs[2 * r + 1], self.to_rgbs[r]
+                out = up.forward_s(out, up.conv.packed_weights()[0], s[j], d[j], noise[1 + 2 * r])
+                tap(i + 1, out)
+                out = conv.forward_s(out, conv.conv.packed_weights()[0], s[j + 1], d[j + 1], noise[2 + 2 * r])
+                tap(i + 2, out)
+                skip = rgb.forward_s(out, s[j + 2], skip)
+            if return_latents:
+                return skip, latent
+            return (skip, acts) if return_intermediate_activations else (skip, None)
         out = self.conv1(out, latent[:, 0], noise=noise[0])
         tap(1, out)
         skip = self.to_rgb1(out, latent[:, 1])

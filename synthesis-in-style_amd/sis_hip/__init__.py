@@ -34,11 +34,13 @@ _SIGNATURES = {
     "sis_pixel_norm": ([_vp, _vp, _i, _i, _vp], _i),
     "sis_equal_linear": ([_vp, _vp, _i64, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp], _i),
     "sis_truncate": ([_vp, _vp, _vp, _f, _i, _i, _vp], _i),
+    "sis_modulation_batch": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp], _i),
+    "sis_demod_batch": ([_vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "sis_modconv_prepack": ([_vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "sis_modconv_demod": ([_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp], _i),
     "sis_modconv2d": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 7 + [_vp, _i64, _vp], _i),
-    "sis_modconv2d_up": ([_vp] * 5 + [_i] * 5 + [_vp, _i64, _vp], _i),
-    "sis_blur_noise_act": ([_vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 9 + [_vp], _i),
+    "sis_modconv2d_up": ([_vp] * 5 + [_i] * 6 + [_vp, _i64, _vp], _i),
+    "sis_blur_noise_act": ([_vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 10 + [_vp], _i),
     "sis_to_rgb": ([_vp] * 7 + [_i] * 9 + [_f, _vp], _i),
     "sis_upsample_ce_workspace": ([_i] * 3, _i),
     "sis_upsample_ce_fwd": ([_vp] * 4 + [_i] * 6 + [_i64, _vp], _i),
@@ -208,6 +210,20 @@ def equal_linear(x, weight, bias, scale, lr_mul, activation, row_stride=None, ba
     return out
 
 
+def modulation_batch(out_flat, latent, table, n_layers, total_blocks, scale):
+    """latent [B, n_latent, dim] -> every layer's style vector, written into ``out_flat`` at the table's offsets."""
+    b, n_latent, dim = latent.shape
+    with torch.cuda.device(latent.device):
+        _check(lib().sis_modulation_batch(_ptr(out_flat), _ptr(latent), _ptr(table), n_layers, total_blocks, b, n_latent,
+                                          dim, float(scale), _stream()), "sis_modulation_batch")
+
+
+def demod_batch(dscale_flat, s_flat, table, n_layers, total_blocks, batch):
+    with torch.cuda.device(s_flat.device):
+        _check(lib().sis_demod_batch(_ptr(dscale_flat), _ptr(s_flat), _ptr(table), n_layers, total_blocks, batch,
+                                     _stream()), "sis_demod_batch")
+
+
 def truncate(w, mean, psi):
     w = _f32(w, "style")
     mean = _f32(mean, "truncation_latent").reshape(-1)
@@ -284,34 +300,39 @@ def modconv2d(x, wpk, s, dscale, ksize, noise=None, noise_weight=None, bias=None
     return out
 
 
-def modconv2d_up(x, wpk, s, dscale):
+def modconv2d_up(x, wpk, s, dscale, padded_rows=False):
+    """Transposed stride-2 modulated conv -> [B, Cout, 2H+1, 2W+1].  ``padded_rows=True`` returns the buffer with
+    rows padded to 2W+4 floats ([..., 2H+1, 2W+4], first 2W+1 columns meaningful) for sis_blur_noise_act."""
     x = _f32(x, "input")
     batch, cin, h, w = x.shape
     cout = wpk.shape[2]
-    out = torch.empty((batch, cout, 2 * h + 1, 2 * w + 1), dtype=torch.float32, device=x.device)
+    row = 2 * w + 4 if padded_rows else 2 * w + 1
+    out = torch.empty((batch, cout, 2 * h + 1, row), dtype=torch.float32, device=x.device)
     ws = _workspace(x.device)
     with torch.cuda.device(x.device):
         _check(_launch("modconv_v2_kernel<1, 3>", 2.0 * batch * cout * cin * 9 * h * w,
                        4.0 * (x.numel() + out.numel() + wpk.numel()),
                        lambda: lib().sis_modconv2d_up(_ptr(out), _ptr(x), _ptr(wpk), _ptr(s), _ptr(dscale), batch, cin,
-                                                      cout, h, w, _ptr(ws), ws.numel(), _stream())),
+                                                      cout, h, w, row, _ptr(ws), ws.numel(), _stream())),
                "sis_modconv2d_up")
     return out
 
 
-def blur_noise_act(x, taps, pad, noise=None, noise_weight=None, bias=None, fuse_act=False):
+def blur_noise_act(x, taps, pad, noise=None, noise_weight=None, bias=None, fuse_act=False, in_w=None):
+    """``in_w``: meaningful width when the rows of ``x`` are padded (x.shape[3] is then the row stride)."""
     x = _f32(x, "input")
     taps = _f32(taps, "kernel")
-    batch, ch, ih, iw = x.shape
+    batch, ch, ih, row_stride = x.shape
+    iw = row_stride if in_w is None else in_w
     kh, kw = taps.shape
     oh, ow = ih + pad[0] + pad[1] - kh + 1, iw + pad[0] + pad[1] - kw + 1
     noise, nbs = _noise_args(noise, batch, oh, ow)
     out = torch.empty((batch, ch, oh, ow), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(_launch("blur_tile_kernel", 0.0, 4.0 * (x.numel() + out.numel()),
+        _check(_launch("blur_rows_kernel", 0.0, 4.0 * (batch * ch * ih * iw + out.numel()),
                        lambda: lib().sis_blur_noise_act(_ptr(out), _ptr(x), _ptr(taps), _ptr(noise), nbs,
-                                                        _ptr(noise_weight), _ptr(bias), batch, ch, ih, iw, kh, kw,
-                                                        pad[0], pad[1], int(bool(fuse_act)), _stream())),
+                                                        _ptr(noise_weight), _ptr(bias), batch, ch, ih, iw, row_stride,
+                                                        kh, kw, pad[0], pad[1], int(bool(fuse_act)), _stream())),
                "sis_blur_noise_act")
     return out
 

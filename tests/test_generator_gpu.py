@@ -84,6 +84,14 @@ def test_modconv_up_vs_oracle(device, b, cin, cout, h, w):
         assert _rel(y, ref) < 2e-5
         ya = sis_hip.blur_noise_act(t, d(taps), (1, 1), d(noise), d(nw), d(bias), fuse_act=True)
         assert _rel(ya, ref_act) < 2e-5
+        # padded-row layout (rows of 2W+4 floats): 8-byte phase-pair stores + the row-streaming blur
+        tp = sis_hip.modconv2d_up(d(x), wpk, s, ds, padded_rows=True)
+        assert tuple(tp.shape) == (b, cout, 2 * h + 1, 2 * w + 4)
+        assert torch.equal(tp[..., :2 * w + 1], t)
+        yp = sis_hip.blur_noise_act(tp, d(taps), (1, 1), d(noise), d(nw), d(bias), fuse_act=True, in_w=2 * w + 1)
+        assert _rel(yp, ref_act) < 2e-5
+        yp0 = sis_hip.blur_noise_act(tp, d(taps), (1, 1), in_w=2 * w + 1)
+        assert _rel(yp0, ref) < 2e-5
 
 
 @pytest.mark.parametrize("b,cin,h", [(2, 32, 4), (3, 64, 8), (2, 128, 32), (1, 16, 6)])
