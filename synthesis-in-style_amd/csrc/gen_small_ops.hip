@@ -215,60 +215,82 @@ __device__ __forceinline__ float skip_up2(const float* __restrict__ sp, const fl
     return v;
 }
 
+// One workgroup = one sample x one group of 64*VEC pixels; its 4 waves each take every 4th input channel
+// (4x the loads in flight: the low-resolution layers have only B x 1 pixel groups and were latency-bound with
+// one wave walking all 512 channels), partial sums meet in LDS, wave 0 adds bias + upsampled skip and stores.
 template <int VEC>
 __global__ __launch_bounds__(256) void to_rgb_kernel(float* __restrict__ out, const float* __restrict__ x,
                                                      const float* __restrict__ w, const float* __restrict__ s,
                                                      const float* __restrict__ bias, const float* __restrict__ skip,
                                                      const float* __restrict__ taps, RgbParams p) {
-    extern __shared__ __attribute__((aligned(16))) float weff[];  // [cout][cin]: scale * w[c,ci] * s[b,ci]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* weff = smem;                       // [cout][cin]: scale * w[c,ci] * s[b,ci]
+    float* part = smem + p.cout * p.cin;      // [3 waves][RGB_MAXC][VEC][64]
     const int hw = p.h * p.w;
-    const int groups = (hw + 256 * VEC - 1) / (256 * VEC);
+    const int groups = (hw + 64 * VEC - 1) / (64 * VEC);
     const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int e = threadIdx.x; e < p.cout * p.cin; e += 256) {
         const int ci = e % p.cin;
         weff[e] = p.scale * w[e] * s[(int64_t)b * p.cin + ci];
     }
     __syncthreads();
-    const int pix = (g * 256 + threadIdx.x) * VEC;
-    if (pix >= hw) return;
+    const int pix = (g * 64 + lane) * VEC;
+    const bool live = pix < hw;
     float acc[RGB_MAXC][VEC];
 #pragma unroll
     for (int c = 0; c < RGB_MAXC; ++c)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[c][v] = 0.f;
-    const float* xb = x + (int64_t)b * p.cin * hw + pix;
+    if (live) {
+        const float* xb = x + (int64_t)b * p.cin * hw + pix;
 #pragma unroll 8
-    for (int ci = 0; ci < p.cin; ++ci) {
-        float xv[4];
-        if (VEC == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(xb + (int64_t)ci * hw);
-            xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
-        } else {
-            xv[0] = xb[(int64_t)ci * hw];
-        }
+        for (int ci = wave; ci < p.cin; ci += 4) {
+            float xv[4];
+            if (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(xb + (int64_t)ci * hw);
+                xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+            } else {
+                xv[0] = xb[(int64_t)ci * hw];
+            }
 #pragma unroll
-        for (int c = 0; c < RGB_MAXC; ++c) {
-            if (c < p.cout) {
-                const float wv = weff[c * p.cin + ci];
+            for (int c = 0; c < RGB_MAXC; ++c) {
+                if (c < p.cout) {
+                    const float wv = weff[c * p.cin + ci];
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) acc[c][v] += wv * xv[v];
+                    for (int v = 0; v < VEC; ++v) acc[c][v] += wv * xv[v];
+                }
             }
         }
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int c = 0; c < RGB_MAXC; ++c)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) part[(((wave - 1) * RGB_MAXC + c) * VEC + v) * 64 + lane] = acc[c][v];
+    }
+    __syncthreads();
+    if (wave != 0 || !live) return;
 #pragma unroll
     for (int c = 0; c < RGB_MAXC; ++c) {
         if (c >= p.cout) continue;
         const float bb = bias ? bias[c] : 0.f;
         float* o = out + ((int64_t)b * p.cout + c) * hw + pix;
+        float r[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            float r = acc[c][v] + bb;
+            float a = acc[c][v];
+#pragma unroll
+            for (int ww = 0; ww < 3; ++ww) a += part[((ww * RGB_MAXC + c) * VEC + v) * 64 + lane];
+            a += bb;
             if (skip) {
                 const int y = (pix + v) / p.w, xx = (pix + v) % p.w;
-                r += skip_up2(skip + ((int64_t)b * p.cout + c) * p.sh * p.sw, taps, p, y, xx);
+                a += skip_up2(skip + ((int64_t)b * p.cout + c) * p.sh * p.sw, taps, p, y, xx);
             }
-            o[v] = r;
+            r[v] = a;
         }
+        if (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
+        else o[0] = r[0];
     }
 }
 
@@ -367,14 +389,15 @@ extern "C" int sis_to_rgb(float* out, const float* x, const float* w, const floa
                     "sis_to_rgb: upsampled skip would not match the %dx%d output", h, wd);
     }
     const int hw = h * wd;
-    const size_t lds = (size_t)cin * cout * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (hw % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
-        const int groups = sis_cdiv(hw, 1024);
-        hipLaunchKernelGGL(to_rgb_kernel<4>, dim3(batch * groups), dim3(256), lds, st, out, x, w, s, bias, skip, taps, p);
+    if (hw % 4 == 0 && hw >= 256 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+        const size_t lds = ((size_t)cin * cout + 3 * RGB_MAXC * 4 * 64) * sizeof(float);
+        hipLaunchKernelGGL(to_rgb_kernel<4>, dim3(batch * sis_cdiv(hw, 256)), dim3(256), lds, st, out, x, w, s, bias, skip,
+                           taps, p);
     } else {
-        const int groups = sis_cdiv(hw, 256);
-        hipLaunchKernelGGL(to_rgb_kernel<1>, dim3(batch * groups), dim3(256), lds, st, out, x, w, s, bias, skip, taps, p);
+        const size_t lds = ((size_t)cin * cout + 3 * RGB_MAXC * 64) * sizeof(float);
+        hipLaunchKernelGGL(to_rgb_kernel<1>, dim3(batch * sis_cdiv(hw, 64)), dim3(256), lds, st, out, x, w, s, bias, skip,
+                           taps, p);
     }
     SIS_CHECK_LAUNCH("sis_to_rgb");
     return 0;
