@@ -176,6 +176,20 @@ int sis_sgd_momentum(const int64_t* table, int n_chunks, const float* lr, const 
 int sis_ema_update(float* mu, const float* mu_batch, float momentum, float one_minus_momentum,
                    int batch, int numel, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Dataset-loop neighbours of Generator.forward (SURVEY.md §8f "next" rows 1 and 2).
+ */
+
+/* Nearest k-means centre per pixel: labels[b,p] = argmin_k sum_c (x[b,c,p] - centres[k,c])^2, ties to the lowest
+ * k (segmentation/gan_local_edit/factor_catalog.py:47-62 + :69-75: FactorCatalog.predict on [B,C,H,W]).
+ * x [B,C,HW] float32, centres [K,C] float32 (K <= 64), labels int64 [B,HW]. */
+int sis_kmeans_assign(int64_t* labels, const float* x, const float* centres, int batch, int channels,
+                      int hw, int n_centres, void* stream);
+
+/* float32 NCHW image in [-1,1] -> uint8 NHWC: clamp, (x+1)/2*255, truncating cast (the third-party make_image
+ * called at create_dataset_for_segmentation.py:135; its rounding is not pinned by the reference). */
+int sis_make_image_u8(uint8_t* out, const float* x, int batch, int channels, int hw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

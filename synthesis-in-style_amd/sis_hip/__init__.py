@@ -48,6 +48,8 @@ _SIGNATURES = {
     "sis_sgd_chunk_elems": ([], _i),
     "sis_sgd_momentum": ([_vp, _i, ctypes.POINTER(_f), ctypes.POINTER(_f), _i, _f, _i, _vp], _i),
     "sis_ema_update": ([_vp, _vp, _f, _f, _i, _i, _vp], _i),
+    "sis_kmeans_assign": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "sis_make_image_u8": ([_vp, _vp, _i, _i, _i, _vp], _i),
 }
 
 
@@ -414,3 +416,31 @@ def ema_update(mu, mu_batch, momentum):
         _check(lib().sis_ema_update(_ptr(mu), _ptr(mb), float(momentum), float(1 - momentum), mb.numel() // n, n,
                                     _stream()), "sis_ema_update")
     return mu
+
+
+# ------------------------------------------------------------------------------ dataset-loop neighbours
+
+
+def kmeans_assign(x, centres):
+    """[B,C,H,W] activations, [K,C] centres -> int64 [B,H,W] nearest-centre ids (FactorCatalog.predict)."""
+    x = _f32(x, "input")
+    c = _f32(centres, "cluster_centers")
+    b, ch, h, w = x.shape
+    if c.shape[1] != ch:
+        raise RuntimeError(f"centres have {c.shape[1]} channels, activations {ch}")
+    labels = torch.empty((b, h, w), dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(_launch("kmeans_assign_kernel", 3.0 * b * ch * h * w * c.shape[0], 4.0 * x.numel() + 8.0 * labels.numel(),
+                       lambda: lib().sis_kmeans_assign(_ptr(labels), _ptr(x), _ptr(c), b, ch, h * w, c.shape[0],
+                                                       _stream())), "sis_kmeans_assign")
+    return labels
+
+
+def make_image_u8(x):
+    """[B,C,H,W] float32 in [-1,1] -> uint8 [B,H,W,C] on the device."""
+    x = _f32(x, "image")
+    b, ch, h, w = x.shape
+    out = torch.empty((b, h, w, ch), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_make_image_u8(_ptr(out), _ptr(x), b, ch, h * w, _stream()), "sis_make_image_u8")
+    return out

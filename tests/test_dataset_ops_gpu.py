@@ -1,0 +1,67 @@
+"""GPU parity, part 6 ("next" rows): nearest-centre label maps and the uint8 image conversion.
+
+Label maps are integer outputs: they must be bit-exact wherever the best and second-best squared distances of the
+fp64 oracle differ by more than fp32 rounding of the sums (the kernel accumulates channels in order, torch's
+reduction is pairwise -- both are fp32 sums of the same terms)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kmeans_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("b,c,h,w,k", [(2, 128, 64, 64, 20), (1, 512, 16, 16, 7), (3, 32, 5, 7, 40), (2, 64, 32, 32, 16),
+                                       (1, 16, 8, 8, 1)])
+def test_kmeans_assign_matches_reference_rule(device, b, c, h, w, k):
+    from segmentation.gan_local_edit.factor_catalog import FactorCatalog
+    gen = torch.Generator().manual_seed(c + k)
+    x = torch.randn(b, c, h, w, generator=gen)
+    centres = torch.randn(k, c, generator=gen)
+    ref32, _ = kmeans_ref.predict(x, centres)
+    ref64, d64 = kmeans_ref.predict(x.double(), centres.double())
+    cat = FactorCatalog(k, cluster_centers=centres)
+    got = cat.predict(x.to(device)).cpu()
+    assert got.dtype == torch.int64 and tuple(got.shape) == (b, h, w)
+    if k > 1:
+        top2 = d64.topk(2, dim=-1, largest=False).values
+        decided = (top2[..., 1] - top2[..., 0]) > 1e-4 * top2[..., 0]
+    else:
+        decided = torch.ones(b, h, w, dtype=torch.bool)
+    assert torch.equal(got[decided], ref64[decided])
+    assert decided.float().mean() > 0.99
+    assert (got == ref32).float().mean() > 0.999
+    flat = x.permute(0, 2, 3, 1).reshape(-1, c)
+    assert torch.equal(cat.pairwise_distance(flat.to(device)).cpu()[decided.reshape(-1)], ref64.reshape(-1)[decided.reshape(-1)])
+
+
+def test_kmeans_ties_go_to_lowest_index(device):
+    import sis_hip
+    x = torch.zeros(1, 4, 2, 2, device=device)
+    centres = torch.tensor([[1., 0, 0, 0], [0, 1., 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]], device=device)
+    assert torch.equal(sis_hip.kmeans_assign(x, centres).cpu(), torch.full((1, 2, 2), 2))
+
+
+def test_kmeans_on_generator_activations_256(device):
+    """Layer keys "12"/"13" of the shipped dataset config are [B,128,256,256]."""
+    import sis_hip
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 128, 256, 256, generator=gen)
+    centres = torch.randn(20, 128, generator=gen)
+    got = sis_hip.kmeans_assign(x.to(device), centres.to(device)).cpu()
+    ref, d = kmeans_ref.predict(x[:1, :, :64], centres)
+    assert (got[:1, :64] == ref).float().mean() > 0.999
+
+
+def test_make_image_u8(device):
+    import sis_hip
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(3, 3, 32, 40, generator=gen) * 0.8
+    x[0, 0, 0, 0], x[0, 1, 0, 0], x[0, 2, 0, 0] = -1.0, 1.0, 0.0
+    got = sis_hip.make_image_u8(x.to(device)).cpu()
+    ref = kmeans_ref.make_image(x)
+    assert got.dtype == torch.uint8 and tuple(got.shape) == (3, 32, 40, 3)
+    assert (got.int() - ref.int()).abs().max().item() <= 1  # (x+1)/2*255 may round across an integer boundary
+    assert (got == ref).float().mean() > 0.999
+    assert got[0, 0, 0].tolist() == [0, 255, 127]
