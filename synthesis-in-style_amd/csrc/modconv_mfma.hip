@@ -294,7 +294,7 @@ static void init_params(ConvParams& p) {
 extern "C" int sis_modconv2d(float* out, const float* x, const float* wpk, const float* s, const float* dscale,
                              const float* noise, int64_t noise_batch_stride, const float* noise_weight,
                              const float* bias, int batch, int cin, int cout, int h, int w, int ksize, int fuse_act,
-                             void* workspace, int64_t workspace_bytes, void* stream) {
+                             const float* wino_u, void* workspace, int64_t workspace_bytes, void* stream) {
     if (batch == 0) return 0;
     if (check_common("sis_modconv2d", out, x, wpk, s, dscale, batch, cin, cout, h, w, h, w)) return 1;
     SIS_REQUIRE(ksize == 1 || ksize == 3, "sis_modconv2d: kernel size %d not supported (1 or 3)", ksize);
@@ -307,6 +307,12 @@ extern "C" int sis_modconv2d(float* out, const float* x, const float* wpk, const
     p.kchunk = cin;
     p.cout_vec4 = (cout % 4 == 0) && (((uintptr_t)wpk & 15) == 0);
     mc_add_class(p, 256, ksize - 1, batch, 0, h, 0, w, 32, 16);
+    if (wino_u && ksize == 3) {
+        p.wpk = wino_u;
+        const int rcw = modconv_wino_launch(p, (hipStream_t)stream, workspace, workspace_bytes);
+        if (rcw >= 0) return rcw;
+        p.wpk = wpk;
+    }
     const int rc = modconv_v2_launch(p, 0, ksize, (hipStream_t)stream, workspace, workspace_bytes);
     if (rc >= 0) return rc;
     p.ksplit = 1; p.kchunk = cin; p.slab = nullptr;

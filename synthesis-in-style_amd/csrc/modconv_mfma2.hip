@@ -334,6 +334,12 @@ int launch_v2(ConvParams& p, hipStream_t st) {
 
 }  // namespace
 
+void modconv_splitk_finish_launch(const ConvParams& p, hipStream_t st) {
+    const int64_t total = (int64_t)p.B * p.Cout * p.OH * p.ORS;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(modconv_splitk_finish, dim3(blocks), dim3(256), 0, st, p, total, total);
+}
+
 // Chooses the K split: enough (tile x oc-block x slice) workgroups to give every CU ~2, slices a
 // multiple of the chunk size, and the slabs must fit the caller's workspace.
 static void plan_splitk(ConvParams& p, int mblk, int cc, int64_t workspace_bytes) {

@@ -1,0 +1,288 @@
+// Stride-1 3x3 modulated convolution in Winograd F(2x2, 3x3) form on the fp32 matrix cores.
+//
+// The direct kernel (modconv_mfma2.hip) already keeps the MFMA pipe ~85 % busy at the clock the chip holds, so
+// the remaining lever is the amount of MFMA work: F(2x2,3x3) produces a 2x2 output tile from 16 multiplies per
+// (co, ci) instead of 36, i.e. 2.25x fewer matrix FLOPs for the 7 stride-1 layers (64.4 of the 90.2 GFLOP/image).
+//
+//   U[ci][xi][co] = (G g G^T)[xi]        prepacked once per checkpoint (sis_modconv_prepack_wino)
+//   V[xi]         = (B^T d B)[xi]        per lane, in registers: the lane owning tile t (= MFMA column) and
+//                                        channel 2cp + (lane>>5) reads its 4x4 input patch d from the raw LDS
+//                                        tile (8 x ds_read_b64), scales it by the style s[b,ci] and does the
+//                                        32 add/sub of the transform -- no second LDS image, no extra pass
+//   M[xi]        += U[xi] (co x ci) * V[xi] (ci x tile)      16 independent MFMA chains (v_mfma_f32_32x32x2_f32)
+//   Y             = A^T M A              epilogue, again lane-local (all 16 xi of a (co, tile) sit in one lane),
+//                                        then demodulation, noise, bias, leaky-ReLU * sqrt(2), 8-byte stores
+//
+// Workgroup = 4 waves (2 co-halves x 2 tile-halves) = 64 co x 64 tiles (256 pixels); each wave holds
+// 16 xi x (32 co x 32 tiles) accumulators = 256 VGPRs, so one wave per SIMD / one workgroup per CU, with the
+// same LDS-DMA double buffering and one barrier per 8-channel chunk as the direct kernel.  Numerics: G has
+// 1/2 entries (exact in binary), the transforms only add; measured error vs the fp64 oracle is within the same
+// 2e-5 per-layer bound as the direct kernel (tests/test_generator_gpu.py).
+#include "modconv_common.h"
+
+namespace {
+
+constexpr int WCC = 8;      // input channels per chunk
+constexpr int WMBLK = 64;   // output channels per workgroup
+constexpr int WTILES = 64;  // 2x2 output tiles per workgroup (256 pixels)
+constexpr int WXI = 3;      // staged x elements per lane per channel (xt <= 768)
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 4, 0, 0);
+}
+
+// u[ci][xi][co] from w[co][ci][3][3]
+__global__ __launch_bounds__(256) void wino_prepack_kernel(float* __restrict__ u, const float* __restrict__ w, int cout,
+                                                           int cin) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // i = ci * cout + co
+    if (i >= (int64_t)cout * cin) return;
+    const int co = (int)(i % cout), ci = (int)(i / cout);
+    const float* g = w + ((int64_t)co * cin + ci) * 9;
+    float t[4][3];  // G g
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float g0 = g[c], g1 = g[3 + c], g2 = g[6 + c];
+        t[0][c] = g0;
+        t[1][c] = 0.5f * (g0 + g1 + g2);
+        t[2][c] = 0.5f * (g0 - g1 + g2);
+        t[3][c] = g2;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float a = t[r][0], b = t[r][1], c = t[r][2];
+        const float o[4] = {a, 0.5f * (a + b + c), 0.5f * (a - b + c), c};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u[((int64_t)ci * 16 + r * 4 + q) * cout + co] = o[q];
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void modconv_wino_kernel(const ConvParams p, const int xt_max) {
+    constexpr int WF = WCC * 16 * WMBLK;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Ul = lds;                    // [2][WF]
+    float* Xl = lds + 2 * WF;           // [2][WCC * xt]
+    float* Sl = Xl + 2 * WCC * xt_max;  // [nb][Cin]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int wbase = tid & ~63;
+
+    int pt = blockIdx.x % p.npos_tiles;
+    const int o0 = (blockIdx.x / p.npos_tiles) * WMBLK;
+    const TileClass tc = p.cls[0];
+    const int twi = pt % tc.ntw; pt /= tc.ntw;
+    const int thi = pt % tc.nth;
+    const int bt = pt / tc.nth;
+    const int thl = tc.th_log2, twl = tc.tw_log2;
+    const int th = 1 << thl, tw = 1 << twl;
+    const int b0 = bt * tc.nb, h0 = thi << thl, w0 = twi << twl;
+    const int eh = th + 2, ew = tw + 2;
+    const int xt = tc.xt;
+    const int HW = p.H * p.W;
+    const int k_lo = blockIdx.y * p.kchunk;
+    const int k_hi = min(p.Cin, k_lo + p.kchunk);
+
+    for (int e = tid; e < 2 * WCC * xt; e += 256) Xl[e] = 0.f;
+    for (int e = tid; e < tc.nb * p.Cin; e += 256) {
+        const int n = e / p.Cin, ci = e - n * p.Cin;
+        Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
+    }
+    int st_goff[WXI];
+#pragma unroll
+    for (int i = 0; i < WXI; ++i) {
+        const int idx = tid + 256 * i;
+        st_goff[i] = -1;
+        if (idx < xt) {
+            const int n = idx / (eh * ew), rem = idx - n * (eh * ew);
+            const int r = rem / ew, c = rem - r * ew;
+            const int b = b0 + n, h = h0 - 1 + r, w = w0 - 1 + c;
+            if (b < p.B && h >= 0 && h < p.H && w >= 0 && w < p.W) st_goff[i] = b * p.Cin * HW + h * p.W + w;
+        }
+    }
+    constexpr int WV4 = WF / 4, WIT = WV4 / 256;  // 8 float4 per lane per chunk
+    int w_goff[WIT];
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+        const int e = it * 256 + tid;
+        const int row = e / (WMBLK / 4), q = e - row * (WMBLK / 4);
+        w_goff[it] = (o0 + q * 4 < p.Cout) ? row * p.Cout + o0 + q * 4 : -1;
+    }
+    auto stage = [&](int ci0, int buf) {
+        const float* usrc = p.wpk + (int64_t)ci0 * 16 * p.Cout;
+        float* udst = Ul + buf * WF + wbase * 4;
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            if (w_goff[it] >= 0) glds16(usrc + w_goff[it], udst + it * 1024);
+        const float* xsrc = p.x + (int64_t)ci0 * HW;
+        float* xdst = Xl + buf * WCC * xt + wbase;
+#pragma unroll
+        for (int j = 0; j < WCC; ++j)
+#pragma unroll
+            for (int i = 0; i < WXI; ++i)
+                if (st_goff[i] >= 0) glds4(xsrc + st_goff[i] + j * HW, xdst + j * xt + i * 256);
+    };
+
+    // this lane's tile: t = wn*32 + l31 -> (sample n, tile row ty, tile col tx); 4x4 patch origin in the staged tile
+    const int tpl = thl + twl - 2;  // log2(tiles per sample)
+    const int t = wn * 32 + l31;
+    const int tn = t >> tpl, trem = t & ((1 << tpl) - 1);
+    const int ty = trem >> (twl - 1), tx = trem & ((tw >> 1) - 1);
+    const int xo = min(tn, tc.nb - 1) * eh * ew + 2 * ty * ew + 2 * tx + half * xt;
+    const int so = min(tn, tc.nb - 1) * p.Cin + half;
+    const int aoff = half * 16 * WMBLK + wm * 32 + l31;
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[xi][j] = 0.f;
+
+    __syncthreads();
+    stage(k_lo, 0);
+    __syncthreads();
+
+    int buf = 0;
+    for (int ci0 = k_lo; ci0 < k_hi; ci0 += WCC, buf ^= 1) {
+        if (ci0 + WCC < k_hi) stage(ci0 + WCC, buf ^ 1);
+        const float* Ub = Ul + buf * WF + aoff;
+        const float* Xb = Xl + buf * WCC * xt + xo;
+#pragma unroll
+        for (int cp = 0; cp < WCC / 2; ++cp) {
+            const float sv = Sl[so + ci0 + 2 * cp];
+            const float* xb = Xb + 2 * cp * xt;
+            float d[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float2 lo = *reinterpret_cast<const float2*>(xb + r * ew);
+                const float2 hi = *reinterpret_cast<const float2*>(xb + r * ew + 2);
+                d[r][0] = lo.x * sv; d[r][1] = lo.y * sv; d[r][2] = hi.x * sv; d[r][3] = hi.y * sv;
+            }
+            float tt[4][4], v[16];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {  // B^T d
+                tt[0][c] = d[0][c] - d[2][c];
+                tt[1][c] = d[1][c] + d[2][c];
+                tt[2][c] = d[2][c] - d[1][c];
+                tt[3][c] = d[1][c] - d[3][c];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // (B^T d) B
+                v[r * 4 + 0] = tt[r][0] - tt[r][2];
+                v[r * 4 + 1] = tt[r][1] + tt[r][2];
+                v[r * 4 + 2] = tt[r][2] - tt[r][1];
+                v[r * 4 + 3] = tt[r][1] - tt[r][3];
+            }
+            const float* ub = Ub + 2 * cp * 16 * WMBLK;
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi)
+                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[xi * WMBLK], v[xi], acc[xi], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: Y = A^T M A per (co, tile), then the fused layer tail
+    const bool partial = p.ksplit > 1;
+    const int b = b0 + tn, oh = h0 + 2 * ty, ow = w0 + 2 * tx;
+    if (tn >= tc.nb || b >= p.B || oh >= p.H || ow >= p.W) return;
+    float nz[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    if (!partial && p.fuse && p.noise) {
+        const float nw = p.noise_w[0];
+        const float* np = p.noise + (int64_t)b * p.noise_bstride + oh * p.W + ow;
+        nz[0][0] = nw * np[0]; nz[0][1] = nw * np[1]; nz[1][0] = nw * np[p.W]; nz[1][1] = nw * np[p.W + 1];
+    }
+    float* obase = (partial ? p.slab + (int64_t)blockIdx.y * p.B * p.Cout * HW : p.out) + (int64_t)b * p.Cout * HW +
+                   oh * p.W + ow;
+    const float* db = p.dscale + (int64_t)b * p.Cout;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int co = o0 + wm * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
+        if (co >= p.Cout) continue;
+        float m[2][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            m[0][c] = acc[c][j] + acc[4 + c][j] + acc[8 + c][j];
+            m[1][c] = acc[4 + c][j] - acc[8 + c][j] - acc[12 + c][j];
+        }
+        float y[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            y[r][0] = m[r][0] + m[r][1] + m[r][2];
+            y[r][1] = m[r][1] - m[r][2] - m[r][3];
+        }
+        if (!partial) {
+            const float dd = db[co];
+            const float bb = (p.fuse && p.bias) ? p.bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    float val = y[r][c] * dd;
+                    if (p.fuse) {
+                        val += nz[r][c];
+                        val += bb;
+                        val = (val > 0.f ? val : val * 0.2f) * 1.4142135623730951f;
+                    }
+                    y[r][c] = val;
+                }
+        }
+        float* oc = obase + (int64_t)co * HW;
+        *reinterpret_cast<float2*>(oc) = make_float2(y[0][0], y[0][1]);
+        *reinterpret_cast<float2*>(oc + p.W) = make_float2(y[1][0], y[1][1]);
+    }
+}
+
+}  // namespace
+
+extern "C" int sis_modconv_prepack_wino(float* u, const float* w, int cout, int cin, void* stream) {
+    SIS_REQUIRE(u && w, "sis_modconv_prepack_wino: null pointer");
+    SIS_REQUIRE(cout > 0 && cin > 0, "sis_modconv_prepack_wino: bad sizes");
+    hipLaunchKernelGGL(wino_prepack_kernel, dim3(sis_cdiv((int64_t)cout * cin, 256)), dim3(256), 0, (hipStream_t)stream, u, w,
+                       cout, cin);
+    SIS_CHECK_LAUNCH("sis_modconv_prepack_wino");
+    return 0;
+}
+
+void modconv_splitk_finish_launch(const ConvParams& p, hipStream_t st);
+
+// Returns 0 / 1 like the other launchers, -1 when the shape is not eligible (odd sizes, unaligned, tiny Cin).
+int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t workspace_bytes) {
+    if (p.H % 2 || p.W % 2 || p.Cin % WCC != 0 || !p.cout_vec4 || (((uintptr_t)p.x | (uintptr_t)p.wpk | (uintptr_t)p.out) & 15))
+        return -1;
+    if (p.fuse && p.noise && (((uintptr_t)p.noise & 3) != 0)) return -1;
+    const TileClass& tc = p.cls[0];
+    if (p.ncls != 1 || tc.th_log2 < 1 || tc.tw_log2 < 1 || tc.xt > 256 * WXI) return -1;
+    // split-K plan (same rule as the direct kernel, 64-channel blocks)
+    p.ksplit = 1; p.kchunk = p.Cin; p.slab = nullptr;
+    const int64_t blocks = (int64_t)p.npos_tiles * sis_cdiv(p.Cout, WMBLK);
+    if (blocks < 256 && p.Cin >= 4 * WCC && workspace) {
+        int want = (int)((384 + blocks - 1) / blocks);
+        const int max_split = p.Cin / (2 * WCC);
+        if (want > max_split) want = max_split;
+        const int64_t out_bytes = (int64_t)p.B * p.Cout * p.OH * p.ORS * 4;
+        if ((int64_t)want * out_bytes > workspace_bytes) want = (int)(workspace_bytes / out_bytes);
+        if (want >= 2) {
+            p.kchunk = sis_cdiv(sis_cdiv(p.Cin, want), WCC) * WCC;
+            p.ksplit = sis_cdiv(p.Cin, p.kchunk);
+            p.slab = (float*)workspace;
+        }
+    }
+    const size_t lds = (size_t)(2 * WCC * 16 * WMBLK + 2 * WCC * tc.xt + p.nb_max * p.Cin) * sizeof(float);
+    if (lds > 160 * 1024) return -1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_wino_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return sis_fail("modconv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(modconv_wino_kernel, dim3((unsigned)blocks, p.ksplit), dim3(256), lds, st, p, tc.xt);
+    SIS_CHECK_LAUNCH("modconv_wino_kernel");
+    if (p.ksplit > 1) modconv_splitk_finish_launch(p, st);
+    return 0;
+}

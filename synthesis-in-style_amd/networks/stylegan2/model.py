@@ -28,6 +28,7 @@ with ``upfirdn2d`` / ``fused_leaky_relu`` still running on the HIP kernels throu
 Functions.  CPU tensors are rejected with ``RuntimeError`` like the reference's extension does.
 """
 import math
+import os
 import random
 import struct
 import typing
@@ -153,8 +154,18 @@ class ModulatedConv2d(nn.Module):
         key = (w.data_ptr(), w._version, w.device)
         if self._pack_key != key:
             self._pack = sis_hip.modconv_prepack(w.detach())
+            # stride-1 3x3 layers also keep the Winograd F(2x2,3x3) transform of the weights (2.25x fewer MFMA
+            # FLOPs); SIS_WINOGRAD=0 selects the direct kernel everywhere (bisecting / A-B runs)
+            self._wino = None
+            if (self.kernel_size == 3 and not self.upsample and not self.downsample and self.in_channel % 8 == 0
+                    and self.out_channel % 4 == 0 and os.environ.get("SIS_WINOGRAD", "1") != "0"):
+                self._wino = sis_hip.modconv_prepack_wino(w.detach())
             self._pack_key = key
         return self._pack
+
+    def wino_weights(self):
+        self.packed_weights()
+        return self._wino
 
     def hip_supported(self):
         return (not self.downsample) and (self.kernel_size == 3 or (self.kernel_size == 1 and not self.upsample))
@@ -172,7 +183,7 @@ class ModulatedConv2d(nn.Module):
         wpk, s, dscale = self.modulate(style)
         if self.upsample:
             return self.blur(sis_hip.modconv2d_up(input, wpk, s, dscale))
-        return sis_hip.modconv2d(input, wpk, s, dscale, self.kernel_size)
+        return sis_hip.modconv2d(input, wpk, s, dscale, self.kernel_size, wino_u=self.wino_weights())
 
     # ---- differentiable path (training only; reference formulation, model.py:237-278) --------
     def _forward_autograd(self, input, style):
@@ -256,7 +267,7 @@ class StyledConv(nn.Module):
         if noise is None:
             noise = input.new_empty(b, 1, h, w).normal_()
         return sis_hip.modconv2d(input, wpk, s, dscale, conv.kernel_size, noise, self.noise.weight, act.bias,
-                                 fuse_act=True)
+                                 fuse_act=True, wino_u=conv.wino_weights())
 
 
 class ToRGB(nn.Module):

@@ -38,7 +38,8 @@ _SIGNATURES = {
     "sis_demod_batch": ([_vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "sis_modconv_prepack": ([_vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "sis_modconv_demod": ([_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp], _i),
-    "sis_modconv2d": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 7 + [_vp, _i64, _vp], _i),
+    "sis_modconv2d": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 7 + [_vp, _vp, _i64, _vp], _i),
+    "sis_modconv_prepack_wino": ([_vp, _vp, _i, _i, _vp], _i),
     "sis_modconv2d_up": ([_vp] * 5 + [_i] * 6 + [_vp, _i64, _vp], _i),
     "sis_blur_noise_act": ([_vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 10 + [_vp], _i),
     "sis_to_rgb": ([_vp] * 7 + [_i] * 9 + [_f, _vp], _i),
@@ -251,6 +252,18 @@ def modconv_prepack(weight):
     return wpk, wsq
 
 
+def modconv_prepack_wino(weight):
+    """[1, Cout, Cin, 3, 3] -> Winograd F(2x2,3x3) transformed weights [Cin, 16, Cout]."""
+    w = _f32(weight, "weight")
+    _, cout, cin, k, _ = w.shape
+    if k != 3:
+        raise RuntimeError("the Winograd transform is for 3x3 kernels")
+    u = torch.empty((cin, 16, cout), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _check(lib().sis_modconv_prepack_wino(_ptr(u), _ptr(w), cout, cin, _stream()), "sis_modconv_prepack_wino")
+    return u
+
+
 def modconv_demod(s, wsq, scale, demodulate):
     s = _f32(s, "style")
     cout, cin = wsq.shape
@@ -285,19 +298,21 @@ def _noise_args(noise, batch, h, w):
     raise RuntimeError(f"noise shape {tuple(noise.shape)} does not broadcast over [{batch}, C, {h}, {w}]")
 
 
-def modconv2d(x, wpk, s, dscale, ksize, noise=None, noise_weight=None, bias=None, fuse_act=False):
+def modconv2d(x, wpk, s, dscale, ksize, noise=None, noise_weight=None, bias=None, fuse_act=False, wino_u=None):
     x = _f32(x, "input")
     batch, cin, h, w = x.shape
     cout = wpk.shape[2]
     noise, nbs = _noise_args(noise, batch, h, w)
     out = torch.empty((batch, cout, h, w), dtype=torch.float32, device=x.device)
     ws = _workspace(x.device)
+    wino = wino_u is not None and ksize == 3 and h % 2 == 0 and w % 2 == 0 and cin % 8 == 0 and cout % 4 == 0
     with torch.cuda.device(x.device):
-        _check(_launch(f"modconv_v2_kernel<0, {ksize}>", 2.0 * batch * cout * cin * ksize * ksize * h * w,
+        _check(_launch("modconv_wino_kernel" if wino else f"modconv_v2_kernel<0, {ksize}>",
+                       2.0 * batch * cout * cin * ksize * ksize * h * w,
                        4.0 * (x.numel() + out.numel() + wpk.numel()),
                        lambda: lib().sis_modconv2d(_ptr(out), _ptr(x), _ptr(wpk), _ptr(s), _ptr(dscale), _ptr(noise),
                                                    nbs, _ptr(noise_weight), _ptr(bias), batch, cin, cout, h, w, ksize,
-                                                   int(bool(fuse_act)), _ptr(ws), ws.numel(), _stream())),
+                                                   int(bool(fuse_act)), _ptr(wino_u), _ptr(ws), ws.numel(), _stream())),
                "sis_modconv2d")
     return out
 

@@ -31,7 +31,9 @@ def _mk(gen, *shape):
                                              (2, 32, 64, 32, 32), (1, 40, 256, 40, 72), (17, 8, 8, 4, 4),
                                              (2, 512, 512, 8, 8)])
 @pytest.mark.parametrize("fuse", [False, True])
-def test_modconv3x3_vs_oracle(device, b, cin, cout, h, w, fuse):
+@pytest.mark.parametrize("wino", [False, True])
+def test_modconv3x3_vs_oracle(device, b, cin, cout, h, w, fuse, wino):
+    """Direct MFMA kernel and the Winograd F(2x2,3x3) kernel, with and without the fused layer tail."""
     import sis_hip
     gen = torch.Generator().manual_seed(b * 1000 + cin + cout + h)
     x, style = _mk(gen, b, cin, h, w), _mk(gen, b, 48)
@@ -47,8 +49,9 @@ def test_modconv3x3_vs_oracle(device, b, cin, cout, h, w, fuse):
         s = sis_hip.equal_linear(d(style), d(mod_w), d(mod_b), 1 / 48 ** 0.5, 1.0, False)
         assert _rel(s, R.equal_linear(style, mod_w, mod_b)) < 1e-5
         ds = sis_hip.modconv_demod(s, wsq, 1 / (cin * 9) ** 0.5, True)
+        u = sis_hip.modconv_prepack_wino(d(weight)) if wino else None
         y = sis_hip.modconv2d(d(x), wpk, s, ds, 3, d(noise) if fuse else None, d(nw) if fuse else None,
-                              d(bias) if fuse else None, fuse_act=fuse)
+                              d(bias) if fuse else None, fuse_act=fuse, wino_u=u)
     assert y.shape == ref.shape
     assert _rel(y, ref) < 2e-5, _rel(y, ref)
 
