@@ -307,11 +307,16 @@ extern "C" int sis_modconv2d(float* out, const float* x, const float* wpk, const
     p.kchunk = cin;
     p.cout_vec4 = (cout % 4 == 0) && (((uintptr_t)wpk & 15) == 0);
     mc_add_class(p, 256, ksize - 1, batch, 0, h, 0, w, 32, 16);
-    if (wino_u && ksize == 3) {
-        p.wpk = wino_u;
-        const int rcw = modconv_wino_launch(p, (hipStream_t)stream, workspace, workspace_bytes);
+    if (wino_u && ksize == 3 && w % 4 == 0 && h % 2 == 0) {
+        // Winograd tiles: 16x16-pixel regions (conflict-free patch reads), rows staged as 16-byte aligned supersets
+        ConvParams pw = p;
+        pw.npos_tiles = 0; pw.ncls = 0; pw.nb_max = 0;
+        mc_add_class(pw, 256, 2, batch, 0, h, 0, w, 16, 16);
+        TileClass& tcw = pw.cls[0];
+        tcw.xt = tcw.nb * ((1 << tcw.th_log2) + 2) * ((1 << tcw.tw_log2) + 8);
+        pw.wpk = wino_u;
+        const int rcw = modconv_wino_launch(pw, (hipStream_t)stream, workspace, workspace_bytes);
         if (rcw >= 0) return rcw;
-        p.wpk = wpk;
     }
     const int rc = modconv_v2_launch(p, 0, ksize, (hipStream_t)stream, workspace, workspace_bytes);
     if (rc >= 0) return rc;

@@ -13,9 +13,10 @@
 //   Y             = A^T M A              epilogue, again lane-local (all 16 xi of a (co, tile) sit in one lane),
 //                                        then demodulation, noise, bias, leaky-ReLU * sqrt(2), 8-byte stores
 //
-// Workgroup = 4 waves (2 co-halves x 2 tile-halves) = 64 co x 64 tiles (256 pixels); each wave holds
-// 16 xi x (32 co x 32 tiles) accumulators = 256 VGPRs, so one wave per SIMD / one workgroup per CU, with the
-// same LDS-DMA double buffering and one barrier per 8-channel chunk as the direct kernel.  Numerics: G has
+// Workgroup = 8 waves = 64 co x 64 tiles (256 pixels), see the kernel's header comment; same LDS-DMA double
+// buffering and one barrier per 8-channel chunk as the direct kernel.  (A first version with 4 waves x 16 xi
+// = 256 accumulator VGPRs, one wave per SIMD, reached only 46 % MFMA efficiency: nothing covered the patch
+// reads and transform adds.)  Numerics: G has
 // 1/2 entries (exact in binary), the transforms only add; measured error vs the fp64 oracle is within the same
 // 2e-5 per-layer bound as the direct kernel (tests/test_generator_gpu.py).
 #include "modconv_common.h"
@@ -25,7 +26,6 @@ namespace {
 constexpr int WCC = 8;      // input channels per chunk
 constexpr int WMBLK = 64;   // output channels per workgroup
 constexpr int WTILES = 64;  // 2x2 output tiles per workgroup (256 pixels)
-constexpr int WXI = 3;      // staged x elements per lane per channel (xt <= 768)
 
 __device__ __forceinline__ void glds16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -61,16 +61,23 @@ __global__ __launch_bounds__(256) void wino_prepack_kernel(float* __restrict__ u
     }
 }
 
-__global__ __launch_bounds__(256, 1) void modconv_wino_kernel(const ConvParams p, const int xt_max) {
+// 8 waves: (co half wm) x (tile half wn) x (xi column pair q).  Wave q owns the Winograd columns j in {2q, 2q+1}
+// of M (xi = 4 i + j), i.e. 8 of the 16 MFMA chains = 128 accumulator VGPRs, so two waves share a SIMD and one
+// wave's patch reads / transform adds run under the other's MFMAs.  A^T M is column-local; only the final
+// "* A" mixes columns, so the q = 1 waves hand 4 partial values per (co, tile) to their q = 0 partner through
+// the (by then idle) weight staging LDS and the q = 0 waves run the layer tail.
+constexpr int WNTHR = 512;
+
+__global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams p, const int xt_max) {
     constexpr int WF = WCC * 16 * WMBLK;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Ul = lds;                    // [2][WF]
+    float* Ul = lds;                    // [2][WF]   (64 KB; reused for the column exchange in the epilogue)
     float* Xl = lds + 2 * WF;           // [2][WCC * xt]
     float* Sl = Xl + 2 * WCC * xt_max;  // [nb][Cin]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int q = __builtin_amdgcn_readfirstlane(wave & 1), wn = (wave >> 1) & 1, wm = wave >> 2;
     const int wbase = tid & ~63;
 
     int pt = blockIdx.x % p.npos_tiles;
@@ -82,66 +89,67 @@ __global__ __launch_bounds__(256, 1) void modconv_wino_kernel(const ConvParams p
     const int thl = tc.th_log2, twl = tc.tw_log2;
     const int th = 1 << thl, tw = 1 << twl;
     const int b0 = bt * tc.nb, h0 = thi << thl, w0 = twi << twl;
-    const int eh = th + 2, ew = tw + 2;
+    // staged input tile: rows h0-1 .. h0+th, columns w0-4 .. w0+tw+3 (16-byte aligned superset of the 1-pixel
+    // halo: W and w0 are multiples of 4, so every aligned float4 is entirely inside or entirely outside the image)
+    const int eh = th + 2, ew = tw + 8;
     const int xt = tc.xt;
     const int HW = p.H * p.W;
     const int k_lo = blockIdx.y * p.kchunk;
     const int k_hi = min(p.Cin, k_lo + p.kchunk);
 
-    for (int e = tid; e < 2 * WCC * xt; e += 256) Xl[e] = 0.f;
-    for (int e = tid; e < tc.nb * p.Cin; e += 256) {
+    for (int e = tid; e < 2 * WCC * xt; e += WNTHR) Xl[e] = 0.f;
+    for (int e = tid; e < tc.nb * p.Cin; e += WNTHR) {
         const int n = e / p.Cin, ci = e - n * p.Cin;
         Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
     }
-    int st_goff[WXI];
-#pragma unroll
-    for (int i = 0; i < WXI; ++i) {
-        const int idx = tid + 256 * i;
-        st_goff[i] = -1;
-        if (idx < xt) {
-            const int n = idx / (eh * ew), rem = idx - n * (eh * ew);
-            const int r = rem / ew, c = rem - r * ew;
-            const int b = b0 + n, h = h0 - 1 + r, w = w0 - 1 + c;
-            if (b < p.B && h >= 0 && h < p.H && w >= 0 && w < p.W) st_goff[i] = b * p.Cin * HW + h * p.W + w;
+    // one float4 chunk of the tile per lane per channel (<= 512 chunks: host-checked)
+    int st_goff = -1;
+    {
+        const int ew4 = ew >> 2;
+        if (tid < (xt >> 2)) {
+            const int n = tid / (eh * ew4), rem = tid - n * (eh * ew4);
+            const int r = rem / ew4, c4 = rem - r * ew4;
+            const int b = b0 + n, h = h0 - 1 + r, w = w0 - 4 + 4 * c4;
+            if (b < p.B && h >= 0 && h < p.H && w >= 0 && w < p.W) st_goff = b * p.Cin * HW + h * p.W + w;
         }
     }
-    constexpr int WV4 = WF / 4, WIT = WV4 / 256;  // 8 float4 per lane per chunk
+    constexpr int WV4 = WF / 4, WIT = WV4 / WNTHR;  // 4 float4 per lane per chunk
     int w_goff[WIT];
 #pragma unroll
     for (int it = 0; it < WIT; ++it) {
-        const int e = it * 256 + tid;
-        const int row = e / (WMBLK / 4), q = e - row * (WMBLK / 4);
-        w_goff[it] = (o0 + q * 4 < p.Cout) ? row * p.Cout + o0 + q * 4 : -1;
+        const int e = it * WNTHR + tid;
+        const int row = e / (WMBLK / 4), qq = e - row * (WMBLK / 4);
+        w_goff[it] = (o0 + qq * 4 < p.Cout) ? row * p.Cout + o0 + qq * 4 : -1;
     }
     auto stage = [&](int ci0, int buf) {
         const float* usrc = p.wpk + (int64_t)ci0 * 16 * p.Cout;
         float* udst = Ul + buf * WF + wbase * 4;
 #pragma unroll
         for (int it = 0; it < WIT; ++it)
-            if (w_goff[it] >= 0) glds16(usrc + w_goff[it], udst + it * 1024);
+            if (w_goff[it] >= 0) glds16(usrc + w_goff[it], udst + it * WNTHR * 4);
         const float* xsrc = p.x + (int64_t)ci0 * HW;
-        float* xdst = Xl + buf * WCC * xt + wbase;
+        float* xdst = Xl + buf * WCC * xt + wbase * 4;
+        if (st_goff >= 0) {
 #pragma unroll
-        for (int j = 0; j < WCC; ++j)
-#pragma unroll
-            for (int i = 0; i < WXI; ++i)
-                if (st_goff[i] >= 0) glds4(xsrc + st_goff[i] + j * HW, xdst + j * xt + i * 256);
+            for (int j = 0; j < WCC; ++j) glds16(xsrc + st_goff + j * HW, xdst + j * xt);
+        }
     };
 
-    // this lane's tile: t = wn*32 + l31 -> (sample n, tile row ty, tile col tx); 4x4 patch origin in the staged tile
     const int tpl = thl + twl - 2;  // log2(tiles per sample)
     const int t = wn * 32 + l31;
     const int tn = t >> tpl, trem = t & ((1 << tpl) - 1);
     const int ty = trem >> (twl - 1), tx = trem & ((tw >> 1) - 1);
-    const int xo = min(tn, tc.nb - 1) * eh * ew + 2 * ty * ew + 2 * tx + half * xt;
+    const int xo = min(tn, tc.nb - 1) * eh * ew + 2 * ty * ew + 2 * tx + 2 + half * xt;  // even: 8-byte aligned reads
     const int so = min(tn, tc.nb - 1) * p.Cin + half;
-    const int aoff = half * 16 * WMBLK + wm * 32 + l31;
+    const int aoff = half * 16 * WMBLK + wm * 32 + l31 + 2 * q * WMBLK;  // + (4 i + jj) * WMBLK
 
-    f32x16 acc[16];
+    f32x16 acc[4][2];  // [row i of M][column jj of this wave's pair]
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[xi][j] = 0.f;
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[i][jj][j] = 0.f;
 
     __syncthreads();
     stage(k_lo, 0);
@@ -158,12 +166,13 @@ __global__ __launch_bounds__(256, 1) void modconv_wino_kernel(const ConvParams p
             const float* xb = Xb + 2 * cp * xt;
             float d[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float2 lo = *reinterpret_cast<const float2*>(xb + r * ew);
-                const float2 hi = *reinterpret_cast<const float2*>(xb + r * ew + 2);
-                d[r][0] = lo.x * sv; d[r][1] = lo.y * sv; d[r][2] = hi.x * sv; d[r][3] = hi.y * sv;
+            for (int r = 0; r < 4; ++r) {  // patch columns sit at odd offsets: three aligned 8-byte reads, middle 4 used
+                const float2 a0 = *reinterpret_cast<const float2*>(xb + r * ew);
+                const float2 a1 = *reinterpret_cast<const float2*>(xb + r * ew + 2);
+                const float2 a2 = *reinterpret_cast<const float2*>(xb + r * ew + 4);
+                d[r][0] = a0.y; d[r][1] = a1.x; d[r][2] = a1.y; d[r][3] = a2.x;
             }
-            float tt[4][4], v[16];
+            float tt[4][4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {  // B^T d
                 tt[0][c] = d[0][c] - d[2][c];
@@ -171,30 +180,59 @@ __global__ __launch_bounds__(256, 1) void modconv_wino_kernel(const ConvParams p
                 tt[2][c] = d[2][c] - d[1][c];
                 tt[3][c] = d[1][c] - d[3][c];
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {  // (B^T d) B
-                v[r * 4 + 0] = tt[r][0] - tt[r][2];
-                v[r * 4 + 1] = tt[r][1] + tt[r][2];
-                v[r * 4 + 2] = tt[r][2] - tt[r][1];
-                v[r * 4 + 3] = tt[r][1] - tt[r][3];
-            }
             const float* ub = Ub + 2 * cp * 16 * WMBLK;
+            float v0[4], v1[4];
+            if (q == 0) {  // wave-uniform: this wave's two columns of (B^T d) B, scaled by the style
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi)
-                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[xi * WMBLK], v[xi], acc[xi], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) { v0[i] = (tt[i][0] - tt[i][2]) * sv; v1[i] = (tt[i][1] + tt[i][2]) * sv; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v0[i] = (tt[i][2] - tt[i][1]) * sv; v1[i] = (tt[i][1] - tt[i][3]) * sv; }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[(4 * i) * WMBLK], v0[i], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[(4 * i + 1) * WMBLK], v1[i], acc[i][1], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
 
-    // ---- epilogue: Y = A^T M A per (co, tile), then the fused layer tail
+    // ---- epilogue.  m[r][jj] = (A^T M)[r][column 2q+jj];  Y[r][0] = m0 + m1 + m2,  Y[r][1] = m1 - m2 - m3.
+    // q = 0 contributes (m0 + m1, m1), q = 1 contributes (m2, -m2 - m3).
+    float part[16][4];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float m[2][2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            m[0][jj] = acc[0][jj][j] + acc[1][jj][j] + acc[2][jj][j];
+            m[1][jj] = acc[1][jj][j] - acc[2][jj][j] - acc[3][jj][j];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            part[j][2 * r] = q == 0 ? m[r][0] + m[r][1] : m[r][0];
+            part[j][2 * r + 1] = q == 0 ? m[r][1] : -m[r][0] - m[r][1];
+        }
+    }
+    float* xch = Ul + (wave >> 1) * (64 * 64);  // [16 j][4][64 lanes] per wave pair
+    if (q == 1) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xch[(j * 4 + e) * 64 + lane] = part[j][e];
+    }
+    __syncthreads();
+    if (q == 1) return;
+
     const bool partial = p.ksplit > 1;
     const int b = b0 + tn, oh = h0 + 2 * ty, ow = w0 + 2 * tx;
     if (tn >= tc.nb || b >= p.B || oh >= p.H || ow >= p.W) return;
-    float nz[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float nz[4] = {0.f, 0.f, 0.f, 0.f};
     if (!partial && p.fuse && p.noise) {
         const float nw = p.noise_w[0];
         const float* np = p.noise + (int64_t)b * p.noise_bstride + oh * p.W + ow;
-        nz[0][0] = nw * np[0]; nz[0][1] = nw * np[1]; nz[1][0] = nw * np[p.W]; nz[1][1] = nw * np[p.W + 1];
+        nz[0] = nw * np[0]; nz[1] = nw * np[1]; nz[2] = nw * np[p.W]; nz[3] = nw * np[p.W + 1];
     }
     float* obase = (partial ? p.slab + (int64_t)blockIdx.y * p.B * p.Cout * HW : p.out) + (int64_t)b * p.Cout * HW +
                    oh * p.W + ow;
@@ -203,37 +241,26 @@ __global__ __launch_bounds__(256, 1) void modconv_wino_kernel(const ConvParams p
     for (int j = 0; j < 16; ++j) {
         const int co = o0 + wm * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
         if (co >= p.Cout) continue;
-        float m[2][4];
+        float y[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            m[0][c] = acc[c][j] + acc[4 + c][j] + acc[8 + c][j];
-            m[1][c] = acc[4 + c][j] - acc[8 + c][j] - acc[12 + c][j];
-        }
-        float y[2][2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            y[r][0] = m[r][0] + m[r][1] + m[r][2];
-            y[r][1] = m[r][1] - m[r][2] - m[r][3];
-        }
+        for (int e = 0; e < 4; ++e) y[e] = part[j][e] + xch[(j * 4 + e) * 64 + lane];
         if (!partial) {
             const float dd = db[co];
             const float bb = (p.fuse && p.bias) ? p.bias[co] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    float val = y[r][c] * dd;
-                    if (p.fuse) {
-                        val += nz[r][c];
-                        val += bb;
-                        val = (val > 0.f ? val : val * 0.2f) * 1.4142135623730951f;
-                    }
-                    y[r][c] = val;
+            for (int e = 0; e < 4; ++e) {
+                float val = y[e] * dd;
+                if (p.fuse) {
+                    val += nz[e];
+                    val += bb;
+                    val = (val > 0.f ? val : val * 0.2f) * 1.4142135623730951f;
                 }
+                y[e] = val;
+            }
         }
         float* oc = obase + (int64_t)co * HW;
-        *reinterpret_cast<float2*>(oc) = make_float2(y[0][0], y[0][1]);
-        *reinterpret_cast<float2*>(oc + p.W) = make_float2(y[1][0], y[1][1]);
+        *reinterpret_cast<float2*>(oc) = make_float2(y[0], y[1]);
+        *reinterpret_cast<float2*>(oc + p.W) = make_float2(y[2], y[3]);
     }
 }
 
@@ -252,11 +279,11 @@ void modconv_splitk_finish_launch(const ConvParams& p, hipStream_t st);
 
 // Returns 0 / 1 like the other launchers, -1 when the shape is not eligible (odd sizes, unaligned, tiny Cin).
 int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t workspace_bytes) {
-    if (p.H % 2 || p.W % 2 || p.Cin % WCC != 0 || !p.cout_vec4 || (((uintptr_t)p.x | (uintptr_t)p.wpk | (uintptr_t)p.out) & 15))
+    if (p.H % 2 || p.W % 4 || p.Cin % WCC != 0 || !p.cout_vec4 || (((uintptr_t)p.x | (uintptr_t)p.wpk | (uintptr_t)p.out) & 15))
         return -1;
     if (p.fuse && p.noise && (((uintptr_t)p.noise & 3) != 0)) return -1;
     const TileClass& tc = p.cls[0];
-    if (p.ncls != 1 || tc.th_log2 < 1 || tc.tw_log2 < 1 || tc.xt > 256 * WXI) return -1;
+    if (p.ncls != 1 || tc.th_log2 < 1 || tc.tw_log2 < 2 || tc.xt > WNTHR * 4) return -1;  // xt: padded-row tile, see mc_add_class ext
     // split-K plan (same rule as the direct kernel, 64-channel blocks)
     p.ksplit = 1; p.kchunk = p.Cin; p.slab = nullptr;
     const int64_t blocks = (int64_t)p.npos_tiles * sis_cdiv(p.Cout, WMBLK);
@@ -281,7 +308,7 @@ int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t 
         if (e != hipSuccess) return sis_fail("modconv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL(modconv_wino_kernel, dim3((unsigned)blocks, p.ksplit), dim3(256), lds, st, p, tc.xt);
+    hipLaunchKernelGGL(modconv_wino_kernel, dim3((unsigned)blocks, p.ksplit), dim3(WNTHR), lds, st, p, tc.xt);
     SIS_CHECK_LAUNCH("modconv_wino_kernel");
     if (p.ksplit > 1) modconv_splitk_finish_launch(p, st);
     return 0;

@@ -11,6 +11,7 @@ import sis_hip  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 only = sys.argv[3] if len(sys.argv) > 3 else ""
+WINO = os.environ.get("SIS_WINOGRAD", "1") != "0"
 dev = torch.device("cuda:0")
 layers = [("conv", 512, 512, 4), ("up", 512, 512, 4), ("conv", 512, 512, 8), ("up", 512, 512, 8),
           ("conv", 512, 512, 16), ("up", 512, 512, 16), ("conv", 512, 512, 32), ("up", 512, 512, 32),
@@ -29,7 +30,8 @@ for kind, cin, cout, h in layers:
     noise = torch.randn(1, 1, oh, oh, device=dev)
     nw = torch.full((1,), 0.1, device=dev)
     bias = torch.zeros(cout, device=dev)
-    f = (lambda: sis_hip.modconv2d(x, wpk, s, ds, 3, noise, nw, bias, fuse_act=True)) if kind == "conv" else \
+    u = sis_hip.modconv_prepack_wino(w) if (WINO and kind == "conv") else None
+    f = (lambda: sis_hip.modconv2d(x, wpk, s, ds, 3, noise, nw, bias, fuse_act=True, wino_u=u)) if kind == "conv" else \
         (lambda: sis_hip.modconv2d_up(x, wpk, s, ds))
     f()
     torch.cuda.synchronize()
