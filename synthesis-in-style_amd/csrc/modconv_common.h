@@ -73,6 +73,17 @@ static inline void mc_add_class(ConvParams& p, int npos, int ext, int batch, int
     p.ncls++;
 }
 
+// Fast paths stage the input tile with 16-byte LDS-DMA: rows become the 16-byte aligned superset of the halo'd
+// tile columns (left pad 4 instead of 1, right edge rounded up to a multiple of 4).  W % 4 == 0 makes every
+// aligned float4 lie entirely inside or entirely outside the image.
+static inline int mc_padded_ew(int tw, int pad_lo, int ext) { return (pad_lo ? 4 : 0) + ((tw + ext - pad_lo + 3) & ~3); }
+static inline void mc_set_padded_xt(ConvParams& p, int pad_lo, int ext) {
+    for (int c = 0; c < p.ncls; ++c) {
+        TileClass& tc = p.cls[c];
+        tc.xt = tc.nb * ((1 << tc.th_log2) + ext) * mc_padded_ew(1 << tc.tw_log2, pad_lo, ext);
+    }
+}
+
 // modconv_mfma2.hip: returns 0 on success, 1 on error, -1 when the shape is not eligible for the fast path.
 int modconv_v2_launch(ConvParams& p, int mode, int ks, hipStream_t st, void* workspace, int64_t workspace_bytes);
 // modconv_wino.hip: Winograd F(2x2,3x3) path for stride-1 3x3 layers (p.wpk must then hold the transformed weights).

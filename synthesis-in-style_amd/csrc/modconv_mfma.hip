@@ -321,6 +321,8 @@ extern "C" int sis_modconv2d(float* out, const float* x, const float* wpk, const
     const int rc = modconv_v2_launch(p, 0, ksize, (hipStream_t)stream, workspace, workspace_bytes);
     if (rc >= 0) return rc;
     p.ksplit = 1; p.kchunk = cin; p.slab = nullptr;
+    p.npos_tiles = 0; p.ncls = 0; p.nb_max = 0;
+    mc_add_class(p, 256, ksize - 1, batch, 0, h, 0, w, 32, 16);  // exact-halo tiles for the register-staged kernel
     if (ksize == 3) return launch<0, 3>(p, (hipStream_t)stream);
     return launch<0, 1>(p, (hipStream_t)stream);
 }

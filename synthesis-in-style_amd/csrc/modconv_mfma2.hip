@@ -4,9 +4,11 @@
 // Same GEMM mapping as modconv_mfma.hip (see its header); what changes is how operands arrive:
 //   * weights   global_load_lds_dwordx4: one wave instruction moves two 512-byte rows
 //               [ci][tap][co0..co0+127] straight into LDS (no VGPRs, no ds_write);
-//   * input     global_load_lds_dword, EXEC-masked: halo / out-of-image positions are never
-//               written, they keep the zeros stored once before the K loop (the set of padded
-//               positions of a tile is the same for every channel chunk);
+//   * input     global_load_lds_dwordx4, EXEC-masked, over the 16-byte aligned superset of the halo'd tile
+//               (W % 4 == 0: every aligned float4 is wholly inside or outside the image); out-of-image
+//               chunks are never written, they keep the zeros stored once before the K loop (the set of
+//               padded positions of a tile is the same for every channel chunk).  Dword-granular DMA of
+//               the exact halo cost the transposed kernel 22 % (3x the DMA instructions);
 //   * style     s[b, :] of the tile's samples sits in LDS for the whole kernel and multiplies
 //               the B operand after its ds_read (one v_mul per operand, hidden under the MFMAs),
 //               so staging is a pure copy and needs no arithmetic.
@@ -39,16 +41,12 @@ struct V2Cfg {
     static constexpr int NACC = MODE == 0 ? NT : 4;
     static constexpr int PAD_LO = MODE == 0 ? KS / 2 : 1;
     static constexpr int EXT = MODE == 0 ? KS - 1 : 1;
-    static constexpr int XI = (768 + THREADS - 1) / THREADS;  // covers xt <= 768
+    static constexpr int XI = (512 + THREADS - 1) / THREADS;  // float4 chunks per lane per channel (xt <= 2048)
 };
 
 __device__ __forceinline__ void glds16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
-__device__ __forceinline__ void glds4(const float* g, float* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 4, 0, 0);
 }
 
 template <int MODE, int KS, typename C>
@@ -82,7 +80,8 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
     const int thl = tc.th_log2, twl = tc.tw_log2;
     const int th = 1 << thl, tw = 1 << twl;
     const int b0 = bt * tc.nb, h0 = tc.h0 + (thi << thl), w0 = tc.w0 + (twi << twl);
-    const int eh = th + C::EXT, ew = tw + C::EXT;
+    constexpr int LP = C::PAD_LO ? 4 : 0;  // staged rows start at w0 - LP: 16-byte aligned superset of the halo
+    const int eh = th + C::EXT, ew = LP + ((tw + C::EXT - C::PAD_LO + 3) & ~3);
     const int xt = tc.xt;
     const int HW = p.H * p.W;
     const int k_lo = blockIdx.y * p.kchunk;
@@ -95,17 +94,21 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
         Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
     }
 
-    // ---- per-lane DMA source offsets for the input tile (-1: padded position, never written)
+    // ---- per-lane DMA source offsets for the input tile, one float4 chunk each (-1: outside the image, never
+    // written: those positions keep the zeros stored above)
     int st_goff[XI];
+    {
+        const int ew4 = ew >> 2;
 #pragma unroll
-    for (int i = 0; i < XI; ++i) {
-        const int idx = tid + NTHR * i;
-        st_goff[i] = -1;
-        if (idx < xt) {
-            const int n = idx / (eh * ew), rem = idx - n * (eh * ew);
-            const int r = rem / ew, c = rem - r * ew;
-            const int b = b0 + n, h = h0 - C::PAD_LO + r, w = w0 - C::PAD_LO + c;
-            if (b < p.B && h >= 0 && h < p.H && w >= 0 && w < p.W) st_goff[i] = b * p.Cin * HW + h * p.W + w;
+        for (int i = 0; i < XI; ++i) {
+            const int idx = tid + NTHR * i;
+            st_goff[i] = -1;
+            if (idx < (xt >> 2)) {
+                const int n = idx / (eh * ew4), rem = idx - n * (eh * ew4);
+                const int r = rem / ew4, c4 = rem - r * ew4;
+                const int b = b0 + n, h = h0 - C::PAD_LO + r, w = w0 - LP + 4 * c4;
+                if (b < p.B && h >= 0 && h < p.H && w >= 0 && w < p.W) st_goff[i] = b * p.Cin * HW + h * p.W + w;
+            }
         }
     }
     // weight DMA: float4 e = it*256 + tid of the chunk's [CC*NTAPS][MBLK] slab
@@ -125,12 +128,12 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
         for (int it = 0; it < WIT; ++it)
             if (w_goff[it] >= 0) glds16(wsrc + w_goff[it], wdst + it * NTHR * 4);
         const float* xsrc = p.x + (int64_t)ci0 * HW;
-        float* xdst = Xl + buf * CC * xt + wbase;
+        float* xdst = Xl + buf * CC * xt + wbase * 4;
 #pragma unroll
         for (int j = 0; j < CC; ++j)
 #pragma unroll
             for (int i = 0; i < XI; ++i)
-                if (st_goff[i] >= 0) glds4(xsrc + st_goff[i] + j * HW, xdst + j * xt + i * NTHR);
+                if (st_goff[i] >= 0) glds16(xsrc + st_goff[i] + j * HW, xdst + j * xt + i * NTHR * 4);
     };
 
     // ---- per-lane operand offsets
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
         const int pp = (wn * C::NT + t) * 32 + l31;
         const int n = pp >> (thl + twl), rem = pp & ((1 << (thl + twl)) - 1);
         const int r = rem >> twl, c = rem & (tw - 1);
-        xo[t] = n * eh * ew + r * ew + c + half * xt;
+        xo[t] = n * eh * ew + r * ew + c + (LP - C::PAD_LO) + half * xt;
         so[t] = min(n, tc.nb - 1) * p.Cin + half;
     }
     const int aoff = half * C::NTAPS * C::MBLK + wm * C::MT * 32 + l31;
@@ -309,7 +312,7 @@ int launch_v2(ConvParams& p, hipStream_t st) {
     constexpr int CC = V2<MODE>::CC;
     int xt_max = 0;
     for (int c = 0; c < p.ncls; ++c) xt_max = p.cls[c].xt > xt_max ? p.cls[c].xt : xt_max;
-    if (xt_max > C::THREADS * C::XI) return -1;
+    if (xt_max > C::THREADS * C::XI * 4) return -1;
     const size_t lds = (size_t)(2 * CC * C::NTAPS * C::MBLK + 2 * CC * xt_max + p.nb_max * p.Cin) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     static bool attr_set = false;
@@ -380,7 +383,10 @@ int modconv_v2_tile(int mode, int* mblk, int* npos) {
 
 int modconv_v2_launch(ConvParams& p, int mode, int ks, hipStream_t st, void* workspace, int64_t workspace_bytes) {
     const int cc = mode == 0 ? V2<0>::CC : V2<1>::CC;
-    if (p.Cin % cc != 0 || !p.cout_vec4 || (((uintptr_t)p.x | (uintptr_t)p.wpk) & 15) != 0) return -1;
+    if (p.Cin % cc != 0 || !p.cout_vec4 || (((uintptr_t)p.x | (uintptr_t)p.wpk) & 15) != 0 || p.W % 4 != 0) return -1;
+    for (int c = 0; c < p.ncls; ++c)
+        if (p.cls[c].w0 % 4 != 0) return -1;
+    mc_set_padded_xt(p, mode == 0 ? ks / 2 : 1, mode == 0 ? ks - 1 : 1);
     int mblk, npos;
     const int c = modconv_v2_tile(mode, &mblk, &npos);
     plan_splitk(p, mblk, cc, workspace ? workspace_bytes : 0);
