@@ -31,8 +31,9 @@ struct V2 {
 
 // Wave layout of a workgroup: WM x WN waves, each owning MT x NT 32x32 accumulator tiles
 // (MODE 1: NT = 1 and the 4 output phases take the place of the N tiles).
-template <int MODE, int KS, int WM_, int WN_, int MT_, int NT_, int OCC_>
+template <int MODE, int KS, int WM_, int WN_, int MT_, int NT_, int OCC_, int CC_ = V2<MODE>::CC>
 struct V2Cfg {
+    static constexpr int CC = CC_;
     static constexpr int NTAPS = KS * KS;
     static constexpr int WM = WM_, WN = WN_, MT = MT_, NT = NT_, OCC = OCC_;
     static constexpr int THREADS = 64 * WM * WN;
@@ -51,7 +52,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 
 template <int MODE, int KS, typename C>
 __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const ConvParams p, const int xt_max) {
-    constexpr int CC = V2<MODE>::CC;
+    constexpr int CC = C::CC;
     constexpr int NTHR = C::THREADS;
     constexpr int XI = C::XI;
     constexpr int WF = CC * C::NTAPS * C::MBLK;
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256) void modconv_splitk_finish(const ConvParams p,
 
 template <int MODE, int KS, typename C>
 int launch_v2(ConvParams& p, hipStream_t st) {
-    constexpr int CC = V2<MODE>::CC;
+    constexpr int CC = C::CC;
     int xt_max = 0;
     for (int c = 0; c < p.ncls; ++c) xt_max = p.cls[c].xt > xt_max ? p.cls[c].xt : xt_max;
     if (xt_max > C::THREADS * C::XI * 4) return -1;
@@ -368,6 +369,7 @@ typedef V2Cfg<0, 1, 2, 2, 2, 4, 2> Conv1A;
 typedef V2Cfg<1, 3, 1, 4, 2, 1, 2> UpA;      // 256 thr, 64 co x 128 pos, wave 64 co x 32 pos x 4 phases
 typedef V2Cfg<1, 3, 2, 4, 1, 1, 4> UpB;      // 512 thr, 64 co x 128 pos, wave 32 co x 32 pos x 4 phases
 typedef V2Cfg<1, 3, 1, 8, 2, 1, 2> UpC;      // 512 thr, 64 co x 256 pos, wave 64 co x 32 pos x 4 phases
+typedef V2Cfg<1, 3, 1, 8, 1, 1, 4, 16> UpD;  // 512 thr, 32 co x 256 pos, 16-channel chunks (half the barriers per MFMA)
 
 int modconv_v2_tile(int mode, int* mblk, int* npos) {
     static int cfg = -1;
@@ -377,12 +379,14 @@ int modconv_v2_tile(int mode, int* mblk, int* npos) {
     }
     const int c = mode == 0 ? cfg / 10 : cfg % 10;
     if (mode == 0) { *mblk = 128; *npos = 256; }
-    else { *mblk = 64; *npos = c == 2 ? 256 : 128; }
+    else { *mblk = c == 3 ? 32 : 64; *npos = (c == 2 || c == 3) ? 256 : 128; }
     return c;
 }
 
 int modconv_v2_launch(ConvParams& p, int mode, int ks, hipStream_t st, void* workspace, int64_t workspace_bytes) {
-    const int cc = mode == 0 ? V2<0>::CC : V2<1>::CC;
+    int mblk0, npos0;
+    const int cfg0 = modconv_v2_tile(mode, &mblk0, &npos0);
+    const int cc = mode == 0 ? V2<0>::CC : (cfg0 == 3 ? 16 : V2<1>::CC);
     if (p.Cin % cc != 0 || !p.cout_vec4 || (((uintptr_t)p.x | (uintptr_t)p.wpk) & 15) != 0 || p.W % 4 != 0) return -1;
     for (int c = 0; c < p.ncls; ++c)
         if (p.cls[c].w0 % 4 != 0) return -1;
@@ -394,6 +398,7 @@ int modconv_v2_launch(ConvParams& p, int mode, int ks, hipStream_t st, void* wor
     if (mode == 0 && ks == 3) return c == 1 ? launch_v2<0, 3, Conv3B>(p, st) : launch_v2<0, 3, Conv3A>(p, st);
     if (mode == 0 && ks == 1) return launch_v2<0, 1, Conv1A>(p, st);
     if (mode == 1 && ks == 3)
-        return c == 1 ? launch_v2<1, 3, UpB>(p, st) : c == 2 ? launch_v2<1, 3, UpC>(p, st) : launch_v2<1, 3, UpA>(p, st);
+        return c == 1 ? launch_v2<1, 3, UpB>(p, st) : c == 2 ? launch_v2<1, 3, UpC>(p, st)
+               : c == 3 ? launch_v2<1, 3, UpD>(p, st) : launch_v2<1, 3, UpA>(p, st);
     return -1;
 }
