@@ -181,6 +181,23 @@ int sis_sgd_momentum(const int64_t* table, int n_chunks, const float* lr, const 
 int sis_ema_update(float* mu, const float* mu_batch, float momentum, float one_minus_momentum,
                    int batch, int numel, void* stream);
 
+/* Batch normalisation (training: batch statistics; F.batch_norm semantics incl. the unbiased running_var update)
+ * fused with an optional residual add and ReLU, fp32 NCHW with H*W % 4 == 0
+ * (networks/ema_net/network.py:37-56 bottleneck tail, :169-184 ConvBNReLU; bn_lib/nn/modules/batchnorm.py:51-56).
+ * workspace: sis_bn_workspace_floats(batch, channels, hw) floats.  running_* may be NULL (no update).
+ *   sis_bn_stats    mean[c], invstd[c] = 1/sqrt(var_biased + eps)   (+ running stats with `momentum`)
+ *   sis_bn_act_fwd  y = [relu]( gamma*(x-mean)*invstd + beta [+ residual] )     (eval: pass running statistics)
+ *   sis_bn_act_bwd  dy' = dy*[y>0] (when relu); dbeta = sum dy'; dgamma = sum dy'*xhat;
+ *                   dx = gamma*invstd*(dy' - mean(dy') - xhat*mean(dy'*xhat)); dresidual = dy' (when not NULL). */
+int64_t sis_bn_workspace_floats(int batch, int channels, int hw);
+int sis_bn_stats(float* mean, float* invstd, float* running_mean, float* running_var, const float* x,
+                 float* workspace, int batch, int channels, int hw, float eps, float momentum, void* stream);
+int sis_bn_act_fwd(float* y, const float* x, const float* residual, const float* mean, const float* invstd,
+                   const float* gamma, const float* beta, int batch, int channels, int hw, int relu, void* stream);
+int sis_bn_act_bwd(float* dx, float* dresidual, float* dgamma, float* dbeta, const float* dy, const float* y,
+                   const float* x, const float* mean, const float* invstd, const float* gamma, float* workspace,
+                   int batch, int channels, int hw, int relu, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Dataset-loop neighbours of Generator.forward (SURVEY.md §8f "next" rows 1 and 2).
  */

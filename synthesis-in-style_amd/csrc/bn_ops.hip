@@ -1,0 +1,282 @@
+// Batch normalisation fused with its neighbours, fp32 NCHW: the HBM-bound half of the EMANet training step.
+//
+// Reference code path: every convolution of networks/ema_net/network.py is followed by
+// `norm_layer` (= F.batch_norm with batch statistics, momentum 3e-4, eps 1e-5: bn_lib/nn/modules/batchnorm.py:51-56),
+// usually a ReLU, and in the bottlenecks a residual add + ReLU (network.py:37-56) -- on the reference each of these is
+// its own full-tensor pass (and its own backward pass).  Here:
+//
+//   forward   bn_stats_kernel     one read of x   -> per-(channel, slice) count/mean/M2 partials (two sweeps over a
+//                                                    16K-element slice that the second time comes from L2), merged in
+//                                                    fixed order with Chan's formula: no E[x^2]-E[x]^2 cancellation,
+//                                                    bitwise reproducible; also updates running_mean / running_var
+//             bn_act_fwd_kernel   one read of x (+ residual), one write of y = relu(gamma*xhat + beta + residual)
+//   backward  bn_bwd_reduce       one read of dy, y, x -> sum(dy') and sum(dy'*xhat) per channel (dy' = dy * [y > 0])
+//             bn_bwd_apply        one read of dy, y, x, one write of dx (and of the residual gradient dy')
+//
+// Algorithmic HBM bytes per element: forward 4*(2 reads + 1 write) (+4 with residual), backward 4*(6 reads + 1 write)
+// (+4 for the residual gradient); unfused ATen does forward BN (2r+1w) + ReLU (1r+1w) + add (2r+1w) + ReLU (1r+1w).
+#include "sis_common.h"
+
+namespace {
+
+constexpr int BN_SLICE = 16384;  // elements per (channel, slice) partial
+
+struct BnGeom { int B, C, HW, slices_per_plane_group, S; int64_t n; };
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// A channel's data = B planes of HW floats.  Slice s of channel c covers elements [s*BN_SLICE, (s+1)*BN_SLICE) of
+// the channel's B*HW logical elements (element e lives at plane e / HW, offset e % HW).  Lanes walk float4s; one
+// division at the start, then plane / offset advance incrementally (HW % 4 == 0: a float4 never straddles planes).
+struct ChanWalk {
+    int64_t e, hi;
+    int b, r, C, HW, c;
+    __device__ __forceinline__ ChanWalk(int64_t lo, int64_t hi_, int c_, int C_, int HW_) : hi(hi_), C(C_), HW(HW_), c(c_) {
+        e = lo + (int64_t)threadIdx.x * 4;
+        b = (int)(e / HW);
+        r = (int)(e - (int64_t)b * HW);
+    }
+    __device__ __forceinline__ bool valid() const { return e < hi; }
+    __device__ __forceinline__ int64_t addr() const { return ((int64_t)b * C + c) * HW + r; }
+    __device__ __forceinline__ void next() {
+        e += 1024; r += 1024;
+        while (r >= HW) { r -= HW; ++b; }
+    }
+};
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(float* __restrict__ partial, const float* __restrict__ x, int C,
+                                                       int HW, int64_t n, int S) {
+    __shared__ float red[4];
+    const int c = blockIdx.x / S, s = blockIdx.x % S;
+    const int64_t lo = (int64_t)s * BN_SLICE, hi = min(n, lo + BN_SLICE);
+    float sum = 0.f;
+    for (ChanWalk w(lo, hi, c, C, HW); w.valid(); w.next()) {
+        const float4 v = *reinterpret_cast<const float4*>(x + w.addr());
+        sum += (v.x + v.y) + (v.z + v.w);
+    }
+    const float cnt = (float)(hi - lo);
+    const float mean = block_sum(sum, red) / cnt;
+    float m2 = 0.f;
+    for (ChanWalk w(lo, hi, c, C, HW); w.valid(); w.next()) {
+        const float4 v = *reinterpret_cast<const float4*>(x + w.addr());
+        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+        m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    m2 = block_sum(m2, red);
+    if (threadIdx.x == 0) {
+        float* o = partial + ((int64_t)c * S + s) * 3;
+        o[0] = cnt; o[1] = mean; o[2] = m2;
+    }
+}
+
+__global__ __launch_bounds__(64) void bn_stats_finish_kernel(float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                             float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var,
+                                                             const float* __restrict__ partial, int C, int S, float eps,
+                                                             float momentum) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int s = 0; s < S; ++s) {  // Chan et al. pairwise merge, fixed order
+        const float* p = partial + ((int64_t)c * S + s) * 3;
+        const float nb = p[0], mb = p[1], m2b = p[2];
+        const float nt = n + nb, delta = mb - mean;
+        mean += delta * (nb / nt);
+        m2 += m2b + delta * delta * (n * nb / nt);
+        n = nt;
+    }
+    const float var = m2 / n;
+    mean_out[c] = mean;
+    invstd_out[c] = rsqrtf(var + eps);
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
+    }
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(float4* __restrict__ y, const float4* __restrict__ x,
+                                                         const float4* __restrict__ res, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int C, int HW4, int64_t total4) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+        const int c = (int)((i / HW4) % C);
+        const float a = (gamma ? gamma[c] : 1.f) * invstd[c];
+        const float b = (beta ? beta[c] : 0.f) - mean[c] * a;
+        float4 v = x[i];
+        v.x = v.x * a + b; v.y = v.y * a + b; v.z = v.z * a + b; v.w = v.w * a + b;
+        if (RES) { const float4 r = res[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+        if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        y[i] = v;
+    }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(float* __restrict__ partial, const float* __restrict__ dy,
+                                                            const float* __restrict__ y, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            int C, int HW, int64_t n, int S) {
+    __shared__ float red[4];
+    const int c = blockIdx.x / S, s = blockIdx.x % S;
+    const int64_t lo = (int64_t)s * BN_SLICE, hi = min(n, lo + BN_SLICE);
+    const float mu = mean[c], is = invstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (ChanWalk w(lo, hi, c, C, HW); w.valid(); w.next()) {
+        const int64_t a = w.addr();
+        float4 g = *reinterpret_cast<const float4*>(dy + a);
+        if (RELU) {
+            const float4 o = *reinterpret_cast<const float4*>(y + a);
+            if (!(o.x > 0.f)) g.x = 0.f;
+            if (!(o.y > 0.f)) g.y = 0.f;
+            if (!(o.z > 0.f)) g.z = 0.f;
+            if (!(o.w > 0.f)) g.w = 0.f;
+        }
+        const float4 xv = *reinterpret_cast<const float4*>(x + a);
+        s1 += (g.x + g.y) + (g.z + g.w);
+        s2 += (g.x * ((xv.x - mu) * is) + g.y * ((xv.y - mu) * is)) + (g.z * ((xv.z - mu) * is) + g.w * ((xv.w - mu) * is));
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) { partial[((int64_t)c * S + s) * 2] = s1; partial[((int64_t)c * S + s) * 2 + 1] = s2; }
+}
+
+__global__ __launch_bounds__(64) void bn_bwd_finish_kernel(float* __restrict__ sum_dy, float* __restrict__ sum_dy_xhat,
+                                                           const float* __restrict__ partial, int C, int S) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int s = 0; s < S; ++s) { a += partial[((int64_t)c * S + s) * 2]; b += partial[((int64_t)c * S + s) * 2 + 1]; }
+    sum_dy[c] = a; sum_dy_xhat[c] = b;
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float4* __restrict__ dx, float4* __restrict__ dres,
+                                                           const float4* __restrict__ dy, const float4* __restrict__ y,
+                                                           const float4* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ sum_dy,
+                                                           const float* __restrict__ sum_dy_xhat, int C, int HW4,
+                                                           int64_t total4, float inv_n) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+        const int c = (int)((i / HW4) % C);
+        const float mu = mean[c], is = invstd[c];
+        const float k = (gamma ? gamma[c] : 1.f) * is;
+        const float m1 = sum_dy[c] * inv_n, m2 = sum_dy_xhat[c] * inv_n;
+        float4 g = dy[i];
+        if (RELU) {
+            const float4 o = y[i];
+            if (!(o.x > 0.f)) g.x = 0.f;
+            if (!(o.y > 0.f)) g.y = 0.f;
+            if (!(o.z > 0.f)) g.z = 0.f;
+            if (!(o.w > 0.f)) g.w = 0.f;
+        }
+        if (RES) dres[i] = g;
+        const float4 xv = x[i];
+        float4 r;
+        r.x = k * (g.x - m1 - (xv.x - mu) * is * m2);
+        r.y = k * (g.y - m1 - (xv.y - mu) * is * m2);
+        r.z = k * (g.z - m1 - (xv.z - mu) * is * m2);
+        r.w = k * (g.w - m1 - (xv.w - mu) * is * m2);
+        dx[i] = r;
+    }
+}
+
+int slices(int64_t n) { return (int)((n + BN_SLICE - 1) / BN_SLICE); }
+int ew_blocks(int64_t total4) { const int64_t b = (total4 + 255) / 256; return (int)(b < 4096 ? b : 4096); }
+
+int check_geom(const char* name, int B, int C, int HW) {
+    SIS_REQUIRE(B > 0 && C > 0 && HW > 0, "%s: non-positive size", name);
+    SIS_REQUIRE(HW % 4 == 0, "%s: H*W must be a multiple of 4 (16-byte rows)", name);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t sis_bn_workspace_floats(int batch, int channels, int hw) {
+    return (int64_t)channels * slices((int64_t)batch * hw) * 3;
+}
+
+extern "C" int sis_bn_stats(float* mean, float* invstd, float* running_mean, float* running_var, const float* x,
+                            float* workspace, int batch, int channels, int hw, float eps, float momentum, void* stream) {
+    if (check_geom("sis_bn_stats", batch, channels, hw)) return 1;
+    SIS_REQUIRE(mean && invstd && x && workspace, "sis_bn_stats: null pointer");
+    const int64_t n = (int64_t)batch * hw;
+    const int S = slices(n);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(channels * S), dim3(256), 0, st, workspace, x, channels, hw, n, S);
+    SIS_CHECK_LAUNCH("bn_stats_kernel");
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(sis_cdiv(channels, 64)), dim3(64), 0, st, mean, invstd, running_mean,
+                       running_var, workspace, channels, S, eps, momentum);
+    SIS_CHECK_LAUNCH("bn_stats_finish_kernel");
+    return 0;
+}
+
+extern "C" int sis_bn_act_fwd(float* y, const float* x, const float* residual, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, int batch, int channels, int hw, int relu,
+                              void* stream) {
+    if (check_geom("sis_bn_act_fwd", batch, channels, hw)) return 1;
+    SIS_REQUIRE(y && x && mean && invstd, "sis_bn_act_fwd: null pointer");
+    SIS_REQUIRE((((uintptr_t)y | (uintptr_t)x | (uintptr_t)residual) & 15) == 0, "sis_bn_act_fwd: 16-byte alignment");
+    const int64_t total4 = (int64_t)batch * channels * hw / 4;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(ew_blocks(total4)), blk(256);
+#define SIS_BN_FWD(R, S_)                                                                                              \
+    hipLaunchKernelGGL((bn_act_fwd_kernel<R, S_>), grid, blk, 0, st, (float4*)y, (const float4*)x, (const float4*)residual, \
+                       mean, invstd, gamma, beta, channels, hw / 4, total4)
+    if (relu && residual) SIS_BN_FWD(true, true);
+    else if (relu) SIS_BN_FWD(true, false);
+    else if (residual) SIS_BN_FWD(false, true);
+    else SIS_BN_FWD(false, false);
+#undef SIS_BN_FWD
+    SIS_CHECK_LAUNCH("bn_act_fwd_kernel");
+    return 0;
+}
+
+extern "C" int sis_bn_act_bwd(float* dx, float* dresidual, float* dgamma, float* dbeta, const float* dy, const float* y,
+                              const float* x, const float* mean, const float* invstd, const float* gamma, float* workspace,
+                              int batch, int channels, int hw, int relu, void* stream) {
+    if (check_geom("sis_bn_act_bwd", batch, channels, hw)) return 1;
+    SIS_REQUIRE(dx && dgamma && dbeta && dy && x && mean && invstd && workspace, "sis_bn_act_bwd: null pointer");
+    SIS_REQUIRE(!relu || y, "sis_bn_act_bwd: the ReLU gate needs the forward output");
+    SIS_REQUIRE((((uintptr_t)dx | (uintptr_t)dresidual | (uintptr_t)dy | (uintptr_t)y | (uintptr_t)x) & 15) == 0,
+                "sis_bn_act_bwd: 16-byte alignment");
+    const int64_t n = (int64_t)batch * hw;
+    const int S = slices(n);
+    hipStream_t st = (hipStream_t)stream;
+    if (relu)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(channels * S), dim3(256), 0, st, workspace, dy, y, x, mean, invstd,
+                           channels, hw, n, S);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(channels * S), dim3(256), 0, st, workspace, dy, y, x, mean,
+                           invstd, channels, hw, n, S);
+    SIS_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(sis_cdiv(channels, 64)), dim3(64), 0, st, dbeta, dgamma, workspace, channels, S);
+    SIS_CHECK_LAUNCH("bn_bwd_finish_kernel");
+    const int64_t total4 = (int64_t)batch * channels * hw / 4;
+    const dim3 grid(ew_blocks(total4)), blk(256);
+    const float inv_n = 1.f / (float)n;
+#define SIS_BN_BWD(R, S_)                                                                                              \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<R, S_>), grid, blk, 0, st, (float4*)dx, (float4*)dresidual, (const float4*)dy, \
+                       (const float4*)y, (const float4*)x, mean, invstd, gamma, dbeta, dgamma, channels, hw / 4, total4, inv_n)
+    if (relu && dresidual) SIS_BN_BWD(true, true);
+    else if (relu) SIS_BN_BWD(true, false);
+    else if (dresidual) SIS_BN_BWD(false, true);
+    else SIS_BN_BWD(false, false);
+#undef SIS_BN_BWD
+    SIS_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return 0;
+}

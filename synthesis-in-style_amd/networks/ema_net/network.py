@@ -32,13 +32,50 @@ BN_MOM = 3e-4
 RESNET_BLOCKS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
 
 
-class SynchronizedBatchNorm2d(nn.BatchNorm2d):
-    """Per-process batch norm; always the functional call, so ``num_batches_tracked`` stays untouched exactly
-    as in the reference's code path."""
+class _FusedBatchNormAct(Function):
+    """y = [relu]( batch_norm(x) [+ residual] ) on the HIP kernels of csrc/bn_ops.hip (one statistics pass and one
+    apply pass forward; one reduction pass and one apply pass backward, residual gradient included)."""
 
-    def forward(self, input):
-        return F.batch_norm(input, self.running_mean, self.running_var, self.weight, self.bias, self.training,
-                            self.momentum, self.eps)
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+        if training:
+            mean, invstd = sis_hip.bn_stats(x, running_mean, running_var, eps, momentum)
+        else:
+            mean, invstd = running_mean, torch.rsqrt(running_var + eps)
+        y = sis_hip.bn_act_fwd(x, residual, mean, invstd, weight, bias, relu)
+        ctx.save_for_backward(x, y, mean, invstd, weight)
+        ctx.relu, ctx.training, ctx.has_residual = relu, training, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise RuntimeError("fused batch norm: backward through evaluation-mode statistics is not implemented")
+        x, y, mean, invstd, weight = ctx.saved_tensors
+        need_res = ctx.has_residual and ctx.needs_input_grad[1]
+        dx, dres, dgamma, dbeta = sis_hip.bn_act_bwd(dy.contiguous(), y, x, mean, invstd, weight, ctx.relu, need_res)
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+
+
+class SynchronizedBatchNorm2d(nn.BatchNorm2d):
+    """Per-process batch norm (what the reference's class amounts to under DistributedDataParallel); always batch /
+    running statistics through the functional path, so ``num_batches_tracked`` stays untouched as in the reference.
+    ``forward(x, residual=None, relu=False)`` additionally fuses the residual add and ReLU that follow it in the
+    bottlenecks / ConvBNReLU blocks; on a HIP device with fp32 NCHW input the whole thing runs on the hand-written
+    kernels, otherwise (other dtypes / layouts) on the ATen composite."""
+
+    def forward(self, input, residual=None, relu=False):
+        fused = (sis_hip.bn_supported(input) and self.weight is not None and self.bias is not None
+                 and (residual is None or (sis_hip.bn_supported(residual) and residual.shape == input.shape))
+                 and (self.training or not torch.is_grad_enabled()))
+        if fused:
+            return _FusedBatchNormAct.apply(input, residual, self.weight, self.bias, self.running_mean, self.running_var,
+                                            self.training, self.momentum, self.eps, relu)
+        out = F.batch_norm(input, self.running_mean, self.running_var, self.weight, self.bias, self.training,
+                           self.momentum, self.eps)
+        if residual is not None:
+            out = out + residual
+        return F.relu(out, inplace=True) if relu else out
 
 
 norm_layer = partial(SynchronizedBatchNorm2d, momentum=BN_MOM)
@@ -74,10 +111,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         shortcut = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
-        return self.relu(y + shortcut)
+        y = self.bn1(self.conv1(x), relu=True)
+        y = self.bn2(self.conv2(y), relu=True)
+        return self.bn3(self.conv3(y), residual=shortcut, relu=True)
 
 
 class ResNet(nn.Module):
@@ -124,8 +160,15 @@ class ResNet(nn.Module):
                   for i in range(1, blocks)]
         return nn.Sequential(*units)
 
+    @staticmethod
+    def stem(conv1, bn1, x):
+        """conv-bn-relu x3 of the deep stem with the norm / activation pairs fused."""
+        x = conv1[1](conv1[0](x), relu=True)
+        x = conv1[4](conv1[3](x), relu=True)
+        return bn1(conv1[6](x), relu=True)
+
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.stem(self.conv1, self.bn1, x))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = self.avgpool(x)
         return self.fc(x.view(x.size(0), -1))
@@ -149,7 +192,7 @@ class ConvBNReLU(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        return self.relu(self.bn(self.conv(x)))
+        return self.bn(self.conv(x), relu=True)
 
 
 class EMAU(nn.Module):
@@ -179,7 +222,7 @@ class EMAU(nn.Module):
                 z_ = z / (1e-6 + z.sum(dim=1, keepdim=True))
                 mu = self._l2norm(torch.bmm(x, z_), dim=1)             # M: bases             [b, c, k]
         x = F.relu(mu.matmul(z.permute(0, 2, 1)).view(b, c, h, w), inplace=True)
-        x = F.relu(self.conv2(x) + idn, inplace=True)
+        x = self.conv2[1](self.conv2[0](x), residual=idn, relu=True)
         return x, mu
 
     @staticmethod
@@ -231,8 +274,15 @@ class EMANet(BaseSegmenter):
         self.crit = CrossEntropyLoss2d(ignore_index=ignore_label, reduction='none')
         self.ignore_label = ignore_label
 
+    def features(self, img):
+        ex = self.extractor  # (stem convs, bn1, relu, maxpool, layer1..4): same modules, fused norm/activation calls
+        x = ex[3](ResNet.stem(ex[0], ex[1], img))
+        for stage in (ex[4], ex[5], ex[6], ex[7]):
+            x = stage(x)
+        return x
+
     def logits(self, img):
-        x = self.fc0(self.extractor(img))
+        x = self.fc0(self.features(img))
         x, mu = self.emau(x)
         return self.fc2(self.fc1(x)), mu
 

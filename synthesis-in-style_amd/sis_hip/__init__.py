@@ -49,6 +49,10 @@ _SIGNATURES = {
     "sis_sgd_chunk_elems": ([], _i),
     "sis_sgd_momentum": ([_vp, _i, ctypes.POINTER(_f), ctypes.POINTER(_f), _i, _f, _i, _vp], _i),
     "sis_ema_update": ([_vp, _vp, _f, _f, _i, _i, _vp], _i),
+    "sis_bn_workspace_floats": ([_i, _i, _i], _i64),
+    "sis_bn_stats": ([_vp] * 6 + [_i, _i, _i, _f, _f, _vp], _i),
+    "sis_bn_act_fwd": ([_vp] * 7 + [_i, _i, _i, _i, _vp], _i),
+    "sis_bn_act_bwd": ([_vp] * 11 + [_i, _i, _i, _i, _vp], _i),
     "sis_kmeans_assign": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "sis_make_image_u8": ([_vp, _vp, _i, _i, _i, _vp], _i),
 }
@@ -459,3 +463,44 @@ def make_image_u8(x):
     with torch.cuda.device(x.device):
         _check(lib().sis_make_image_u8(_ptr(out), _ptr(x), b, ch, h * w, _stream()), "sis_make_image_u8")
     return out
+
+
+# ------------------------------------------------------------------------------ fused batch norm
+
+
+def bn_supported(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and (x.shape[2] * x.shape[3]) % 4 == 0 and x.is_contiguous()
+
+
+def bn_stats(x, running_mean, running_var, eps, momentum):
+    b, c, h, w = x.shape
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib().sis_bn_workspace_floats(b, c, h * w), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_bn_stats(_ptr(mean), _ptr(invstd), _ptr(running_mean), _ptr(running_var), _ptr(x), _ptr(ws), b, c,
+                                  h * w, float(eps), float(momentum), _stream()), "sis_bn_stats")
+    return mean, invstd
+
+
+def bn_act_fwd(x, residual, mean, invstd, gamma, beta, relu):
+    b, c, h, w = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_bn_act_fwd(_ptr(y), _ptr(x), _ptr(residual), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), b, c,
+                                    h * w, int(bool(relu)), _stream()), "sis_bn_act_fwd")
+    return y
+
+
+def bn_act_bwd(dy, y, x, mean, invstd, gamma, relu, want_residual_grad):
+    b, c, h, w = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_residual_grad else None
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib().sis_bn_workspace_floats(b, c, h * w), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_bn_act_bwd(_ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(dy), _ptr(y), _ptr(x), _ptr(mean),
+                                    _ptr(invstd), _ptr(gamma), _ptr(ws), b, c, h * w, int(bool(relu)), _stream()),
+               "sis_bn_act_bwd")
+    return dx, dres, dgamma, dbeta

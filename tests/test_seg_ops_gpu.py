@@ -99,3 +99,43 @@ def test_ema_update(device):
     d = mu.to(device)
     sis_hip.ema_update(d, mub.to(device), 0.9)
     assert torch.allclose(d.cpu(), ref, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("b,c,h,w", [(2, 64, 128, 128), (16, 8, 4, 4), (3, 20, 10, 6), (2, 512, 32, 32)])
+@pytest.mark.parametrize("relu,use_res", [(True, True), (True, False), (False, False), (False, True)])
+def test_fused_batch_norm_act(device, b, c, h, w, relu, use_res):
+    """csrc/bn_ops.hip vs F.batch_norm (+ add + relu) in fp64: output, running statistics, every gradient."""
+    from networks.ema_net.network import SynchronizedBatchNorm2d
+    gen = torch.Generator().manual_seed(b + c + h)
+    x = torch.randn(b, c, h, w, generator=gen) * 2 + 0.5
+    res = torch.randn(b, c, h, w, generator=gen)
+    gy = torch.randn(b, c, h, w, generator=gen)
+    gamma, beta = 1 + 0.1 * torch.randn(c, generator=gen), 0.1 * torch.randn(c, generator=gen)
+    xr, rr = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm, rv = torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)
+    ref = F.batch_norm(xr, rm, rv, gr, br, True, 3e-4, 1e-5)
+    if use_res:
+        ref = ref + rr
+    if relu:
+        ref = F.relu(ref)
+    grads_ref = torch.autograd.grad(ref, [xr, gr, br] + ([rr] if use_res else []), gy.double())
+    bn = SynchronizedBatchNorm2d(c, momentum=3e-4).to(device).train()
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    xd, rd = x.to(device).requires_grad_(True), res.to(device).requires_grad_(True)
+    y = bn(xd, residual=rd if use_res else None, relu=relu)
+    assert torch.allclose(y.detach().cpu().double(), ref.detach(), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(bn.running_mean.cpu().double(), rm, rtol=1e-4, atol=1e-7)
+    assert torch.allclose(bn.running_var.cpu().double(), rv, rtol=1e-5)
+    assert int(bn.num_batches_tracked) == 0
+    grads = torch.autograd.grad(y, [xd, bn.weight, bn.bias] + ([rd] if use_res else []), gy.to(device))
+    for got, want in zip(grads, grads_ref):
+        scale = want.abs().max().item() + 1e-12
+        assert (got.cpu().double() - want).abs().max().item() <= 2e-4 * scale
+    bn.eval()
+    with torch.no_grad():
+        ye = bn(x.to(device), relu=relu)
+        re = F.batch_norm(x.double(), rm, rv, gamma.double(), beta.double(), False, 3e-4, 1e-5)
+        assert torch.allclose(ye.cpu().double(), F.relu(re) if relu else re, rtol=1e-4, atol=1e-5)
