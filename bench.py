@@ -132,6 +132,8 @@ def bench_training(args, workload, world, rank, device, distributed):
     from utils.synthetic_data import SyntheticSegmentationLoader
     config = yaml.safe_load(open(os.path.join(ROOT, "synthesis-in-style_amd", SEG_CONFIG[workload])))
     config["fine_tune"] = None
+    if args.dtype:
+        config["amp"] = None if args.dtype == "f32" else args.dtype
     if args.batch:
         config["batch_size"] = args.batch
     loader = SyntheticSegmentationLoader(config["batch_size"], config["image_size"], config["num_classes"],
@@ -164,14 +166,15 @@ def bench_training(args, workload, world, rank, device, distributed):
     return {
         "metric": METRIC, "value": round(images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": config.get("amp") or "f32", "data": "synthetic",
         "config": {"workload": f"{config['network']} training step, {config['image_size']}x{config['image_size']}, batch "
                                f"{config['batch_size']} per GPU (BASELINE.json configs[{3 if workload == 'emanet' else 4}])",
                    "batch_per_gpu": config["batch_size"], "image_size": config["image_size"],
                    "parallelism": f"dp{world}, DDP bucketed all-reduce over RCCL"},
         "roofline": {"kernel": "whole step (convolutions on ROCm libraries this round)", "bound": "mfma",
-                     "achieved": round(tf, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(tf / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None},
+                     "achieved": round(tf, 2), "peak": 2500.0 if config.get("amp") else PEAK_MFMA_F32_TFLOPS,
+                     "unit": "TFLOP/s",
+                     "frac": round(tf / (2500.0 if config.get("amp") else PEAK_MFMA_F32_TFLOPS), 4), "traffic": None},
     }
 
 
@@ -183,6 +186,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="training workloads: override the config's amp")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

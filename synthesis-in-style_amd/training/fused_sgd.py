@@ -4,11 +4,13 @@ Same constructor arguments and ``param_groups`` layout as ``torch.optim.SGD(para
 weight_decay)`` (what training_builder/ema_net_train_builder.py:27-48 and trans_u_net_train_builder.py:39-40
 build), so LR schedulers and checkpoints (``state_dict`` with ``momentum_buffer`` per parameter) keep working.
 Per step it launches ONE kernel over a device-resident table of (param, grad, momentum buffer) chunks instead
-of a foreach sequence; the table is rebuilt only when a parameter or gradient storage moves.
-
-``zero_grad`` defaults to ``set_to_none=False`` -- the behaviour of the torch 1.9 the reference pins
-(requirements.txt:1) -- which also keeps gradient storage, and therefore the table, stable.
+of a foreach sequence.  Parameter and momentum pointers are fixed; the gradient column is refreshed on the host
+with numpy whenever gradient storage moved (one 20 KB pinned, non-blocking copy) -- which makes
+``zero_grad(set_to_none=True)`` the cheap default: no 178 fill kernels, and autograd assigns fresh gradients instead
+of launching 178 accumulate-adds into stale ones (measured 1.8 ms of a 45 ms EMANet-50 step).  With
+DistributedDataParallel(gradient_as_bucket_view=True) gradients live in the buckets and never move.
 """
+import numpy as np
 import torch
 from torch.optim.optimizer import Optimizer
 
@@ -27,21 +29,39 @@ class FusedSGD(Optimizer):
             raise ValueError("all parameter groups must share one momentum")
         self._table = None
         self._table_key = None
+        self._grad_key = None
         self._steps = 0
 
-    def zero_grad(self, set_to_none: bool = False):
+    def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)
 
-    def _build_table(self, entries, device):
+    def _layout(self, entries):
+        """Static part of the table: which chunk belongs to which tensor at which offset."""
         chunk = sis_hip.sgd_chunk_elems()
-        rows = []
-        for gi, p, g, buf in entries:
+        owner, offset, count, group = [], [], [], []
+        for ti, (gi, p, _, _) in enumerate(entries):
             n = p.numel()
             for off in range(0, n, chunk):
-                cnt = min(chunk, n - off)
-                rows.append((p.data_ptr() + 4 * off, g.data_ptr() + 4 * off, buf.data_ptr() + 4 * off, cnt | (gi << 48)))
-        self._table = torch.tensor(rows, dtype=torch.int64).to(device)
-        self._n_chunks = len(rows)
+                owner.append(ti)
+                offset.append(4 * off)
+                count.append(min(chunk, n - off) | (gi << 48))
+        self._owner = np.asarray(owner, dtype=np.int64)
+        self._offset = np.asarray(offset, dtype=np.int64)
+        self._count = np.asarray(count, dtype=np.int64)
+        self._n_chunks = len(owner)
+        # two pinned staging buffers, alternated: the previous step's non-blocking copy may still be in flight
+        self._hosts = [torch.empty((self._n_chunks, 4), dtype=torch.int64).pin_memory() for _ in range(2)]
+        self._flip = 0
+        self._table = torch.empty((self._n_chunks, 4), dtype=torch.int64, device=entries[0][1].device)
+
+    def _upload(self, entries):
+        ptrs = np.asarray([(p.data_ptr(), g.data_ptr(), b.data_ptr()) for _, p, g, b in entries], dtype=np.int64)
+        self._flip ^= 1
+        pinned = self._hosts[self._flip]
+        host = pinned.numpy()
+        host[:, :3] = ptrs[self._owner] + self._offset[:, None]
+        host[:, 3] = self._count
+        self._table.copy_(pinned, non_blocking=True)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -49,8 +69,7 @@ class FusedSGD(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        entries, key, fresh = [], [], False
-        device = None
+        entries, fresh = [], False
         for gi, group in enumerate(self.param_groups):
             for p in group['params']:
                 if p.grad is None:
@@ -59,21 +78,24 @@ class FusedSGD(Optimizer):
                 if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
                     raise RuntimeError("FusedSGD needs contiguous float32 parameters and gradients")
                 state = self.state[p]
-                if 'momentum_buffer' not in state or state['momentum_buffer'] is None:
+                if state.get('momentum_buffer') is None:
                     state['momentum_buffer'] = torch.empty_like(p)
                     state['fresh'] = True
                 fresh = fresh or state.get('fresh', False)
                 entries.append((gi, p, p.grad, state['momentum_buffer']))
-                key.append((p.data_ptr(), p.grad.data_ptr(), state['momentum_buffer'].data_ptr()))
-                device = p.device
         if not entries:
             return loss
         if fresh and not all(self.state[p].get('fresh', False) for _, p, _, _ in entries):
             raise RuntimeError("FusedSGD: parameters gained gradients after the first step; rebuild the optimizer")
-        key = tuple(key)
-        if key != self._table_key:
-            self._build_table(entries, device)
-            self._table_key = key
+        static_key = tuple(id(p) for _, p, _, _ in entries)
+        if static_key != self._table_key:
+            self._layout(entries)
+            self._table_key = static_key
+            self._grad_key = None
+        grad_key = tuple(g.data_ptr() for _, _, g, _ in entries) + tuple(p.data_ptr() for _, p, _, _ in entries)
+        if grad_key != self._grad_key:
+            self._upload(entries)
+            self._grad_key = grad_key
         lrs = [g['lr'] for g in self.param_groups]
         wds = [g['weight_decay'] for g in self.param_groups]
         sis_hip.sgd_momentum(self._table, self._n_chunks, lrs, wds, self.param_groups[0]['momentum'], fresh)

@@ -39,6 +39,7 @@ class TransUNetTrainBuilder(BaseSingleNetworkTrainBuilder):
         return self._optimizers
 
     def get_updater(self) -> TransUNetUpdater:
-        return TransUNetUpdater(num_classes=self.config['num_classes'], iterators={'images': self.train_data_loader},
+        return TransUNetUpdater(num_classes=self.config['num_classes'], amp=self.config.get('amp'),
+                                iterators={'images': self.train_data_loader},
                                 networks=self.get_networks_for_updater(), optimizers=self.get_optimizers(),
                                 device=self.device(), copy_to_device=(self.world_size == 1))

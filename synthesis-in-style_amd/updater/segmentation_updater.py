@@ -55,9 +55,11 @@ class EMANetUpdater(Updater):
 class TransUNetUpdater(Updater):
     def __init__(self, *args, **kwargs):
         num_classes = kwargs.pop('num_classes')
+        amp = kwargs.pop('amp', None)  # None / 'bf16': the reference is fp32; bf16 autocast is this build's option
         super().__init__(*args, **kwargs)
         self.ce_loss = nn.CrossEntropyLoss()
         self.dice_loss = DiceLoss(num_classes)
+        self.amp_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16}.get(amp)
 
     def update_core(self):
         batch = next(self.iterators['images'])
