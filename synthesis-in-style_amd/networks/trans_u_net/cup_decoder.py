@@ -1,0 +1,61 @@
+"""Cascaded-upsampling CNN decoder ("CUP") and segmentation head of TransUNet
+(reference: networks/trans_u_net/vit_seg_modeling.py:265-373): tokens -> [B, hidden, h, w] -> 3x3 conv to 512 ->
+four (bilinear x2, concat skip, 2 x conv-BN-ReLU) stages -> 3x3 head."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+class Conv2dReLU(nn.Sequential):
+    def __init__(self, in_channels, out_channels, kernel_size, padding=0, stride=1, use_batchnorm=True):
+        super().__init__(nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                                   bias=not use_batchnorm),
+                         nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
+
+
+class DecoderBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, skip_channels=0, use_batchnorm=True):
+        super().__init__()
+        self.conv1 = Conv2dReLU(in_channels + skip_channels, out_channels, kernel_size=3, padding=1,
+                                use_batchnorm=use_batchnorm)
+        self.conv2 = Conv2dReLU(out_channels, out_channels, kernel_size=3, padding=1, use_batchnorm=use_batchnorm)
+        self.up = nn.UpsamplingBilinear2d(scale_factor=2)
+
+    def forward(self, x, skip=None):
+        x = self.up(x)
+        if skip is not None:
+            x = torch.cat([x, skip], dim=1)
+        return self.conv2(self.conv1(x))
+
+
+class SegmentationHead(nn.Sequential):
+    def __init__(self, in_channels, out_channels, kernel_size=3, upsampling=1):
+        super().__init__(nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, padding=kernel_size // 2),
+                         nn.UpsamplingBilinear2d(scale_factor=upsampling) if upsampling > 1 else nn.Identity())
+
+
+class DecoderCup(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        head_channels = 512
+        self.conv_more = Conv2dReLU(config.hidden_size, head_channels, kernel_size=3, padding=1, use_batchnorm=True)
+        decoder_channels = config.decoder_channels
+        in_channels = [head_channels] + list(decoder_channels[:-1])
+        if self.config.n_skip != 0:
+            skip_channels = self.config.skip_channels
+            for i in range(4 - self.config.n_skip):  # unused skips contribute no channels
+                skip_channels[3 - i] = 0
+        else:
+            skip_channels = [0, 0, 0, 0]
+        self.blocks = nn.ModuleList([DecoderBlock(i, o, s) for i, o, s in zip(in_channels, decoder_channels,
+                                                                              skip_channels)])
+
+    def forward(self, hidden_states, features=None):
+        b, n_patch, hidden = hidden_states.size()
+        h = w = int(np.sqrt(n_patch))
+        x = self.conv_more(hidden_states.permute(0, 2, 1).contiguous().view(b, hidden, h, w))
+        for i, block in enumerate(self.blocks):
+            skip = features[i] if (features is not None and i < self.config.n_skip) else None
+            x = block(x, skip=skip)
+        return x

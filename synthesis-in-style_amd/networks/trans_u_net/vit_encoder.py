@@ -1,0 +1,159 @@
+"""ViT encoder of TransUNet: patch / position embeddings (optionally on top of the ResNetV2 stem), pre-norm
+transformer blocks, final LayerNorm.  Class names, constructor signatures and parameter names follow
+/root/reference/stylegan_code_finder/networks/trans_u_net/vit_seg_modeling.py:53-262 so checkpoints line up.
+
+Attention runs through ``scaled_dot_product_attention`` (no [B,12,N,N] score tensor in HBM; the reference's attention
+dropout rate is 0.0, so it is the same function) unless attention maps are requested (``vis``).
+"""
+import copy
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn import Conv2d, Dropout, LayerNorm, Linear, Softmax
+from torch.nn.modules.utils import _pair
+
+from .vit_seg_modeling_resnet_skip import ResNetV2
+
+
+def swish(x):
+    return x * torch.sigmoid(x)
+
+
+ACT2FN = {"gelu": F.gelu, "relu": F.relu, "swish": swish}
+
+
+class Attention(nn.Module):
+    def __init__(self, config, vis):
+        super().__init__()
+        self.vis = vis
+        self.num_attention_heads = config.transformer["num_heads"]
+        self.attention_head_size = int(config.hidden_size / self.num_attention_heads)
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        self.query = Linear(config.hidden_size, self.all_head_size)
+        self.key = Linear(config.hidden_size, self.all_head_size)
+        self.value = Linear(config.hidden_size, self.all_head_size)
+        self.out = Linear(config.hidden_size, config.hidden_size)
+        self.attn_dropout = Dropout(config.transformer["attention_dropout_rate"])
+        self.proj_dropout = Dropout(config.transformer["attention_dropout_rate"])
+        self.softmax = Softmax(dim=-1)
+
+    def transpose_for_scores(self, x):
+        b, n, _ = x.shape
+        return x.view(b, n, self.num_attention_heads, self.attention_head_size).permute(0, 2, 1, 3)
+
+    def forward(self, hidden_states):
+        q = self.transpose_for_scores(self.query(hidden_states))
+        k = self.transpose_for_scores(self.key(hidden_states))
+        v = self.transpose_for_scores(self.value(hidden_states))
+        weights = None
+        if self.vis or (self.training and self.attn_dropout.p > 0):
+            scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(self.attention_head_size)
+            probs = self.softmax(scores)
+            weights = probs if self.vis else None
+            context = torch.matmul(self.attn_dropout(probs), v)
+        else:
+            context = F.scaled_dot_product_attention(q, k, v)
+        b, _, n, _ = context.shape
+        context = context.permute(0, 2, 1, 3).reshape(b, n, self.all_head_size)
+        return self.proj_dropout(self.out(context)), weights
+
+
+class Mlp(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.fc1 = Linear(config.hidden_size, config.transformer["mlp_dim"])
+        self.fc2 = Linear(config.transformer["mlp_dim"], config.hidden_size)
+        self.act_fn = ACT2FN["gelu"]
+        self.dropout = Dropout(config.transformer["dropout_rate"])
+        for fc in (self.fc1, self.fc2):
+            nn.init.xavier_uniform_(fc.weight)
+            nn.init.normal_(fc.bias, std=1e-6)
+
+    def forward(self, x):
+        return self.dropout(self.fc2(self.dropout(self.act_fn(self.fc1(x)))))
+
+
+class Embeddings(nn.Module):
+    """Patch + position embeddings; in hybrid mode the "patches" are 1x1 (or p x p) cells of the ResNetV2
+    stride-16 feature map and the stem's intermediate maps are returned as decoder skips."""
+
+    def __init__(self, config, img_size, in_channels=3):
+        super().__init__()
+        self.config = config
+        img_size = _pair(img_size)
+        if config.patches.get("grid") is not None:
+            grid = config.patches["grid"]
+            patch_size = (img_size[0] // 16 // grid[0], img_size[1] // 16 // grid[1])
+            real = (patch_size[0] * 16, patch_size[1] * 16)
+            n_patches = (img_size[0] // real[0]) * (img_size[1] // real[1])
+            self.hybrid = True
+        else:
+            patch_size = _pair(config.patches["size"])
+            n_patches = (img_size[0] // patch_size[0]) * (img_size[1] // patch_size[1])
+            self.hybrid = False
+        if self.hybrid:
+            self.hybrid_model = ResNetV2(block_units=config.resnet.num_layers, width_factor=config.resnet.width_factor)
+            in_channels = self.hybrid_model.width * 16
+        self.patch_embeddings = Conv2d(in_channels=in_channels, out_channels=config.hidden_size,
+                                       kernel_size=patch_size, stride=patch_size)
+        self.position_embeddings = nn.Parameter(torch.zeros(1, n_patches, config.hidden_size))
+        self.dropout = Dropout(config.transformer["dropout_rate"])
+
+    def forward(self, x):
+        features = None
+        if self.hybrid:
+            x, features = self.hybrid_model(x)
+        x = self.patch_embeddings(x).flatten(2).transpose(-1, -2)  # [B, n_patches, hidden]
+        return self.dropout(x + self.position_embeddings), features
+
+
+class Block(nn.Module):
+    def __init__(self, config, vis):
+        super().__init__()
+        self.hidden_size = config.hidden_size
+        self.attention_norm = LayerNorm(config.hidden_size, eps=1e-6)
+        self.ffn_norm = LayerNorm(config.hidden_size, eps=1e-6)
+        self.ffn = Mlp(config)
+        self.attn = Attention(config, vis)
+
+    def forward(self, x):
+        a, weights = self.attn(self.attention_norm(x))
+        x = x + a
+        return x + self.ffn(self.ffn_norm(x)), weights
+
+    def load_from(self, weights, n_block):
+        from .npz_import import load_encoder_block
+        load_encoder_block(self, weights, n_block)
+
+
+class Encoder(nn.Module):
+    def __init__(self, config, vis):
+        super().__init__()
+        self.vis = vis
+        self.layer = nn.ModuleList()
+        self.encoder_norm = LayerNorm(config.hidden_size, eps=1e-6)
+        prototype = Block(config, vis)
+        for _ in range(config.transformer["num_layers"]):
+            self.layer.append(copy.deepcopy(prototype))
+
+    def forward(self, hidden_states):
+        attn_weights = []
+        for block in self.layer:
+            hidden_states, weights = block(hidden_states)
+            if self.vis:
+                attn_weights.append(weights)
+        return self.encoder_norm(hidden_states), attn_weights
+
+
+class Transformer(nn.Module):
+    def __init__(self, config, img_size, vis):
+        super().__init__()
+        self.embeddings = Embeddings(config, img_size=img_size)
+        self.encoder = Encoder(config, vis)
+
+    def forward(self, input_ids):
+        embedding_output, features = self.embeddings(input_ids)
+        encoded, attn_weights = self.encoder(embedding_output)
+        return encoded, attn_weights, features

@@ -55,7 +55,7 @@ def _worker(rank, world, port, out):
     try:
         from training_builder.base_train_builder import BaseSingleNetworkTrainBuilder, strip_parallel_module
         torch.manual_seed(0)
-        builder = BaseSingleNetworkTrainBuilder({"fine_tune": None, "bucket_cap_mb": 1}, rank=rank, world_size=world)
+        builder = BaseSingleNetworkTrainBuilder({"fine_tune": None, "bucket_cap_mb": 1}, rank=rank, world_size=world, build=False)
         net = _TinySegmenter()
         with torch.no_grad():
             net.mu.fill_(float(rank))  # per-rank buffer must survive (broadcast_buffers=False)
