@@ -65,3 +65,27 @@ def test_make_image_u8(device):
     assert (got.int() - ref.int()).abs().max().item() <= 1  # (x+1)/2*255 may round across an integer boundary
     assert (got == ref).float().mean() > 0.999
     assert got[0, 0, 0].tolist() == [0, 255, 127]
+
+
+def test_create_dataset_loop_shards_and_writes(device, tmp_path):
+    """Hot loop of create_dataset_for_segmentation.py on a small generator: two 'ranks' cover disjoint id ranges,
+    files land in the reference's directory layout, PNG = [image | label] side by side."""
+    import argparse
+    import numpy as np
+    from PIL import Image
+    import create_dataset_for_segmentation as cds
+    centres = tmp_path / "c.npy"
+    np.save(centres, np.random.RandomState(0).standard_normal((5, 512)).astype(np.float32))
+    cfg = {"image_size": 32, "latent_size": 512, "n_mlp": 2, "seed": 3, "catalogs": {"7": str(centres)}, "label_layer": 7}
+    args = argparse.Namespace(checkpoint=None, config=None, num_images=7, save_to=str(tmp_path / "out"), batch_size=3,
+                              truncate=True)
+    torch.manual_seed(0)
+    d0, r0 = cds.build_dataset(args, cfg, rank=0, world_size=2)
+    d1, r1 = cds.build_dataset(args, cfg, rank=1, world_size=2)
+    assert (r0, r1) == ((0, 4), (4, 7)) and d0 == 4 and d1 == 3
+    files = sorted((tmp_path / "out").rglob("*.png"))
+    assert [f.name for f in files] == [f"{i:04d}.png" for i in range(7)]
+    assert files[0].parent.name == "0" and files[0].parent.parent.name == "0"
+    im = np.asarray(Image.open(files[5]))
+    assert im.shape == (32, 64, 3) and im.dtype == np.uint8
+    assert set(np.unique(im[:, 32:])) <= {0, 63, 127, 191, 255}
