@@ -369,7 +369,6 @@ typedef V2Cfg<0, 1, 2, 2, 2, 4, 2> Conv1A;
 typedef V2Cfg<1, 3, 1, 4, 2, 1, 2> UpA;      // 256 thr, 64 co x 128 pos, wave 64 co x 32 pos x 4 phases
 typedef V2Cfg<1, 3, 2, 4, 1, 1, 4> UpB;      // 512 thr, 64 co x 128 pos, wave 32 co x 32 pos x 4 phases
 typedef V2Cfg<1, 3, 1, 8, 2, 1, 2> UpC;      // 512 thr, 64 co x 256 pos, wave 64 co x 32 pos x 4 phases
-typedef V2Cfg<1, 3, 1, 8, 1, 1, 4, 16> UpD;  // 512 thr, 32 co x 256 pos, 16-channel chunks (half the barriers per MFMA)
 
 int modconv_v2_tile(int mode, int* mblk, int* npos) {
     static int cfg = -1;
@@ -379,14 +378,12 @@ int modconv_v2_tile(int mode, int* mblk, int* npos) {
     }
     const int c = mode == 0 ? cfg / 10 : cfg % 10;
     if (mode == 0) { *mblk = 128; *npos = 256; }
-    else { *mblk = c == 3 ? 32 : 64; *npos = (c == 2 || c == 3) ? 256 : 128; }
+    else { *mblk = 64; *npos = c == 2 ? 256 : 128; }
     return c;
 }
 
 int modconv_v2_launch(ConvParams& p, int mode, int ks, hipStream_t st, void* workspace, int64_t workspace_bytes) {
-    int mblk0, npos0;
-    const int cfg0 = modconv_v2_tile(mode, &mblk0, &npos0);
-    const int cc = mode == 0 ? V2<0>::CC : (cfg0 == 3 ? 16 : V2<1>::CC);
+    const int cc = mode == 0 ? V2<0>::CC : V2<1>::CC;  // (16-channel chunks for the transposed kernel measured 2x slower)
     if (p.Cin % cc != 0 || !p.cout_vec4 || (((uintptr_t)p.x | (uintptr_t)p.wpk) & 15) != 0 || p.W % 4 != 0) return -1;
     for (int c = 0; c < p.ncls; ++c)
         if (p.cls[c].w0 % 4 != 0) return -1;
@@ -398,7 +395,6 @@ int modconv_v2_launch(ConvParams& p, int mode, int ks, hipStream_t st, void* wor
     if (mode == 0 && ks == 3) return c == 1 ? launch_v2<0, 3, Conv3B>(p, st) : launch_v2<0, 3, Conv3A>(p, st);
     if (mode == 0 && ks == 1) return launch_v2<0, 1, Conv1A>(p, st);
     if (mode == 1 && ks == 3)
-        return c == 1 ? launch_v2<1, 3, UpB>(p, st) : c == 2 ? launch_v2<1, 3, UpC>(p, st)
-               : c == 3 ? launch_v2<1, 3, UpD>(p, st) : launch_v2<1, 3, UpA>(p, st);
+        return c == 1 ? launch_v2<1, 3, UpB>(p, st) : c == 2 ? launch_v2<1, 3, UpC>(p, st) : launch_v2<1, 3, UpA>(p, st);
     return -1;
 }
