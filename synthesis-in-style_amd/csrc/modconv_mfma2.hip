@@ -67,8 +67,13 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
     const int wn = wave % C::WN;
     const int wbase = tid & ~63;  // wave-uniform: LDS-DMA destinations are base + lane * size
 
-    int pt = blockIdx.x % p.npos_tiles;
-    const int o0 = (blockIdx.x / p.npos_tiles) * C::MBLK;
+    // XCD-aware order: output-channel block fastest.  Workgroups are dealt round-robin over the 8 XCDs, so with
+    // n_co = Cout / MBLK in {2,4,8} every XCD keeps working on the same weight slice (<= 2.4 MB: stays in its
+    // 4 MiB L2) while the n_co workgroups that share an input tile run at the same time on different XCDs
+    // (one HBM read, the rest MALL hits).  Pixel-tile-fastest order measured a 48 % L2 miss rate on this kernel.
+    const int n_co = (p.Cout + C::MBLK - 1) / C::MBLK;
+    int pt = blockIdx.x / n_co;
+    const int o0 = (blockIdx.x % n_co) * C::MBLK;
     int ci_cls = 0;
 #pragma unroll
     for (int c = 1; c < MC_MAX_CLS; ++c)

@@ -80,8 +80,13 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams
     const int q = __builtin_amdgcn_readfirstlane(wave & 1), wn = (wave >> 1) & 1, wm = wave >> 2;
     const int wbase = tid & ~63;
 
-    int pt = blockIdx.x % p.npos_tiles;
-    const int o0 = (blockIdx.x / p.npos_tiles) * WMBLK;
+    // XCD-aware order: output-channel block fastest.  Workgroups are dealt round-robin over the 8 XCDs, so with
+    // n_co = Cout / MBLK in {2,4,8} every XCD keeps working on the same weight slice (<= 2.4 MB: stays in its
+    // 4 MiB L2) while the n_co workgroups that share an input tile run at the same time on different XCDs
+    // (one HBM read, the rest MALL hits).  Pixel-tile-fastest order measured a 48 % L2 miss rate on this kernel.
+    const int n_co = (p.Cout + WMBLK - 1) / WMBLK;
+    int pt = blockIdx.x / n_co;
+    const int o0 = (blockIdx.x % n_co) * WMBLK;
     const TileClass tc = p.cls[0];
     const int twi = pt % tc.ntw; pt /= tc.ntw;
     const int thi = pt % tc.nth;

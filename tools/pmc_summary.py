@@ -13,7 +13,7 @@ for d in sorted(glob.glob(base + "/p*/")):
     for r in csv.DictReader(open(f[0])):
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, cs in acc.items():
-        if "modconv_v2" not in k and "modconv_mfma" not in k and len(sys.argv) < 3:
+        if "modconv_" not in k and len(sys.argv) < 3:
             continue
         ds = dur.get(k, [0])
         print(f"{d} {k[:70]} n={len(ds)} avg_us={sum(ds)/len(ds)/1e3:.1f}")
