@@ -269,6 +269,239 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams
     }
 }
 
+// Pipelined variant (default when its 158 KB of LDS fit): the input transform is done ONCE per (channel, tile) --
+// one patch per lane per chunk, 512 lanes = 8 channels x 64 tiles -- into a second LDS image V[xi][channel][tile],
+// one chunk ahead of the MFMAs, so the matrix loop is nothing but ds_read_b32 pairs and MFMAs (in the kernel above
+// every patch is re-read and re-transformed by the 4 waves that share it: 48.5 % MFMA-busy measured).  Per
+// iteration c: DMA weights(c+1), DMA input(c+2), transform(c+1) -> V, MFMA(c); one barrier.
+__global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParams p, const int xt_max) {
+    constexpr int WF = WCC * 16 * WMBLK;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int VF = 16 * WCC * WTILES;  // transformed input of one chunk: [xi][channel][tile]
+    float* Ul = lds;                    // [2][WF]   (64 KB; reused for the column exchange in the epilogue)
+    float* Vl = lds + 2 * WF;           // [2][VF]   (64 KB)
+    float* Xl = Vl + 2 * VF;            // [2][WCC * xt]
+    float* Sl = Xl + 2 * WCC * xt_max;  // [nb][Cin]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int q = __builtin_amdgcn_readfirstlane(wave & 1), wn = (wave >> 1) & 1, wm = wave >> 2;
+    const int wbase = tid & ~63;
+
+    // XCD-aware order: output-channel block fastest.  Workgroups are dealt round-robin over the 8 XCDs, so with
+    // n_co = Cout / MBLK in {2,4,8} every XCD keeps working on the same weight slice (<= 2.4 MB: stays in its
+    // 4 MiB L2) while the n_co workgroups that share an input tile run at the same time on different XCDs
+    // (one HBM read, the rest MALL hits).  Pixel-tile-fastest order measured a 48 % L2 miss rate on this kernel.
+    const int n_co = (p.Cout + WMBLK - 1) / WMBLK;
+    int pt = blockIdx.x / n_co;
+    const int o0 = (blockIdx.x % n_co) * WMBLK;
+    const TileClass tc = p.cls[0];
+    const int twi = pt % tc.ntw; pt /= tc.ntw;
+    const int thi = pt % tc.nth;
+    const int bt = pt / tc.nth;
+    const int thl = tc.th_log2, twl = tc.tw_log2;
+    const int th = 1 << thl, tw = 1 << twl;
+    const int b0 = bt * tc.nb, h0 = thi << thl, w0 = twi << twl;
+    // staged input tile: rows h0-1 .. h0+th, columns w0-4 .. w0+tw+3 (16-byte aligned superset of the 1-pixel
+    // halo: W and w0 are multiples of 4, so every aligned float4 is entirely inside or entirely outside the image)
+    const int eh = th + 2, ew = tw + 8;
+    const int xt = tc.xt;
+    const int HW = p.H * p.W;
+    const int k_lo = blockIdx.y * p.kchunk;
+    const int k_hi = min(p.Cin, k_lo + p.kchunk);
+
+    for (int e = tid; e < 2 * WCC * xt; e += WNTHR) Xl[e] = 0.f;
+    for (int e = tid; e < tc.nb * p.Cin; e += WNTHR) {
+        const int n = e / p.Cin, ci = e - n * p.Cin;
+        Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
+    }
+    // one float4 chunk of the tile per lane per channel (<= 512 chunks: host-checked)
+    const int tpl0 = thl + twl - 2;  // log2(tiles per sample)
+    int st_goff = -1;
+    {
+        const int ew4 = ew >> 2;
+        if (tid < (xt >> 2)) {
+            const int n = tid / (eh * ew4), rem = tid - n * (eh * ew4);
+            const int r = rem / ew4, c4 = rem - r * ew4;
+            const int b = b0 + n, h = h0 - 1 + r, w = w0 - 4 + 4 * c4;
+            if (b < p.B && h >= 0 && h < p.H && w >= 0 && w < p.W) st_goff = b * p.Cin * HW + h * p.W + w;
+        }
+    }
+    constexpr int WV4 = WF / 4, WIT = WV4 / WNTHR;  // 4 float4 per lane per chunk
+    int w_goff[WIT];
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+        const int e = it * WNTHR + tid;
+        const int row = e / (WMBLK / 4), qq = e - row * (WMBLK / 4);
+        w_goff[it] = (o0 + qq * 4 < p.Cout) ? row * p.Cout + o0 + qq * 4 : -1;
+    }
+    auto stage_u = [&](int ci0, int buf) {
+        const float* usrc = p.wpk + (int64_t)ci0 * 16 * p.Cout;
+        float* udst = Ul + buf * WF + wbase * 4;
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            if (w_goff[it] >= 0) glds16(usrc + w_goff[it], udst + it * WNTHR * 4);
+    };
+    auto stage_x = [&](int ci0, int buf) {
+        const float* xsrc = p.x + (int64_t)ci0 * HW;
+        float* xdst = Xl + buf * WCC * xt + wbase * 4;
+        if (st_goff >= 0) {
+#pragma unroll
+            for (int j = 0; j < WCC; ++j) glds16(xsrc + st_goff + j * HW, xdst + j * xt);
+        }
+    };
+    // Input transform, ONE patch per lane per chunk: lane = tile (0..63), wave = channel of the chunk.  V = B^T d B
+    // scaled by the style of the tile's sample, written as [xi][channel][tile] (lane-contiguous ds_write_b32).
+    const int ttile = lane, tch = wave;
+    const int ttn = ttile >> tpl0, ttrem = ttile & ((1 << tpl0) - 1);
+    const int tty = ttrem >> (twl - 1), ttx = ttrem & ((tw >> 1) - 1);
+    const int txo = min(ttn, tc.nb - 1) * eh * ew + 2 * tty * ew + 2 * ttx + 2 + tch * xt;
+    const int tso = min(ttn, tc.nb - 1) * p.Cin + tch;
+    auto transform = [&](int ci0, int xbuf, int vbuf) {
+        const float sv = Sl[tso + ci0];
+        const float* xb = Xl + xbuf * WCC * xt + txo;
+        float d[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float2 a0 = *reinterpret_cast<const float2*>(xb + r * ew);
+            const float2 a1 = *reinterpret_cast<const float2*>(xb + r * ew + 2);
+            const float2 a2 = *reinterpret_cast<const float2*>(xb + r * ew + 4);
+            d[r][0] = a0.y * sv; d[r][1] = a1.x * sv; d[r][2] = a1.y * sv; d[r][3] = a2.x * sv;
+        }
+        float tt[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            tt[0][c] = d[0][c] - d[2][c];
+            tt[1][c] = d[1][c] + d[2][c];
+            tt[2][c] = d[2][c] - d[1][c];
+            tt[3][c] = d[1][c] - d[3][c];
+        }
+        float* vb = Vl + vbuf * VF + tch * WTILES + ttile;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            vb[(r * 4 + 0) * WCC * WTILES] = tt[r][0] - tt[r][2];
+            vb[(r * 4 + 1) * WCC * WTILES] = tt[r][1] + tt[r][2];
+            vb[(r * 4 + 2) * WCC * WTILES] = tt[r][2] - tt[r][1];
+            vb[(r * 4 + 3) * WCC * WTILES] = tt[r][1] - tt[r][3];
+        }
+    };
+
+    const int tpl = tpl0;
+    const int t = wn * 32 + l31;
+    const int tn = t >> tpl, trem = t & ((1 << tpl) - 1);
+    const int ty = trem >> (twl - 1), tx = trem & ((tw >> 1) - 1);
+    const int aoff = half * 16 * WMBLK + wm * 32 + l31 + 2 * q * WMBLK;  // + (4 i + jj) * WMBLK
+
+    f32x16 acc[4][2];  // [row i of M][column jj of this wave's pair]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[i][jj][j] = 0.f;
+
+    // B operand of this lane in the V image: [xi][channel 2cp + half][tile wn*32 + l31]
+    const int voff = half * WTILES + wn * 32 + l31 + 2 * q * WCC * WTILES;  // + (4 i + jj) * WCC*WTILES + 2cp*WTILES
+
+    __syncthreads();
+    stage_u(k_lo, 0);
+    stage_x(k_lo, 0);
+    __syncthreads();  // chunk 0 landed
+    if (k_lo + WCC < k_hi) stage_x(k_lo + WCC, 1);
+    transform(k_lo, 0, 0);
+    __syncthreads();  // V(0) visible, X(1) landed
+
+    const bool late_transform = __builtin_amdgcn_readfirstlane(wave) >= 4;
+    int c = 0;
+    for (int ci0 = k_lo; ci0 < k_hi; ci0 += WCC, ++c) {
+        const int cur = c & 1, nxt = cur ^ 1;
+        if (ci0 + WCC < k_hi) stage_u(ci0 + WCC, nxt);          // weights lead by one chunk
+        if (ci0 + 2 * WCC < k_hi) stage_x(ci0 + 2 * WCC, cur);   // input leads by two (its transform sits in between)
+        // Stagger the two waves that share a SIMD (waves w and w+4): one transforms first and multiplies second, its
+        // partner the other way round, so the matrix pipe is not left idle while both do their transform.
+        if (!late_transform && ci0 + WCC < k_hi) transform(ci0 + WCC, nxt, nxt);
+        const float* Ub = Ul + cur * WF + aoff;
+        const float* Vb = Vl + cur * VF + voff;
+#pragma unroll
+        for (int cp = 0; cp < WCC / 2; ++cp) {
+            const float* ub = Ub + 2 * cp * 16 * WMBLK;
+            const float* vb = Vb + 2 * cp * WTILES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[(4 * i) * WMBLK], vb[(4 * i) * WCC * WTILES], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[(4 * i + 1) * WMBLK], vb[(4 * i + 1) * WCC * WTILES], acc[i][1], 0, 0, 0);
+            }
+        }
+        if (late_transform && ci0 + WCC < k_hi) transform(ci0 + WCC, nxt, nxt);
+        __syncthreads();  // V(c+1) written, DMA retired, everyone done with U(c) / V(c)
+    }
+
+    // ---- epilogue.  m[r][jj] = (A^T M)[r][column 2q+jj];  Y[r][0] = m0 + m1 + m2,  Y[r][1] = m1 - m2 - m3.
+    // q = 0 contributes (m0 + m1, m1), q = 1 contributes (m2, -m2 - m3).
+    float part[16][4];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float m[2][2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            m[0][jj] = acc[0][jj][j] + acc[1][jj][j] + acc[2][jj][j];
+            m[1][jj] = acc[1][jj][j] - acc[2][jj][j] - acc[3][jj][j];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            part[j][2 * r] = q == 0 ? m[r][0] + m[r][1] : m[r][0];
+            part[j][2 * r + 1] = q == 0 ? m[r][1] : -m[r][0] - m[r][1];
+        }
+    }
+    float* xch = Ul + (wave >> 1) * (64 * 64);  // [16 j][4][64 lanes] per wave pair
+    if (q == 1) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xch[(j * 4 + e) * 64 + lane] = part[j][e];
+    }
+    __syncthreads();
+    if (q == 1) return;
+
+    const bool partial = p.ksplit > 1;
+    const int b = b0 + tn, oh = h0 + 2 * ty, ow = w0 + 2 * tx;
+    if (tn >= tc.nb || b >= p.B || oh >= p.H || ow >= p.W) return;
+    float nz[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!partial && p.fuse && p.noise) {
+        const float nw = p.noise_w[0];
+        const float* np = p.noise + (int64_t)b * p.noise_bstride + oh * p.W + ow;
+        nz[0] = nw * np[0]; nz[1] = nw * np[1]; nz[2] = nw * np[p.W]; nz[3] = nw * np[p.W + 1];
+    }
+    float* obase = (partial ? p.slab + (int64_t)blockIdx.y * p.B * p.Cout * HW : p.out) + (int64_t)b * p.Cout * HW +
+                   oh * p.W + ow;
+    const float* db = p.dscale + (int64_t)b * p.Cout;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int co = o0 + wm * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
+        if (co >= p.Cout) continue;
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = part[j][e] + xch[(j * 4 + e) * 64 + lane];
+        if (!partial) {
+            const float dd = db[co];
+            const float bb = (p.fuse && p.bias) ? p.bias[co] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float val = y[e] * dd;
+                if (p.fuse) {
+                    val += nz[e];
+                    val += bb;
+                    val = (val > 0.f ? val : val * 0.2f) * 1.4142135623730951f;
+                }
+                y[e] = val;
+            }
+        }
+        float* oc = obase + (int64_t)co * HW;
+        *reinterpret_cast<float2*>(oc) = make_float2(y[0], y[1]);
+        *reinterpret_cast<float2*>(oc + p.W) = make_float2(y[2], y[3]);
+    }
+}
+
 }  // namespace
 
 extern "C" int sis_modconv_prepack_wino(float* u, const float* w, int cout, int cin, void* stream) {
@@ -305,15 +538,23 @@ int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t 
         }
     }
     const size_t lds = (size_t)(2 * WCC * 16 * WMBLK + 2 * WCC * tc.xt + p.nb_max * p.Cin) * sizeof(float);
+    const size_t lds2 = lds + (size_t)2 * 16 * WCC * WTILES * sizeof(float);
     if (lds > 160 * 1024) return -1;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_wino_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_wino2_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return sis_fail("modconv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL(modconv_wino_kernel, dim3((unsigned)blocks, p.ksplit), dim3(WNTHR), lds, st, p, tc.xt);
+    static const bool pipelined = !(getenv("SIS_WINO_PIPE") && getenv("SIS_WINO_PIPE")[0] == '0');
+    if (pipelined && lds2 <= 160 * 1024)
+        hipLaunchKernelGGL(modconv_wino2_kernel, dim3((unsigned)blocks, p.ksplit), dim3(WNTHR), lds2, st, p, tc.xt);
+    else
+        hipLaunchKernelGGL(modconv_wino_kernel, dim3((unsigned)blocks, p.ksplit), dim3(WNTHR), lds, st, p, tc.xt);
     SIS_CHECK_LAUNCH("modconv_wino_kernel");
     if (p.ksplit > 1) modconv_splitk_finish_launch(p, st);
     return 0;
