@@ -31,6 +31,15 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+// 8-byte LDS read of two adjacent floats, typed as double on purpose: the compiler's wait-count pass puts
+// s_waitcnt vmcnt(0) in front of every LDS read it thinks may alias an in-flight LDS-DMA write, and type-based alias
+// info is what tells it otherwise -- float2 (a struct) aliases everything, which stalled every chunk on the DMA it
+// had just issued; float and double reads do not.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 lds_ld2(const float* p) {
+    const f32x2 d = *reinterpret_cast<const f32x2*>(p);
+    return make_float2(d.x, d.y);
+}
 __device__ __forceinline__ void glds4(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 4, 0, 0);
@@ -172,9 +181,9 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams
             float d[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {  // patch columns sit at odd offsets: three aligned 8-byte reads, middle 4 used
-                const float2 a0 = *reinterpret_cast<const float2*>(xb + r * ew);
-                const float2 a1 = *reinterpret_cast<const float2*>(xb + r * ew + 2);
-                const float2 a2 = *reinterpret_cast<const float2*>(xb + r * ew + 4);
+                const float2 a0 = lds_ld2(xb + r * ew);
+                const float2 a1 = lds_ld2(xb + r * ew + 2);
+                const float2 a2 = lds_ld2(xb + r * ew + 4);
                 d[r][0] = a0.y; d[r][1] = a1.x; d[r][2] = a1.y; d[r][3] = a2.x;
             }
             float tt[4][4];
@@ -310,11 +319,6 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     const int k_lo = blockIdx.y * p.kchunk;
     const int k_hi = min(p.Cin, k_lo + p.kchunk);
 
-    for (int e = tid; e < 2 * WCC * xt; e += WNTHR) Xl[e] = 0.f;
-    for (int e = tid; e < tc.nb * p.Cin; e += WNTHR) {
-        const int n = e / p.Cin, ci = e - n * p.Cin;
-        Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
-    }
     // one float4 chunk of the tile per lane per channel (<= 512 chunks: host-checked)
     const int tpl0 = thl + twl - 2;  // log2(tiles per sample)
     int st_goff = -1;
@@ -363,9 +367,9 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
         float d[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float2 a0 = *reinterpret_cast<const float2*>(xb + r * ew);
-            const float2 a1 = *reinterpret_cast<const float2*>(xb + r * ew + 2);
-            const float2 a2 = *reinterpret_cast<const float2*>(xb + r * ew + 4);
+            const float2 a0 = lds_ld2(xb + r * ew);
+            const float2 a1 = lds_ld2(xb + r * ew + 2);
+            const float2 a2 = lds_ld2(xb + r * ew + 4);
             d[r][0] = a0.y * sv; d[r][1] = a1.x * sv; d[r][2] = a1.y * sv; d[r][3] = a2.x * sv;
         }
         float tt[4][4];
@@ -403,13 +407,49 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     // B operand of this lane in the V image: [xi][channel 2cp + half][tile wn*32 + l31]
     const int voff = half * WTILES + wn * 32 + l31 + 2 * q * WCC * WTILES;  // + (4 i + jj) * WCC*WTILES + 2cp*WTILES
 
-    __syncthreads();
+    // ---- prologue: every global access of the start-up is in flight before the first wait (one memory round trip
+    // instead of three).  The DMA never writes out-of-image float4 slots, so the lanes owning such slots store the
+    // zeros themselves (disjoint from every DMA destination: no ordering needed).
     stage_u(k_lo, 0);
     stage_x(k_lo, 0);
-    __syncthreads();  // chunk 0 landed
     if (k_lo + WCC < k_hi) stage_x(k_lo + WCC, 1);
+    if (tid < (xt >> 2) && st_goff < 0) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 2 * WCC; ++j) *reinterpret_cast<float4*>(Xl + j * xt + tid * 4) = z;
+    }
+    for (int e = tid; e < tc.nb * p.Cin; e += WNTHR) {
+        const int n = e / p.Cin, ci = e - n * p.Cin;
+        Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
+    }
+    // layer-tail operands of the 8 accumulator rows this lane finalises (see the epilogue), fetched now so that
+    // the tail is not a chain of dependent global loads
+    const bool partial = p.ksplit > 1;
+    const int ob = b0 + tn, oh = h0 + 2 * ty, ow = w0 + 2 * tx;
+    const bool live = tn < tc.nb && ob < p.B && oh < p.H && ow < p.W;
+    float nz[4] = {0.f, 0.f, 0.f, 0.f};
+    float dd[8], bb[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) { dd[jj] = 1.f; bb[jj] = 0.f; }
+    if (live && !partial) {
+        if (p.fuse && p.noise) {
+            const float nw = p.noise_w[0];
+            const float* np = p.noise + (int64_t)ob * p.noise_bstride + oh * p.W + ow;
+            nz[0] = nw * np[0]; nz[1] = nw * np[1]; nz[2] = nw * np[p.W]; nz[3] = nw * np[p.W + 1];
+        }
+        const float* db = p.dscale + (int64_t)ob * p.Cout;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int co = o0 + wm * 32 + 16 * q + 4 * half + (jj & 3) + 8 * (jj >> 2);
+            if (co < p.Cout) {
+                dd[jj] = db[co];
+                if (p.fuse && p.bias) bb[jj] = p.bias[co];
+            }
+        }
+    }
+    __syncthreads();  // chunk 0 (and input chunk 1) landed, styles and zeros visible
     transform(k_lo, 0, 0);
-    __syncthreads();  // V(0) visible, X(1) landed
+    __syncthreads();  // V(0) visible
 
     const bool late_transform = __builtin_amdgcn_readfirstlane(wave) >= 4;
     int c = 0;
@@ -437,68 +477,68 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     }
 
     // ---- epilogue.  m[r][jj] = (A^T M)[r][column 2q+jj];  Y[r][0] = m0 + m1 + m2,  Y[r][1] = m1 - m2 - m3.
-    // q = 0 contributes (m0 + m1, m1), q = 1 contributes (m2, -m2 - m3).
-    float part[16][4];
+    // q = 0 contributes (m0 + m1, m1), q = 1 contributes (m2, -m2 - m3).  The two waves of a pair swap halves:
+    // wave q finalises accumulator rows j in [8q, 8q+8) and hands its partial sums of the other 8 rows to its
+    // partner through the (by now idle) weight staging LDS, so both run the layer tail and the stores.
+    float mine[8][4];
+    float* xch = Ul + (wave >> 1) * (64 * 64);  // [sender q][8 rows][4][64 lanes] per wave pair
+    auto reduce_and_send = [&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        float m[2][2];
+        for (int j = 0; j < 16; ++j) {
+            float m[2][2];
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            m[0][jj] = acc[0][jj][j] + acc[1][jj][j] + acc[2][jj][j];
-            m[1][jj] = acc[1][jj][j] - acc[2][jj][j] - acc[3][jj][j];
-        }
+            for (int jj = 0; jj < 2; ++jj) {
+                m[0][jj] = acc[0][jj][j] + acc[1][jj][j] + acc[2][jj][j];
+                m[1][jj] = acc[1][jj][j] - acc[2][jj][j] - acc[3][jj][j];
+            }
+            float pr[4];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            part[j][2 * r] = q == 0 ? m[r][0] + m[r][1] : m[r][0];
-            part[j][2 * r + 1] = q == 0 ? m[r][1] : -m[r][0] - m[r][1];
-        }
-    }
-    float* xch = Ul + (wave >> 1) * (64 * 64);  // [16 j][4][64 lanes] per wave pair
-    if (q == 1) {
+            for (int r = 0; r < 2; ++r) {
+                pr[2 * r] = Q == 0 ? m[r][0] + m[r][1] : m[r][0];
+                pr[2 * r + 1] = Q == 0 ? m[r][1] : -m[r][0] - m[r][1];
+            }
+            if ((j >> 3) == Q) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
+                for (int e = 0; e < 4; ++e) mine[j & 7][e] = pr[e];
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xch[(j * 4 + e) * 64 + lane] = part[j][e];
-    }
-    __syncthreads();
-    if (q == 1) return;
-
-    const bool partial = p.ksplit > 1;
-    const int b = b0 + tn, oh = h0 + 2 * ty, ow = w0 + 2 * tx;
-    if (tn >= tc.nb || b >= p.B || oh >= p.H || ow >= p.W) return;
-    float nz[4] = {0.f, 0.f, 0.f, 0.f};
-    if (!partial && p.fuse && p.noise) {
-        const float nw = p.noise_w[0];
-        const float* np = p.noise + (int64_t)b * p.noise_bstride + oh * p.W + ow;
-        nz[0] = nw * np[0]; nz[1] = nw * np[1]; nz[2] = nw * np[p.W]; nz[3] = nw * np[p.W + 1];
-    }
-    float* obase = (partial ? p.slab + (int64_t)blockIdx.y * p.B * p.Cout * HW : p.out) + (int64_t)b * p.Cout * HW +
-                   oh * p.W + ow;
-    const float* db = p.dscale + (int64_t)b * p.Cout;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int co = o0 + wm * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
-        if (co >= p.Cout) continue;
-        float y[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = part[j][e] + xch[(j * 4 + e) * 64 + lane];
-        if (!partial) {
-            const float dd = db[co];
-            const float bb = (p.fuse && p.bias) ? p.bias[co] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float val = y[e] * dd;
-                if (p.fuse) {
-                    val += nz[e];
-                    val += bb;
-                    val = (val > 0.f ? val : val * 0.2f) * 1.4142135623730951f;
-                }
-                y[e] = val;
+                for (int e = 0; e < 4; ++e) xch[(Q * 32 + (j & 7) * 4 + e) * 64 + lane] = pr[e];
             }
         }
-        float* oc = obase + (int64_t)co * HW;
-        *reinterpret_cast<float2*>(oc) = make_float2(y[0], y[1]);
-        *reinterpret_cast<float2*>(oc + p.W) = make_float2(y[2], y[3]);
+    };
+    if (q == 0) reduce_and_send(std::integral_constant<int, 0>());
+    else reduce_and_send(std::integral_constant<int, 1>());
+    __syncthreads();
+    if (!live) return;
+
+    float* obase = (partial ? p.slab + (int64_t)blockIdx.y * p.B * p.Cout * HW : p.out) + (int64_t)ob * p.Cout * HW +
+                   oh * p.W + ow;
+    const float* xin = xch + (1 - q) * 32 * 64 + lane;
+    const int co0 = o0 + wm * 32 + 16 * q + 4 * half;  // row j = 8 q + jj sits at co0 + (jj & 3) + 8 * (jj >> 2)
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int co = co0 + (jj & 3) + 8 * (jj >> 2);
+        if (co < p.Cout) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = mine[jj][e] + xin[(jj * 4 + e) * 64];
+            if (!partial) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float val = y[e] * dd[jj];
+                    if (p.fuse) {
+                        val += nz[e];
+                        val += bb[jj];
+                        val = (val > 0.f ? val : val * 0.2f) * 1.4142135623730951f;
+                    }
+                    y[e] = val;
+                }
+            }
+            float* oc = obase + (int64_t)co * HW;
+            *reinterpret_cast<float2*>(oc) = make_float2(y[0], y[1]);
+            *reinterpret_cast<float2*>(oc + p.W) = make_float2(y[2], y[3]);
+        }
     }
 }
 
