@@ -178,6 +178,21 @@ def bench_training(args, workload, world, rank, device, distributed):
     }
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` from the committed PMC passes (profiles/*traffic*.json, written by
+    tools/pmc_traffic.sh on the GPU box: counters cannot be collected from inside the timed process)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*traffic*.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        data = json.load(f)
+    for name, v in data.get("kernels", {}).items():
+        if name.split("<")[0] == kernel.split("<")[0] and name.count("1, 3") == kernel.count("1, 3"):
+            return v["traffic_bytes"], os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="synthesis", choices=["synthesis", "emanet", "transunet"])
@@ -250,8 +265,11 @@ def main():
         # "achieved" is ALGORITHMIC (direct-convolution) FLOP/s as SURVEY.md §8(d) defines the unit work; the MFMA
         # pipe itself runs at executed = achieved * 16/36.
         exec_ratio = 16.0 / 36.0 if "wino" in dom_name else 1.0
+        traffic, traffic_src = measured_traffic(dom_name)
         roofline = {"kernel": dom_name, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "bytes per launch (HBM-side, PMC)", "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                     "executed_tflops": round(achieved * exec_ratio, 2),
                     "executed_frac": round(achieved * exec_ratio / PEAK_MFMA_F32_TFLOPS, 4),
                     "launches_per_step": dom["launches"] // min(args.steps, 5),

@@ -28,6 +28,10 @@ extern "C" {
 /* library version (major*1000 + minor) and last error text of the calling thread */
 int sis_version(void);
 const char* sis_last_error(void);
+/* Name of the device kernel the calling thread's last sis_modconv2d / sis_modconv2d_up call dispatched to (the
+ * dispatch depends on shape and alignment); bench.py uses it so that its per-kernel timings carry the names
+ * rocprofv3 reports. */
+const char* sis_last_kernel(void);
 
 /* ------------------------------------------------------------------------------------------
  * K1  fused bias + activation.

@@ -271,6 +271,7 @@ int launch(ConvParams& p, hipStream_t st) {
     const size_t lds = (size_t)(C::WFLOATS + CC * xt_max) * sizeof(float);
     const int64_t blocks = (int64_t)p.npos_tiles * sis_cdiv(p.Cout, C::MBLK);
     SIS_REQUIRE(blocks > 0 && blocks < ((int64_t)1 << 31), "modconv: bad grid");
+    sis_kernel_name = MODE == 1 ? "modconv_mfma_kernel<1, 3>" : KS == 3 ? "modconv_mfma_kernel<0, 3>" : "modconv_mfma_kernel<0, 1>";
     hipLaunchKernelGGL((modconv_mfma_kernel<MODE, KS>), dim3((unsigned)blocks), dim3(256), lds, st, p);
     SIS_CHECK_LAUNCH("modconv_mfma_kernel");
     return 0;

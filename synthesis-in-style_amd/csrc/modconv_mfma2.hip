@@ -330,6 +330,7 @@ int launch_v2(ConvParams& p, hipStream_t st) {
     }
     const int64_t bx = (int64_t)p.npos_tiles * sis_cdiv(p.Cout, C::MBLK);
     SIS_REQUIRE(bx > 0 && bx < ((int64_t)1 << 31), "modconv: bad grid");
+    sis_kernel_name = MODE == 1 ? "modconv_v2_kernel<1, 3>" : KS == 3 ? "modconv_v2_kernel<0, 3>" : "modconv_v2_kernel<0, 1>";
     hipLaunchKernelGGL((modconv_v2_kernel<MODE, KS, C>), dim3((unsigned)bx, p.ksplit), dim3(C::THREADS), lds, st, p, xt_max);
     SIS_CHECK_LAUNCH("modconv_v2_kernel");
     if (p.ksplit > 1) {

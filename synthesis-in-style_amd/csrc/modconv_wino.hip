@@ -591,10 +591,13 @@ int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t 
         attr_set = true;
     }
     static const bool pipelined = !(getenv("SIS_WINO_PIPE") && getenv("SIS_WINO_PIPE")[0] == '0');
-    if (pipelined && lds2 <= 160 * 1024)
+    if (pipelined && lds2 <= 160 * 1024) {
+        sis_kernel_name = "modconv_wino2_kernel";
         hipLaunchKernelGGL(modconv_wino2_kernel, dim3((unsigned)blocks, p.ksplit), dim3(WNTHR), lds2, st, p, tc.xt);
-    else
+    } else {
+        sis_kernel_name = "modconv_wino_kernel";
         hipLaunchKernelGGL(modconv_wino_kernel, dim3((unsigned)blocks, p.ksplit), dim3(WNTHR), lds, st, p, tc.xt);
+    }
     SIS_CHECK_LAUNCH("modconv_wino_kernel");
     if (p.ksplit > 1) modconv_splitk_finish_launch(p, st);
     return 0;

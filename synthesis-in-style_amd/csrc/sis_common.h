@@ -10,6 +10,7 @@
 #include "../../include/sis_hip.h"
 
 extern thread_local char sis_err_buf[512];
+extern thread_local const char* sis_kernel_name;  // device kernel the last sis_modconv2d* call dispatched to
 
 static inline int sis_fail(const char* fmt, ...) {
     va_list ap;

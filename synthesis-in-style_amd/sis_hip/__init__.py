@@ -40,6 +40,7 @@ _SIGNATURES = {
     "sis_modconv_demod": ([_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp], _i),
     "sis_modconv2d": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 7 + [_vp, _vp, _i64, _vp], _i),
     "sis_modconv_prepack_wino": ([_vp, _vp, _i, _i, _vp], _i),
+    "sis_last_kernel": ([], ctypes.c_char_p),
     "sis_modconv2d_up": ([_vp] * 5 + [_i] * 6 + [_vp, _i64, _vp], _i),
     "sis_blur_noise_act": ([_vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 10 + [_vp], _i),
     "sis_to_rgb": ([_vp] * 7 + [_i] * 9 + [_f, _vp], _i),
@@ -96,6 +97,8 @@ def _launch(kernel, flops, nbytes, call):
     e0.record()
     rc = call()
     e1.record()
+    if kernel is None:  # convolutions: the library picks the kernel by shape / alignment and reports its name
+        kernel = lib().sis_last_kernel().decode()
     _prof.append((kernel, flops, nbytes, e0, e1))
     return rc
 
@@ -311,7 +314,7 @@ def modconv2d(x, wpk, s, dscale, ksize, noise=None, noise_weight=None, bias=None
     ws = _workspace(x.device)
     wino = wino_u is not None and ksize == 3 and h % 2 == 0 and w % 2 == 0 and cin % 8 == 0 and cout % 4 == 0
     with torch.cuda.device(x.device):
-        _check(_launch("modconv_wino_kernel" if wino else f"modconv_v2_kernel<0, {ksize}>",
+        _check(_launch(None,
                        2.0 * batch * cout * cin * ksize * ksize * h * w,
                        4.0 * (x.numel() + out.numel() + wpk.numel()),
                        lambda: lib().sis_modconv2d(_ptr(out), _ptr(x), _ptr(wpk), _ptr(s), _ptr(dscale), _ptr(noise),
@@ -331,7 +334,7 @@ def modconv2d_up(x, wpk, s, dscale, padded_rows=False):
     out = torch.empty((batch, cout, 2 * h + 1, row), dtype=torch.float32, device=x.device)
     ws = _workspace(x.device)
     with torch.cuda.device(x.device):
-        _check(_launch("modconv_v2_kernel<1, 3>", 2.0 * batch * cout * cin * 9 * h * w,
+        _check(_launch(None, 2.0 * batch * cout * cin * 9 * h * w,
                        4.0 * (x.numel() + out.numel() + wpk.numel()),
                        lambda: lib().sis_modconv2d_up(_ptr(out), _ptr(x), _ptr(wpk), _ptr(s), _ptr(dscale), batch, cin,
                                                       cout, h, w, row, _ptr(ws), ws.numel(), _stream())),
