@@ -188,7 +188,7 @@ def measured_traffic(kernel):
     with open(files[-1]) as f:
         data = json.load(f)
     for name, v in data.get("kernels", {}).items():
-        if name.split("<")[0] == kernel.split("<")[0] and name.count("1, 3") == kernel.count("1, 3"):
+        if name == kernel or name.startswith(kernel.rstrip(">") + ","):
             return v["traffic_bytes"], os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))
     return None, None
 
