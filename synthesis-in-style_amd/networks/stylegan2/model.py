@@ -40,6 +40,8 @@ from torch.nn import functional as F
 import sis_hip
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 
+_RGB_STREAMS = {}  # device -> side stream of the ToRGB chain (process-wide: streams are not copyable module state)
+
 
 def _needs_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
@@ -393,6 +395,14 @@ class Generator(nn.Module):
         return all(m.conv.hip_supported() and m.conv.modulation.lr_mul == 1 and m.conv.modulation.activation is None
                    for m, _ in self._layer_sequence())
 
+    def _rgb_stream(self, device):
+        """Side stream of the ToRGB chain (one per device, created on first use; SIS_RGB_STREAM=0 disables it)."""
+        if os.environ.get("SIS_RGB_STREAM", "1") == "0":
+            return None
+        if device not in _RGB_STREAMS:
+            _RGB_STREAMS[device] = torch.cuda.Stream(device=device)
+        return _RGB_STREAMS[device]
+
     def _modulate_all(self, latent):
         """Every layer's s [B,Cin] (and scale*demod [B,Cout] for the styled convs): two launches in total."""
         latent = latent.contiguous()
@@ -440,9 +450,22 @@ class Generator(nn.Module):
         tap(0, out)
         if self._fast_path(latent):
             s, d = self._modulate_all(latent)
+            # The ToRGB / skip chain only reads each resolution's activation: it runs on a side stream so that its
+            # HBM-bound passes overlap the MFMA-bound convolutions of the next resolution.
+            main, side = torch.cuda.current_stream(latent.device), self._rgb_stream(latent.device)
+
+            def rgb_branch(layer, x, style, prev):
+                if side is None:
+                    return layer.forward_s(x, style, prev)
+                ready = main.record_event()
+                x.record_stream(side)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    return layer.forward_s(x, style, prev)
+
             out = self.conv1.forward_s(out, self.conv1.conv.packed_weights()[0], s[0], d[0], noise[0])
             tap(1, out)
-            skip = self.to_rgb1.forward_s(out, s[1])
+            skip = rgb_branch(self.to_rgb1, out, s[1], None)
             for r in range(self.log_size - 2):
                 i, j = 1 + 2 * r, 2 + 3 * r
                 up, conv, rgb = self.convs[2 * r], self.convs[2 * r + 1], self.to_rgbs[r]
@@ -450,7 +473,9 @@ class Generator(nn.Module):
                 tap(i + 1, out)
                 out = conv.forward_s(out, conv.conv.packed_weights()[0], s[j + 1], d[j + 1], noise[2 + 2 * r])
                 tap(i + 2, out)
-                skip = rgb.forward_s(out, s[j + 2], skip)
+                skip = rgb_branch(rgb, out, s[j + 2], skip)
+            if side is not None:
+                main.wait_event(side.record_event())
             if return_latents:
                 return skip, latent
             return (skip, acts) if return_intermediate_activations else (skip, None)

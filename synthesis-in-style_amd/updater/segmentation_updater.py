@@ -68,7 +68,12 @@ class TransUNetUpdater(Updater):
         network = self.networks['segmentation']
 
         with GradientApplier([network], [self.optimizers['main']]):
-            prediction = network(batch['images'])
+            # bf16 autocast covers the network only (GEMMs / convolutions / attention on the bf16 matrix cores,
+            # fp32 master weights, fp32 SGD); the losses are evaluated on fp32 logits as in the reference.
+            with torch.autocast(device_type='cuda', dtype=self.amp_dtype or torch.bfloat16,
+                                enabled=self.amp_dtype is not None):
+                prediction = network(batch['images'])
+            prediction = prediction.float()
             ground_truth = torch.squeeze(batch['segmented'], dim=1)
             loss_ce = self.ce_loss(prediction, ground_truth.long())
             loss_dice = self.dice_loss(prediction, ground_truth, softmax=True)
