@@ -170,7 +170,8 @@ def bench_training(args, workload, world, rank, device, distributed):
         "config": {"workload": f"{config['network']} training step, {config['image_size']}x{config['image_size']}, batch "
                                f"{config['batch_size']} per GPU (BASELINE.json configs[{3 if workload == 'emanet' else 4}])",
                    "batch_per_gpu": config["batch_size"], "image_size": config["image_size"],
-                   "parallelism": f"dp{world}, DDP bucketed all-reduce over RCCL"},
+                   "parallelism": f"dp{world}, DDP bucketed all-reduce over RCCL",
+                   "hip_graph": bool(getattr(updater, "_step_graph", None) and updater._step_graph.graph is not None)},
         "roofline": {"kernel": "whole step (convolutions on ROCm libraries this round)", "bound": "mfma",
                      "achieved": round(tf, 2), "peak": 2500.0 if config.get("amp") else PEAK_MFMA_F32_TFLOPS,
                      "unit": "TFLOP/s",

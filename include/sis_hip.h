@@ -180,6 +180,11 @@ int sis_sgd_chunk_elems(void);
 int sis_sgd_momentum(const int64_t* table, int n_chunks, const float* lr, const float* weight_decay,
                      int n_groups, float momentum, int first_step, void* stream);
 
+/* The same step (not the first one: momentum buffers exist) with the hyper-parameters in DEVICE memory,
+ * hyper = {lr[0..3], weight_decay[0..3], momentum}: the launch carries only pointers, so it can be captured in a
+ * hipGraph and still follow a per-iteration LR schedule (the host rewrites `hyper` between replays). */
+int sis_sgd_momentum_dev(const int64_t* table, int n_chunks, const float* hyper, void* stream);
+
 /* emau.mu[i] = mu[i]*momentum + mean_b(mu_batch[b,i])*one_minus_momentum
  * (updater/segmentation_updater.py:56-66; in-place on the buffer, outside autograd). */
 int sis_ema_update(float* mu, const float* mu_batch, float momentum, float one_minus_momentum,

@@ -155,6 +155,25 @@ __global__ __launch_bounds__(256) void sgd_kernel(const int64_t* __restrict__ ta
     }
 }
 
+// Same update with the hyper-parameters read from device memory: hyper = {lr[4], wd[4], momentum}.  Nothing but
+// pointers in the kernel arguments, so a captured launch (hipGraph) follows the LR schedule on replay.
+__global__ __launch_bounds__(256) void sgd_dev_kernel(const int64_t* __restrict__ table, const float* __restrict__ hyper) {
+    const int64_t* row = table + (int64_t)blockIdx.x * 4;
+    float* __restrict__ p = reinterpret_cast<float*>(row[0]);
+    const float* __restrict__ gr = reinterpret_cast<const float*>(row[1]);
+    float* __restrict__ buf = reinterpret_cast<float*>(row[2]);
+    const int n = (int)(row[3] & 0xffffffffll), grp = (int)(row[3] >> 48);
+    const float lr = hyper[grp], wd = hyper[4 + grp], momentum = hyper[8];
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float pv = p[i];
+        float d = gr[i];
+        if (wd != 0.f) d += wd * pv;
+        const float bv = momentum * buf[i] + d;
+        buf[i] = bv;
+        p[i] = pv - lr * bv;
+    }
+}
+
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ mu, const float* __restrict__ mu_b, float mom,
                                                   float one_minus, int batch, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -226,6 +245,14 @@ extern "C" int sis_sgd_momentum(const int64_t* table, int n_chunks, const float*
     g.momentum = momentum; g.first = first_step;
     hipLaunchKernelGGL(sgd_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, g);
     SIS_CHECK_LAUNCH("sgd_kernel");
+    return 0;
+}
+
+extern "C" int sis_sgd_momentum_dev(const int64_t* table, int n_chunks, const float* hyper, void* stream) {
+    if (n_chunks <= 0) return 0;
+    SIS_REQUIRE(table && hyper, "sis_sgd_momentum_dev: null pointer");
+    hipLaunchKernelGGL(sgd_dev_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, hyper);
+    SIS_CHECK_LAUNCH("sgd_dev_kernel");
     return 0;
 }
 

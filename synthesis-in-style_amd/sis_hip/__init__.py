@@ -49,6 +49,7 @@ _SIGNATURES = {
     "sis_upsample_ce_bwd": ([_vp] * 4 + [_i] * 6 + [_i64, _vp], _i),
     "sis_sgd_chunk_elems": ([], _i),
     "sis_sgd_momentum": ([_vp, _i, ctypes.POINTER(_f), ctypes.POINTER(_f), _i, _f, _i, _vp], _i),
+    "sis_sgd_momentum_dev": ([_vp, _i, _vp, _vp], _i),
     "sis_ema_update": ([_vp, _vp, _f, _f, _i, _i, _vp], _i),
     "sis_bn_workspace_floats": ([_i, _i, _i], _i64),
     "sis_bn_stats": ([_vp] * 6 + [_i, _i, _i, _f, _f, _vp], _i),
@@ -425,6 +426,12 @@ def sgd_momentum(table, n_chunks, lrs, wds, momentum, first_step):
     with torch.cuda.device(table.device):
         _check(lib().sis_sgd_momentum(_ptr(table), n_chunks, arr(*lrs), arr(*wds), n, float(momentum),
                                       int(bool(first_step)), _stream()), "sis_sgd_momentum")
+
+
+def sgd_momentum_dev(table, n_chunks, hyper):
+    """Capturable variant: lr[4], wd[4], momentum are read from the device tensor ``hyper`` (float32[9])."""
+    with torch.cuda.device(table.device):
+        _check(lib().sis_sgd_momentum_dev(_ptr(table), n_chunks, _ptr(hyper), _stream()), "sis_sgd_momentum_dev")
 
 
 def ema_update(mu, mu_batch, momentum):

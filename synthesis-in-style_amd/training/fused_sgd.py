@@ -9,6 +9,11 @@ with numpy whenever gradient storage moved (one 20 KB pinned, non-blocking copy)
 ``zero_grad(set_to_none=True)`` the cheap default: no 178 fill kernels, and autograd assigns fresh gradients instead
 of launching 178 accumulate-adds into stale ones (measured 1.8 ms of a 45 ms EMANet-50 step).  With
 DistributedDataParallel(gradient_as_bucket_view=True) gradients live in the buckets and never move.
+
+hipGraph capture (training/graph_step.py): when ``step()`` runs on a capturing stream it launches the variant
+that reads lr / weight decay / momentum from a 9-float device tensor (``sis_sgd_momentum_dev``), so the captured
+launch holds nothing but pointers; ``push_hyper()`` refreshes that tensor from ``param_groups`` before every replay
+and the per-iteration LR schedule keeps working.
 """
 import numpy as np
 import torch
@@ -31,6 +36,9 @@ class FusedSGD(Optimizer):
         self._table_key = None
         self._grad_key = None
         self._steps = 0
+        self._hyper = None        # device float32[9]: lr[4], wd[4], momentum (capturable step)
+        self._hyper_hosts = None  # pinned staging ring + the events guarding its reuse
+        self._capture_host = None  # pinned source of the pointer-table copy recorded in a captured step
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)
@@ -54,10 +62,37 @@ class FusedSGD(Optimizer):
         self._flip = 0
         self._table = torch.empty((self._n_chunks, 4), dtype=torch.int64, device=entries[0][1].device)
 
-    def _upload(self, entries):
+    def push_hyper(self):
+        """Copies the current lr / weight decay / momentum of ``param_groups`` into the device tensor the captured
+        step reads (non-blocking, from a ring of pinned buffers each guarded by an event)."""
+        device = self.param_groups[0]['params'][0].device
+        if self._hyper is None:
+            self._hyper = torch.zeros(9, dtype=torch.float32, device=device)
+            self._hyper_hosts = [[torch.zeros(9, dtype=torch.float32).pin_memory(), None] for _ in range(4)]
+            self._hyper_slot = 0
+        if self._table is not None and (self._capture_host is None or self._capture_host.shape[0] != self._n_chunks):
+            self._capture_host = torch.empty((self._n_chunks, 4), dtype=torch.int64).pin_memory()
+        self._hyper_slot = (self._hyper_slot + 1) % len(self._hyper_hosts)
+        slot = self._hyper_hosts[self._hyper_slot]
+        if slot[1] is not None:
+            slot[1].synchronize()  # only blocks when the host is a whole ring ahead of the device
+        host = slot[0].numpy()
+        host[:] = 0.0
+        for gi, group in enumerate(self.param_groups):
+            host[gi], host[4 + gi] = group['lr'], group['weight_decay']
+        host[8] = self.param_groups[0]['momentum']
+        self._hyper.copy_(slot[0], non_blocking=True)
+        slot[1] = torch.cuda.current_stream(device).record_event()
+
+    def _upload(self, entries, capturing=False):
         ptrs = np.asarray([(p.data_ptr(), g.data_ptr(), b.data_ptr()) for _, p, g, b in entries], dtype=np.int64)
-        self._flip ^= 1
-        pinned = self._hosts[self._flip]
+        if capturing:
+            # the captured copy node re-reads its source on every replay: it gets a buffer nothing else writes
+            # (allocated by push_hyper(): pinning memory is not allowed while a stream is capturing)
+            pinned = self._capture_host
+        else:
+            self._flip ^= 1
+            pinned = self._hosts[self._flip]
         host = pinned.numpy()
         host[:, :3] = ptrs[self._owner] + self._offset[:, None]
         host[:, 3] = self._count
@@ -92,10 +127,17 @@ class FusedSGD(Optimizer):
             self._layout(entries)
             self._table_key = static_key
             self._grad_key = None
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing and (fresh or self._hyper is None or self._capture_host is None):
+            raise RuntimeError("FusedSGD: capture needs one eager step() and a push_hyper() call first")
         grad_key = tuple(g.data_ptr() for _, _, g, _ in entries) + tuple(p.data_ptr() for _, p, _, _ in entries)
-        if grad_key != self._grad_key:
-            self._upload(entries)
-            self._grad_key = grad_key
+        if grad_key != self._grad_key or capturing:
+            self._upload(entries, capturing)
+            self._grad_key = None if capturing else grad_key
+        if capturing:
+            sis_hip.sgd_momentum_dev(self._table, self._n_chunks, self._hyper)
+            self._steps += 1
+            return loss
         lrs = [g['lr'] for g in self.param_groups]
         wds = [g['weight_decay'] for g in self.param_groups]
         sis_hip.sgd_momentum(self._table, self._n_chunks, lrs, wds, self.param_groups[0]['momentum'], fresh)

@@ -114,7 +114,8 @@ class BaseTrainBuilder:
     def get_updater(self):
         return self.updater_class(iterators={'images': self.train_data_loader}, networks=self.get_networks_for_updater(),
                                   optimizers=self.get_optimizers(), device=self.device(),
-                                  copy_to_device=(self.world_size == 1), **self.updater_options())
+                                  copy_to_device=(self.world_size == 1),
+                                  **{'hip_graph': self.config.get('hip_graph', True), **self.updater_options()})
 
     def get_snapshotter(self):
         if self.rank != 0:

@@ -10,12 +10,15 @@ Mirrors updater/segmentation_updater.py:42-106 of the reference: same class name
 MI355X specifics: the bases update is one HIP kernel (``sis_ema_update``), the EMANet loss tail is fused inside
 the network (networks/ema_net/network.py), the optimizer step is the one-launch ``FusedSGD`` the builders
 create, gradients are all-reduced by DistributedDataParallel over RCCL while backward is still running.
+Single-process training replays the whole iteration as a hipGraph after three eager iterations
+(training/graph_step.py; keyword ``hip_graph=False`` or SIS_STEP_GRAPH=0 keeps it eager).
 """
 import torch
 from torch import nn
 
 import sis_hip
 from networks.trans_u_net.utils import DiceLoss
+from training.graph_step import StepGraph
 from training.loop import GradientApplier, Updater, get_current_reporter
 
 
@@ -24,15 +27,39 @@ def _unwrap(network):
     return network.module if hasattr(network, 'module') and not hasattr(network, 'emau') else network
 
 
-class EMANetUpdater(Updater):
+def _graphable(network, optimizer, device):
+    """Whole-iteration capture is used for single-process training on a HIP device with the fused optimizer."""
+    if isinstance(network, nn.parallel.DistributedDataParallel) or not hasattr(optimizer, 'push_hyper'):
+        return False
+    return torch.device(device if not isinstance(device, int) else f'cuda:{device}').type == 'cuda'
+
+
+class _GraphedUpdater(Updater):
+    """``update_core`` = next batch -> ``_iteration(batch)`` (eager or as a replayed hipGraph) -> report."""
+    report_prefix = 'loss'
+
     def __init__(self, *args, **kwargs):
-        self.em_mom = kwargs.pop('em_mom')
+        hip_graph = kwargs.pop('hip_graph', True)
         super().__init__(*args, **kwargs)
+        self._step_graph = StepGraph(warmup=3, enabled=bool(hip_graph) and _graphable(
+            self.networks['segmentation'], self.optimizers['main'], self.device))
+
+    def _iteration(self, batch):
+        raise NotImplementedError
 
     def update_core(self):
         batch = next(self.iterators['images'])
         batch = {key: value.to(self.device, non_blocking=True) for key, value in batch.items()}
-        reporter = get_current_reporter()
+        observed = self._step_graph.run(batch, self._iteration, [self.optimizers['main']])
+        get_current_reporter().add_observation(observed, self.report_prefix)
+
+
+class EMANetUpdater(_GraphedUpdater):
+    def __init__(self, *args, **kwargs):
+        self.em_mom = kwargs.pop('em_mom')
+        super().__init__(*args, **kwargs)
+
+    def _iteration(self, batch):
         network = self.networks['segmentation']
         optimizer = self.optimizers['main']
 
@@ -49,10 +76,10 @@ class EMANetUpdater(Updater):
         optimizer.zero_grad()
         loss.backward()
         optimizer.step()
-        reporter.add_observation({'softmax': loss.detach()}, 'loss')
+        return {'softmax': loss.detach()}
 
 
-class TransUNetUpdater(Updater):
+class TransUNetUpdater(_GraphedUpdater):
     def __init__(self, *args, **kwargs):
         num_classes = kwargs.pop('num_classes')
         amp = kwargs.pop('amp', None)  # None / 'bf16': the reference is fp32; bf16 autocast is this build's option
@@ -61,10 +88,7 @@ class TransUNetUpdater(Updater):
         self.dice_loss = DiceLoss(num_classes)
         self.amp_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16}.get(amp)
 
-    def update_core(self):
-        batch = next(self.iterators['images'])
-        batch = {key: value.to(self.device, non_blocking=True) for key, value in batch.items()}
-        reporter = get_current_reporter()
+    def _iteration(self, batch):
         network = self.networks['segmentation']
 
         with GradientApplier([network], [self.optimizers['main']]):
@@ -80,5 +104,4 @@ class TransUNetUpdater(Updater):
             loss = 0.5 * loss_ce + 0.5 * loss_dice
             loss.backward()
 
-        reporter.add_observation({'combined': loss.detach(), 'CE': loss_ce.detach(), 'Dice': loss_dice.detach()},
-                                 'loss')
+        return {'combined': loss.detach(), 'CE': loss_ce.detach(), 'Dice': loss_dice.detach()}
