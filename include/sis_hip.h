@@ -221,6 +221,20 @@ int sis_kmeans_assign(int64_t* labels, const float* x, const float* centres, int
  * called at create_dataset_for_segmentation.py:135; its rounding is not pinned by the reference). */
 int sis_make_image_u8(uint8_t* out, const float* x, int batch, int channels, int hw, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Patch-wise page inference.  The patch grid is the product of `nx` left edges `xs` and
+ * `ny` top edges `ys` (device int32 arrays, ascending), patch n = yi * nx + xi, as
+ * segmentation/analysis_segmenter.py:83-113 enumerates them.
+ * sis_crop_patches_u8: image uint8 [height][width][channels] -> out float32 [ny*nx][channels][patch][patch] =
+ *   ((u8 / 255) - 0.5) / 0.5 with zeros read outside the image (PIL crop + ToTensor + Normalize, :115-130).
+ * sis_assemble_max: pred float32 [ny*nx][classes][patch][patch] -> out [classes][height][width] = maximum over
+ *   the covering patches (:147-167); labels (uint8 [height][width], may be NULL) = first maximal class
+ *   (networks/base_segmenter.py:59-62).  classes / channels <= 16. */
+int sis_crop_patches_u8(float* out, const unsigned char* image, const int* xs, const int* ys, int nx, int ny,
+                        int height, int width, int channels, int patch, void* stream);
+int sis_assemble_max(float* out, unsigned char* labels, const float* pred, const int* xs, const int* ys, int nx,
+                     int ny, int classes, int height, int width, int patch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

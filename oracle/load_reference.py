@@ -96,3 +96,36 @@ def load_reference_segmenters():
     vit = importlib.import_module("networks.trans_u_net.vit_seg_modeling")
     tu_utils = importlib.import_module("networks.trans_u_net.utils")
     return ema, vit, tu_utils, ema_utils
+
+
+def load_reference_analysis_segmenter():
+    """The reference's ``segmentation/analysis_segmenter.py`` module, importable here with: the bare ``networks`` /
+    ``utils`` packages above, stand-in modules for what the file only *names* at import time and that need absent
+    third-party packages -- ``torchvision.transforms`` (used in ``crop_and_batch_patches``: ToTensor + Normalize,
+    restated in oracle/analysis_ref.py), ``training_builder.train_builder_selection`` (needs ``pytorch_training``) --
+    and the reference's own ``visualization`` package as a bare package.  The patch-grid and max-assemble methods
+    (`calculate_bboxes_for_patches`, `assemble_predictions`) are then the reference's own code."""
+    load_reference_segmenters()
+    import importlib
+    if "torchvision" not in sys.modules:
+        try:
+            import torchvision  # noqa: F401
+        except Exception:
+            tv = types.ModuleType("torchvision")
+            tv.transforms = types.ModuleType("torchvision.transforms")
+            sys.modules["torchvision"] = tv
+            sys.modules["torchvision.transforms"] = tv.transforms
+    for name in ("segmentation", "visualization"):
+        if name not in sys.modules:
+            pkg = types.ModuleType(name)
+            pkg.__path__ = [os.path.join(REFERENCE_ROOT, name)]
+            pkg._sis_ref_stub = True
+            sys.modules[name] = pkg
+    if "training_builder" not in sys.modules:
+        tb = types.ModuleType("training_builder")
+        tb.__path__ = []
+        sel = types.ModuleType("training_builder.train_builder_selection")
+        sel.get_train_builder_class = lambda config: (_ for _ in ()).throw(RuntimeError("not available in the oracle"))
+        sys.modules["training_builder"] = tb
+        sys.modules["training_builder.train_builder_selection"] = sel
+    return importlib.import_module("segmentation.analysis_segmenter")

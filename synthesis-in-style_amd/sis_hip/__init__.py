@@ -57,6 +57,8 @@ _SIGNATURES = {
     "sis_bn_act_bwd": ([_vp] * 11 + [_i, _i, _i, _i, _vp], _i),
     "sis_kmeans_assign": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "sis_make_image_u8": ([_vp, _vp, _i, _i, _i, _vp], _i),
+    "sis_crop_patches_u8": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "sis_assemble_max": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
 }
 
 
@@ -473,6 +475,46 @@ def make_image_u8(x):
     with torch.cuda.device(x.device):
         _check(lib().sis_make_image_u8(_ptr(out), _ptr(x), b, ch, h * w, _stream()), "sis_make_image_u8")
     return out
+
+
+# ------------------------------------------------------------------------------ patch-wise page inference
+
+
+def _grid(xs, ys, device):
+    xs = torch.as_tensor(xs, dtype=torch.int32).to(device).contiguous()
+    ys = torch.as_tensor(ys, dtype=torch.int32).to(device).contiguous()
+    return xs, ys
+
+
+def crop_patches_u8(image, xs, ys, patch):
+    """uint8 [H,W,C] page on the device -> float32 [len(ys)*len(xs), C, patch, patch] in [-1,1] (zero padding outside
+    the page, ToTensor + Normalize(0.5, 0.5)); patch n = yi * len(xs) + xi."""
+    require_device(image, "image")
+    if image.dtype != torch.uint8 or image.dim() != 3:
+        raise RuntimeError("image must be a uint8 [H, W, C] tensor")
+    image = image.contiguous()
+    h, w, c = image.shape
+    xs, ys = _grid(xs, ys, image.device)
+    out = torch.empty((ys.numel() * xs.numel(), c, patch, patch), dtype=torch.float32, device=image.device)
+    with torch.cuda.device(image.device):
+        _check(lib().sis_crop_patches_u8(_ptr(out), _ptr(image), _ptr(xs), _ptr(ys), xs.numel(), ys.numel(), h, w, c,
+                                         patch, _stream()), "sis_crop_patches_u8")
+    return out
+
+
+def assemble_max(pred, xs, ys, height, width, with_labels=False):
+    """[N,C,P,P] patch predictions -> [C,height,width] maximum over the covering patches (+ uint8 label map)."""
+    pred = _f32(pred, "predictions")
+    n, c, p, p2 = pred.shape
+    xs, ys = _grid(xs, ys, pred.device)
+    if p != p2 or n != xs.numel() * ys.numel():
+        raise RuntimeError(f"predictions {tuple(pred.shape)} do not match a {ys.numel()} x {xs.numel()} patch grid")
+    out = torch.empty((c, height, width), dtype=torch.float32, device=pred.device)
+    labels = torch.empty((height, width), dtype=torch.uint8, device=pred.device) if with_labels else None
+    with torch.cuda.device(pred.device):
+        _check(lib().sis_assemble_max(_ptr(out), _ptr(labels), _ptr(pred), _ptr(xs), _ptr(ys), xs.numel(), ys.numel(), c,
+                                      height, width, p, _stream()), "sis_assemble_max")
+    return (out, labels) if with_labels else out
 
 
 # ------------------------------------------------------------------------------ fused batch norm
