@@ -129,3 +129,38 @@ def load_reference_analysis_segmenter():
         sys.modules["training_builder"] = tb
         sys.modules["training_builder.train_builder_selection"] = sel
     return importlib.import_module("segmentation.analysis_segmenter")
+
+
+def load_reference_swagan():
+    """The reference ``networks/swagan/model.py`` module, loaded by file path into a synthetic package tree whose
+    ``.op`` sub-packages are the oracle's CPU ops and whose ``..stylegan2.model`` is the reference's own stylegan2
+    model (the only two relative imports of that file, model.py:11-12).  ``conv2d_gradfix`` is only used by the
+    discriminator's ConvLayer path and is stood in by ``torch.nn.functional``."""
+    if "refsw.swagan.model" in sys.modules:
+        return sys.modules["refsw.swagan.model"]
+    from oracle import ops_ref
+
+    def package(name):
+        pkg = types.ModuleType(name)
+        pkg.__path__ = []
+        sys.modules[name] = pkg
+        return pkg
+
+    def load(name, *parts):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REFERENCE_ROOT, *parts))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    for name in ("refsw", "refsw.stylegan2", "refsw.swagan"):
+        package(name)
+    sys.modules["refsw.stylegan2.op"] = ops_ref
+    load("refsw.stylegan2.model", "networks", "stylegan2", "model.py")
+    sw_op = types.ModuleType("refsw.swagan.op")
+    sw_op.FusedLeakyReLU, sw_op.fused_leaky_relu = ops_ref.FusedLeakyReLU, ops_ref.fused_leaky_relu
+    sw_op.upfirdn2d = ops_ref.upfirdn2d
+    import torch.nn.functional as F
+    sw_op.conv2d_gradfix = F
+    sys.modules["refsw.swagan.op"] = sw_op
+    return load("refsw.swagan.model", "networks", "swagan", "model.py")
