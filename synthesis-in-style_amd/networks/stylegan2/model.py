@@ -298,6 +298,37 @@ class ToRGB(nn.Module):
         return sis_hip.to_rgb(input, conv.weight, s, self.bias, conv.scale, skip, up.kernel, up.pad)
 
 
+def truncate_styles(style, truncation, truncation_latent):
+    """truncation_latent + truncation * (style - truncation_latent) (model.py:509-516), one HIP launch in inference."""
+    if _needs_grad(style, truncation_latent) or not style.is_cuda or truncation_latent.numel() != style.shape[-1]:
+        return truncation_latent + truncation * (style - truncation_latent)
+    return sis_hip.truncate(style, truncation_latent, truncation)
+
+
+def resolve_latents(generator, styles, inject_index, truncation, truncation_latent, input_is_latent, noise,
+                    randomize_noise):
+    """The argument handling every generator variant of the reference opens ``forward`` with (stylegan2
+    model.py:491-531, swagan model.py:214-250): mapping network unless ``input_is_latent``, stored / fresh noise
+    selection, truncation towards ``truncation_latent``, and the [B, n_latent, D] latent with optional style mixing
+    at ``inject_index``.  Returns (latent, noise list)."""
+    if not input_is_latent:
+        styles = [generator.style(s) for s in styles]
+    if noise is None:
+        noise = [None] * generator.num_layers if randomize_noise else [
+            getattr(generator.noises, f'noise_{i}') for i in range(generator.num_layers)]
+    if truncation < 1:
+        styles = [truncate_styles(s, truncation, truncation_latent) for s in styles]
+    n_latent = generator.n_latent
+    if len(styles) < 2:
+        latent = styles[0].unsqueeze(1).repeat(1, n_latent, 1) if styles[0].ndim < 3 else styles[0]
+    else:
+        if inject_index is None:
+            inject_index = random.randint(1, n_latent - 1)
+        latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
+                            styles[1].unsqueeze(1).repeat(1, n_latent - inject_index, 1)], 1)
+    return latent, noise
+
+
 class Generator(nn.Module):
     def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01):
         super().__init__()
@@ -416,29 +447,10 @@ class Generator(nn.Module):
         d_list = [None if sl is None else d_flat[sl[0]:sl[0] + b * sl[1]].view(b, sl[1]) for sl in plan['d_slices']]
         return s_list, d_list
 
-    def _truncate(self, style, truncation, truncation_latent):
-        if _needs_grad(style, truncation_latent) or not style.is_cuda or truncation_latent.numel() != style.shape[-1]:
-            return truncation_latent + truncation * (style - truncation_latent)
-        return sis_hip.truncate(style, truncation_latent, truncation)
-
     def forward(self, styles, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
                 input_is_latent=False, noise=None, randomize_noise=True, return_intermediate_activations=False):
-        if not input_is_latent:
-            styles = [self.style(s) for s in styles]
-        if noise is None:
-            noise = [None] * self.num_layers if randomize_noise else [
-                getattr(self.noises, f'noise_{i}') for i in range(self.num_layers)]
-        if truncation < 1:
-            styles = [self._truncate(s, truncation, truncation_latent) for s in styles]
-
-        if len(styles) < 2:
-            inject_index = self.n_latent
-            latent = styles[0].unsqueeze(1).repeat(1, inject_index, 1) if styles[0].ndim < 3 else styles[0]
-        else:
-            if inject_index is None:
-                inject_index = random.randint(1, self.n_latent - 1)
-            latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
-                                styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
+        latent, noise = resolve_latents(self, styles, inject_index, truncation, truncation_latent, input_is_latent,
+                                        noise, randomize_noise)
 
         acts = {} if return_intermediate_activations else None
 

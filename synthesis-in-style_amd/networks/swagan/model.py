@@ -8,12 +8,12 @@ modulated convolution runs on the MI355X kernels of libsis_hip.so (stride-1 3x3 
 ``upfirdn2d`` passes each (K2 with the +/- 1/2 Haar taps: modes up=2 / down=2 with pad (1, 0) / (0, 0)).
 """
 import math
-import random
 
 import torch
 from torch import nn
 
-from networks.stylegan2.model import ConstantInput, EqualLinear, ModulatedConv2d, PixelNorm, StyledConv, Upsample
+from networks.stylegan2.model import (ConstantInput, EqualLinear, ModulatedConv2d, PixelNorm, StyledConv, Upsample,
+                                      resolve_latents)
 from .op import upfirdn2d
 
 
@@ -114,36 +114,19 @@ class Generator(nn.Module):
 
     def make_noise(self):
         device = self.input.input.device
-        noises = [torch.randn(1, 1, 2 ** 2, 2 ** 2, device=device)]
-        for i in range(3, self.log_size + 1):
-            for _ in range(2):
-                noises.append(torch.randn(1, 1, 2 ** i, 2 ** i, device=device))
-        return noises
+        sizes = [4] + [2 ** i for i in range(3, self.log_size + 1) for _ in range(2)]
+        return [torch.randn(1, 1, n, n, device=device) for n in sizes]
 
     def mean_latent(self, n_latent):
-        latent_in = torch.randn(n_latent, self.style_dim, device=self.input.input.device)
-        return self.style(latent_in).mean(0, keepdim=True)
+        return self.style(torch.randn(n_latent, self.style_dim, device=self.input.input.device)).mean(0, keepdim=True)
 
     def get_latent(self, input):
         return self.style(input)
 
     def forward(self, styles, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
                 input_is_latent=False, noise=None, randomize_noise=True, return_intermediate_activations=False):
-        if not input_is_latent:
-            styles = [self.style(s) for s in styles]
-        if noise is None:
-            noise = [None] * self.num_layers if randomize_noise else [
-                getattr(self.noises, f"noise_{i}") for i in range(self.num_layers)]
-        if truncation < 1:
-            styles = [truncation_latent + truncation * (style - truncation_latent) for style in styles]
-        if len(styles) < 2:
-            inject_index = self.n_latent
-            latent = styles[0].unsqueeze(1).repeat(1, inject_index, 1) if styles[0].ndim < 3 else styles[0]
-        else:
-            if inject_index is None:
-                inject_index = random.randint(1, self.n_latent - 1)
-            latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
-                                styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
+        latent, noise = resolve_latents(self, styles, inject_index, truncation, truncation_latent, input_is_latent,
+                                        noise, randomize_noise)
 
         acts = {} if return_intermediate_activations else None
 
