@@ -252,6 +252,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     assert torch.isfinite(out[0]).all()
+    # SURVEY.md §8(d) config 2 asks for both modes: (ii) with the 14 activations returned is `value` above (what
+    # dataset creation calls); (i) image only is timed here the same way (same kernels, nothing retained).
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        with torch.no_grad():
+            img_only = g([z], noise=noise)
+    fence()
+    elapsed_image_only = time.perf_counter() - t1
+    del img_only
+    if distributed:
+        t = torch.tensor([elapsed_image_only], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_image_only = t.item()
 
     result = None
     if rank == 0:
@@ -287,7 +301,8 @@ def main():
             "config": {"workload": "StyleGAN2 Generator(256,512,8,cm=2).forward, batch 32 per GPU, explicit noise, "
                                    "return_intermediate_activations=True (BASELINE.json configs[1])",
                        "batch_per_gpu": args.batch, "image_size": SIZE, "parallelism": f"replicated x{n_gpus}, "
-                       "images sharded, no collective"},
+                       "images sharded, no collective",
+                       "images_per_s_image_only": round(total_images / elapsed_image_only, 2)},
             "roofline": roofline,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
