@@ -30,6 +30,7 @@ for _p in (ROOT, os.path.join(ROOT, "synthesis-in-style_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 METRIC = "StyleGAN2 synth images/sec + seg-train images/sec @256², 1/2/4/8 MI355X"
@@ -179,6 +180,60 @@ def bench_training(args, workload, world, rank, device, distributed):
     }
 
 
+def bench_dataset(args, world, rank, device, distributed):
+    """Dataset-creation hot loop (BASELINE.json configs[2], per GPU): seeded CPU latents -> Generator.forward with
+    activations and fresh device noise -> nearest k-means centre maps for the reference config's four activation
+    keys (8, 9, 12, 13) -> uint8 images, all on the device; PNG encoding / file IO is not part of the step."""
+    import torch.distributed as dist
+    import sis_hip
+    from segmentation.gan_local_edit.factor_catalog import FactorCatalog
+    batch = args.batch or BATCH
+    g = build_generator(device)
+    rng = np.random.RandomState(7)
+    chans = {8: 512, 9: 512, 12: 128, 13: 128}
+    catalogs = {k: FactorCatalog(cluster_centers=rng.randn(24, c).astype(np.float32)) for k, c in chans.items()}
+    torch.random.manual_seed(1 + rank)
+
+    def one_batch():
+        with torch.no_grad():
+            z = torch.randn(batch, g.style_dim).to(device, non_blocking=True)
+            image, acts = g([z], noise=g.make_noise(), return_intermediate_activations=True)
+            labels = {k: cat.predict(acts[k]) for k, cat in catalogs.items()}
+            return sis_hip.make_image_u8(image), labels
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = one_batch()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_batch()
+    fence()
+    elapsed = time.perf_counter() - t0
+    assert out[0].dtype == torch.uint8
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank != 0:
+        return None
+    images = batch * args.steps * world
+    return {"metric": METRIC, "value": round(images / elapsed, 2), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "create_dataset_for_segmentation hot loop: Generator(256) forward + 4 k-means label "
+                                   "maps (24 centres, layers 8/9/12/13) + uint8 images, no file IO "
+                                   "(BASELINE.json configs[2], per-GPU shard)", "batch_per_gpu": batch,
+                       "image_size": SIZE, "parallelism": f"image-id shards x{world}, no collective"},
+            "roofline": {"kernel": "whole loop body", "bound": "mfma", "achieved": round(
+                90.24e9 * images / elapsed / 1e12 / world, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(90.24e9 * images / elapsed / 1e12 / world / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None}}
+
+
 def measured_traffic(kernel):
     """HBM bytes per launch of ``kernel`` from the committed PMC passes (profiles/*traffic*.json, written by
     tools/pmc_traffic.sh on the GPU box: counters cannot be collected from inside the timed process)."""
@@ -196,7 +251,7 @@ def measured_traffic(kernel):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="synthesis", choices=["synthesis", "emanet", "transunet"])
+    ap.add_argument("--workload", default="synthesis", choices=["synthesis", "emanet", "transunet", "dataset"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
@@ -219,7 +274,10 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     if args.workload != "synthesis":
-        result = bench_training(args, args.workload, world, rank, device, distributed)
+        if args.workload == "dataset":
+            result = bench_dataset(args, world, rank, device, distributed)
+        else:
+            result = bench_training(args, args.workload, world, rank, device, distributed)
         if distributed:
             dist.barrier()
             dist.destroy_process_group()
