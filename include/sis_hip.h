@@ -222,6 +222,19 @@ int sis_kmeans_assign(int64_t* labels, const float* x, const float* centres, int
 int sis_make_image_u8(uint8_t* out, const float* x, int batch, int channels, int hw, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Plain 3x3 convolution (stride 1, padding 1, no bias) of the segmentation networks on the Winograd F(2x2,3x3)
+ * MFMA kernel -- replaces F.conv2d / cuDNN for networks/ema_net/network.py's 3x3 layers (ConvBNReLU :169-184, the
+ * deep stem :71-79, Bottleneck.conv2 :27-28 where stride = dilation = 1), forward and data gradient.
+ * sis_conv3x3_prepack: w [Cout_w][Cin_w][3][3] -> u, the transformed weights the kernel streams.  adjoint = 0: the
+ *   forward convolution (cout = Cout_w, cin = Cin_w).  adjoint = 1: the convolution that maps dL/dy to dL/dx
+ *   (cout = Cin_w, cin = Cout_w, taps rotated by 180 degrees).  u holds cin * 16 * cout floats.
+ * sis_conv3x3: out [B,cout,H,W] = conv(x [B,cin,H,W], u).  Needs W % 4 == 0, H % 2 == 0, cin % 8 == 0,
+ *   cout % 4 == 0; workspace as for sis_modconv2d (split-K scratch, may be NULL). */
+int sis_conv3x3_prepack(float* u, const float* w, int cout, int cin, int adjoint, void* stream);
+int sis_conv3x3(float* out, const float* x, const float* u, int batch, int cin, int cout, int h, int w,
+                void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Patch-wise page inference.  The patch grid is the product of `nx` left edges `xs` and
  * `ny` top edges `ys` (device int32 arrays, ascending), patch n = yi * nx + xi, as
  * segmentation/analysis_segmenter.py:83-113 enumerates them.

@@ -328,6 +328,32 @@ extern "C" int sis_modconv2d(float* out, const float* x, const float* wpk, const
     return launch<0, 1>(p, (hipStream_t)stream);
 }
 
+// Plain (unmodulated) 3x3 convolution, stride 1, padding 1, on the Winograd kernel: unit style, unit demodulation,
+// no epilogue.  Used for the segmentation networks' 3x3 layers (forward, and data gradient with adjoint weights).
+extern "C" int sis_conv3x3(float* out, const float* x, const float* u, int batch, int cin, int cout, int h, int w,
+                           void* workspace, int64_t workspace_bytes, void* stream) {
+    if (batch == 0) return 0;
+    SIS_REQUIRE(out && x && u, "sis_conv3x3: null pointer");
+    SIS_REQUIRE(batch > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "sis_conv3x3: non-positive size");
+    SIS_REQUIRE((int64_t)batch * (cin > cout ? cin : cout) * h * w < ((int64_t)1 << 31),
+                "sis_conv3x3: tensor too large for 32-bit plane offsets");
+    SIS_REQUIRE(w % 4 == 0 && h % 2 == 0 && cin % 8 == 0 && cout % 4 == 0,
+                "sis_conv3x3: needs W %% 4 == 0, H %% 2 == 0, Cin %% 8 == 0, Cout %% 4 == 0 (got %dx%d, %d -> %d)", h, w, cin, cout);
+    ConvParams p;
+    init_params(p);
+    p.x = x; p.wpk = u; p.s = nullptr; p.dscale = nullptr; p.noise = nullptr; p.noise_w = nullptr; p.bias = nullptr;
+    p.out = out; p.noise_bstride = 0;
+    p.B = batch; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w; p.OH = h; p.OW = w; p.ORS = w; p.fuse = 0;
+    p.kchunk = cin;
+    p.cout_vec4 = (((uintptr_t)u & 15) == 0);
+    mc_add_class(p, 256, 2, batch, 0, h, 0, w, 16, 16);
+    TileClass& tc = p.cls[0];
+    tc.xt = tc.nb * ((1 << tc.th_log2) + 2) * ((1 << tc.tw_log2) + 8);
+    const int rc = modconv_wino_launch(p, (hipStream_t)stream, workspace, workspace_bytes);
+    SIS_REQUIRE(rc >= 0, "sis_conv3x3: shape %dx%d, %d -> %d not eligible for the Winograd kernel", h, w, cin, cout);
+    return rc;
+}
+
 extern "C" int sis_modconv2d_up(float* t, const float* x, const float* wpk, const float* s, const float* dscale,
                                 int batch, int cin, int cout, int h, int w, int t_row_stride, void* workspace,
                                 int64_t workspace_bytes, void* stream) {

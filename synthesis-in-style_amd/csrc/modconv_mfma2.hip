@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void modconv_splitk_finish(const ConvParams p,
         for (int k = 0; k < p.ksplit; ++k) v += p.slab[k * plane_elems + i];
         const int64_t bc = i / ohw, hw = i - bc * ohw;
         const int b = (int)(bc / p.Cout), co = (int)(bc - (int64_t)b * p.Cout);
-        v *= p.dscale[bc];
+        if (p.dscale) v *= p.dscale[bc];
         if (p.fuse) {
             if (p.noise) v += nw * p.noise[(int64_t)b * p.noise_bstride + hw];
             if (p.bias) v += p.bias[co];

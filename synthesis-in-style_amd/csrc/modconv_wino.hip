@@ -46,12 +46,19 @@ __device__ __forceinline__ void glds4(const float* g, float* l) {
 }
 
 // u[ci][xi][co] from w[co][ci][3][3]
+// ADJOINT = true builds the weights of the data gradient instead: the convolution that maps dL/dy back to dL/dx
+// uses w'[ci][co][r][c] = w[co][ci][2-r][2-c] (roles of the channel axes swapped, taps rotated by 180 degrees);
+// `cout` / `cin` are then the output / input channels of THAT convolution (= cin / cout of w's own layout).
+template <bool ADJOINT>
 __global__ __launch_bounds__(256) void wino_prepack_kernel(float* __restrict__ u, const float* __restrict__ w, int cout,
                                                            int cin) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // i = ci * cout + co
     if (i >= (int64_t)cout * cin) return;
     const int co = (int)(i % cout), ci = (int)(i / cout);
-    const float* g = w + ((int64_t)co * cin + ci) * 9;
+    const float* gsrc = ADJOINT ? w + ((int64_t)ci * cout + co) * 9 : w + ((int64_t)co * cin + ci) * 9;
+    float g[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k] = gsrc[ADJOINT ? 8 - k : k];
     float t[4][3];  // G g
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams
     for (int e = tid; e < 2 * WCC * xt; e += WNTHR) Xl[e] = 0.f;
     for (int e = tid; e < tc.nb * p.Cin; e += WNTHR) {
         const int n = e / p.Cin, ci = e - n * p.Cin;
-        Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
+        Sl[e] = (b0 + n < p.B) ? (p.s ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 1.f) : 0.f;
     }
     // one float4 chunk of the tile per lane per channel (<= 512 chunks: host-checked)
     int st_goff = -1;
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = part[j][e] + xch[(j * 4 + e) * 64 + lane];
         if (!partial) {
-            const float dd = db[co];
+            const float dd = p.dscale ? db[co] : 1.f;
             const float bb = (p.fuse && p.bias) ? p.bias[co] : 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     }
     for (int e = tid; e < tc.nb * p.Cin; e += WNTHR) {
         const int n = e / p.Cin, ci = e - n * p.Cin;
-        Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
+        Sl[e] = (b0 + n < p.B) ? (p.s ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 1.f) : 0.f;
     }
     // layer-tail operands of the 8 accumulator rows this lane finalises (see the epilogue), fetched now so that
     // the tail is not a chain of dependent global loads
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
         for (int jj = 0; jj < 8; ++jj) {
             const int co = o0 + wm * 32 + 16 * q + 4 * half + (jj & 3) + 8 * (jj >> 2);
             if (co < p.Cout) {
-                dd[jj] = db[co];
+                if (p.dscale) dd[jj] = db[co];
                 if (p.fuse && p.bias) bb[jj] = p.bias[co];
             }
         }
@@ -547,9 +554,21 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
 extern "C" int sis_modconv_prepack_wino(float* u, const float* w, int cout, int cin, void* stream) {
     SIS_REQUIRE(u && w, "sis_modconv_prepack_wino: null pointer");
     SIS_REQUIRE(cout > 0 && cin > 0, "sis_modconv_prepack_wino: bad sizes");
-    hipLaunchKernelGGL(wino_prepack_kernel, dim3(sis_cdiv((int64_t)cout * cin, 256)), dim3(256), 0, (hipStream_t)stream, u, w,
-                       cout, cin);
+    hipLaunchKernelGGL(wino_prepack_kernel<false>, dim3(sis_cdiv((int64_t)cout * cin, 256)), dim3(256), 0,
+                       (hipStream_t)stream, u, w, cout, cin);
     SIS_CHECK_LAUNCH("sis_modconv_prepack_wino");
+    return 0;
+}
+
+extern "C" int sis_conv3x3_prepack(float* u, const float* w, int cout, int cin, int adjoint, void* stream) {
+    SIS_REQUIRE(u && w, "sis_conv3x3_prepack: null pointer");
+    SIS_REQUIRE(cout > 0 && cin > 0, "sis_conv3x3_prepack: bad sizes");
+    const dim3 grid(sis_cdiv((int64_t)cout * cin, 256));
+    if (adjoint)
+        hipLaunchKernelGGL(wino_prepack_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, u, w, cout, cin);
+    else
+        hipLaunchKernelGGL(wino_prepack_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, u, w, cout, cin);
+    SIS_CHECK_LAUNCH("sis_conv3x3_prepack");
     return 0;
 }
 

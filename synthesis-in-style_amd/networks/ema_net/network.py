@@ -27,6 +27,7 @@ from torch.nn.modules.batchnorm import _BatchNorm
 
 import sis_hip
 from networks.base_segmenter import BaseSegmenter
+from networks.hip_conv import HipConv2d
 
 BN_MOM = 3e-4
 RESNET_BLOCKS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
@@ -100,7 +101,7 @@ class Bottleneck(nn.Module):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
         self.bn1 = norm_layer(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride, dilation, dilation, bias=False)
+        self.conv2 = HipConv2d(planes, planes, 3, stride, dilation, dilation, bias=False)
         self.bn2 = norm_layer(planes)
         self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
         self.bn3 = norm_layer(planes * self.expansion)
@@ -124,8 +125,8 @@ class ResNet(nn.Module):
         self.inplanes = 128
         self.conv1 = nn.Sequential(
             nn.Conv2d(3, 64, 3, 2, 1, bias=False), norm_layer(64), nn.ReLU(inplace=True),
-            nn.Conv2d(64, 64, 3, 1, 1, bias=False), norm_layer(64), nn.ReLU(inplace=True),
-            nn.Conv2d(64, 128, 3, 1, 1, bias=False))
+            HipConv2d(64, 64, 3, 1, 1, bias=False), norm_layer(64), nn.ReLU(inplace=True),
+            HipConv2d(64, 128, 3, 1, 1, bias=False))
         self.bn1 = norm_layer(self.inplanes)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
@@ -187,7 +188,7 @@ def resnet(n_layers, stride, use_pretrained_resnet, pretrained_path):
 class ConvBNReLU(nn.Module):
     def __init__(self, c_in, c_out, kernel_size, stride, padding, dilation):
         super().__init__()
-        self.conv = nn.Conv2d(c_in, c_out, kernel_size, stride, padding, dilation, bias=False)
+        self.conv = HipConv2d(c_in, c_out, kernel_size, stride, padding, dilation, bias=False)
         self.bn = norm_layer(c_out)
         self.relu = nn.ReLU(inplace=True)
 

@@ -41,6 +41,8 @@ _SIGNATURES = {
     "sis_modconv2d": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 7 + [_vp, _vp, _i64, _vp], _i),
     "sis_modconv_prepack_wino": ([_vp, _vp, _i, _i, _vp], _i),
     "sis_last_kernel": ([], ctypes.c_char_p),
+    "sis_conv3x3_prepack": ([_vp, _vp, _i, _i, _i, _vp], _i),
+    "sis_conv3x3": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
     "sis_modconv2d_up": ([_vp] * 5 + [_i] * 6 + [_vp, _i64, _vp], _i),
     "sis_blur_noise_act": ([_vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 10 + [_vp], _i),
     "sis_to_rgb": ([_vp] * 7 + [_i] * 9 + [_f, _vp], _i),
@@ -272,6 +274,41 @@ def modconv_prepack_wino(weight):
     with torch.cuda.device(w.device):
         _check(lib().sis_modconv_prepack_wino(_ptr(u), _ptr(w), cout, cin, _stream()), "sis_modconv_prepack_wino")
     return u
+
+
+def conv3x3_supported(x, weight):
+    """Shapes the plain Winograd path takes: 3x3 kernel, float32 NCHW, W % 4 == 0, H % 2 == 0, channels % 8 == 0."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
+            and x.shape[3] % 4 == 0 and x.shape[2] % 2 == 0 and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0
+            and x.shape[0] * max(weight.shape[0], weight.shape[1]) * x.shape[2] * x.shape[3] < 2 ** 31)
+
+
+def conv3x3_prepack(weight, adjoint=False):
+    """[Cout, Cin, 3, 3] -> Winograd-transformed weights of the forward convolution, or (adjoint) of the convolution
+    that takes dL/dy to dL/dx."""
+    w = _f32(weight, "weight")
+    cout_w, cin_w = w.shape[0], w.shape[1]
+    cout, cin = (cin_w, cout_w) if adjoint else (cout_w, cin_w)
+    u = torch.empty((cin, 16, cout), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _check(lib().sis_conv3x3_prepack(_ptr(u), _ptr(w), cout, cin, int(bool(adjoint)), _stream()), "sis_conv3x3_prepack")
+    return u
+
+
+def conv3x3(x, u):
+    """Stride-1, padding-1 3x3 convolution of x [B,Cin,H,W] with prepacked weights u [Cin,16,Cout]."""
+    x = _f32(x, "input")
+    batch, cin, h, w = x.shape
+    if u.shape[0] != cin:
+        raise RuntimeError(f"prepacked weights are for {u.shape[0]} input channels, input has {cin}")
+    cout = u.shape[2]
+    out = torch.empty((batch, cout, h, w), dtype=torch.float32, device=x.device)
+    ws = _workspace(x.device)
+    with torch.cuda.device(x.device):
+        _check(_launch(None, 2.0 * batch * cout * cin * 9 * h * w, 4.0 * (x.numel() + out.numel() + u.numel()),
+                       lambda: lib().sis_conv3x3(_ptr(out), _ptr(x), _ptr(u), batch, cin, cout, h, w, _ptr(ws), ws.numel(),
+                                                 _stream())), "sis_conv3x3")
+    return out
 
 
 def modconv_demod(s, wsq, scale, demodulate):

@@ -1,0 +1,63 @@
+"""GPU parity: the plain 3x3 Winograd convolution (sis_conv3x3) and its autograd wrapper against ATen fp32.
+Tolerance: Winograd F(2x2,3x3) in fp32 re-associates the 9-tap sums; 2e-5 of the output range per layer forward, and
+the same for the data gradient (the library path it replaces is itself a Winograd kernel)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(2, 64, 128, 32, 32), (3, 128, 64, 16, 24), (1, 256, 8, 8, 8), (16, 64, 64, 64, 64), (2, 2048, 512, 32, 32),
+          (5, 8, 8, 2, 4)]
+
+
+@pytest.mark.parametrize("batch,cin,cout,h,w", SHAPES)
+def test_forward_and_data_gradient(device, batch, cin, cout, h, w):
+    import sis_hip
+    from networks.hip_conv import conv3x3
+    g = torch.Generator().manual_seed(batch * 1000 + cin)
+    x = torch.randn(batch, cin, h, w, generator=g).to(device).requires_grad_(True)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (cin * 9) ** -0.5).to(device).requires_grad_(True)
+    gy = torch.randn(batch, cout, h, w, generator=g).to(device)
+    assert sis_hip.conv3x3_supported(x, wt)
+    y = conv3x3(x, wt)
+    y.backward(gy)
+    gx, gw = x.grad.clone(), wt.grad.clone()
+    x.grad = wt.grad = None
+    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    ref.backward(gy.double())
+    for got, want, name in ((y, ref, "y"), (gx, x.grad, "dx"), (gw, wt.grad, "dw")):
+        want = want.detach().float()
+        err = (got.detach() - want).abs().max().item() / want.abs().max().item()
+        assert err < (2e-5 if name != "dw" else 1e-4), (name, err)
+
+
+def test_module_dispatch_and_fallback(device):
+    from networks.hip_conv import HipConv2d
+    import sis_hip
+    conv = HipConv2d(64, 64, 3, 1, 1, bias=False).to(device)
+    x = torch.randn(2, 64, 16, 16, device=device)
+    rec = []
+    sis_hip.set_profiler(rec)
+    try:
+        y = conv(x)
+    finally:
+        sis_hip.set_profiler(None)
+    assert [r[0] for r in rec] == ["modconv_wino2_kernel"], "the 3x3 layer did not run on the HIP kernel"
+    np.testing.assert_allclose(y.detach().cpu().numpy(), F.conv2d(x, conv.weight, padding=1).detach().cpu().numpy(),
+                               atol=2e-5 * float(y.abs().max()))
+    # not eligible: dilation 2, stride 2, odd width, bias -> ATen, same result as nn.Conv2d
+    for kwargs, shape in (({"dilation": 2, "padding": 2}, (2, 64, 16, 16)), ({"stride": 2, "padding": 1}, (2, 64, 16, 16)),
+                          ({"padding": 1}, (2, 64, 16, 15))):
+        c = HipConv2d(64, 32, 3, bias=False, **kwargs).to(device)
+        xi = torch.randn(*shape, device=device)
+        rec = []
+        sis_hip.set_profiler(rec)
+        try:
+            out = c(xi)
+        finally:
+            sis_hip.set_profiler(None)
+        assert rec == []
+        assert torch.equal(out, F.conv2d(xi, c.weight, None, c.stride, c.padding, c.dilation))
+    assert sorted(HipConv2d(8, 8, 3).state_dict().keys()) == ["bias", "weight"]
