@@ -230,6 +230,7 @@ int sis_make_image_u8(uint8_t* out, const float* x, int batch, int channels, int
  *   (cout = Cin_w, cin = Cout_w, taps rotated by 180 degrees).  u holds cin * 16 * cout floats.
  * sis_conv3x3: out [B,cout,H,W] = conv(x [B,cin,H,W], u).  Needs W % 4 == 0, H % 2 == 0, cin % 8 == 0,
  *   cout % 4 == 0; workspace as for sis_modconv2d (split-K scratch, may be NULL). */
+int sis_conv3x3_eligible(int batch, int cin, int cout, int h, int w); /* 1 if sis_conv3x3 takes this shape */
 int sis_conv3x3_prepack(float* u, const float* w, int cout, int cin, int adjoint, void* stream);
 int sis_conv3x3(float* out, const float* x, const float* u, int batch, int cin, int cout, int h, int w,
                 void* workspace, int64_t workspace_bytes, void* stream);

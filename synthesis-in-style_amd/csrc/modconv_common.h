@@ -87,6 +87,6 @@ static inline void mc_set_padded_xt(ConvParams& p, int pad_lo, int ext) {
 // modconv_mfma2.hip: returns 0 on success, 1 on error, -1 when the shape is not eligible for the fast path.
 int modconv_v2_launch(ConvParams& p, int mode, int ks, hipStream_t st, void* workspace, int64_t workspace_bytes);
 // modconv_wino.hip: Winograd F(2x2,3x3) path for stride-1 3x3 layers (p.wpk must then hold the transformed weights).
-int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t workspace_bytes);
+int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t workspace_bytes, bool plan_only = false);
 // Block tile of the fast path for `mode` (positions per tile depend on the selected wave layout).
 int modconv_v2_tile(int mode, int* mblk, int* npos);

@@ -330,16 +330,11 @@ extern "C" int sis_modconv2d(float* out, const float* x, const float* wpk, const
 
 // Plain (unmodulated) 3x3 convolution, stride 1, padding 1, on the Winograd kernel: unit style, unit demodulation,
 // no epilogue.  Used for the segmentation networks' 3x3 layers (forward, and data gradient with adjoint weights).
-extern "C" int sis_conv3x3(float* out, const float* x, const float* u, int batch, int cin, int cout, int h, int w,
-                           void* workspace, int64_t workspace_bytes, void* stream) {
-    if (batch == 0) return 0;
-    SIS_REQUIRE(out && x && u, "sis_conv3x3: null pointer");
-    SIS_REQUIRE(batch > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "sis_conv3x3: non-positive size");
-    SIS_REQUIRE((int64_t)batch * (cin > cout ? cin : cout) * h * w < ((int64_t)1 << 31),
-                "sis_conv3x3: tensor too large for 32-bit plane offsets");
-    SIS_REQUIRE(w % 4 == 0 && h % 2 == 0 && cin % 8 == 0 && cout % 4 == 0,
-                "sis_conv3x3: needs W %% 4 == 0, H %% 2 == 0, Cin %% 8 == 0, Cout %% 4 == 0 (got %dx%d, %d -> %d)", h, w, cin, cout);
-    ConvParams p;
+static int conv3x3_plan(ConvParams& p, float* out, const float* x, const float* u, int batch, int cin, int cout, int h,
+                        int w) {
+    if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return -1;
+    if ((int64_t)batch * (cin > cout ? cin : cout) * h * w >= ((int64_t)1 << 31)) return -1;
+    if (w % 4 != 0 || h % 2 != 0 || cin % 8 != 0 || cout % 4 != 0) return -1;
     init_params(p);
     p.x = x; p.wpk = u; p.s = nullptr; p.dscale = nullptr; p.noise = nullptr; p.noise_w = nullptr; p.bias = nullptr;
     p.out = out; p.noise_bstride = 0;
@@ -349,6 +344,23 @@ extern "C" int sis_conv3x3(float* out, const float* x, const float* u, int batch
     mc_add_class(p, 256, 2, batch, 0, h, 0, w, 16, 16);
     TileClass& tc = p.cls[0];
     tc.xt = tc.nb * ((1 << tc.th_log2) + 2) * ((1 << tc.tw_log2) + 8);
+    return 0;
+}
+
+extern "C" int sis_conv3x3_eligible(int batch, int cin, int cout, int h, int w) {
+    ConvParams p;
+    if (conv3x3_plan(p, nullptr, nullptr, nullptr, batch, cin, cout, h, w) < 0) return 0;
+    return modconv_wino_launch(p, nullptr, nullptr, 0, true) == 0 ? 1 : 0;
+}
+
+extern "C" int sis_conv3x3(float* out, const float* x, const float* u, int batch, int cin, int cout, int h, int w,
+                           void* workspace, int64_t workspace_bytes, void* stream) {
+    if (batch == 0) return 0;
+    SIS_REQUIRE(out && x && u, "sis_conv3x3: null pointer");
+    ConvParams p;
+    SIS_REQUIRE(conv3x3_plan(p, out, x, u, batch, cin, cout, h, w) == 0,
+                "sis_conv3x3: needs W %% 4 == 0, H %% 2 == 0, Cin %% 8 == 0, Cout %% 4 == 0 and < 2^31 elements "
+                "(got %d x %dx%d, %d -> %d)", batch, h, w, cin, cout);
     const int rc = modconv_wino_launch(p, (hipStream_t)stream, workspace, workspace_bytes);
     SIS_REQUIRE(rc >= 0, "sis_conv3x3: shape %dx%d, %d -> %d not eligible for the Winograd kernel", h, w, cin, cout);
     return rc;

@@ -575,7 +575,7 @@ extern "C" int sis_conv3x3_prepack(float* u, const float* w, int cout, int cin, 
 void modconv_splitk_finish_launch(const ConvParams& p, hipStream_t st);
 
 // Returns 0 / 1 like the other launchers, -1 when the shape is not eligible (odd sizes, unaligned, tiny Cin).
-int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t workspace_bytes) {
+int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t workspace_bytes, bool plan_only) {
     if (p.H % 2 || p.W % 4 || p.Cin % WCC != 0 || !p.cout_vec4 || (((uintptr_t)p.x | (uintptr_t)p.wpk | (uintptr_t)p.out) & 15))
         return -1;
     if (p.fuse && p.noise && (((uintptr_t)p.noise & 3) != 0)) return -1;
@@ -599,6 +599,7 @@ int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t 
     const size_t lds = (size_t)(2 * WCC * 16 * WMBLK + 2 * WCC * tc.xt + p.nb_max * p.Cin) * sizeof(float);
     const size_t lds2 = lds + (size_t)2 * 16 * WCC * WTILES * sizeof(float);
     if (lds > 160 * 1024) return -1;
+    if (plan_only) return 0;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_wino_kernel),

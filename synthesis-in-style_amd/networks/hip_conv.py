@@ -1,8 +1,10 @@
 """3x3 convolutions of the segmentation networks on the hand-written Winograd MFMA kernel.
 
 ``HipConv2d`` is an ``nn.Conv2d`` (same constructor, parameters and state_dict keys) whose forward takes the MI355X
-kernel when the layer is a plain 3x3, stride 1, padding 1, dilation 1, bias-free convolution on a float32 NCHW tensor
-with aligned shapes, and ATen otherwise.  Measured on EMANet-50's shapes (B = 16, tools/bench_conv_shapes.py) the
+kernel when the layer is a plain 3x3, stride 1, padding = dilation, bias-free convolution on a float32 NCHW tensor
+with aligned shapes, and ATen otherwise.  Dilation d is run as the d*d ordinary convolutions of the stride-d
+sub-images (EMANet's output-stride-8 trunk: d = 2 at 32^2 -> 16^2 sub-images; d = 8 / 16 leave 4^2 / 2^2
+sub-images, which the tile plan rejects: ATen).  Measured on EMANet-50's shapes (B = 16, tools/bench_conv_shapes.py) the
 kernel is 1.5-1.9x faster than the library's fp32 path (2048->512 @32^2: 1.70 vs 2.48 ms; 64->128 @128^2: 0.22 vs
 0.37 ms); 1x1 and dilated convolutions stay on hipBLASLt / MIOpen, which are faster there than this library's
 direct kernels.
@@ -18,38 +20,59 @@ from torch.autograd import Function
 import sis_hip
 
 
+def _space_to_batch(t, d):
+    """[B,C,H,W] -> [B*d*d,C,H/d,W/d]: the d*d stride-d sub-images of every sample (a dilated 3x3 convolution is an
+    ordinary one on each of them)."""
+    if d == 1:
+        return t
+    b, c, h, w = t.shape
+    return t.view(b, c, h // d, d, w // d, d).permute(0, 3, 5, 1, 2, 4).reshape(b * d * d, c, h // d, w // d)
+
+
+def _batch_to_space(t, d):
+    if d == 1:
+        return t
+    bdd, c, h, w = t.shape
+    return t.view(bdd // (d * d), d, d, c, h, w).permute(0, 3, 4, 1, 5, 2).reshape(bdd // (d * d), c, h * d, w * d)
+
+
 class _Conv3x3Function(Function):
     @staticmethod
-    def forward(ctx, input, weight):
+    def forward(ctx, input, weight, dilation):
         ctx.save_for_backward(input, weight)
-        return sis_hip.conv3x3(input, sis_hip.conv3x3_prepack(weight))
+        ctx.dilation = dilation
+        out = sis_hip.conv3x3(_space_to_batch(input, dilation), sis_hip.conv3x3_prepack(weight))
+        return _batch_to_space(out, dilation)
 
     @staticmethod
     def backward(ctx, grad_output):
         input, weight = ctx.saved_tensors
+        d = ctx.dilation
         grad_input = grad_weight = None
         grad_output = grad_output.contiguous()
         if ctx.needs_input_grad[0]:
-            grad_input = sis_hip.conv3x3(grad_output, sis_hip.conv3x3_prepack(weight, adjoint=True))
+            grad_input = _batch_to_space(sis_hip.conv3x3(_space_to_batch(grad_output, d),
+                                                         sis_hip.conv3x3_prepack(weight, adjoint=True)), d)
         if ctx.needs_input_grad[1]:
             grad_weight = torch.ops.aten.convolution_backward(
-                grad_output, input, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1]
-        return grad_input, grad_weight
+                grad_output, input, weight, None, (1, 1), (d, d), (d, d), False, (0, 0), 1, (False, True, False))[1]
+        return grad_input, grad_weight, None
 
 
-def conv3x3(input, weight):
-    """Differentiable stride-1, padding-1 3x3 convolution on the Winograd kernel (caller checks eligibility)."""
-    return _Conv3x3Function.apply(input, weight)
+def conv3x3(input, weight, dilation=1):
+    """Differentiable stride-1 3x3 convolution with padding = dilation on the Winograd kernel (caller checks
+    eligibility with ``sis_hip.conv3x3_supported``)."""
+    return _Conv3x3Function.apply(input, weight, dilation)
 
 
 class HipConv2d(nn.Conv2d):
     def _eligible(self, input):
-        return (self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1)
-                and self.dilation == (1, 1) and self.groups == 1 and self.bias is None
+        return (self.kernel_size == (3, 3) and self.stride == (1, 1) and self.dilation[0] == self.dilation[1]
+                and self.padding == self.dilation and self.groups == 1 and self.bias is None
                 and self.padding_mode == 'zeros' and not torch.is_autocast_enabled()
-                and input.is_contiguous() and sis_hip.conv3x3_supported(input, self.weight))
+                and input.is_contiguous() and sis_hip.conv3x3_supported(input, self.weight, self.dilation[0]))
 
     def forward(self, input):
         if self._eligible(input):
-            return conv3x3(input, self.weight)
+            return conv3x3(input, self.weight, self.dilation[0])
         return super().forward(input)

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "sis_modconv_prepack_wino": ([_vp, _vp, _i, _i, _vp], _i),
     "sis_last_kernel": ([], ctypes.c_char_p),
     "sis_conv3x3_prepack": ([_vp, _vp, _i, _i, _i, _vp], _i),
+    "sis_conv3x3_eligible": ([_i] * 5, _i),
     "sis_conv3x3": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
     "sis_modconv2d_up": ([_vp] * 5 + [_i] * 6 + [_vp, _i64, _vp], _i),
     "sis_blur_noise_act": ([_vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 10 + [_vp], _i),
@@ -276,11 +277,29 @@ def modconv_prepack_wino(weight):
     return u
 
 
-def conv3x3_supported(x, weight):
-    """Shapes the plain Winograd path takes: 3x3 kernel, float32 NCHW, W % 4 == 0, H % 2 == 0, channels % 8 == 0."""
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
-            and x.shape[3] % 4 == 0 and x.shape[2] % 2 == 0 and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0
-            and x.shape[0] * max(weight.shape[0], weight.shape[1]) * x.shape[2] * x.shape[3] < 2 ** 31)
+def conv3x3_supported(x, weight, dilation=1):
+    """True when the plain Winograd path takes this layer in both directions (forward and data gradient): 3x3
+    kernel, float32 NCHW; a dilation d is run as d*d independent convolutions of the stride-d sub-images, so the
+    constraints (W % 4 == 0, H % 2 == 0, channels % 8 == 0, tile plan fits the LDS) apply to [B*d*d, C, H/d, W/d]."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4
+            and tuple(weight.shape[2:]) == (3, 3) and weight.shape[1] == x.shape[1]):
+        return False
+    b, _, h, w = x.shape
+    d = int(dilation)
+    if d < 1 or h % d or w % d:
+        return False
+    cout, cin = weight.shape[0], weight.shape[1]
+    if cout % 8 or cin % 8:
+        return False
+    key = (b * d * d, cin, cout, h // d, w // d)
+    hit = _conv3x3_ok.get(key)
+    if hit is None:
+        hit = bool(lib().sis_conv3x3_eligible(*key)) and bool(lib().sis_conv3x3_eligible(key[0], cout, cin, key[3], key[4]))
+        _conv3x3_ok[key] = hit
+    return hit
+
+
+_conv3x3_ok = {}
 
 
 def conv3x3_prepack(weight, adjoint=False):

@@ -12,20 +12,21 @@ SHAPES = [(2, 64, 128, 32, 32), (3, 128, 64, 16, 24), (1, 256, 8, 8, 8), (16, 64
           (5, 8, 8, 2, 4)]
 
 
-@pytest.mark.parametrize("batch,cin,cout,h,w", SHAPES)
-def test_forward_and_data_gradient(device, batch, cin, cout, h, w):
+@pytest.mark.parametrize("batch,cin,cout,h,w,dil", [s + (1,) for s in SHAPES] + [(2, 64, 32, 32, 32, 2), (3, 256, 256, 32, 32, 2),
+                                                   (2, 64, 64, 32, 32, 4), (1, 8, 16, 16, 24, 2)])
+def test_forward_and_data_gradient(device, batch, cin, cout, h, w, dil):
     import sis_hip
     from networks.hip_conv import conv3x3
     g = torch.Generator().manual_seed(batch * 1000 + cin)
     x = torch.randn(batch, cin, h, w, generator=g).to(device).requires_grad_(True)
     wt = (torch.randn(cout, cin, 3, 3, generator=g) * (cin * 9) ** -0.5).to(device).requires_grad_(True)
     gy = torch.randn(batch, cout, h, w, generator=g).to(device)
-    assert sis_hip.conv3x3_supported(x, wt)
-    y = conv3x3(x, wt)
+    assert sis_hip.conv3x3_supported(x, wt, dil)
+    y = conv3x3(x, wt, dil)
     y.backward(gy)
     gx, gw = x.grad.clone(), wt.grad.clone()
     x.grad = wt.grad = None
-    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    ref = F.conv2d(x.double(), wt.double(), padding=dil, dilation=dil)
     ref.backward(gy.double())
     for got, want, name in ((y, ref, "y"), (gx, x.grad, "dx"), (gw, wt.grad, "dw")):
         want = want.detach().float()
@@ -46,9 +47,10 @@ def test_module_dispatch_and_fallback(device):
         sis_hip.set_profiler(None)
     assert [r[0] for r in rec] == ["modconv_wino2_kernel"], "the 3x3 layer did not run on the HIP kernel"
     np.testing.assert_allclose(y.detach().cpu().numpy(), F.conv2d(x, conv.weight, padding=1).detach().cpu().numpy(),
-                               atol=2e-5 * float(y.abs().max()))
+                               atol=2e-5 * float(y.detach().abs().max()))
     # not eligible: dilation 2, stride 2, odd width, bias -> ATen, same result as nn.Conv2d
-    for kwargs, shape in (({"dilation": 2, "padding": 2}, (2, 64, 16, 16)), ({"stride": 2, "padding": 1}, (2, 64, 16, 16)),
+    for kwargs, shape in (({"dilation": 16, "padding": 16}, (2, 64, 32, 32)), ({"dilation": 2, "padding": 1}, (2, 64, 16, 16)),
+                          ({"stride": 2, "padding": 1}, (2, 64, 16, 16)),
                           ({"padding": 1}, (2, 64, 16, 15))):
         c = HipConv2d(64, 32, 3, bias=False, **kwargs).to(device)
         xi = torch.randn(*shape, device=device)

@@ -11,7 +11,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 dev = torch.device("cuda")
 shapes = [  # (k, cin, cout, hw, dilation)
     (3, 2048, 512, 32, 1), (3, 512, 256, 32, 1), (3, 64, 64, 128, 1), (3, 64, 128, 128, 1), (3, 64, 64, 64, 1),
-    (3, 128, 128, 32, 1), (3, 256, 256, 32, 2), (3, 512, 512, 32, 4),
+    (3, 128, 128, 32, 1), (3, 256, 256, 32, 2), (3, 512, 512, 32, 2), (3, 512, 512, 32, 4), (3, 512, 512, 32, 8),
     (1, 128, 64, 64, 1), (1, 64, 256, 64, 1), (1, 256, 64, 64, 1), (1, 128, 512, 32, 1), (1, 512, 128, 32, 1),
     (1, 512, 256, 32, 1), (1, 256, 1024, 32, 1), (1, 1024, 256, 32, 1), (1, 1024, 512, 32, 1), (1, 512, 2048, 32, 1),
     (1, 2048, 512, 32, 1), (1, 512, 512, 32, 1),
@@ -36,6 +36,25 @@ for k, cin, cout, hw, dil in shapes:
     flops = 2.0 * B * cout * cin * k * k * hw * hw
     t_aten = timeit(lambda: F.conv2d(x, w, padding=dil * (k // 2), dilation=dil))
     ours = float("nan")
+    if dil > 1 and k == 3:
+        d = dil
+        u = sis_hip.conv3x3_prepack(w)
+
+        def s2b(t):
+            b, c, h, ww = t.shape
+            return t.view(b, c, h // d, d, ww // d, d).permute(0, 3, 5, 1, 2, 4).reshape(b * d * d, c, h // d, ww // d)
+
+        def b2s(t, b):
+            _, c, h, ww = t.shape
+            return t.view(b, d, d, c, h, ww).permute(0, 3, 4, 1, 5, 2).reshape(b, c, h * d, ww * d)
+
+        def run():
+            return b2s(sis_hip.conv3x3(s2b(x).contiguous(), u), B)
+        y = run()
+        ref = F.conv2d(x, w, padding=dil, dilation=dil)
+        err = ((y - ref).abs().max() / ref.abs().max()).item()
+        assert err < 1e-4, err
+        ours = timeit(run)
     if dil == 1:
         wpk, _ = sis_hip.modconv_prepack(w.view(1, cout, cin, k, k))
         u = sis_hip.modconv_prepack_wino(w.view(1, cout, cin, k, k)) if k == 3 else None
