@@ -10,8 +10,9 @@ kernel is 1.5-1.9x faster than the library's fp32 path (2048->512 @32^2: 1.70 vs
 direct kernels.
 
 Autograd: the data gradient is the same kernel with adjoint weights (``sis_conv3x3_prepack(adjoint=1)``: channel
-axes swapped, taps rotated by 180 degrees); the weight gradient (a reduction over pixels, a different kernel
-shape) is ATen's ``convolution_backward``.
+axes swapped, taps rotated by 180 degrees); the weight gradient is ``sis_conv3x3_wgrad`` (Winograd-domain GEMM over
+the tile axis, csrc/conv_wgrad_wino.hip) where its tile plan applies (channels % 64, W % 16) and ATen's
+``convolution_backward`` otherwise.
 """
 import torch
 from torch import nn
@@ -54,8 +55,12 @@ class _Conv3x3Function(Function):
             grad_input = _batch_to_space(sis_hip.conv3x3(_space_to_batch(grad_output, d),
                                                          sis_hip.conv3x3_prepack(weight, adjoint=True)), d)
         if ctx.needs_input_grad[1]:
-            grad_weight = torch.ops.aten.convolution_backward(
-                grad_output, input, weight, None, (1, 1), (d, d), (d, d), False, (0, 0), 1, (False, True, False))[1]
+            b, cin, h, w = input.shape
+            if sis_hip.conv3x3_wgrad_supported(b * d * d, cin, weight.shape[0], h // d, w // d):
+                grad_weight = sis_hip.conv3x3_wgrad(_space_to_batch(input, d), _space_to_batch(grad_output, d))
+            else:  # narrow sub-images / channel counts below a 64 x 64 tile: the library's kernel
+                grad_weight = torch.ops.aten.convolution_backward(
+                    grad_output, input, weight, None, (1, 1), (d, d), (d, d), False, (0, 0), 1, (False, True, False))[1]
         return grad_input, grad_weight, None
 
 

@@ -43,6 +43,8 @@ _SIGNATURES = {
     "sis_last_kernel": ([], ctypes.c_char_p),
     "sis_conv3x3_prepack": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "sis_conv3x3_eligible": ([_i] * 5, _i),
+    "sis_conv3x3_wgrad_eligible": ([_i] * 5 + [_i64], _i),
+    "sis_conv3x3_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
     "sis_conv3x3": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
     "sis_modconv2d_up": ([_vp] * 5 + [_i] * 6 + [_vp, _i64, _vp], _i),
     "sis_blur_noise_act": ([_vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 10 + [_vp], _i),
@@ -328,6 +330,30 @@ def conv3x3(x, u):
                        lambda: lib().sis_conv3x3(_ptr(out), _ptr(x), _ptr(u), batch, cin, cout, h, w, _ptr(ws), ws.numel(),
                                                  _stream())), "sis_conv3x3")
     return out
+
+
+def conv3x3_wgrad_supported(batch, cin, cout, h, w, min_work=5e8):
+    """Capability (tile plan: channels % 64, W % 16, workspace) and policy: below ~5e8 multiply-accumulates per tap
+    the split-K reduction outweighs the MFMA time and the library's kernel is as fast or faster (measured on
+    EMANet-50's layers, tools/bench_wgrad_shapes.py: 64->64 @64^2 loses, 64->64 @128^2 and 256->256 @32^2 win)."""
+    if float(batch) * h * w * cin * cout < min_work:
+        return False
+    return bool(lib().sis_conv3x3_wgrad_eligible(batch, cin, cout, h, w, WORKSPACE_BYTES))
+
+
+def conv3x3_wgrad(x, grad_output):
+    """dL/dw [Cout,Cin,3,3] of a stride-1, padding-1 3x3 convolution from its input x [B,Cin,H,W] and dL/dy."""
+    x = _f32(x, "input")
+    gy = _f32(grad_output, "grad_output")
+    batch, cin, h, w = x.shape
+    cout = gy.shape[1]
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    ws = _workspace(x.device)
+    with torch.cuda.device(x.device):
+        _check(_launch(None, 2.0 * batch * cout * cin * 9 * h * w, 4.0 * (x.numel() + gy.numel() + dw.numel()),
+                       lambda: lib().sis_conv3x3_wgrad(_ptr(dw), _ptr(x), _ptr(gy), batch, cin, cout, h, w, _ptr(ws),
+                                                       ws.numel(), _stream())), "sis_conv3x3_wgrad")
+    return dw
 
 
 def modconv_demod(s, wsq, scale, demodulate):

@@ -8,7 +8,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(2, 64, 128, 32, 32), (3, 128, 64, 16, 24), (1, 256, 8, 8, 8), (16, 64, 64, 64, 64), (2, 2048, 512, 32, 32),
+SHAPES = [(2, 64, 128, 32, 32), (2, 128, 64, 16, 32), (3, 64, 64, 64, 64), (3, 128, 64, 16, 24), (1, 256, 8, 8, 8), (16, 64, 64, 64, 64), (2, 2048, 512, 32, 32),
           (5, 8, 8, 2, 4)]
 
 
@@ -31,7 +31,23 @@ def test_forward_and_data_gradient(device, batch, cin, cout, h, w, dil):
     for got, want, name in ((y, ref, "y"), (gx, x.grad, "dx"), (gw, wt.grad, "dw")):
         want = want.detach().float()
         err = (got.detach() - want).abs().max().item() / want.abs().max().item()
-        assert err < (2e-5 if name != "dw" else 1e-4), (name, err)
+        assert err < (2e-5 if name != "dw" else 2e-4), (name, err)
+
+
+@pytest.mark.parametrize("batch,cin,cout,h,w", [(2, 64, 128, 32, 32), (1, 128, 64, 16, 16), (3, 64, 64, 64, 48), (16, 512, 256, 32, 32)])
+def test_weight_gradient_kernel(device, batch, cin, cout, h, w):
+    """sis_conv3x3_wgrad directly (the autograd wrapper only takes it above a work threshold)."""
+    import sis_hip
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(batch, cin, h, w, generator=g).to(device)
+    gy = torch.randn(batch, cout, h, w, generator=g).to(device)
+    assert sis_hip.conv3x3_wgrad_supported(batch, cin, cout, h, w, min_work=0)
+    got = sis_hip.conv3x3_wgrad(x, gy)
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, device=device, requires_grad=True)
+    F.conv2d(x.double(), wt, padding=1).backward(gy.double())
+    err = (got - wt.grad.float()).abs().max().item() / wt.grad.abs().max().item()
+    assert err < 2e-4, err
+    assert not sis_hip.conv3x3_wgrad_supported(batch, cin, cout, h, w + 4, min_work=0)  # W % 16
 
 
 def test_module_dispatch_and_fallback(device):
