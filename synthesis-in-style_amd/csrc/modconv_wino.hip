@@ -119,9 +119,9 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams
     const int k_hi = min(p.Cin, k_lo + p.kchunk);
 
     for (int e = tid; e < 2 * WCC * xt; e += WNTHR) Xl[e] = 0.f;
-    for (int e = tid; e < tc.nb * p.Cin; e += WNTHR) {
+    for (int e = tid; e < (p.s ? tc.nb * p.Cin : 0); e += WNTHR) {  // plain convolution (p.s == nullptr): no style rows
         const int n = e / p.Cin, ci = e - n * p.Cin;
-        Sl[e] = (b0 + n < p.B) ? (p.s ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 1.f) : 0.f;
+        Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
     }
     // one float4 chunk of the tile per lane per channel (<= 512 chunks: host-checked)
     int st_goff = -1;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams
         const float* Xb = Xl + buf * WCC * xt + xo;
 #pragma unroll
         for (int cp = 0; cp < WCC / 2; ++cp) {
-            const float sv = Sl[so + ci0 + 2 * cp];
+            const float sv = p.s ? Sl[so + ci0 + 2 * cp] : 1.f;
             const float* xb = Xb + 2 * cp * xt;
             float d[4][4];
 #pragma unroll
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     const int txo = min(ttn, tc.nb - 1) * eh * ew + 2 * tty * ew + 2 * ttx + 2 + tch * xt;
     const int tso = min(ttn, tc.nb - 1) * p.Cin + tch;
     auto transform = [&](int ci0, int xbuf, int vbuf) {
-        const float sv = Sl[tso + ci0];
+        const float sv = p.s ? Sl[tso + ci0] : 1.f;
         const float* xb = Xl + xbuf * WCC * xt + txo;
         float d[4][4];
 #pragma unroll
@@ -425,9 +425,9 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
 #pragma unroll
         for (int j = 0; j < 2 * WCC; ++j) *reinterpret_cast<float4*>(Xl + j * xt + tid * 4) = z;
     }
-    for (int e = tid; e < tc.nb * p.Cin; e += WNTHR) {
+    for (int e = tid; e < (p.s ? tc.nb * p.Cin : 0); e += WNTHR) {  // plain convolution (p.s == nullptr): no style rows
         const int n = e / p.Cin, ci = e - n * p.Cin;
-        Sl[e] = (b0 + n < p.B) ? (p.s ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 1.f) : 0.f;
+        Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
     }
     // layer-tail operands of the 8 accumulator rows this lane finalises (see the epilogue), fetched now so that
     // the tail is not a chain of dependent global loads
@@ -596,7 +596,7 @@ int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t 
             p.slab = (float*)workspace;
         }
     }
-    const size_t lds = (size_t)(2 * WCC * 16 * WMBLK + 2 * WCC * tc.xt + p.nb_max * p.Cin) * sizeof(float);
+    const size_t lds = (size_t)(2 * WCC * 16 * WMBLK + 2 * WCC * tc.xt + (p.s ? p.nb_max * p.Cin : 0)) * sizeof(float);
     const size_t lds2 = lds + (size_t)2 * 16 * WCC * WTILES * sizeof(float);
     if (lds > 160 * 1024) return -1;
     if (plan_only) return 0;
