@@ -70,6 +70,22 @@ def conv3x3(input, weight, dilation=1):
     return _Conv3x3Function.apply(input, weight, dilation)
 
 
+def conv3x3_half_image_dilation(input, weight):
+    """3x3 convolution whose dilation is half the image side (padding = dilation): every output pixel (u*d + p,
+    v*d + q) only sees the 2 x 2 pixels {(u'*d + p, v'*d + q)} -- EMANet's last bottleneck (dilation 16 on 32 x 32).
+    That is one dense [4 Cin] -> [4 Cout] linear map per (p, q), a single GEMM with 4/9 of the multiplies a 9-tap
+    convolution spends (5 of its taps fall into the zero padding); autograd differentiates the composite."""
+    b, cin, h, w = input.shape
+    d = h // 2
+    cout = weight.shape[0]
+    x = input.view(b, cin, 2, d, 2, d).permute(0, 3, 5, 2, 4, 1).reshape(b * d * d, 4 * cin)  # rows (b,p,q), cols (u',v',ci)
+    taps = torch.stack([torch.stack([torch.stack([torch.stack([weight[:, :, u2 - u + 1, v2 - v + 1] for v2 in (0, 1)], 1)
+                                                  for u2 in (0, 1)], 1) for v in (0, 1)], 0) for u in (0, 1)], 0)
+    # taps [u, v, co, u', v', ci]
+    y = x @ taps.reshape(4 * cout, 4 * cin).t()
+    return y.view(b, d, d, 2, 2, cout).permute(0, 5, 3, 1, 4, 2).reshape(b, cout, h, w)
+
+
 class HipConv2d(nn.Conv2d):
     def _eligible(self, input):
         return (self.kernel_size == (3, 3) and self.stride == (1, 1) and self.dilation[0] == self.dilation[1]
@@ -77,7 +93,15 @@ class HipConv2d(nn.Conv2d):
                 and self.padding_mode == 'zeros' and not torch.is_autocast_enabled()
                 and input.is_contiguous() and sis_hip.conv3x3_supported(input, self.weight, self.dilation[0]))
 
+    def _half_image_dilation(self, input):
+        d = self.dilation[0]
+        return (self.kernel_size == (3, 3) and self.stride == (1, 1) and self.dilation == (d, d) and self.padding == (d, d)
+                and self.groups == 1 and self.bias is None and self.padding_mode == 'zeros' and input.dim() == 4
+                and input.shape[2] == 2 * d and input.shape[3] == 2 * d and input.is_cuda)
+
     def forward(self, input):
+        if self._half_image_dilation(input):
+            return conv3x3_half_image_dilation(input, self.weight)
         if self._eligible(input):
             return conv3x3(input, self.weight, self.dilation[0])
         return super().forward(input)

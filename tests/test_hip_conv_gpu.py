@@ -65,7 +65,7 @@ def test_module_dispatch_and_fallback(device):
     np.testing.assert_allclose(y.detach().cpu().numpy(), F.conv2d(x, conv.weight, padding=1).detach().cpu().numpy(),
                                atol=2e-5 * float(y.detach().abs().max()))
     # not eligible: dilation 2, stride 2, odd width, bias -> ATen, same result as nn.Conv2d
-    for kwargs, shape in (({"dilation": 16, "padding": 16}, (2, 64, 32, 32)), ({"dilation": 2, "padding": 1}, (2, 64, 16, 16)),
+    for kwargs, shape in (({"dilation": 3, "padding": 3}, (2, 64, 32, 32)), ({"dilation": 2, "padding": 1}, (2, 64, 16, 16)),
                           ({"stride": 2, "padding": 1}, (2, 64, 16, 16)),
                           ({"padding": 1}, (2, 64, 16, 15))):
         c = HipConv2d(64, 32, 3, bias=False, **kwargs).to(device)
@@ -79,3 +79,22 @@ def test_module_dispatch_and_fallback(device):
         assert rec == []
         assert torch.equal(out, F.conv2d(xi, c.weight, None, c.stride, c.padding, c.dilation))
     assert sorted(HipConv2d(8, 8, 3).state_dict().keys()) == ["bias", "weight"]
+
+
+def test_half_image_dilation_is_the_dilated_convolution(device):
+    from networks.hip_conv import HipConv2d, conv3x3_half_image_dilation
+    g = torch.Generator().manual_seed(16)
+    x = torch.randn(3, 16, 32, 32, generator=g).to(device).requires_grad_(True)
+    conv = HipConv2d(16, 24, 3, 1, 16, 16, bias=False).to(device)
+    gy = torch.randn(3, 24, 32, 32, generator=g).to(device)
+    assert conv._half_image_dilation(x)
+    y = conv(x)
+    y.backward(gy)
+    got = (y.detach(), x.grad.clone(), conv.weight.grad.clone())
+    x.grad = conv.weight.grad = None
+    ref = F.conv2d(x.double(), conv.weight.double(), padding=16, dilation=16)
+    ref.backward(gy.double())
+    for a, b in zip(got, (ref, x.grad, conv.weight.grad)):
+        b = b.detach().float()
+        assert (a - b).abs().max().item() < 1e-5 * b.abs().max().item()
+    assert not conv._half_image_dilation(torch.zeros(1, 16, 64, 64, device=device))
