@@ -7,7 +7,7 @@
 // dY_t = 2x2 tile of dL/dy, d_t = the 4x4 input patch around it: 16 multiplies per (co, ci, tile) instead of 36.
 // Per Winograd point xi this is a GEMM  S[xi] (co x ci) += E[xi] (co x tiles) * V[xi] (tiles x ci)  whose reduction
 // axis is the tile index.  Workgroup = 8 waves = 64 co x 64 ci x 16 xi (same accumulator split over wave pairs as
-// the forward kernel), K chunk = 8 tiles of one tile row; per chunk every lane loads ONE dY tile and ONE input
+// the forward kernel), K chunk = 8 consecutive tiles of the flattened (sample, row, column) tile order; per chunk every lane loads ONE dY tile and ONE input
 // patch from global memory into registers (one chunk ahead), transforms both and writes them into two LDS images
 // E / V [xi][tile][channel] (row stride 72 floats: the 8 tiles x 8 channels of a wave land 2-way on the banks,
 // which costs a ds_write_b32 nothing); the MFMA operands are then plain conflict-free ds_read_b32.  The two waves
@@ -29,7 +29,7 @@ constexpr int GTHR = 512;
 struct WgradParams {
     const float* x; const float* gy; float* slab;
     int B, Cin, Cout, H, W;
-    int chunks_total, chunks_per_slice, chunks_per_row, rows_per_sample;
+    int chunks_total, chunks_per_slice, tiles_per_row, tiles_per_sample;
 };
 
 __global__ __launch_bounds__(GTHR, 2) void conv_wgrad_wino_kernel(const WgradParams p) {
@@ -54,10 +54,10 @@ __global__ __launch_bounds__(GTHR, 2) void conv_wgrad_wino_kernel(const WgradPar
 
     f32x2 xr[4][3];  // input patch rows 2ty-1 .. 2ty+2, columns 2tx-2 .. 2tx+3 as three aligned pairs
     f32x2 gr[2];     // dY tile rows
-    auto load = [&](int chunk) {
-        const int row_id = chunk / p.chunks_per_row, cx = chunk - row_id * p.chunks_per_row;
-        const int b = row_id / p.rows_per_sample, ty = row_id - b * p.rows_per_sample;
-        const int tx = cx * GK + tk;
+    auto load = [&](int chunk) {  // tile t = chunk * GK + tk of the flattened (sample, tile row, tile column) order
+        const int t = chunk * GK + tk;
+        const int b = t / p.tiles_per_sample, rem = t - b * p.tiles_per_sample;
+        const int ty = rem / p.tiles_per_row, tx = rem - ty * p.tiles_per_row;
         const float* xb = xplane + (int64_t)b * p.Cin * HW + (2 * ty - 1) * p.W + 2 * tx - 2;
         const float* gb = gplane + (int64_t)b * p.Cout * HW + 2 * ty * p.W + 2 * tx;
         const bool left = tx > 0, right = 2 * tx + 2 < p.W;
@@ -218,12 +218,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(float* __restric
 
 int wgrad_plan(WgradParams& p, int* ksplit, int batch, int cin, int cout, int h, int w, int64_t workspace_bytes) {
     if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return -1;
-    if (h % 2 || w % 16 || cin % GBLK || cout % GBLK) return -1;
+    if (h % 2 || w % 2 || cin % GBLK || cout % GBLK) return -1;
+    if (((int64_t)batch * (h / 2) * (w / 2)) % GK) return -1;  // whole chunks of GK tiles
     if ((int64_t)batch * (cin > cout ? cin : cout) * h * w >= ((int64_t)1 << 31)) return -1;
     p.B = batch; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w;
-    p.chunks_per_row = w / (2 * GK);
-    p.rows_per_sample = h / 2;
-    p.chunks_total = batch * p.rows_per_sample * p.chunks_per_row;
+    p.tiles_per_row = w / 2;
+    p.tiles_per_sample = (h / 2) * (w / 2);
+    p.chunks_total = (int)((int64_t)batch * p.tiles_per_sample / GK);
     const int64_t blocks = (int64_t)(cin / GBLK) * (cout / GBLK);
     const int64_t slab_bytes = (int64_t)16 * cin * cout * 4;
     int want = (int)((512 + blocks - 1) / blocks);            // ~2 workgroup rounds over 256 CUs
@@ -251,7 +252,7 @@ extern "C" int sis_conv3x3_wgrad(float* dw, const float* x, const float* gy, int
     WgradParams p;
     int ksplit = 1;
     SIS_REQUIRE(wgrad_plan(p, &ksplit, batch, cin, cout, h, w, workspace_bytes) == 0,
-                "sis_conv3x3_wgrad: needs H %% 2 == 0, W %% 16 == 0, channels %% 64 == 0 and a workspace of at least "
+                "sis_conv3x3_wgrad: needs even H and W, B*H*W/4 %% 8 == 0, channels %% 64 == 0 and a workspace of at least "
                 "64 * Cin * Cout bytes (got %d x %dx%d, %d -> %d)", batch, h, w, cin, cout);
     p.x = x; p.gy = gy; p.slab = (float*)workspace;
     const size_t lds = (size_t)4 * 16 * GK * GLD * sizeof(float);

@@ -11,7 +11,7 @@ direct kernels.
 
 Autograd: the data gradient is the same kernel with adjoint weights (``sis_conv3x3_prepack(adjoint=1)``: channel
 axes swapped, taps rotated by 180 degrees); the weight gradient is ``sis_conv3x3_wgrad`` (Winograd-domain GEMM over
-the tile axis, csrc/conv_wgrad_wino.hip) where its tile plan applies (channels % 64, W % 16) and ATen's
+the tile axis, csrc/conv_wgrad_wino.hip) where its tile plan applies (channels % 64) and there is enough work, ATen's
 ``convolution_backward`` otherwise.
 """
 import torch

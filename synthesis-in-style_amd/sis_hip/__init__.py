@@ -333,7 +333,7 @@ def conv3x3(x, u):
 
 
 def conv3x3_wgrad_supported(batch, cin, cout, h, w, min_work=5e8):
-    """Capability (tile plan: channels % 64, W % 16, workspace) and policy: below ~5e8 multiply-accumulates per tap
+    """Capability (tile plan: channels % 64, even H / W, whole 8-tile chunks, workspace) and policy: below ~5e8 multiply-accumulates per tap
     the split-K reduction outweighs the MFMA time and the library's kernel is as fast or faster (measured on
     EMANet-50's layers, tools/bench_wgrad_shapes.py: 64->64 @64^2 loses, 64->64 @128^2 and 256->256 @32^2 win)."""
     if float(batch) * h * w * cin * cout < min_work:
