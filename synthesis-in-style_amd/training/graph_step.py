@@ -17,7 +17,7 @@ import torch
 
 
 class StepGraph:
-    def __init__(self, warmup: int = 3, enabled: bool = True):
+    def __init__(self, warmup: int = 2, enabled: bool = True):
         self.warmup = max(int(warmup), 1)  # FusedSGD needs one eager step before capture
         self.enabled = enabled and os.environ.get("SIS_STEP_GRAPH", "1") != "0"
         self.graph = None

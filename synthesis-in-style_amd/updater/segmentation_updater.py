@@ -10,7 +10,7 @@ Mirrors updater/segmentation_updater.py:42-106 of the reference: same class name
 MI355X specifics: the bases update is one HIP kernel (``sis_ema_update``), the EMANet loss tail is fused inside
 the network (networks/ema_net/network.py), the optimizer step is the one-launch ``FusedSGD`` the builders
 create, gradients are all-reduced by DistributedDataParallel over RCCL while backward is still running.
-Single-process training replays the whole iteration as a hipGraph after three eager iterations
+Single-process training replays the whole iteration as a hipGraph after two eager iterations
 (training/graph_step.py; keyword ``hip_graph=False`` or SIS_STEP_GRAPH=0 keeps it eager).
 """
 import torch
@@ -41,7 +41,7 @@ class _GraphedUpdater(Updater):
     def __init__(self, *args, **kwargs):
         hip_graph = kwargs.pop('hip_graph', True)
         super().__init__(*args, **kwargs)
-        self._step_graph = StepGraph(warmup=3, enabled=bool(hip_graph) and _graphable(
+        self._step_graph = StepGraph(warmup=2, enabled=bool(hip_graph) and _graphable(
             self.networks['segmentation'], self.optimizers['main'], self.device))
 
     def _iteration(self, batch):
