@@ -290,14 +290,18 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams
 // one chunk ahead of the MFMAs, so the matrix loop is nothing but ds_read_b32 pairs and MFMAs (in the kernel above
 // every patch is re-read and re-transformed by the 4 waves that share it: 48.5 % MFMA-busy measured).  Per
 // iteration c: DMA weights(c+1), DMA input(c+2), transform(c+1) -> V, MFMA(c); one barrier.
-__global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParams p, const int xt_max) {
+__global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParams p, const int xt_max, const int tiles_per_wg) {
     constexpr int WF = WCC * 16 * WMBLK;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int VF = 16 * WCC * WTILES;  // transformed input of one chunk: [xi][channel][tile]
-    float* Ul = lds;                    // [2][WF]   (64 KB; reused for the column exchange in the epilogue)
-    float* Vl = lds + 2 * WF;           // [2][VF]   (64 KB)
+    float* Ul = lds;                    // [2][WF]   (64 KB)
+    float* Vl = lds + 2 * WF;           // [2][VF]   (64 KB; reused for the column exchange in the epilogue)
     float* Xl = Vl + 2 * VF;            // [2][WCC * xt]
-    float* Sl = Xl + 2 * WCC * xt_max;  // [nb][Cin]
+    float* Sl = Xl + 2 * WCC * xt_max;  // [nb][Cin]   (absent for a plain convolution)
+    float* Tl = Sl + (p.s ? p.nb_max * p.Cin : 0);  // layer-tail operands of the current tile:
+    float* Dl = Tl;                      //   [nb][WMBLK] scale * demodulation
+    float* Bl = Dl + p.nb_max * WMBLK;   //   [WMBLK]     bias
+    float* Nl = Bl + WMBLK;              //   [WTILES][4] noise_weight * noise of the tile's pixels
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -309,15 +313,10 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     // 4 MiB L2) while the n_co workgroups that share an input tile run at the same time on different XCDs
     // (one HBM read, the rest MALL hits).  Pixel-tile-fastest order measured a 48 % L2 miss rate on this kernel.
     const int n_co = (p.Cout + WMBLK - 1) / WMBLK;
-    int pt = blockIdx.x / n_co;
     const int o0 = (blockIdx.x % n_co) * WMBLK;
     const TileClass tc = p.cls[0];
-    const int twi = pt % tc.ntw; pt /= tc.ntw;
-    const int thi = pt % tc.nth;
-    const int bt = pt / tc.nth;
     const int thl = tc.th_log2, twl = tc.tw_log2;
     const int th = 1 << thl, tw = 1 << twl;
-    const int b0 = bt * tc.nb, h0 = thi << thl, w0 = twi << twl;
     // staged input tile: rows h0-1 .. h0+th, columns w0-4 .. w0+tw+3 (16-byte aligned superset of the 1-pixel
     // halo: W and w0 are multiples of 4, so every aligned float4 is entirely inside or entirely outside the image)
     const int eh = th + 2, ew = tw + 8;
@@ -325,11 +324,19 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     const int HW = p.H * p.W;
     const int k_lo = blockIdx.y * p.kchunk;
     const int k_hi = min(p.Cin, k_lo + p.kchunk);
-
-    // one float4 chunk of the tile per lane per channel (<= 512 chunks: host-checked)
     const int tpl0 = thl + twl - 2;  // log2(tiles per sample)
-    int st_goff = -1;
-    {
+
+    // A workgroup walks `tiles_per_wg` consecutive pixel tiles of its output-channel block (persistent over
+    // tiles): the next tile's first DMA flies under the current tile's epilogue, and the per-workgroup launch /
+    // first-touch latency is paid once per `tiles_per_wg` tiles instead of once per tile (7 us against 16 chunks
+    // x 2.5 us on the 128-channel 256^2 layer).
+    int b0, h0, w0;
+    int st_goff;  // one float4 chunk of the tile per lane per channel (<= 512 chunks: host-checked); -1: outside
+    auto tile_setup = [&](int pt) {
+        const int twi = pt % tc.ntw; pt /= tc.ntw;
+        const int thi = pt % tc.nth;
+        b0 = (pt / tc.nth) * tc.nb; h0 = thi << thl; w0 = twi << twl;
+        st_goff = -1;
         const int ew4 = ew >> 2;
         if (tid < (xt >> 2)) {
             const int n = tid / (eh * ew4), rem = tid - n * (eh * ew4);
@@ -337,7 +344,9 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
             const int b = b0 + n, h = h0 - 1 + r, w = w0 - 4 + 4 * c4;
             if (b < p.B && h >= 0 && h < p.H && w >= 0 && w < p.W) st_goff = b * p.Cin * HW + h * p.W + w;
         }
-    }
+    };
+    const int pt_first = (blockIdx.x / n_co) * tiles_per_wg;
+    tile_setup(pt_first);
     constexpr int WV4 = WF / 4, WIT = WV4 / WNTHR;  // 4 float4 per lane per chunk
     int w_goff[WIT];
 #pragma unroll
@@ -404,148 +413,179 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     const int aoff = half * 16 * WMBLK + wm * 32 + l31 + 2 * q * WMBLK;  // + (4 i + jj) * WMBLK
 
     f32x16 acc[4][2];  // [row i of M][column jj of this wave's pair]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc[i][jj][j] = 0.f;
 
     // B operand of this lane in the V image: [xi][channel 2cp + half][tile wn*32 + l31]
     const int voff = half * WTILES + wn * 32 + l31 + 2 * q * WCC * WTILES;  // + (4 i + jj) * WCC*WTILES + 2cp*WTILES
-
-    // ---- prologue: every global access of the start-up is in flight before the first wait (one memory round trip
-    // instead of three).  The DMA never writes out-of-image float4 slots, so the lanes owning such slots store the
-    // zeros themselves (disjoint from every DMA destination: no ordering needed).
-    stage_u(k_lo, 0);
-    stage_x(k_lo, 0);
-    if (k_lo + WCC < k_hi) stage_x(k_lo + WCC, 1);
-    if (tid < (xt >> 2) && st_goff < 0) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int j = 0; j < 2 * WCC; ++j) *reinterpret_cast<float4*>(Xl + j * xt + tid * 4) = z;
-    }
-    for (int e = tid; e < (p.s ? tc.nb * p.Cin : 0); e += WNTHR) {  // plain convolution (p.s == nullptr): no style rows
-        const int n = e / p.Cin, ci = e - n * p.Cin;
-        Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
-    }
-    // layer-tail operands of the 8 accumulator rows this lane finalises (see the epilogue), fetched now so that
-    // the tail is not a chain of dependent global loads
     const bool partial = p.ksplit > 1;
-    const int ob = b0 + tn, oh = h0 + 2 * ty, ow = w0 + 2 * tx;
-    const bool live = tn < tc.nb && ob < p.B && oh < p.H && ow < p.W;
-    float nz[4] = {0.f, 0.f, 0.f, 0.f};
-    float dd[8], bb[8];
+    const bool late_transform = __builtin_amdgcn_readfirstlane(wave) >= 4;
+
+    // First DMA of a tile: every global access of the start-up is in flight before the first wait (one memory
+    // round trip).  The DMA never writes out-of-image float4 slots, so the lanes owning such slots store the zeros
+    // themselves (disjoint from every DMA destination: no ordering needed).
+    auto tile_first_dma = [&]() {
+        stage_u(k_lo, 0);
+        stage_x(k_lo, 0);
+        if (k_lo + WCC < k_hi) stage_x(k_lo + WCC, 1);
+        if (tid < (xt >> 2) && st_goff < 0) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) { dd[jj] = 1.f; bb[jj] = 0.f; }
-    if (live && !partial) {
-        if (p.fuse && p.noise) {
-            const float nw = p.noise_w[0];
-            const float* np = p.noise + (int64_t)ob * p.noise_bstride + oh * p.W + ow;
-            nz[0] = nw * np[0]; nz[1] = nw * np[1]; nz[2] = nw * np[p.W]; nz[3] = nw * np[p.W + 1];
+            for (int j = 0; j < 2 * WCC; ++j) *reinterpret_cast<float4*>(Xl + j * xt + tid * 4) = z;
         }
-        const float* db = p.dscale + (int64_t)ob * p.Cout;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int co = o0 + wm * 32 + 16 * q + 4 * half + (jj & 3) + 8 * (jj >> 2);
-            if (co < p.Cout) {
-                if (p.dscale) dd[jj] = db[co];
-                if (p.fuse && p.bias) bb[jj] = p.bias[co];
-            }
+        for (int e = tid; e < (p.s ? tc.nb * p.Cin : 0); e += WNTHR) {  // plain convolution (p.s == nullptr): no style rows
+            const int n = e / p.Cin, ci = e - n * p.Cin;
+            Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
         }
-    }
+    };
+    // Layer-tail operands (demodulation, bias, noise) of a tile: fetched into registers a whole tile ahead, parked in
+    // LDS once nobody reads the previous tile's any more, read back in the epilogue -- no dependent global loads
+    // in the tail and no registers held across the matrix loop.
+    float t_noise = 0.f, t_scale = 1.f, t_bias = 0.f;
+    auto tail_load = [&]() {
+        t_noise = 0.f; t_scale = 1.f; t_bias = 0.f;
+        if (partial) return;
+        if (p.fuse && p.noise && tid < WTILES * 4) {
+            const int tt_ = tid >> 2, e = tid & 3;
+            const int n = tt_ >> tpl0, rem = tt_ & ((1 << tpl0) - 1);
+            const int yy = h0 + 2 * (rem >> (twl - 1)) + (e >> 1), xx = w0 + 2 * (rem & ((tw >> 1) - 1)) + (e & 1);
+            if (n < tc.nb && b0 + n < p.B && yy < p.H && xx < p.W)
+                t_noise = p.noise_w[0] * p.noise[(int64_t)(b0 + n) * p.noise_bstride + yy * p.W + xx];
+        }
+        if (tid < tc.nb * WMBLK) {
+            const int n = tid / WMBLK, co = o0 + tid % WMBLK;
+            if (p.dscale && b0 + n < p.B && co < p.Cout) t_scale = p.dscale[(int64_t)(b0 + n) * p.Cout + co];
+            if (n == 0 && p.fuse && p.bias && co < p.Cout) t_bias = p.bias[co];
+        }
+    };
+    auto tail_store = [&]() {
+        if (tid < WTILES * 4) Nl[tid] = t_noise;
+        if (tid < tc.nb * WMBLK) Dl[tid] = t_scale;
+        if (tid < WMBLK) Bl[tid] = t_bias;
+    };
+
+    tile_first_dma();
+    tail_load();
     __syncthreads();  // chunk 0 (and input chunk 1) landed, styles and zeros visible
+    tail_store();
     transform(k_lo, 0, 0);
     __syncthreads();  // V(0) visible
 
-    const bool late_transform = __builtin_amdgcn_readfirstlane(wave) >= 4;
-    int c = 0;
-    for (int ci0 = k_lo; ci0 < k_hi; ci0 += WCC, ++c) {
-        const int cur = c & 1, nxt = cur ^ 1;
-        if (ci0 + WCC < k_hi) stage_u(ci0 + WCC, nxt);          // weights lead by one chunk
-        if (ci0 + 2 * WCC < k_hi) stage_x(ci0 + 2 * WCC, cur);   // input leads by two (its transform sits in between)
-        // Stagger the two waves that share a SIMD (waves w and w+4): one transforms first and multiplies second, its
-        // partner the other way round, so the matrix pipe is not left idle while both do their transform.
-        if (!late_transform && ci0 + WCC < k_hi) transform(ci0 + WCC, nxt, nxt);
-        const float* Ub = Ul + cur * WF + aoff;
-        const float* Vb = Vl + cur * VF + voff;
+    for (int k = 0;; ++k) {
 #pragma unroll
-        for (int cp = 0; cp < WCC / 2; ++cp) {
-            const float* ub = Ub + 2 * cp * 16 * WMBLK;
-            const float* vb = Vb + 2 * cp * WTILES;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[(4 * i) * WMBLK], vb[(4 * i) * WCC * WTILES], acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[(4 * i + 1) * WMBLK], vb[(4 * i + 1) * WCC * WTILES], acc[i][1], 0, 0, 0);
-            }
-        }
-        if (late_transform && ci0 + WCC < k_hi) transform(ci0 + WCC, nxt, nxt);
-        __syncthreads();  // V(c+1) written, DMA retired, everyone done with U(c) / V(c)
-    }
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[i][jj][j] = 0.f;
 
-    // ---- epilogue.  m[r][jj] = (A^T M)[r][column 2q+jj];  Y[r][0] = m0 + m1 + m2,  Y[r][1] = m1 - m2 - m3.
-    // q = 0 contributes (m0 + m1, m1), q = 1 contributes (m2, -m2 - m3).  The two waves of a pair swap halves:
-    // wave q finalises accumulator rows j in [8q, 8q+8) and hands its partial sums of the other 8 rows to its
-    // partner through the (by now idle) weight staging LDS, so both run the layer tail and the stores.
-    float mine[8][4];
-    float* xch = Ul + (wave >> 1) * (64 * 64);  // [sender q][8 rows][4][64 lanes] per wave pair
-    auto reduce_and_send = [&](auto qc) {
-        constexpr int Q = decltype(qc)::value;
+        int c = 0;
+        for (int ci0 = k_lo; ci0 < k_hi; ci0 += WCC, ++c) {
+            const int cur = c & 1, nxt = cur ^ 1;
+            if (ci0 + WCC < k_hi) stage_u(ci0 + WCC, nxt);          // weights lead by one chunk
+            if (ci0 + 2 * WCC < k_hi) stage_x(ci0 + 2 * WCC, cur);   // input leads by two (its transform sits in between)
+            // Stagger the two waves that share a SIMD (waves w and w+4): one transforms first and multiplies second,
+            // its partner the other way round, so the matrix pipe is not left idle while both do their transform.
+            if (!late_transform && ci0 + WCC < k_hi) transform(ci0 + WCC, nxt, nxt);
+            const float* Ub = Ul + cur * WF + aoff;
+            const float* Vb = Vl + cur * VF + voff;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            float m[2][2];
+            for (int cp = 0; cp < WCC / 2; ++cp) {
+                const float* ub = Ub + 2 * cp * 16 * WMBLK;
+                const float* vb = Vb + 2 * cp * WTILES;
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                m[0][jj] = acc[0][jj][j] + acc[1][jj][j] + acc[2][jj][j];
-                m[1][jj] = acc[1][jj][j] - acc[2][jj][j] - acc[3][jj][j];
-            }
-            float pr[4];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                pr[2 * r] = Q == 0 ? m[r][0] + m[r][1] : m[r][0];
-                pr[2 * r + 1] = Q == 0 ? m[r][1] : -m[r][0] - m[r][1];
-            }
-            if ((j >> 3) == Q) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) mine[j & 7][e] = pr[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xch[(Q * 32 + (j & 7) * 4 + e) * 64 + lane] = pr[e];
-            }
-        }
-    };
-    if (q == 0) reduce_and_send(std::integral_constant<int, 0>());
-    else reduce_and_send(std::integral_constant<int, 1>());
-    __syncthreads();
-    if (!live) return;
-
-    float* obase = (partial ? p.slab + (int64_t)blockIdx.y * p.B * p.Cout * HW : p.out) + (int64_t)ob * p.Cout * HW +
-                   oh * p.W + ow;
-    const float* xin = xch + (1 - q) * 32 * 64 + lane;
-    const int co0 = o0 + wm * 32 + 16 * q + 4 * half;  // row j = 8 q + jj sits at co0 + (jj & 3) + 8 * (jj >> 2)
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-        const int co = co0 + (jj & 3) + 8 * (jj >> 2);
-        if (co < p.Cout) {
-            float y[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = mine[jj][e] + xin[(jj * 4 + e) * 64];
-            if (!partial) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float val = y[e] * dd[jj];
-                    if (p.fuse) {
-                        val += nz[e];
-                        val += bb[jj];
-                        val = (val > 0.f ? val : val * 0.2f) * 1.4142135623730951f;
-                    }
-                    y[e] = val;
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[(4 * i) * WMBLK], vb[(4 * i) * WCC * WTILES], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[(4 * i + 1) * WMBLK], vb[(4 * i + 1) * WCC * WTILES], acc[i][1], 0, 0, 0);
                 }
             }
-            float* oc = obase + (int64_t)co * HW;
-            *reinterpret_cast<float2*>(oc) = make_float2(y[0], y[1]);
-            *reinterpret_cast<float2*>(oc + p.W) = make_float2(y[2], y[3]);
+            if (late_transform && ci0 + WCC < k_hi) transform(ci0 + WCC, nxt, nxt);
+            __syncthreads();  // V(c+1) written, DMA retired, everyone done with U(c) / V(c)
         }
+
+        // All staging buffers are idle now.  Start the next tile's first DMA before this tile's epilogue; the output
+        // coordinates of THIS tile were taken above, its tail operands sit in LDS.
+        const bool has_next = k + 1 < tiles_per_wg;
+        const int ob = b0 + tn, oh = h0 + 2 * ty, ow = w0 + 2 * tx;  // this tile's output pixel, before b0/h0/w0 move on
+        const bool live = tn < tc.nb && ob < p.B && oh < p.H && ow < p.W;
+        if (has_next) {
+            tile_setup(pt_first + k + 1);
+            tile_first_dma();
+        }
+
+        // ---- epilogue.  m[r][jj] = (A^T M)[r][column 2q+jj];  Y[r][0] = m0 + m1 + m2,  Y[r][1] = m1 - m2 - m3.
+        // q = 0 contributes (m0 + m1, m1), q = 1 contributes (m2, -m2 - m3).  The two waves of a pair swap halves:
+        // wave q finalises accumulator rows j in [8q, 8q+8) and hands its partial sums of the other 8 rows to its
+        // partner through the (by now idle) V image LDS, so both run the layer tail and the stores.
+        float mine[8][4];
+        float* xch = Vl + (wave >> 1) * (64 * 64);  // [sender q][8 rows][4][64 lanes] per wave pair
+        auto reduce_and_send = [&](auto qc) {
+            constexpr int Q = decltype(qc)::value;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float m[2][2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    m[0][jj] = acc[0][jj][j] + acc[1][jj][j] + acc[2][jj][j];
+                    m[1][jj] = acc[1][jj][j] - acc[2][jj][j] - acc[3][jj][j];
+                }
+                float pr[4];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    pr[2 * r] = Q == 0 ? m[r][0] + m[r][1] : m[r][0];
+                    pr[2 * r + 1] = Q == 0 ? m[r][1] : -m[r][0] - m[r][1];
+                }
+                if ((j >> 3) == Q) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mine[j & 7][e] = pr[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xch[(Q * 32 + (j & 7) * 4 + e) * 64 + lane] = pr[e];
+                }
+            }
+        };
+        if (q == 0) reduce_and_send(std::integral_constant<int, 0>());
+        else reduce_and_send(std::integral_constant<int, 1>());
+        __syncthreads();
+
+        if (live) {
+            float* obase = (partial ? p.slab + (int64_t)blockIdx.y * p.B * p.Cout * HW : p.out) +
+                           (int64_t)ob * p.Cout * HW + oh * p.W + ow;
+            const float* xin = xch + (1 - q) * 32 * 64 + lane;
+            const int cl0 = wm * 32 + 16 * q + 4 * half;  // row j = 8 q + jj sits at channel cl0 + (jj & 3) + 8 * (jj >> 2)
+            float nz[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) nz[e] = Nl[t * 4 + e];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int cl = cl0 + (jj & 3) + 8 * (jj >> 2), co = o0 + cl;
+                if (co < p.Cout) {
+                    const float dd = Dl[tn * WMBLK + cl], bbv = Bl[cl];
+                    float y[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = mine[jj][e] + xin[(jj * 4 + e) * 64];
+                    if (!partial) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float val = y[e] * dd;
+                            if (p.fuse) {
+                                val += nz[e];
+                                val += bbv;
+                                val = (val > 0.f ? val : val * 0.2f) * 1.4142135623730951f;
+                            }
+                            y[e] = val;
+                        }
+                    }
+                    float* oc = obase + (int64_t)co * HW;
+                    *reinterpret_cast<float2*>(oc) = make_float2(y[0], y[1]);
+                    *reinterpret_cast<float2*>(oc + p.W) = make_float2(y[2], y[3]);
+                }
+            }
+        }
+        if (!has_next) break;
+        tail_load();
+        __syncthreads();  // next tile: chunk 0 (and input chunk 1) landed; everyone is done with the exchange area
+        tail_store();
+        transform(k_lo, 0, 0);
+        __syncthreads();  // V(0) visible
     }
 }
 
@@ -597,7 +637,7 @@ int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t 
         }
     }
     const size_t lds = (size_t)(2 * WCC * 16 * WMBLK + 2 * WCC * tc.xt + (p.s ? p.nb_max * p.Cin : 0)) * sizeof(float);
-    const size_t lds2 = lds + (size_t)2 * 16 * WCC * WTILES * sizeof(float);
+    const size_t lds2 = lds + (size_t)(2 * 16 * WCC * WTILES + p.nb_max * WMBLK + WMBLK + WTILES * 4) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     if (plan_only) return 0;
     static bool attr_set = false;
@@ -613,7 +653,11 @@ int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t 
     static const bool pipelined = !(getenv("SIS_WINO_PIPE") && getenv("SIS_WINO_PIPE")[0] == '0');
     if (pipelined && lds2 <= 160 * 1024) {
         sis_kernel_name = "modconv_wino2_kernel";
-        hipLaunchKernelGGL(modconv_wino2_kernel, dim3((unsigned)blocks, p.ksplit), dim3(WNTHR), lds2, st, p, tc.xt);
+        // consecutive pixel tiles per workgroup: as many as keep >= 1024 workgroups (4 per CU) in flight
+        static const int tpw_cap = getenv("SIS_WINO_TPW") ? atoi(getenv("SIS_WINO_TPW")) : 16;
+        int tpw = 1;
+        while (tpw * 2 <= tpw_cap && p.npos_tiles % (tpw * 2) == 0 && blocks / (tpw * 2) >= 1024) tpw *= 2;
+        hipLaunchKernelGGL(modconv_wino2_kernel, dim3((unsigned)(blocks / tpw), p.ksplit), dim3(WNTHR), lds2, st, p, tc.xt, tpw);
     } else {
         sis_kernel_name = "modconv_wino_kernel";
         hipLaunchKernelGGL(modconv_wino_kernel, dim3((unsigned)blocks, p.ksplit), dim3(WNTHR), lds, st, p, tc.xt);
