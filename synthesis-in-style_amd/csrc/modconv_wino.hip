@@ -656,7 +656,8 @@ int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t 
         // consecutive pixel tiles per workgroup: as many as keep >= 1024 workgroups (4 per CU) in flight
         static const int tpw_cap = getenv("SIS_WINO_TPW") ? atoi(getenv("SIS_WINO_TPW")) : 16;
         int tpw = 1;
-        while (tpw * 2 <= tpw_cap && p.npos_tiles % (tpw * 2) == 0 && blocks / (tpw * 2) >= 1024) tpw *= 2;
+        static const int min_wg = getenv("SIS_WINO_MINWG") ? atoi(getenv("SIS_WINO_MINWG")) : 1024;
+        while (tpw * 2 <= tpw_cap && p.npos_tiles % (tpw * 2) == 0 && blocks / (tpw * 2) >= min_wg) tpw *= 2;
         hipLaunchKernelGGL(modconv_wino2_kernel, dim3((unsigned)(blocks / tpw), p.ksplit), dim3(WNTHR), lds2, st, p, tc.xt, tpw);
     } else {
         sis_kernel_name = "modconv_wino_kernel";
