@@ -366,7 +366,7 @@ def modconv_demod(s, wsq, scale, demodulate):
     return out
 
 
-WORKSPACE_BYTES = 128 << 20
+WORKSPACE_BYTES = int(os.environ.get("SIS_WORKSPACE_MB", "128")) << 20  # split-K slabs (per device)
 _workspaces = {}
 
 
