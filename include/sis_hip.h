@@ -243,6 +243,14 @@ int sis_conv3x3(float* out, const float* x, const float* u, int batch, int cin, 
                 void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * nn.UpsamplingBilinear2d (align_corners=True) of the TransUNet decoder
+ * (networks/trans_u_net/vit_seg_modeling.py:290-329), forward and backward, f32 / f16 / bf16 (dtype = SIS_*).
+ * backward = 0: out [planes][out_h][out_w] from x [planes][h][w].
+ * backward = 1: out = grad_x [planes][h][w] from x = grad_out [planes][out_h][out_w] (gather, deterministic). */
+int sis_upsample_bilinear(void* out, const void* x, int dtype, int64_t planes, int h, int w, int out_h, int out_w,
+                          int backward, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Patch-wise page inference.  The patch grid is the product of `nx` left edges `xs` and
  * `ny` top edges `ys` (device int32 arrays, ascending), patch n = yi * nx + xi, as
  * segmentation/analysis_segmenter.py:83-113 enumerates them.

@@ -1,0 +1,128 @@
+// Bilinear upsampling with align_corners=True (nn.UpsamplingBilinear2d), forward and backward -- the TransUNet decoder
+// (networks/trans_u_net/vit_seg_modeling.py:290-329: every DecoderBlock and the SegmentationHead upsample by 2).
+// ATen's kernel runs these four tensors at ~1/8 of the HBM roofline and its backward scatters with float atomics;
+// here the forward is one pass (each lane 4 consecutive outputs of a row: 16-byte stores, the two source rows come
+// from L2) and the backward is a gather (one lane per input pixel sums the <= 4 x 4 outputs whose footprint touches
+// it): deterministic, no atomics.  Index rule = PyTorch's: src = dst * (in - 1) / (out - 1), i0 = (int) src,
+// i1 = i0 + (i0 < in - 1), lambda1 = src - i0.  Arithmetic in fp32 for f32 / bf16 / f16 tensors.
+#include "sis_common.h"
+
+namespace {
+
+struct Lerp1 { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp1 lerp1(int dst, float scale, int in_size) {
+    const float src = scale * (float)dst;
+    Lerp1 r;
+    r.i0 = (int)src;
+    if (r.i0 > in_size - 1) r.i0 = in_size - 1;
+    r.i1 = r.i0 + (r.i0 < in_size - 1 ? 1 : 0);
+    r.l1 = src - (float)r.i0;
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_up_fwd_kernel(T* __restrict__ out, const T* __restrict__ x, int h, int w,
+                                                              int oh, int ow, float sy, float sx, int64_t total4) {
+    const int ow4 = (ow + 3) >> 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+        const int c4 = (int)(i % ow4);
+        const int64_t row = i / ow4;
+        const int oy = (int)(row % oh);
+        const int64_t plane = row / oh;
+        const Lerp1 ly = lerp1(oy, sy, h);
+        const T* r0 = x + (plane * h + ly.i0) * w;
+        const T* r1 = x + (plane * h + ly.i1) * w;
+        T* o = out + (plane * oh + oy) * (int64_t)ow + 4 * c4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ox = 4 * c4 + e;
+            const Lerp1 lx = lerp1(ox < ow ? ox : ow - 1, sx, w);
+            v[e] = ly.l0 * (lx.l0 * sis_ld(r0, lx.i0) + lx.l1 * sis_ld(r0, lx.i1)) +
+                   ly.l1 * (lx.l0 * sis_ld(r1, lx.i0) + lx.l1 * sis_ld(r1, lx.i1));
+        }
+        if (sizeof(T) == 4 && (ow & 3) == 0) {  // 16-byte store (rows are 16-byte aligned when ow % 4 == 0)
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * c4 + e < ow) sis_st(o, e, v[e]);
+        }
+    }
+}
+
+// grad_x[y][x] = sum over outputs (oy, ox) of wy(oy -> y) * wx(ox -> x) * grad_out[oy][ox]
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(T* __restrict__ gx, const T* __restrict__ gout, int h, int w,
+                                                              int oh, int ow, float sy, float sx, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int xx = (int)(i % w);
+    const int64_t row = i / w;
+    const int y = (int)(row % h);
+    const int64_t plane = row / h;
+    // outputs o with floor(s * o) in {y - 1, y}
+    const float inv_sy = sy > 0.f ? 1.f / sy : 0.f, inv_sx = sx > 0.f ? 1.f / sx : 0.f;
+    int oy_lo = sy > 0.f ? (int)floorf((float)(y - 1) * inv_sy) - 1 : 0;
+    int oy_hi = sy > 0.f ? (int)ceilf((float)(y + 1) * inv_sy) + 1 : oh - 1;
+    int ox_lo = sx > 0.f ? (int)floorf((float)(xx - 1) * inv_sx) - 1 : 0;
+    int ox_hi = sx > 0.f ? (int)ceilf((float)(xx + 1) * inv_sx) + 1 : ow - 1;
+    oy_lo = max(oy_lo, 0); ox_lo = max(ox_lo, 0); oy_hi = min(oy_hi, oh - 1); ox_hi = min(ox_hi, ow - 1);
+    const T* g = gout + plane * oh * (int64_t)ow;
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        const Lerp1 ly = lerp1(oy, sy, h);
+        float wy = 0.f;
+        if (ly.i0 == y) wy += ly.l0;
+        if (ly.i1 == y) wy += ly.l1;
+        if (wy == 0.f) continue;
+        float racc = 0.f;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            const Lerp1 lx = lerp1(ox, sx, w);
+            float wx = 0.f;
+            if (lx.i0 == xx) wx += lx.l0;
+            if (lx.i1 == xx) wx += lx.l1;
+            if (wx != 0.f) racc += wx * sis_ld(g, (int64_t)oy * ow + ox);
+        }
+        acc += wy * racc;
+    }
+    sis_st(gx, i, acc);
+}
+
+template <typename T>
+int launch_up(void* out, const void* x, int64_t planes, int h, int w, int oh, int ow, int backward, hipStream_t st) {
+    const float sy = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.f;
+    const float sx = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.f;
+    if (!backward) {
+        const int64_t total4 = planes * oh * ((ow + 3) >> 2);
+        const int64_t blocks = (total4 + 255) / 256;
+        hipLaunchKernelGGL(bilinear_up_fwd_kernel<T>, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st,
+                           (T*)out, (const T*)x, h, w, oh, ow, sy, sx, total4);
+        SIS_CHECK_LAUNCH("bilinear_up_fwd_kernel");
+    } else {  // out = grad_x [planes][h][w], x = grad_out [planes][oh][ow]
+        const int64_t total = planes * h * w;
+        hipLaunchKernelGGL(bilinear_up_bwd_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (T*)out,
+                           (const T*)x, h, w, oh, ow, sy, sx, total);
+        SIS_CHECK_LAUNCH("bilinear_up_bwd_kernel");
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int sis_upsample_bilinear(void* out, const void* x, int dtype, int64_t planes, int h, int w, int out_h,
+                                     int out_w, int backward, void* stream) {
+    if (planes == 0) return 0;
+    SIS_REQUIRE(out && x, "sis_upsample_bilinear: null pointer");
+    SIS_REQUIRE(planes > 0 && h > 0 && w > 0 && out_h > 0 && out_w > 0, "sis_upsample_bilinear: non-positive size");
+    SIS_REQUIRE(planes * (int64_t)out_h * out_w < ((int64_t)1 << 40), "sis_upsample_bilinear: tensor too large");
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case SIS_F32: return launch_up<float>(out, x, planes, h, w, out_h, out_w, backward, st);
+        case SIS_F16: return launch_up<__half>(out, x, planes, h, w, out_h, out_w, backward, st);
+        case SIS_BF16: return launch_up<__hip_bfloat16>(out, x, planes, h, w, out_h, out_w, backward, st);
+        default: return sis_fail("sis_upsample_bilinear: dtype code %d not supported (f32, f16, bf16)", dtype);
+    }
+}

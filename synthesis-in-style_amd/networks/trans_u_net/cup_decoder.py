@@ -5,6 +5,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from networks.hip_upsample import HipUpsamplingBilinear2d
+
 
 class Conv2dReLU(nn.Sequential):
     def __init__(self, in_channels, out_channels, kernel_size, padding=0, stride=1, use_batchnorm=True):
@@ -19,7 +21,7 @@ class DecoderBlock(nn.Module):
         self.conv1 = Conv2dReLU(in_channels + skip_channels, out_channels, kernel_size=3, padding=1,
                                 use_batchnorm=use_batchnorm)
         self.conv2 = Conv2dReLU(out_channels, out_channels, kernel_size=3, padding=1, use_batchnorm=use_batchnorm)
-        self.up = nn.UpsamplingBilinear2d(scale_factor=2)
+        self.up = HipUpsamplingBilinear2d(scale_factor=2)
 
     def forward(self, x, skip=None):
         x = self.up(x)
@@ -31,7 +33,7 @@ class DecoderBlock(nn.Module):
 class SegmentationHead(nn.Sequential):
     def __init__(self, in_channels, out_channels, kernel_size=3, upsampling=1):
         super().__init__(nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, padding=kernel_size // 2),
-                         nn.UpsamplingBilinear2d(scale_factor=upsampling) if upsampling > 1 else nn.Identity())
+                         HipUpsamplingBilinear2d(scale_factor=upsampling) if upsampling > 1 else nn.Identity())
 
 
 class DecoderCup(nn.Module):

@@ -43,6 +43,7 @@ _SIGNATURES = {
     "sis_last_kernel": ([], ctypes.c_char_p),
     "sis_conv3x3_prepack": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "sis_conv3x3_eligible": ([_i] * 5, _i),
+    "sis_upsample_bilinear": ([_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp], _i),
     "sis_conv3x3_wgrad_eligible": ([_i] * 5 + [_i64], _i),
     "sis_conv3x3_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
     "sis_conv3x3": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
@@ -556,6 +557,26 @@ def make_image_u8(x):
     out = torch.empty((b, h, w, ch), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
         _check(lib().sis_make_image_u8(_ptr(out), _ptr(x), b, ch, h * w, _stream()), "sis_make_image_u8")
+    return out
+
+
+# ------------------------------------------------------------------------------ bilinear upsampling (align_corners)
+
+
+def upsample_bilinear(x, out_h, out_w, grad_output=None):
+    """Forward: x [B,C,H,W] -> [B,C,out_h,out_w].  With ``grad_output`` [B,C,out_h,out_w]: the gradient w.r.t. an input
+    of x's shape (x is only used for its shape / dtype)."""
+    require_device(x, "input")
+    if x.dtype not in _DTYPE_CODE or x.dtype == torch.float64:
+        raise RuntimeError(f"upsample_bilinear: dtype {x.dtype} not supported")
+    b, c, h, w = x.shape
+    if grad_output is None:
+        src, out, backward = x.contiguous(), torch.empty((b, c, out_h, out_w), dtype=x.dtype, device=x.device), 0
+    else:
+        src, out, backward = grad_output.contiguous(), torch.empty((b, c, h, w), dtype=x.dtype, device=x.device), 1
+    with torch.cuda.device(x.device):
+        _check(lib().sis_upsample_bilinear(_ptr(out), _ptr(src), _DTYPE_CODE[x.dtype], b * c, h, w, out_h, out_w, backward,
+                                           _stream()), "sis_upsample_bilinear")
     return out
 
 

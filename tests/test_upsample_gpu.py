@@ -1,0 +1,44 @@
+"""GPU parity: bilinear upsampling with align_corners (csrc/upsample_ops.hip) against torch's fp32 reference, forward
+and backward, f32 / bf16 / f16.  The interpolation weights are formed in fp32 exactly as ATen forms them (src = dst * scale):
+against a float64 reference both this kernel and ATen's fp32 kernel sit at ~1e-5 on unit-variance data (measured
+1.04e-5 vs 1.08e-5 at 64 -> 128), hence atol 4e-5; 16-bit types: one rounding of the fp32 result."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape,size", [((2, 3, 8, 8), (16, 16)), ((1, 5, 7, 9), (14, 18)), ((2, 4, 16, 12), (32, 27)),
+                                        ((1, 2, 1, 5), (2, 10)), ((1, 16, 64, 64), (128, 128)), ((2, 2, 6, 6), (6, 6))])
+def test_forward_backward_f32(device, shape, size):
+    import sis_hip
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g).to(device)
+    gy = torch.randn(shape[0], shape[1], *size, generator=g).to(device)
+    y = sis_hip.upsample_bilinear(x, *size)
+    xr = x.double().requires_grad_(True)
+    ref = F.interpolate(xr, size=size, mode="bilinear", align_corners=True)
+    ref.backward(gy.double())
+    np.testing.assert_allclose(y.cpu().numpy(), ref.detach().float().cpu().numpy(), rtol=1e-5, atol=4e-5)
+    gx = sis_hip.upsample_bilinear(x, *size, grad_output=gy)
+    np.testing.assert_allclose(gx.cpu().numpy(), xr.grad.float().cpu().numpy(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float16, 2e-3)])
+def test_module_16bit_and_autograd(device, dtype, tol):
+    from networks.hip_upsample import HipUpsamplingBilinear2d
+    up = HipUpsamplingBilinear2d(scale_factor=2)
+    x = torch.randn(2, 8, 16, 16, device=device).to(dtype).requires_grad_(True)
+    y = up(x)
+    assert y.dtype == dtype and tuple(y.shape) == (2, 8, 32, 32)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_(True)
+    ref = F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=True)
+    ref.backward(gy.float())
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), ref.detach().cpu().numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(x.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=tol, atol=4 * tol)
+    assert up(torch.zeros(1, 1, 4, 4)).shape == (1, 1, 8, 8)  # CPU tensors take the torch path
+    assert list(up.state_dict().keys()) == []
