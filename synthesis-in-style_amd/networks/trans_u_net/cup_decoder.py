@@ -5,12 +5,13 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from networks.hip_conv import HipConv2d
 from networks.hip_upsample import HipUpsamplingBilinear2d
 
 
 class Conv2dReLU(nn.Sequential):
     def __init__(self, in_channels, out_channels, kernel_size, padding=0, stride=1, use_batchnorm=True):
-        super().__init__(nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+        super().__init__(HipConv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
                                    bias=not use_batchnorm),
                          nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
 
