@@ -243,6 +243,17 @@ int sis_conv3x3(float* out, const float* x, const float* u, int batch, int cin, 
                 void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Weight standardisation of StdConv2d (networks/trans_u_net/vit_seg_modeling_resnet_skip.py:20-27), one launch per
+ * direction.  w [rows][n] float32 (rows = Cout, n = Cin*kh*kw).
+ * fwd: w_hat (dtype out_dtype = SIS_F32 / SIS_F16 / SIS_BF16) = (w - mean_row) / sqrt(var_row + eps), biased variance;
+ *      invstd [rows] = 1 / sqrt(var_row + eps).
+ * bwd: dw [rows][n] float32 = invstd * (g - mean(g) - w_hat * mean(g * w_hat)), g = dL/dw_hat in grad_dtype. */
+int sis_weight_std_fwd(void* w_hat, float* invstd, const float* w, int out_dtype, int rows, int n, float eps,
+                       void* stream);
+int sis_weight_std_bwd(float* dw, const void* grad_w_hat, const float* w, const float* invstd, int grad_dtype,
+                       int rows, int n, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * nn.UpsamplingBilinear2d (align_corners=True) of the TransUNet decoder
  * (networks/trans_u_net/vit_seg_modeling.py:290-329), forward and backward, f32 / f16 / bf16 (dtype = SIS_*).
  * backward = 0: out [planes][out_h][out_w] from x [planes][h][w].

@@ -17,6 +17,9 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from torch.autograd import Function
+
+import sis_hip
 
 
 def np2th(weights, conv=False):
@@ -24,13 +27,37 @@ def np2th(weights, conv=False):
     return torch.from_numpy(weights.transpose([3, 2, 0, 1]) if conv else weights)
 
 
+class _WeightStandardize(Function):
+    """w_hat = (w - mean) / sqrt(var + eps) per output channel on one HIP launch (csrc/weight_std.hip), written in the
+    autocast dtype when autocast is on so that the convolution needs no separate cast of its weight."""
+
+    @staticmethod
+    def forward(ctx, weight, eps, out_dtype):
+        w_hat, invstd = sis_hip.weight_std_fwd(weight, eps, out_dtype)
+        ctx.save_for_backward(weight, invstd)
+        ctx.eps = eps
+        return w_hat
+
+    @staticmethod
+    def backward(ctx, grad):
+        weight, invstd = ctx.saved_tensors
+        return sis_hip.weight_std_bwd(grad, weight, invstd, ctx.eps), None, None
+
+
 class StdConv2d(nn.Conv2d):
     EPS = 1e-5
 
+    def standardized_weight(self):
+        w = self.weight
+        if w.is_cuda and w.dtype == torch.float32:
+            out_dtype = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else torch.float32
+            if out_dtype in (torch.float32, torch.float16, torch.bfloat16):
+                return _WeightStandardize.apply(w, self.EPS, out_dtype)
+        var, mean = torch.var_mean(w, dim=[1, 2, 3], keepdim=True, unbiased=False)
+        return (w - mean) / torch.sqrt(var + self.EPS)
+
     def forward(self, x):
-        var, mean = torch.var_mean(self.weight, dim=[1, 2, 3], keepdim=True, unbiased=False)
-        return F.conv2d(x, (self.weight - mean) / torch.sqrt(var + self.EPS), self.bias, self.stride, self.padding,
-                        self.dilation, self.groups)
+        return F.conv2d(x, self.standardized_weight(), self.bias, self.stride, self.padding, self.dilation, self.groups)
 
 
 def conv3x3(cin, cout, stride=1, groups=1, bias=False):

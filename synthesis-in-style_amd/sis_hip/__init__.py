@@ -44,6 +44,8 @@ _SIGNATURES = {
     "sis_conv3x3_prepack": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "sis_conv3x3_eligible": ([_i] * 5, _i),
     "sis_upsample_bilinear": ([_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp], _i),
+    "sis_weight_std_fwd": ([_vp, _vp, _vp, _i, _i, _i, _f, _vp], _i),
+    "sis_weight_std_bwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp], _i),
     "sis_conv3x3_wgrad_eligible": ([_i] * 5 + [_i64], _i),
     "sis_conv3x3_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
     "sis_conv3x3": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
@@ -558,6 +560,32 @@ def make_image_u8(x):
     with torch.cuda.device(x.device):
         _check(lib().sis_make_image_u8(_ptr(out), _ptr(x), b, ch, h * w, _stream()), "sis_make_image_u8")
     return out
+
+
+# ------------------------------------------------------------------------------ weight standardisation
+
+
+def weight_std_fwd(weight, eps, out_dtype=torch.float32):
+    """weight [Cout, ...] float32 -> (w_hat in ``out_dtype``, invstd [Cout]) standardised per output channel."""
+    w = _f32(weight, "weight")
+    rows, n = w.shape[0], w[0].numel()
+    w_hat = torch.empty(w.shape, dtype=out_dtype, device=w.device)
+    invstd = torch.empty(rows, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _check(lib().sis_weight_std_fwd(_ptr(w_hat), _ptr(invstd), _ptr(w), _DTYPE_CODE[out_dtype], rows, n, float(eps),
+                                        _stream()), "sis_weight_std_fwd")
+    return w_hat, invstd
+
+
+def weight_std_bwd(grad_w_hat, weight, invstd, eps):
+    w = _f32(weight, "weight")
+    g = grad_w_hat.contiguous()
+    rows, n = w.shape[0], w[0].numel()
+    dw = torch.empty_like(w)
+    with torch.cuda.device(w.device):
+        _check(lib().sis_weight_std_bwd(_ptr(dw), _ptr(g), _ptr(w), _ptr(invstd), _DTYPE_CODE[g.dtype], rows, n, float(eps),
+                                        _stream()), "sis_weight_std_bwd")
+    return dw
 
 
 # ------------------------------------------------------------------------------ bilinear upsampling (align_corners)

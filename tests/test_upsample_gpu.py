@@ -42,3 +42,24 @@ def test_module_16bit_and_autograd(device, dtype, tol):
     np.testing.assert_allclose(x.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=tol, atol=4 * tol)
     assert up(torch.zeros(1, 1, 4, 4)).shape == (1, 1, 8, 8)  # CPU tensors take the torch path
     assert list(up.state_dict().keys()) == []
+
+
+@pytest.mark.parametrize("shape", [(64, 3, 7, 7), (256, 64, 1, 1), (128, 128, 3, 3), (1024, 1024, 1, 1), (5, 3, 3, 3)])
+def test_weight_standardisation(device, shape):
+    """csrc/weight_std.hip against the reference formula (vit_seg_modeling_resnet_skip.py:22-27), both directions."""
+    import sis_hip
+    g = torch.Generator().manual_seed(shape[0])
+    w = (torch.randn(*shape, generator=g) * 0.3 + 0.1).to(device)
+    gy = torch.randn(*shape, generator=g).to(device)
+    w_hat, invstd = sis_hip.weight_std_fwd(w, 1e-5)
+    wr = w.double().requires_grad_(True)
+    var, mean = torch.var_mean(wr, dim=[1, 2, 3], keepdim=True, unbiased=False)
+    ref = (wr - mean) / torch.sqrt(var + 1e-5)
+    ref.backward(gy.double())
+    np.testing.assert_allclose(w_hat.cpu().numpy(), ref.detach().float().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    dw = sis_hip.weight_std_bwd(gy, w, invstd, 1e-5)
+    np.testing.assert_allclose(dw.cpu().numpy(), wr.grad.float().cpu().numpy(), rtol=1e-4, atol=1e-4 * float(wr.grad.abs().max()))
+    w16, _ = sis_hip.weight_std_fwd(w, 1e-5, torch.bfloat16)
+    np.testing.assert_allclose(w16.float().cpu().numpy(), ref.detach().float().cpu().numpy(), rtol=1e-2, atol=1e-2)
+    dw16 = sis_hip.weight_std_bwd(gy.bfloat16(), w, invstd, 1e-5)
+    np.testing.assert_allclose(dw16.cpu().numpy(), wr.grad.float().cpu().numpy(), rtol=5e-2, atol=2e-2 * float(wr.grad.abs().max()))
