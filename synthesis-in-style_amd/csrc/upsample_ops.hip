@@ -65,10 +65,12 @@ __global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(T* __restrict__ gx
     const int64_t plane = row / h;
     // outputs o with floor(s * o) in {y - 1, y}
     const float inv_sy = sy > 0.f ? 1.f / sy : 0.f, inv_sx = sx > 0.f ? 1.f / sx : 0.f;
-    int oy_lo = sy > 0.f ? (int)floorf((float)(y - 1) * inv_sy) - 1 : 0;
-    int oy_hi = sy > 0.f ? (int)ceilf((float)(y + 1) * inv_sy) + 1 : oh - 1;
-    int ox_lo = sx > 0.f ? (int)floorf((float)(xx - 1) * inv_sx) - 1 : 0;
-    int ox_hi = sx > 0.f ? (int)ceilf((float)(xx + 1) * inv_sx) + 1 : ow - 1;
+    // (floor / ceil of the real bounds already bracket every contributor; a rounding error of the quotient can only
+    // move them outwards by one, never inwards past a contributor, and non-contributors get weight 0 below)
+    int oy_lo = sy > 0.f ? (int)floorf((float)(y - 1) * inv_sy) : 0;
+    int oy_hi = sy > 0.f ? (int)ceilf((float)(y + 1) * inv_sy) : oh - 1;
+    int ox_lo = sx > 0.f ? (int)floorf((float)(xx - 1) * inv_sx) : 0;
+    int ox_hi = sx > 0.f ? (int)ceilf((float)(xx + 1) * inv_sx) : ow - 1;
     oy_lo = max(oy_lo, 0); ox_lo = max(ox_lo, 0); oy_hi = min(oy_hi, oh - 1); ox_hi = min(ox_hi, ow - 1);
     const T* g = gout + plane * oh * (int64_t)ow;
     float acc = 0.f;
