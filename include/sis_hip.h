@@ -254,6 +254,20 @@ int sis_weight_std_bwd(float* dw, const void* grad_w_hat, const float* w, const 
                        int rows, int n, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * nn.GroupNorm (+ optional ReLU) of TransUNet's ResNetV2 trunk (vit_seg_modeling_resnet_skip.py:40-75,114-126),
+ * x [B][C][hw] in x_dtype (SIS_F32 / SIS_F16 / SIS_BF16), fp32 arithmetic, affine gamma / beta [C] float32.
+ * fwd: y (y_dtype = x_dtype or SIS_F32) = relu?((x - mean_g) * rstd_g * gamma_c + beta_c); mean / rstd [B*groups] kept.
+ * bwd: dx (x_dtype), dgamma / dbeta [C]; grad_y in g_dtype (= x_dtype or SIS_F32); the ReLU mask is recomputed from x;
+ *      workspace (both directions): sis_group_norm_workspace_floats(B, C) floats. */
+int sis_group_norm_workspace_floats(int batch, int channels);
+int sis_group_norm_fwd(void* y, float* mean, float* rstd, float* workspace, const void* x, const float* gamma,
+                       const float* beta, int x_dtype, int y_dtype, int batch, int channels, int hw, int groups, float eps,
+                       int relu, void* stream);
+int sis_group_norm_bwd(void* dx, float* dgamma, float* dbeta, float* workspace, const void* grad_y, const void* x,
+                       const float* mean, const float* rstd, const float* gamma, const float* beta, int x_dtype,
+                       int g_dtype, int batch, int channels, int hw, int groups, int relu, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * nn.UpsamplingBilinear2d (align_corners=True) of the TransUNet decoder
  * (networks/trans_u_net/vit_seg_modeling.py:290-329), forward and backward, f32 / f16 / bf16 (dtype = SIS_*).
  * backward = 0: out [planes][out_h][out_w] from x [planes][h][w].

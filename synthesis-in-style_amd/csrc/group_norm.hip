@@ -1,0 +1,250 @@
+// GroupNorm (+ optional ReLU) of TransUNet's ResNetV2 trunk (networks/trans_u_net/vit_seg_modeling_resnet_skip.py:
+// 40-75,114-126: a GroupNorm after every StdConv2d, ReLU after most), forward and backward, with 16-bit or fp32
+// tensors in and out and fp32 arithmetic.  Under bf16 autocast ATen runs each of the 52 norms as: cast to fp32, row
+// moments, normalise, (ReLU), cast back -- and twice that in backward; here one launch per direction reads the
+// convolution's bf16 output and writes what the next convolution consumes.
+//
+// Three launches per direction, each fully parallel: (1) one workgroup per (sample, channel) plane reduces it -- mean /
+// M2 forward, sum(g') / sum(g' * xhat) backward (g' = g masked by the recomputed ReLU: nothing but x is saved);
+// (2) a tiny per-group kernel merges the planes of a group (Chan's formula, fixed order: deterministic) into per-plane
+// scale / shift coefficients; (3) a grid-strided element-wise kernel applies them (4 elements per lane when HW % 4 == 0).
+// d(gamma) / d(beta) = plane sums added over the batch in fixed order.
+#include "sis_common.h"
+
+namespace {
+
+__device__ __forceinline__ float gn_block_sum(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---- statistics: one workgroup per (sample, channel) plane -> (mean, M2) of the plane; gn_row_finish merges the
+// planes of a group with Chan's formula in channel order (no E[x^2] - E[x]^2 cancellation, deterministic).
+template <typename TI>
+__global__ __launch_bounds__(256) void gn_plane_stats_kernel(float* __restrict__ part, const TI* __restrict__ x, int hw) {
+    __shared__ float red[4];
+    const TI* pl = x + (int64_t)blockIdx.x * hw;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < hw; i += 256) s += sis_ld(pl, i);
+    const float mean = gn_block_sum(s, red) / (float)hw;
+    float m2 = 0.f;
+    for (int i = threadIdx.x; i < hw; i += 256) { const float d = sis_ld(pl, i) - mean; m2 += d * d; }
+    m2 = gn_block_sum(m2, red);
+    if (threadIdx.x == 0) { part[2 * (int64_t)blockIdx.x] = mean; part[2 * (int64_t)blockIdx.x + 1] = m2; }
+}
+
+// per (sample, channel): a = rstd_row * gamma_c, b = beta_c - mean_row * a  (the apply kernel's scale / shift)
+__global__ __launch_bounds__(64) void gn_row_finish_kernel(float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                           float* __restrict__ ab, const float* __restrict__ part,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           int rows, int groups, int cpg, int hw, float eps) {
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= rows) return;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int c = 0; c < cpg; ++c) {
+        const float* p = part + 2 * ((int64_t)row * cpg + c);
+        const float nb = (float)hw, nt = n + nb, delta = p[0] - mean;
+        mean += delta * (nb / nt);
+        m2 += p[1] + delta * delta * (n * nb / nt);
+        n = nt;
+    }
+    const float rstd = rsqrtf(m2 / n + eps);
+    mean_out[row] = mean; rstd_out[row] = rstd;
+    const int c0 = (row % groups) * cpg;
+    for (int c = 0; c < cpg; ++c) {
+        const float a = rstd * gamma[c0 + c];
+        ab[2 * ((int64_t)row * cpg + c)] = a;
+        ab[2 * ((int64_t)row * cpg + c) + 1] = beta[c0 + c] - mean * a;
+    }
+}
+
+// y = relu?(x * a[plane] + b[plane]); VEC elements per lane (VEC = 4 when hw % 4 == 0: planes stay vector-aligned)
+template <typename TI, typename TO, int VEC>
+__global__ __launch_bounds__(256) void gn_apply_kernel(TO* __restrict__ y, const TI* __restrict__ x,
+                                                       const float* __restrict__ ab, int hw, int64_t total, int relu) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < total; i += stride) {
+        const int64_t plane = i / hw;
+        const float a = ab[2 * plane], b = ab[2 * plane + 1];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float v = sis_ld(x, i + e) * a + b;
+            if (relu) v = fmaxf(v, 0.f);
+            sis_st(y, i + e, v);
+        }
+    }
+}
+
+// ---- backward.  g' = g * [y > 0] (mask recomputed: y = x*a + b).  Per plane: sum(g'), sum(g' * xhat).
+template <typename TI, typename TG>
+__global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ part, const TG* __restrict__ g,
+                                                           const TI* __restrict__ x, const float* __restrict__ mean_in,
+                                                           const float* __restrict__ rstd_in, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int C, int cpg, int hw, int relu) {
+    __shared__ float red[4];
+    const int64_t plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const int64_t row = plane / cpg;  // (sample * C + c) / cpg = sample * groups + group
+    const float mean = mean_in[row], rstd = rstd_in[row], gm = gamma[c], bt = beta[c];
+    const TI* px = x + plane * hw;
+    const TG* pg = g + plane * hw;
+    float sg = 0.f, sgx = 0.f;
+    for (int i = threadIdx.x; i < hw; i += 256) {
+        const float xh = (sis_ld(px, i) - mean) * rstd;
+        float gi = sis_ld(pg, i);
+        if (relu && xh * gm + bt <= 0.f) gi = 0.f;
+        sg += gi; sgx += gi * xh;
+    }
+    sg = gn_block_sum(sg, red);
+    sgx = gn_block_sum(sgx, red);
+    if (threadIdx.x == 0) { part[2 * plane] = sg; part[2 * plane + 1] = sgx; }
+}
+
+// per row: m1 = mean(g'*gamma), m2 = mean(g'*gamma*xhat) -> per plane coefficients (k1, k2, k3) with
+// dx = k1 * g' - k2 - k3 * xhat;  k1 = rstd*gamma_c, k2 = rstd*m1, k3 = rstd*m2
+__global__ __launch_bounds__(64) void gn_bwd_row_kernel(float* __restrict__ coef, const float* __restrict__ part,
+                                                        const float* __restrict__ rstd_in, const float* __restrict__ gamma,
+                                                        int rows, int groups, int cpg, int hw) {
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= rows) return;
+    const int c0 = (row % groups) * cpg;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < cpg; ++c) {
+        const float* p = part + 2 * ((int64_t)row * cpg + c);
+        s1 += gamma[c0 + c] * p[0]; s2 += gamma[c0 + c] * p[1];
+    }
+    const float n = (float)cpg * (float)hw, rstd = rstd_in[row];
+    for (int c = 0; c < cpg; ++c) {
+        float* k = coef + 3 * ((int64_t)row * cpg + c);
+        k[0] = rstd * gamma[c0 + c]; k[1] = rstd * s1 / n; k[2] = rstd * s2 / n;
+    }
+}
+
+template <typename TI, typename TG, int VEC>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(TI* __restrict__ dx, const TG* __restrict__ g,
+                                                           const TI* __restrict__ x, const float* __restrict__ coef,
+                                                           const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           int C, int cpg, int hw, int64_t total, int relu) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < total; i += stride) {
+        const int64_t plane = i / hw, row = plane / cpg;
+        const int c = (int)(plane % C);
+        const float mean = mean_in[row], rstd = rstd_in[row], gm = gamma[c], bt = beta[c];
+        const float k1 = coef[3 * plane], k2 = coef[3 * plane + 1], k3 = coef[3 * plane + 2];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float xh = (sis_ld(x, i + e) - mean) * rstd;
+            float gi = sis_ld(g, i + e);
+            if (relu && xh * gm + bt <= 0.f) gi = 0.f;
+            sis_st(dx, i + e, k1 * gi - k2 - k3 * xh);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_param_reduce_kernel(float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              const float* __restrict__ part, int batch, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int n = 0; n < batch; ++n) { b += part[2 * ((int64_t)n * C + c)]; a += part[2 * ((int64_t)n * C + c) + 1]; }
+    dgamma[c] = a; dbeta[c] = b;
+}
+
+inline unsigned gn_grid(int64_t total, int vec) {
+    const int64_t blocks = (total / vec + 255) / 256;
+    return (unsigned)(blocks < 16384 ? (blocks > 0 ? blocks : 1) : 16384);
+}
+
+template <typename TI, typename TO>
+void gn_fwd_run(void* y, float* mean, float* rstd, float* ws, const void* x, const float* gamma, const float* beta, int batch,
+                int C, int hw, int groups, float eps, int relu, hipStream_t st) {
+    const int cpg = C / groups, rows = batch * groups;
+    const int64_t planes = (int64_t)batch * C, total = planes * hw;
+    float* part = ws;              // [planes][2]
+    float* ab = ws + 2 * planes;   // [planes][2]
+    hipLaunchKernelGGL(gn_plane_stats_kernel<TI>, dim3((unsigned)planes), dim3(256), 0, st, part, (const TI*)x, hw);
+    hipLaunchKernelGGL(gn_row_finish_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, mean, rstd, ab, part, gamma, beta, rows,
+                       groups, cpg, hw, eps);
+    if (hw % 4 == 0)
+        hipLaunchKernelGGL((gn_apply_kernel<TI, TO, 4>), dim3(gn_grid(total, 4)), dim3(256), 0, st, (TO*)y, (const TI*)x, ab, hw,
+                           total, relu);
+    else
+        hipLaunchKernelGGL((gn_apply_kernel<TI, TO, 1>), dim3(gn_grid(total, 1)), dim3(256), 0, st, (TO*)y, (const TI*)x, ab, hw,
+                           total, relu);
+}
+
+template <typename TI, typename TG>
+void gn_bwd_run(void* dx, float* dgamma, float* dbeta, float* ws, const void* g, const void* x, const float* mean,
+                const float* rstd, const float* gamma, const float* beta, int batch, int C, int hw, int groups, int relu,
+                hipStream_t st) {
+    const int cpg = C / groups, rows = batch * groups;
+    const int64_t planes = (int64_t)batch * C, total = planes * hw;
+    float* part = ws;              // [planes][2]
+    float* coef = ws + 2 * planes; // [planes][3]
+    hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG>), dim3((unsigned)planes), dim3(256), 0, st, part, (const TG*)g, (const TI*)x,
+                       mean, rstd, gamma, beta, C, cpg, hw, relu);
+    hipLaunchKernelGGL(gn_bwd_row_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, coef, part, rstd, gamma, rows, groups, cpg, hw);
+    if (hw % 4 == 0)
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<TI, TG, 4>), dim3(gn_grid(total, 4)), dim3(256), 0, st, (TI*)dx, (const TG*)g,
+                           (const TI*)x, coef, mean, rstd, gamma, beta, C, cpg, hw, total, relu);
+    else
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<TI, TG, 1>), dim3(gn_grid(total, 1)), dim3(256), 0, st, (TI*)dx, (const TG*)g,
+                           (const TI*)x, coef, mean, rstd, gamma, beta, C, cpg, hw, total, relu);
+    hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(sis_cdiv(C, 256)), dim3(256), 0, st, dgamma, dbeta, part, batch, C);
+}
+
+}  // namespace
+
+extern "C" int sis_group_norm_workspace_floats(int batch, int channels) { return 5 * batch * channels; }
+
+extern "C" int sis_group_norm_fwd(void* y, float* mean, float* rstd, float* workspace, const void* x, const float* gamma,
+                                  const float* beta, int x_dtype, int y_dtype, int batch, int channels, int hw, int groups,
+                                  float eps, int relu, void* stream) {
+    if (batch == 0) return 0;
+    SIS_REQUIRE(y && mean && rstd && workspace && x && gamma && beta, "sis_group_norm_fwd: null pointer");
+    SIS_REQUIRE(batch > 0 && channels > 0 && hw > 0 && groups > 0 && channels % groups == 0,
+                "sis_group_norm_fwd: bad sizes (C %d, groups %d)", channels, groups);
+    SIS_REQUIRE(y_dtype == x_dtype || y_dtype == SIS_F32, "sis_group_norm_fwd: output dtype must be the input's or f32");
+    hipStream_t st = (hipStream_t)stream;
+#define GN_FWD(TI)                                                                                                       \
+    if (y_dtype == SIS_F32) gn_fwd_run<TI, float>(y, mean, rstd, workspace, x, gamma, beta, batch, channels, hw, groups, eps, relu, st); \
+    else gn_fwd_run<TI, TI>(y, mean, rstd, workspace, x, gamma, beta, batch, channels, hw, groups, eps, relu, st);
+    switch (x_dtype) {
+        case SIS_F32: GN_FWD(float) break;
+        case SIS_F16: GN_FWD(__half) break;
+        case SIS_BF16: GN_FWD(__hip_bfloat16) break;
+        default: return sis_fail("sis_group_norm_fwd: dtype code %d not supported (f32, f16, bf16)", x_dtype);
+    }
+#undef GN_FWD
+    SIS_CHECK_LAUNCH("gn_fwd");
+    return 0;
+}
+
+extern "C" int sis_group_norm_bwd(void* dx, float* dgamma, float* dbeta, float* workspace, const void* grad_y, const void* x,
+                                  const float* mean, const float* rstd, const float* gamma, const float* beta, int x_dtype,
+                                  int g_dtype, int batch, int channels, int hw, int groups, int relu, void* stream) {
+    if (batch == 0) return 0;
+    SIS_REQUIRE(dx && dgamma && dbeta && workspace && grad_y && x && mean && rstd && gamma && beta,
+                "sis_group_norm_bwd: null pointer");
+    SIS_REQUIRE(batch > 0 && channels > 0 && hw > 0 && groups > 0 && channels % groups == 0,
+                "sis_group_norm_bwd: bad sizes (C %d, groups %d)", channels, groups);
+    SIS_REQUIRE(g_dtype == x_dtype || g_dtype == SIS_F32, "sis_group_norm_bwd: gradient dtype must be the input's or f32");
+    hipStream_t st = (hipStream_t)stream;
+#define GN_BWD(TI)                                                                                                        \
+    if (g_dtype == SIS_F32) gn_bwd_run<TI, float>(dx, dgamma, dbeta, workspace, grad_y, x, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, st); \
+    else gn_bwd_run<TI, TI>(dx, dgamma, dbeta, workspace, grad_y, x, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, st);
+    switch (x_dtype) {
+        case SIS_F32: GN_BWD(float) break;
+        case SIS_F16: GN_BWD(__half) break;
+        case SIS_BF16: GN_BWD(__hip_bfloat16) break;
+        default: return sis_fail("sis_group_norm_bwd: dtype code %d not supported (f32, f16, bf16)", x_dtype);
+    }
+#undef GN_BWD
+    SIS_CHECK_LAUNCH("gn_bwd");
+    return 0;
+}

@@ -44,6 +44,35 @@ class _WeightStandardize(Function):
         return sis_hip.weight_std_bwd(grad, weight, invstd, ctx.eps), None, None
 
 
+class _GroupNormAct(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, relu, out_dtype):
+        y, mean, rstd = sis_hip.group_norm_fwd(x, weight, bias, groups, eps, relu, out_dtype)
+        ctx.save_for_backward(x, mean, rstd, weight, bias)
+        ctx.groups, ctx.relu = groups, relu
+        return y
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, mean, rstd, weight, bias = ctx.saved_tensors
+        dx, dgamma, dbeta = sis_hip.group_norm_bwd(grad, x, mean, rstd, weight, bias, ctx.groups, ctx.relu)
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+class HipGroupNorm(nn.GroupNorm):
+    """``nn.GroupNorm`` whose forward can also apply the ReLU that follows it and, under autocast, reads and writes the
+    16-bit tensors of the neighbouring convolutions directly (csrc/group_norm.hip: one launch per direction instead of
+    cast -> moments -> normalise -> relu -> cast).  ``keep_fp32=True`` returns float32 (the residual sum of a bottleneck
+    stays in fp32, as autocast would have it)."""
+
+    def forward(self, x, relu=False, keep_fp32=False):
+        if x.is_cuda and self.affine and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and x.dim() >= 3:
+            out_dtype = torch.float32 if keep_fp32 else x.dtype
+            return _GroupNormAct.apply(x, self.weight, self.bias, self.num_groups, self.eps, relu, out_dtype)
+        y = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
+        return F.relu(y) if relu else y
+
+
 class StdConv2d(nn.Conv2d):
     EPS = 1e-5
 
@@ -77,20 +106,18 @@ class PreActBottleneck(nn.Module):
         cmid = cmid or cout // 4
         plan = ((conv1x1, cin, cmid, 1), (conv3x3, cmid, cmid, stride), (conv1x1, cmid, cout, 1))
         for i, (make, a, b, s) in enumerate(plan, start=1):  # registration order gn_i, conv_i as in the reference
-            self.add_module(f'gn{i}', nn.GroupNorm(32, b, eps=1e-6))
+            self.add_module(f'gn{i}', HipGroupNorm(32, b, eps=1e-6))
             self.add_module(f'conv{i}', make(a, b, s) if make is conv3x3 else make(a, b))
         self.relu = nn.ReLU(inplace=True)
         if stride != 1 or cin != cout:
             self.downsample = conv1x1(cin, cout, stride)
-            self.gn_proj = nn.GroupNorm(cout, cout)
+            self.gn_proj = HipGroupNorm(cout, cout)
 
     def forward(self, x):
-        shortcut = self.gn_proj(self.downsample(x)) if hasattr(self, 'downsample') else x
+        shortcut = self.gn_proj(self.downsample(x), keep_fp32=True) if hasattr(self, 'downsample') else x
         y = x
-        for i in (1, 2, 3):
-            y = getattr(self, f'gn{i}')(getattr(self, f'conv{i}')(y))
-            if i < 3:
-                y = self.relu(y)
+        for i in (1, 2, 3):  # GroupNorm and the ReLU after the first two in one kernel; the residual sum stays fp32
+            y = getattr(self, f'gn{i}')(getattr(self, f'conv{i}')(y), relu=i < 3, keep_fp32=i == 3)
         return self.relu(shortcut + y)
 
     def load_from(self, weights, n_block, n_unit):
@@ -98,12 +125,19 @@ class PreActBottleneck(nn.Module):
         load_bottleneck(self, weights, n_block, n_unit)
 
 
+class _Root(nn.Sequential):
+    """conv -> gn -> relu with the reference's child names; GroupNorm and ReLU run as one kernel."""
+
+    def forward(self, x):
+        return self.gn(self.conv(x), relu=True)
+
+
 class ResNetV2(nn.Module):
     def __init__(self, block_units, width_factor):
         super().__init__()
         width = self.width = int(64 * width_factor)
-        self.root = nn.Sequential(OrderedDict(conv=StdConv2d(3, width, kernel_size=7, stride=2, bias=False, padding=3),
-                                              gn=nn.GroupNorm(32, width, eps=1e-6), relu=nn.ReLU(inplace=True)))
+        self.root = _Root(OrderedDict(conv=StdConv2d(3, width, kernel_size=7, stride=2, bias=False, padding=3),
+                                      gn=HipGroupNorm(32, width, eps=1e-6), relu=nn.ReLU(inplace=True)))
         stages, cin = OrderedDict(), width
         for si, n_units in enumerate(block_units):
             cout, cmid = width * 4 * 2 ** si, width * 2 ** si

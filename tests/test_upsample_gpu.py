@@ -63,3 +63,43 @@ def test_weight_standardisation(device, shape):
     np.testing.assert_allclose(w16.float().cpu().numpy(), ref.detach().float().cpu().numpy(), rtol=1e-2, atol=1e-2)
     dw16 = sis_hip.weight_std_bwd(gy.bfloat16(), w, invstd, 1e-5)
     np.testing.assert_allclose(dw16.cpu().numpy(), wr.grad.float().cpu().numpy(), rtol=5e-2, atol=2e-2 * float(wr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("shape,groups,relu", [((2, 64, 16, 16), 32, True), ((3, 256, 7, 9), 32, False), ((2, 96, 5, 5), 96, True),
+                                               ((1, 64, 127, 127), 32, True)])
+def test_group_norm_relu(device, shape, groups, relu):
+    """csrc/group_norm.hip against F.group_norm (+ relu) in float64, fp32 and bf16 tensors, both directions."""
+    import sis_hip
+    g = torch.Generator().manual_seed(shape[1])
+    x = (torch.randn(*shape, generator=g) * 2 + 0.5).to(device)
+    gamma = (1 + 0.2 * torch.randn(shape[1], generator=g)).to(device)
+    beta = (0.3 * torch.randn(shape[1], generator=g)).to(device)
+    gy = torch.randn(*shape, generator=g).to(device)
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = F.group_norm(xr, groups, gr, br, 1e-6)
+    if relu:
+        ref = F.relu(ref)
+    ref.backward(gy.double())
+    y, mean, rstd = sis_hip.group_norm_fwd(x, gamma, beta, groups, 1e-6, relu)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.detach().float().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    dx, dg, db = sis_hip.group_norm_bwd(gy, x, mean, rstd, gamma, beta, groups, relu)
+    np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(dg.cpu().numpy(), gr.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), br.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-3)
+    # bf16 tensors in and out (fp32 arithmetic inside), fp32 output on request
+    xb = x.bfloat16()
+    yb, mb, rb = sis_hip.group_norm_fwd(xb, gamma, beta, groups, 1e-6, relu)
+    assert yb.dtype == torch.bfloat16
+    refb = F.group_norm(xb.double(), groups, gamma.double(), beta.double(), 1e-6)
+    refb = F.relu(refb) if relu else refb
+    np.testing.assert_allclose(yb.float().cpu().numpy(), refb.float().cpu().numpy(), rtol=1e-2, atol=1e-2)
+    y32, _, _ = sis_hip.group_norm_fwd(xb, gamma, beta, groups, 1e-6, relu, torch.float32)
+    np.testing.assert_allclose(y32.cpu().numpy(), refb.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    dxb, dgb, dbb = sis_hip.group_norm_bwd(gy.bfloat16(), xb, mb, rb, gamma, beta, groups, relu)
+    assert dxb.dtype == torch.bfloat16
+    xq = xb.double().requires_grad_(True)  # reference on the SAME (bf16-rounded) input: the ReLU mask depends on it
+    rq = F.group_norm(xq, groups, gamma.double(), beta.double(), 1e-6)
+    (F.relu(rq) if relu else rq).backward(gy.bfloat16().double())
+    scale = float(xq.grad.abs().max())
+    np.testing.assert_allclose(dxb.float().cpu().numpy(), xq.grad.float().cpu().numpy(), rtol=2e-2, atol=1e-2 * scale)
