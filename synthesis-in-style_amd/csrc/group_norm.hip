@@ -24,32 +24,40 @@ __device__ __forceinline__ float gn_block_sum(float v, float* red) {
 
 // ---- statistics: one workgroup per (sample, channel) plane -> (mean, M2) of the plane; gn_row_finish merges the
 // planes of a group with Chan's formula in channel order (no E[x^2] - E[x]^2 cancellation, deterministic).
+// Planes are cut into S slices of `sl` elements (blockIdx.y) so that few-channel, high-resolution tensors (the decoder's
+// 16 x 512^2 maps) still fill the chip; part[plane][slice] = (count, mean, M2).
 template <typename TI>
-__global__ __launch_bounds__(256) void gn_plane_stats_kernel(float* __restrict__ part, const TI* __restrict__ x, int hw) {
+__global__ __launch_bounds__(256) void gn_plane_stats_kernel(float* __restrict__ part, const TI* __restrict__ x, int hw,
+                                                             int sl) {
     __shared__ float red[4];
+    const int lo = blockIdx.y * sl, hi = min(hw, lo + sl);
     const TI* pl = x + (int64_t)blockIdx.x * hw;
     float s = 0.f;
-    for (int i = threadIdx.x; i < hw; i += 256) s += sis_ld(pl, i);
-    const float mean = gn_block_sum(s, red) / (float)hw;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) s += sis_ld(pl, i);
+    const float cnt = (float)(hi - lo);
+    const float mean = gn_block_sum(s, red) / cnt;
     float m2 = 0.f;
-    for (int i = threadIdx.x; i < hw; i += 256) { const float d = sis_ld(pl, i) - mean; m2 += d * d; }
+    for (int i = lo + threadIdx.x; i < hi; i += 256) { const float d = sis_ld(pl, i) - mean; m2 += d * d; }
     m2 = gn_block_sum(m2, red);
-    if (threadIdx.x == 0) { part[2 * (int64_t)blockIdx.x] = mean; part[2 * (int64_t)blockIdx.x + 1] = m2; }
+    if (threadIdx.x == 0) {
+        float* o = part + 3 * ((int64_t)blockIdx.x * gridDim.y + blockIdx.y);
+        o[0] = cnt; o[1] = mean; o[2] = m2;
+    }
 }
 
 // per (sample, channel): a = rstd_row * gamma_c, b = beta_c - mean_row * a  (the apply kernel's scale / shift)
 __global__ __launch_bounds__(64) void gn_row_finish_kernel(float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                            float* __restrict__ ab, const float* __restrict__ part,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           int rows, int groups, int cpg, int hw, float eps) {
+                                                           int rows, int groups, int cpg, int S, float eps) {
     const int row = blockIdx.x * 64 + threadIdx.x;
     if (row >= rows) return;
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int c = 0; c < cpg; ++c) {
-        const float* p = part + 2 * ((int64_t)row * cpg + c);
-        const float nb = (float)hw, nt = n + nb, delta = p[0] - mean;
+    for (int j = 0; j < cpg * S; ++j) {  // the group's planes are adjacent: (row * cpg + c) * S + slice
+        const float* p = part + 3 * ((int64_t)row * cpg * S + j);
+        const float nb = p[0], nt = n + nb, delta = p[1] - mean;
         mean += delta * (nb / nt);
-        m2 += p[1] + delta * delta * (n * nb / nt);
+        m2 += p[2] + delta * delta * (n * nb / nt);
         n = nt;
     }
     const float rstd = rsqrtf(m2 / n + eps);
@@ -84,16 +92,18 @@ template <typename TI, typename TG>
 __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ part, const TG* __restrict__ g,
                                                            const TI* __restrict__ x, const float* __restrict__ mean_in,
                                                            const float* __restrict__ rstd_in, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, int C, int cpg, int hw, int relu) {
+                                                           const float* __restrict__ beta, int C, int cpg, int hw, int sl,
+                                                           int relu) {
     __shared__ float red[4];
     const int64_t plane = blockIdx.x;
     const int c = (int)(plane % C);
-    const int64_t row = plane / cpg;  // (sample * C + c) / cpg = sample * groups + group
+    const int64_t row = cpg > 0 ? plane / cpg : c;  // group norm: sample * groups + group; batch norm (cpg = 0): channel
     const float mean = mean_in[row], rstd = rstd_in[row], gm = gamma[c], bt = beta[c];
     const TI* px = x + plane * hw;
     const TG* pg = g + plane * hw;
+    const int lo = blockIdx.y * sl, hi = min(hw, lo + sl);
     float sg = 0.f, sgx = 0.f;
-    for (int i = threadIdx.x; i < hw; i += 256) {
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
         const float xh = (sis_ld(px, i) - mean) * rstd;
         float gi = sis_ld(pg, i);
         if (relu && xh * gm + bt <= 0.f) gi = 0.f;
@@ -101,21 +111,30 @@ __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ p
     }
     sg = gn_block_sum(sg, red);
     sgx = gn_block_sum(sgx, red);
-    if (threadIdx.x == 0) { part[2 * plane] = sg; part[2 * plane + 1] = sgx; }
+    if (threadIdx.x == 0) {
+        float* o = part + 2 * (plane * gridDim.y + blockIdx.y);
+        o[0] = sg; o[1] = sgx;
+    }
 }
 
 // per row: m1 = mean(g'*gamma), m2 = mean(g'*gamma*xhat) -> per plane coefficients (k1, k2, k3) with
 // dx = k1 * g' - k2 - k3 * xhat;  k1 = rstd*gamma_c, k2 = rstd*m1, k3 = rstd*m2
-__global__ __launch_bounds__(64) void gn_bwd_row_kernel(float* __restrict__ coef, const float* __restrict__ part,
-                                                        const float* __restrict__ rstd_in, const float* __restrict__ gamma,
-                                                        int rows, int groups, int cpg, int hw) {
+__global__ __launch_bounds__(64) void gn_bwd_row_kernel(float* __restrict__ coef, float* __restrict__ psum,
+                                                        const float* __restrict__ part, const float* __restrict__ rstd_in,
+                                                        const float* __restrict__ gamma, int rows, int groups, int cpg, int hw,
+                                                        int S) {
     const int row = blockIdx.x * 64 + threadIdx.x;
     if (row >= rows) return;
     const int c0 = (row % groups) * cpg;
     float s1 = 0.f, s2 = 0.f;
     for (int c = 0; c < cpg; ++c) {
-        const float* p = part + 2 * ((int64_t)row * cpg + c);
-        s1 += gamma[c0 + c] * p[0]; s2 += gamma[c0 + c] * p[1];
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < S; ++k) {
+            const float* p = part + 2 * (((int64_t)row * cpg + c) * S + k);
+            a += p[0]; b += p[1];
+        }
+        psum[2 * ((int64_t)row * cpg + c)] = a; psum[2 * ((int64_t)row * cpg + c) + 1] = b;  // plane sums (for d gamma / beta)
+        s1 += gamma[c0 + c] * a; s2 += gamma[c0 + c] * b;
     }
     const float n = (float)cpg * (float)hw, rstd = rstd_in[row];
     for (int c = 0; c < cpg; ++c) {
@@ -132,8 +151,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(TI* __restrict__ dx, 
                                                            int C, int cpg, int hw, int64_t total, int relu) {
     const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < total; i += stride) {
-        const int64_t plane = i / hw, row = plane / cpg;
+        const int64_t plane = i / hw;
         const int c = (int)(plane % C);
+        const int64_t row = cpg > 0 ? plane / cpg : c;
         const float mean = mean_in[row], rstd = rstd_in[row], gm = gamma[c], bt = beta[c];
         const float k1 = coef[3 * plane], k2 = coef[3 * plane + 1], k3 = coef[3 * plane + 2];
 #pragma unroll
@@ -155,6 +175,58 @@ __global__ __launch_bounds__(256) void gn_param_reduce_kernel(float* __restrict_
     dgamma[c] = a; dbeta[c] = b;
 }
 
+// ---- batch-norm mode (statistics per channel over the batch): the planes of channel c are n * C + c.
+__global__ __launch_bounds__(64) void bn_chan_finish_kernel(float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            float* __restrict__ ab, float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var, const float* __restrict__ part,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            int batch, int C, int S, float eps, float momentum) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int b = 0; b < batch; ++b)
+        for (int k = 0; k < S; ++k) {
+            const float* p = part + 3 * (((int64_t)b * C + c) * S + k);
+            const float nb = p[0], nt = n + nb, delta = p[1] - mean;
+            mean += delta * (nb / nt);
+            m2 += p[2] + delta * delta * (n * nb / nt);
+            n = nt;
+        }
+    const float rstd = rsqrtf(m2 / n + eps);
+    mean_out[c] = mean; rstd_out[c] = rstd;
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : m2 / n);
+    }
+    const float a = rstd * gamma[c], sh = beta[c] - mean * a;
+    for (int b = 0; b < batch; ++b) { ab[2 * ((int64_t)b * C + c)] = a; ab[2 * ((int64_t)b * C + c) + 1] = sh; }
+}
+
+// dx = rstd*gamma * (g' - sum(g')/N - xhat * sum(g'*xhat)/N),  d(gamma) = sum(g'*xhat),  d(beta) = sum(g')
+__global__ __launch_bounds__(64) void bn_bwd_chan_kernel(float* __restrict__ coef, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, const float* __restrict__ part,
+                                                         const float* __restrict__ rstd_in, const float* __restrict__ gamma,
+                                                         int batch, int C, int hw, int S) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < batch; ++b)
+        for (int k = 0; k < S; ++k) {
+            const float* p = part + 2 * (((int64_t)b * C + c) * S + k);
+            s1 += p[0]; s2 += p[1];
+        }
+    dbeta[c] = s1; dgamma[c] = s2;
+    const float n = (float)batch * (float)hw, k1 = rstd_in[c] * gamma[c];
+    for (int b = 0; b < batch; ++b) {
+        float* k = coef + 3 * ((int64_t)b * C + c);
+        k[0] = k1; k[1] = k1 * s1 / n; k[2] = k1 * s2 / n;
+    }
+}
+
+constexpr int GN_SLICE = 16384;  // elements of a plane per statistics workgroup
+inline int gn_slices(int hw) { return (hw + GN_SLICE - 1) / GN_SLICE; }
+inline int gn_slice_len(int hw) { const int S = gn_slices(hw); return (((hw + S - 1) / S) + 3) & ~3; }
+
 inline unsigned gn_grid(int64_t total, int vec) {
     const int64_t blocks = (total / vec + 255) / 256;
     return (unsigned)(blocks < 16384 ? (blocks > 0 ? blocks : 1) : 16384);
@@ -165,11 +237,12 @@ void gn_fwd_run(void* y, float* mean, float* rstd, float* ws, const void* x, con
                 int C, int hw, int groups, float eps, int relu, hipStream_t st) {
     const int cpg = C / groups, rows = batch * groups;
     const int64_t planes = (int64_t)batch * C, total = planes * hw;
-    float* part = ws;              // [planes][2]
-    float* ab = ws + 2 * planes;   // [planes][2]
-    hipLaunchKernelGGL(gn_plane_stats_kernel<TI>, dim3((unsigned)planes), dim3(256), 0, st, part, (const TI*)x, hw);
+    const int S = gn_slices(hw), sl = gn_slice_len(hw);
+    float* ab = ws;                // [planes][2]
+    float* part = ws + 5 * planes; // [planes][S][3]
+    hipLaunchKernelGGL(gn_plane_stats_kernel<TI>, dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl);
     hipLaunchKernelGGL(gn_row_finish_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, mean, rstd, ab, part, gamma, beta, rows,
-                       groups, cpg, hw, eps);
+                       groups, cpg, S, eps);
     if (hw % 4 == 0)
         hipLaunchKernelGGL((gn_apply_kernel<TI, TO, 4>), dim3(gn_grid(total, 4)), dim3(256), 0, st, (TO*)y, (const TI*)x, ab, hw,
                            total, relu);
@@ -184,23 +257,65 @@ void gn_bwd_run(void* dx, float* dgamma, float* dbeta, float* ws, const void* g,
                 hipStream_t st) {
     const int cpg = C / groups, rows = batch * groups;
     const int64_t planes = (int64_t)batch * C, total = planes * hw;
-    float* part = ws;              // [planes][2]
+    const int S = gn_slices(hw), sl = gn_slice_len(hw);
+    float* psum = ws;              // [planes][2]
     float* coef = ws + 2 * planes; // [planes][3]
-    hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG>), dim3((unsigned)planes), dim3(256), 0, st, part, (const TG*)g, (const TI*)x,
-                       mean, rstd, gamma, beta, C, cpg, hw, relu);
-    hipLaunchKernelGGL(gn_bwd_row_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, coef, part, rstd, gamma, rows, groups, cpg, hw);
+    float* part = ws + 5 * planes; // [planes][S][2]
+    hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
+                       (const TI*)x, mean, rstd, gamma, beta, C, cpg, hw, sl, relu);
+    hipLaunchKernelGGL(gn_bwd_row_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, coef, psum, part, rstd, gamma, rows, groups,
+                       cpg, hw, S);
     if (hw % 4 == 0)
         hipLaunchKernelGGL((gn_bwd_apply_kernel<TI, TG, 4>), dim3(gn_grid(total, 4)), dim3(256), 0, st, (TI*)dx, (const TG*)g,
                            (const TI*)x, coef, mean, rstd, gamma, beta, C, cpg, hw, total, relu);
     else
         hipLaunchKernelGGL((gn_bwd_apply_kernel<TI, TG, 1>), dim3(gn_grid(total, 1)), dim3(256), 0, st, (TI*)dx, (const TG*)g,
                            (const TI*)x, coef, mean, rstd, gamma, beta, C, cpg, hw, total, relu);
-    hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(sis_cdiv(C, 256)), dim3(256), 0, st, dgamma, dbeta, part, batch, C);
+    hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(sis_cdiv(C, 256)), dim3(256), 0, st, dgamma, dbeta, psum, batch, C);
+}
+
+template <typename TI, typename TO>
+void bn_fwd_run(void* y, float* mean, float* rstd, float* rm, float* rv, float* ws, const void* x, const float* gamma,
+                const float* beta, int batch, int C, int hw, float eps, float momentum, int relu, hipStream_t st) {
+    const int64_t planes = (int64_t)batch * C, total = planes * hw;
+    const int S = gn_slices(hw), sl = gn_slice_len(hw);
+    float* ab = ws;
+    float* part = ws + 5 * planes;
+    hipLaunchKernelGGL(gn_plane_stats_kernel<TI>, dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl);
+    hipLaunchKernelGGL(bn_chan_finish_kernel, dim3(sis_cdiv(C, 64)), dim3(64), 0, st, mean, rstd, ab, rm, rv, part, gamma, beta,
+                       batch, C, S, eps, momentum);
+    if (hw % 4 == 0)
+        hipLaunchKernelGGL((gn_apply_kernel<TI, TO, 4>), dim3(gn_grid(total, 4)), dim3(256), 0, st, (TO*)y, (const TI*)x, ab, hw,
+                           total, relu);
+    else
+        hipLaunchKernelGGL((gn_apply_kernel<TI, TO, 1>), dim3(gn_grid(total, 1)), dim3(256), 0, st, (TO*)y, (const TI*)x, ab, hw,
+                           total, relu);
+}
+
+template <typename TI, typename TG>
+void bn_bwd_run(void* dx, float* dgamma, float* dbeta, float* ws, const void* g, const void* x, const float* mean,
+                const float* rstd, const float* gamma, const float* beta, int batch, int C, int hw, int relu, hipStream_t st) {
+    const int64_t planes = (int64_t)batch * C, total = planes * hw;
+    const int S = gn_slices(hw), sl = gn_slice_len(hw);
+    float* coef = ws + 2 * planes;
+    float* part = ws + 5 * planes;
+    hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
+                       (const TI*)x, mean, rstd, gamma, beta, C, 0, hw, sl, relu);
+    hipLaunchKernelGGL(bn_bwd_chan_kernel, dim3(sis_cdiv(C, 64)), dim3(64), 0, st, coef, dgamma, dbeta, part, rstd, gamma, batch,
+                       C, hw, S);
+    if (hw % 4 == 0)
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<TI, TG, 4>), dim3(gn_grid(total, 4)), dim3(256), 0, st, (TI*)dx, (const TG*)g,
+                           (const TI*)x, coef, mean, rstd, gamma, beta, C, 0, hw, total, relu);
+    else
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<TI, TG, 1>), dim3(gn_grid(total, 1)), dim3(256), 0, st, (TI*)dx, (const TG*)g,
+                           (const TI*)x, coef, mean, rstd, gamma, beta, C, 0, hw, total, relu);
 }
 
 }  // namespace
 
-extern "C" int sis_group_norm_workspace_floats(int batch, int channels) { return 5 * batch * channels; }
+extern "C" int64_t sis_group_norm_workspace_floats(int batch, int channels, int hw) {
+    return (int64_t)batch * channels * (5 + 3 * gn_slices(hw));
+}
 
 extern "C" int sis_group_norm_fwd(void* y, float* mean, float* rstd, float* workspace, const void* x, const float* gamma,
                                   const float* beta, int x_dtype, int y_dtype, int batch, int channels, int hw, int groups,
@@ -246,5 +361,54 @@ extern "C" int sis_group_norm_bwd(void* dx, float* dgamma, float* dbeta, float* 
     }
 #undef GN_BWD
     SIS_CHECK_LAUNCH("gn_bwd");
+    return 0;
+}
+
+// ---- nn.BatchNorm2d in training mode (+ ReLU) with 16-bit or fp32 tensors: the TransUNet decoder's Conv2dReLU blocks
+// (vit_seg_modeling.py:265-287).  Same three-launch structure, statistics per channel over (batch, H, W); running
+// statistics updated with `momentum` (unbiased variance), may be NULL.  Workspace as for group norm.
+extern "C" int sis_batch_norm_fwd(void* y, float* mean, float* rstd, float* running_mean, float* running_var, float* workspace,
+                                  const void* x, const float* gamma, const float* beta, int x_dtype, int y_dtype, int batch,
+                                  int channels, int hw, float eps, float momentum, int relu, void* stream) {
+    if (batch == 0) return 0;
+    SIS_REQUIRE(y && mean && rstd && workspace && x && gamma && beta, "sis_batch_norm_fwd: null pointer");
+    SIS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sis_batch_norm_fwd: running statistics come in pairs");
+    SIS_REQUIRE(batch > 0 && channels > 0 && hw > 0, "sis_batch_norm_fwd: non-positive size");
+    SIS_REQUIRE(y_dtype == x_dtype || y_dtype == SIS_F32, "sis_batch_norm_fwd: output dtype must be the input's or f32");
+    hipStream_t st = (hipStream_t)stream;
+#define BN_FWD(TI)                                                                                                        \
+    if (y_dtype == SIS_F32) bn_fwd_run<TI, float>(y, mean, rstd, running_mean, running_var, workspace, x, gamma, beta, batch, channels, hw, eps, momentum, relu, st); \
+    else bn_fwd_run<TI, TI>(y, mean, rstd, running_mean, running_var, workspace, x, gamma, beta, batch, channels, hw, eps, momentum, relu, st);
+    switch (x_dtype) {
+        case SIS_F32: BN_FWD(float) break;
+        case SIS_F16: BN_FWD(__half) break;
+        case SIS_BF16: BN_FWD(__hip_bfloat16) break;
+        default: return sis_fail("sis_batch_norm_fwd: dtype code %d not supported (f32, f16, bf16)", x_dtype);
+    }
+#undef BN_FWD
+    SIS_CHECK_LAUNCH("bn_fwd");
+    return 0;
+}
+
+extern "C" int sis_batch_norm_bwd(void* dx, float* dgamma, float* dbeta, float* workspace, const void* grad_y, const void* x,
+                                  const float* mean, const float* rstd, const float* gamma, const float* beta, int x_dtype,
+                                  int g_dtype, int batch, int channels, int hw, int relu, void* stream) {
+    if (batch == 0) return 0;
+    SIS_REQUIRE(dx && dgamma && dbeta && workspace && grad_y && x && mean && rstd && gamma && beta,
+                "sis_batch_norm_bwd: null pointer");
+    SIS_REQUIRE(batch > 0 && channels > 0 && hw > 0, "sis_batch_norm_bwd: non-positive size");
+    SIS_REQUIRE(g_dtype == x_dtype || g_dtype == SIS_F32, "sis_batch_norm_bwd: gradient dtype must be the input's or f32");
+    hipStream_t st = (hipStream_t)stream;
+#define BN_BWD(TI)                                                                                                        \
+    if (g_dtype == SIS_F32) bn_bwd_run<TI, float>(dx, dgamma, dbeta, workspace, grad_y, x, mean, rstd, gamma, beta, batch, channels, hw, relu, st); \
+    else bn_bwd_run<TI, TI>(dx, dgamma, dbeta, workspace, grad_y, x, mean, rstd, gamma, beta, batch, channels, hw, relu, st);
+    switch (x_dtype) {
+        case SIS_F32: BN_BWD(float) break;
+        case SIS_F16: BN_BWD(__half) break;
+        case SIS_BF16: BN_BWD(__hip_bfloat16) break;
+        default: return sis_fail("sis_batch_norm_bwd: dtype code %d not supported (f32, f16, bf16)", x_dtype);
+    }
+#undef BN_BWD
+    SIS_CHECK_LAUNCH("bn_bwd");
     return 0;
 }

@@ -4,16 +4,55 @@ four (bilinear x2, concat skip, 2 x conv-BN-ReLU) stages -> 3x3 head."""
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+import sis_hip
 
 from networks.hip_conv import HipConv2d
 from networks.hip_upsample import HipUpsamplingBilinear2d
 
 
+class _BatchNormAct(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu):
+        y, mean, rstd = sis_hip.batch_norm_train_fwd(x, weight, bias, running_mean, running_var, eps, momentum, relu)
+        ctx.save_for_backward(x, mean, rstd, weight, bias)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, mean, rstd, weight, bias = ctx.saved_tensors
+        dx, dgamma, dbeta = sis_hip.batch_norm_train_bwd(grad, x, mean, rstd, weight, bias, ctx.relu)
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class HipBatchNorm2d(nn.BatchNorm2d):
+    """``nn.BatchNorm2d`` whose training-mode forward can apply the following ReLU and reads / writes the 16-bit
+    tensors of the neighbouring convolutions directly under autocast (csrc/group_norm.hip, batch-norm mode)."""
+
+    def forward(self, x, relu=False):
+        if (self.training and x.is_cuda and self.affine and self.track_running_stats and self.momentum is not None
+                and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and x.dim() == 4):
+            if self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            return _BatchNormAct.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                       self.momentum, relu)
+        y = super().forward(x)
+        return F.relu(y) if relu else y
+
+
 class Conv2dReLU(nn.Sequential):
+    """conv -> batch norm -> ReLU with the reference's child indices (0, 1, 2); norm and ReLU run as one kernel."""
+
     def __init__(self, in_channels, out_channels, kernel_size, padding=0, stride=1, use_batchnorm=True):
         super().__init__(HipConv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
                                    bias=not use_batchnorm),
-                         nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
+                         HipBatchNorm2d(out_channels), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return self[1](self[0](x), relu=True)
 
 
 class DecoderBlock(nn.Module):

@@ -46,7 +46,9 @@ _SIGNATURES = {
     "sis_upsample_bilinear": ([_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp], _i),
     "sis_weight_std_fwd": ([_vp, _vp, _vp, _i, _i, _i, _f, _vp], _i),
     "sis_group_norm_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
-    "sis_group_norm_workspace_floats": ([_i, _i], _i),
+    "sis_group_norm_workspace_floats": ([_i, _i, _i], _i64),
+    "sis_batch_norm_fwd": ([_vp] * 9 + [_i] * 5 + [_f, _f, _i, _vp], _i),
+    "sis_batch_norm_bwd": ([_vp] * 10 + [_i] * 6 + [_vp], _i),
     "sis_group_norm_bwd": ([_vp] * 10 + [_i] * 7 + [_vp], _i),
     "sis_weight_std_bwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp], _i),
     "sis_conv3x3_wgrad_eligible": ([_i] * 5 + [_i64], _i),
@@ -578,7 +580,7 @@ def group_norm_fwd(x, gamma, beta, groups, eps, relu, out_dtype=None):
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     mean = torch.empty(b * groups, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
-    ws = torch.empty(lib().sis_group_norm_workspace_floats(b, c), dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib().sis_group_norm_workspace_floats(b, c, hw), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _check(lib().sis_group_norm_fwd(_ptr(y), _ptr(mean), _ptr(rstd), _ptr(ws), _ptr(x), _ptr(_f32(gamma, "weight")),
                                         _ptr(_f32(beta, "bias")), _DTYPE_CODE[x.dtype], _DTYPE_CODE[out_dtype], b, c, hw,
@@ -596,11 +598,48 @@ def group_norm_bwd(grad_y, x, mean, rstd, gamma, beta, groups, relu):
     dx = torch.empty_like(x)
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
     dbeta = torch.empty_like(dgamma)
-    ws = torch.empty(lib().sis_group_norm_workspace_floats(b, c), dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib().sis_group_norm_workspace_floats(b, c, hw), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _check(lib().sis_group_norm_bwd(_ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _ptr(g), _ptr(x), _ptr(mean), _ptr(rstd),
                                         _ptr(gamma), _ptr(beta), _DTYPE_CODE[x.dtype], _DTYPE_CODE[g.dtype], b, c, hw, groups,
                                         int(bool(relu)), _stream()), "sis_group_norm_bwd")
+    return dx, dgamma, dbeta
+
+
+def batch_norm_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, relu, out_dtype=None):
+    """Training-mode batch norm (+ ReLU) on f32 / f16 / bf16 tensors -> (y, mean [C], rstd [C])."""
+    require_device(x, "input")
+    x = x.contiguous()
+    out_dtype = out_dtype or x.dtype
+    b, c = x.shape[0], x.shape[1]
+    hw = x[0, 0].numel()
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    ws = torch.empty(lib().sis_group_norm_workspace_floats(b, c, hw), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_batch_norm_fwd(_ptr(y), _ptr(mean), _ptr(rstd), _ptr(running_mean), _ptr(running_var), _ptr(ws), _ptr(x),
+                                        _ptr(_f32(gamma, "weight")), _ptr(_f32(beta, "bias")), _DTYPE_CODE[x.dtype],
+                                        _DTYPE_CODE[out_dtype], b, c, hw, float(eps), float(momentum), int(bool(relu)),
+                                        _stream()), "sis_batch_norm_fwd")
+    return y, mean, rstd
+
+
+def batch_norm_train_bwd(grad_y, x, mean, rstd, gamma, beta, relu):
+    x = x.contiguous()
+    g = grad_y.contiguous()
+    if g.dtype != x.dtype and g.dtype != torch.float32:
+        g = g.to(x.dtype)
+    b, c = x.shape[0], x.shape[1]
+    hw = x[0, 0].numel()
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty_like(dgamma)
+    ws = torch.empty(lib().sis_group_norm_workspace_floats(b, c, hw), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_batch_norm_bwd(_ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _ptr(g), _ptr(x), _ptr(mean), _ptr(rstd),
+                                        _ptr(gamma), _ptr(beta), _DTYPE_CODE[x.dtype], _DTYPE_CODE[g.dtype], b, c, hw,
+                                        int(bool(relu)), _stream()), "sis_batch_norm_bwd")
     return dx, dgamma, dbeta
 
 

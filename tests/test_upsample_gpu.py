@@ -103,3 +103,33 @@ def test_group_norm_relu(device, shape, groups, relu):
     (F.relu(rq) if relu else rq).backward(gy.bfloat16().double())
     scale = float(xq.grad.abs().max())
     np.testing.assert_allclose(dxb.float().cpu().numpy(), xq.grad.float().cpu().numpy(), rtol=2e-2, atol=1e-2 * scale)
+
+
+@pytest.mark.parametrize("shape,relu", [((4, 16, 12, 12), True), ((2, 64, 33, 31), False), ((8, 256, 16, 16), True)])
+def test_batch_norm_train_relu(device, shape, relu):
+    """Batch-norm mode of csrc/group_norm.hip against F.batch_norm(training=True) (+ relu), incl. running statistics."""
+    import sis_hip
+    g = torch.Generator().manual_seed(shape[1] + shape[2])
+    x = (torch.randn(*shape, generator=g) * 1.5 - 0.3).to(device)
+    c = shape[1]
+    gamma = (1 + 0.2 * torch.randn(c, generator=g)).to(device)
+    beta = (0.3 * torch.randn(c, generator=g)).to(device)
+    gy = torch.randn(*shape, generator=g).to(device)
+    rm, rv = torch.zeros(c, device=device), torch.ones(c, device=device)
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    ref = F.relu(ref) if relu else ref
+    ref.backward(gy.double())
+    y, mean, rstd = sis_hip.batch_norm_train_fwd(x, gamma, beta, rm, rv, 1e-5, 0.1, relu)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.detach().float().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rm.cpu().numpy(), rm_ref.float().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), rv_ref.float().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    dx, dg, db = sis_hip.batch_norm_train_bwd(gy, x, mean, rstd, gamma, beta, relu)
+    np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(dg.cpu().numpy(), gr.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), br.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-3)
+    yb, _, _ = sis_hip.batch_norm_train_fwd(x.bfloat16(), gamma, beta, None, None, 1e-5, 0.1, relu)
+    assert yb.dtype == torch.bfloat16
+    np.testing.assert_allclose(yb.float().cpu().numpy(), ref.detach().float().cpu().numpy(), rtol=3e-2, atol=3e-2)
