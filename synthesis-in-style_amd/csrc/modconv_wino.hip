@@ -326,7 +326,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     const int k_hi = min(p.Cin, k_lo + p.kchunk);
     const int tpl0 = thl + twl - 2;  // log2(tiles per sample)
 
-    // A workgroup walks `tiles_per_wg` consecutive pixel tiles of its output-channel block (persistent over
+    // A workgroup walks `tiles_per_wg` pixel tiles of its output-channel block (persistent over
     // tiles): the next tile's first DMA flies under the current tile's epilogue, and the per-workgroup launch /
     // first-touch latency is paid once per `tiles_per_wg` tiles instead of once per tile (7 us against 16 chunks
     // x 2.5 us on the 128-channel 256^2 layer).
@@ -345,7 +345,10 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
             if (b < p.B && h >= 0 && h < p.H && w >= 0 && w < p.W) st_goff = b * p.Cin * HW + h * p.W + w;
         }
     };
-    const int pt_first = (blockIdx.x / n_co) * tiles_per_wg;
+    // Tile k of workgroup g is pixel tile g + k * (#workgroups per channel block): the workgroups running at the same
+    // time cover NEIGHBOURING tiles, whose halos they share through L2 (consecutive tiles per workgroup measured 57 %
+    // more fetched bytes).
+    const int pt_first = blockIdx.x / n_co, pt_step = gridDim.x / n_co;
     tile_setup(pt_first);
     constexpr int WV4 = WF / 4, WIT = WV4 / WNTHR;  // 4 float4 per lane per chunk
     int w_goff[WIT];
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
         const int ob = b0 + tn, oh = h0 + 2 * ty, ow = w0 + 2 * tx;  // this tile's output pixel, before b0/h0/w0 move on
         const bool live = tn < tc.nb && ob < p.B && oh < p.H && ow < p.W;
         if (has_next) {
-            tile_setup(pt_first + k + 1);
+            tile_setup(pt_first + (k + 1) * pt_step);
             tile_first_dma();
         }
 
@@ -653,7 +656,7 @@ int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t 
     static const bool pipelined = !(getenv("SIS_WINO_PIPE") && getenv("SIS_WINO_PIPE")[0] == '0');
     if (pipelined && lds2 <= 160 * 1024) {
         sis_kernel_name = "modconv_wino2_kernel";
-        // consecutive pixel tiles per workgroup: as many as keep >= 1024 workgroups (4 per CU) in flight
+        // pixel tiles per workgroup: as many as keep >= 1024 workgroups (4 per CU) in flight
         static const int tpw_cap = getenv("SIS_WINO_TPW") ? atoi(getenv("SIS_WINO_TPW")) : 16;
         int tpw = 1;
         static const int min_wg = getenv("SIS_WINO_MINWG") ? atoi(getenv("SIS_WINO_MINWG")) : 1024;
