@@ -22,22 +22,50 @@ __device__ __forceinline__ float gn_block_sum(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// VEC consecutive elements as floats: one 16-byte (f32) or 8-byte (f16 / bf16) load when VEC == 4
+template <int VEC, typename T>
+__device__ __forceinline__ void gn_load(const T* p, float* v) {
+    if constexpr (VEC == 4 && sizeof(T) == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else if constexpr (VEC == 4 && sizeof(T) == 2) {
+        const uint2 q = *reinterpret_cast<const uint2*>(p);
+        T t[4];
+        __builtin_memcpy(t, &q, 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = sis_ld(t, e);
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = sis_ld(p, e);
+    }
+}
+
 // ---- statistics: one workgroup per (sample, channel) plane -> (mean, M2) of the plane; gn_row_finish merges the
 // planes of a group with Chan's formula in channel order (no E[x^2] - E[x]^2 cancellation, deterministic).
 // Planes are cut into S slices of `sl` elements (blockIdx.y) so that few-channel, high-resolution tensors (the decoder's
 // 16 x 512^2 maps) still fill the chip; part[plane][slice] = (count, mean, M2).
-template <typename TI>
+template <typename TI, int VEC>
 __global__ __launch_bounds__(256) void gn_plane_stats_kernel(float* __restrict__ part, const TI* __restrict__ x, int hw,
                                                              int sl) {
     __shared__ float red[4];
     const int lo = blockIdx.y * sl, hi = min(hw, lo + sl);
     const TI* pl = x + (int64_t)blockIdx.x * hw;
     float s = 0.f;
-    for (int i = lo + threadIdx.x; i < hi; i += 256) s += sis_ld(pl, i);
+    for (int i = lo + threadIdx.x * VEC; i < hi; i += 256 * VEC) {
+        float v[VEC];
+        gn_load<VEC>(pl + i, v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s += v[e];
+    }
     const float cnt = (float)(hi - lo);
     const float mean = gn_block_sum(s, red) / cnt;
     float m2 = 0.f;
-    for (int i = lo + threadIdx.x; i < hi; i += 256) { const float d = sis_ld(pl, i) - mean; m2 += d * d; }
+    for (int i = lo + threadIdx.x * VEC; i < hi; i += 256 * VEC) {
+        float v[VEC];
+        gn_load<VEC>(pl + i, v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { const float d = v[e] - mean; m2 += d * d; }
+    }
     m2 = gn_block_sum(m2, red);
     if (threadIdx.x == 0) {
         float* o = part + 3 * ((int64_t)blockIdx.x * gridDim.y + blockIdx.y);
@@ -78,9 +106,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(TO* __restrict__ y, const
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < total; i += stride) {
         const int64_t plane = i / hw;
         const float a = ab[2 * plane], b = ab[2 * plane + 1];
+        float xv[VEC];
+        gn_load<VEC>(x + i, xv);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            float v = sis_ld(x, i + e) * a + b;
+            float v = xv[e] * a + b;
             if (relu) v = fmaxf(v, 0.f);
             sis_st(y, i + e, v);
         }
@@ -88,7 +118,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(TO* __restrict__ y, const
 }
 
 // ---- backward.  g' = g * [y > 0] (mask recomputed: y = x*a + b).  Per plane: sum(g'), sum(g' * xhat).
-template <typename TI, typename TG>
+template <typename TI, typename TG, int VEC>
 __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ part, const TG* __restrict__ g,
                                                            const TI* __restrict__ x, const float* __restrict__ mean_in,
                                                            const float* __restrict__ rstd_in, const float* __restrict__ gamma,
@@ -103,11 +133,17 @@ __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ p
     const TG* pg = g + plane * hw;
     const int lo = blockIdx.y * sl, hi = min(hw, lo + sl);
     float sg = 0.f, sgx = 0.f;
-    for (int i = lo + threadIdx.x; i < hi; i += 256) {
-        const float xh = (sis_ld(px, i) - mean) * rstd;
-        float gi = sis_ld(pg, i);
-        if (relu && xh * gm + bt <= 0.f) gi = 0.f;
-        sg += gi; sgx += gi * xh;
+    for (int i = lo + threadIdx.x * VEC; i < hi; i += 256 * VEC) {
+        float xv[VEC], gv[VEC];
+        gn_load<VEC>(px + i, xv);
+        gn_load<VEC>(pg + i, gv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float xh = (xv[e] - mean) * rstd;
+            float gi = gv[e];
+            if (relu && xh * gm + bt <= 0.f) gi = 0.f;
+            sg += gi; sgx += gi * xh;
+        }
     }
     sg = gn_block_sum(sg, red);
     sgx = gn_block_sum(sgx, red);
@@ -156,10 +192,13 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(TI* __restrict__ dx, 
         const int64_t row = cpg > 0 ? plane / cpg : c;
         const float mean = mean_in[row], rstd = rstd_in[row], gm = gamma[c], bt = beta[c];
         const float k1 = coef[3 * plane], k2 = coef[3 * plane + 1], k3 = coef[3 * plane + 2];
+        float xv[VEC], gv[VEC];
+        gn_load<VEC>(x + i, xv);
+        gn_load<VEC>(g + i, gv);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            const float xh = (sis_ld(x, i + e) - mean) * rstd;
-            float gi = sis_ld(g, i + e);
+            const float xh = (xv[e] - mean) * rstd;
+            float gi = gv[e];
             if (relu && xh * gm + bt <= 0.f) gi = 0.f;
             sis_st(dx, i + e, k1 * gi - k2 - k3 * xh);
         }
@@ -240,7 +279,10 @@ void gn_fwd_run(void* y, float* mean, float* rstd, float* ws, const void* x, con
     const int S = gn_slices(hw), sl = gn_slice_len(hw);
     float* ab = ws;                // [planes][2]
     float* part = ws + 5 * planes; // [planes][S][3]
-    hipLaunchKernelGGL(gn_plane_stats_kernel<TI>, dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl);
+    if (hw % 4 == 0)
+        hipLaunchKernelGGL((gn_plane_stats_kernel<TI, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl);
+    else
+        hipLaunchKernelGGL((gn_plane_stats_kernel<TI, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl);
     hipLaunchKernelGGL(gn_row_finish_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, mean, rstd, ab, part, gamma, beta, rows,
                        groups, cpg, S, eps);
     if (hw % 4 == 0)
@@ -261,8 +303,13 @@ void gn_bwd_run(void* dx, float* dgamma, float* dbeta, float* ws, const void* g,
     float* psum = ws;              // [planes][2]
     float* coef = ws + 2 * planes; // [planes][3]
     float* part = ws + 5 * planes; // [planes][S][2]
-    hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
+    if (hw % 4 == 0) {
+    hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
                        (const TI*)x, mean, rstd, gamma, beta, C, cpg, hw, sl, relu);
+    } else {
+    hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
+                       (const TI*)x, mean, rstd, gamma, beta, C, cpg, hw, sl, relu);
+    }
     hipLaunchKernelGGL(gn_bwd_row_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, coef, psum, part, rstd, gamma, rows, groups,
                        cpg, hw, S);
     if (hw % 4 == 0)
@@ -281,7 +328,10 @@ void bn_fwd_run(void* y, float* mean, float* rstd, float* rm, float* rv, float* 
     const int S = gn_slices(hw), sl = gn_slice_len(hw);
     float* ab = ws;
     float* part = ws + 5 * planes;
-    hipLaunchKernelGGL(gn_plane_stats_kernel<TI>, dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl);
+    if (hw % 4 == 0)
+        hipLaunchKernelGGL((gn_plane_stats_kernel<TI, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl);
+    else
+        hipLaunchKernelGGL((gn_plane_stats_kernel<TI, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl);
     hipLaunchKernelGGL(bn_chan_finish_kernel, dim3(sis_cdiv(C, 64)), dim3(64), 0, st, mean, rstd, ab, rm, rv, part, gamma, beta,
                        batch, C, S, eps, momentum);
     if (hw % 4 == 0)
@@ -299,8 +349,13 @@ void bn_bwd_run(void* dx, float* dgamma, float* dbeta, float* ws, const void* g,
     const int S = gn_slices(hw), sl = gn_slice_len(hw);
     float* coef = ws + 2 * planes;
     float* part = ws + 5 * planes;
-    hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
+    if (hw % 4 == 0) {
+    hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
                        (const TI*)x, mean, rstd, gamma, beta, C, 0, hw, sl, relu);
+    } else {
+    hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
+                       (const TI*)x, mean, rstd, gamma, beta, C, 0, hw, sl, relu);
+    }
     hipLaunchKernelGGL(bn_bwd_chan_kernel, dim3(sis_cdiv(C, 64)), dim3(64), 0, st, coef, dgamma, dbeta, part, rstd, gamma, batch,
                        C, hw, S);
     if (hw % 4 == 0)
