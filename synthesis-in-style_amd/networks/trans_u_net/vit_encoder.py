@@ -44,9 +44,11 @@ class Attention(nn.Module):
         return x.view(b, n, self.num_attention_heads, self.attention_head_size).permute(0, 2, 1, 3)
 
     def forward(self, hidden_states):
-        q = self.transpose_for_scores(self.query(hidden_states))
-        k = self.transpose_for_scores(self.key(hidden_states))
-        v = self.transpose_for_scores(self.value(hidden_states))
+        # one [hidden -> 3 * hidden] GEMM instead of three (the parameters stay separate, as in the reference's
+        # checkpoints): 8192 x 768 x 768 products run the bf16 matrix cores at ~7 % of peak, the fused one is 3x larger
+        qkv = F.linear(hidden_states, torch.cat([self.query.weight, self.key.weight, self.value.weight], 0),
+                       torch.cat([self.query.bias, self.key.bias, self.value.bias], 0))
+        q, k, v = (self.transpose_for_scores(t) for t in qkv.split(self.all_head_size, dim=-1))
         weights = None
         if self.vis or (self.training and self.attn_dropout.p > 0):
             scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(self.attention_head_size)
