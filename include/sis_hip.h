@@ -257,16 +257,18 @@ int sis_weight_std_bwd(float* dw, const void* grad_w_hat, const float* w, const 
  * nn.GroupNorm (+ optional ReLU) of TransUNet's ResNetV2 trunk (vit_seg_modeling_resnet_skip.py:40-75,114-126),
  * x [B][C][hw] in x_dtype (SIS_F32 / SIS_F16 / SIS_BF16), fp32 arithmetic, affine gamma / beta [C] float32.
  * fwd: y (y_dtype = x_dtype or SIS_F32) = relu?((x - mean_g) * rstd_g * gamma_c + beta_c); mean / rstd [B*groups] kept.
- * bwd: dx (x_dtype), dgamma / dbeta [C]; grad_y in g_dtype (= x_dtype or SIS_F32); the ReLU mask is recomputed from x;
+ * residual (float32, may be NULL; needs y_dtype = SIS_F32): y = relu?(norm(x) + residual), the bottleneck's shortcut sum.
+ * bwd: dx (x_dtype), dgamma / dbeta [C]; grad_y in g_dtype (= x_dtype or SIS_F32); the ReLU mask is recomputed from x, or
+ *      taken from y_mask (the saved float32 output) when a residual was added; dresidual (float32, may be NULL) = masked grad;
  *      workspace (both directions): sis_group_norm_workspace_floats(B, C, hw) floats. */
 int64_t sis_group_norm_workspace_floats(int batch, int channels, int hw);
-int sis_group_norm_fwd(void* y, float* mean, float* rstd, float* workspace, const void* x, const float* gamma,
-                       const float* beta, int x_dtype, int y_dtype, int batch, int channels, int hw, int groups, float eps,
-                       int relu, void* stream);
-int sis_group_norm_bwd(void* dx, float* dgamma, float* dbeta, float* workspace, const void* grad_y, const void* x,
-                       const float* mean, const float* rstd, const float* gamma, const float* beta, int x_dtype,
-                       int g_dtype, int batch, int channels, int hw, int groups, int relu, void* stream);
-
+int sis_group_norm_fwd(void* y, float* mean, float* rstd, float* workspace, const void* x, const float* residual,
+                       const float* gamma, const float* beta, int x_dtype, int y_dtype, int batch, int channels, int hw,
+                       int groups, float eps, int relu, void* stream);
+int sis_group_norm_bwd(void* dx, float* dresidual, float* dgamma, float* dbeta, float* workspace, const void* grad_y,
+                       const void* x, const float* y_mask, const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, int x_dtype, int g_dtype, int batch, int channels, int hw, int groups, int relu,
+                       void* stream);
 /* nn.BatchNorm2d in training mode (+ optional ReLU) with 16-bit or fp32 tensors -- the TransUNet decoder's Conv2dReLU
  * blocks (networks/trans_u_net/vit_seg_modeling.py:265-287).  Arguments as for group norm; statistics per channel over
  * (B, hw); mean / rstd [C]; running_mean / running_var (float32 [C], may both be NULL) are updated with `momentum`

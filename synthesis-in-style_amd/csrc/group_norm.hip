@@ -101,7 +101,8 @@ __global__ __launch_bounds__(64) void gn_row_finish_kernel(float* __restrict__ m
 // y = relu?(x * a[plane] + b[plane]); VEC elements per lane (VEC = 4 when hw % 4 == 0: planes stay vector-aligned)
 template <typename TI, typename TO, int VEC>
 __global__ __launch_bounds__(256) void gn_apply_kernel(TO* __restrict__ y, const TI* __restrict__ x,
-                                                       const float* __restrict__ ab, int hw, int64_t total, int relu) {
+                                                       const float* __restrict__ ab, const float* __restrict__ res, int hw,
+                                                       int64_t total, int relu) {
     const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < total; i += stride) {
         const int64_t plane = i / hw;
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(TO* __restrict__ y, const
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             float v = xv[e] * a + b;
+            if (res) v += res[i + e];  // residual sum of a bottleneck (fp32), before the ReLU
             if (relu) v = fmaxf(v, 0.f);
             sis_st(y, i + e, v);
         }
@@ -122,8 +124,8 @@ template <typename TI, typename TG, int VEC>
 __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ part, const TG* __restrict__ g,
                                                            const TI* __restrict__ x, const float* __restrict__ mean_in,
                                                            const float* __restrict__ rstd_in, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, int C, int cpg, int hw, int sl,
-                                                           int relu) {
+                                                           const float* __restrict__ beta, const float* __restrict__ ymask, int C,
+                                                           int cpg, int hw, int sl, int relu) {
     __shared__ float red[4];
     const int64_t plane = blockIdx.x;
     const int c = (int)(plane % C);
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ p
         for (int e = 0; e < VEC; ++e) {
             const float xh = (xv[e] - mean) * rstd;
             float gi = gv[e];
-            if (relu && xh * gm + bt <= 0.f) gi = 0.f;
+            if (relu && (ymask ? ymask[plane * hw + i + e] <= 0.f : xh * gm + bt <= 0.f)) gi = 0.f;
             sg += gi; sgx += gi * xh;
         }
     }
@@ -184,7 +186,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(TI* __restrict__ dx, 
                                                            const TI* __restrict__ x, const float* __restrict__ coef,
                                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           int C, int cpg, int hw, int64_t total, int relu) {
+                                                           const float* __restrict__ ymask, float* __restrict__ dres, int C,
+                                                           int cpg, int hw, int64_t total, int relu) {
     const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < total; i += stride) {
         const int64_t plane = i / hw;
@@ -199,7 +202,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(TI* __restrict__ dx, 
         for (int e = 0; e < VEC; ++e) {
             const float xh = (xv[e] - mean) * rstd;
             float gi = gv[e];
-            if (relu && xh * gm + bt <= 0.f) gi = 0.f;
+            if (relu && (ymask ? ymask[i + e] <= 0.f : xh * gm + bt <= 0.f)) gi = 0.f;
+            if (dres) dres[i + e] = gi;  // gradient of the residual branch = masked incoming gradient
             sis_st(dx, i + e, k1 * gi - k2 - k3 * xh);
         }
     }
@@ -272,8 +276,8 @@ inline unsigned gn_grid(int64_t total, int vec) {
 }
 
 template <typename TI, typename TO>
-void gn_fwd_run(void* y, float* mean, float* rstd, float* ws, const void* x, const float* gamma, const float* beta, int batch,
-                int C, int hw, int groups, float eps, int relu, hipStream_t st) {
+void gn_fwd_run(void* y, float* mean, float* rstd, float* ws, const void* x, const float* res, const float* gamma,
+                const float* beta, int batch, int C, int hw, int groups, float eps, int relu, hipStream_t st) {
     const int cpg = C / groups, rows = batch * groups;
     const int64_t planes = (int64_t)batch * C, total = planes * hw;
     const int S = gn_slices(hw), sl = gn_slice_len(hw);
@@ -286,17 +290,17 @@ void gn_fwd_run(void* y, float* mean, float* rstd, float* ws, const void* x, con
     hipLaunchKernelGGL(gn_row_finish_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, mean, rstd, ab, part, gamma, beta, rows,
                        groups, cpg, S, eps);
     if (hw % 4 == 0)
-        hipLaunchKernelGGL((gn_apply_kernel<TI, TO, 4>), dim3(gn_grid(total, 4)), dim3(256), 0, st, (TO*)y, (const TI*)x, ab, hw,
+        hipLaunchKernelGGL((gn_apply_kernel<TI, TO, 4>), dim3(gn_grid(total, 4)), dim3(256), 0, st, (TO*)y, (const TI*)x, ab, res, hw,
                            total, relu);
     else
-        hipLaunchKernelGGL((gn_apply_kernel<TI, TO, 1>), dim3(gn_grid(total, 1)), dim3(256), 0, st, (TO*)y, (const TI*)x, ab, hw,
+        hipLaunchKernelGGL((gn_apply_kernel<TI, TO, 1>), dim3(gn_grid(total, 1)), dim3(256), 0, st, (TO*)y, (const TI*)x, ab, res, hw,
                            total, relu);
 }
 
 template <typename TI, typename TG>
-void gn_bwd_run(void* dx, float* dgamma, float* dbeta, float* ws, const void* g, const void* x, const float* mean,
-                const float* rstd, const float* gamma, const float* beta, int batch, int C, int hw, int groups, int relu,
-                hipStream_t st) {
+void gn_bwd_run(void* dx, float* dres, float* dgamma, float* dbeta, float* ws, const void* g, const void* x,
+                const float* ymask, const float* mean, const float* rstd, const float* gamma, const float* beta, int batch, int C,
+                int hw, int groups, int relu, hipStream_t st) {
     const int cpg = C / groups, rows = batch * groups;
     const int64_t planes = (int64_t)batch * C, total = planes * hw;
     const int S = gn_slices(hw), sl = gn_slice_len(hw);
@@ -305,25 +309,26 @@ void gn_bwd_run(void* dx, float* dgamma, float* dbeta, float* ws, const void* g,
     float* part = ws + 5 * planes; // [planes][S][2]
     if (hw % 4 == 0) {
     hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
-                       (const TI*)x, mean, rstd, gamma, beta, C, cpg, hw, sl, relu);
+                       (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu);
     } else {
     hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
-                       (const TI*)x, mean, rstd, gamma, beta, C, cpg, hw, sl, relu);
+                       (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu);
     }
     hipLaunchKernelGGL(gn_bwd_row_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, coef, psum, part, rstd, gamma, rows, groups,
                        cpg, hw, S);
     if (hw % 4 == 0)
         hipLaunchKernelGGL((gn_bwd_apply_kernel<TI, TG, 4>), dim3(gn_grid(total, 4)), dim3(256), 0, st, (TI*)dx, (const TG*)g,
-                           (const TI*)x, coef, mean, rstd, gamma, beta, C, cpg, hw, total, relu);
+                           (const TI*)x, coef, mean, rstd, gamma, beta, ymask, dres, C, cpg, hw, total, relu);
     else
         hipLaunchKernelGGL((gn_bwd_apply_kernel<TI, TG, 1>), dim3(gn_grid(total, 1)), dim3(256), 0, st, (TI*)dx, (const TG*)g,
-                           (const TI*)x, coef, mean, rstd, gamma, beta, C, cpg, hw, total, relu);
+                           (const TI*)x, coef, mean, rstd, gamma, beta, ymask, dres, C, cpg, hw, total, relu);
     hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(sis_cdiv(C, 256)), dim3(256), 0, st, dgamma, dbeta, psum, batch, C);
 }
 
 template <typename TI, typename TO>
 void bn_fwd_run(void* y, float* mean, float* rstd, float* rm, float* rv, float* ws, const void* x, const float* gamma,
                 const float* beta, int batch, int C, int hw, float eps, float momentum, int relu, hipStream_t st) {
+    const float* res = nullptr;
     const int64_t planes = (int64_t)batch * C, total = planes * hw;
     const int S = gn_slices(hw), sl = gn_slice_len(hw);
     float* ab = ws;
@@ -335,10 +340,10 @@ void bn_fwd_run(void* y, float* mean, float* rstd, float* rm, float* rv, float* 
     hipLaunchKernelGGL(bn_chan_finish_kernel, dim3(sis_cdiv(C, 64)), dim3(64), 0, st, mean, rstd, ab, rm, rv, part, gamma, beta,
                        batch, C, S, eps, momentum);
     if (hw % 4 == 0)
-        hipLaunchKernelGGL((gn_apply_kernel<TI, TO, 4>), dim3(gn_grid(total, 4)), dim3(256), 0, st, (TO*)y, (const TI*)x, ab, hw,
+        hipLaunchKernelGGL((gn_apply_kernel<TI, TO, 4>), dim3(gn_grid(total, 4)), dim3(256), 0, st, (TO*)y, (const TI*)x, ab, res, hw,
                            total, relu);
     else
-        hipLaunchKernelGGL((gn_apply_kernel<TI, TO, 1>), dim3(gn_grid(total, 1)), dim3(256), 0, st, (TO*)y, (const TI*)x, ab, hw,
+        hipLaunchKernelGGL((gn_apply_kernel<TI, TO, 1>), dim3(gn_grid(total, 1)), dim3(256), 0, st, (TO*)y, (const TI*)x, ab, res, hw,
                            total, relu);
 }
 
@@ -351,19 +356,19 @@ void bn_bwd_run(void* dx, float* dgamma, float* dbeta, float* ws, const void* g,
     float* part = ws + 5 * planes;
     if (hw % 4 == 0) {
     hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
-                       (const TI*)x, mean, rstd, gamma, beta, C, 0, hw, sl, relu);
+                       (const TI*)x, mean, rstd, gamma, beta, nullptr, C, 0, hw, sl, relu);
     } else {
     hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
-                       (const TI*)x, mean, rstd, gamma, beta, C, 0, hw, sl, relu);
+                       (const TI*)x, mean, rstd, gamma, beta, nullptr, C, 0, hw, sl, relu);
     }
     hipLaunchKernelGGL(bn_bwd_chan_kernel, dim3(sis_cdiv(C, 64)), dim3(64), 0, st, coef, dgamma, dbeta, part, rstd, gamma, batch,
                        C, hw, S);
     if (hw % 4 == 0)
         hipLaunchKernelGGL((gn_bwd_apply_kernel<TI, TG, 4>), dim3(gn_grid(total, 4)), dim3(256), 0, st, (TI*)dx, (const TG*)g,
-                           (const TI*)x, coef, mean, rstd, gamma, beta, C, 0, hw, total, relu);
+                           (const TI*)x, coef, mean, rstd, gamma, beta, nullptr, nullptr, C, 0, hw, total, relu);
     else
         hipLaunchKernelGGL((gn_bwd_apply_kernel<TI, TG, 1>), dim3(gn_grid(total, 1)), dim3(256), 0, st, (TI*)dx, (const TG*)g,
-                           (const TI*)x, coef, mean, rstd, gamma, beta, C, 0, hw, total, relu);
+                           (const TI*)x, coef, mean, rstd, gamma, beta, nullptr, nullptr, C, 0, hw, total, relu);
 }
 
 }  // namespace
@@ -372,18 +377,19 @@ extern "C" int64_t sis_group_norm_workspace_floats(int batch, int channels, int 
     return (int64_t)batch * channels * (5 + 3 * gn_slices(hw));
 }
 
-extern "C" int sis_group_norm_fwd(void* y, float* mean, float* rstd, float* workspace, const void* x, const float* gamma,
-                                  const float* beta, int x_dtype, int y_dtype, int batch, int channels, int hw, int groups,
-                                  float eps, int relu, void* stream) {
+extern "C" int sis_group_norm_fwd(void* y, float* mean, float* rstd, float* workspace, const void* x, const float* residual,
+                                  const float* gamma, const float* beta, int x_dtype, int y_dtype, int batch, int channels,
+                                  int hw, int groups, float eps, int relu, void* stream) {
     if (batch == 0) return 0;
     SIS_REQUIRE(y && mean && rstd && workspace && x && gamma && beta, "sis_group_norm_fwd: null pointer");
     SIS_REQUIRE(batch > 0 && channels > 0 && hw > 0 && groups > 0 && channels % groups == 0,
                 "sis_group_norm_fwd: bad sizes (C %d, groups %d)", channels, groups);
     SIS_REQUIRE(y_dtype == x_dtype || y_dtype == SIS_F32, "sis_group_norm_fwd: output dtype must be the input's or f32");
+    SIS_REQUIRE(!residual || y_dtype == SIS_F32, "sis_group_norm_fwd: a residual needs a float32 output");
     hipStream_t st = (hipStream_t)stream;
 #define GN_FWD(TI)                                                                                                       \
-    if (y_dtype == SIS_F32) gn_fwd_run<TI, float>(y, mean, rstd, workspace, x, gamma, beta, batch, channels, hw, groups, eps, relu, st); \
-    else gn_fwd_run<TI, TI>(y, mean, rstd, workspace, x, gamma, beta, batch, channels, hw, groups, eps, relu, st);
+    if (y_dtype == SIS_F32) gn_fwd_run<TI, float>(y, mean, rstd, workspace, x, residual, gamma, beta, batch, channels, hw, groups, eps, relu, st); \
+    else gn_fwd_run<TI, TI>(y, mean, rstd, workspace, x, nullptr, gamma, beta, batch, channels, hw, groups, eps, relu, st);
     switch (x_dtype) {
         case SIS_F32: GN_FWD(float) break;
         case SIS_F16: GN_FWD(__half) break;
@@ -395,9 +401,10 @@ extern "C" int sis_group_norm_fwd(void* y, float* mean, float* rstd, float* work
     return 0;
 }
 
-extern "C" int sis_group_norm_bwd(void* dx, float* dgamma, float* dbeta, float* workspace, const void* grad_y, const void* x,
-                                  const float* mean, const float* rstd, const float* gamma, const float* beta, int x_dtype,
-                                  int g_dtype, int batch, int channels, int hw, int groups, int relu, void* stream) {
+extern "C" int sis_group_norm_bwd(void* dx, float* dresidual, float* dgamma, float* dbeta, float* workspace, const void* grad_y,
+                                  const void* x, const float* y_mask, const float* mean, const float* rstd, const float* gamma,
+                                  const float* beta, int x_dtype, int g_dtype, int batch, int channels, int hw, int groups,
+                                  int relu, void* stream) {
     if (batch == 0) return 0;
     SIS_REQUIRE(dx && dgamma && dbeta && workspace && grad_y && x && mean && rstd && gamma && beta,
                 "sis_group_norm_bwd: null pointer");
@@ -406,8 +413,8 @@ extern "C" int sis_group_norm_bwd(void* dx, float* dgamma, float* dbeta, float* 
     SIS_REQUIRE(g_dtype == x_dtype || g_dtype == SIS_F32, "sis_group_norm_bwd: gradient dtype must be the input's or f32");
     hipStream_t st = (hipStream_t)stream;
 #define GN_BWD(TI)                                                                                                        \
-    if (g_dtype == SIS_F32) gn_bwd_run<TI, float>(dx, dgamma, dbeta, workspace, grad_y, x, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, st); \
-    else gn_bwd_run<TI, TI>(dx, dgamma, dbeta, workspace, grad_y, x, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, st);
+    if (g_dtype == SIS_F32) gn_bwd_run<TI, float>(dx, dresidual, dgamma, dbeta, workspace, grad_y, x, y_mask, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, st); \
+    else gn_bwd_run<TI, TI>(dx, dresidual, dgamma, dbeta, workspace, grad_y, x, y_mask, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, st);
     switch (x_dtype) {
         case SIS_F32: GN_BWD(float) break;
         case SIS_F16: GN_BWD(__half) break;

@@ -12,6 +12,7 @@ ResNetV2 :114-162), same parameter names and arithmetic:
 * skip features for the decoder = root output and the outputs of stages 1 and 2, zero-padded on the bottom / right up
   to S/2, S/4, S/8 when the un-padded pooling left them 1-2 pixels short; returned deepest first.
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -44,19 +45,27 @@ class _WeightStandardize(Function):
         return sis_hip.weight_std_bwd(grad, weight, invstd, ctx.eps), None, None
 
 
+_FUSE_RESIDUAL = os.environ.get('SIS_GN_RES', '1') != '0'
+
+
 class _GroupNormAct(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, eps, relu, out_dtype):
-        y, mean, rstd = sis_hip.group_norm_fwd(x, weight, bias, groups, eps, relu, out_dtype)
-        ctx.save_for_backward(x, mean, rstd, weight, bias)
+    def forward(ctx, x, residual, weight, bias, groups, eps, relu, out_dtype):
+        y, mean, rstd = sis_hip.group_norm_fwd(x, weight, bias, groups, eps, relu, out_dtype, residual)
+        ctx.has_residual = residual is not None
+        ctx.save_for_backward(x, mean, rstd, weight, bias, y if ctx.has_residual else None)
         ctx.groups, ctx.relu = groups, relu
         return y
 
     @staticmethod
     def backward(ctx, grad):
-        x, mean, rstd, weight, bias = ctx.saved_tensors
-        dx, dgamma, dbeta = sis_hip.group_norm_bwd(grad, x, mean, rstd, weight, bias, ctx.groups, ctx.relu)
-        return dx, dgamma, dbeta, None, None, None, None
+        x, mean, rstd, weight, bias, y = ctx.saved_tensors
+        if ctx.has_residual:
+            dx, dgamma, dbeta, dres = sis_hip.group_norm_bwd(grad, x, mean, rstd, weight, bias, ctx.groups, ctx.relu, y_mask=y,
+                                                             want_residual_grad=True)
+        else:
+            (dx, dgamma, dbeta), dres = sis_hip.group_norm_bwd(grad, x, mean, rstd, weight, bias, ctx.groups, ctx.relu), None
+        return dx, dres, dgamma, dbeta, None, None, None, None
 
 
 class HipGroupNorm(nn.GroupNorm):
@@ -65,11 +74,15 @@ class HipGroupNorm(nn.GroupNorm):
     cast -> moments -> normalise -> relu -> cast).  ``keep_fp32=True`` returns float32 (the residual sum of a bottleneck
     stays in fp32, as autocast would have it)."""
 
-    def forward(self, x, relu=False, keep_fp32=False):
-        if x.is_cuda and self.affine and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and x.dim() >= 3:
-            out_dtype = torch.float32 if keep_fp32 else x.dtype
-            return _GroupNormAct.apply(x, self.weight, self.bias, self.num_groups, self.eps, relu, out_dtype)
+    def forward(self, x, relu=False, keep_fp32=False, residual=None):
+        """``residual`` (float32): y = relu?(norm(x) + residual) in one pass -- the tail of a bottleneck."""
+        if x.is_cuda and self.affine and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and x.dim() >= 3 \
+                and (residual is None or (residual.dtype == torch.float32 and residual.shape == x.shape)):
+            out_dtype = torch.float32 if (keep_fp32 or residual is not None) else x.dtype
+            return _GroupNormAct.apply(x, residual, self.weight, self.bias, self.num_groups, self.eps, relu, out_dtype)
         y = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
+        if residual is not None:
+            y = y + residual
         return F.relu(y) if relu else y
 
 
@@ -116,9 +129,11 @@ class PreActBottleneck(nn.Module):
     def forward(self, x):
         shortcut = self.gn_proj(self.downsample(x), keep_fp32=True) if hasattr(self, 'downsample') else x
         y = x
-        for i in (1, 2, 3):  # GroupNorm and the ReLU after the first two in one kernel; the residual sum stays fp32
-            y = getattr(self, f'gn{i}')(getattr(self, f'conv{i}')(y), relu=i < 3, keep_fp32=i == 3)
-        return self.relu(shortcut + y)
+        y = self.gn1(self.conv1(y), relu=True)   # GroupNorm and the ReLU after it in one kernel
+        y = self.gn2(self.conv2(y), relu=True)
+        if shortcut.dtype == torch.float32 and _FUSE_RESIDUAL:  # relu(shortcut + gn3(conv3(y))) in one kernel, fp32 residual stream
+            return self.gn3(self.conv3(y), relu=True, residual=shortcut.contiguous())
+        return self.relu(shortcut + self.gn3(self.conv3(y), keep_fp32=True))
 
     def load_from(self, weights, n_block, n_unit):
         from .npz_import import load_bottleneck

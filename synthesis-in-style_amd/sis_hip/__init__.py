@@ -45,11 +45,11 @@ _SIGNATURES = {
     "sis_conv3x3_eligible": ([_i] * 5, _i),
     "sis_upsample_bilinear": ([_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp], _i),
     "sis_weight_std_fwd": ([_vp, _vp, _vp, _i, _i, _i, _f, _vp], _i),
-    "sis_group_norm_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
+    "sis_group_norm_fwd": ([_vp] * 8 + [_i, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
     "sis_group_norm_workspace_floats": ([_i, _i, _i], _i64),
     "sis_batch_norm_fwd": ([_vp] * 9 + [_i] * 5 + [_f, _f, _i, _vp], _i),
     "sis_batch_norm_bwd": ([_vp] * 10 + [_i] * 6 + [_vp], _i),
-    "sis_group_norm_bwd": ([_vp] * 10 + [_i] * 7 + [_vp], _i),
+    "sis_group_norm_bwd": ([_vp] * 12 + [_i] * 7 + [_vp], _i),
     "sis_weight_std_bwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp], _i),
     "sis_conv3x3_wgrad_eligible": ([_i] * 5 + [_i64], _i),
     "sis_conv3x3_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
@@ -570,10 +570,16 @@ def make_image_u8(x):
 # ------------------------------------------------------------------------------ group norm (+ ReLU)
 
 
-def group_norm_fwd(x, gamma, beta, groups, eps, relu, out_dtype=None):
-    """x [B,C,...] (f32 / f16 / bf16) -> (y in ``out_dtype`` (default: x's), mean [B*groups], rstd [B*groups])."""
+def group_norm_fwd(x, gamma, beta, groups, eps, relu, out_dtype=None, residual=None):
+    """x [B,C,...] (f32 / f16 / bf16) -> (y in ``out_dtype`` (default: x's), mean [B*groups], rstd [B*groups]).
+    ``residual`` (float32, x's shape) is added before the ReLU; the output is then float32."""
     require_device(x, "input")
     x = x.contiguous()
+    if residual is not None:
+        out_dtype = torch.float32
+        residual = _f32(residual, "residual")
+        if residual.shape != x.shape:
+            raise RuntimeError("residual must have the input's shape")
     out_dtype = out_dtype or x.dtype
     b, c = x.shape[0], x.shape[1]
     hw = x[0, 0].numel()
@@ -582,13 +588,16 @@ def group_norm_fwd(x, gamma, beta, groups, eps, relu, out_dtype=None):
     rstd = torch.empty_like(mean)
     ws = torch.empty(lib().sis_group_norm_workspace_floats(b, c, hw), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(lib().sis_group_norm_fwd(_ptr(y), _ptr(mean), _ptr(rstd), _ptr(ws), _ptr(x), _ptr(_f32(gamma, "weight")),
-                                        _ptr(_f32(beta, "bias")), _DTYPE_CODE[x.dtype], _DTYPE_CODE[out_dtype], b, c, hw,
-                                        groups, float(eps), int(bool(relu)), _stream()), "sis_group_norm_fwd")
+        _check(lib().sis_group_norm_fwd(_ptr(y), _ptr(mean), _ptr(rstd), _ptr(ws), _ptr(x), _ptr(residual),
+                                        _ptr(_f32(gamma, "weight")), _ptr(_f32(beta, "bias")), _DTYPE_CODE[x.dtype],
+                                        _DTYPE_CODE[out_dtype], b, c, hw, groups, float(eps), int(bool(relu)), _stream()),
+               "sis_group_norm_fwd")
     return y, mean, rstd
 
 
-def group_norm_bwd(grad_y, x, mean, rstd, gamma, beta, groups, relu):
+def group_norm_bwd(grad_y, x, mean, rstd, gamma, beta, groups, relu, y_mask=None, want_residual_grad=False):
+    """-> (dx, dgamma, dbeta[, dresidual]).  ``y_mask``: the saved float32 output when a residual was added (its sign is
+    the ReLU mask); ``want_residual_grad`` also returns the gradient of the residual branch."""
     x = x.contiguous()
     g = grad_y.contiguous()
     if g.dtype != x.dtype and g.dtype != torch.float32:
@@ -596,14 +605,15 @@ def group_norm_bwd(grad_y, x, mean, rstd, gamma, beta, groups, relu):
     b, c = x.shape[0], x.shape[1]
     hw = x[0, 0].numel()
     dx = torch.empty_like(x)
+    dres = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_residual_grad else None
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
     dbeta = torch.empty_like(dgamma)
     ws = torch.empty(lib().sis_group_norm_workspace_floats(b, c, hw), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(lib().sis_group_norm_bwd(_ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _ptr(g), _ptr(x), _ptr(mean), _ptr(rstd),
-                                        _ptr(gamma), _ptr(beta), _DTYPE_CODE[x.dtype], _DTYPE_CODE[g.dtype], b, c, hw, groups,
-                                        int(bool(relu)), _stream()), "sis_group_norm_bwd")
-    return dx, dgamma, dbeta
+        _check(lib().sis_group_norm_bwd(_ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _ptr(g), _ptr(x), _ptr(y_mask),
+                                        _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _DTYPE_CODE[x.dtype], _DTYPE_CODE[g.dtype],
+                                        b, c, hw, groups, int(bool(relu)), _stream()), "sis_group_norm_bwd")
+    return (dx, dgamma, dbeta, dres) if want_residual_grad else (dx, dgamma, dbeta)
 
 
 def batch_norm_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, relu, out_dtype=None):

@@ -133,3 +133,28 @@ def test_batch_norm_train_relu(device, shape, relu):
     yb, _, _ = sis_hip.batch_norm_train_fwd(x.bfloat16(), gamma, beta, None, None, 1e-5, 0.1, relu)
     assert yb.dtype == torch.bfloat16
     np.testing.assert_allclose(yb.float().cpu().numpy(), ref.detach().float().cpu().numpy(), rtol=3e-2, atol=3e-2)
+
+
+def test_group_norm_residual_relu(device):
+    """y = relu(group_norm(x) + residual) in one pass (bottleneck tail), bf16 x, fp32 residual / output / gradients."""
+    import sis_hip
+    g = torch.Generator().manual_seed(9)
+    shape, groups = (2, 64, 12, 12), 32
+    x = (torch.randn(*shape, generator=g) * 2).to(device).bfloat16()
+    res = torch.randn(*shape, generator=g).to(device)
+    gamma = (1 + 0.2 * torch.randn(64, generator=g)).to(device)
+    beta = (0.3 * torch.randn(64, generator=g)).to(device)
+    gy = torch.randn(*shape, generator=g).to(device)
+    xr, rr = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = F.relu(F.group_norm(xr, groups, gr, br, 1e-6) + rr)
+    ref.backward(gy.double())
+    y, mean, rstd = sis_hip.group_norm_fwd(x, gamma, beta, groups, 1e-6, True, residual=res)
+    assert y.dtype == torch.float32
+    np.testing.assert_allclose(y.cpu().numpy(), ref.detach().float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    dx, dg, db, dres = sis_hip.group_norm_bwd(gy, x, mean, rstd, gamma, beta, groups, True, y_mask=y, want_residual_grad=True)
+    np.testing.assert_allclose(dres.cpu().numpy(), rr.grad.float().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    scale = float(xr.grad.abs().max())
+    np.testing.assert_allclose(dx.float().cpu().numpy(), xr.grad.float().cpu().numpy(), rtol=2e-2, atol=1e-2 * scale)
+    np.testing.assert_allclose(dg.cpu().numpy(), gr.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), br.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-3)
