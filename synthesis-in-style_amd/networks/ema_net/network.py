@@ -99,11 +99,11 @@ class Bottleneck(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, previous_dilation=1):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.conv1 = HipConv2d(inplanes, planes, 1, bias=False)
         self.bn1 = norm_layer(planes)
         self.conv2 = HipConv2d(planes, planes, 3, stride, dilation, dilation, bias=False)
         self.bn2 = norm_layer(planes)
-        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
+        self.conv3 = HipConv2d(planes, planes * self.expansion, 1, bias=False)
         self.bn3 = norm_layer(planes * self.expansion)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
@@ -151,7 +151,7 @@ class ResNet(nn.Module):
         out_planes = planes * block.expansion
         downsample = None
         if stride != 1 or self.inplanes != out_planes:
-            downsample = nn.Sequential(nn.Conv2d(self.inplanes, out_planes, 1, stride, bias=False),
+            downsample = nn.Sequential(HipConv2d(self.inplanes, out_planes, 1, stride, bias=False),
                                        norm_layer(out_planes))
         first_dilation = 2 if dilation == 4 else 1
         units = [block(self.inplanes, planes, stride, dilation=first_dilation, downsample=downsample,
@@ -206,8 +206,8 @@ class EMAU(nn.Module):
         self.stage_num = stage_num
         mu = torch.empty(1, c, k).normal_(0, math.sqrt(2. / k))
         self.register_buffer('mu', self._l2norm(mu, dim=1))
-        self.conv1 = nn.Conv2d(c, c, 1)
-        self.conv2 = nn.Sequential(nn.Conv2d(c, c, 1, bias=False), norm_layer(c))
+        self.conv1 = HipConv2d(c, c, 1)
+        self.conv2 = nn.Sequential(HipConv2d(c, c, 1, bias=False), norm_layer(c))
         _init_weights(self)
 
     def forward(self, x):
@@ -271,7 +271,7 @@ class EMANet(BaseSegmenter):
         self.fc0 = ConvBNReLU(2048, 512, 3, 1, 1, 1)
         self.emau = EMAU(512, 64, stage_num)
         self.fc1 = nn.Sequential(ConvBNReLU(512, 256, 3, 1, 1, 1), nn.Dropout2d(p=0.1))
-        self.fc2 = nn.Conv2d(256, num_classes, 1)
+        self.fc2 = HipConv2d(256, num_classes, 1)
         self.crit = CrossEntropyLoss2d(ignore_index=ignore_label, reduction='none')
         self.ignore_label = ignore_label
 

@@ -98,3 +98,26 @@ def test_half_image_dilation_is_the_dilated_convolution(device):
         b = b.detach().float()
         assert (a - b).abs().max().item() < 1e-5 * b.abs().max().item()
     assert not conv._half_image_dilation(torch.zeros(1, 16, 64, 64, device=device))
+
+
+def test_pointwise_convolution_is_a_batched_gemm(device):
+    from networks.hip_conv import HipConv2d
+    g = torch.Generator().manual_seed(5)
+    for cin, cout, bias in ((64, 256, False), (256, 3, True)):
+        conv = HipConv2d(cin, cout, 1, bias=bias).to(device)
+        x = torch.randn(3, cin, 16, 12, generator=g).to(device).requires_grad_(True)
+        gy = torch.randn(3, cout, 16, 12, generator=g).to(device)
+        assert conv._pointwise(x)
+        y = conv(x)
+        y.backward(gy)
+        got = [y.detach(), x.grad.clone(), conv.weight.grad.clone()] + ([conv.bias.grad.clone()] if bias else [])
+        x.grad = conv.weight.grad = None
+        if bias:
+            conv.bias.grad = None
+        ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double() if bias else None)
+        ref.backward(gy.double())
+        want = [ref, x.grad, conv.weight.grad] + ([conv.bias.grad] if bias else [])
+        for a, b in zip(got, want):
+            b = b.detach().float()
+            assert (a - b).abs().max().item() < 2e-5 * b.abs().max().item()
+    assert not HipConv2d(8, 8, 1, stride=2)._pointwise(torch.zeros(1, 8, 4, 4, device=device))
