@@ -21,6 +21,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 import sis_hip
+from networks.hip_conv import _Pointwise
 
 
 def np2th(weights, conv=False):
@@ -99,7 +100,11 @@ class StdConv2d(nn.Conv2d):
         return (w - mean) / torch.sqrt(var + self.EPS)
 
     def forward(self, x):
-        return F.conv2d(x, self.standardized_weight(), self.bias, self.stride, self.padding, self.dilation, self.groups)
+        w = self.standardized_weight()
+        if (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.groups == 1
+                and x.is_cuda and x.dim() == 4 and x.is_contiguous() and x.dtype == w.dtype):
+            return _Pointwise.apply(x, w, self.bias)  # weight gradient as a batched GEMM on the NCHW tensors
+        return F.conv2d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
 
 def conv3x3(cin, cout, stride=1, groups=1, bias=False):
