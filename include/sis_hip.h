@@ -281,6 +281,18 @@ int sis_batch_norm_bwd(void* dx, float* dgamma, float* dbeta, float* workspace, 
                        int g_dtype, int batch, int channels, int hw, int relu, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * nn.LayerNorm over the last dimension (TransUNet encoder, networks/trans_u_net/vit_seg_modeling.py:171-190,233-250),
+ * x [rows][n], n in {256, 512, 768, 1024}, x / y / grad dtypes SIS_F32 or SIS_BF16 (fp32 arithmetic), gamma / beta [n].
+ * fwd: y = (x - mean_row) * rstd_row * gamma + beta; mean / rstd [rows] kept.
+ * bwd: dx (x's dtype), dgamma / dbeta [n]; workspace: sis_layer_norm_workspace_floats(n) floats. */
+int sis_layer_norm_workspace_floats(int n);
+int sis_layer_norm_fwd(void* y, float* mean, float* rstd, const void* x, const float* gamma, const float* beta, int x_dtype,
+                       int y_dtype, int rows, int n, float eps, void* stream);
+int sis_layer_norm_bwd(void* dx, float* dgamma, float* dbeta, float* workspace, const void* grad_y, const void* x,
+                       const float* mean, const float* rstd, const float* gamma, int x_dtype, int g_dtype, int rows, int n,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * nn.UpsamplingBilinear2d (align_corners=True) of the TransUNet decoder
  * (networks/trans_u_net/vit_seg_modeling.py:290-329), forward and backward, f32 / f16 / bf16 (dtype = SIS_*).
  * backward = 0: out [planes][out_h][out_w] from x [planes][h][w].

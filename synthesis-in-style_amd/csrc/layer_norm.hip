@@ -1,0 +1,213 @@
+// LayerNorm of the TransUNet encoder (networks/trans_u_net/vit_seg_modeling.py:171-190,233-250: two per block, one
+// final), forward and backward, rows of n = hidden elements, n % 256 == 0 (ViT-B: 768).
+// One wave per row: lane l holds elements [4 (l + 64 j), +4) for j < n / 256 in registers (one 16/8-byte load each),
+// so the two-pass mean / variance and the normalisation never re-read memory.  The output can be written in a 16-bit
+// type (what the following Linear consumes under autocast: no separate cast kernel).
+// Backward: dx per row as usual; d(gamma) / d(beta) are column sums over all rows -- every workgroup walks a strip
+// of rows, keeps its column sums in registers, writes one partial row per workgroup; ln_param_reduce adds the partials
+// in fixed order (deterministic, no atomics).
+#include "sis_common.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ void ln_load4(const T* p, float* v) {
+    if constexpr (sizeof(T) == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+        const uint2 q = *reinterpret_cast<const uint2*>(p);
+        T t[4];
+        __builtin_memcpy(t, &q, 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = sis_ld(t, e);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void ln_store4(T* p, const float* v) {
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        T t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sis_st(t, e, v[e]);
+        uint2 q;
+        __builtin_memcpy(&q, t, 8);
+        *reinterpret_cast<uint2*>(p) = q;
+    }
+}
+__device__ __forceinline__ float ln_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename TI, typename TO, int NJ>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(TO* __restrict__ y, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, const TI* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     int rows, float eps) {
+    constexpr int N = NJ * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const TI* xr = x + (int64_t)row * N;
+    float v[NJ][4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        ln_load4(xr + 4 * (lane + 64 * j), v[j]);
+        s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    }
+    const float mean = ln_wave_sum(s) / (float)N;
+    float m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; m2 += d * d; }
+    const float rstd = rsqrtf(ln_wave_sum(m2) / (float)N + eps);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    TO* yr = y + (int64_t)row * N;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = 4 * (lane + 64 * j);
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+        float o[4] = {(v[j][0] - mean) * rstd * g.x + b.x, (v[j][1] - mean) * rstd * g.y + b.y,
+                      (v[j][2] - mean) * rstd * g.z + b.z, (v[j][3] - mean) * rstd * g.w + b.w};
+        ln_store4(yr + c, o);
+    }
+}
+
+template <typename TI, typename TG, int NJ>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(TI* __restrict__ dx, float* __restrict__ part, const TG* __restrict__ g,
+                                                     const TI* __restrict__ x, const float* __restrict__ mean_in,
+                                                     const float* __restrict__ rstd_in, const float* __restrict__ gamma,
+                                                     int rows) {
+    constexpr int N = NJ * 256;
+    __shared__ float red[2][4][N];  // per-wave column sums, merged by wave 0 at the end
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dg[NJ][4], db[NJ][4], gm[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const float4 q = *reinterpret_cast<const float4*>(gamma + 4 * (lane + 64 * j));
+        gm[j][0] = q.x; gm[j][1] = q.y; gm[j][2] = q.z; gm[j][3] = q.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dg[j][e] = 0.f; db[j][e] = 0.f; }
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const TI* xr = x + (int64_t)row * N;
+        const TG* gr = g + (int64_t)row * N;
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float xh[NJ][4], gv[NJ][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            ln_load4(xr + 4 * (lane + 64 * j), xh[j]);
+            ln_load4(gr + 4 * (lane + 64 * j), gv[j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[j][e] = (xh[j][e] - mean) * rstd;
+                dg[j][e] += gv[j][e] * xh[j][e];
+                db[j][e] += gv[j][e];
+                gv[j][e] *= gm[j][e];
+                s1 += gv[j][e]; s2 += gv[j][e] * xh[j][e];
+            }
+        }
+        const float m1 = ln_wave_sum(s1) / (float)N, m2 = ln_wave_sum(s2) / (float)N;
+        TI* dr = dx + (int64_t)row * N;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rstd * (gv[j][e] - m1 - xh[j][e] * m2);
+            ln_store4(dr + 4 * (lane + 64 * j), o);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[0][wave][4 * (lane + 64 * j) + e] = dg[j][e];
+            red[1][wave][4 * (lane + 64 * j) + e] = db[j][e];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < N; c += 256) {
+        part[((int64_t)blockIdx.x * 2) * N + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        part[((int64_t)blockIdx.x * 2 + 1) * N + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    }
+}
+
+// 64 columns per workgroup; wave w adds the partials k = w, w + 4, ... (fixed order), then the four are combined
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              const float* __restrict__ part, int n_part, int n) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float a = 0.f, b = 0.f;
+    if (c < n)
+        for (int k = wave; k < n_part; k += 4) { a += part[((int64_t)k * 2) * n + c]; b += part[((int64_t)k * 2 + 1) * n + c]; }
+    red[0][wave][lane] = a; red[1][wave][lane] = b;
+    __syncthreads();
+    if (wave == 0 && c < n) {
+        dgamma[c] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+        dbeta[c] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    }
+}
+
+constexpr int LN_BWD_BLOCKS = 128;  // workgroups of the backward pass = partial rows to add afterwards
+
+}  // namespace
+
+extern "C" int sis_layer_norm_workspace_floats(int n) { return 2 * LN_BWD_BLOCKS * n; }
+
+#define LN_SWITCH_NJ(NJV, CALL)                  \
+    switch (NJV) {                               \
+        case 1: { constexpr int NJ = 1; CALL; } break; \
+        case 2: { constexpr int NJ = 2; CALL; } break; \
+        case 3: { constexpr int NJ = 3; CALL; } break; \
+        case 4: { constexpr int NJ = 4; CALL; } break; \
+        default: return sis_fail("layer norm: row length %d not supported (256, 512, 768 or 1024)", (NJV) * 256); \
+    }
+
+extern "C" int sis_layer_norm_fwd(void* y, float* mean, float* rstd, const void* x, const float* gamma, const float* beta,
+                                  int x_dtype, int y_dtype, int rows, int n, float eps, void* stream) {
+    if (rows == 0) return 0;
+    SIS_REQUIRE(y && mean && rstd && x && gamma && beta, "sis_layer_norm_fwd: null pointer");
+    SIS_REQUIRE(rows > 0 && n > 0 && n % 256 == 0, "sis_layer_norm_fwd: row length %d must be a multiple of 256", n);
+    SIS_REQUIRE((x_dtype == SIS_F32 || x_dtype == SIS_BF16) && (y_dtype == SIS_F32 || y_dtype == SIS_BF16),
+                "sis_layer_norm_fwd: dtypes must be f32 or bf16");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(sis_cdiv(rows, 4));
+#define LN_FWD(TI, TO) hipLaunchKernelGGL((ln_fwd_kernel<TI, TO, NJ>), grid, dim3(256), 0, st, (TO*)y, mean, rstd, (const TI*)x, gamma, beta, rows, eps)
+    if (x_dtype == SIS_F32 && y_dtype == SIS_F32) { LN_SWITCH_NJ(n / 256, LN_FWD(float, float)) }
+    else if (x_dtype == SIS_F32) { LN_SWITCH_NJ(n / 256, LN_FWD(float, __hip_bfloat16)) }
+    else if (y_dtype == SIS_F32) { LN_SWITCH_NJ(n / 256, LN_FWD(__hip_bfloat16, float)) }
+    else { LN_SWITCH_NJ(n / 256, LN_FWD(__hip_bfloat16, __hip_bfloat16)) }
+#undef LN_FWD
+    SIS_CHECK_LAUNCH("ln_fwd_kernel");
+    return 0;
+}
+
+extern "C" int sis_layer_norm_bwd(void* dx, float* dgamma, float* dbeta, float* workspace, const void* grad_y, const void* x,
+                                  const float* mean, const float* rstd, const float* gamma, int x_dtype, int g_dtype, int rows,
+                                  int n, void* stream) {
+    if (rows == 0) return 0;
+    SIS_REQUIRE(dx && dgamma && dbeta && workspace && grad_y && x && mean && rstd && gamma, "sis_layer_norm_bwd: null pointer");
+    SIS_REQUIRE(rows > 0 && n > 0 && n % 256 == 0, "sis_layer_norm_bwd: row length %d must be a multiple of 256", n);
+    SIS_REQUIRE((x_dtype == SIS_F32 || x_dtype == SIS_BF16) && (g_dtype == SIS_F32 || g_dtype == SIS_BF16),
+                "sis_layer_norm_bwd: dtypes must be f32 or bf16");
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = sis_cdiv(rows, 4);
+    if (blocks > LN_BWD_BLOCKS) blocks = LN_BWD_BLOCKS;
+    const dim3 grid(blocks);
+#define LN_BWD(TI, TG) hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, NJ>), grid, dim3(256), 0, st, (TI*)dx, workspace, (const TG*)grad_y, (const TI*)x, mean, rstd, gamma, rows)
+    if (x_dtype == SIS_F32 && g_dtype == SIS_F32) { LN_SWITCH_NJ(n / 256, LN_BWD(float, float)) }
+    else if (x_dtype == SIS_F32) { LN_SWITCH_NJ(n / 256, LN_BWD(float, __hip_bfloat16)) }
+    else if (g_dtype == SIS_F32) { LN_SWITCH_NJ(n / 256, LN_BWD(__hip_bfloat16, float)) }
+    else { LN_SWITCH_NJ(n / 256, LN_BWD(__hip_bfloat16, __hip_bfloat16)) }
+#undef LN_BWD
+    SIS_CHECK_LAUNCH("ln_bwd_kernel");
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(sis_cdiv(n, 64)), dim3(256), 0, st, dgamma, dbeta, workspace, blocks, n);
+    SIS_CHECK_LAUNCH("ln_param_reduce_kernel");
+    return 0;
+}

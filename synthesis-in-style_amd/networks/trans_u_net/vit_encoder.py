@@ -7,11 +7,15 @@ dropout rate is 0.0, so it is the same function) unless attention maps are reque
 """
 import copy
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-from torch.nn import Conv2d, Dropout, LayerNorm, Linear, Softmax
+from torch.autograd import Function
+from torch.nn import Conv2d, Dropout, Linear, Softmax
+
+import sis_hip
 from torch.nn.modules.utils import _pair
 
 from .vit_seg_modeling_resnet_skip import ResNetV2
@@ -22,6 +26,37 @@ def swish(x):
 
 
 ACT2FN = {"gelu": F.gelu, "relu": F.relu, "swish": swish}
+
+
+_HIP_LN = os.environ.get('SIS_HIP_LN', '1') != '0'
+
+
+class _LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        y, mean, rstd = sis_hip.layer_norm_fwd(x, weight, bias, eps, out_dtype)
+        ctx.save_for_backward(x, mean, rstd, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, mean, rstd, weight = ctx.saved_tensors
+        dx, dgamma, dbeta = sis_hip.layer_norm_bwd(grad, x, mean, rstd, weight)
+        return dx, dgamma, dbeta, None, None
+
+
+class LayerNorm(nn.LayerNorm):
+    """``nn.LayerNorm`` on one HIP launch per direction (csrc/layer_norm.hip: a wave per token, the row held in
+    registers); under autocast the result is written in the autocast dtype, i.e. what the following Linear reads."""
+
+    def forward(self, x):
+        n = self.normalized_shape[-1]
+        if len(self.normalized_shape) == 1 and self.elementwise_affine and self.bias is not None \
+                and _HIP_LN and sis_hip.layer_norm_supported(x, n):
+            out_dtype = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else x.dtype
+            if out_dtype in (torch.float32, torch.bfloat16):
+                return _LayerNormFn.apply(x, self.weight, self.bias, self.eps, out_dtype)
+        return super().forward(x)
 
 
 class Attention(nn.Module):

@@ -44,6 +44,9 @@ _SIGNATURES = {
     "sis_conv3x3_prepack": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "sis_conv3x3_eligible": ([_i] * 5, _i),
     "sis_upsample_bilinear": ([_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp], _i),
+    "sis_layer_norm_workspace_floats": ([_i], _i),
+    "sis_layer_norm_fwd": ([_vp] * 6 + [_i, _i, _i, _i, _f, _vp], _i),
+    "sis_layer_norm_bwd": ([_vp] * 9 + [_i, _i, _i, _i, _vp], _i),
     "sis_weight_std_fwd": ([_vp, _vp, _vp, _i, _i, _i, _f, _vp], _i),
     "sis_group_norm_fwd": ([_vp] * 8 + [_i, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
     "sis_group_norm_workspace_floats": ([_i, _i, _i], _i64),
@@ -565,6 +568,48 @@ def make_image_u8(x):
     with torch.cuda.device(x.device):
         _check(lib().sis_make_image_u8(_ptr(out), _ptr(x), b, ch, h * w, _stream()), "sis_make_image_u8")
     return out
+
+
+# ------------------------------------------------------------------------------ layer norm
+
+
+def layer_norm_supported(x, n):
+    return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and n in (256, 512, 768, 1024) and x.shape[-1] == n
+
+
+def layer_norm_fwd(x, gamma, beta, eps, out_dtype=None):
+    """x [..., n] (f32 / bf16) -> (y in ``out_dtype``, mean [rows], rstd [rows])."""
+    require_device(x, "input")
+    x = x.contiguous()
+    out_dtype = out_dtype or x.dtype
+    n = x.shape[-1]
+    rows = x.numel() // n
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_layer_norm_fwd(_ptr(y), _ptr(mean), _ptr(rstd), _ptr(x), _ptr(_f32(gamma, "weight")),
+                                        _ptr(_f32(beta, "bias")), _DTYPE_CODE[x.dtype], _DTYPE_CODE[out_dtype], rows, n,
+                                        float(eps), _stream()), "sis_layer_norm_fwd")
+    return y, mean, rstd
+
+
+def layer_norm_bwd(grad_y, x, mean, rstd, gamma):
+    x = x.contiguous()
+    g = grad_y.contiguous()
+    if g.dtype not in (torch.float32, torch.bfloat16):
+        g = g.float()
+    n = x.shape[-1]
+    rows = x.numel() // n
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(n, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty_like(dgamma)
+    ws = torch.empty(lib().sis_layer_norm_workspace_floats(n), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_layer_norm_bwd(_ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _ptr(g), _ptr(x), _ptr(mean), _ptr(rstd),
+                                        _ptr(gamma), _DTYPE_CODE[x.dtype], _DTYPE_CODE[g.dtype], rows, n, _stream()),
+               "sis_layer_norm_bwd")
+    return dx, dgamma, dbeta
 
 
 # ------------------------------------------------------------------------------ group norm (+ ReLU)

@@ -158,3 +158,31 @@ def test_group_norm_residual_relu(device):
     np.testing.assert_allclose(dx.float().cpu().numpy(), xr.grad.float().cpu().numpy(), rtol=2e-2, atol=1e-2 * scale)
     np.testing.assert_allclose(dg.cpu().numpy(), gr.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(db.cpu().numpy(), br.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("rows,n", [(37, 768), (1024, 256), (5, 1024)])
+def test_layer_norm(device, rows, n):
+    """csrc/layer_norm.hip against F.layer_norm in float64, fp32 and bf16 tensors, both directions."""
+    import sis_hip
+    g = torch.Generator().manual_seed(n + rows)
+    x = (torch.randn(rows, n, generator=g) * 2 + 0.5).to(device)
+    gamma = (1 + 0.2 * torch.randn(n, generator=g)).to(device)
+    beta = (0.3 * torch.randn(n, generator=g)).to(device)
+    gy = torch.randn(rows, n, generator=g).to(device)
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    F.layer_norm(xr, (n,), gr, br, 1e-6).backward(gy.double())
+    ref = F.layer_norm(x.double(), (n,), gamma.double(), beta.double(), 1e-6)
+    y, mean, rstd = sis_hip.layer_norm_fwd(x, gamma, beta, 1e-6)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    dx, dg, db = sis_hip.layer_norm_bwd(gy, x, mean, rstd, gamma)
+    np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(dg.cpu().numpy(), gr.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), br.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-3)
+    yb, _, _ = sis_hip.layer_norm_fwd(x, gamma, beta, 1e-6, torch.bfloat16)  # fp32 in, bf16 out (autocast case)
+    assert yb.dtype == torch.bfloat16
+    np.testing.assert_allclose(yb.float().cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-2, atol=1e-2)
+    dxb, dgb, dbb = sis_hip.layer_norm_bwd(gy.bfloat16(), x, mean, rstd, gamma)  # bf16 gradient, fp32 x
+    assert dxb.dtype == torch.float32
+    np.testing.assert_allclose(dxb.cpu().numpy(), xr.grad.float().cpu().numpy(), rtol=5e-2, atol=2e-2 * float(xr.grad.abs().max()))
+    assert not sis_hip.layer_norm_supported(x[:, :100], 100)
