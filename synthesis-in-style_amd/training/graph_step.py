@@ -34,7 +34,14 @@ class StepGraph:
             if self.seen < self.warmup:
                 self.seen += 1
                 return step_fn(batch)
-            self._capture(batch, step_fn, optimizers)
+            try:
+                self._capture(batch, step_fn, optimizers)
+            except Exception as err:  # a library call that cannot be captured: stay eager (nothing was executed)
+                import warnings
+                warnings.warn(f"hipGraph capture of the training step failed ({err!r}); continuing eagerly")
+                self.enabled, self.graph = False, None
+                torch.cuda.synchronize()
+                return step_fn(batch)
         for key, value in batch.items():
             self.static_batch[key].copy_(value, non_blocking=True)
         for opt in optimizers:
