@@ -227,3 +227,26 @@ def test_dataset_creation_driver(device):
     mean_latent = ae.decoder.mean_latent(64)
     acts, img = generate_images(next(it), ae, device=device, mean_latent=mean_latent)
     assert tuple(img.shape) == (3, 3, 32, 32)
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(512, 512, 64), (128, 128, 256)])
+def test_full_size_winograd_agrees_with_direct_kernel(device, cin, cout, hw):
+    """BASELINE configs[1] layer sizes (B = 32), too large for the CPU oracle: the Winograd kernel (persistent
+    workgroups, 16 tiles each at these sizes) and the independently written direct MFMA kernel must agree, with the
+    fused noise / bias / activation tail."""
+    import sis_hip
+    g = torch.Generator().manual_seed(cin + hw)
+    b = 32
+    x = torch.randn(b, cin, hw, hw, generator=g).to(device)
+    weight = (torch.randn(1, cout, cin, 3, 3, generator=g)).to(device)
+    s = (1 + 0.3 * torch.randn(b, cin, generator=g)).to(device)
+    noise = torch.randn(1, 1, hw, hw, generator=g).to(device)
+    nw = torch.tensor([0.1], device=device)
+    bias = (0.1 * torch.randn(cout, generator=g)).to(device)
+    wpk, wsq = sis_hip.modconv_prepack(weight)
+    dscale = sis_hip.modconv_demod(s, wsq, 1.0 / (cin * 9) ** 0.5, True)
+    u = sis_hip.modconv_prepack_wino(weight)
+    direct = sis_hip.modconv2d(x, wpk, s, dscale, 3, noise=noise, noise_weight=nw, bias=bias, fuse_act=True)
+    wino = sis_hip.modconv2d(x, wpk, s, dscale, 3, noise=noise, noise_weight=nw, bias=bias, fuse_act=True, wino_u=u)
+    err = (direct - wino).abs().max().item() / direct.abs().max().item()
+    assert err < 2e-5, err
