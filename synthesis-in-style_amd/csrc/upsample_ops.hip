@@ -45,6 +45,13 @@ __global__ __launch_bounds__(256) void bilinear_up_fwd_kernel(T* __restrict__ ou
         }
         if (sizeof(T) == 4 && (ow & 3) == 0) {  // 16-byte store (rows are 16-byte aligned when ow % 4 == 0)
             *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else if (sizeof(T) == 2 && (ow & 3) == 0) {  // four 16-bit results as one 8-byte store
+            T t[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sis_st(t, e, v[e]);
+            uint2 q;
+            __builtin_memcpy(&q, t, 8);
+            *reinterpret_cast<uint2*>(o) = q;
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
