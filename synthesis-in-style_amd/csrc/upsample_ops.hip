@@ -81,6 +81,37 @@ __global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(T* __restrict__ gx
     oy_lo = max(oy_lo, 0); ox_lo = max(ox_lo, 0); oy_hi = min(oy_hi, oh - 1); ox_hi = min(ox_hi, ow - 1);
     const T* g = gout + plane * oh * (int64_t)ow;
     float acc = 0.f;
+    if (ox_hi - ox_lo < 6 && oy_hi - oy_lo < 6) {
+        // x2 upsampling: at most 6 candidates per axis; the column weights are formed once, not once per row
+        float wxs[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int ox = ox_lo + k;
+            const Lerp1 lx = lerp1(ox <= ox_hi ? ox : ox_hi, sx, w);
+            float wx = 0.f;
+            if (ox <= ox_hi && lx.i0 == xx) wx += lx.l0;
+            if (ox <= ox_hi && lx.i1 == xx) wx += lx.l1;
+            wxs[k] = wx;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int oy = oy_lo + j;
+            if (oy > oy_hi) break;
+            const Lerp1 ly = lerp1(oy, sy, h);
+            float wy = 0.f;
+            if (ly.i0 == y) wy += ly.l0;
+            if (ly.i1 == y) wy += ly.l1;
+            if (wy == 0.f) continue;
+            const T* grow = g + (int64_t)oy * ow + ox_lo;
+            float racc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (wxs[k] != 0.f) racc += wxs[k] * sis_ld(grow, k);
+            acc += wy * racc;
+        }
+        sis_st(gx, i, acc);
+        return;
+    }
     for (int oy = oy_lo; oy <= oy_hi; ++oy) {
         const Lerp1 ly = lerp1(oy, sy, h);
         float wy = 0.f;
