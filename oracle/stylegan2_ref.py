@@ -110,6 +110,54 @@ def seeded_state_dict(size, style_dim=512, n_mlp=8, channel_multiplier=2, seed=0
     return sd
 
 
+def discriminator_schema(size, channel_multiplier=2):
+    """(name, shape) of every ``Discriminator(size, channel_multiplier).state_dict()`` entry in registration order
+    (model.py:634-668 with ConvLayer :564-609 -- a downsampling layer is Blur (child 0, buffer ``kernel``) + conv
+    (child 1) [+ FusedLeakyReLU (child 2, ``bias``)] -- and ResBlock :612-620)."""
+    ch = get_channels(channel_multiplier)
+    out = []
+
+    def conv_layer(prefix, cin, cout, k, down=False, bias=True, activate=True):
+        i = 0
+        if down:
+            out.append((f"{prefix}.0.kernel", (4, 4)))
+            i = 1
+        out.append((f"{prefix}.{i}.weight", (cout, cin, k, k)))
+        if bias and not activate:
+            out.append((f"{prefix}.{i}.bias", (cout,)))
+        if activate and bias:
+            out.append((f"{prefix}.{i + 1}.bias", (cout,)))
+
+    width = ch[size]
+    conv_layer("convs.0", 3, width, 1)
+    log_size = int(math.log(size, 2))
+    for n, i in enumerate(range(log_size, 2, -1), start=1):
+        nxt = ch[2 ** (i - 1)]
+        conv_layer(f"convs.{n}.conv1", width, width, 3)
+        conv_layer(f"convs.{n}.conv2", width, nxt, 3, down=True)
+        conv_layer(f"convs.{n}.skip", width, nxt, 1, down=True, bias=False, activate=False)
+        width = nxt
+    conv_layer("final_conv", width + 1, ch[4], 3)
+    out += [("final_linear.0.weight", (ch[4], ch[4] * 16)), ("final_linear.0.bias", (ch[4],)),
+            ("final_linear.1.weight", (1, ch[4])), ("final_linear.1.bias", (1,))]
+    return out
+
+
+def seeded_discriminator_state_dict(size, channel_multiplier=2, seed=0, dtype=torch.float32):
+    """Synthetic ``ckpt['d']``: N(0,1) weights (model.py:103,139), activation / linear biases N(0, 0.1^2) instead of the
+    zeros of a fresh network so that every bias path is exercised; blur taps = make_kernel([1,3,3,1]) (:79-85)."""
+    rng = np.random.RandomState(seed)
+    k2d = ops_ref.make_kernel([1, 3, 3, 1])
+    sd = {}
+    for name, shape in discriminator_schema(size, channel_multiplier):
+        if name.endswith(".kernel"):
+            sd[name] = k2d.to(dtype)
+            continue
+        t = torch.from_numpy(rng.standard_normal(shape)).to(dtype)
+        sd[name] = (t * 0.1 if name.endswith(".bias") else t).contiguous()
+    return sd
+
+
 def seeded_inputs(size, batch, style_dim=512, seed=1, dtype=torch.float32):
     """z [B, style_dim] and the explicit noise list (13 maps at 256) from a frozen numpy stream."""
     rng = np.random.RandomState(seed)

@@ -17,6 +17,7 @@ the tile axis, csrc/conv_wgrad_wino.hip) where its tile plan applies (channels %
 import torch
 from torch import nn
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 from torch.nn import functional as F
 
 import sis_hip
@@ -38,31 +39,72 @@ def _batch_to_space(t, d):
     return t.view(bdd // (d * d), d, d, c, h, w).permute(0, 3, 4, 1, 5, 2).reshape(bdd // (d * d), c, h * d, w * d)
 
 
+def _conv3x3_fwd(input, weight, d):
+    return _batch_to_space(sis_hip.conv3x3(_space_to_batch(input, d), sis_hip.conv3x3_prepack(weight)), d)
+
+
+def _conv3x3_dgrad(grad_output, weight, d):
+    return _batch_to_space(sis_hip.conv3x3(_space_to_batch(grad_output, d), sis_hip.conv3x3_prepack(weight, adjoint=True)), d)
+
+
+def _conv3x3_wgrad(input, grad_output, weight_shape, d):
+    b, cin, h, w = input.shape
+    if sis_hip.conv3x3_wgrad_supported(b * d * d, cin, weight_shape[0], h // d, w // d):
+        return sis_hip.conv3x3_wgrad(_space_to_batch(input, d), _space_to_batch(grad_output, d))
+    # narrow sub-images / channel counts below a 64 x 64 tile / too little work: the library's kernel
+    return torch.ops.aten.convolution_backward(grad_output, input, input.new_empty(weight_shape), None, (1, 1), (d, d), (d, d),
+                                               False, (0, 0), 1, (False, True, False))[1]
+
+
 class _Conv3x3Function(Function):
     @staticmethod
     def forward(ctx, input, weight, dilation):
         ctx.save_for_backward(input, weight)
         ctx.dilation = dilation
-        out = sis_hip.conv3x3(_space_to_batch(input, dilation), sis_hip.conv3x3_prepack(weight))
-        return _batch_to_space(out, dilation)
+        return _conv3x3_fwd(input, weight, dilation)
 
     @staticmethod
     def backward(ctx, grad_output):
         input, weight = ctx.saved_tensors
-        d = ctx.dilation
-        grad_input = grad_weight = None
-        grad_output = grad_output.contiguous()
-        if ctx.needs_input_grad[0]:
-            grad_input = _batch_to_space(sis_hip.conv3x3(_space_to_batch(grad_output, d),
-                                                         sis_hip.conv3x3_prepack(weight, adjoint=True)), d)
-        if ctx.needs_input_grad[1]:
-            b, cin, h, w = input.shape
-            if sis_hip.conv3x3_wgrad_supported(b * d * d, cin, weight.shape[0], h // d, w // d):
-                grad_weight = sis_hip.conv3x3_wgrad(_space_to_batch(input, d), _space_to_batch(grad_output, d))
-            else:  # narrow sub-images / channel counts below a 64 x 64 tile: the library's kernel
-                grad_weight = torch.ops.aten.convolution_backward(
-                    grad_output, input, weight, None, (1, 1), (d, d), (d, d), False, (0, 0), 1, (False, True, False))[1]
+        grad_input, grad_weight = _Conv3x3Backward.apply(grad_output.contiguous(), input, weight, ctx.dilation,
+                                                         ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return grad_input, grad_weight, None
+
+
+class _Conv3x3Backward(Function):
+    """(dy, x, W) -> (dx, dW), itself differentiable once more (R1 / path-length regularisers of GAN training take
+    a gradient of a gradient): with incoming (ggx, ggW),
+
+        d dy = conv(ggx, W) + conv(x, ggW)      d x = dgrad(dy, ggW)      d W = wgrad(ggx, dy)
+
+    all three on the same Winograd kernels as the first-order pass."""
+
+    @staticmethod
+    def forward(ctx, grad_output, input, weight, dilation, want_input, want_weight):
+        ctx.save_for_backward(grad_output, input, weight)
+        ctx.dilation = dilation
+        grad_input = _conv3x3_dgrad(grad_output, weight, dilation) if want_input else None
+        grad_weight = _conv3x3_wgrad(input, grad_output, weight.shape, dilation) if want_weight else None
+        return grad_input, grad_weight
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gg_input, gg_weight):
+        grad_output, input, weight = ctx.saved_tensors
+        d = ctx.dilation
+        need_gy, need_x, need_w = ctx.needs_input_grad[:3]
+        d_gy = d_x = d_w = None
+        if need_gy:
+            if gg_input is not None:
+                d_gy = _conv3x3_fwd(gg_input.contiguous(), weight, d)
+            if gg_weight is not None:
+                t = _conv3x3_fwd(input, gg_weight.contiguous(), d)
+                d_gy = t if d_gy is None else d_gy + t
+        if need_x and gg_weight is not None:
+            d_x = _conv3x3_dgrad(grad_output, gg_weight.contiguous(), d)
+        if need_w and gg_input is not None:
+            d_w = _conv3x3_wgrad(gg_input.contiguous(), grad_output, weight.shape, d)
+        return d_gy, d_x, d_w, None, None, None
 
 
 def conv3x3(input, weight, dilation=1):

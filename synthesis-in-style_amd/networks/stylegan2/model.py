@@ -22,10 +22,12 @@ per-(Cout,Cin) squared sums that give the demodulation coefficients from a [B,Ci
 product).  Requested intermediate activations are the layer outputs themselves (never written
 in place afterwards), not extra ``detach().clone()`` copies (model.py:532-549).
 
-With autograd enabled (GAN training / latent projection -- outside the synthesis path) the layers
-fall back to differentiable device code: the reference's grouped-convolution formulation on ATen,
-with ``upfirdn2d`` / ``fused_leaky_relu`` still running on the HIP kernels through their autograd
-Functions.  CPU tensors are rejected with ``RuntimeError`` like the reference's extension does.
+With autograd enabled (GAN training / latent projection) the layers run as
+differentiable device code: a modulated convolution is channel-scale -> ONE shared-weight convolution
+-> channel-scale (``ModulatedConv2d._forward_autograd``; stride-1 3x3 layers on the Winograd kernels,
+twice differentiable for the path-length regulariser), with ``upfirdn2d`` / ``fused_leaky_relu`` on
+the HIP kernels through their autograd Functions.  The discriminator half of the reference file lives
+in ``discriminator.py`` and is re-exported here.  CPU tensors are rejected with ``RuntimeError`` like the reference's extension does.
 """
 import math
 import os
@@ -38,6 +40,7 @@ from torch import nn
 from torch.nn import functional as F
 
 import sis_hip
+from networks import hip_conv
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 
 _RGB_STREAMS = {}  # device -> side stream of the ToRGB chain (process-wide: streams are not copyable module state)
@@ -187,8 +190,34 @@ class ModulatedConv2d(nn.Module):
             return self.blur(sis_hip.modconv2d_up(input, wpk, s, dscale))
         return sis_hip.modconv2d(input, wpk, s, dscale, self.kernel_size, wino_u=self.wino_weights())
 
-    # ---- differentiable path (training only; reference formulation, model.py:237-278) --------
+    # ---- differentiable path (GAN training / latent projection) ---------------------------------
     def _forward_autograd(self, input, style):
+        """y[b] = dcoef[b] (.) conv(W, s[b] (.) x[b]): the per-sample weights w[b] = scale * W * s[b] * demod[b] of the
+        reference (model.py:237-278) factor into a channel scaling of the input, ONE convolution with the shared
+        weights over the whole batch, and a channel scaling of the output with
+        dcoef[b,co] = scale * rsqrt(scale^2 * sum_ci s[b,ci]^2 * sum_taps W[co,ci]^2 + 1e-8) -- no [B,Cout,Cin,k,k]
+        tensor, no B-group convolution; stride-1 3x3 layers run on the Winograd kernels (first and second order).
+        SIS_MODCONV_GROUPED=1 selects the reference's grouped formulation (A/B runs; downsampling layers always)."""
+        if self.downsample or os.environ.get("SIS_MODCONV_GROUPED", "0") == "1":
+            return self._forward_grouped(input, style)
+        b, cin, h, w = input.shape
+        k, cout = self.kernel_size, self.out_channel
+        s = self.modulation(style)
+        weight = self.weight[0]
+        if self.demodulate:
+            wsq = weight.pow(2).sum((2, 3))
+            dcoef = self.scale * torch.rsqrt((self.scale * self.scale) * (s.pow(2) @ wsq.t()) + 1e-8)
+        x = input * s.view(b, cin, 1, 1)
+        if self.upsample:
+            out = F.conv_transpose2d(x, weight.transpose(0, 1), stride=2)
+        elif k == 3 and x.is_cuda and x.is_contiguous() and sis_hip.conv3x3_supported(x, weight):
+            out = hip_conv.conv3x3(x, weight)
+        else:
+            out = F.conv2d(x, weight, padding=self.padding)
+        out = out * dcoef.view(b, cout, 1, 1) if self.demodulate else out * self.scale
+        return self.blur(out) if self.upsample else out
+
+    def _forward_grouped(self, input, style):
         b, cin, h, w = input.shape
         k, cout = self.kernel_size, self.out_channel
         mod = self.modulation(style).view(b, 1, cin, 1, 1)
@@ -507,3 +536,6 @@ class Generator(nn.Module):
         if return_intermediate_activations:
             return image, acts
         return image, None
+
+
+from .discriminator import ConvLayer, Discriminator, EqualConv2d, ResBlock, ScaledLeakyReLU  # noqa: E402,F401

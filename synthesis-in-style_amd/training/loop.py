@@ -9,9 +9,13 @@ training_builder/ema_net_train_builder.py:50-59):
 * ``Updater(iterators, networks, optimizers, device, copy_to_device)`` holds the three dicts; ``update()``
   runs ``update_core()`` once and counts iterations;
 * ``GradientApplier(networks, optimizers)`` is a context manager: ``zero_grad`` on entry, ``step`` on exit;
-* ``get_current_reporter().add_observation(dict, prefix)`` records scalars under ``prefix/key``.
+* ``get_current_reporter().add_observation(dict, prefix)`` records scalars under ``prefix/key``;
+* ``UpdateDisabler(network)`` (updater/stylegan_2_updater.py:130,164) freezes a network's parameters inside the block;
+* ``reduce_sum`` (distributed/__init__.py:4-14) / ``get_world_size``: sum over ranks, identity without a process group.
 """
 from typing import Dict, Iterable
+
+import torch.distributed as dist
 
 
 class Reporter:
@@ -47,6 +51,37 @@ class GradientApplier:
             for opt in self.optimizers:
                 opt.step()
         return False
+
+
+class UpdateDisabler:
+    """``requires_grad = False`` on every parameter of ``network`` inside the block, restored afterwards."""
+
+    def __init__(self, network):
+        self.network = network
+        self._saved = None
+
+    def __enter__(self):
+        self._saved = [(p, p.requires_grad) for p in self.network.parameters()]
+        for p, _ in self._saved:
+            p.requires_grad = False
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        for p, flag in self._saved:
+            p.requires_grad = flag
+        return False
+
+
+def get_world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def reduce_sum(tensor):
+    if not (dist.is_available() and dist.is_initialized()):
+        return tensor
+    tensor = tensor.clone()
+    dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+    return tensor
 
 
 class Updater:
