@@ -249,9 +249,74 @@ def measured_traffic(kernel):
     return None, None
 
 
+def bench_gan(args, world, rank, device, distributed):
+    """StyleGAN2 training images/s (reference train_stylegan_2.py:57-124 +
+    configs/stylegan/stylegan_256px.yaml: 256^2, batch 24, lr 1e-3, lazy regularisers every 4 / 16 iterations): one step
+    = one ``Stylegan2Updater.update_core`` (D step, [R1], G step, [path length], g_ema average) on real images resident
+    in HBM.  Run with --steps a multiple of 16 so that the timed region holds whole regulariser cycles."""
+    import torch.distributed as dist
+    from networks.stylegan2.model import Discriminator, Generator
+    from updater.stylegan_2_updater import Stylegan2Updater
+    batch = args.batch or 24
+    torch.manual_seed(rank)
+    g, g_ema = Generator(256, 512, 8, channel_multiplier=2).to(device), Generator(256, 512, 8, channel_multiplier=2).to(device)
+    g_ema.eval()
+    d = Discriminator(256, channel_multiplier=2).to(device)
+    g_ratio, d_ratio = 4 / 5, 16 / 17
+    opts = {"generator": torch.optim.Adam(g.parameters(), lr=1e-3 * g_ratio, betas=(0.0, 0.99 ** g_ratio)),
+            "discriminator": torch.optim.Adam(d.parameters(), lr=1e-3 * d_ratio, betas=(0.0, 0.99 ** d_ratio))}
+    if distributed:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        g = DDP(g, device_ids=[device.index], broadcast_buffers=False, output_device=device.index)
+        d = DDP(d, device_ids=[device.index], broadcast_buffers=False, output_device=device.index)
+    images = torch.rand(batch, 3, 256, 256, device=device) * 2 - 1
+
+    def batches():
+        while True:
+            yield {"image": images.clone()}
+
+    updater = Stylegan2Updater(iterators={"images": batches()}, networks={"generator": g, "discriminator": d}, optimizers=opts,
+                               device=device, g_ema=g_ema, latent_size=512, style_mixing_prob=0.9,
+                               regularization_options={"g_interval": 4, "d_interval": 16, "r1_weight": 10, "path_reg_weight": 2},
+                               freeze_stochastic_noise_layers=[0, 1, 2, 3, 4, 5])
+    updater.accumulate(g, 0)
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        updater.update()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        updater.update()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank != 0:
+        return None
+    n_images = batch * args.steps * world
+    return {
+        "metric": METRIC, "value": round(n_images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"StyleGAN2 GAN training iteration (D, lazy R1 /16, G, lazy path length /4, g_ema), 256x256, "
+                               f"batch {batch} per GPU, Adam (SURVEY.md 8(f) row 4; not a BASELINE.json config)",
+                   "batch_per_gpu": batch, "image_size": 256, "parallelism": f"dp{world}",
+                   "modconv": "grouped" if os.environ.get("SIS_MODCONV_GROUPED", "0") == "1" else "shared-weight",
+                   "winograd": os.environ.get("SIS_GAN_WINOGRAD", "1") != "0"},
+        "roofline": None,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="synthesis", choices=["synthesis", "emanet", "transunet", "dataset"])
+    ap.add_argument("--workload", default="synthesis", choices=["synthesis", "emanet", "transunet", "dataset", "gan"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
@@ -276,6 +341,8 @@ def main():
     if args.workload != "synthesis":
         if args.workload == "dataset":
             result = bench_dataset(args, world, rank, device, distributed)
+        elif args.workload == "gan":
+            result = bench_gan(args, world, rank, device, distributed)
         else:
             result = bench_training(args, args.workload, world, rank, device, distributed)
         if distributed:

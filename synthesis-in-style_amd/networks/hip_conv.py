@@ -14,6 +14,8 @@ axes swapped, taps rotated by 180 degrees); the weight gradient is ``sis_conv3x3
 the tile axis, csrc/conv_wgrad_wino.hip) where its tile plan applies (channels % 64) and there is enough work, ATen's
 ``convolution_backward`` otherwise.
 """
+import os
+
 import torch
 from torch import nn
 from torch.autograd import Function
@@ -105,6 +107,12 @@ class _Conv3x3Backward(Function):
         if need_w and gg_input is not None:
             d_w = _conv3x3_wgrad(gg_input.contiguous(), grad_output, weight.shape, d)
         return d_gy, d_x, d_w, None, None, None
+
+
+def gan_winograd_enabled():
+    """SIS_GAN_WINOGRAD=0 sends the GAN-training convolutions (Discriminator, Generator under autograd) to the library
+    instead of the Winograd kernels (A/B runs of ``bench.py --workload gan``)."""
+    return os.environ.get("SIS_GAN_WINOGRAD", "1") != "0"
 
 
 def conv3x3(input, weight, dilation=1):

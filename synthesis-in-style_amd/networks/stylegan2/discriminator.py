@@ -23,7 +23,7 @@ from torch import nn
 from torch.nn import functional as F
 
 import sis_hip
-from networks.hip_conv import conv3x3
+from networks.hip_conv import conv3x3, gan_winograd_enabled
 from .op import FusedLeakyReLU
 
 
@@ -49,7 +49,7 @@ class EqualConv2d(nn.Module):
 
     def _winograd(self, input, weight):
         return (self.stride == 1 and self.padding == 1 and self.bias is None and input.is_contiguous()
-                and not torch.is_autocast_enabled() and sis_hip.conv3x3_supported(input, weight))
+                and not torch.is_autocast_enabled() and gan_winograd_enabled() and sis_hip.conv3x3_supported(input, weight))
 
     def forward(self, input):
         weight = self.weight * self.scale

@@ -210,7 +210,8 @@ class ModulatedConv2d(nn.Module):
         x = input * s.view(b, cin, 1, 1)
         if self.upsample:
             out = F.conv_transpose2d(x, weight.transpose(0, 1), stride=2)
-        elif k == 3 and x.is_cuda and x.is_contiguous() and sis_hip.conv3x3_supported(x, weight):
+        elif (k == 3 and x.is_cuda and x.is_contiguous() and hip_conv.gan_winograd_enabled()
+              and sis_hip.conv3x3_supported(x, weight)):
             out = hip_conv.conv3x3(x, weight)
         else:
             out = F.conv2d(x, weight, padding=self.padding)

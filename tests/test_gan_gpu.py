@@ -142,7 +142,7 @@ def test_shared_weight_modconv_matches_grouped_formulation(device, upsample, k, 
         grads = autograd.grad((y * probe).sum(), (x, style, layer.weight, layer.modulation.weight))
         results.append((y,) + grads)
     for u, v in zip(*results):
-        np.testing.assert_allclose(u.detach().cpu().numpy(), v.detach().cpu().numpy(), rtol=0, atol=2e-4 * float(v.abs().max()))
+        np.testing.assert_allclose(u.detach().cpu().numpy(), v.detach().cpu().numpy(), rtol=0, atol=2e-4 * float(v.detach().abs().max()))
 
 
 def test_update_core_runs_the_schedule(device):

@@ -2,7 +2,7 @@
 import collections, csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "sgd_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "sgd_kernel" in r["Kernel_Name"] or "sgd_dev_kernel" in r["Kernel_Name"]]
 if len(idx) < 3:
     raise SystemExit("need >= 3 optimizer steps in the trace")
 a, b = idx[-3], idx[-2]
