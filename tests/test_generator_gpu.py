@@ -250,3 +250,19 @@ def test_full_size_winograd_agrees_with_direct_kernel(device, cin, cout, hw):
     wino = sis_hip.modconv2d(x, wpk, s, dscale, 3, noise=noise, noise_weight=nw, bias=bias, fuse_act=True, wino_u=u)
     err = (direct - wino).abs().max().item() / direct.abs().max().item()
     assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("size,cm,batch", [(512, 2, 3), (1024, 1, 1), (128, 2, 5), (64, 1, 1)])
+def test_generator_other_resolutions_vs_oracle(device, size, cm, batch):
+    """Every size of ``get_channels`` (model.py:443-455) beyond the benchmarked 256: the narrow tails (64 / 32 / 16
+    channels at 512 / 1024) and odd batches take other tile plans and the direct-kernel fallbacks; each activation is
+    compared in full with the oracle run live on the host cores."""
+    g, sd = _build(size, 512, 8, cm, 21, device)
+    z, noise = R.seeded_inputs(size, batch, 512, seed=22)
+    with torch.no_grad():
+        img, acts = g([z.to(device)], noise=[n.to(device) for n in noise], return_intermediate_activations=True)
+        img_o, acts_o = R.generator_forward(sd, [z], noise=noise, return_intermediate_activations=True)
+    assert tuple(img.shape) == (batch, 3, size, size) and len(acts) == len(acts_o) == 2 * int(np.log2(size)) - 2
+    assert _rel(img, img_o) < 2e-4
+    for k in acts_o:
+        assert _rel(acts[k], acts_o[k]) < 1e-4, k
