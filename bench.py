@@ -124,6 +124,33 @@ SEG_CONFIG = {"emanet": "configs/segmenter/ema_net_resnet50_256.yaml",
               "transunet": "configs/segmenter/trans_u_net_r50_vit_b16_512.yaml"}
 
 
+def cpu_baseline_training(workload, config):
+    """Oracle training step on the host cores (B = 4 for EMANet-50 @256^2, B = 2 for TransUNet @512^2,
+    fp32): 1 warm-up + 1 timed iteration, bounded to tens of seconds."""
+    threads = host_cores()
+    torch.set_num_threads(threads)
+    size, classes = config["image_size"], config["num_classes"]
+    if workload == "emanet":
+        from oracle import ema_net_ref as O
+        batch_size, sd = 4, O.seeded_state_dict(50, classes, seed=0)
+        step = lambda b: O.train_step(sd, bufs, b)  # noqa: E731
+    else:
+        from oracle import trans_u_net_ref as O
+        batch_size, sd = 2, O.seeded_state_dict(size, classes, seed=0)
+        step = lambda b: O.train_step(sd, bufs, b, num_classes=classes)  # noqa: E731
+    gen = torch.Generator().manual_seed(7)
+    batch = {"images": torch.rand(batch_size, 3, size, size, generator=gen) * 2 - 1,
+             "segmented": torch.randint(0, classes, (batch_size, 1, size, size), generator=gen)}
+    bufs = {}
+    step(batch)
+    t0 = time.perf_counter()
+    step(batch)
+    sec = time.perf_counter() - t0
+    return {"value": round(batch_size / sec, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{config['network']} oracle training step (forward, loss, backward, SGD), {size}x{size}, batch "
+                      f"{batch_size}, fp32, {threads} torch threads, 1 timed iteration after 1 warm-up ({sec:.2f} s)"}
+
+
 def bench_training(args, workload, world, rank, device, distributed):
     """Segmentation training images/s (BASELINE.json configs[3] / [4]): one step = one updater iteration
     (forward, loss, backward with bucketed RCCL all-reduce, fused SGD step) on a synthetic batch resident in HBM."""
@@ -173,10 +200,13 @@ def bench_training(args, workload, world, rank, device, distributed):
                    "batch_per_gpu": config["batch_size"], "image_size": config["image_size"],
                    "parallelism": f"dp{world}, DDP bucketed all-reduce over RCCL",
                    "hip_graph": bool(getattr(updater, "_step_graph", None) and updater._step_graph.graph is not None)},
-        "roofline": {"kernel": "whole step (convolutions on ROCm libraries this round)", "bound": "mfma",
+        "roofline": {"kernel": "whole step, nominal 2*MAC FLOPs (3x3 convolutions on the Winograd HIP kernels in fp32, norms / "
+                               "loss / optimizer on HIP kernels, 1x1 convolutions and GEMMs on hipBLASLt, bf16 convolutions on "
+                               "MIOpen)", "bound": "mfma",
                      "achieved": round(tf, 2), "peak": 2500.0 if config.get("amp") else PEAK_MFMA_F32_TFLOPS,
                      "unit": "TFLOP/s",
                      "frac": round(tf / (2500.0 if config.get("amp") else PEAK_MFMA_F32_TFLOPS), 4), "traffic": None},
+        "cpu_baseline": None if (world > 1 or args.no_cpu_baseline) else cpu_baseline_training(workload, config),
     }
 
 
