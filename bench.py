@@ -161,6 +161,9 @@ def bench_training(args, workload, world, rank, device, distributed):
     config = yaml.safe_load(open(os.path.join(ROOT, "synthesis-in-style_amd", SEG_CONFIG[workload])))
     config["fine_tune"] = None
     if args.dtype:
+        if workload == "emanet" and args.dtype != "f32":
+            raise SystemExit("the EMANet row is fp32, the reference's precision (BASELINE.json configs[3]); only the TransUNet "
+                             "row (configs[4]) names bf16")
         config["amp"] = None if args.dtype == "f32" else args.dtype
     if args.batch:
         config["batch_size"] = args.batch
