@@ -142,7 +142,10 @@ class Embeddings(nn.Module):
         features = None
         if self.hybrid:
             x, features = self.hybrid_model(x)
-        x = self.patch_embeddings(x).flatten(2).transpose(-1, -2)  # [B, n_patches, hidden]
+        # [B, n_patches, hidden], made contiguous HERE: element-wise ops keep their first operand's strides, so a
+        # transposed view would put the whole fp32 residual stream of the encoder in [B, hidden, n] memory order and
+        # every LayerNorm / GEMM below (and their gradients) would start with a strided 25 MB copy
+        x = self.patch_embeddings(x).flatten(2).transpose(-1, -2).contiguous()
         return self.dropout(x + self.position_embeddings), features
 
 

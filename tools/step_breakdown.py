@@ -10,7 +10,7 @@ step = rows[a + 1:b + 1]
 span = (int(rows[b]["End_Timestamp"]) - int(rows[a]["End_Timestamp"])) / 1e6
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in step:
-    k = r["Kernel_Name"][:100]
+    k = r["Kernel_Name"][:int(sys.argv[3]) if len(sys.argv) > 3 else 100]
     agg[k][0] += 1
     agg[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 print(f"step span {span:.2f} ms, busy {sum(v[1] for v in agg.values()):.2f} ms, {len(step)} launches")
