@@ -220,6 +220,7 @@ def bench_dataset(args, world, rank, device, distributed):
     import torch.distributed as dist
     import sis_hip
     from segmentation.gan_local_edit.factor_catalog import FactorCatalog
+    from utils.dataset_creation import label_and_encode
     batch = args.batch or BATCH
     g = build_generator(device)
     rng = np.random.RandomState(7)
@@ -231,8 +232,7 @@ def bench_dataset(args, world, rank, device, distributed):
         with torch.no_grad():
             z = torch.randn(batch, g.style_dim).to(device, non_blocking=True)
             image, acts = g([z], noise=g.make_noise(), return_intermediate_activations=True)
-            labels = {k: cat.predict(acts[k]) for k, cat in catalogs.items()}
-            return sis_hip.make_image_u8(image), labels
+            return label_and_encode(image, acts, catalogs)  # side stream: overlaps the next batch's first layers
 
     def fence():
         if distributed:

@@ -28,7 +28,7 @@ import torch
 import sis_hip
 from networks.stylegan2.model import Generator
 from segmentation.gan_local_edit.factor_catalog import FactorCatalog
-from utils.dataset_creation import shard_range
+from utils.dataset_creation import label_and_encode, shard_range
 
 
 def save_image(image: numpy.ndarray, image_id: int, base_dir: Path, name_format: str = "{id}.png"):
@@ -66,6 +66,27 @@ def build_dataset(args, creation_config, rank=0, world_size=1):
     save_dir = Path(args.save_to) if args.save_to else None
     torch.random.manual_seed(creation_config.get('seed', 1))
     done = 0
+
+    def flush(job):
+        """Host side of a finished batch: wait for its label pass, then encode / write the files."""
+        first_id, pixels, labels, ready = job
+        if ready is not None:
+            ready.synchronize()
+        if save_dir is None:
+            return
+        rgb = pixels.cpu().numpy()
+        if label_layer in labels:
+            k = catalogs[label_layer].cluster_centers.shape[0]
+            lab = labels[label_layer]
+            if lab.shape[-1] != rgb.shape[2]:
+                lab = torch.nn.functional.interpolate(lab[:, None].float(), size=rgb.shape[1:3], mode='nearest')[:, 0].long()
+            grey = (lab * 255 // max(k - 1, 1)).to(torch.uint8).cpu().numpy()
+            lab_img = numpy.repeat(grey[..., None], 3, axis=3)
+        else:
+            lab_img = numpy.zeros_like(rgb)
+        save_generated_images(rgb, lab_img, first_id, save_dir, args.num_images)
+
+    pending = None
     with torch.no_grad():
         for first in range(0, args.num_images, args.batch_size):
             n = min(args.batch_size, args.num_images - first)
@@ -76,21 +97,13 @@ def build_dataset(args, creation_config, rank=0, world_size=1):
             z = z[a - first:b - first].to(device)
             image, acts = g([z], noise=g.make_noise(), return_intermediate_activations=True,
                             truncation=0.7 if mean_latent is not None else 1, truncation_latent=mean_latent)
-            labels = {layer: cat.predict(acts[layer]) for layer, cat in catalogs.items()}
-            pixels = sis_hip.make_image_u8(image)
-            if save_dir is not None:
-                rgb = pixels.cpu().numpy()
-                if label_layer in labels:
-                    k = catalogs[label_layer].cluster_centers.shape[0]
-                    lab = labels[label_layer]
-                    if lab.shape[-1] != rgb.shape[2]:
-                        lab = torch.nn.functional.interpolate(lab[:, None].float(), size=rgb.shape[1:3], mode='nearest')[:, 0].long()
-                    grey = (lab * 255 // max(k - 1, 1)).to(torch.uint8).cpu().numpy()
-                    lab_img = numpy.repeat(grey[..., None], 3, axis=3)
-                else:
-                    lab_img = numpy.zeros_like(rgb)
-                save_generated_images(rgb, lab_img, a, save_dir, args.num_images)
+            job = (a,) + label_and_encode(image, acts, catalogs)  # side stream; the next batch's forward is issued first
+            if pending is not None:
+                flush(pending)
+            pending = job
             done += b - a
+        if pending is not None:
+            flush(pending)
     torch.cuda.synchronize()
     return done, (lo, hi)
 

@@ -12,9 +12,12 @@ create_dataset_for_segmentation.py:129-148 calls).  Same observable behaviour:
 The image-encoding branch of the reference (``autoencoder.encode`` for non-``Latents`` batches) belongs
 to the projection research code and is out of scope.
 """
+import os
 from typing import Dict, Iterable, Optional, Tuple
 
 import torch
+
+import sis_hip
 
 from latent_projecting import Latents
 
@@ -43,3 +46,30 @@ def generate_images(batch: Latents, autoencoder, device='cuda', mean_latent: Opt
             [latents.latent], input_is_latent=False, noise=latents.noise, return_intermediate_activations=True,
             truncation=0.7 if mean_latent is not None else 1, truncation_latent=mean_latent)
     return activations, image
+
+
+_LABEL_STREAMS = {}  # device -> side stream of the label / uint8 pass
+
+
+def label_and_encode(image: torch.Tensor, activations: Dict[int, torch.Tensor], catalogs: Dict) \
+        -> Tuple[torch.Tensor, Dict[int, torch.Tensor], Optional[torch.cuda.Event]]:
+    """What the reference does with a batch after ``generate_images`` (create_dataset_for_segmentation.py:131-135 ->
+    ``predict_clusters`` -> ``FactorCatalog.predict``; ``make_image``): nearest-centre label maps of the catalogued
+    activation layers and the uint8 NHWC image, here issued on a side stream.  Both passes are HBM-bound
+    readers of finished tensors, so they overlap the MFMA-bound first layers of the NEXT batch, whose small grids
+    leave most compute units idle.  Returns (pixels u8 [B,H,W,3], {layer: labels}, event): wait for / synchronise on
+    the event before touching the results from another stream or the host.  SIS_LABEL_STREAM=0 keeps everything on the
+    current stream (event None)."""
+    device = image.device
+    if os.environ.get("SIS_LABEL_STREAM", "1") == "0" or not image.is_cuda:
+        return sis_hip.make_image_u8(image), {k: cat.predict(activations[k]) for k, cat in catalogs.items()}, None
+    if device not in _LABEL_STREAMS:
+        _LABEL_STREAMS[device] = torch.cuda.Stream(device=device)
+    side, main = _LABEL_STREAMS[device], torch.cuda.current_stream(device)
+    side.wait_event(main.record_event())
+    with torch.cuda.stream(side):
+        labels = {k: cat.predict(activations[k]) for k, cat in catalogs.items()}
+        pixels = sis_hip.make_image_u8(image)
+    for t in [image] + [activations[k] for k in catalogs]:
+        t.record_stream(side)  # the caching allocator must not hand these blocks out again before the side pass has read them
+    return pixels, labels, side.record_event()

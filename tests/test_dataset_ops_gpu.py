@@ -89,3 +89,40 @@ def test_create_dataset_loop_shards_and_writes(device, tmp_path):
     im = np.asarray(Image.open(files[5]))
     assert im.shape == (32, 64, 3) and im.dtype == np.uint8
     assert set(np.unique(im[:, 32:])) <= {0, 63, 127, 191, 255}
+
+
+def test_label_and_encode_side_stream_is_bit_identical(device, monkeypatch):
+    """utils.dataset_creation.label_and_encode: label maps and uint8 pixels issued on the side stream while the next
+    batch is generated equal the same-stream results bit for bit (index / byte work), batch after batch."""
+    from networks.stylegan2.model import Generator
+    from segmentation.gan_local_edit.factor_catalog import FactorCatalog
+    from utils.dataset_creation import label_and_encode
+    torch.manual_seed(3)
+    g = Generator(64, 64, 2, channel_multiplier=1).to(device).eval()
+    rng = np.random.RandomState(5)
+    catalogs = {k: FactorCatalog(cluster_centers=rng.randn(7, c).astype(np.float32)) for k, c in ((4, 512), (5, 512), (9, 256))}
+    zs = [torch.randn(6, 64, device=device) for _ in range(4)]
+    noise = g.make_noise()
+
+    def run():
+        jobs = []
+        with torch.no_grad():
+            for z in zs:  # forward of batch i+1 is issued while the label pass of batch i may still be running
+                image, acts = g([z], noise=noise, return_intermediate_activations=True)
+                jobs.append(label_and_encode(image, acts, catalogs))
+                del image, acts
+        out = []
+        for pixels, labels, ready in jobs:
+            if ready is not None:
+                ready.synchronize()
+            out.append((pixels.cpu(), {k: v.cpu() for k, v in labels.items()}))
+        return out
+
+    monkeypatch.setenv("SIS_LABEL_STREAM", "0")
+    want = run()
+    monkeypatch.setenv("SIS_LABEL_STREAM", "1")
+    got = run()
+    for (p0, l0), (p1, l1) in zip(want, got):
+        assert p1.dtype == torch.uint8 and torch.equal(p0, p1)
+        for k in l0:
+            assert torch.equal(l0[k], l1[k])
