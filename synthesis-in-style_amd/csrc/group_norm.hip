@@ -40,6 +40,39 @@ __device__ __forceinline__ void gn_load(const T* p, float* v) {
     }
 }
 
+template <int VEC, typename T>
+__device__ __forceinline__ void gn_store(T* p, const float* v) {
+    if constexpr (VEC == 4 && sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (VEC == 4 && sizeof(T) == 2) {
+        T t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sis_st(t, e, v[e]);
+        uint2 q;
+        __builtin_memcpy(&q, t, 8);
+        *reinterpret_cast<uint2*>(p) = q;
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sis_st(p, e, v[e]);
+    }
+}
+
+// Elements [lo, hi) of a plane whose first element sits at flat offset `base` of a vector-aligned tensor: scalar head up
+// to the next multiple of VEC, vector body, scalar tail -- planes of odd size (127 x 127 after the un-padded max-pool)
+// still move 8 / 16 bytes per lane.  VEC == 1: everything through `scalar`.
+template <int VEC, typename FS, typename FV>
+__device__ __forceinline__ void gn_span(int64_t base, int lo, int hi, FS scalar, FV vec) {
+    int a0 = lo, a1 = lo;
+    if constexpr (VEC > 1) {
+        a0 = lo + (int)((VEC - ((base + lo) & (VEC - 1))) & (VEC - 1));
+        if (a0 > hi) a0 = hi;
+        a1 = a0 + ((hi - a0) & ~(VEC - 1));
+        for (int i = a0 + threadIdx.x * VEC; i < a1; i += 256 * VEC) vec(i);
+    }
+    const int nh = a0 - lo, nt = hi - a1;
+    for (int j = threadIdx.x; j < nh + nt; j += 256) scalar(j < nh ? lo + j : a1 + (j - nh));
+}
+
 // ---- statistics: one workgroup per (sample, channel) plane -> (mean, M2) of the plane; gn_row_finish merges the
 // planes of a group with Chan's formula in channel order (no E[x^2] - E[x]^2 cancellation, deterministic).
 // Planes are cut into S slices of `sl` elements (blockIdx.y) so that few-channel, high-resolution tensors (the decoder's
@@ -49,23 +82,24 @@ __global__ __launch_bounds__(256) void gn_plane_stats_kernel(float* __restrict__
                                                              int sl) {
     __shared__ float red[4];
     const int lo = blockIdx.y * sl, hi = min(hw, lo + sl);
-    const TI* pl = x + (int64_t)blockIdx.x * hw;
+    const int64_t base = (int64_t)blockIdx.x * hw;
+    const TI* pl = x + base;
     float s = 0.f;
-    for (int i = lo + threadIdx.x * VEC; i < hi; i += 256 * VEC) {
+    gn_span<VEC>(base, lo, hi, [&](int i) { s += sis_ld(pl, i); }, [&](int i) {
         float v[VEC];
         gn_load<VEC>(pl + i, v);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) s += v[e];
-    }
+    });
     const float cnt = (float)(hi - lo);
     const float mean = gn_block_sum(s, red) / cnt;
     float m2 = 0.f;
-    for (int i = lo + threadIdx.x * VEC; i < hi; i += 256 * VEC) {
+    gn_span<VEC>(base, lo, hi, [&](int i) { const float d = sis_ld(pl, i) - mean; m2 += d * d; }, [&](int i) {
         float v[VEC];
         gn_load<VEC>(pl + i, v);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { const float d = v[e] - mean; m2 += d * d; }
-    }
+    });
     m2 = gn_block_sum(m2, red);
     if (threadIdx.x == 0) {
         float* o = part + 3 * ((int64_t)blockIdx.x * gridDim.y + blockIdx.y);
@@ -98,24 +132,31 @@ __global__ __launch_bounds__(64) void gn_row_finish_kernel(float* __restrict__ m
     }
 }
 
-// y = relu?(x * a[plane] + b[plane]); VEC elements per lane (VEC = 4 when hw % 4 == 0: planes stay vector-aligned)
-template <typename TI, typename TO, int VEC>
+// y = relu?(x * a[plane] + b[plane] (+ residual)); VEC elements per lane.  FLAT: hw is not a multiple of VEC, a lane's
+// vector may straddle two planes (VEC <= hw: at most one boundary) and picks its coefficients per element.
+template <typename TI, typename TO, int VEC, bool FLAT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(TO* __restrict__ y, const TI* __restrict__ x,
                                                        const float* __restrict__ ab, const float* __restrict__ res, int hw,
                                                        int64_t total, int relu) {
     const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < total; i += stride) {
         const int64_t plane = i / hw;
-        const float a = ab[2 * plane], b = ab[2 * plane + 1];
-        float xv[VEC];
+        const int rem = FLAT ? (int)(i - plane * hw) : 0;
+        const float a0 = ab[2 * plane], b0 = ab[2 * plane + 1];
+        float a1 = a0, b1 = b0;
+        if (FLAT && rem + VEC > hw) { a1 = ab[2 * plane + 2]; b1 = ab[2 * plane + 3]; }
+        float xv[VEC], rv[VEC], out[VEC];
         gn_load<VEC>(x + i, xv);
+        if (res) gn_load<VEC>(res + i, rv);  // residual sum of a bottleneck (fp32), before the ReLU
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            float v = xv[e] * a + b;
-            if (res) v += res[i + e];  // residual sum of a bottleneck (fp32), before the ReLU
+            const bool nx = FLAT && rem + e >= hw;
+            float v = xv[e] * (nx ? a1 : a0) + (nx ? b1 : b0);
+            if (res) v += rv[e];
             if (relu) v = fmaxf(v, 0.f);
-            sis_st(y, i + e, v);
+            out[e] = v;
         }
+        gn_store<VEC>(y + i, out);
     }
 }
 
@@ -133,20 +174,22 @@ __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ p
     const float mean = mean_in[row], rstd = rstd_in[row], gm = gamma[c], bt = beta[c];
     const TI* px = x + plane * hw;
     const TG* pg = g + plane * hw;
+    const float* pm = ymask ? ymask + plane * hw : nullptr;
     const int lo = blockIdx.y * sl, hi = min(hw, lo + sl);
     float sg = 0.f, sgx = 0.f;
-    for (int i = lo + threadIdx.x * VEC; i < hi; i += 256 * VEC) {
-        float xv[VEC], gv[VEC];
+    auto one = [&](float xe, float ge, float me) {
+        const float xh = (xe - mean) * rstd;
+        if (relu && (pm ? me <= 0.f : xh * gm + bt <= 0.f)) ge = 0.f;
+        sg += ge; sgx += ge * xh;
+    };
+    gn_span<VEC>(plane * hw, lo, hi, [&](int i) { one(sis_ld(px, i), sis_ld(pg, i), pm ? pm[i] : 1.f); }, [&](int i) {
+        float xv[VEC], gv[VEC], mv[VEC];
         gn_load<VEC>(px + i, xv);
         gn_load<VEC>(pg + i, gv);
+        if (pm) gn_load<VEC>(pm + i, mv);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const float xh = (xv[e] - mean) * rstd;
-            float gi = gv[e];
-            if (relu && (ymask ? ymask[plane * hw + i + e] <= 0.f : xh * gm + bt <= 0.f)) gi = 0.f;
-            sg += gi; sgx += gi * xh;
-        }
-    }
+        for (int e = 0; e < VEC; ++e) one(xv[e], gv[e], pm ? mv[e] : 1.f);
+    });
     sg = gn_block_sum(sg, red);
     sgx = gn_block_sum(sgx, red);
     if (threadIdx.x == 0) {
@@ -181,31 +224,41 @@ __global__ __launch_bounds__(64) void gn_bwd_row_kernel(float* __restrict__ coef
     }
 }
 
-template <typename TI, typename TG, int VEC>
+template <typename TI, typename TG, int VEC, bool FLAT>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(TI* __restrict__ dx, const TG* __restrict__ g,
                                                            const TI* __restrict__ x, const float* __restrict__ coef,
                                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ ymask, float* __restrict__ dres, int C,
                                                            int cpg, int hw, int64_t total, int relu) {
+    struct PlaneCoef { float mean, rstd, gm, bt, k1, k2, k3; };
+    auto coefs = [&](int64_t plane) {
+        const int c = (int)(plane % C);
+        const int64_t row = cpg > 0 ? plane / cpg : c;
+        return PlaneCoef{mean_in[row], rstd_in[row], gamma[c], beta[c], coef[3 * plane], coef[3 * plane + 1], coef[3 * plane + 2]};
+    };
     const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < total; i += stride) {
         const int64_t plane = i / hw;
-        const int c = (int)(plane % C);
-        const int64_t row = cpg > 0 ? plane / cpg : c;
-        const float mean = mean_in[row], rstd = rstd_in[row], gm = gamma[c], bt = beta[c];
-        const float k1 = coef[3 * plane], k2 = coef[3 * plane + 1], k3 = coef[3 * plane + 2];
-        float xv[VEC], gv[VEC];
+        const int rem = FLAT ? (int)(i - plane * hw) : 0;
+        const PlaneCoef p0 = coefs(plane);
+        PlaneCoef p1 = p0;
+        if (FLAT && rem + VEC > hw) p1 = coefs(plane + 1);
+        float xv[VEC], gv[VEC], mv[VEC], dxv[VEC], drv[VEC];
         gn_load<VEC>(x + i, xv);
         gn_load<VEC>(g + i, gv);
+        if (ymask) gn_load<VEC>(ymask + i, mv);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            const float xh = (xv[e] - mean) * rstd;
+            const PlaneCoef& p = (FLAT && rem + e >= hw) ? p1 : p0;
+            const float xh = (xv[e] - p.mean) * p.rstd;
             float gi = gv[e];
-            if (relu && (ymask ? ymask[i + e] <= 0.f : xh * gm + bt <= 0.f)) gi = 0.f;
-            if (dres) dres[i + e] = gi;  // gradient of the residual branch = masked incoming gradient
-            sis_st(dx, i + e, k1 * gi - k2 - k3 * xh);
+            if (relu && (ymask ? mv[e] <= 0.f : xh * p.gm + p.bt <= 0.f)) gi = 0.f;
+            drv[e] = gi;  // gradient of the residual branch = masked incoming gradient
+            dxv[e] = p.k1 * gi - p.k2 - p.k3 * xh;
         }
+        if (dres) gn_store<VEC>(dres + i, drv);
+        gn_store<VEC>(dx + i, dxv);
     }
 }
 
@@ -275,26 +328,54 @@ inline unsigned gn_grid(int64_t total, int vec) {
     return (unsigned)(blocks < 16384 ? (blocks > 0 ? blocks : 1) : 16384);
 }
 
+inline bool gn_aligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// element-wise kernels: 4 per lane when planes are vector-aligned (hw % 4 == 0) or, failing that, when the flat tensor is
+// (FLAT: per-element plane lookup); plane kernels: 4 per lane with head / tail peeling whenever the base pointers are aligned
+#define GN_DISPATCH_APPLY(KERNEL, T1, T2, ok4, ...)                                                                            \
+    do {                                                                                                                       \
+        if ((ok4) && hw % 4 == 0)                                                                                              \
+            hipLaunchKernelGGL((KERNEL<T1, T2, 4, false>), dim3(gn_grid(total, 4)), dim3(256), 0, st, __VA_ARGS__);            \
+        else if ((ok4) && total % 4 == 0 && hw >= 4)                                                                           \
+            hipLaunchKernelGGL((KERNEL<T1, T2, 4, true>), dim3(gn_grid(total, 4)), dim3(256), 0, st, __VA_ARGS__);             \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((KERNEL<T1, T2, 1, false>), dim3(gn_grid(total, 1)), dim3(256), 0, st, __VA_ARGS__);            \
+    } while (0)
+
+template <typename TI>
+void gn_launch_stats(float* part, const void* x, int64_t planes, int hw, hipStream_t st) {
+    const int S = gn_slices(hw), sl = gn_slice_len(hw);
+    if (gn_aligned(x))
+        hipLaunchKernelGGL((gn_plane_stats_kernel<TI, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl);
+    else
+        hipLaunchKernelGGL((gn_plane_stats_kernel<TI, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl);
+}
+
+template <typename TI, typename TG>
+void gn_launch_bwd_plane(float* part, const void* g, const void* x, const float* mean, const float* rstd, const float* gamma,
+                         const float* beta, const float* ymask, int64_t planes, int C, int cpg, int hw, int relu, hipStream_t st) {
+    const int S = gn_slices(hw), sl = gn_slice_len(hw);
+    if (gn_aligned(x) && gn_aligned(g) && gn_aligned(ymask))
+        hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
+                           (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu);
+    else
+        hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
+                           (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu);
+}
+
 template <typename TI, typename TO>
 void gn_fwd_run(void* y, float* mean, float* rstd, float* ws, const void* x, const float* res, const float* gamma,
                 const float* beta, int batch, int C, int hw, int groups, float eps, int relu, hipStream_t st) {
     const int cpg = C / groups, rows = batch * groups;
     const int64_t planes = (int64_t)batch * C, total = planes * hw;
-    const int S = gn_slices(hw), sl = gn_slice_len(hw);
+    const int S = gn_slices(hw);
     float* ab = ws;                // [planes][2]
     float* part = ws + 5 * planes; // [planes][S][3]
-    if (hw % 4 == 0)
-        hipLaunchKernelGGL((gn_plane_stats_kernel<TI, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl);
-    else
-        hipLaunchKernelGGL((gn_plane_stats_kernel<TI, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl);
+    gn_launch_stats<TI>(part, x, planes, hw, st);
     hipLaunchKernelGGL(gn_row_finish_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, mean, rstd, ab, part, gamma, beta, rows,
                        groups, cpg, S, eps);
-    if (hw % 4 == 0)
-        hipLaunchKernelGGL((gn_apply_kernel<TI, TO, 4>), dim3(gn_grid(total, 4)), dim3(256), 0, st, (TO*)y, (const TI*)x, ab, res, hw,
-                           total, relu);
-    else
-        hipLaunchKernelGGL((gn_apply_kernel<TI, TO, 1>), dim3(gn_grid(total, 1)), dim3(256), 0, st, (TO*)y, (const TI*)x, ab, res, hw,
-                           total, relu);
+    GN_DISPATCH_APPLY(gn_apply_kernel, TI, TO, gn_aligned(x) && gn_aligned(y) && gn_aligned(res), (TO*)y, (const TI*)x, ab, res, hw,
+                      total, relu);
 }
 
 template <typename TI, typename TG>
@@ -303,25 +384,16 @@ void gn_bwd_run(void* dx, float* dres, float* dgamma, float* dbeta, float* ws, c
                 int hw, int groups, int relu, hipStream_t st) {
     const int cpg = C / groups, rows = batch * groups;
     const int64_t planes = (int64_t)batch * C, total = planes * hw;
-    const int S = gn_slices(hw), sl = gn_slice_len(hw);
+    const int S = gn_slices(hw);
     float* psum = ws;              // [planes][2]
     float* coef = ws + 2 * planes; // [planes][3]
     float* part = ws + 5 * planes; // [planes][S][2]
-    if (hw % 4 == 0) {
-    hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
-                       (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu);
-    } else {
-    hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
-                       (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu);
-    }
+    gn_launch_bwd_plane<TI, TG>(part, g, x, mean, rstd, gamma, beta, ymask, planes, C, cpg, hw, relu, st);
     hipLaunchKernelGGL(gn_bwd_row_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, coef, psum, part, rstd, gamma, rows, groups,
                        cpg, hw, S);
-    if (hw % 4 == 0)
-        hipLaunchKernelGGL((gn_bwd_apply_kernel<TI, TG, 4>), dim3(gn_grid(total, 4)), dim3(256), 0, st, (TI*)dx, (const TG*)g,
-                           (const TI*)x, coef, mean, rstd, gamma, beta, ymask, dres, C, cpg, hw, total, relu);
-    else
-        hipLaunchKernelGGL((gn_bwd_apply_kernel<TI, TG, 1>), dim3(gn_grid(total, 1)), dim3(256), 0, st, (TI*)dx, (const TG*)g,
-                           (const TI*)x, coef, mean, rstd, gamma, beta, ymask, dres, C, cpg, hw, total, relu);
+    GN_DISPATCH_APPLY(gn_bwd_apply_kernel, TI, TG,
+                      gn_aligned(dx) && gn_aligned(g) && gn_aligned(x) && gn_aligned(ymask) && gn_aligned(dres), (TI*)dx,
+                      (const TG*)g, (const TI*)x, coef, mean, rstd, gamma, beta, ymask, dres, C, cpg, hw, total, relu);
     hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(sis_cdiv(C, 256)), dim3(256), 0, st, dgamma, dbeta, psum, batch, C);
 }
 
@@ -330,45 +402,29 @@ void bn_fwd_run(void* y, float* mean, float* rstd, float* rm, float* rv, float* 
                 const float* beta, int batch, int C, int hw, float eps, float momentum, int relu, hipStream_t st) {
     const float* res = nullptr;
     const int64_t planes = (int64_t)batch * C, total = planes * hw;
-    const int S = gn_slices(hw), sl = gn_slice_len(hw);
+    const int S = gn_slices(hw);
     float* ab = ws;
     float* part = ws + 5 * planes;
-    if (hw % 4 == 0)
-        hipLaunchKernelGGL((gn_plane_stats_kernel<TI, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl);
-    else
-        hipLaunchKernelGGL((gn_plane_stats_kernel<TI, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl);
+    gn_launch_stats<TI>(part, x, planes, hw, st);
     hipLaunchKernelGGL(bn_chan_finish_kernel, dim3(sis_cdiv(C, 64)), dim3(64), 0, st, mean, rstd, ab, rm, rv, part, gamma, beta,
                        batch, C, S, eps, momentum);
-    if (hw % 4 == 0)
-        hipLaunchKernelGGL((gn_apply_kernel<TI, TO, 4>), dim3(gn_grid(total, 4)), dim3(256), 0, st, (TO*)y, (const TI*)x, ab, res, hw,
-                           total, relu);
-    else
-        hipLaunchKernelGGL((gn_apply_kernel<TI, TO, 1>), dim3(gn_grid(total, 1)), dim3(256), 0, st, (TO*)y, (const TI*)x, ab, res, hw,
-                           total, relu);
+    GN_DISPATCH_APPLY(gn_apply_kernel, TI, TO, gn_aligned(x) && gn_aligned(y), (TO*)y, (const TI*)x, ab, res, hw, total, relu);
 }
 
 template <typename TI, typename TG>
 void bn_bwd_run(void* dx, float* dgamma, float* dbeta, float* ws, const void* g, const void* x, const float* mean,
                 const float* rstd, const float* gamma, const float* beta, int batch, int C, int hw, int relu, hipStream_t st) {
     const int64_t planes = (int64_t)batch * C, total = planes * hw;
-    const int S = gn_slices(hw), sl = gn_slice_len(hw);
+    const int S = gn_slices(hw);
     float* coef = ws + 2 * planes;
     float* part = ws + 5 * planes;
-    if (hw % 4 == 0) {
-    hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
-                       (const TI*)x, mean, rstd, gamma, beta, nullptr, C, 0, hw, sl, relu);
-    } else {
-    hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
-                       (const TI*)x, mean, rstd, gamma, beta, nullptr, C, 0, hw, sl, relu);
-    }
+    const float* none = nullptr;
+    float* no_dres = nullptr;
+    gn_launch_bwd_plane<TI, TG>(part, g, x, mean, rstd, gamma, beta, none, planes, C, 0, hw, relu, st);
     hipLaunchKernelGGL(bn_bwd_chan_kernel, dim3(sis_cdiv(C, 64)), dim3(64), 0, st, coef, dgamma, dbeta, part, rstd, gamma, batch,
                        C, hw, S);
-    if (hw % 4 == 0)
-        hipLaunchKernelGGL((gn_bwd_apply_kernel<TI, TG, 4>), dim3(gn_grid(total, 4)), dim3(256), 0, st, (TI*)dx, (const TG*)g,
-                           (const TI*)x, coef, mean, rstd, gamma, beta, nullptr, nullptr, C, 0, hw, total, relu);
-    else
-        hipLaunchKernelGGL((gn_bwd_apply_kernel<TI, TG, 1>), dim3(gn_grid(total, 1)), dim3(256), 0, st, (TI*)dx, (const TG*)g,
-                           (const TI*)x, coef, mean, rstd, gamma, beta, nullptr, nullptr, C, 0, hw, total, relu);
+    GN_DISPATCH_APPLY(gn_bwd_apply_kernel, TI, TG, gn_aligned(dx) && gn_aligned(g) && gn_aligned(x), (TI*)dx, (const TG*)g,
+                      (const TI*)x, coef, mean, rstd, gamma, beta, none, no_dres, C, 0, hw, total, relu);
 }
 
 }  // namespace

@@ -66,7 +66,7 @@ def test_weight_standardisation(device, shape):
 
 
 @pytest.mark.parametrize("shape,groups,relu", [((2, 64, 16, 16), 32, True), ((3, 256, 7, 9), 32, False), ((2, 96, 5, 5), 96, True),
-                                               ((1, 64, 127, 127), 32, True)])
+                                               ((1, 64, 127, 127), 32, True), ((1, 6, 5, 5), 3, True)])
 def test_group_norm_relu(device, shape, groups, relu):
     """csrc/group_norm.hip against F.group_norm (+ relu) in float64, fp32 and bf16 tensors, both directions."""
     import sis_hip
@@ -135,11 +135,13 @@ def test_batch_norm_train_relu(device, shape, relu):
     np.testing.assert_allclose(yb.float().cpu().numpy(), ref.detach().float().cpu().numpy(), rtol=3e-2, atol=3e-2)
 
 
-def test_group_norm_residual_relu(device):
-    """y = relu(group_norm(x) + residual) in one pass (bottleneck tail), bf16 x, fp32 residual / output / gradients."""
+@pytest.mark.parametrize("shape", [(2, 64, 12, 12), (2, 64, 9, 7), (1, 64, 3, 3)])
+def test_group_norm_residual_relu(device, shape):
+    """y = relu(group_norm(x) + residual) in one pass (bottleneck tail), bf16 x, fp32 residual / output / gradients;
+    odd planes take the flat-vector kernels (a lane's 4 elements straddle two planes) or, total % 4 != 0, the scalar ones."""
     import sis_hip
     g = torch.Generator().manual_seed(9)
-    shape, groups = (2, 64, 12, 12), 32
+    groups = 32
     x = (torch.randn(*shape, generator=g) * 2).to(device).bfloat16()
     res = torch.randn(*shape, generator=g).to(device)
     gamma = (1 + 0.2 * torch.randn(64, generator=g)).to(device)
