@@ -260,13 +260,16 @@ int sis_weight_std_bwd(float* dw, const void* grad_w_hat, const float* w, const 
  * residual (float32, may be NULL; needs y_dtype = SIS_F32): y = relu?(norm(x) + residual), the bottleneck's shortcut sum.
  * bwd: dx (x_dtype), dgamma / dbeta [C]; grad_y in g_dtype (= x_dtype or SIS_F32); the ReLU mask is recomputed from x, or
  *      taken from y_mask (the saved float32 output) when a residual was added; dresidual (float32, may be NULL) = masked grad;
- *      workspace (both directions): sis_group_norm_workspace_floats(B, C, hw) floats. */
+ *      workspace (both directions): sis_group_norm_workspace_floats(B, C, hw) floats.
+ *      y_lp (may be NULL; needs a float32 y of a 16-bit x): the same output also rounded to x's dtype in the same pass --
+ *      the fp32 residual stream and the 16-bit tensor the next convolution reads; grad_y_lp (may be NULL): the gradient
+ *      that came back through that copy, added to grad_y on load. */
 int64_t sis_group_norm_workspace_floats(int batch, int channels, int hw);
-int sis_group_norm_fwd(void* y, float* mean, float* rstd, float* workspace, const void* x, const float* residual,
+int sis_group_norm_fwd(void* y, void* y_lp, float* mean, float* rstd, float* workspace, const void* x, const float* residual,
                        const float* gamma, const float* beta, int x_dtype, int y_dtype, int batch, int channels, int hw,
                        int groups, float eps, int relu, void* stream);
 int sis_group_norm_bwd(void* dx, float* dresidual, float* dgamma, float* dbeta, float* workspace, const void* grad_y,
-                       const void* x, const float* y_mask, const float* mean, const float* rstd, const float* gamma,
+                       const void* grad_y_lp, const void* x, const float* y_mask, const float* mean, const float* rstd, const float* gamma,
                        const float* beta, int x_dtype, int g_dtype, int batch, int channels, int hw, int groups, int relu,
                        void* stream);
 /* nn.BatchNorm2d in training mode (+ optional ReLU) with 16-bit or fp32 tensors -- the TransUNet decoder's Conv2dReLU

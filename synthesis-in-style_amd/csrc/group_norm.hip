@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64) void gn_row_finish_kernel(float* __restrict__ m
 // y = relu?(x * a[plane] + b[plane] (+ residual)); VEC elements per lane.  FLAT: hw is not a multiple of VEC, a lane's
 // vector may straddle two planes (VEC <= hw: at most one boundary) and picks its coefficients per element.
 template <typename TI, typename TO, int VEC, bool FLAT>
-__global__ __launch_bounds__(256) void gn_apply_kernel(TO* __restrict__ y, const TI* __restrict__ x,
+__global__ __launch_bounds__(256) void gn_apply_kernel(TO* __restrict__ y, TI* __restrict__ y_lp, const TI* __restrict__ x,
                                                        const float* __restrict__ ab, const float* __restrict__ res, int hw,
                                                        int64_t total, int relu) {
     const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
@@ -157,13 +157,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(TO* __restrict__ y, const
             out[e] = v;
         }
         gn_store<VEC>(y + i, out);
+        if (y_lp) gn_store<VEC>(y_lp + i, out);  // the same values rounded to the convolutions' dtype (what autocast would cast to)
     }
 }
 
 // ---- backward.  g' = g * [y > 0] (mask recomputed: y = x*a + b).  Per plane: sum(g'), sum(g' * xhat).
 template <typename TI, typename TG, int VEC>
 __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ part, const TG* __restrict__ g,
-                                                           const TI* __restrict__ x, const float* __restrict__ mean_in,
+                                                           const TI* __restrict__ g_lp, const TI* __restrict__ x, const float* __restrict__ mean_in,
                                                            const float* __restrict__ rstd_in, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ ymask, int C,
                                                            int cpg, int hw, int sl, int relu) {
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ p
     const float mean = mean_in[row], rstd = rstd_in[row], gm = gamma[c], bt = beta[c];
     const TI* px = x + plane * hw;
     const TG* pg = g + plane * hw;
+    const TI* pg2 = g_lp ? g_lp + plane * hw : nullptr;  // gradient that arrived through the 16-bit copy of the output
     const float* pm = ymask ? ymask + plane * hw : nullptr;
     const int lo = blockIdx.y * sl, hi = min(hw, lo + sl);
     float sg = 0.f, sgx = 0.f;
@@ -182,13 +184,16 @@ __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ p
         if (relu && (pm ? me <= 0.f : xh * gm + bt <= 0.f)) ge = 0.f;
         sg += ge; sgx += ge * xh;
     };
-    gn_span<VEC>(plane * hw, lo, hi, [&](int i) { one(sis_ld(px, i), sis_ld(pg, i), pm ? pm[i] : 1.f); }, [&](int i) {
-        float xv[VEC], gv[VEC], mv[VEC];
+    gn_span<VEC>(plane * hw, lo, hi, [&](int i) {
+        one(sis_ld(px, i), sis_ld(pg, i) + (pg2 ? sis_ld(pg2, i) : 0.f), pm ? pm[i] : 1.f);
+    }, [&](int i) {
+        float xv[VEC], gv[VEC], g2[VEC], mv[VEC];
         gn_load<VEC>(px + i, xv);
         gn_load<VEC>(pg + i, gv);
+        if (pg2) gn_load<VEC>(pg2 + i, g2);
         if (pm) gn_load<VEC>(pm + i, mv);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) one(xv[e], gv[e], pm ? mv[e] : 1.f);
+        for (int e = 0; e < VEC; ++e) one(xv[e], gv[e] + (pg2 ? g2[e] : 0.f), pm ? mv[e] : 1.f);
     });
     sg = gn_block_sum(sg, red);
     sgx = gn_block_sum(sgx, red);
@@ -226,7 +231,8 @@ __global__ __launch_bounds__(64) void gn_bwd_row_kernel(float* __restrict__ coef
 
 template <typename TI, typename TG, int VEC, bool FLAT>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(TI* __restrict__ dx, const TG* __restrict__ g,
-                                                           const TI* __restrict__ x, const float* __restrict__ coef,
+                                                           const TI* __restrict__ g_lp, const TI* __restrict__ x,
+                                                           const float* __restrict__ coef,
                                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ ymask, float* __restrict__ dres, int C,
@@ -244,15 +250,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(TI* __restrict__ dx, 
         const PlaneCoef p0 = coefs(plane);
         PlaneCoef p1 = p0;
         if (FLAT && rem + VEC > hw) p1 = coefs(plane + 1);
-        float xv[VEC], gv[VEC], mv[VEC], dxv[VEC], drv[VEC];
+        float xv[VEC], gv[VEC], g2[VEC], mv[VEC], dxv[VEC], drv[VEC];
         gn_load<VEC>(x + i, xv);
         gn_load<VEC>(g + i, gv);
+        if (g_lp) gn_load<VEC>(g_lp + i, g2);
         if (ymask) gn_load<VEC>(ymask + i, mv);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const PlaneCoef& p = (FLAT && rem + e >= hw) ? p1 : p0;
             const float xh = (xv[e] - p.mean) * p.rstd;
-            float gi = gv[e];
+            float gi = gv[e] + (g_lp ? g2[e] : 0.f);
             if (relu && (ymask ? mv[e] <= 0.f : xh * p.gm + p.bt <= 0.f)) gi = 0.f;
             drv[e] = gi;  // gradient of the residual branch = masked incoming gradient
             dxv[e] = p.k1 * gi - p.k2 - p.k3 * xh;
@@ -352,19 +359,19 @@ void gn_launch_stats(float* part, const void* x, int64_t planes, int hw, hipStre
 }
 
 template <typename TI, typename TG>
-void gn_launch_bwd_plane(float* part, const void* g, const void* x, const float* mean, const float* rstd, const float* gamma,
+void gn_launch_bwd_plane(float* part, const void* g, const void* g_lp, const void* x, const float* mean, const float* rstd, const float* gamma,
                          const float* beta, const float* ymask, int64_t planes, int C, int cpg, int hw, int relu, hipStream_t st) {
     const int S = gn_slices(hw), sl = gn_slice_len(hw);
-    if (gn_aligned(x) && gn_aligned(g) && gn_aligned(ymask))
+    if (gn_aligned(x) && gn_aligned(g) && gn_aligned(g_lp) && gn_aligned(ymask))
         hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
-                           (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu);
+                           (const TI*)g_lp, (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu);
     else
         hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
-                           (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu);
+                           (const TI*)g_lp, (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu);
 }
 
 template <typename TI, typename TO>
-void gn_fwd_run(void* y, float* mean, float* rstd, float* ws, const void* x, const float* res, const float* gamma,
+void gn_fwd_run(void* y, void* y_lp, float* mean, float* rstd, float* ws, const void* x, const float* res, const float* gamma,
                 const float* beta, int batch, int C, int hw, int groups, float eps, int relu, hipStream_t st) {
     const int cpg = C / groups, rows = batch * groups;
     const int64_t planes = (int64_t)batch * C, total = planes * hw;
@@ -374,12 +381,12 @@ void gn_fwd_run(void* y, float* mean, float* rstd, float* ws, const void* x, con
     gn_launch_stats<TI>(part, x, planes, hw, st);
     hipLaunchKernelGGL(gn_row_finish_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, mean, rstd, ab, part, gamma, beta, rows,
                        groups, cpg, S, eps);
-    GN_DISPATCH_APPLY(gn_apply_kernel, TI, TO, gn_aligned(x) && gn_aligned(y) && gn_aligned(res), (TO*)y, (const TI*)x, ab, res, hw,
-                      total, relu);
+    GN_DISPATCH_APPLY(gn_apply_kernel, TI, TO, gn_aligned(x) && gn_aligned(y) && gn_aligned(y_lp) && gn_aligned(res), (TO*)y,
+                      (TI*)y_lp, (const TI*)x, ab, res, hw, total, relu);
 }
 
 template <typename TI, typename TG>
-void gn_bwd_run(void* dx, float* dres, float* dgamma, float* dbeta, float* ws, const void* g, const void* x,
+void gn_bwd_run(void* dx, float* dres, float* dgamma, float* dbeta, float* ws, const void* g, const void* g_lp, const void* x,
                 const float* ymask, const float* mean, const float* rstd, const float* gamma, const float* beta, int batch, int C,
                 int hw, int groups, int relu, hipStream_t st) {
     const int cpg = C / groups, rows = batch * groups;
@@ -388,12 +395,12 @@ void gn_bwd_run(void* dx, float* dres, float* dgamma, float* dbeta, float* ws, c
     float* psum = ws;              // [planes][2]
     float* coef = ws + 2 * planes; // [planes][3]
     float* part = ws + 5 * planes; // [planes][S][2]
-    gn_launch_bwd_plane<TI, TG>(part, g, x, mean, rstd, gamma, beta, ymask, planes, C, cpg, hw, relu, st);
+    gn_launch_bwd_plane<TI, TG>(part, g, g_lp, x, mean, rstd, gamma, beta, ymask, planes, C, cpg, hw, relu, st);
     hipLaunchKernelGGL(gn_bwd_row_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, coef, psum, part, rstd, gamma, rows, groups,
                        cpg, hw, S);
     GN_DISPATCH_APPLY(gn_bwd_apply_kernel, TI, TG,
-                      gn_aligned(dx) && gn_aligned(g) && gn_aligned(x) && gn_aligned(ymask) && gn_aligned(dres), (TI*)dx,
-                      (const TG*)g, (const TI*)x, coef, mean, rstd, gamma, beta, ymask, dres, C, cpg, hw, total, relu);
+                      gn_aligned(dx) && gn_aligned(g) && gn_aligned(g_lp) && gn_aligned(x) && gn_aligned(ymask) && gn_aligned(dres),
+                      (TI*)dx, (const TG*)g, (const TI*)g_lp, (const TI*)x, coef, mean, rstd, gamma, beta, ymask, dres, C, cpg, hw, total, relu);
     hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(sis_cdiv(C, 256)), dim3(256), 0, st, dgamma, dbeta, psum, batch, C);
 }
 
@@ -408,7 +415,8 @@ void bn_fwd_run(void* y, float* mean, float* rstd, float* rm, float* rv, float* 
     gn_launch_stats<TI>(part, x, planes, hw, st);
     hipLaunchKernelGGL(bn_chan_finish_kernel, dim3(sis_cdiv(C, 64)), dim3(64), 0, st, mean, rstd, ab, rm, rv, part, gamma, beta,
                        batch, C, S, eps, momentum);
-    GN_DISPATCH_APPLY(gn_apply_kernel, TI, TO, gn_aligned(x) && gn_aligned(y), (TO*)y, (const TI*)x, ab, res, hw, total, relu);
+    GN_DISPATCH_APPLY(gn_apply_kernel, TI, TO, gn_aligned(x) && gn_aligned(y), (TO*)y, (TI*)nullptr, (const TI*)x, ab, res, hw, total,
+                      relu);
 }
 
 template <typename TI, typename TG>
@@ -420,11 +428,11 @@ void bn_bwd_run(void* dx, float* dgamma, float* dbeta, float* ws, const void* g,
     float* part = ws + 5 * planes;
     const float* none = nullptr;
     float* no_dres = nullptr;
-    gn_launch_bwd_plane<TI, TG>(part, g, x, mean, rstd, gamma, beta, none, planes, C, 0, hw, relu, st);
+    gn_launch_bwd_plane<TI, TG>(part, g, nullptr, x, mean, rstd, gamma, beta, none, planes, C, 0, hw, relu, st);
     hipLaunchKernelGGL(bn_bwd_chan_kernel, dim3(sis_cdiv(C, 64)), dim3(64), 0, st, coef, dgamma, dbeta, part, rstd, gamma, batch,
                        C, hw, S);
     GN_DISPATCH_APPLY(gn_bwd_apply_kernel, TI, TG, gn_aligned(dx) && gn_aligned(g) && gn_aligned(x), (TI*)dx, (const TG*)g,
-                      (const TI*)x, coef, mean, rstd, gamma, beta, none, no_dres, C, 0, hw, total, relu);
+                      (const TI*)nullptr, (const TI*)x, coef, mean, rstd, gamma, beta, none, no_dres, C, 0, hw, total, relu);
 }
 
 }  // namespace
@@ -433,7 +441,8 @@ extern "C" int64_t sis_group_norm_workspace_floats(int batch, int channels, int 
     return (int64_t)batch * channels * (5 + 3 * gn_slices(hw));
 }
 
-extern "C" int sis_group_norm_fwd(void* y, float* mean, float* rstd, float* workspace, const void* x, const float* residual,
+extern "C" int sis_group_norm_fwd(void* y, void* y_lp, float* mean, float* rstd, float* workspace, const void* x,
+                                  const float* residual,
                                   const float* gamma, const float* beta, int x_dtype, int y_dtype, int batch, int channels,
                                   int hw, int groups, float eps, int relu, void* stream) {
     if (batch == 0) return 0;
@@ -442,10 +451,12 @@ extern "C" int sis_group_norm_fwd(void* y, float* mean, float* rstd, float* work
                 "sis_group_norm_fwd: bad sizes (C %d, groups %d)", channels, groups);
     SIS_REQUIRE(y_dtype == x_dtype || y_dtype == SIS_F32, "sis_group_norm_fwd: output dtype must be the input's or f32");
     SIS_REQUIRE(!residual || y_dtype == SIS_F32, "sis_group_norm_fwd: a residual needs a float32 output");
+    SIS_REQUIRE(!y_lp || (y_dtype == SIS_F32 && x_dtype != SIS_F32),
+                "sis_group_norm_fwd: the 16-bit copy goes with a float32 output of a 16-bit input");
     hipStream_t st = (hipStream_t)stream;
 #define GN_FWD(TI)                                                                                                       \
-    if (y_dtype == SIS_F32) gn_fwd_run<TI, float>(y, mean, rstd, workspace, x, residual, gamma, beta, batch, channels, hw, groups, eps, relu, st); \
-    else gn_fwd_run<TI, TI>(y, mean, rstd, workspace, x, nullptr, gamma, beta, batch, channels, hw, groups, eps, relu, st);
+    if (y_dtype == SIS_F32) gn_fwd_run<TI, float>(y, y_lp, mean, rstd, workspace, x, residual, gamma, beta, batch, channels, hw, groups, eps, relu, st); \
+    else gn_fwd_run<TI, TI>(y, nullptr, mean, rstd, workspace, x, nullptr, gamma, beta, batch, channels, hw, groups, eps, relu, st);
     switch (x_dtype) {
         case SIS_F32: GN_FWD(float) break;
         case SIS_F16: GN_FWD(__half) break;
@@ -458,7 +469,7 @@ extern "C" int sis_group_norm_fwd(void* y, float* mean, float* rstd, float* work
 }
 
 extern "C" int sis_group_norm_bwd(void* dx, float* dresidual, float* dgamma, float* dbeta, float* workspace, const void* grad_y,
-                                  const void* x, const float* y_mask, const float* mean, const float* rstd, const float* gamma,
+                                  const void* grad_y_lp, const void* x, const float* y_mask, const float* mean, const float* rstd, const float* gamma,
                                   const float* beta, int x_dtype, int g_dtype, int batch, int channels, int hw, int groups,
                                   int relu, void* stream) {
     if (batch == 0) return 0;
@@ -467,10 +478,12 @@ extern "C" int sis_group_norm_bwd(void* dx, float* dresidual, float* dgamma, flo
     SIS_REQUIRE(batch > 0 && channels > 0 && hw > 0 && groups > 0 && channels % groups == 0,
                 "sis_group_norm_bwd: bad sizes (C %d, groups %d)", channels, groups);
     SIS_REQUIRE(g_dtype == x_dtype || g_dtype == SIS_F32, "sis_group_norm_bwd: gradient dtype must be the input's or f32");
+    SIS_REQUIRE(!grad_y_lp || (g_dtype == SIS_F32 && x_dtype != SIS_F32),
+                "sis_group_norm_bwd: the 16-bit gradient goes with a float32 gradient of a 16-bit input");
     hipStream_t st = (hipStream_t)stream;
 #define GN_BWD(TI)                                                                                                        \
-    if (g_dtype == SIS_F32) gn_bwd_run<TI, float>(dx, dresidual, dgamma, dbeta, workspace, grad_y, x, y_mask, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, st); \
-    else gn_bwd_run<TI, TI>(dx, dresidual, dgamma, dbeta, workspace, grad_y, x, y_mask, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, st);
+    if (g_dtype == SIS_F32) gn_bwd_run<TI, float>(dx, dresidual, dgamma, dbeta, workspace, grad_y, grad_y_lp, x, y_mask, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, st); \
+    else gn_bwd_run<TI, TI>(dx, dresidual, dgamma, dbeta, workspace, grad_y, nullptr, x, y_mask, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, st);
     switch (x_dtype) {
         case SIS_F32: GN_BWD(float) break;
         case SIS_F16: GN_BWD(__half) break;

@@ -47,26 +47,32 @@ class _WeightStandardize(Function):
 
 
 _FUSE_RESIDUAL = os.environ.get('SIS_GN_RES', '1') != '0'
+_DUAL_STREAM = os.environ.get('SIS_GN_DUAL', '1') != '0'  # bottlenecks hand (fp32 residual stream, 16-bit copy) to the next one
 
 
 class _GroupNormAct(Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, groups, eps, relu, out_dtype):
-        y, mean, rstd = sis_hip.group_norm_fwd(x, weight, bias, groups, eps, relu, out_dtype, residual)
+    def forward(ctx, x, residual, weight, bias, groups, eps, relu, out_dtype, dual):
+        out = sis_hip.group_norm_fwd(x, weight, bias, groups, eps, relu, out_dtype, residual, low_precision_copy=dual)
+        y, mean, rstd = out[:3]
         ctx.has_residual = residual is not None
         ctx.save_for_backward(x, mean, rstd, weight, bias, y if ctx.has_residual else None)
         ctx.groups, ctx.relu = groups, relu
-        return y
+        ctx.set_materialize_grads(False)  # an unused output of the pair arrives as None, not as a tensor of zeros
+        return (y, out[3]) if dual else y
 
     @staticmethod
-    def backward(ctx, grad):
+    def backward(ctx, grad, grad_lp=None):
         x, mean, rstd, weight, bias, y = ctx.saved_tensors
+        if grad is None:  # only the 16-bit copy was used downstream
+            grad, grad_lp = grad_lp, None
         if ctx.has_residual:
             dx, dgamma, dbeta, dres = sis_hip.group_norm_bwd(grad, x, mean, rstd, weight, bias, ctx.groups, ctx.relu, y_mask=y,
-                                                             want_residual_grad=True)
+                                                             want_residual_grad=True, grad_y_lp=grad_lp)
         else:
-            (dx, dgamma, dbeta), dres = sis_hip.group_norm_bwd(grad, x, mean, rstd, weight, bias, ctx.groups, ctx.relu), None
-        return dx, dres, dgamma, dbeta, None, None, None, None
+            (dx, dgamma, dbeta), dres = sis_hip.group_norm_bwd(grad, x, mean, rstd, weight, bias, ctx.groups, ctx.relu,
+                                                               grad_y_lp=grad_lp), None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None
 
 
 class HipGroupNorm(nn.GroupNorm):
@@ -75,12 +81,16 @@ class HipGroupNorm(nn.GroupNorm):
     cast -> moments -> normalise -> relu -> cast).  ``keep_fp32=True`` returns float32 (the residual sum of a bottleneck
     stays in fp32, as autocast would have it)."""
 
-    def forward(self, x, relu=False, keep_fp32=False, residual=None):
-        """``residual`` (float32): y = relu?(norm(x) + residual) in one pass -- the tail of a bottleneck."""
+    def forward(self, x, relu=False, keep_fp32=False, residual=None, dual=False):
+        """``residual`` (float32): y = relu?(norm(x) + residual) in one pass -- the tail of a bottleneck.  ``dual`` (with a
+        16-bit x and a float32 result): returns ``(y, y rounded to x's dtype)`` -- the fp32 residual stream plus the tensor
+        the next convolutions read, so that autocast has nothing left to cast; the two gradients are summed in the backward
+        kernel's loads."""
         if x.is_cuda and self.affine and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and x.dim() >= 3 \
                 and (residual is None or (residual.dtype == torch.float32 and residual.shape == x.shape)):
             out_dtype = torch.float32 if (keep_fp32 or residual is not None) else x.dtype
-            return _GroupNormAct.apply(x, residual, self.weight, self.bias, self.num_groups, self.eps, relu, out_dtype)
+            dual = bool(dual) and out_dtype == torch.float32 and x.dtype != torch.float32
+            return _GroupNormAct.apply(x, residual, self.weight, self.bias, self.num_groups, self.eps, relu, out_dtype, dual)
         y = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
         if residual is not None:
             y = y + residual
@@ -132,12 +142,14 @@ class PreActBottleneck(nn.Module):
             self.gn_proj = HipGroupNorm(cout, cout)
 
     def forward(self, x):
-        shortcut = self.gn_proj(self.downsample(x), keep_fp32=True) if hasattr(self, 'downsample') else x
-        y = x
-        y = self.gn1(self.conv1(y), relu=True)   # GroupNorm and the ReLU after it in one kernel
+        """``x``: a tensor, or the pair (fp32 residual stream, its 16-bit copy) the previous bottleneck produced under
+        autocast -- the convolutions read the copy, the shortcut stays fp32; returns the same kind of pair when it can."""
+        x_res, x_conv = x if isinstance(x, tuple) else (x, x)
+        shortcut = self.gn_proj(self.downsample(x_conv), keep_fp32=True) if hasattr(self, 'downsample') else x_res
+        y = self.gn1(self.conv1(x_conv), relu=True)   # GroupNorm and the ReLU after it in one kernel
         y = self.gn2(self.conv2(y), relu=True)
         if shortcut.dtype == torch.float32 and _FUSE_RESIDUAL:  # relu(shortcut + gn3(conv3(y))) in one kernel, fp32 residual stream
-            return self.gn3(self.conv3(y), relu=True, residual=shortcut.contiguous())
+            return self.gn3(self.conv3(y), relu=True, residual=shortcut.contiguous(), dual=_DUAL_STREAM)
         return self.relu(shortcut + self.gn3(self.conv3(y), keep_fp32=True))
 
     def load_from(self, weights, n_block, n_unit):
@@ -175,11 +187,13 @@ class ResNetV2(nn.Module):
         skips = [x]
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=0)
         for i, stage in enumerate(self.body):
-            x = stage(x)
+            x = stage(x)  # possibly (fp32, 16-bit) pairs between the units; everything outside the trunk reads the 16-bit copy
+            feat = x[1] if isinstance(x, tuple) else x
             if i == len(self.body) - 1:
+                x = feat
                 break
             want = int(in_size / 4 / (i + 1))
-            short = want - x.size(2)
-            assert 0 <= short < 3, f"x {x.size()} should {want}"
-            skips.append(F.pad(x, (0, short, 0, short)) if short else x)
+            short = want - feat.size(2)
+            assert 0 <= short < 3, f"x {feat.size()} should {want}"
+            skips.append(F.pad(feat, (0, short, 0, short)) if short else feat)
         return x, skips[::-1]

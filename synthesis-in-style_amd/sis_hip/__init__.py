@@ -48,11 +48,11 @@ _SIGNATURES = {
     "sis_layer_norm_fwd": ([_vp] * 6 + [_i, _i, _i, _i, _f, _vp], _i),
     "sis_layer_norm_bwd": ([_vp] * 9 + [_i, _i, _i, _i, _vp], _i),
     "sis_weight_std_fwd": ([_vp, _vp, _vp, _i, _i, _i, _f, _vp], _i),
-    "sis_group_norm_fwd": ([_vp] * 8 + [_i, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
+    "sis_group_norm_fwd": ([_vp] * 9 + [_i, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
     "sis_group_norm_workspace_floats": ([_i, _i, _i], _i64),
     "sis_batch_norm_fwd": ([_vp] * 9 + [_i] * 5 + [_f, _f, _i, _vp], _i),
     "sis_batch_norm_bwd": ([_vp] * 10 + [_i] * 6 + [_vp], _i),
-    "sis_group_norm_bwd": ([_vp] * 12 + [_i] * 7 + [_vp], _i),
+    "sis_group_norm_bwd": ([_vp] * 13 + [_i] * 7 + [_vp], _i),
     "sis_weight_std_bwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp], _i),
     "sis_conv3x3_wgrad_eligible": ([_i] * 5 + [_i64], _i),
     "sis_conv3x3_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
@@ -615,9 +615,11 @@ def layer_norm_bwd(grad_y, x, mean, rstd, gamma):
 # ------------------------------------------------------------------------------ group norm (+ ReLU)
 
 
-def group_norm_fwd(x, gamma, beta, groups, eps, relu, out_dtype=None, residual=None):
+def group_norm_fwd(x, gamma, beta, groups, eps, relu, out_dtype=None, residual=None, low_precision_copy=False):
     """x [B,C,...] (f32 / f16 / bf16) -> (y in ``out_dtype`` (default: x's), mean [B*groups], rstd [B*groups]).
-    ``residual`` (float32, x's shape) is added before the ReLU; the output is then float32."""
+    ``residual`` (float32, x's shape) is added before the ReLU; the output is then float32.
+    ``low_precision_copy`` (16-bit x, float32 y): also returns y rounded to x's dtype, written in the same pass
+    -> (y, mean, rstd, y_lp)."""
     require_device(x, "input")
     x = x.contiguous()
     if residual is not None:
@@ -626,27 +628,35 @@ def group_norm_fwd(x, gamma, beta, groups, eps, relu, out_dtype=None, residual=N
         if residual.shape != x.shape:
             raise RuntimeError("residual must have the input's shape")
     out_dtype = out_dtype or x.dtype
+    if low_precision_copy and not (out_dtype == torch.float32 and x.dtype in (torch.float16, torch.bfloat16)):
+        raise RuntimeError("low_precision_copy needs a float32 output of a 16-bit input")
     b, c = x.shape[0], x.shape[1]
     hw = x[0, 0].numel()
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    y_lp = torch.empty_like(x) if low_precision_copy else None
     mean = torch.empty(b * groups, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
     ws = torch.empty(lib().sis_group_norm_workspace_floats(b, c, hw), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(lib().sis_group_norm_fwd(_ptr(y), _ptr(mean), _ptr(rstd), _ptr(ws), _ptr(x), _ptr(residual),
+        _check(lib().sis_group_norm_fwd(_ptr(y), _ptr(y_lp), _ptr(mean), _ptr(rstd), _ptr(ws), _ptr(x), _ptr(residual),
                                         _ptr(_f32(gamma, "weight")), _ptr(_f32(beta, "bias")), _DTYPE_CODE[x.dtype],
                                         _DTYPE_CODE[out_dtype], b, c, hw, groups, float(eps), int(bool(relu)), _stream()),
                "sis_group_norm_fwd")
-    return y, mean, rstd
+    return (y, mean, rstd, y_lp) if low_precision_copy else (y, mean, rstd)
 
 
-def group_norm_bwd(grad_y, x, mean, rstd, gamma, beta, groups, relu, y_mask=None, want_residual_grad=False):
+def group_norm_bwd(grad_y, x, mean, rstd, gamma, beta, groups, relu, y_mask=None, want_residual_grad=False, grad_y_lp=None):
     """-> (dx, dgamma, dbeta[, dresidual]).  ``y_mask``: the saved float32 output when a residual was added (its sign is
-    the ReLU mask); ``want_residual_grad`` also returns the gradient of the residual branch."""
+    the ReLU mask); ``want_residual_grad`` also returns the gradient of the residual branch; ``grad_y_lp`` (x's 16-bit
+    dtype): the gradient that came back through the low-precision copy of the output, added to ``grad_y`` (float32) on load."""
     x = x.contiguous()
     g = grad_y.contiguous()
     if g.dtype != x.dtype and g.dtype != torch.float32:
         g = g.to(x.dtype)
+    if grad_y_lp is not None:
+        if g.dtype != torch.float32 or grad_y_lp.dtype != x.dtype or x.dtype == torch.float32:
+            raise RuntimeError("grad_y_lp needs a float32 grad_y and the 16-bit dtype of x")
+        grad_y_lp = grad_y_lp.contiguous()
     b, c = x.shape[0], x.shape[1]
     hw = x[0, 0].numel()
     dx = torch.empty_like(x)
@@ -655,9 +665,9 @@ def group_norm_bwd(grad_y, x, mean, rstd, gamma, beta, groups, relu, y_mask=None
     dbeta = torch.empty_like(dgamma)
     ws = torch.empty(lib().sis_group_norm_workspace_floats(b, c, hw), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(lib().sis_group_norm_bwd(_ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _ptr(g), _ptr(x), _ptr(y_mask),
-                                        _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _DTYPE_CODE[x.dtype], _DTYPE_CODE[g.dtype],
-                                        b, c, hw, groups, int(bool(relu)), _stream()), "sis_group_norm_bwd")
+        _check(lib().sis_group_norm_bwd(_ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _ptr(g), _ptr(grad_y_lp), _ptr(x),
+                                        _ptr(y_mask), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _DTYPE_CODE[x.dtype],
+                                        _DTYPE_CODE[g.dtype], b, c, hw, groups, int(bool(relu)), _stream()), "sis_group_norm_bwd")
     return (dx, dgamma, dbeta, dres) if want_residual_grad else (dx, dgamma, dbeta)
 
 

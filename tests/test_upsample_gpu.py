@@ -160,6 +160,14 @@ def test_group_norm_residual_relu(device, shape):
     np.testing.assert_allclose(dx.float().cpu().numpy(), xr.grad.float().cpu().numpy(), rtol=2e-2, atol=1e-2 * scale)
     np.testing.assert_allclose(dg.cpu().numpy(), gr.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(db.cpu().numpy(), br.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-3)
+    # dual output: the same pass also writes y rounded to x's dtype; the gradient arriving through that copy is added on load
+    y2, _, _, y_lp = sis_hip.group_norm_fwd(x, gamma, beta, groups, 1e-6, True, residual=res, low_precision_copy=True)
+    assert torch.equal(y2, y) and y_lp.dtype == x.dtype and torch.equal(y_lp, y.to(x.dtype))
+    g_lp = torch.randn(*shape, generator=g).to(device).bfloat16()
+    got = sis_hip.group_norm_bwd(gy, x, mean, rstd, gamma, beta, groups, True, y_mask=y, want_residual_grad=True, grad_y_lp=g_lp)
+    want = sis_hip.group_norm_bwd(gy + g_lp.float(), x, mean, rstd, gamma, beta, groups, True, y_mask=y, want_residual_grad=True)
+    for u, v in zip(got, want):
+        assert torch.equal(u, v)
 
 
 @pytest.mark.parametrize("rows,n", [(37, 768), (1024, 256), (5, 1024)])
