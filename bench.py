@@ -167,6 +167,8 @@ def bench_training(args, workload, world, rank, device, distributed):
         config["amp"] = None if args.dtype == "f32" else args.dtype
     if args.batch:
         config["batch_size"] = args.batch
+    if args.miopen_search:
+        config["miopen_search"] = True
     loader = SyntheticSegmentationLoader(config["batch_size"], config["image_size"], config["num_classes"],
                                          seed=1234 + rank, device=device)
     torch.manual_seed(0)
@@ -202,7 +204,8 @@ def bench_training(args, workload, world, rank, device, distributed):
                                f"{config['batch_size']} per GPU (BASELINE.json configs[{3 if workload == 'emanet' else 4}])",
                    "batch_per_gpu": config["batch_size"], "image_size": config["image_size"],
                    "parallelism": f"dp{world}, DDP bucketed all-reduce over RCCL",
-                   "hip_graph": bool(getattr(updater, "_step_graph", None) and updater._step_graph.graph is not None)},
+                   "hip_graph": bool(getattr(updater, "_step_graph", None) and updater._step_graph.graph is not None),
+                   "miopen_search": bool(config.get("miopen_search"))},
         "roofline": {"kernel": "whole step, nominal 2*MAC FLOPs (3x3 convolutions on the Winograd HIP kernels in fp32, norms / "
                                "loss / optimizer on HIP kernels, 1x1 convolutions and GEMMs on hipBLASLt, bf16 convolutions on "
                                "MIOpen)", "bound": "mfma",
@@ -356,6 +359,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="training workloads: override the config's amp")
+    ap.add_argument("--miopen-search", action="store_true",
+                    help="training workloads: MIOpen solver search for the library convolutions (minutes at start-up)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
