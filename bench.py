@@ -294,6 +294,8 @@ def bench_gan(args, world, rank, device, distributed):
     from networks.stylegan2.model import Discriminator, Generator
     from updater.stylegan_2_updater import Stylegan2Updater
     batch = args.batch or 24
+    if args.miopen_search:
+        torch.backends.cudnn.benchmark = True
     torch.manual_seed(rank)
     g, g_ema = Generator(256, 512, 8, channel_multiplier=2).to(device), Generator(256, 512, 8, channel_multiplier=2).to(device)
     g_ema.eval()
@@ -345,7 +347,7 @@ def bench_gan(args, world, rank, device, distributed):
                                f"batch {batch} per GPU, Adam (SURVEY.md 8(f) row 4; not a BASELINE.json config)",
                    "batch_per_gpu": batch, "image_size": 256, "parallelism": f"dp{world}",
                    "modconv": "grouped" if os.environ.get("SIS_MODCONV_GROUPED", "0") == "1" else "shared-weight",
-                   "winograd": os.environ.get("SIS_GAN_WINOGRAD", "1") != "0"},
+                   "winograd": os.environ.get("SIS_GAN_WINOGRAD", "1") != "0", "miopen_search": bool(args.miopen_search)},
         "roofline": None,
     }
 
