@@ -463,7 +463,7 @@ def main():
             "metric": METRIC, "value": round(total_images / elapsed, 2), "unit": "images/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "StyleGAN2 Generator(256,512,8,cm=2).forward, batch 32 per GPU, explicit noise, "
+            "config": {"workload": f"StyleGAN2 Generator(256,512,8,cm=2).forward, batch {args.batch} per GPU, explicit noise, "
                                    "return_intermediate_activations=True (BASELINE.json configs[1])",
                        "batch_per_gpu": args.batch, "image_size": SIZE, "parallelism": f"replicated x{n_gpus}, "
                        "images sharded, no collective",
