@@ -27,39 +27,45 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(int64_t* __restrict_
     __syncthreads();
     const int pix = (g * 256 + threadIdx.x) * VEC;
     if (pix >= HW) return;
-    float d[KMAX][VEC];
+    // pixel pairs as 2-wide vectors: the subtract and the fused multiply-add issue as packed fp32 instructions
+    // (v_pk_add_f32 / v_pk_fma_f32: two pixels per lane and instruction), same per-element arithmetic as the scalar form
+    constexpr int NP = VEC >= 2 ? VEC / 2 : 1;
+    typedef float pkf __attribute__((ext_vector_type(VEC >= 2 ? 2 : 1)));
+    pkf d[KMAX][NP];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) d[k][v] = 0.f;
+        for (int v = 0; v < NP; ++v) d[k][v] = (pkf)(0.f);
     const float* xb = x + (int64_t)b * C * HW + pix;
     for (int c = 0; c < C; ++c) {
-        float xv[VEC];
-        if (VEC == 4) {
+        pkf xv[NP];
+        if constexpr (VEC == 4) {
             const float4 t = *reinterpret_cast<const float4*>(xb + (int64_t)c * HW);
-            xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+            xv[0][0] = t.x; xv[0][1] = t.y; xv[1][0] = t.z; xv[1][1] = t.w;
+        } else if constexpr (VEC == 2) {
+            const float2 t = *reinterpret_cast<const float2*>(xb + (int64_t)c * HW);
+            xv[0][0] = t.x; xv[0][1] = t.y;
         } else {
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) xv[v] = xb[(int64_t)c * HW + v];
+            xv[0][0] = xb[(int64_t)c * HW];
         }
         const float* cc = cen + c * KMAX;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
-            const float ck = cc[k];
+            const pkf ck = (pkf)(cc[k]);
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                const float diff = xv[v] - ck;
-                d[k][v] += diff * diff;
+            for (int v = 0; v < NP; ++v) {
+                const pkf diff = xv[v] - ck;
+                d[k][v] = __builtin_elementwise_fma(diff, diff, d[k][v]);
             }
         }
     }
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-        float best = d[0][v];
+        float best = d[0][v / 2][v % 2];
         int arg = 0;
 #pragma unroll
         for (int k = 1; k < KMAX; ++k)
-            if (k < K && d[k][v] < best) { best = d[k][v]; arg = k; }
+            if (k < K && d[k][v / 2][v % 2] < best) { best = d[k][v / 2][v % 2]; arg = k; }
         labels[(int64_t)b * HW + pix + v] = arg;
     }
 }
@@ -105,12 +111,14 @@ extern "C" int sis_kmeans_assign(int64_t* labels, const float* x, const float* c
     SIS_REQUIRE(channels >= 1, "sis_kmeans_assign: no channels");
     hipStream_t st = (hipStream_t)stream;
     const bool vec = hw % 4 == 0 && (((uintptr_t)x) & 15) == 0;
-    if (n_centres <= 16) return vec ? launch_kmeans<16, 4>(labels, x, centres, batch, channels, hw, n_centres, st)
-                                    : launch_kmeans<16, 1>(labels, x, centres, batch, channels, hw, n_centres, st);
-    if (n_centres <= 32) return vec ? launch_kmeans<32, 4>(labels, x, centres, batch, channels, hw, n_centres, st)
-                                    : launch_kmeans<32, 1>(labels, x, centres, batch, channels, hw, n_centres, st);
-    return hw % 2 == 0 ? launch_kmeans<64, 2>(labels, x, centres, batch, channels, hw, n_centres, st)
-                       : launch_kmeans<64, 1>(labels, x, centres, batch, channels, hw, n_centres, st);
+    // accumulators for the centre count rounded up to a multiple of 8 (the reference config's 24 centres: no padded work)
+#define KM_CASE(KM)                                                                                                      \
+    if (n_centres <= KM) return vec ? launch_kmeans<KM, 4>(labels, x, centres, batch, channels, hw, n_centres, st)        \
+                                    : launch_kmeans<KM, 1>(labels, x, centres, batch, channels, hw, n_centres, st);
+    KM_CASE(8) KM_CASE(16) KM_CASE(24) KM_CASE(32)
+#undef KM_CASE
+    return hw % 2 == 0 && (((uintptr_t)x) & 7) == 0 ? launch_kmeans<64, 2>(labels, x, centres, batch, channels, hw, n_centres, st)
+                                                    : launch_kmeans<64, 1>(labels, x, centres, batch, channels, hw, n_centres, st);
 }
 
 extern "C" int sis_make_image_u8(uint8_t* out, const float* x, int batch, int channels, int hw, void* stream) {
