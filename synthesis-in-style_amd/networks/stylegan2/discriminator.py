@@ -36,6 +36,23 @@ class ScaledLeakyReLU(nn.Module):
         return F.leaky_relu(input, negative_slope=self.negative_slope) * math.sqrt(2)
 
 
+class Downsample(nn.Module):
+    """x1/2 FIR decimation (model.py:55-73): normalised taps, pad ((p+1)//2, p//2) with p = taps - factor."""
+
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        from .model import make_kernel
+        from .op import upfirdn2d
+        self._op = upfirdn2d
+        self.factor = factor
+        self.register_buffer('kernel', make_kernel(kernel))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2, p // 2)
+
+    def forward(self, input):
+        return self._op(input, self.kernel, up=1, down=self.factor, pad=self.pad)
+
+
 class EqualConv2d(nn.Module):
     """Convolution with equalised learning rate: unit-variance weights, scaled by 1/sqrt(fan_in) at run time."""
 

@@ -539,4 +539,4 @@ class Generator(nn.Module):
         return image, None
 
 
-from .discriminator import ConvLayer, Discriminator, EqualConv2d, ResBlock, ScaledLeakyReLU  # noqa: E402,F401
+from .discriminator import ConvLayer, Discriminator, Downsample, EqualConv2d, ResBlock, ScaledLeakyReLU  # noqa: E402,F401

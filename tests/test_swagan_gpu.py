@@ -41,3 +41,30 @@ def test_haar_transforms_invert_each_other(device):
     np.testing.assert_allclose(back.cpu().numpy(), x.cpu().numpy(), atol=1e-6)
     filters = W.haar_filters()
     np.testing.assert_allclose(bands.cpu().numpy(), W.dwt(x.cpu(), filters).numpy(), atol=1e-6)
+
+
+def test_discriminator_matches_reference_golden(device, golden_dir):
+    """SWAGAN discriminator (wavelet pyramid FromRGB + ConvBlocks) forward and the logistic-loss gradients against the
+    unmodified reference module; 3x3 stride-1 layers run on the Winograd kernels."""
+    import sys
+    import torch.nn.functional as F
+    sys.path.insert(0, golden_dir)
+    from make_golden_swagan_d import seed_discriminator, seeded_images
+    from networks.swagan import Discriminator
+    g = np.load(os.path.join(golden_dir, "swagan_d32.npz"))
+    size, cm, b = g["cfg"].tolist()
+    net = Discriminator(size, channel_multiplier=cm)
+    seed_discriminator(net, 31)
+    net = net.to(device).train()
+    real, fake = (t.to(device) for t in seeded_images(size, b, 32))
+    real_pred, fake_pred = net(real), net(fake)
+    loss = F.softplus(-real_pred).mean() + F.softplus(fake_pred).mean()
+    loss.backward()
+    np.testing.assert_allclose(real_pred.detach().cpu().numpy(), g["real_pred"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(fake_pred.detach().cpu().numpy(), g["fake_pred"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(loss.item(), g["d_loss"], rtol=2e-4)
+    for name, p in net.named_parameters():
+        want_norm, want_head = float(g[f"norm/{name}"]), g[f"head/{name}"]
+        np.testing.assert_allclose(p.grad.double().norm().item(), want_norm, rtol=2e-3, atol=1e-5, err_msg=name)
+        np.testing.assert_allclose(p.grad.flatten()[:16].cpu().numpy(), want_head, rtol=0,
+                                   atol=2e-3 * max(np.abs(want_head).max(), want_norm / np.sqrt(p.numel())) + 1e-5, err_msg=name)

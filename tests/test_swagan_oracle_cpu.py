@@ -42,3 +42,16 @@ def test_product_state_dict_is_the_reference_schema(golden_dir):
     net.load_state_dict(sd, strict=True)
     assert (net.log_size, net.n_latent, net.num_layers) == (4, 6, 5)
     assert [tuple(n.shape[-2:]) for n in net.make_noise()] == [(4, 4), (8, 8), (8, 8), (16, 16), (16, 16)]
+
+
+def test_product_discriminator_has_the_reference_schema(golden_dir):
+    """networks.swagan.Discriminator: the same state_dict keys / shapes, in the same order, as the reference module
+    whose golden run is stored in swagan_d32.npz (tests/golden/make_golden_swagan_d.py)."""
+    from networks.swagan import Discriminator
+    g = np.load(os.path.join(golden_dir, "swagan_d32.npz"))
+    size, cm, _ = g["cfg"].tolist()
+    net = Discriminator(size, channel_multiplier=cm)
+    assert list(net.state_dict().keys()) == g["schema_names"].tolist()
+    assert [",".join(map(str, v.shape)) for v in net.state_dict().values()] == g["schema_shapes"].tolist()
+    ref_like = {k: v for k, v in net.state_dict().items() if k.endswith(("kernel", ".ll", ".lh", ".hl", ".hh"))}
+    assert all(torch.isfinite(v).all() for v in ref_like.values()) and len(ref_like) > 0
