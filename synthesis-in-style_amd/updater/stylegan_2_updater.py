@@ -17,16 +17,16 @@ instead of a Python loop over 135 tensors.  Gradients cross ranks through Distri
 networks are wrapped, exactly as in the reference; the only explicit collective is ``reduce_sum`` of the mean path
 length (:203-205).
 """
-import math
+import contextlib
 import random
 from collections.abc import Iterable
 from typing import Tuple
 
 import torch
-import torch.nn.functional as F
-from torch import autograd, nn
+from torch import nn
 from torch.nn.parallel import DistributedDataParallel
 
+from updater import gan_losses
 from training.loop import GradientApplier, UpdateDisabler, Updater, get_current_reporter, get_world_size, reduce_sum
 
 
@@ -79,16 +79,15 @@ class Stylegan2Updater(Updater):
         mix = self.style_mixing_prob > 0 and random.random() < self.style_mixing_prob
         return self.make_noise(batch_size, 2 if mix else 1)
 
-    # ---- losses -----------------------------------------------------------------------------
+    # ---- losses (updater/gan_losses.py; kept as methods because callers and subclasses use them as such) -------------
     def d_logistic_loss(self, real_pred: torch.Tensor, fake_pred: torch.Tensor) -> torch.Tensor:
-        return F.softplus(-real_pred).mean() + F.softplus(fake_pred).mean()
+        return gan_losses.logistic_discriminator_loss(real_pred, fake_pred)
 
     def d_r1_loss(self, real_pred: torch.Tensor, real_img: torch.Tensor) -> torch.Tensor:
-        grad_real, = autograd.grad(outputs=real_pred.sum(), inputs=real_img, create_graph=True)
-        return grad_real.pow(2).view(grad_real.shape[0], -1).sum(1).mean()
+        return gan_losses.r1_penalty(real_pred, real_img)
 
     def g_nonsaturating_loss(self, fake_pred: torch.Tensor) -> torch.Tensor:
-        return F.softplus(-fake_pred).mean()
+        return gan_losses.nonsaturating_generator_loss(fake_pred)
 
     def requires_grad(self, network: nn.Module, flag: bool):
         for parameter in network.parameters():
@@ -96,68 +95,66 @@ class Stylegan2Updater(Updater):
 
     def g_path_regularize(self, fake_img: torch.Tensor, latents: torch.Tensor, mean_path_length, decay: float = 0.01,
                           noise: torch.Tensor = None):
-        """``noise`` (optional, a build-side addition for the parity tests): the N(0,1) image the reference draws here."""
-        if noise is None:
-            noise = torch.randn_like(fake_img)
-        noise = noise / math.sqrt(fake_img.shape[2] * fake_img.shape[3])
-        grad, = autograd.grad(outputs=(fake_img * noise).sum(), inputs=latents, create_graph=True)
-        path_lengths = torch.sqrt(grad.pow(2).sum(2).mean(1))
-        path_mean = mean_path_length + decay * (path_lengths.mean() - mean_path_length)
-        path_penalty = (path_lengths - path_mean).pow(2).mean()
-        return path_penalty, path_mean.detach(), path_lengths
+        return gan_losses.path_length_penalty(fake_img, latents, mean_path_length, decay, noise)
 
     # ---- the four sub-steps -----------------------------------------------------------------
+    def _fakes(self, count: int, **generator_kwargs):
+        """G(mixing styles) with the frozen / fresh per-layer noise selection of this run."""
+        return self.networks['generator'](self.mixing_styles(count), noise=self.make_stochastic_noise(), **generator_kwargs)
+
+    def _training(self, trained: str, frozen: str = None):
+        """Context of one sub-step: zero_grad / step of ``trained``'s optimizer around it, ``frozen``'s parameters
+        switched off inside it (for the D step that sends the generator down its fused inference path)."""
+        stack = contextlib.ExitStack()
+        if frozen is not None:
+            stack.enter_context(UpdateDisabler(self.networks[frozen]))
+        stack.enter_context(GradientApplier([self.networks[trained]], [self.optimizers[trained]]))
+        return stack
+
     def update_discriminator(self, images: torch.Tensor) -> dict:
-        generator, discriminator = self.networks['generator'], self.networks['discriminator']
-        with UpdateDisabler(generator), GradientApplier([discriminator], [self.optimizers['discriminator']]):
-            generated_image, _ = generator(self.mixing_styles(len(images)), noise=self.make_stochastic_noise())
-            fake_prediction = discriminator(generated_image)
-            real_prediction = discriminator(images)
-            d_loss = self.d_logistic_loss(real_prediction, fake_prediction)
-            d_loss.backward()
-        return {"discriminator_loss": d_loss.detach(), "real_score": real_prediction.mean().detach(),
-                "fake_score": fake_prediction.mean().detach()}
+        critic = self.networks['discriminator']
+        with self._training('discriminator', frozen='generator'):
+            fake_score = critic(self._fakes(len(images))[0])
+            real_score = critic(images)
+            loss = self.d_logistic_loss(real_score, fake_score)
+            loss.backward()
+        return {"discriminator_loss": loss.detach(), "real_score": real_score.mean().detach(),
+                "fake_score": fake_score.mean().detach()}
 
     def regularize_discriminator(self, images: torch.Tensor) -> dict:
-        discriminator = self.networks['discriminator']
-        with GradientApplier([discriminator], [self.optimizers['discriminator']]):
+        with self._training('discriminator'):
             images.requires_grad = True
-            real_pred = discriminator(images)
-            r1_loss = self.d_r1_loss(real_pred, images)
-            (self.r1_weight / 2 * r1_loss * self.d_reg_interval + 0 * real_pred[0]).backward()
-        return {"r1_loss": r1_loss.detach()}
+            real_score = self.networks['discriminator'](images)
+            penalty = self.d_r1_loss(real_score, images)
+            # lazy regularisation: the weight is scaled by the interval; "+ 0 * score" keeps every output in the graph (DDP)
+            (self.r1_weight / 2 * penalty * self.d_reg_interval + 0 * real_score[0]).backward()
+        return {"r1_loss": penalty.detach()}
 
     def update_generator(self, images: torch.Tensor) -> dict:
-        generator, discriminator = self.networks['generator'], self.networks['discriminator']
-        with UpdateDisabler(discriminator), GradientApplier([generator], [self.optimizers['generator']]):
-            fake_images, _ = generator(self.mixing_styles(len(images)), noise=self.make_stochastic_noise())
-            g_loss = self.g_nonsaturating_loss(discriminator(fake_images))
-            g_loss.backward()
-        return {"generator_loss": g_loss.detach()}
+        with self._training('generator', frozen='discriminator'):
+            loss = self.g_nonsaturating_loss(self.networks['discriminator'](self._fakes(len(images))[0]))
+            loss.backward()
+        return {"generator_loss": loss.detach()}
 
     def regularize_generator(self, images: torch.Tensor) -> dict:
-        generator = self.networks['generator']
-        with GradientApplier([generator], [self.optimizers['generator']]):
-            path_batch_size = max(1, len(images) // self.g_reg_batch_size_shrink_factor)
-            fake_images, latents = generator(self.mixing_styles(path_batch_size), return_latents=True,
-                                             noise=self.make_stochastic_noise())
-            path_loss, self.mean_path_length, path_lengths = self.g_path_regularize(fake_images, latents,
-                                                                                    self.mean_path_length)
-            weighted_path_loss = self.path_reg_weight * self.g_reg_interval * path_loss
+        with self._training('generator'):
+            count = max(1, len(images) // self.g_reg_batch_size_shrink_factor)
+            fakes, latents = self._fakes(count, return_latents=True)
+            penalty, self.mean_path_length, lengths = self.g_path_regularize(fakes, latents, self.mean_path_length)
+            weighted = self.path_reg_weight * self.g_reg_interval * penalty
             if self.g_reg_batch_size_shrink_factor:
-                weighted_path_loss += 0 * fake_images[0, 0, 0, 0]
-            weighted_path_loss.backward()
+                weighted = weighted + 0 * fakes[0, 0, 0, 0]
+            weighted.backward()
             self.mean_path_length_avg = reduce_sum(self.mean_path_length).item() / get_world_size()
-        return {"perceputal_path_loss": path_loss.detach(), "perceptual_path_lengths": path_lengths.mean().detach()}
+        return {"perceputal_path_loss": penalty.detach(), "perceptual_path_lengths": lengths.mean().detach()}  # (sic) reference keys
 
     def update_core(self):
-        batch = next(self.iterators['images'])
-        batch = {key: value.to(self.device) for key, value in batch.items()}
-        reporter = get_current_reporter()
-        reporter.add_observation(self.update_discriminator(batch['image']), 'discriminator')
+        batch = {key: value.to(self.device) for key, value in next(self.iterators['images']).items()}
+        images, report = batch['image'], get_current_reporter().add_observation
+        report(self.update_discriminator(images), 'discriminator')
         if self.iteration % self.d_reg_interval == 0:
-            reporter.add_observation(self.regularize_discriminator(batch['image']), 'discriminator')
-        reporter.add_observation(self.update_generator(batch['image']), 'generator')
+            report(self.regularize_discriminator(images), 'discriminator')
+        report(self.update_generator(images), 'generator')
         if self.iteration % self.g_reg_interval == 0:
-            reporter.add_observation(self.regularize_generator(batch['image']), 'generator')
+            report(self.regularize_generator(images), 'generator')
         self.accumulate(self.networks['generator'], self.accumulation_decay)
