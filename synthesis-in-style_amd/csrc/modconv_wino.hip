@@ -290,7 +290,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams
 // one chunk ahead of the MFMAs, so the matrix loop is nothing but ds_read_b32 pairs and MFMAs (in the kernel above
 // every patch is re-read and re-transformed by the 4 waves that share it: 48.5 % MFMA-busy measured).  Per
 // iteration c: DMA weights(c+1), DMA input(c+2), transform(c+1) -> V, MFMA(c); one barrier.
-__global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParams p, const int xt_max, const int tiles_per_wg) {
+__global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParams p, const int xt_max, const int tiles_per_wg, const int xcd_group) {
     constexpr int WF = WCC * 16 * WMBLK;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int VF = 16 * WCC * WTILES;  // transformed input of one chunk: [xi][channel][tile]
@@ -312,8 +312,12 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     // n_co = Cout / MBLK in {2,4,8} every XCD keeps working on the same weight slice (<= 2.4 MB: stays in its
     // 4 MiB L2) while the n_co workgroups that share an input tile run at the same time on different XCDs
     // (one HBM read, the rest MALL hits).  Pixel-tile-fastest order measured a 48 % L2 miss rate on this kernel.
+    // When ALL the transformed weights fit one L2 (128 / 256 channels: 1 / 4 MB) the order is the other way
+    // round (xcd_group): logical workgroup id = (hardware id % 8) * (grid / 8) + hardware id / 8, so the n_co
+    // workgroups of a pixel tile sit on ONE XCD and the input tile is fetched once instead of n_co times.
     const int n_co = (p.Cout + WMBLK - 1) / WMBLK;
-    const int o0 = (blockIdx.x % n_co) * WMBLK;
+    const int wg = xcd_group ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int o0 = (wg % n_co) * WMBLK;
     const TileClass tc = p.cls[0];
     const int thl = tc.th_log2, twl = tc.tw_log2;
     const int th = 1 << thl, tw = 1 << twl;
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     // Tile k of workgroup g is pixel tile g + k * (#workgroups per channel block): the workgroups running at the same
     // time cover NEIGHBOURING tiles, whose halos they share through L2 (consecutive tiles per workgroup measured 57 %
     // more fetched bytes).
-    const int pt_first = blockIdx.x / n_co, pt_step = gridDim.x / n_co;
+    const int pt_first = wg / n_co, pt_step = gridDim.x / n_co;
     tile_setup(pt_first);
     constexpr int WV4 = WF / 4, WIT = WV4 / WNTHR;  // 4 float4 per lane per chunk
     int w_goff[WIT];
@@ -661,7 +665,12 @@ int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t 
         int tpw = 1;
         static const int min_wg = getenv("SIS_WINO_MINWG") ? atoi(getenv("SIS_WINO_MINWG")) : 1024;
         while (tpw * 2 <= tpw_cap && p.npos_tiles % (tpw * 2) == 0 && blocks / (tpw * 2) >= min_wg) tpw *= 2;
-        hipLaunchKernelGGL(modconv_wino2_kernel, dim3((unsigned)(blocks / tpw), p.ksplit), dim3(WNTHR), lds2, st, p, tc.xt, tpw);
+        // all co-blocks of a pixel tile on one XCD when the whole transformed weight tensor stays L2-resident there
+        static const double swz_mb = getenv("SIS_WINO_XCD_MB") ? atof(getenv("SIS_WINO_XCD_MB")) : 5.0;
+        const int64_t grid = blocks / tpw;
+        const int n_co_h = (p.Cout + WMBLK - 1) / WMBLK;
+        const int xcd_group = (double)p.Cin * p.Cout * 16 * sizeof(float) <= swz_mb * 1048576.0 && n_co_h > 1 && grid % (8 * n_co_h) == 0;
+        hipLaunchKernelGGL(modconv_wino2_kernel, dim3((unsigned)grid, p.ksplit), dim3(WNTHR), lds2, st, p, tc.xt, tpw, xcd_group);
     } else {
         sis_kernel_name = "modconv_wino_kernel";
         hipLaunchKernelGGL(modconv_wino_kernel, dim3((unsigned)blocks, p.ksplit), dim3(WNTHR), lds, st, p, tc.xt);
