@@ -98,3 +98,86 @@ def test_ddp_wrap_world_size_2_gloo():
         assert params_ok, "parameters diverged across ranks after one step"
         assert mu == float(rank), "buffers were broadcast (must stay per-rank)"
     assert out[0][3] != out[1][3], "batch-norm statistics must be per-rank"
+
+
+class _TinyGenerator(nn.Module):
+    """CPU stand-in with the call surface Stylegan2Updater uses: ``g(styles, noise=..., return_latents=...)`` ->
+    (image, latents | None), ``noises`` buffers, differentiable from the latents to the image."""
+
+    def __init__(self, dim=8, n_latent=4):
+        super().__init__()
+        self.n_latent = n_latent
+        self.mapping = nn.Linear(dim, dim)
+        self.synthesis = nn.Linear(dim, 3 * 4 * 4)
+        self.noises = nn.Module()
+        self.noises.register_buffer("noise_0", torch.zeros(1, 1, 4, 4))
+
+    def forward(self, styles, return_latents=False, noise=None, **_):
+        w = [self.mapping(s) for s in styles]
+        latent = w[0].unsqueeze(1).repeat(1, self.n_latent, 1) if len(w) == 1 else torch.cat(
+            [w[0].unsqueeze(1).repeat(1, 2, 1), w[1].unsqueeze(1).repeat(1, self.n_latent - 2, 1)], 1)
+        image = torch.tanh(self.synthesis(latent.mean(1))).view(-1, 3, 4, 4)
+        return image, (latent if return_latents else None)
+
+
+class _TinyDiscriminator(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(3, 4, 3, padding=1)
+        self.out = nn.Linear(4 * 4 * 4, 1)
+
+    def forward(self, x):
+        return self.out(nn.functional.leaky_relu(self.conv(x), 0.2).flatten(1))
+
+
+def _gan_worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, "synthesis-in-style_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import copy
+        import random
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from updater.stylegan_2_updater import Stylegan2Updater
+        torch.manual_seed(0)  # identical initial weights on every rank
+        g, d = _TinyGenerator(), _TinyDiscriminator()
+        g_ema = copy.deepcopy(g)
+        opts = {"generator": torch.optim.Adam(g.parameters(), lr=1e-2, betas=(0.0, 0.99)),
+                "discriminator": torch.optim.Adam(d.parameters(), lr=1e-2, betas=(0.0, 0.99))}
+        networks = {"generator": DDP(g, broadcast_buffers=False), "discriminator": DDP(d, broadcast_buffers=False)}
+        torch.manual_seed(100 + rank)  # per-rank data and latents from here on
+        random.seed(7)  # the style-mixing coin must agree across ranks: it decides which parameters take part
+
+        def batches():
+            while True:
+                yield {"image": torch.rand(4, 3, 4, 4) * 2 - 1}
+
+        up = Stylegan2Updater(iterators={"images": batches()}, networks=networks, optimizers=opts, device="cpu", g_ema=g_ema,
+                              latent_size=8, regularization_options={"d_reg_interval": 2, "g_reg_interval": 2})
+        up.accumulate(networks["generator"], 0)
+        for _ in range(4):  # iterations 0 and 2 run both lazy regularisers (second-order backward through DDP)
+            up.update()
+        flat = torch.cat([p.detach().flatten() for net in (g, d) for p in net.parameters()])
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        ema_start = [p.detach().clone() for p in _TinyGenerator().parameters()]  # a fresh init differs from the average
+        ema_moved = any(not torch.equal(a, b) for a, b in zip(g_ema.parameters(), ema_start))
+        out[rank] = (all(torch.allclose(gathered[0], q, atol=1e-6) for q in gathered), float(up.mean_path_length_avg),
+                     bool(torch.isfinite(flat).all()), all(p.requires_grad for p in list(g.parameters()) + list(d.parameters())),
+                     bool(ema_moved))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stylegan2_updater_world_size_2_gloo():
+    """The GAN iteration under DistributedDataParallel (gloo, CPU stand-in networks): freezing one network per sub-step
+    (UpdateDisabler) and the lazy regularisers' second-order backward leave the replicas in lock-step, and the mean path
+    length is averaged over ranks (the updater's only explicit collective, reduce_sum)."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gan_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert len(out) == world
+    assert all(out[r][0] for r in range(world)), "replicas diverged"
+    assert out[0][1] == pytest.approx(out[1][1], rel=1e-6) and out[0][1] > 0, "mean path length is not the all-rank average"
+    assert all(out[r][2] and out[r][3] for r in range(world))
