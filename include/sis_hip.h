@@ -284,6 +284,13 @@ int sis_batch_norm_bwd(void* dx, float* dgamma, float* dbeta, float* workspace, 
                        int g_dtype, int batch, int channels, int hw, int relu, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Column sums out[c] = sum_r x[r][c] of a [rows][n] matrix (n % 4 == 0; x SIS_F32 / SIS_F16 / SIS_BF16, out float32): the
+ * bias gradient of the encoder's Linear layers (networks/trans_u_net/vit_seg_modeling.py:53-110, what autograd computes as
+ * grad_output.sum(0)); deterministic two-stage reduction.  workspace: sis_column_sum_workspace_floats(n) floats. */
+int64_t sis_column_sum_workspace_floats(int n);
+int sis_column_sum(float* out, float* workspace, const void* x, int x_dtype, int rows, int n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * nn.LayerNorm over the last dimension (TransUNet encoder, networks/trans_u_net/vit_seg_modeling.py:171-190,233-250),
  * x [rows][n], n in {256, 512, 768, 1024}, x / y / grad dtypes SIS_F32 or SIS_BF16 (fp32 arithmetic), gamma / beta [n].
  * fwd: y = (x - mean_row) * rstd_row * gamma + beta; mean / rstd [rows] kept.

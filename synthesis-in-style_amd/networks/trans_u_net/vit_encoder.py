@@ -45,6 +45,48 @@ class _LayerNormFn(Function):
         return dx, dgamma, dbeta, None, None
 
 
+class _AmpLinearFn(Function):
+    """``F.linear`` under 16-bit autocast with the backward issued explicitly: dW as one 16-bit x 16-bit -> float32 GEMM
+    (autocast would round it to 16 bits and cast it back for the fp32 master weight), d(bias) by the column-sum kernel
+    (csrc/column_sum.hip, float32) instead of a generic reduction + cast."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        w_lp, b_lp = weight.to(x.dtype), bias.to(x.dtype)
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(x2, w_lp)
+        ctx.x_shape = x.shape
+        return torch.addmm(b_lp, x2, w_lp.t()).view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, grad):
+        x2, w_lp = ctx.saved_tensors
+        g2 = grad.reshape(-1, grad.shape[-1])
+        if g2.dtype != x2.dtype:
+            g2 = g2.to(x2.dtype)
+        g2 = g2.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(g2, w_lp).view(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.mm(g2.t(), x2, out_dtype=torch.float32)
+        if ctx.needs_input_grad[2]:
+            db = sis_hip.column_sum(g2)
+        return dx, dw, db
+
+
+_AMP_LINEAR = os.environ.get('SIS_AMP_LINEAR', '1') != '0'
+
+
+def linear(x, weight, bias):
+    """``F.linear``; on a HIP device under 16-bit autocast with a 16-bit input, the explicit-backward variant above."""
+    if (_AMP_LINEAR and bias is not None and x.is_cuda and torch.is_autocast_enabled() and x.dtype in (torch.bfloat16, torch.float16)
+            and x.dtype == torch.get_autocast_dtype('cuda') and weight.dtype == torch.float32 and weight.shape[0] % 4 == 0
+            and x.is_contiguous()):
+        return _AmpLinearFn.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
 class LayerNorm(nn.LayerNorm):
     """``nn.LayerNorm`` on one HIP launch per direction (csrc/layer_norm.hip: a wave per token, the row held in
     registers); under autocast the result is written in the autocast dtype, i.e. what the following Linear reads."""
@@ -81,8 +123,8 @@ class Attention(nn.Module):
     def forward(self, hidden_states):
         # one [hidden -> 3 * hidden] GEMM instead of three (the parameters stay separate, as in the reference's
         # checkpoints): 8192 x 768 x 768 products run the bf16 matrix cores at ~7 % of peak, the fused one is 3x larger
-        qkv = F.linear(hidden_states, torch.cat([self.query.weight, self.key.weight, self.value.weight], 0),
-                       torch.cat([self.query.bias, self.key.bias, self.value.bias], 0))
+        qkv = linear(hidden_states, torch.cat([self.query.weight, self.key.weight, self.value.weight], 0),
+                     torch.cat([self.query.bias, self.key.bias, self.value.bias], 0))
         q, k, v = (self.transpose_for_scores(t) for t in qkv.split(self.all_head_size, dim=-1))
         weights = None
         if self.vis or (self.training and self.attn_dropout.p > 0):
@@ -94,7 +136,7 @@ class Attention(nn.Module):
             context = F.scaled_dot_product_attention(q, k, v)
         b, _, n, _ = context.shape
         context = context.permute(0, 2, 1, 3).reshape(b, n, self.all_head_size)
-        return self.proj_dropout(self.out(context)), weights
+        return self.proj_dropout(linear(context, self.out.weight, self.out.bias)), weights
 
 
 class Mlp(nn.Module):
@@ -109,7 +151,8 @@ class Mlp(nn.Module):
             nn.init.normal_(fc.bias, std=1e-6)
 
     def forward(self, x):
-        return self.dropout(self.fc2(self.dropout(self.act_fn(self.fc1(x)))))
+        hidden = self.dropout(self.act_fn(linear(x, self.fc1.weight, self.fc1.bias)))
+        return self.dropout(linear(hidden, self.fc2.weight, self.fc2.bias))
 
 
 class Embeddings(nn.Module):

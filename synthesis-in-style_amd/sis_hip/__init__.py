@@ -45,6 +45,8 @@ _SIGNATURES = {
     "sis_conv3x3_eligible": ([_i] * 5, _i),
     "sis_upsample_bilinear": ([_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp], _i),
     "sis_layer_norm_workspace_floats": ([_i], _i),
+    "sis_column_sum_workspace_floats": ([_i], _i64),
+    "sis_column_sum": ([_vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "sis_layer_norm_fwd": ([_vp] * 6 + [_i, _i, _i, _i, _f, _vp], _i),
     "sis_layer_norm_bwd": ([_vp] * 9 + [_i, _i, _i, _i, _vp], _i),
     "sis_weight_std_fwd": ([_vp, _vp, _vp, _i, _i, _i, _f, _vp], _i),
@@ -610,6 +612,18 @@ def layer_norm_bwd(grad_y, x, mean, rstd, gamma):
                                         _ptr(gamma), _DTYPE_CODE[x.dtype], _DTYPE_CODE[g.dtype], rows, n, _stream()),
                "sis_layer_norm_bwd")
     return dx, dgamma, dbeta
+
+
+def column_sum(x):
+    """x [rows, n] (f32 / f16 / bf16, n % 4 == 0) -> float32 [n] column sums (bias gradient of a Linear layer)."""
+    require_device(x, "input")
+    x = x.contiguous()
+    rows, n = x.shape
+    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib().sis_column_sum_workspace_floats(n), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_column_sum(_ptr(out), _ptr(ws), _ptr(x), _DTYPE_CODE[x.dtype], rows, n, _stream()), "sis_column_sum")
+    return out
 
 
 # ------------------------------------------------------------------------------ group norm (+ ReLU)

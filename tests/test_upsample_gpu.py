@@ -196,3 +196,40 @@ def test_layer_norm(device, rows, n):
     assert dxb.dtype == torch.float32
     np.testing.assert_allclose(dxb.cpu().numpy(), xr.grad.float().cpu().numpy(), rtol=5e-2, atol=2e-2 * float(xr.grad.abs().max()))
     assert not sis_hip.layer_norm_supported(x[:, :100], 100)
+
+
+@pytest.mark.parametrize("rows,n,dt", [(8192, 768, torch.bfloat16), (77, 3072, torch.bfloat16), (513, 260, torch.float32),
+                                        (5, 4, torch.float16)])
+def test_column_sum(device, rows, n, dt):
+    """csrc/column_sum.hip: float32 column sums of 16-bit / fp32 matrices against a float64 sum."""
+    import sis_hip
+    x = torch.randn(rows, n, generator=torch.Generator().manual_seed(rows + n)).to(device).to(dt)
+    got = sis_hip.column_sum(x)
+    want = x.double().sum(0)
+    assert got.dtype == torch.float32
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-4 * rows ** 0.5)
+    assert torch.equal(got, sis_hip.column_sum(x))  # deterministic
+
+
+def test_amp_linear_matches_autocast_linear(device):
+    """networks.trans_u_net.vit_encoder.linear under bf16 autocast: same output as F.linear, weight / bias gradients equal
+    to the float64 ones up to the 16-bit inputs' rounding (they are accumulated and returned in float32)."""
+    from networks.trans_u_net import vit_encoder as V
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(4, 96, 768, generator=g).to(device).bfloat16().requires_grad_(True)
+    w = (torch.randn(2304, 768, generator=g) * 0.03).to(device).requires_grad_(True)
+    b = (torch.randn(2304, generator=g) * 0.1).to(device).requires_grad_(True)
+    gy = torch.randn(4, 96, 2304, generator=g).to(device).bfloat16()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = V.linear(x, w, b)
+        y_ref = F.linear(x, w, b)
+    assert y.dtype == torch.bfloat16 and y.grad_fn.name().startswith("_AmpLinearFn")
+    np.testing.assert_allclose(y.float().detach().cpu().numpy(), y_ref.float().detach().cpu().numpy(), rtol=2e-2, atol=2e-2)
+    dx, dw, db = torch.autograd.grad(y, (x, w, b), gy)
+    assert dw.dtype == torch.float32 and db.dtype == torch.float32 and dx.dtype == torch.bfloat16
+    x64, w64, g64 = x.detach().double(), w.detach().bfloat16().double(), gy.double()
+    np.testing.assert_allclose(db.cpu().numpy(), g64.sum((0, 1)).cpu().numpy(), rtol=1e-5, atol=1e-4)
+    want_dw = g64.reshape(-1, 2304).t() @ x64.reshape(-1, 768)
+    np.testing.assert_allclose(dw.cpu().numpy(), want_dw.cpu().numpy(), rtol=1e-3, atol=1e-3 * float(want_dw.abs().max()))
+    want_dx = g64 @ w64
+    np.testing.assert_allclose(dx.float().cpu().numpy(), want_dx.cpu().numpy(), rtol=2e-2, atol=2e-2 * float(want_dx.abs().max()))
