@@ -12,9 +12,15 @@ weights (default init, noise weights ~N(0, 0.1^2) so the noise path is live), in
 A "step" is one such forward.  Synthesis shards by image with no collective, so N GPUs
 = N independent batches per step: weak scaling; value = N * 32 * K / time.
 
+With the default ``--workload all`` (what the driver runs) the same process then times the two segmentation training
+steps the metric also names -- BASELINE.json configs[3] EMANet-50 256^2 B=16 fp32 and configs[4] TransUNet R50-ViT-B/16
+512^2 B=8 bf16 -- with the same K, and nests them as ``seg_train: {emanet: {...}, transunet_bf16: {...}}`` (images/s,
+ms/step, roofline with executed vs nominal FLOPs, cpu_baseline); ``value`` stays the synthesis rate.
+
 Two extra objects on the JSON line:
   roofline      dominant kernel (by summed device time) measured live with HIP events on the launch
-                stream: algorithmic FLOPs per launch / average launch duration vs the fp32 MFMA peak.
+                stream: EXECUTED FLOPs per launch / average launch duration vs the fp32 MFMA peak (frac <= 1); the
+                direct-form (algorithmic) count of SURVEY.md 8(d) rides along as algorithmic_tflops / algorithmic_frac.
   cpu_baseline  the oracle (CPU restatement of the reference's own grouped-conv formulation,
                 oracle/stylegan2_ref.py) timed on the host cores of this box on a bounded sample
                 (batch 4), rank 0 / N = 1 only.  A reported baseline, not the target.
@@ -35,6 +41,7 @@ import torch  # noqa: E402
 
 METRIC = "StyleGAN2 synth images/sec + seg-train images/sec @256², 1/2/4/8 MI355X"
 PEAK_MFMA_F32_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_MFMA_BF16_TFLOPS = 2500.0  # dense, same table
 PEAK_HBM_GBS = 8000.0
 BATCH = 32
 SIZE = 256
@@ -100,7 +107,7 @@ def host_cores():
 
 
 def cpu_baseline(g, seed):
-    """Oracle on the host cores: B=4 (BASELINE.json configs[0]), 1 warm-up + 2 timed iterations."""
+    """Oracle on the host cores: B=4 (BASELINE.json configs[0]), 1 warm-up + 3 timed iterations, median."""
     from oracle import stylegan2_ref as R
     sd = {k: v.detach().cpu() for k, v in g.state_dict().items()}
     z, noise = synth_inputs(g, 4, "cpu", seed)
@@ -109,14 +116,14 @@ def cpu_baseline(g, seed):
     with torch.no_grad():
         img, _ = R.generator_forward(sd, [z], noise=noise, return_intermediate_activations=True)
         t = []
-        for _ in range(2):
+        for _ in range(3):
             t0 = time.perf_counter()
             img, _ = R.generator_forward(sd, [z], noise=noise, return_intermediate_activations=True)
             t.append(time.perf_counter() - t0)
-    sec = sorted(t)[0]
+    sec = sorted(t)[1]
     return {"value": round(4 / sec, 3), "unit": "images/s", "cores": threads, "kind": "port",
             "sample": f"Generator(256,512,8,cm=2) forward with activations, batch 4, fp32, {threads} torch threads, "
-                      f"best of 2 after 1 warm-up ({sec:.2f} s/iter)"}, img, (z, noise)
+                      f"median of 3 after 1 warm-up ({sec:.2f} s/iter)"}, img, (z, noise)
 
 
 SEG_FLOPS_PER_IMAGE = {"emanet": 227.38e9, "transunet": 1007.79e9}  # fwd+bwd, SURVEY.md §8(d) (2*MAC)
@@ -126,7 +133,7 @@ SEG_CONFIG = {"emanet": "configs/segmenter/ema_net_resnet50_256.yaml",
 
 def cpu_baseline_training(workload, config):
     """Oracle training step on the host cores (B = 4 for EMANet-50 @256^2, B = 2 for TransUNet @512^2,
-    fp32): 1 warm-up + 1 timed iteration, bounded to tens of seconds."""
+    fp32): 1 warm-up + 3 timed iterations (median), bounded to tens of seconds."""
     threads = host_cores()
     torch.set_num_threads(threads)
     size, classes = config["image_size"], config["num_classes"]
@@ -143,12 +150,15 @@ def cpu_baseline_training(workload, config):
              "segmented": torch.randint(0, classes, (batch_size, 1, size, size), generator=gen)}
     bufs = {}
     step(batch)
-    t0 = time.perf_counter()
-    step(batch)
-    sec = time.perf_counter() - t0
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        step(batch)
+        times.append(time.perf_counter() - t0)
+    sec = sorted(times)[1]
     return {"value": round(batch_size / sec, 3), "unit": "images/s", "cores": threads, "kind": "port",
             "sample": f"{config['network']} oracle training step (forward, loss, backward, SGD), {size}x{size}, batch "
-                      f"{batch_size}, fp32, {threads} torch threads, 1 timed iteration after 1 warm-up ({sec:.2f} s)"}
+                      f"{batch_size}, fp32, {threads} torch threads, median of 3 iterations after 1 warm-up ({sec:.2f} s)"}
 
 
 def bench_training(args, workload, world, rank, device, distributed):
@@ -180,7 +190,25 @@ def bench_training(args, workload, world, rank, device, distributed):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # Iterations 1-2 are eager (StepGraph warm-up); the second one is bracketed kernel by kernel with HIP events on the
+    # launch stream: nominal FLOPs and device time of every hand-written convolution launch of one step.
+    import sis_hip
+    warmup = max(args.warmup, 4)  # two eager iterations, the capture, one replay before the clock starts
+    updater.update()
+    records = []
+    sis_hip.set_profiler(records)
+    try:
+        updater.update()
+        torch.cuda.synchronize()
+    finally:
+        sis_hip.set_profiler(None)
+    own = {}
+    for name, flops, nbytes, e0, e1 in records:
+        a = own.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        a["launches"] += 1
+        a["ms"] += e0.elapsed_time(e1)
+        a["flops"] += flops
+    for _ in range(warmup - 2):
         updater.update()
     fence()
     t0 = time.perf_counter()
@@ -195,10 +223,16 @@ def bench_training(args, workload, world, rank, device, distributed):
     if rank != 0:
         return None
     images = config["batch_size"] * args.steps * world
-    tf = SEG_FLOPS_PER_IMAGE[workload] * images / elapsed / 1e12 / world
+    step_flops = SEG_FLOPS_PER_IMAGE[workload] * config["batch_size"]           # nominal 2*MAC, SURVEY.md §8(d)
+    wino_flops = sum(v["flops"] for k, v in own.items() if "wino" in k)         # nominal FLOPs run as Winograd F(2x2,3x3)
+    executed_flops = step_flops - wino_flops * (1.0 - 16.0 / 36.0)              # those execute 16 of 36 multiplies
+    step_s = elapsed / args.steps
+    peak = PEAK_MFMA_BF16_TFLOPS if config.get("amp") else PEAK_MFMA_F32_TFLOPS
+    nominal_tf, executed_tf = step_flops / step_s / 1e12, executed_flops / step_s / 1e12
+    dom = max(own, key=lambda k: own[k]["ms"]) if own else None
     return {
         "metric": METRIC, "value": round(images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "warmup": warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": config.get("amp") or "f32", "data": "synthetic",
         "config": {"workload": f"{config['network']} training step, {config['image_size']}x{config['image_size']}, batch "
                                f"{config['batch_size']} per GPU (BASELINE.json configs[{3 if workload == 'emanet' else 4}])",
@@ -206,12 +240,16 @@ def bench_training(args, workload, world, rank, device, distributed):
                    "parallelism": f"dp{world}, DDP bucketed all-reduce over RCCL",
                    "hip_graph": bool(getattr(updater, "_step_graph", None) and updater._step_graph.graph is not None),
                    "miopen_search": bool(config.get("miopen_search"))},
-        "roofline": {"kernel": "whole step, nominal 2*MAC FLOPs (3x3 convolutions on the Winograd HIP kernels in fp32, norms / "
-                               "loss / optimizer on HIP kernels, 1x1 convolutions and GEMMs on hipBLASLt, bf16 convolutions on "
-                               "MIOpen)", "bound": "mfma",
-                     "achieved": round(tf, 2), "peak": 2500.0 if config.get("amp") else PEAK_MFMA_F32_TFLOPS,
-                     "unit": "TFLOP/s",
-                     "frac": round(tf / (2500.0 if config.get("amp") else PEAK_MFMA_F32_TFLOPS), 4), "traffic": None},
+        "roofline": {"kernel": "whole training step (forward, loss, backward, SGD)", "bound": "mfma",
+                     "achieved": round(executed_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(executed_tf / peak, 4),
+                     "note": "achieved / frac count EXECUTED matrix FLOPs (Winograd launches at 16/36 of their direct-form "
+                             "count); algorithmic_* use the nominal 2*MAC count of SURVEY.md 8(d)",
+                     "algorithmic_tflops": round(nominal_tf, 2), "algorithmic_frac": round(nominal_tf / peak, 4),
+                     "flops_per_step_nominal": step_flops, "flops_per_step_executed": executed_flops, "traffic": None,
+                     "dominant_own_kernel": dom,
+                     "own_kernels_eager_iteration": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                                         "nominal_tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] else None}
+                                                     for k, v in sorted(own.items(), key=lambda kv: -kv[1]["ms"])}},
         "cpu_baseline": None if (world > 1 or args.no_cpu_baseline) else cpu_baseline_training(workload, config),
     }
 
@@ -352,49 +390,12 @@ def bench_gan(args, world, rank, device, distributed):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="synthesis", choices=["synthesis", "emanet", "transunet", "dataset", "gan"])
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="training workloads: override the config's amp")
-    ap.add_argument("--miopen-search", action="store_true",
-                    help="training workloads: MIOpen solver search for the library convolutions (minutes at start-up)")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
-    if not torch.cuda.is_available():
-        raise RuntimeError("bench.py needs a HIP device (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
-
-    if args.workload != "synthesis":
-        if args.workload == "dataset":
-            result = bench_dataset(args, world, rank, device, distributed)
-        elif args.workload == "gan":
-            result = bench_gan(args, world, rank, device, distributed)
-        else:
-            result = bench_training(args, args.workload, world, rank, device, distributed)
-        if distributed:
-            dist.barrier()
-            dist.destroy_process_group()
-        if result is not None:
-            print(json.dumps(result))
-        return
-    args.batch = args.batch or BATCH
-
+def bench_synthesis(args, world, rank, device, distributed):
+    """BASELINE.json configs[1]: the headline ``value``."""
+    import torch.distributed as dist
+    batch = args.batch or BATCH
     g = build_generator(device)
-    z, noise = synth_inputs(g, args.batch, device, seed=1 + rank)
+    z, noise = synth_inputs(g, batch, device, seed=1 + rank)
 
     out = None
     for _ in range(args.warmup):
@@ -431,52 +432,119 @@ def main():
         t = torch.tensor([elapsed_image_only], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_image_only = t.item()
+    if rank != 0:
+        return None
 
-    result = None
-    if rank == 0:
-        n_gpus = world
-        total_images = args.batch * args.steps * n_gpus
-        agg = kernel_profile(g, z, noise, min(args.steps, 5))
-        dom_name = max(agg, key=lambda k: agg[k]["ms"])
-        dom = agg[dom_name]
-        per_launch_ms = dom["ms"] / dom["launches"]
-        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        # The Winograd F(2x2,3x3) kernel executes 16 of the 36 multiplies of the direct form per 2x2 output tile:
-        # "achieved" is ALGORITHMIC (direct-convolution) FLOP/s as SURVEY.md §8(d) defines the unit work; the MFMA
-        # pipe itself runs at executed = achieved * 16/36.
-        exec_ratio = 16.0 / 36.0 if "wino" in dom_name else 1.0
-        traffic, traffic_src = measured_traffic(dom_name)
-        roofline = {"kernel": dom_name, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "bytes per launch (HBM-side, PMC)", "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
-                    "executed_tflops": round(achieved * exec_ratio, 2),
-                    "executed_frac": round(achieved * exec_ratio / PEAK_MFMA_F32_TFLOPS, 4),
-                    "launches_per_step": dom["launches"] // min(args.steps, 5),
-                    "avg_launch_ms": round(per_launch_ms, 4),
-                    "flops_per_launch": dom["flops"] / dom["launches"],
-                    "kernels": {k: {"ms_per_step": round(v["ms"] / min(args.steps, 5), 4),
-                                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
-                                    "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
-                                for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}}
-        result = {
-            "metric": METRIC, "value": round(total_images / elapsed, 2), "unit": "images/s", "n_gpus": n_gpus,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"StyleGAN2 Generator(256,512,8,cm=2).forward, batch {args.batch} per GPU, explicit noise, "
-                                   "return_intermediate_activations=True (BASELINE.json configs[1])",
-                       "batch_per_gpu": args.batch, "image_size": SIZE, "parallelism": f"replicated x{n_gpus}, "
-                       "images sharded, no collective",
-                       "images_per_s_image_only": round(total_images / elapsed_image_only, 2)},
-            "roofline": roofline,
-        }
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            cb, img_cpu, (z4, noise4) = cpu_baseline(g, seed=1234)
-            with torch.no_grad():
-                img_gpu, _ = g([z4.to(device)], noise=[n.to(device) for n in noise4])
-            cb["gpu_vs_cpu_image_max_rel_err"] = float(
-                (img_gpu.cpu() - img_cpu).abs().max() / img_cpu.abs().max())
-            result["cpu_baseline"] = cb
+    n_gpus = world
+    total_images = batch * args.steps * n_gpus
+    prof_steps = min(args.steps, 5)
+    agg = kernel_profile(g, z, noise, prof_steps)
+    dom_name = max(agg, key=lambda k: agg[k]["ms"])
+    dom = agg[dom_name]
+    per_launch_ms = dom["ms"] / dom["launches"]
+    algorithmic = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    # The Winograd F(2x2,3x3) kernel executes 16 of the 36 multiplies of the direct form per 2x2 output tile.  SURVEY.md
+    # §8(d) defines the unit work as direct-convolution FLOPs ("algorithmic_*" below, which can exceed the peak); the
+    # roofline fraction proper is what the MFMA pipe EXECUTES: achieved = algorithmic * 16/36, frac = achieved / peak <= 1.
+    exec_ratio = 16.0 / 36.0 if "wino" in dom_name else 1.0
+    executed = algorithmic * exec_ratio
+    traffic, traffic_src = measured_traffic(dom_name)
+    roofline = {"kernel": dom_name, "bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_MFMA_F32_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(executed / PEAK_MFMA_F32_TFLOPS, 4),
+                "note": "achieved / frac = EXECUTED fp32 MFMA rate (Winograd: 16/36 of the direct-form FLOPs); "
+                        "algorithmic_* = direct-form 2*MAC FLOPs of SURVEY.md 8(d) per launch / launch time",
+                "algorithmic_tflops": round(algorithmic, 2),
+                "algorithmic_frac": round(algorithmic / PEAK_MFMA_F32_TFLOPS, 4),
+                "traffic": traffic, "traffic_unit": "bytes per launch (HBM-side, PMC)", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
+                "launches_per_step": dom["launches"] // prof_steps,
+                "avg_launch_ms": round(per_launch_ms, 4),
+                "flops_per_launch": dom["flops"] / dom["launches"],
+                "executed_flops_per_launch": dom["flops"] / dom["launches"] * exec_ratio,
+                "kernels": {k: {"ms_per_step": round(v["ms"] / prof_steps, 4),
+                                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                                "executed_tflops": round(v["flops"] * (16.0 / 36.0 if "wino" in k else 1.0)
+                                                         / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                                "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
+                            for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}}
+    result = {
+        "metric": METRIC, "value": round(total_images / elapsed, 2), "unit": "images/s", "n_gpus": n_gpus,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"StyleGAN2 Generator(256,512,8,cm=2).forward, batch {batch} per GPU, explicit noise, "
+                               "return_intermediate_activations=True (BASELINE.json configs[1])",
+                   "batch_per_gpu": batch, "image_size": SIZE, "parallelism": f"replicated x{n_gpus}, "
+                   "images sharded, no collective",
+                   "images_per_s_image_only": round(total_images / elapsed_image_only, 2)},
+        "roofline": roofline,
+    }
+    if n_gpus == 1 and not args.no_cpu_baseline:
+        cb, img_cpu, (z4, noise4) = cpu_baseline(g, seed=1234)
+        with torch.no_grad():
+            img_gpu, _ = g([z4.to(device)], noise=[n.to(device) for n in noise4])
+        cb["gpu_vs_cpu_image_max_rel_err"] = float(
+            (img_gpu.cpu() - img_cpu).abs().max() / img_cpu.abs().max())
+        result["cpu_baseline"] = cb
+    return result
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="all", choices=["all", "synthesis", "emanet", "transunet", "dataset", "gan"],
+                    help="all (default, what the driver runs): the synthesis headline + both segmentation training steps on "
+                         "one JSON line")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="training workloads: override the config's amp")
+    ap.add_argument("--miopen-search", action="store_true",
+                    help="training workloads: MIOpen solver search for the library convolutions (minutes at start-up)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    if args.workload == "dataset":
+        result = bench_dataset(args, world, rank, device, distributed)
+    elif args.workload == "gan":
+        result = bench_gan(args, world, rank, device, distributed)
+    elif args.workload in ("emanet", "transunet"):
+        result = bench_training(args, args.workload, world, rank, device, distributed)
+    else:
+        result = bench_synthesis(args, world, rank, device, distributed)
+        if args.workload == "all":
+            # The metric names two numbers: `value` stays the configs[1] synthesis rate; the segmentation training steps of
+            # configs[3] (EMANet-50, 256^2, B=16, fp32) and configs[4] (TransUNet R50-ViT-B/16, 512^2, B=8, bf16) are timed
+            # next in the same process with the same K, each with its own roofline and CPU baseline.
+            import copy
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            seg = {}
+            for key, workload, dtype in (("emanet", "emanet", "f32"), ("transunet_bf16", "transunet", "bf16")):
+                sub_args = copy.copy(args)
+                sub_args.batch, sub_args.dtype, sub_args.miopen_search = 0, dtype, False
+                sub = bench_training(sub_args, workload, world, rank, device, distributed)
+                gc.collect()
+                torch.cuda.empty_cache()
+                if sub is not None:
+                    seg[key] = {"images_per_s": sub["value"], "ms_per_step": sub["ms_per_step"], "steps": sub["steps"],
+                                "warmup": sub["warmup"], "dtype": sub["dtype"], "scaling": sub["scaling"],
+                                "config": sub["config"], "roofline": sub["roofline"], "cpu_baseline": sub["cpu_baseline"]}
+            if result is not None:
+                result["seg_train"] = seg
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -164,3 +164,21 @@ def load_reference_swagan():
     sw_op.conv2d_gradfix = F
     sys.modules["refsw.swagan.op"] = sw_op
     return load("refsw.swagan.model", "networks", "swagan", "model.py")
+
+
+def load_reference_upfirdn2d_native():
+    """The reference's own pure-PyTorch statement of K2, ``upfirdn2d_native`` (networks/stylegan2/op/upfirdn2d.py:152-186),
+    lifted out of its file with ``ast`` -- the module itself cannot be imported (it JIT-builds the CUDA extension at
+    import, upfirdn2d.py:10-17) and the function is dead code there that uses ``F`` without importing it (SURVEY.md
+    appendix A) -- and exec'd with ``torch`` / ``torch.nn.functional as F`` in scope.  The function body is the
+    reference's text, unmodified."""
+    import ast
+    import torch
+    import torch.nn.functional as F
+    path = os.path.join(REFERENCE_ROOT, "networks", "stylegan2", "op", "upfirdn2d.py")
+    with open(path) as f:
+        source = f.read()
+    node = next(n for n in ast.parse(source).body if isinstance(n, ast.FunctionDef) and n.name == "upfirdn2d_native")
+    scope = {"torch": torch, "F": F}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), scope)
+    return scope["upfirdn2d_native"]

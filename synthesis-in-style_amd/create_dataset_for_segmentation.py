@@ -14,8 +14,9 @@ class colours.
 Multi-GPU (BASELINE.json configs[2]: 100k images on 8 GPUs): one process per GPU (``torch.distributed.run`` or
 manual RANK/WORLD_SIZE), rank r generates the image-id range ``shard_range(num_images, r, world)``; no collective.
 The latent stream is one global seeded stream: every rank draws the whole stream in batch order and keeps its own
-rows, so the union over ranks equals the single-GPU dataset bit for bit (on the inputs; noise maps are per batch and
-drawn from the device RNG exactly as the reference does, so they differ across runs).
+rows; the per-batch noise maps ([1,1,h,h], shared by the batch's samples) are likewise drawn from the seeded device RNG
+for EVERY batch on every rank, also the batches a rank skips.  So the image an id maps to does not depend on the world
+size: the union over ranks equals the single-GPU dataset (tests/test_dataset_ops_gpu.py).
 """
 import argparse
 import json
@@ -26,7 +27,7 @@ import numpy
 import torch
 
 import sis_hip
-from networks.stylegan2.model import Generator
+from networks import get_stylegan2_generator
 from segmentation.gan_local_edit.factor_catalog import FactorCatalog
 from utils.dataset_creation import label_and_encode, shard_range
 
@@ -46,9 +47,9 @@ def save_generated_images(generated_images, label_images, first_id: int, base_di
 
 
 def load_generator(checkpoint, size, latent_size, n_mlp, channel_multiplier, device):
-    g = Generator(size, latent_size, n_mlp, channel_multiplier=channel_multiplier)
-    if checkpoint:
-        g.load_state_dict(torch.load(checkpoint, map_location='cpu')['g_ema'], strict=True)  # networks/__init__.py:422
+    """Generator-only branch of ``load_autoencoder_or_generator`` (networks/__init__.py:415-423: key 'g_ema', strict)."""
+    g = get_stylegan2_generator(size, latent_size, n_mlp=n_mlp, channel_multiplier=channel_multiplier,
+                                init_ckpt=checkpoint or None, ckpt_key='g_ema', strict=True)
     return g.to(device).eval()
 
 
@@ -90,12 +91,13 @@ def build_dataset(args, creation_config, rank=0, world_size=1):
     with torch.no_grad():
         for first in range(0, args.num_images, args.batch_size):
             n = min(args.batch_size, args.num_images - first)
-            z = torch.randn(args.batch_size, g.style_dim)[:n]  # the whole stream is drawn on every rank
+            z = torch.randn(args.batch_size, g.style_dim)[:n]  # the whole stream is drawn on every rank ...
+            noise = g.make_noise()  # ... and so are the batch's noise maps (device RNG, same seed on every rank)
             a, b = max(first, lo), min(first + n, hi)
             if a >= b:
                 continue
             z = z[a - first:b - first].to(device)
-            image, acts = g([z], noise=g.make_noise(), return_intermediate_activations=True,
+            image, acts = g([z], noise=noise, return_intermediate_activations=True,
                             truncation=0.7 if mean_latent is not None else 1, truncation_latent=mean_latent)
             job = (a,) + label_and_encode(image, acts, catalogs)  # side stream; the next batch's forward is issued first
             if pending is not None:

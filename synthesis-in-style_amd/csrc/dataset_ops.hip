@@ -4,20 +4,36 @@
 //                        labels[b,h,w] = argmin_k sum_c (x[b,c,h,w] - centre[k,c])^2
 //                        (segmentation/gan_local_edit/factor_catalog.py:47-62 of the reference, which ships the
 //                        activations to the CPU and materialises an N x K x C tensor there).  Direct
-//                        (x - c)^2 form in fp32 -- not the |x|^2 - 2xc + |c|^2 expansion, whose cancellation would
-//                        move near-tie labels -- ties go to the lowest index like torch.argmin.  Reads the
-//                        activation exactly once: HBM 4*C bytes per pixel, VALU 3*K flops per pixel-channel.
+//                        (x - c)^2 form in fp32 with the reference's own association of the adds (see the kernel):
+//                        label maps are bit-exact against the fp32 oracle.  Reads the activation exactly once:
+//                        HBM 4*C bytes per pixel, VALU 3*K flops per pixel-channel.
 //  * sis_make_image_u8   float image in [-1,1] (NCHW) -> uint8 NHWC, the conversion in front of the PNG writer
-//                        (create_dataset_for_segmentation.py:135; third-party make_image: clamp, (x+1)/2*255,
-//                        truncating cast -- rounding unpinned by the reference).
+//                        (create_dataset_for_segmentation.py:135; third-party make_image: clamp, add 1, div 2, mul 255,
+//                        truncating cast; every step a separate fp32 operation as in the oracle: bytes are bit-exact).
 #include "sis_common.h"
 
 namespace {
 
-template <int KMAX, int VEC>
+// Summation order (documented, bit-exact contract).  The reference evaluates ``((A - B) ** 2.0).sum(dim=-1)`` with
+// torch's CPU reduction (factor_catalog.py:55-59), whose result for near-ties depends on the association of the fp32
+// adds.  This kernel reproduces, add for add, the association of ATen's inner-dimension float sum
+// (aten/src/ATen/native/cpu/SumKernel.cpp: vectorized_inner_sum -> row_sum -> multi_row_sum; 8-float vectors under both
+// the AVX2 and the AVX-512 dispatch), restated in oracle/kmeans_ref.py::predict_ordered and pinned there against
+// torch's own sum:
+//   * channel c < 8*(C/8) is element l = c % 8 of vector i = c / 8; vector i feeds partial sum k = i % 4 in row
+//     r = i / 4, for i < 4*(C/32).  Per (l, k): running sum over the rows in order starting from 0; after every 16th
+//     row the running sum is added to a second-level sum and reset; p[k] = running + second level;
+//   * lane total = (((p[0] + vectors i >= 4*(C/32) in order) + p[1]) + p[2]) + p[3];
+//   * result = (((0 + scalar tail terms c >= 8*(C/8) in order) + lane 0) + lane 1) ... + lane 7;
+//   * every term is round(round(x - c) * round(x - c)): subtract, multiply and add are separate IEEE operations
+//     (no FMA contraction: #pragma clang fp contract(off)); ties go to the lowest centre index (torch.argmin).
+// 8 <= C < 8192 (below 8 ATen takes its scalar path, at 8192 a third cascade level starts).  The activations are
+// still read exactly once, one channel plane row per step.
+template <int KMAX, int VEC, bool CASCADE>
 __global__ __launch_bounds__(256) void kmeans_assign_kernel(int64_t* __restrict__ labels, const float* __restrict__ x,
                                                             const float* __restrict__ centres, int C, int HW, int K,
                                                             int groups) {
+#pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float cen[];  // [C][KMAX]
     const int b = blockIdx.x / groups, g = blockIdx.x % groups;
     for (int e = threadIdx.x; e < C * KMAX; e += 256) {
@@ -27,75 +43,116 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(int64_t* __restrict_
     __syncthreads();
     const int pix = (g * 256 + threadIdx.x) * VEC;
     if (pix >= HW) return;
-    // pixel pairs as 2-wide vectors: the subtract and the fused multiply-add issue as packed fp32 instructions
-    // (v_pk_add_f32 / v_pk_fma_f32: two pixels per lane and instruction), same per-element arithmetic as the scalar form
-    constexpr int NP = VEC >= 2 ? VEC / 2 : 1;
-    typedef float pkf __attribute__((ext_vector_type(VEC >= 2 ? 2 : 1)));
-    pkf d[KMAX][NP];
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k)
-#pragma unroll
-        for (int v = 0; v < NP; ++v) d[k][v] = (pkf)(0.f);
+    constexpr int NA1 = CASCADE ? KMAX : 1;
+    float fin[KMAX][VEC], lt[KMAX][VEC], acc0[KMAX][VEC], acc1[NA1][VEC];
     const float* xb = x + (int64_t)b * C * HW + pix;
-    for (int c = 0; c < C; ++c) {
-        pkf xv[NP];
-        if constexpr (VEC == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(xb + (int64_t)c * HW);
-            xv[0][0] = t.x; xv[0][1] = t.y; xv[1][0] = t.z; xv[1][1] = t.w;
-        } else if constexpr (VEC == 2) {
+    auto accumulate = [&](int c, float (&acc)[KMAX][VEC]) {  // acc[k][v] += (x[c] - centre[k][c])^2, three roundings
+        float xv[VEC];
+        if constexpr (VEC == 2) {
             const float2 t = *reinterpret_cast<const float2*>(xb + (int64_t)c * HW);
-            xv[0][0] = t.x; xv[0][1] = t.y;
+            xv[0] = t.x; xv[1] = t.y;
         } else {
-            xv[0][0] = xb[(int64_t)c * HW];
+            xv[0] = xb[(int64_t)c * HW];
         }
         const float* cc = cen + c * KMAX;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const pkf ck = (pkf)(cc[k]);
+        for (int k = 0; k < KMAX; ++k)
 #pragma unroll
-            for (int v = 0; v < NP; ++v) {
-                const pkf diff = xv[v] - ck;
-                d[k][v] = __builtin_elementwise_fma(diff, diff, d[k][v]);
+            for (int v = 0; v < VEC; ++v) {
+                const float diff = xv[v] - cc[k];
+                acc[k][v] = acc[k][v] + diff * diff;
+            }
+    };
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) fin[k][v] = 0.f;
+    const int nvec = C >> 3, rows = nvec >> 2;
+    for (int c = nvec << 3; c < C; ++c) accumulate(c, fin);  // scalar tail first
+    for (int l = 0; l < 8; ++l) {
+        for (int part = 0; part < 4; ++part) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    acc0[k][v] = 0.f;
+                    if constexpr (CASCADE) acc1[k][v] = 0.f;
+                }
+            for (int r = 0; r < rows; ++r) {
+                accumulate((((r << 2) + part) << 3) + l, acc0);
+                if constexpr (CASCADE) {
+                    if ((r & 15) == 15) {
+#pragma unroll
+                        for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) { acc1[k][v] = acc1[k][v] + acc0[k][v]; acc0[k][v] = 0.f; }
+                    }
+                }
+            }
+            if constexpr (CASCADE) {
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc0[k][v] = acc0[k][v] + acc1[k][v];
+            }
+            if (part == 0) {
+                for (int i = rows << 2; i < nvec; ++i) accumulate((i << 3) + l, acc0);  // left-over vectors join p[0]
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) lt[k][v] = acc0[k][v];
+            } else {
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) lt[k][v] = lt[k][v] + acc0[k][v];
             }
         }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) fin[k][v] = fin[k][v] + lt[k][v];
     }
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-        float best = d[0][v / 2][v % 2];
+        float best = fin[0][v];
         int arg = 0;
 #pragma unroll
         for (int k = 1; k < KMAX; ++k)
-            if (k < K && d[k][v / 2][v % 2] < best) { best = d[k][v / 2][v % 2]; arg = k; }
+            if (k < K && fin[k][v] < best) { best = fin[k][v]; arg = k; }
         labels[(int64_t)b * HW + pix + v] = arg;
     }
 }
 
 __global__ __launch_bounds__(256) void make_image_kernel(uint8_t* __restrict__ out, const float* __restrict__ x,
                                                          int C, int HW, int64_t total) {
+#pragma clang fp contract(off)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one lane = one pixel, writes C bytes (NHWC)
     if (i >= total) return;
     const int64_t b = i / HW, p = i - b * HW;
     for (int c = 0; c < C; ++c) {
         float v = x[(b * C + c) * HW + p];
-        v = fminf(fmaxf(v, -1.f), 1.f);
-        v = (v + 1.f) / 2.f * 255.f;
-        out[i * C + c] = (uint8_t)v;  // truncating cast, as tensor.type(torch.uint8)
+        v = fminf(fmaxf(v, -1.f), 1.f);  // clamp(min=-1, max=1)
+        v = v + 1.f;                     // .add(1)   each step rounded to fp32 on its own, in the oracle's order
+        v = v / 2.f;                     // .div(2)
+        v = v * 255.f;                   // .mul(255)
+        out[i * C + c] = (uint8_t)v;     // truncating cast, as tensor.type(torch.uint8)
     }
 }
 
-template <int KMAX, int VEC>
+template <int KMAX, int VEC, bool CASCADE>
 int launch_kmeans(int64_t* labels, const float* x, const float* centres, int batch, int C, int HW, int K, hipStream_t st) {
     const int groups = sis_cdiv(HW, 256 * VEC);
     const size_t lds = (size_t)C * KMAX * sizeof(float);
     SIS_REQUIRE(lds <= 160 * 1024, "sis_kmeans_assign: %d channels x %d centres do not fit in LDS", C, KMAX);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kmeans_assign_kernel<KMAX, VEC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kmeans_assign_kernel<KMAX, VEC, CASCADE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return sis_fail("sis_kmeans_assign: cannot raise the LDS limit: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((kmeans_assign_kernel<KMAX, VEC>), dim3(batch * groups), dim3(256), lds, st, labels, x, centres, C,
+    hipLaunchKernelGGL((kmeans_assign_kernel<KMAX, VEC, CASCADE>), dim3(batch * groups), dim3(256), lds, st, labels, x, centres, C,
                        HW, K, groups);
     SIS_CHECK_LAUNCH("kmeans_assign_kernel");
     return 0;
@@ -110,15 +167,20 @@ extern "C" int sis_kmeans_assign(int64_t* labels, const float* x, const float* c
     SIS_REQUIRE(n_centres >= 1 && n_centres <= 64, "sis_kmeans_assign: %d centres outside 1..64", n_centres);
     SIS_REQUIRE(channels >= 1, "sis_kmeans_assign: no channels");
     hipStream_t st = (hipStream_t)stream;
-    const bool vec = hw % 4 == 0 && (((uintptr_t)x) & 15) == 0;
+    SIS_REQUIRE(channels >= 8 && channels < 8192,
+                "sis_kmeans_assign: %d channels (the documented summation order covers 8 <= C < 8192)", channels);
+    const bool vec = hw % 2 == 0 && (((uintptr_t)x) & 7) == 0;
+    const bool cascade = (channels >> 5) > 16;  // more than 16 rows of 4 vectors: the second-level sums carry a rounding
     // accumulators for the centre count rounded up to a multiple of 8 (the reference config's 24 centres: no padded work)
 #define KM_CASE(KM)                                                                                                      \
-    if (n_centres <= KM) return vec ? launch_kmeans<KM, 4>(labels, x, centres, batch, channels, hw, n_centres, st)        \
-                                    : launch_kmeans<KM, 1>(labels, x, centres, batch, channels, hw, n_centres, st);
-    KM_CASE(8) KM_CASE(16) KM_CASE(24) KM_CASE(32)
+    if (n_centres <= KM) {                                                                                               \
+        if (cascade) return launch_kmeans<KM, 1, true>(labels, x, centres, batch, channels, hw, n_centres, st);           \
+        return vec ? launch_kmeans<KM, 2, false>(labels, x, centres, batch, channels, hw, n_centres, st)                  \
+                   : launch_kmeans<KM, 1, false>(labels, x, centres, batch, channels, hw, n_centres, st);                 \
+    }
+    KM_CASE(8) KM_CASE(16) KM_CASE(24) KM_CASE(32) KM_CASE(64)
 #undef KM_CASE
-    return hw % 2 == 0 && (((uintptr_t)x) & 7) == 0 ? launch_kmeans<64, 2>(labels, x, centres, batch, channels, hw, n_centres, st)
-                                                    : launch_kmeans<64, 1>(labels, x, centres, batch, channels, hw, n_centres, st);
+    return sis_fail("sis_kmeans_assign: unreachable");
 }
 
 extern "C" int sis_make_image_u8(uint8_t* out, const float* x, int batch, int channels, int hw, void* stream) {

@@ -15,11 +15,8 @@
 
 namespace {
 
-__host__ __device__ __forceinline__ int floor_div(int a, int b) {
-    int c = a / b;
-    if (c * b > a) c--;
-    return c;
-}
+// floor(a / b) for an up-sampling factor b >= 1 (C division truncates toward zero: shift negative numerators first)
+__host__ __device__ __forceinline__ int floor_div(int a, int b) { return (a >= 0 ? a : a - b + 1) / b; }
 
 struct UpdnParams {
     int major, in_h, in_w, minor, kh, kw;

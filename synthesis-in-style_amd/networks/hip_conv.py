@@ -178,7 +178,7 @@ class HipConv2d(nn.Conv2d):
         d = self.dilation[0]
         return (self.kernel_size == (3, 3) and self.stride == (1, 1) and self.dilation == (d, d) and self.padding == (d, d)
                 and self.groups == 1 and self.bias is None and self.padding_mode == 'zeros' and input.dim() == 4
-                and input.shape[2] == 2 * d and input.shape[3] == 2 * d and input.is_cuda)
+                and input.shape[2] == 2 * d and input.shape[3] == 2 * d and input.is_cuda and input.is_contiguous())
 
     def _pointwise(self, input):
         return (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.groups == 1

@@ -62,7 +62,11 @@ def get_scheduler(config: dict, iterations_per_epoch: int, optimizers: dict):
         end = config['cosine_max_update_iter']
     else:
         end = config['epochs']
-    return {name: ClampedCosineAnnealingLR(opt, end, eta_min=config.get('end_lr', 0.0)) for name, opt in optimizers.items()}
+    eta_min = config.get('end_lr', 0.0)
+    if config.get('warm_restarts'):  # train.py:50-52 of the reference
+        return {name: torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, end, eta_min=eta_min)
+                for name, opt in optimizers.items()}
+    return {name: ClampedCosineAnnealingLR(opt, end, eta_min=eta_min) for name, opt in optimizers.items()}
 
 
 def get_data_loader(config: dict, rank: int, device):

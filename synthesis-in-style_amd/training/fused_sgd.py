@@ -57,10 +57,17 @@ class FusedSGD(Optimizer):
         self._offset = np.asarray(offset, dtype=np.int64)
         self._count = np.asarray(count, dtype=np.int64)
         self._n_chunks = len(owner)
-        # two pinned staging buffers, alternated: the previous step's non-blocking copy may still be in flight
-        self._hosts = [torch.empty((self._n_chunks, 4), dtype=torch.int64).pin_memory() for _ in range(2)]
+        # pinned staging ring: earlier steps' non-blocking copies may still be in flight, so every buffer carries the
+        # event recorded behind its last copy and is only rewritten after that event (as push_hyper() does)
+        device = entries[0][1].device
+        self._on_gpu = device.type == 'cuda'  # (host-only runs exist for the gloo rehearsal of the bucket aliasing logic)
+        self._hosts = [[self._staging((self._n_chunks, 4)), None] for _ in range(4)]
         self._flip = 0
-        self._table = torch.empty((self._n_chunks, 4), dtype=torch.int64, device=entries[0][1].device)
+        self._table = torch.empty((self._n_chunks, 4), dtype=torch.int64, device=device)
+
+    def _staging(self, shape):
+        host = torch.empty(shape, dtype=torch.int64)
+        return host.pin_memory() if self._on_gpu else host
 
     def push_hyper(self):
         """Copies the current lr / weight decay / momentum of ``param_groups`` into the device tensor the captured
@@ -89,14 +96,19 @@ class FusedSGD(Optimizer):
         if capturing:
             # the captured copy node re-reads its source on every replay: it gets a buffer nothing else writes
             # (allocated by push_hyper(): pinning memory is not allowed while a stream is capturing)
-            pinned = self._capture_host
+            pinned, slot = self._capture_host, None
         else:
-            self._flip ^= 1
-            pinned = self._hosts[self._flip]
+            self._flip = (self._flip + 1) % len(self._hosts)
+            slot = self._hosts[self._flip]
+            if slot[1] is not None:
+                slot[1].synchronize()  # only blocks when the host is a whole ring ahead of the device
+            pinned = slot[0]
         host = pinned.numpy()
         host[:, :3] = ptrs[self._owner] + self._offset[:, None]
         host[:, 3] = self._count
         self._table.copy_(pinned, non_blocking=True)
+        if slot is not None and self._on_gpu:
+            slot[1] = torch.cuda.current_stream(self._table.device).record_event()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -127,7 +139,7 @@ class FusedSGD(Optimizer):
             self._layout(entries)
             self._table_key = static_key
             self._grad_key = None
-        capturing = torch.cuda.is_current_stream_capturing()
+        capturing = self._on_gpu and torch.cuda.is_current_stream_capturing()
         if capturing and (fresh or self._hyper is None or self._capture_host is None):
             raise RuntimeError("FusedSGD: capture needs one eager step() and a push_hyper() call first")
         grad_key = tuple(g.data_ptr() for _, _, g, _ in entries) + tuple(p.data_ptr() for _, p, _, _ in entries)

@@ -36,18 +36,32 @@ class StepGraph:
                 return step_fn(batch)
             try:
                 self._capture(batch, step_fn, optimizers)
-            except Exception as err:  # a library call that cannot be captured: stay eager (nothing was executed)
+            except Exception as err:  # a library call that cannot be captured: stay eager
+                # No captured kernel has executed.  What _capture() did before the failure is harmless for an eager
+                # step: push_hyper() only refreshed the device copy of the hyper-parameters, and the gradients it set to
+                # None are re-created by the step's own zero_grad() / backward.
                 import warnings
                 warnings.warn(f"hipGraph capture of the training step failed ({err!r}); continuing eagerly")
                 self.enabled, self.graph = False, None
                 torch.cuda.synchronize()
                 return step_fn(batch)
+        if not self._matches(batch):
+            # e.g. the last, smaller batch of an epoch: a copy into the static inputs would raise (or silently broadcast a
+            # batch of one over the captured batch size), so this iteration runs eagerly; the graph stays valid (its
+            # captured launches hold their own gradient / table addresses, re-uploaded on every replay)
+            return step_fn(batch)
         for key, value in batch.items():
             self.static_batch[key].copy_(value, non_blocking=True)
         for opt in optimizers:
             opt.push_hyper()
         self.graph.replay()
         return self.static_out
+
+    def _matches(self, batch) -> bool:
+        if batch.keys() != self.static_batch.keys():
+            return False
+        return all(value.shape == self.static_batch[key].shape and value.dtype == self.static_batch[key].dtype
+                   and value.device == self.static_batch[key].device for key, value in batch.items())
 
     def _capture(self, batch, step_fn, optimizers):
         self.static_batch = {key: value.clone() for key, value in batch.items()}

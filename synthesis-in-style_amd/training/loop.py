@@ -7,7 +7,8 @@ updaters rely on, as observed at their call sites (updater/segmentation_updater.
 training_builder/ema_net_train_builder.py:50-59):
 
 * ``Updater(iterators, networks, optimizers, device, copy_to_device)`` holds the three dicts; ``update()``
-  runs ``update_core()`` once and counts iterations;
+  runs ``update_core()`` once and counts iterations; ``next_batch(name)`` restarts a finite loader at its end (epoch
+  boundary);
 * ``GradientApplier(networks, optimizers)`` is a context manager: ``zero_grad`` on entry, ``step`` on exit;
 * ``get_current_reporter().add_observation(dict, prefix)`` records scalars under ``prefix/key``;
 * ``UpdateDisabler(network)`` (updater/stylegan_2_updater.py:130,164) freezes a network's parameters inside the block;
@@ -86,6 +87,7 @@ def reduce_sum(tensor):
 
 class Updater:
     def __init__(self, iterators: Dict, networks: Dict, optimizers: Dict, device='cuda', copy_to_device=True):
+        self.loaders = dict(iterators)  # kept so that an exhausted (one-epoch) iterator can be re-created
         self.iterators = {k: iter(v) for k, v in iterators.items()}
         self.networks = networks
         self.optimizers = optimizers
@@ -96,6 +98,18 @@ class Updater:
     def update(self):
         self.update_core()
         self.iteration += 1
+
+    def next_batch(self, name: str):
+        """Next batch of ``iterators[name]``; a finite loader (one pass = one epoch) is restarted at its end, as the
+        reference's trainer re-creates its iterators per epoch."""
+        try:
+            return next(self.iterators[name])
+        except StopIteration:
+            self.iterators[name] = iter(self.loaders[name])
+            try:
+                return next(self.iterators[name])
+            except StopIteration:
+                raise RuntimeError(f"data loader '{name}' yields no batches") from None
 
     def update_core(self):
         raise NotImplementedError

@@ -48,7 +48,7 @@ class _GraphedUpdater(Updater):
         raise NotImplementedError
 
     def update_core(self):
-        batch = next(self.iterators['images'])
+        batch = self.next_batch('images')  # restarts a finite loader at the epoch boundary
         batch = {key: value.to(self.device, non_blocking=True) for key, value in batch.items()}
         observed = self._step_graph.run(batch, self._iteration, [self.optimizers['main']])
         get_current_reporter().add_observation(observed, self.report_prefix)

@@ -7,10 +7,12 @@ reference produced for them.
 
 Fixtures
 --------
-ops_known_answers.npz   G1  per-op known-answer vectors for upfirdn2d / fused_bias_act.  The
-                            reference's own ops are CUDA-only and cannot run here, so
-                            these come from the two independent restatements (oracle/ops_ref.py,
-                            oracle/ops_c.c), which are asserted equal to 1e-12 (fp64) first.
+ops_known_answers.npz   G1  per-op known-answer vectors.  upfirdn2d: outputs of the reference's OWN
+                            pure-PyTorch statement ``upfirdn2d_native`` (op/upfirdn2d.py:152-186, lifted
+                            with ``ast``: oracle/load_reference.py), asserted equal to 1e-12 (fp64) to
+                            the two independent restatements (oracle/ops_ref.py, oracle/ops_c.c) first.
+                            fused_bias_act: the reference holds only the CUDA kernel, so
+                            these come from the two restatements, asserted equal to each other.
 gen16.npz               G2  reference Generator(16, 64, 3, cm=1): image + all activations, B=2.
 gen32.npz               G2/G4 reference Generator(32, 512, 8, cm=2): image, channel-strided
                             activations, truncation 0.7 image, style-mixing image, B=2.
@@ -53,6 +55,7 @@ OP_CASES = [
 def make_ops():
     rng = np.random.RandomState(1234)
     out = {}
+    native = load_reference.load_reference_upfirdn2d_native()  # the reference's own statement of K2
     for ci, (major, ih, iw, minor, kh, kw, up, down, p0, p1) in enumerate(OP_CASES):
         x = rng.standard_normal((major, ih, iw, minor))
         k = rng.standard_normal((kh, kw))  # asymmetric taps pin the flip
@@ -60,8 +63,10 @@ def make_ops():
         y_t = ops_ref.upfirdn2d_nhwc(torch.from_numpy(x), torch.from_numpy(k), up, up, down, down, p0, p1, p0,
                                      p1).numpy()
         assert y_c.shape == y_t.shape and np.abs(y_c - y_t).max() < 1e-12
+        y_ref = native(torch.from_numpy(x), torch.from_numpy(k), up, up, down, down, p0, p1, p0, p1).numpy()
+        assert y_ref.shape == y_c.shape and np.abs(y_ref - y_c).max() < 1e-12 and np.abs(y_ref - y_t).max() < 1e-12
         out[f"up{ci}_cfg"] = np.array([major, ih, iw, minor, kh, kw, up, down, p0, p1])
-        out[f"up{ci}_x"], out[f"up{ci}_k"], out[f"up{ci}_y"] = x, k, y_c
+        out[f"up{ci}_x"], out[f"up{ci}_k"], out[f"up{ci}_y"] = x, k, y_ref  # the vectors ARE the reference's output
     x = rng.standard_normal((3, 5, 4, 6))
     b = rng.standard_normal(5)
     ref = rng.standard_normal((3, 5, 4, 6))

@@ -100,6 +100,144 @@ def test_ddp_wrap_world_size_2_gloo():
     assert out[0][3] != out[1][3], "batch-norm statistics must be per-rank"
 
 
+class _TinyEmaShaped(nn.Module):
+    """CPU stand-in with EMANet's optimizer-relevant shape: conv weights / norm scales / biases in three groups and
+    one parameter that never receives a gradient (EMANet's ``emau.conv1``: find_unused_parameters)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(3, 8, 3, padding=1, bias=False)
+        self.bn = nn.BatchNorm2d(8)
+        self.unused = nn.Conv2d(8, 8, 1)
+        self.head = nn.Conv2d(8, 3, 1)
+
+    def forward(self, x):
+        return self.head(torch.relu(self.bn(self.conv(x))))
+
+
+def _host_sgd_kernel(table, n_chunks, lrs, wds, momentum, first_step):
+    """Host stand-in for ``sis_sgd_momentum`` (csrc/seg_ops.hip ``sgd_kernel``): walks the SAME chunk table the device
+    kernel gets -- raw (param, grad, momentum) addresses + count | group << 48 -- and applies torch.optim.SGD's update."""
+    import ctypes
+    import numpy as np
+    rows = table.numpy()
+    for p_ptr, g_ptr, b_ptr, packed in rows[:n_chunks]:
+        n, gi = int(packed) & ((1 << 48) - 1), int(packed) >> 48
+        view = lambda ptr: np.ctypeslib.as_array((ctypes.c_float * n).from_address(int(ptr)))  # noqa: E731
+        p, g, b = view(p_ptr), view(g_ptr), view(b_ptr)
+        d = g + np.float32(wds[gi]) * p
+        b[:] = d if first_step else np.float32(momentum) * b + d
+        p -= np.float32(lrs[gi]) * b
+
+
+def _fused_sgd_worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, "synthesis-in-style_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sis_hip
+        from training.fused_sgd import FusedSGD
+        from training_builder.base_train_builder import BaseTrainBuilder
+        from updater.segmentation_updater import _graphable
+        sis_hip.sgd_momentum = _host_sgd_kernel          # the kernel only; table / bucket logic below is the product's
+        sis_hip.require_device = lambda t, name: None
+        sis_hip.sgd_chunk_elems = lambda: 64             # several chunks per tensor
+
+        class Builder(BaseTrainBuilder):  # EMANetTrainBuilder's declarations on the stand-in network
+            find_unused_params = True
+
+            def build_network(self):
+                torch.manual_seed(0)
+                return _TinyEmaShaped()
+
+            def parameter_groups(self, network):
+                conv = [network.conv.weight, network.unused.weight, network.head.weight]
+                return [{'params': conv, 'lr': 0.05, 'weight_decay': 1e-2}, {'params': [network.bn.weight], 'lr': 0.05,
+                        'weight_decay': 0.0}, {'params': [network.bn.bias, network.unused.bias, network.head.bias],
+                                               'lr': 0.1, 'weight_decay': 0.0}]
+
+            def optimizer_defaults(self):
+                return {'momentum': 0.9}
+
+        builder = Builder({"fine_tune": None, "bucket_cap_mb": 1}, rank=rank, world_size=world)
+        ddp = builder.get_network()
+        net = ddp.module
+        opt = builder.get_optimizers()['main']
+        assert isinstance(opt, FusedSGD) and isinstance(ddp, nn.parallel.DistributedDataParallel)
+        graph_off = not _graphable(ddp, opt, 'cuda:0')   # the whole-iteration hipGraph must stay off under DDP
+        # reference run: same data, plain torch.optim.SGD on the hand-averaged gradients
+        torch.manual_seed(0)
+        solo = _TinyEmaShaped()
+        ref_opt = torch.optim.SGD(Builder.parameter_groups(builder, solo), momentum=0.9)
+        uploads, table_ok, alias_ok, ptrs, spans = [], True, True, [], []
+
+        def recording_allreduce(state, bucket):  # the default hook's arithmetic, plus a record of the bucket's storage
+            buf = bucket.buffer()
+            state.append((buf.data_ptr(), buf.data_ptr() + 4 * buf.numel()))
+            fut = dist.all_reduce(buf.div_(world), async_op=True).get_future()
+            return fut.then(lambda f: f.value()[0])
+
+        ddp.register_comm_hook(spans, recording_allreduce)
+        orig_upload = opt._upload
+        opt._upload = lambda entries, capturing=False: (uploads.append(1), orig_upload(entries, capturing))[1]
+        for it in range(3):
+            gen = torch.Generator().manual_seed(100 * it + rank)
+            x, y = torch.randn(2, 3, 8, 8, generator=gen), torch.randint(0, 3, (2, 8, 8), generator=gen)
+            opt.zero_grad()  # set_to_none: DDP re-points .grad at the bucket views during backward
+            nn.functional.cross_entropy(ddp(x), y).backward()
+            live = [p for p in net.parameters() if p.grad is not None]
+            assert net.unused.weight.grad is None and len(live) == 5 and spans
+            alias_ok &= all(any(lo <= p.grad.data_ptr() < hi for lo, hi in spans) for p in live)
+            ptrs.append(tuple(p.grad.data_ptr() for p in live))
+            opt.step()
+            rows = opt._table.numpy()
+            first_chunk = {int(r[0]): int(r[1]) for r in rows}  # param address -> grad address of each tensor's chunk 0
+            table_ok &= all(first_chunk[p.data_ptr()] == p.grad.data_ptr() for p in live)
+            # reference: average of both ranks' local gradients
+            ref_opt.zero_grad()
+            for r in range(world):
+                gen_r = torch.Generator().manual_seed(100 * it + r)
+                xr, yr = torch.randn(2, 3, 8, 8, generator=gen_r), torch.randint(0, 3, (2, 8, 8), generator=gen_r)
+                solo.bn.train()
+                (nn.functional.cross_entropy(solo(xr), yr) / world).backward()
+            ref_opt.step()
+        close = all(torch.allclose(a, b, atol=2e-6) for a, b in zip(net.parameters(), solo.parameters()))
+        flat = torch.cat([p.detach().flatten() for p in net.parameters()])
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        out[rank] = dict(graph_off=graph_off, uploads=len(uploads), stable=len(set(ptrs)) == 1, table_ok=bool(table_ok),
+                         alias_ok=bool(alias_ok), close=bool(close), lockstep=all(torch.equal(gathered[0], q) for q in gathered),
+                         untouched=bool(torch.equal(net.unused.weight, _TinyEmaShaped_init_unused())))
+    finally:
+        dist.destroy_process_group()
+
+
+def _TinyEmaShaped_init_unused():
+    torch.manual_seed(0)
+    return _TinyEmaShaped().unused.weight.detach()
+
+
+def test_fused_sgd_on_ddp_bucket_views_world_size_2_gloo():
+    """EMANetTrainBuilder's shape under DistributedDataParallel(gradient_as_bucket_view=True, find_unused_parameters=True)
+    with the product's FusedSGD: gradients live in the all-reduce buckets at stable addresses (ONE pointer-table upload for
+    three iterations), the table's gradient column points into the buckets, the update equals torch.optim.SGD on the
+    rank-averaged gradients (3 groups: lr / 2 lr / weight decay), the gradient-less parameter is skipped like
+    torch.optim.SGD skips it, replicas stay in lock-step, and the step hipGraph is off under DDP.  Only the kernel is a
+    host stand-in (it consumes the same chunk table).  Unmeasured on hardware until a multi-GPU SCALE record exists."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_fused_sgd_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert len(out) == world
+    for rank in range(world):
+        r = out[rank]
+        assert r["graph_off"], "hipGraph capture must be disabled under DistributedDataParallel"
+        assert r["stable"] and r["uploads"] == 1, f"gradient storage moved between iterations: {r}"
+        assert r["alias_ok"] and r["table_ok"], f"pointer table does not alias the DDP buckets: {r}"
+        assert r["close"], "FusedSGD on bucket views differs from torch.optim.SGD on the averaged gradients"
+        assert r["lockstep"] and r["untouched"]
+
+
 class _TinyGenerator(nn.Module):
     """CPU stand-in with the call surface Stylegan2Updater uses: ``g(styles, noise=..., return_latents=...)`` ->
     (image, latents | None), ``noises`` buffers, differentiable from the latents to the image."""

@@ -136,3 +136,51 @@ def test_oracle_bit_identical_to_imported_reference():
     assert torch.equal(a, b)
     for k in acts_a:
         assert torch.equal(acts_a[k], acts_b[k])
+
+
+@pytest.mark.skipif(not load_reference.reference_available(), reason="reference tree only exists in the build container")
+def test_k2_restatements_equal_the_references_own_native_statement():
+    """``upfirdn2d_native`` (op/upfirdn2d.py:152-186), lifted from the reference file with ``ast``, on fresh inputs."""
+    native = load_reference.load_reference_upfirdn2d_native()
+    rng = np.random.RandomState(77)
+    for major, ih, iw, minor, kh, kw, up, down, p0, p1 in [(3, 9, 7, 1, 4, 4, 1, 1, 1, 1), (2, 5, 6, 2, 4, 4, 2, 1, 2, 1),
+                                                           (2, 8, 9, 1, 4, 4, 1, 2, 1, 1), (1, 6, 5, 3, 3, 2, 2, 2, 1, -1),
+                                                           (2, 4, 4, 1, 2, 2, 2, 1, 1, 0)]:
+        x, k = rng.standard_normal((major, ih, iw, minor)), rng.standard_normal((kh, kw))
+        want = native(torch.from_numpy(x), torch.from_numpy(k), up, up, down, down, p0, p1, p0, p1).numpy()
+        got_c = c_ops.upfirdn2d_nhwc(x, k, up, up, down, down, p0, p1, p0, p1)
+        got_t = ops_ref.upfirdn2d_nhwc(torch.from_numpy(x), torch.from_numpy(k), up, up, down, down, p0, p1, p0, p1).numpy()
+        np.testing.assert_allclose(got_c, want, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(got_t, want, rtol=0, atol=1e-12)
+
+
+def _kmeans_cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_kmeans", os.path.join(os.path.dirname(__file__), "golden",
+                                                                                     "make_golden_kmeans.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_kmeans_oracle_reproduces_the_reference_label_maps(golden_dir):
+    """tests/golden/kmeans_reference.npz: label maps of the reference's own FactorCatalog.predict on inputs whose
+    centres come in near-duplicate pairs (most pixels decided by fp32 rounding)."""
+    from oracle import kmeans_ref
+    mk = _kmeans_cases()
+    g = _load(golden_dir, "kmeans_reference.npz")
+    for i in range(len(mk.CASES)):
+        x, centres = mk.case_inputs(i)
+        want = torch.from_numpy(g[f"labels{i}"].astype(np.int64))
+        assert torch.equal(kmeans_ref.predict(x, centres)[0], want)
+        assert torch.equal(kmeans_ref.predict_ordered(x, centres)[0], want)
+
+
+@pytest.mark.parametrize("size", [1, 3, 7, 8, 9, 16, 17, 20, 31, 32, 100, 128, 300, 512, 543, 544, 1056, 2100, 4100])
+def test_ordered_sum_is_torchs_cpu_sum(size):
+    """The written-out association (oracle/kmeans_ref.py::ordered_sum) equals torch's inner-dimension float sum bit
+    for bit -- the contract csrc/dataset_ops.hip documents."""
+    from oracle import kmeans_ref
+    gen = torch.Generator().manual_seed(size)
+    t = torch.randn(37, 5, size, generator=gen) ** 2
+    assert torch.equal(kmeans_ref.ordered_sum(t), t.sum(dim=-1))

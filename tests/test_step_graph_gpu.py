@@ -96,3 +96,40 @@ def test_lr_change_reaches_the_captured_optimizer(device):
     graph.replay()
     torch.cuda.synchronize()
     np.testing.assert_allclose(p.detach().cpu().numpy(), -0.125, atol=1e-7)
+
+
+def test_partial_batch_runs_eagerly_and_graph_stays_valid(device):
+    """a batch whose shape differs from the captured one (last batch of an epoch) must neither raise from the
+    static-input copy nor be broadcast into it; it runs eagerly, later full batches replay the graph again, and the
+    parameters equal an all-eager run."""
+    from training.fused_sgd import FusedSGD
+    from updater.segmentation_updater import _GraphedUpdater
+    gen = torch.Generator().manual_seed(5)
+    sizes = [4, 4, 4, 4, 2, 4, 1, 4]
+    batches = [{"images": torch.randn(n, 16, generator=gen), "segmented": torch.randn(n, 8, generator=gen)} for n in sizes]
+
+    class Tiny(_GraphedUpdater):
+        def _iteration(self, batch):
+            net, opt = self.networks["segmentation"], self.optimizers["main"]
+            loss = ((net(batch["images"]) - batch["segmented"]) ** 2).mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return {"mse": loss.detach()}
+
+    def run(hip_graph):
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 8)).to(device)
+        opt = FusedSGD(list(net.parameters()), lr=0.05, momentum=0.9)
+        upd = Tiny(iterators={"images": batches}, networks={"segmentation": net}, optimizers={"main": opt}, device=device,
+                   hip_graph=hip_graph)
+        for _ in sizes:
+            upd.update()
+        torch.cuda.synchronize()
+        return [p.detach().cpu().clone() for p in net.parameters()], upd
+
+    eager, _ = run(False)
+    graphed, upd = run(True)
+    assert upd._step_graph.graph is not None and upd.iteration == len(sizes)
+    for a, b in zip(eager, graphed):
+        np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=1e-5, atol=1e-6)
