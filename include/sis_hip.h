@@ -213,7 +213,9 @@ int sis_bn_act_bwd(float* dx, float* dresidual, float* dgamma, float* dbeta, con
 
 /* Nearest k-means centre per pixel: labels[b,p] = argmin_k sum_c (x[b,c,p] - centres[k,c])^2, ties to the lowest
  * k (segmentation/gan_local_edit/factor_catalog.py:47-62 + :69-75: FactorCatalog.predict on [B,C,H,W]).
- * x [B,C,HW] float32, centres [K,C] float32 (K <= 64), labels int64 [B,HW]. */
+ * x [B,C,HW] float32, centres [K,C] float32 (K <= 64, 8 <= C < 8192), labels int64 [B,HW].
+ * Bit-exact contract: the fp32 adds are associated exactly as torch's CPU ``.sum(dim=-1)`` associates them (the
+ * reference's evaluation); the order is written out in csrc/dataset_ops.hip and oracle/kmeans_ref.py. */
 int sis_kmeans_assign(int64_t* labels, const float* x, const float* centres, int batch, int channels,
                       int hw, int n_centres, void* stream);
 
@@ -323,6 +325,27 @@ int sis_crop_patches_u8(float* out, const unsigned char* image, const int* xs, c
                         int height, int width, int channels, int patch, void* stream);
 int sis_assemble_max(float* out, unsigned char* labels, const float* pred, const int* xs, const int* ys, int nx,
                      int ny, int classes, int height, int width, int patch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * bf16 convolutions of the segmentation training step on the matrix cores, direct on NCHW tensors (csrc/conv_bf16.hip):
+ * TransUNet under bf16 autocast -- StdConv2d 3x3 / 1x1 (networks/trans_u_net/vit_seg_modeling_resnet_skip.py:20-37,40-75),
+ * decoder Conv2dReLU and segmentation head (vit_seg_modeling.py:265-287,324-329), patch embedding (:125-168).
+ * Kernel sizes 1 and 3 (padding ksize/2), strides 1 and 2, Cin % 16 == 0 (% 64 for 1x1 stride 1); x / y bf16 NCHW,
+ * fp32 accumulation, optional fp32 bias[cout] added before the rounding to bf16.
+ *   sis_conv_bf16_supported     1 when a tile plan exists for the layer.
+ *   sis_conv_bf16_packed_elems  bf16 elements of the packed weight image (-1: unsupported).
+ *   sis_conv_bf16_pack          weight [cout][cin][k][k] (SIS_F32 or SIS_BF16) -> the kernel's LDS image, per output
+ *                               channel tile / input channel chunk / tap / row, 16-byte units XOR-swizzled.
+ *                               adjoint = 1 packs the convolution that takes dL/dy to dL/dx of a stride-1 layer
+ *                               (channel roles swapped, taps rotated by 180 degrees); it is then used with
+ *                               sis_conv_bf16(cin = the layer's cout, cout = the layer's cin).
+ *   sis_conv_bf16               y [batch][cout][ho][wo] = conv(x [batch][cin][h][w], packed) (+ bias). */
+int sis_conv_bf16_supported(int cin, int cout, int h, int w, int ksize, int stride);
+int64_t sis_conv_bf16_packed_elems(int cin, int cout, int h, int w, int ksize, int stride, int adjoint);
+int sis_conv_bf16_pack(void* packed, const void* weight, int weight_dtype, int cin, int cout, int h, int w, int ksize,
+                       int stride, int adjoint, void* stream);
+int sis_conv_bf16(void* y, const void* x, const void* packed, const float* bias, int batch, int cin, int cout, int h, int w,
+                  int ksize, int stride, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,400 @@
+// bf16 convolutions of the segmentation training step on the CDNA4 matrix cores, direct on NCHW tensors.
+//
+// Replaces, for TransUNet under bf16 autocast (BASELINE.json configs[4]), the library path
+// NCHW -> NHWC transpose -> implicit-GEMM kernel -> NHWC -> NCHW transpose of every convolution
+// (reference call sites: networks/trans_u_net/vit_seg_modeling_resnet_skip.py:20-37,40-75 StdConv2d 3x3 / 1x1,
+// vit_seg_modeling.py:265-287 decoder Conv2dReLU, :324-329 segmentation head, :125-168 patch embedding).
+//
+// GEMM view per image:  D[co][pixel] = sum_{ci,tap} W[co][ci,tap] * X[ci][pixel + tap],  fp32 accumulation on
+// v_mfma_f32_32x32x16_bf16 (A = weights, B = activations, 16 input channels per instruction and tap).
+//
+// The MFMA wants 8 consecutive K elements (= input channels) per lane, NCHW keeps a channel's pixels consecutive.
+// The transposition happens once per staged element on its way into LDS, in registers:
+//   * X tile: [c8][row][x][8 channels] -- one 16-byte unit per pixel and group of 8 channels.  A thread loads 4 pixels
+//     of 8 channel rows (8 x 8 bytes), interleaves them with 16 v_perm_b32 and writes 4 units (ds_write_b128).  Any tap
+//     shift is then a whole number of units: every B fragment is ONE ds_read_b128, consecutive lanes = consecutive pixels
+//     (conflict free), all taps of a chunk addressed from one base register with immediate offsets.
+//   * W tile: prepacked once per weight update by conv_pack_kernel into exactly the LDS image
+//     [co tile][channel chunk][tap][row][unit ^ swizzle(row)][8 channels], copied linearly by LDS-DMA
+//     (global_load_lds_dwordx4); the XOR swizzle makes the 16 rows of a ds_read_b128 lane group hit 16 different banks.
+// Double-buffered stages, one barrier per chunk; X loads for chunk c+1 are issued before the MFMAs of chunk c and
+// written to LDS after them (issue early / write late), the weight DMA flies underneath.
+//
+// The data gradient is the same kernel on adjoint-packed weights (channel roles swapped, taps rotated by 180 degrees);
+// stride-2 layers read their B fragments at a pixel stride of two units.
+#include "sis_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned short u16;
+
+template <int MT_, int KC_, int KH_, int S_, int TW_>
+struct ConvCfg {
+    static constexpr int MT = MT_, KC = KC_, KH = KH_, KW = KH_, S = S_, TW = TW_;
+    static constexpr int PAD = KH / 2, TAPS = KH * KW;
+    static constexpr int TR = 256 / TW;                 // output rows per tile (256 output pixels per workgroup)
+    static constexpr int MB = MT >= 64 ? 2 : 1;          // 32-row MFMA blocks per wave along M
+    static constexpr int WM = MT / (32 * MB);            // waves along M
+    static constexpr int WN = 8 / WM;                    // waves along N
+    static constexpr int NB = 8 / WN;                    // 32-pixel MFMA blocks per wave along N
+    static constexpr int HALO = PAD > 0 ? 8 : 0;         // left / right margin of the staged rows, in pixels (keeps 8-pixel alignment)
+    static constexpr int RI = (TR - 1) * S + KH;         // staged input rows
+    static constexpr int LW = TW * S + 2 * HALO;         // staged input pixels per row
+    static constexpr int P = KC / 8;                     // channel planes per chunk = 16-byte units per weight row
+    static constexpr int XBYTES = P * RI * LW * 16;
+    static constexpr int WBYTES = TAPS * MT * KC * 2;
+    static constexpr int STAGE = XBYTES + WBYTES;
+    static constexpr int TASKS = P * RI * (LW / 4);      // staging tasks of 8 channels x 4 pixels
+    static constexpr int NT = (TASKS + 511) / 512;
+    static constexpr int WDMA = WBYTES / 1024;           // 1 KiB LDS-DMA pieces per chunk
+    static_assert(WBYTES % 1024 == 0, "weight stage must be whole DMA pieces");
+    static_assert(2 * STAGE <= 160 * 1024, "stages exceed the LDS");
+};
+
+__host__ __device__ constexpr int swz_shift(int units) { return units == 2 ? 3 : units == 4 ? 2 : 1; }
+
+// unit index inside a weight row -> position in the LDS / packed image (see the header)
+__host__ __device__ __forceinline__ int swz(int unit, int row, int units) {
+    return unit ^ ((row >> swz_shift(units)) & (units - 1));
+}
+
+struct ConvParams {
+    const u16* x;        // [N, Cin, H, W] bf16
+    const u16* wp;       // packed weights
+    const float* bias;   // [Cout] or null
+    u16* y;              // [N, Cout, Ho, Wo] bf16
+    int N, Cin, Cout, H, W, Ho, Wo;
+    int tiles_x, tiles_y, co_tiles;
+    int aligned;         // rows / planes / tile origins 8-byte aligned and no partially valid 4-pixel group
+};
+
+// ---------------------------------------------------------------------------------------------------- weight packing
+// w: [Mrole... see sis_conv_bf16_pack.  One thread per packed element.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_pack_kernel(u16* __restrict__ out, const T* __restrict__ w, int Cout, int Cin,
+                                                        int KH, int MT, int KC, int adjoint, int64_t total) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int taps = KH * KH, units = KC / 8;
+    const int M = adjoint ? Cin : Cout, K = adjoint ? Cout : Cin;
+    const int nchunks = K / KC;
+    int64_t r = e;
+    const int j = r % 8; r /= 8;
+    const int upos = r % units; r /= units;
+    const int row = r % MT; r /= MT;
+    const int tap = r % taps; r /= taps;
+    const int chunk = r % nchunks; r /= nchunks;
+    const int mt = (int)r;
+    const int unit = swz(upos, row, units);  // the swizzle is an involution on the unit index
+    const int m = mt * MT + row, k = chunk * KC + unit * 8 + j;
+    float v = 0.f;
+    if (m < M) {
+        const int ky = tap / KH, kx = tap % KH;
+        if (!adjoint) v = (float)w[(((int64_t)m * Cin + k) * KH + ky) * KH + kx];
+        else v = (float)w[(((int64_t)k * Cin + m) * KH + (KH - 1 - ky)) * KH + (KH - 1 - kx)];
+    }
+    __hip_bfloat16 b = __float2bfloat16(v);
+    out[e] = *reinterpret_cast<u16*>(&b);
+}
+
+// ---------------------------------------------------------------------------------------------------- the convolution
+template <typename C, bool ALIGNED>
+__global__ __launch_bounds__(512, 2) void conv_bf16_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave % C::WM, wn = wave / C::WM;
+
+    // tile decode: blockIdx.x = (image, tile_y, tile_x), blockIdx.y = output-channel tile
+    int t = blockIdx.x;
+    const int tx_i = t % p.tiles_x; t /= p.tiles_x;
+    const int ty_i = t % p.tiles_y; t /= p.tiles_y;
+    const int n = t;
+    const int co_t = blockIdx.y;
+    const int ox0 = tx_i * C::TW, oy0 = ty_i * C::TR;
+    const int ix0 = ox0 * C::S - C::HALO, iy0 = oy0 * C::S - C::PAD;
+    const int nchunks = p.Cin / C::KC;
+
+    const u16* xin = p.x + (int64_t)n * p.Cin * p.H * p.W;
+    const u16* wsrc = p.wp + (int64_t)co_t * nchunks * (C::WBYTES / 2);
+
+    // ---- staging tasks of this thread (fixed over the chunk loop): 8 channels x 4 pixels each
+    int task_goff[C::NT];   // element offset of (channel 0 of the chunk's plane, row, first pixel) inside the image, or -1
+    int task_lds[C::NT];    // byte offset of the first unit inside a stage's X region
+    int task_mask[C::NT];   // validity of the 4 pixels (bit e), for the unaligned / ragged path
+#pragma unroll
+    for (int i = 0; i < C::NT; ++i) {
+        const int tk = tid + i * 512;
+        task_goff[i] = -1; task_lds[i] = 0; task_mask[i] = 0;
+        if (tk < C::TASKS) {
+            const int q = tk % (C::LW / 4);
+            const int ry = (tk / (C::LW / 4)) % C::RI;
+            const int pl = tk / ((C::LW / 4) * C::RI);
+            const int iy = iy0 + ry, ix = ix0 + 4 * q;
+            task_lds[i] = ((pl * C::RI + ry) * C::LW + 4 * q) * 16;
+            int mask = 0;
+            if (iy >= 0 && iy < p.H)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mask |= (ix + e >= 0 && ix + e < p.W) ? (1 << e) : 0;
+            task_mask[i] = mask;
+            task_goff[i] = mask ? ((pl * 8) * p.H + iy) * p.W + ix : -1;  // fits 31 bits: one image's planes of a chunk
+            if (!mask) task_goff[i] = -2;  // in range of the tile but outside the image: zeros
+        }
+    }
+
+    uint2 xr[C::NT][8];  // staged pixels: [task][channel] = 4 bf16
+
+    auto load_x = [&](int chunk) {
+        const u16* base = xin + (int64_t)chunk * C::KC * p.H * p.W;
+        const int plane = p.H * p.W;
+#pragma unroll
+        for (int i = 0; i < C::NT; ++i) {
+            if (task_goff[i] >= 0) {
+                const u16* g = base + task_goff[i];
+                if constexpr (ALIGNED) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) xr[i][c] = *reinterpret_cast<const uint2*>(g + (int64_t)c * plane);
+                } else {
+                    const int mask = task_mask[i];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const u16* gc = g + (int64_t)c * plane;
+                        const unsigned e0 = (mask & 1) ? gc[0] : 0, e1 = (mask & 2) ? gc[1] : 0;
+                        const unsigned e2 = (mask & 4) ? gc[2] : 0, e3 = (mask & 8) ? gc[3] : 0;
+                        xr[i][c] = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) xr[i][c] = make_uint2(0u, 0u);
+            }
+        }
+    };
+
+    auto store_x = [&](int stage) {
+        unsigned char* xs = lds + stage * C::STAGE + C::WBYTES;
+#pragma unroll
+        for (int i = 0; i < C::NT; ++i) {
+            if (task_goff[i] != -1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    uint4 u;
+                    const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;
+                    if (e < 2) {
+                        u.x = __builtin_amdgcn_perm(xr[i][1].x, xr[i][0].x, sel);
+                        u.y = __builtin_amdgcn_perm(xr[i][3].x, xr[i][2].x, sel);
+                        u.z = __builtin_amdgcn_perm(xr[i][5].x, xr[i][4].x, sel);
+                        u.w = __builtin_amdgcn_perm(xr[i][7].x, xr[i][6].x, sel);
+                    } else {
+                        u.x = __builtin_amdgcn_perm(xr[i][1].y, xr[i][0].y, sel);
+                        u.y = __builtin_amdgcn_perm(xr[i][3].y, xr[i][2].y, sel);
+                        u.z = __builtin_amdgcn_perm(xr[i][5].y, xr[i][4].y, sel);
+                        u.w = __builtin_amdgcn_perm(xr[i][7].y, xr[i][6].y, sel);
+                    }
+                    *reinterpret_cast<uint4*>(xs + task_lds[i] + e * 16) = u;
+                }
+            }
+        }
+    };
+
+    auto dma_w = [&](int chunk, int stage) {
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(wsrc) + (int64_t)chunk * C::WBYTES;
+        unsigned char* dst = lds + stage * C::STAGE;
+        for (int piece = wave; piece < C::WDMA; piece += 8)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment addresses
+    // A: row = wm * 32 * MB + mb * 32 + r (inside the MT tile), unit = ks * 2 + h (swizzled), tap stride = MT * KC * 2 bytes
+    int a_off[C::MB][C::KC / 16];
+#pragma unroll
+    for (int mb = 0; mb < C::MB; ++mb) {
+        const int row = (wm * C::MB + mb) * 32 + r;
+#pragma unroll
+        for (int ks = 0; ks < C::KC / 16; ++ks) a_off[mb][ks] = row * (C::KC * 2) + swz(ks * 2 + h, row, C::P) * 16;
+    }
+    // B: pixel block nb -> (tile row, first pixel); unit = plane (ks * 2 + h), row ty * S + ky, pixel (tx + r) * S + kx + HALO - PAD
+    int b_off[C::NB];
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb) {
+        const int blk = wn * C::NB + nb;
+        const int ty = blk / (C::TW / 32), tx = (blk % (C::TW / 32)) * 32;
+        b_off[nb] = C::WBYTES + (((h * C::RI) + ty * C::S) * C::LW + (tx + r) * C::S + C::HALO - C::PAD) * 16;
+    }
+
+    f32x16 acc[C::MB][C::NB];
+#pragma unroll
+    for (int mb = 0; mb < C::MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+    // ---- prologue: chunk 0 into stage 0
+    dma_w(0, 0);
+    load_x(0);
+    store_x(0);
+    __syncthreads();  // (its fence waits for the LDS-DMA as well)
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int cur = chunk & 1;
+        const bool more = chunk + 1 < nchunks;
+        if (more) {
+            dma_w(chunk + 1, cur ^ 1);
+            load_x(chunk + 1);
+        }
+        const unsigned char* st = lds + cur * C::STAGE;
+#pragma unroll
+        for (int tap = 0; tap < C::TAPS; ++tap) {
+            const int ky = tap / C::KW, kx = tap % C::KW;
+#pragma unroll
+            for (int ks = 0; ks < C::KC / 16; ++ks) {
+                bf16x8 a[C::MB], b[C::NB];
+#pragma unroll
+                for (int mb = 0; mb < C::MB; ++mb)
+                    a[mb] = *reinterpret_cast<const bf16x8*>(st + tap * (C::MT * C::KC * 2) + a_off[mb][ks]);
+#pragma unroll
+                for (int nb = 0; nb < C::NB; ++nb)
+                    b[nb] = *reinterpret_cast<const bf16x8*>(st + b_off[nb] + (ks * 2 * C::RI * C::LW + ky * C::LW + kx) * 16);
+#pragma unroll
+                for (int mb = 0; mb < C::MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < C::NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the write-late half of the staging behind the MFMAs
+        if (more) store_x(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, bf16, NCHW stores (lanes 0-31 of a register write 32 consecutive pixels of one channel row)
+#pragma unroll
+    for (int mb = 0; mb < C::MB; ++mb) {
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb) {
+            const int blk = wn * C::NB + nb;
+            const int oy = oy0 + blk / (C::TW / 32), ox = ox0 + (blk % (C::TW / 32)) * 32 + r;
+            if (oy >= p.Ho || ox >= p.Wo) continue;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = co_t * C::MT + (wm * C::MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (co < p.Cout) {
+                    float v = acc[mb][nb][i];
+                    if (p.bias) v += p.bias[co];
+                    __hip_bfloat16 bv = __float2bfloat16(v);
+                    p.y[(((int64_t)n * p.Cout + co) * p.Ho + oy) * p.Wo + ox] = *reinterpret_cast<u16*>(&bv);
+                }
+            }
+        }
+    }
+}
+
+template <typename C>
+int launch_conv(const ConvParams& p, hipStream_t st, const char* name) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<C, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::STAGE);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<C, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::STAGE);
+        if (e != hipSuccess) return sis_fail("%s: cannot raise the LDS limit: %s", name, hipGetErrorString(e));
+        attr_set = true;
+    }
+    dim3 grid(p.N * p.tiles_y * p.tiles_x, p.co_tiles);
+    if (p.aligned) hipLaunchKernelGGL((conv_bf16_kernel<C, true>), grid, dim3(512), 2 * C::STAGE, st, p);
+    else hipLaunchKernelGGL((conv_bf16_kernel<C, false>), grid, dim3(512), 2 * C::STAGE, st, p);
+    SIS_CHECK_LAUNCH(name);
+    sis_kernel_name = name;
+    return 0;
+}
+
+struct Plan { int mt, kc, tw; };
+
+// Tile plan of a layer: M tile by output channels, channel chunk by kernel size, tile width by image width.
+bool conv_plan(int cin, int cout, int h, int w, int ksize, int stride, Plan* plan) {
+    if (!((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2))) return false;
+    const int kc = (ksize == 1 && stride == 1) ? 64 : 16;
+    if (cin % kc) return false;
+    int mt = cout > 64 ? 128 : cout > 32 ? 64 : 32;
+    int tw = 64;
+    if (ksize == 1 && stride == 1) tw = 256;       // 1x1: the image is one row of H*W pixels
+    else if (stride == 1 && w <= 32) tw = 32;
+    if (stride == 2) { mt = cout > 64 ? 128 : 64; tw = 64; }
+    plan->mt = mt; plan->kc = kc; plan->tw = tw;
+    (void)h;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int sis_conv_bf16_supported(int cin, int cout, int h, int w, int ksize, int stride) {
+    Plan pl;
+    return conv_plan(cin, cout, h, w, ksize, stride, &pl) ? 1 : 0;
+}
+
+extern "C" int64_t sis_conv_bf16_packed_elems(int cin, int cout, int h, int w, int ksize, int stride, int adjoint) {
+    const int M = adjoint ? cin : cout, K = adjoint ? cout : cin;
+    Plan pl;
+    if (!conv_plan(K, M, h, w, ksize, stride, &pl)) return -1;
+    const int64_t mtiles = (M + pl.mt - 1) / pl.mt;
+    return mtiles * pl.mt * (int64_t)K * ksize * ksize;
+}
+
+extern "C" int sis_conv_bf16_pack(void* packed, const void* weight, int weight_dtype, int cin, int cout, int h, int w,
+                                  int ksize, int stride, int adjoint, void* stream) {
+    SIS_REQUIRE(packed && weight, "sis_conv_bf16_pack: null pointer");
+    const int M = adjoint ? cin : cout, K = adjoint ? cout : cin;
+    Plan pl;
+    SIS_REQUIRE(conv_plan(K, M, h, w, ksize, stride, &pl), "sis_conv_bf16_pack: unsupported layer %d->%d k%d s%d", cin, cout, ksize, stride);
+    SIS_REQUIRE(!(adjoint && stride != 1), "sis_conv_bf16_pack: the adjoint packing is for stride-1 layers");
+    const int64_t total = sis_conv_bf16_packed_elems(cin, cout, h, w, ksize, stride, adjoint);
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = sis_cdiv(total, 256);
+    if (weight_dtype == SIS_F32)
+        hipLaunchKernelGGL(conv_pack_kernel<float>, dim3(blocks), dim3(256), 0, st, (u16*)packed, (const float*)weight, cout, cin,
+                           ksize, pl.mt, pl.kc, adjoint, total);
+    else if (weight_dtype == SIS_BF16)
+        hipLaunchKernelGGL(conv_pack_kernel<__hip_bfloat16>, dim3(blocks), dim3(256), 0, st, (u16*)packed,
+                           (const __hip_bfloat16*)weight, cout, cin, ksize, pl.mt, pl.kc, adjoint, total);
+    else
+        return sis_fail("sis_conv_bf16_pack: weights must be float32 or bfloat16");
+    SIS_CHECK_LAUNCH("conv_pack_kernel");
+    return 0;
+}
+
+extern "C" int sis_conv_bf16(void* y, const void* x, const void* packed, const float* bias, int batch, int cin, int cout,
+                             int h, int w, int ksize, int stride, void* stream) {
+    if (batch <= 0) return 0;
+    SIS_REQUIRE(y && x && packed, "sis_conv_bf16: null pointer");
+    Plan pl;
+    SIS_REQUIRE(conv_plan(cin, cout, h, w, ksize, stride, &pl), "sis_conv_bf16: unsupported layer %d->%d k%d s%d", cin, cout, ksize, stride);
+    const int pad = ksize / 2;
+    ConvParams p;
+    p.x = (const u16*)x; p.wp = (const u16*)packed; p.bias = bias; p.y = (u16*)y;
+    p.N = batch; p.Cin = cin; p.Cout = cout;
+    p.Ho = (h + 2 * pad - ksize) / stride + 1; p.Wo = (w + 2 * pad - ksize) / stride + 1;
+    p.H = h; p.W = w;
+    if (ksize == 1 && stride == 1) {  // pointwise: one row of H*W pixels
+        p.H = 1; p.W = h * w; p.Ho = 1; p.Wo = h * w;
+    }
+    SIS_REQUIRE((int64_t)cin * h * w < (1LL << 31) && (int64_t)cout * p.Ho * p.Wo < (1LL << 31), "sis_conv_bf16: image planes exceed 2^31 elements");
+    const int tr = 256 / pl.tw;
+    p.tiles_x = sis_cdiv(p.Wo, pl.tw); p.tiles_y = sis_cdiv(p.Ho, tr);
+    p.co_tiles = sis_cdiv(cout, pl.mt);
+    p.aligned = (p.W % 4 == 0) && (((int64_t)p.H * p.W) % 4 == 0) && ((((uintptr_t)x) & 7) == 0);
+    hipStream_t st = (hipStream_t)stream;
+#define CONV_CASE(MT, KC, KH, S, TW)                                                                         \
+    if (pl.mt == MT && pl.kc == KC && ksize == KH && stride == S && pl.tw == TW)                             \
+        return launch_conv<ConvCfg<MT, KC, KH, S, TW>>(p, st, "conv_bf16_kernel<" #MT "," #KC "," #KH "," #S "," #TW ">");
+    CONV_CASE(128, 16, 3, 1, 64) CONV_CASE(128, 16, 3, 1, 32) CONV_CASE(64, 16, 3, 1, 64) CONV_CASE(64, 16, 3, 1, 32)
+    CONV_CASE(32, 16, 3, 1, 64) CONV_CASE(32, 16, 3, 1, 32)
+    CONV_CASE(128, 64, 1, 1, 256) CONV_CASE(64, 64, 1, 1, 256) CONV_CASE(32, 64, 1, 1, 256)
+    CONV_CASE(128, 16, 3, 2, 64) CONV_CASE(64, 16, 3, 2, 64) CONV_CASE(128, 16, 1, 2, 64) CONV_CASE(64, 16, 1, 2, 64)
+#undef CONV_CASE
+    return sis_fail("sis_conv_bf16: no kernel instance for tile plan mt=%d kc=%d k=%d s=%d tw=%d", pl.mt, pl.kc, ksize, stride, pl.tw);
+}

@@ -77,6 +77,10 @@ _SIGNATURES = {
     "sis_make_image_u8": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "sis_crop_patches_u8": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "sis_assemble_max": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "sis_conv_bf16_supported": ([_i] * 6, _i),
+    "sis_conv_bf16_packed_elems": ([_i] * 7, _i64),
+    "sis_conv_bf16_pack": ([_vp, _vp, _i] + [_i] * 7 + [_vp], _i),
+    "sis_conv_bf16": ([_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp], _i),
 }
 
 
@@ -570,6 +574,56 @@ def make_image_u8(x):
     with torch.cuda.device(x.device):
         _check(lib().sis_make_image_u8(_ptr(out), _ptr(x), b, ch, h * w, _stream()), "sis_make_image_u8")
     return out
+
+
+# ------------------------------------------------------------------------------ bf16 convolutions (matrix cores, NCHW)
+
+
+_conv_bf16_ok = {}
+
+
+def conv_bf16_supported(cin, cout, h, w, ksize, stride):
+    key = (cin, cout, h, w, ksize, stride)
+    hit = _conv_bf16_ok.get(key)
+    if hit is None:
+        hit = _conv_bf16_ok[key] = bool(lib().sis_conv_bf16_supported(*key))
+    return hit
+
+
+def conv_bf16_pack(weight, h, w, stride=1, adjoint=False):
+    """weight [Cout, Cin, k, k] (float32 or bfloat16) -> the kernel's packed LDS image (bf16) for inputs of h x w;
+    ``adjoint``: the packing of the data-gradient convolution of a stride-1 layer."""
+    require_device(weight, "weight")
+    wt = weight.contiguous()
+    if wt.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"conv_bf16_pack: weights must be float32 or bfloat16, got {wt.dtype}")
+    cout, cin, k, k2 = wt.shape
+    n = lib().sis_conv_bf16_packed_elems(cin, cout, h, w, k, stride, int(bool(adjoint)))
+    if k != k2 or n < 0:
+        raise RuntimeError(f"conv_bf16_pack: unsupported layer {cin}->{cout} k{k}x{k2} s{stride}")
+    packed = torch.empty(n, dtype=torch.bfloat16, device=wt.device)
+    with torch.cuda.device(wt.device):
+        _check(lib().sis_conv_bf16_pack(_ptr(packed), _ptr(wt), _DTYPE_CODE[wt.dtype], cin, cout, h, w, k, stride,
+                                        int(bool(adjoint)), _stream()), "sis_conv_bf16_pack")
+    return packed
+
+
+def conv_bf16(x, packed, cout, ksize, stride=1, bias=None):
+    """x [B,Cin,H,W] bf16 (contiguous), packed weights of ``conv_bf16_pack`` -> [B,cout,Ho,Wo] bf16; padding ksize // 2."""
+    require_device(x, "input")
+    if x.dtype != torch.bfloat16 or not x.is_contiguous():
+        raise RuntimeError("conv_bf16: input must be a contiguous bfloat16 tensor")
+    b, cin, h, w = x.shape
+    pad = ksize // 2
+    ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+    y = torch.empty((b, cout, ho, wo), dtype=torch.bfloat16, device=x.device)
+    if bias is not None:
+        bias = _f32(bias, "bias")
+    with torch.cuda.device(x.device):
+        _check(_launch(None, 2.0 * b * cout * cin * ksize * ksize * ho * wo, 2.0 * (x.numel() + y.numel() + packed.numel()),
+                       lambda: lib().sis_conv_bf16(_ptr(y), _ptr(x), _ptr(packed), _ptr(bias), b, cin, cout, h, w, ksize,
+                                                   stride, _stream())), "sis_conv_bf16")
+    return y
 
 
 # ------------------------------------------------------------------------------ layer norm

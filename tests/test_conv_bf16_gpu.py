@@ -1,0 +1,63 @@
+"""GPU parity: the bf16 MFMA convolutions (csrc/conv_bf16.hip) through the C ABI against fp32 ``F.conv2d`` on the same
+bf16-rounded operands.  Stated tolerance: the result is rounded to bf16 once (2^-9 relative) after an fp32 accumulation
+whose association differs from the library's -> |err| <= 1e-2 * max|ref| element-wise."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # batch, cin, cout, h, w, k, stride, bias
+    (2, 64, 64, 32, 32, 3, 1, False),      # MT 64, tile 32 wide
+    (2, 128, 256, 64, 64, 3, 1, False),    # MT 128, tile 64 wide
+    (1, 256, 128, 24, 40, 3, 1, False),    # ragged tiles in both directions
+    (2, 64, 16, 64, 64, 3, 1, False),      # MT 32
+    (1, 16, 3, 64, 64, 3, 1, True),        # segmentation head: 3 output channels + bias
+    (2, 192, 64, 48, 48, 3, 1, False),     # concatenated skip (192 channels)
+    (1, 768, 512, 32, 32, 3, 1, False),    # decoder conv_more
+    (2, 256, 1024, 16, 16, 1, 1, False),   # pointwise, flat pixel row
+    (1, 1024, 768, 32, 32, 1, 1, True),    # patch embedding (bias)
+    (2, 64, 256, 20, 28, 1, 1, False),     # pointwise, ragged tail tile
+    (1, 64, 64, 127, 127, 1, 1, False),    # odd planes: unaligned staging path
+    (1, 64, 64, 127, 127, 3, 1, False),
+    (2, 128, 128, 63, 63, 3, 2, False),    # stride 2 (block2 / block3 entry)
+    (1, 256, 512, 63, 63, 1, 2, False),
+    (1, 128, 128, 127, 127, 3, 2, False),
+]
+
+
+def _ref(x, w, b, k, s):
+    return F.conv2d(x.float(), w.float(), b, stride=s, padding=k // 2)
+
+
+@pytest.mark.parametrize("batch,cin,cout,h,w,k,stride,bias", CASES)
+def test_conv_bf16_forward(device, batch, cin, cout, h, w, k, stride, bias):
+    import sis_hip
+    assert sis_hip.conv_bf16_supported(cin, cout, h, w, k, stride)
+    gen = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(batch, cin, h, w, generator=gen).to(device).bfloat16()
+    wt = (torch.randn(cout, cin, k, k, generator=gen) / (cin * k * k) ** 0.5).to(device)
+    b = torch.randn(cout, generator=gen).to(device) if bias else None
+    for weight in (wt, wt.bfloat16()):  # fp32 master weights and the bf16 output of the weight standardisation
+        y = sis_hip.conv_bf16(x, sis_hip.conv_bf16_pack(weight, h, w, stride), cout, k, stride, b)
+        ref = _ref(x, wt.bfloat16(), b, k, stride)
+        assert y.dtype == torch.bfloat16 and y.shape == ref.shape
+        err = (y.float() - ref).abs().max().item()
+        assert err <= 1e-2 * ref.abs().max().item(), (err, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("batch,cin,cout,h,w,k", [(2, 64, 128, 32, 32, 3), (1, 192, 64, 48, 48, 3), (2, 256, 64, 16, 16, 1),
+                                                  (1, 64, 256, 127, 127, 1), (1, 128, 128, 24, 40, 3)])
+def test_conv_bf16_data_gradient(device, batch, cin, cout, h, w, k):
+    """dL/dx = the same kernel on adjoint-packed weights, against autograd of the fp32 convolution."""
+    import sis_hip
+    gen = torch.Generator().manual_seed(cin * 3 + cout)
+    wt = (torch.randn(cout, cin, k, k, generator=gen) / (cout * k * k) ** 0.5).to(device).bfloat16()
+    gy = torch.randn(batch, cout, h, w, generator=gen).to(device).bfloat16()
+    x = torch.zeros(batch, cin, h, w, device=device, requires_grad=True)
+    F.conv2d(x, wt.float(), padding=k // 2).backward(gy.float())
+    assert sis_hip.conv_bf16_supported(cout, cin, h, w, k, 1)
+    gx = sis_hip.conv_bf16(gy, sis_hip.conv_bf16_pack(wt, h, w, 1, adjoint=True), cin, k, 1)
+    err = (gx.float() - x.grad).abs().max().item()
+    assert err <= 1e-2 * x.grad.abs().max().item(), (err, x.grad.abs().max().item())

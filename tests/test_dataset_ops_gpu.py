@@ -56,8 +56,9 @@ def test_kmeans_assign_matches_reference_fixture(device, golden_dir):
 
 def test_kmeans_ties_go_to_lowest_index(device):
     import sis_hip
-    x = torch.zeros(1, 4, 2, 2, device=device)
-    centres = torch.tensor([[1., 0, 0, 0], [0, 1., 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]], device=device)
+    x = torch.zeros(1, 8, 2, 2, device=device)
+    centres = torch.zeros(4, 8, device=device)
+    centres[0, 0] = centres[1, 1] = 1.0  # centres 2 and 3 tie at distance 0
     assert torch.equal(sis_hip.kmeans_assign(x, centres).cpu(), torch.full((1, 2, 2), 2))
 
 
