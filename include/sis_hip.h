@@ -347,6 +347,14 @@ int sis_conv_bf16_pack(void* packed, const void* weight, int weight_dtype, int c
 int sis_conv_bf16(void* y, const void* x, const void* packed, const float* bias, int batch, int cin, int cout, int h, int w,
                   int ksize, int stride, void* stream);
 
+/* Weight gradient of a stride-1, padding-1 3x3 bf16 convolution (csrc/conv_bf16_wgrad.hip):
+ * dw [cout][cin][3][3] (SIS_F32 or SIS_BF16) = sum_{n,y,x} grad_y[n][co][y][x] * x[n][ci][y+ky-1][x+kx-1], x / grad_y bf16
+ * NCHW, fp32 accumulation; split-K partial tiles go through `workspace` and are added in a fixed order (deterministic).
+ * sis_conv_bf16_wgrad_supported: 1 when a tile plan exists (cin, cout >= 32) and its slabs fit `workspace_bytes`. */
+int sis_conv_bf16_wgrad_supported(int batch, int cin, int cout, int h, int w, int64_t workspace_bytes);
+int sis_conv_bf16_wgrad(void* dw, int dw_dtype, const void* x, const void* grad_y, int batch, int cin, int cout, int h, int w,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,304 @@
+// Weight gradient of the stride-1 3x3 bf16 convolutions on the CDNA4 matrix cores, direct on NCHW tensors.
+//
+//   dW[co][ci][ky][kx] = sum_{n,y,x} dY[n][co][y][x] * X[n][ci][y + ky - 1][x + kx - 1]
+//
+// (reference call sites: the backward of every StdConv2d 3x3, vit_seg_modeling_resnet_skip.py:20-37, and of the decoder's
+// Conv2dReLU, vit_seg_modeling.py:265-287 -- autograd's convolution_backward, which the library runs as NHWC
+// implicit-GEMM kernels between layout transposes).
+//
+// GEMM view: M = co (A = dY), N = ci (B = X), K = pixels, one 32 x 32 fp32 accumulator tile PER TAP (9 of them, 144
+// registers per wave) on v_mfma_f32_32x32x16_bf16.  K = pixels is the contiguous axis of both operands in NCHW, so both
+// LDS images are plain copies of tensor rows -- no transposition anywhere:
+//   * A fragment = 8 consecutive pixels of a dY row: one ds_read_b128 (row pitch padded to 9 units: conflict free);
+//   * B fragment for tap (ky, kx) = 8 consecutive pixels of X row y + ky - 1 starting at x + kx - 1.  kx = 1 is the
+//     aligned 16-byte group itself; kx = 0 / 2 straddle two groups and are assembled in registers with v_alignbit_b32
+//     from the centre group and its left / right neighbour (5 funnel shifts per 16-pixel step serve both).  A lane reads
+//     the 9 groups its four K-steps of a row touch once (9 ds_read_b128 per input row and 12 MFMAs).
+// A workgroup walks down the rows of one 64-pixel (or 32-pixel) column strip of one image: per step it stages ONE new dY
+// row and ONE new X row (ring of 4 X rows in LDS: rows y-1, y, y+1 in use, y+2 arriving), 36 (18) MFMAs per wave between
+// barriers, loads issued before the MFMAs and written to LDS after them.
+// Split-K over (image, strip, row block): every unit writes its partial [tap][co][ci] tile to a slab; a second kernel
+// adds the slabs in unit order (deterministic, no atomics) and writes dW[co][ci][3][3].
+#include "sis_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned short u16;
+
+template <int WM_, int KS_>
+struct WgCfg {
+    static constexpr int WM = WM_, WN = 8 / WM_, KS = KS_;   // waves along co / ci, 16-pixel K-steps per row step
+    static constexpr int MT = 32 * WM, NT = 32 * WN;         // co x ci tile of the workgroup
+    static constexpr int SW = 16 * KS;                       // strip width in pixels
+    static constexpr int DY_UNITS = SW / 8 + 1;              // 16-byte units per dY row (one pad unit)
+    static constexpr int DY_ROW = DY_UNITS * 16;             // bytes
+    static constexpr int DY_BUF = MT * DY_ROW;
+    static constexpr int XR_UNITS = SW / 8 + 2 + 1;          // strip + one halo group each side + pad
+    static constexpr int X_CI = (4 * XR_UNITS + 1) * 16;     // bytes per input channel: ring of 4 rows (+1 unit: odd pitch)
+    static constexpr int X_BYTES = NT * X_CI;
+    static constexpr int LDS = 2 * DY_BUF + X_BYTES;
+    static constexpr int DY_CHUNKS = MT * (SW / 8);          // 16-byte loads per dY row
+    static constexpr int X_CHUNKS = NT * (SW / 8 + 2);
+    static constexpr int NDY = (DY_CHUNKS + 511) / 512, NX = (X_CHUNKS + 511) / 512;
+    static_assert(LDS <= 160 * 1024, "LDS");
+};
+
+struct WgParams {
+    const u16* x;    // [N, Cin, H, W]
+    const u16* gy;   // [N, Cout, H, W]
+    float* slab;     // [units][9][co_pad][ci_pad]
+    int N, Cin, Cout, H, W;
+    int strips, row_blocks, rows_per_block;
+    int co_tiles, ci_tiles;
+    int aligned;
+};
+
+__device__ __forceinline__ uint4 load_chunk(const u16* row, int x0, int W, bool row_ok, bool aligned) {
+    // 8 pixels [x0, x0 + 8) of a tensor row (zeros outside [0, W) or when the row itself is outside the image)
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (!row_ok) return v;
+    if (aligned) {
+        if (x0 >= 0 && x0 + 8 <= W) v = *reinterpret_cast<const uint4*>(row + x0);
+        return v;  // W % 8 == 0: a group is inside or outside as a whole
+    }
+    unsigned e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = (x0 + j >= 0 && x0 + j < W) ? row[x0 + j] : 0u;
+    return make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+}
+
+template <typename C, bool ALIGNED>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(WgParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* const dy_lds = lds;
+    unsigned char* const x_lds = lds + 2 * C::DY_BUF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave % C::WM, wn = wave / C::WM;
+
+    int u = blockIdx.x;
+    const int rb = u % p.row_blocks; u /= p.row_blocks;
+    const int strip = u % p.strips; u /= p.strips;
+    const int n = u;
+    const int co_t = blockIdx.y % p.co_tiles, ci_t = blockIdx.y / p.co_tiles;
+    const int x0 = strip * C::SW;
+    const int y_begin = rb * p.rows_per_block, y_end = min(p.H, y_begin + p.rows_per_block);
+    const int64_t plane = (int64_t)p.H * p.W;
+    const u16* gy_base = p.gy + ((int64_t)n * p.Cout + co_t * C::MT) * plane;
+    const u16* x_base = p.x + ((int64_t)n * p.Cin + ci_t * C::NT) * plane;
+
+    uint4 dyr[C::NDY], xr[C::NX];
+
+    auto load_dy = [&](int y) {  // dY row y of the tile's channels, strip columns
+#pragma unroll
+        for (int i = 0; i < C::NDY; ++i) {
+            const int c = tid + i * 512;
+            if (c < C::DY_CHUNKS) {
+                const int ch = c / (C::SW / 8), g = c % (C::SW / 8);
+                const bool ok = co_t * C::MT + ch < p.Cout;
+                dyr[i] = load_chunk(gy_base + (int64_t)ch * plane + (int64_t)y * p.W, x0 + 8 * g, p.W, ok, ALIGNED);
+            }
+        }
+    };
+    auto store_dy = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < C::NDY; ++i) {
+            const int c = tid + i * 512;
+            if (c < C::DY_CHUNKS) {
+                const int ch = c / (C::SW / 8), g = c % (C::SW / 8);
+                *reinterpret_cast<uint4*>(dy_lds + buf * C::DY_BUF + ch * C::DY_ROW + g * 16) = dyr[i];
+            }
+        }
+    };
+    auto load_x = [&](int y) {  // X row y (may be -1 or H: zeros), strip columns plus one group each side
+#pragma unroll
+        for (int i = 0; i < C::NX; ++i) {
+            const int c = tid + i * 512;
+            if (c < C::X_CHUNKS) {
+                const int ch = c / (C::SW / 8 + 2), g = c % (C::SW / 8 + 2);
+                const bool ok = y >= 0 && y < p.H && ci_t * C::NT + ch < p.Cin;
+                xr[i] = load_chunk(x_base + (int64_t)ch * plane + (int64_t)y * p.W, x0 + 8 * (g - 1), p.W, ok, ALIGNED);
+            }
+        }
+    };
+    auto store_x = [&](int y) {
+        const int slot = (y + 1) & 3;
+#pragma unroll
+        for (int i = 0; i < C::NX; ++i) {
+            const int c = tid + i * 512;
+            if (c < C::X_CHUNKS) {
+                const int ch = c / (C::SW / 8 + 2), g = c % (C::SW / 8 + 2);
+                *reinterpret_cast<uint4*>(x_lds + ch * C::X_CI + (slot * C::XR_UNITS + g) * 16) = xr[i];
+            }
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    // ---- prologue: X rows y_begin - 1, y_begin, y_begin + 1 and dY row y_begin
+    load_x(y_begin - 1); store_x(y_begin - 1);
+    load_x(y_begin); store_x(y_begin);
+    load_x(y_begin + 1); store_x(y_begin + 1);
+    load_dy(y_begin); store_dy(y_begin & 1);
+    __syncthreads();
+
+    const unsigned char* a_base = dy_lds + (wm * 32 + r) * C::DY_ROW + h * 16;
+    const unsigned char* b_base = x_lds + (wn * 32 + r) * C::X_CI + h * 16;
+
+    for (int y = y_begin; y < y_end; ++y) {
+        const bool more = y + 1 < y_end;
+        if (more) {
+            load_dy(y + 1);
+            load_x(y + 2);
+        }
+        bf16x8 a[C::KS];
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks)
+            a[ks] = *reinterpret_cast<const bf16x8*>(a_base + (y & 1) * C::DY_BUF + ks * 32);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int slot = (y + ky) & 3;  // image row y + ky - 1
+            uint4 g[2 * C::KS + 1];          // groups h - 1 .. h + 2 KS - 1 of the strip (LDS group index + 1)
+#pragma unroll
+            for (int i = 0; i < 2 * C::KS + 1; ++i)
+                g[i] = *reinterpret_cast<const uint4*>(b_base + (slot * C::XR_UNITS + i) * 16);
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+                const uint4 lft = g[2 * ks], c = g[2 * ks + 1], rgt = g[2 * ks + 2];
+                const unsigned t0 = __builtin_amdgcn_alignbit(c.x, lft.w, 16), t1 = __builtin_amdgcn_alignbit(c.y, c.x, 16);
+                const unsigned t2 = __builtin_amdgcn_alignbit(c.z, c.y, 16), t3 = __builtin_amdgcn_alignbit(c.w, c.z, 16);
+                const unsigned t4 = __builtin_amdgcn_alignbit(rgt.x, c.w, 16);
+                const uint4 b0 = make_uint4(t0, t1, t2, t3), b2 = make_uint4(t1, t2, t3, t4);
+                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], __builtin_bit_cast(bf16x8, b0), acc[ky * 3 + 0], 0, 0, 0);
+                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], __builtin_bit_cast(bf16x8, c), acc[ky * 3 + 1], 0, 0, 0);
+                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], __builtin_bit_cast(bf16x8, b2), acc[ky * 3 + 2], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            store_dy((y + 1) & 1);
+            store_x(y + 2);
+        }
+        __syncthreads();
+    }
+
+    // ---- partial tile -> slab[unit][tap][co][ci] (ci on the lanes: 128-byte runs)
+    const int co_pad = p.co_tiles * C::MT, ci_pad = p.ci_tiles * C::NT;
+    float* out = p.slab + (int64_t)blockIdx.x * 9 * co_pad * ci_pad;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int co = co_t * C::MT + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int ci = ci_t * C::NT + wn * 32 + r;
+            out[((int64_t)t * co_pad + co) * ci_pad + ci] = acc[t][i];
+        }
+}
+
+// dW[co][ci][tap] = sum over units (in order) of slab[unit][tap][co][ci]; one thread per (co, ci)
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(T* __restrict__ dw, const float* __restrict__ slab, int units,
+                                                                int Cout, int Cin, int co_pad, int ci_pad) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Cout * Cin) return;
+    const int co = idx / Cin, ci = idx % Cin;
+    float s[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[t] = 0.f;
+    const int64_t stride = (int64_t)9 * co_pad * ci_pad;
+    for (int u = 0; u < units; ++u)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) s[t] += slab[u * stride + ((int64_t)t * co_pad + co) * ci_pad + ci];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) sis_st(dw, (int64_t)idx * 9 + t, s[t]);
+}
+
+struct WgPlan { int wm, ks, strips, row_blocks, rows_per_block, co_tiles, ci_tiles, units; int64_t slab_bytes; };
+
+bool wgrad_plan(int batch, int cin, int cout, int h, int w, int64_t workspace_bytes, WgPlan* pl) {
+    if (cin < 32 || cout < 32) return false;          // the 16 / 3-channel tail of the decoder: library
+    pl->ks = w <= 32 ? 2 : 4;
+    const int sw = 16 * pl->ks;
+    pl->wm = cout >= 128 ? 4 : 2;
+    const int mt = 32 * pl->wm, nt = 32 * (8 / pl->wm);
+    pl->co_tiles = sis_cdiv(cout, mt); pl->ci_tiles = sis_cdiv(cin, nt);
+    pl->strips = sis_cdiv(w, sw);
+    const int64_t tile_bytes = (int64_t)9 * pl->co_tiles * mt * pl->ci_tiles * nt * 4;
+    const int tiles = pl->co_tiles * pl->ci_tiles;
+    // row blocks: enough workgroups to fill the chip (~2 per CU), at least 8 rows each, slabs within the workspace
+    int rbk = 1;
+    while (rbk < h / 8 && (int64_t)batch * pl->strips * rbk * tiles < 512 &&
+           (int64_t)batch * pl->strips * (rbk * 2) * tile_bytes <= workspace_bytes) rbk *= 2;
+    pl->rows_per_block = sis_cdiv(h, rbk);
+    pl->row_blocks = sis_cdiv(h, pl->rows_per_block);
+    pl->units = batch * pl->strips * pl->row_blocks;
+    pl->slab_bytes = (int64_t)pl->units * tile_bytes;
+    return pl->slab_bytes <= workspace_bytes;
+}
+
+template <typename C>
+int launch_wgrad(const WgParams& p, int units, hipStream_t st, const char* name) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_bf16_kernel<C, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_bf16_kernel<C, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        if (e != hipSuccess) return sis_fail("%s: cannot raise the LDS limit: %s", name, hipGetErrorString(e));
+        attr_set = true;
+    }
+    dim3 grid(units, p.co_tiles * p.ci_tiles);
+    if (p.aligned) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<C, true>), grid, dim3(512), C::LDS, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<C, false>), grid, dim3(512), C::LDS, st, p);
+    SIS_CHECK_LAUNCH(name);
+    sis_kernel_name = name;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int sis_conv_bf16_wgrad_supported(int batch, int cin, int cout, int h, int w, int64_t workspace_bytes) {
+    WgPlan pl;
+    return wgrad_plan(batch, cin, cout, h, w, workspace_bytes, &pl) ? 1 : 0;
+}
+
+extern "C" int sis_conv_bf16_wgrad(void* dw, int dw_dtype, const void* x, const void* grad_y, int batch, int cin, int cout,
+                                   int h, int w, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (batch <= 0) return 0;
+    SIS_REQUIRE(dw && x && grad_y && workspace, "sis_conv_bf16_wgrad: null pointer");
+    SIS_REQUIRE(dw_dtype == SIS_F32 || dw_dtype == SIS_BF16, "sis_conv_bf16_wgrad: dW must be float32 or bfloat16");
+    WgPlan pl;
+    SIS_REQUIRE(wgrad_plan(batch, cin, cout, h, w, workspace_bytes, &pl),
+                "sis_conv_bf16_wgrad: no tile plan for %d->%d @%dx%d within %lld workspace bytes", cin, cout, h, w,
+                (long long)workspace_bytes);
+    WgParams p;
+    p.x = (const u16*)x; p.gy = (const u16*)grad_y; p.slab = (float*)workspace;
+    p.N = batch; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w;
+    p.strips = pl.strips; p.row_blocks = pl.row_blocks; p.rows_per_block = pl.rows_per_block;
+    p.co_tiles = pl.co_tiles; p.ci_tiles = pl.ci_tiles;
+    p.aligned = (w % 8 == 0) && ((((uintptr_t)x) | ((uintptr_t)grad_y)) & 15) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (pl.wm == 4 && pl.ks == 4) rc = launch_wgrad<WgCfg<4, 4>>(p, pl.units, st, "conv_wgrad_bf16_kernel<4,4>");
+    else if (pl.wm == 4 && pl.ks == 2) rc = launch_wgrad<WgCfg<4, 2>>(p, pl.units, st, "conv_wgrad_bf16_kernel<4,2>");
+    else if (pl.wm == 2 && pl.ks == 4) rc = launch_wgrad<WgCfg<2, 4>>(p, pl.units, st, "conv_wgrad_bf16_kernel<2,4>");
+    else rc = launch_wgrad<WgCfg<2, 2>>(p, pl.units, st, "conv_wgrad_bf16_kernel<2,2>");
+    if (rc) return rc;
+    const int mt = 32 * pl.wm, nt = 32 * (8 / pl.wm);
+    const int blocks = sis_cdiv((int64_t)cout * cin, 256);
+    if (dw_dtype == SIS_F32)
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (float*)dw, (const float*)workspace,
+                           pl.units, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt);
+    else
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel<__hip_bfloat16>, dim3(blocks), dim3(256), 0, st, (__hip_bfloat16*)dw,
+                           (const float*)workspace, pl.units, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt);
+    SIS_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
+    return 0;
+}

@@ -167,7 +167,93 @@ def conv3x3_half_image_dilation(input, weight):
     return y.view(b, d, d, 2, 2, cout).permute(0, 5, 3, 1, 4, 2).reshape(b, cout, h, w)
 
 
+def conv_bf16_applicable(input, weight, stride, padding, dilation, groups):
+    """The bf16 matrix-core kernels (csrc/conv_bf16.hip) take this layer: bf16 NCHW input on a HIP device (what the
+    16-bit norm kernels hand over under autocast), square 1x1 / 3x3 kernel with padding k // 2, stride 1 or 2."""
+    if not (input.is_cuda and input.dim() == 4 and input.dtype == torch.bfloat16 and weight.dim() == 4 and groups == 1
+            and weight.dtype in (torch.float32, torch.bfloat16) and weight.shape[1] == input.shape[1]):
+        return False
+    k = weight.shape[2]
+    if weight.shape[3] != k or tuple(stride) not in ((1, 1), (2, 2)) or tuple(padding) != (k // 2, k // 2) or tuple(dilation) != (1, 1):
+        return False
+    return sis_hip.conv_bf16_supported(weight.shape[1], weight.shape[0], input.shape[2], input.shape[3], k, stride[0])
+
+
+class _ConvBf16Function(Function):
+    """bf16 convolution on the hand-written MFMA kernels, NCHW in and out (no layout transposes, no weight cast: the pack
+    kernel reads the fp32 master weight or the bf16 standardised weight directly).
+
+    forward        sis_conv_bf16 on the packed weight
+    dL/dx          the same kernel on the adjoint packing (stride 1); the library for the four stride-2 layers
+    dL/dw          3x3: sis_conv_bf16_wgrad where its tile plan applies, the library otherwise; 1x1 stride 1: one batched
+                   GEMM dy_b x_b^T on the NCHW tensors + sum over the batch
+    dL/dbias       fp32 sum of dL/dy
+    """
+
+    @staticmethod
+    def forward(ctx, input, weight, bias, stride):
+        input = input.contiguous()
+        k = weight.shape[2]
+        packed = sis_hip.conv_bf16_pack(weight, input.shape[2], input.shape[3], stride)
+        ctx.save_for_backward(input, weight)
+        ctx.stride, ctx.has_bias = stride, bias is not None
+        return sis_hip.conv_bf16(input, packed, weight.shape[0], k, stride, bias)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        input, weight = ctx.saved_tensors
+        b, cin, h, w = input.shape
+        cout, _, k, _ = weight.shape
+        s = ctx.stride
+        gy = grad_output.contiguous()
+        if gy.dtype != torch.bfloat16:
+            gy = gy.bfloat16()
+        grad_input = grad_weight = grad_bias = None
+        lib_weight = None
+        if ctx.needs_input_grad[0]:
+            if s == 1 and sis_hip.conv_bf16_supported(cout, cin, h, w, k, 1):
+                grad_input = sis_hip.conv_bf16(gy, sis_hip.conv_bf16_pack(weight, h, w, 1, adjoint=True), cin, k, 1)
+            else:
+                lib_weight = weight if weight.dtype == torch.bfloat16 else weight.bfloat16()
+                grad_input = torch.ops.aten.convolution_backward(gy, input, lib_weight, None, (s, s), (k // 2, k // 2), (1, 1), False,
+                                                                 (0, 0), 1, (True, False, False))[0]
+        if ctx.needs_input_grad[1]:
+            if k == 3 and s == 1 and sis_hip.conv_bf16_wgrad_supported(b, cin, cout, h, w):
+                grad_weight = sis_hip.conv_bf16_wgrad(input, gy, weight.dtype)
+            elif k == 1 and s == 1:
+                grad_weight = torch.bmm(gy.view(b, cout, h * w), input.view(b, cin, h * w).transpose(1, 2)).sum(0, dtype=torch.float32)
+                grad_weight = grad_weight.view(cout, cin, 1, 1)
+            else:
+                if lib_weight is None:
+                    lib_weight = weight if weight.dtype == torch.bfloat16 else weight.bfloat16()
+                grad_weight = torch.ops.aten.convolution_backward(gy, input, lib_weight, None, (s, s), (k // 2, k // 2), (1, 1), False,
+                                                                  (0, 0), 1, (False, True, False))[1]
+            if grad_weight.dtype != weight.dtype:
+                grad_weight = grad_weight.to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = gy.sum((0, 2, 3), dtype=torch.float32)
+        return grad_input, grad_weight, grad_bias, None
+
+
+def conv_bf16(input, weight, bias=None, stride=1):
+    """Differentiable bf16 convolution (padding k // 2) on the matrix-core kernels; the caller checks
+    ``conv_bf16_applicable``."""
+    return _ConvBf16Function.apply(input, weight, bias, stride)
+
+
+_BF16_CONV = os.environ.get('SIS_BF16_CONV', '1') != '0'  # 0: bf16 convolutions stay on the library (A/B runs)
+
+
 class HipConv2d(nn.Conv2d):
+    def _bf16(self, input):
+        """Under bf16 autocast: the input is already bf16 (norm kernels write it) or is cast here, as autocast would."""
+        if not (_BF16_CONV and input.is_cuda and self.padding_mode == 'zeros' and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype('cuda') == torch.bfloat16 and input.dim() == 4):
+            return None
+        x = input if input.dtype == torch.bfloat16 else input.bfloat16()
+        return x if conv_bf16_applicable(x, self.weight, self.stride, self.padding, self.dilation, self.groups) else None
+
     def _eligible(self, input):
         return (self.kernel_size == (3, 3) and self.stride == (1, 1) and self.dilation[0] == self.dilation[1]
                 and self.padding == self.dilation and self.groups == 1 and self.bias is None
@@ -185,6 +271,9 @@ class HipConv2d(nn.Conv2d):
                 and input.is_cuda and input.dim() == 4 and input.is_contiguous())
 
     def forward(self, input):
+        x = self._bf16(input)
+        if x is not None:
+            return conv_bf16(x, self.weight, self.bias, self.stride[0])
         if self._pointwise(input):
             return _Pointwise.apply(input, self.weight, self.bias)
         if self._half_image_dilation(input):

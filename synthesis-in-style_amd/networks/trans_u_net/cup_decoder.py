@@ -72,7 +72,7 @@ class DecoderBlock(nn.Module):
 
 class SegmentationHead(nn.Sequential):
     def __init__(self, in_channels, out_channels, kernel_size=3, upsampling=1):
-        super().__init__(nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, padding=kernel_size // 2),
+        super().__init__(HipConv2d(in_channels, out_channels, kernel_size=kernel_size, padding=kernel_size // 2),
                          HipUpsamplingBilinear2d(scale_factor=upsampling) if upsampling > 1 else nn.Identity())
 
 

@@ -18,6 +18,8 @@ from torch.nn import Conv2d, Dropout, Linear, Softmax
 import sis_hip
 from torch.nn.modules.utils import _pair
 
+from networks.hip_conv import HipConv2d
+
 from .vit_seg_modeling_resnet_skip import ResNetV2
 
 
@@ -176,8 +178,10 @@ class Embeddings(nn.Module):
         if self.hybrid:
             self.hybrid_model = ResNetV2(block_units=config.resnet.num_layers, width_factor=config.resnet.width_factor)
             in_channels = self.hybrid_model.width * 16
-        self.patch_embeddings = Conv2d(in_channels=in_channels, out_channels=config.hidden_size,
-                                       kernel_size=patch_size, stride=patch_size)
+        # nn.Conv2d subclass with the same parameters: under bf16 autocast the hybrid model's 1x1 patch embedding runs on
+        # the MI355X bf16 MFMA convolution kernel (any other configuration: the library, as nn.Conv2d)
+        self.patch_embeddings = HipConv2d(in_channels=in_channels, out_channels=config.hidden_size,
+                                          kernel_size=patch_size, stride=patch_size)
         self.position_embeddings = nn.Parameter(torch.zeros(1, n_patches, config.hidden_size))
         self.dropout = Dropout(config.transformer["dropout_rate"])
 

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 import sis_hip
-from networks.hip_conv import _Pointwise
+from networks.hip_conv import _BF16_CONV, _Pointwise, conv_bf16, conv_bf16_applicable
 
 
 def np2th(weights, conv=False):
@@ -111,6 +111,10 @@ class StdConv2d(nn.Conv2d):
 
     def forward(self, x):
         w = self.standardized_weight()
+        if _BF16_CONV and w.dtype == torch.bfloat16 and self.padding_mode == 'zeros' and x.is_cuda and x.dim() == 4:
+            xb = x if x.dtype == torch.bfloat16 else x.bfloat16()  # (the root convolution's fp32 image)
+            if conv_bf16_applicable(xb, w, self.stride, self.padding, self.dilation, self.groups):
+                return conv_bf16(xb, w, self.bias, self.stride[0])  # MI355X bf16 MFMA kernels, NCHW in and out
         if (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.groups == 1
                 and x.is_cuda and x.dim() == 4 and x.is_contiguous() and x.dtype == w.dtype):
             return _Pointwise.apply(x, w, self.bias)  # weight gradient as a batched GEMM on the NCHW tensors

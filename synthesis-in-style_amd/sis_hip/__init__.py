@@ -81,6 +81,8 @@ _SIGNATURES = {
     "sis_conv_bf16_packed_elems": ([_i] * 7, _i64),
     "sis_conv_bf16_pack": ([_vp, _vp, _i] + [_i] * 7 + [_vp], _i),
     "sis_conv_bf16": ([_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp], _i),
+    "sis_conv_bf16_wgrad_supported": ([_i] * 5 + [_i64], _i),
+    "sis_conv_bf16_wgrad": ([_vp, _i, _vp, _vp] + [_i] * 5 + [_vp, _i64, _vp], _i),
 }
 
 
@@ -624,6 +626,26 @@ def conv_bf16(x, packed, cout, ksize, stride=1, bias=None):
                        lambda: lib().sis_conv_bf16(_ptr(y), _ptr(x), _ptr(packed), _ptr(bias), b, cin, cout, h, w, ksize,
                                                    stride, _stream())), "sis_conv_bf16")
     return y
+
+
+def conv_bf16_wgrad_supported(batch, cin, cout, h, w):
+    return bool(lib().sis_conv_bf16_wgrad_supported(batch, cin, cout, h, w, WORKSPACE_BYTES))
+
+
+def conv_bf16_wgrad(x, grad_output, out_dtype=torch.float32):
+    """dL/dw [Cout,Cin,3,3] (float32 or bfloat16) of a stride-1, padding-1 3x3 convolution from its bf16 input and dL/dy."""
+    require_device(x, "input")
+    if x.dtype != torch.bfloat16 or grad_output.dtype != torch.bfloat16 or not x.is_contiguous() or not grad_output.is_contiguous():
+        raise RuntimeError("conv_bf16_wgrad: input and grad_output must be contiguous bfloat16 tensors")
+    b, cin, h, w = x.shape
+    cout = grad_output.shape[1]
+    dw = torch.empty((cout, cin, 3, 3), dtype=out_dtype, device=x.device)
+    ws = _workspace(x.device)
+    with torch.cuda.device(x.device):
+        _check(_launch(None, 2.0 * b * cout * cin * 9 * h * w, 2.0 * (x.numel() + grad_output.numel()) + 4.0 * dw.numel(),
+                       lambda: lib().sis_conv_bf16_wgrad(_ptr(dw), _DTYPE_CODE[out_dtype], _ptr(x), _ptr(grad_output), b, cin, cout,
+                                                         h, w, _ptr(ws), ws.numel(), _stream())), "sis_conv_bf16_wgrad")
+    return dw
 
 
 # ------------------------------------------------------------------------------ layer norm

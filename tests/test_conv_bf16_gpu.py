@@ -61,3 +61,45 @@ def test_conv_bf16_data_gradient(device, batch, cin, cout, h, w, k):
     gx = sis_hip.conv_bf16(gy, sis_hip.conv_bf16_pack(wt, h, w, 1, adjoint=True), cin, k, 1)
     err = (gx.float() - x.grad).abs().max().item()
     assert err <= 1e-2 * x.grad.abs().max().item(), (err, x.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("batch,cin,cout,h,w", [(2, 64, 128, 32, 32), (2, 128, 64, 64, 64), (1, 192, 64, 48, 48), (3, 256, 256, 16, 16),
+                                                (1, 64, 64, 127, 127), (2, 96, 160, 24, 40), (8, 64, 64, 128, 128)])
+def test_conv_bf16_weight_gradient(device, batch, cin, cout, h, w):
+    """dL/dw on the pixel-contraction kernel (csrc/conv_bf16_wgrad.hip) against autograd of the fp32 convolution on the
+    same bf16-rounded tensors; fp32 result: |err| <= 2e-3 * max|ref| (fp32 accumulation in a different order), bf16
+    result: 1e-2."""
+    import sis_hip
+    gen = torch.Generator().manual_seed(cin + 7 * cout + h)
+    x = torch.randn(batch, cin, h, w, generator=gen).to(device).bfloat16()
+    gy = torch.randn(batch, cout, h, w, generator=gen).to(device).bfloat16()
+    wt = torch.zeros(cout, cin, 3, 3, device=device, requires_grad=True)
+    F.conv2d(x.float(), wt, padding=1).backward(gy.float())
+    assert sis_hip.conv_bf16_wgrad_supported(batch, cin, cout, h, w)
+    for dtype, tol in ((torch.float32, 2e-3), (torch.bfloat16, 1e-2)):
+        dw = sis_hip.conv_bf16_wgrad(x, gy, dtype)
+        assert dw.dtype == dtype and dw.shape == wt.shape
+        err = (dw.float() - wt.grad).abs().max().item()
+        assert err <= tol * wt.grad.abs().max().item(), (dtype, err, wt.grad.abs().max().item())
+    again = sis_hip.conv_bf16_wgrad(x, gy, torch.float32)
+    assert torch.equal(again, sis_hip.conv_bf16_wgrad(x, gy, torch.float32))  # ordered slab reduction: bitwise reproducible
+
+
+def test_conv_bf16_autograd_function(device):
+    """The autograd wrapper the networks call: forward, data and weight gradients, bias gradient in one graph."""
+    from networks.hip_conv import conv_bf16, conv_bf16_applicable
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 32, 32, generator=gen).to(device).bfloat16().requires_grad_(True)
+    w = (torch.randn(128, 64, 3, 3, generator=gen) / 24).to(device).requires_grad_(True)
+    b = torch.randn(128, generator=gen).to(device).requires_grad_(True)
+    assert conv_bf16_applicable(x, w, (1, 1), (1, 1), (1, 1), 1)
+    y = conv_bf16(x, w, b, 1)
+    gy = torch.randn(y.shape, generator=gen).to(device).bfloat16()
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().bfloat16().float().requires_grad_(True)
+    br = b.detach().clone().requires_grad_(True)
+    F.conv2d(xr, wr, br, padding=1).backward(gy.float())
+    for got, ref, tol in ((x.grad, xr.grad, 1e-2), (w.grad, wr.grad, 2e-3), (b.grad, br.grad, 1e-3)):
+        assert (got.float() - ref).abs().max().item() <= tol * ref.abs().max().item()
+    assert w.grad.dtype == torch.float32 and x.grad.dtype == torch.bfloat16

@@ -43,6 +43,21 @@ def main():
     tot_mine = tot_lib = 0.0
     print(f"{'layer':18s} {'GF':>7s} {'mine ms':>8s} {'TF/s':>7s} {'lib ms':>8s} {'TF/s':>7s}  kernel")
     for name, cin, cout, h, w, k, s in LAYERS:
+        if mode == "wgrad":
+            if k != 3 or s != 1 or not sis_hip.conv_bf16_wgrad_supported(B, cin, cout, h, w):
+                continue
+            x = torch.randn(B, cin, h, w, device=dev).bfloat16()
+            gy = torch.randn(B, cout, h, w, device=dev).bfloat16()
+            wt = torch.zeros(cout, cin, 3, 3, device=dev).bfloat16()
+            gf = 2.0 * B * cout * cin * 9 * h * w / 1e9
+            t_mine = timeit(lambda: sis_hip.conv_bf16_wgrad(x, gy, torch.float32))
+            kern = sis_hip.lib().sis_last_kernel().decode()
+            t_lib = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, wt, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                                       (False, True, False)))
+            tot_mine += t_mine
+            tot_lib += t_lib
+            print(f"{name:18s} {gf:7.1f} {t_mine:8.3f} {gf / t_mine:7.1f} {t_lib:8.3f} {gf / t_lib:7.1f}  {kern}", flush=True)
+            continue
         if mode == "dgrad":
             if s != 1:
                 continue
