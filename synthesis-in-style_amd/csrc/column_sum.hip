@@ -56,13 +56,20 @@ __global__ __launch_bounds__(256) void column_sum_partial_kernel(float* __restri
         part[(int64_t)blockIdx.y * n + cc] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// 64 columns per workgroup, the slices dealt to the four waves (wave q adds slices q, q + 4, ... in order, 8 loads in
+// flight), then (s0 + s1) + (s2 + s3): a fixed order, and ~2 us instead of one 64-deep chain of dependent-latency loads.
 __global__ __launch_bounds__(256) void column_sum_finish_kernel(float* __restrict__ out, const float* __restrict__ part, int n,
                                                                 int slices) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n) return;
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
     float s = 0.f;
-    for (int k = 0; k < slices; ++k) s += part[(int64_t)k * n + c];
-    out[c] = s;
+    if (c < n) {
+#pragma unroll 8
+        for (int k = q; k < slices; k += 4) s += part[(int64_t)k * n + c];
+    }
+    red[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && c < n) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 constexpr int CS_MAX_SLICES = 64;
@@ -91,7 +98,7 @@ extern "C" int sis_column_sum(float* out, float* workspace, const void* x, int x
         default: return sis_fail("sis_column_sum: dtype code %d not supported (f32, f16, bf16)", x_dtype);
     }
     SIS_CHECK_LAUNCH("column_sum_partial_kernel");
-    hipLaunchKernelGGL(column_sum_finish_kernel, dim3(sis_cdiv(n, 256)), dim3(256), 0, st, out, workspace, n, slices);
+    hipLaunchKernelGGL(column_sum_finish_kernel, dim3(sis_cdiv(n, 64)), dim3(256), 0, st, out, workspace, n, slices);
     SIS_CHECK_LAUNCH("column_sum_finish_kernel");
     return 0;
 }

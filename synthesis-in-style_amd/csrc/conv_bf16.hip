@@ -30,15 +30,17 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef unsigned short u16;
 
-template <int MT_, int KC_, int KH_, int S_, int TW_>
+template <int MT_, int NPIX_, int KC_, int KH_, int S_, int TW_>
 struct ConvCfg {
-    static constexpr int MT = MT_, KC = KC_, KH = KH_, KW = KH_, S = S_, TW = TW_;
+    static constexpr int MT = MT_, NPIX = NPIX_, KC = KC_, KH = KH_, KW = KH_, S = S_, TW = TW_;
     static constexpr int PAD = KH / 2, TAPS = KH * KW;
-    static constexpr int TR = 256 / TW;                 // output rows per tile (256 output pixels per workgroup)
-    static constexpr int MB = MT >= 64 ? 2 : 1;          // 32-row MFMA blocks per wave along M
-    static constexpr int WM = MT / (32 * MB);            // waves along M
-    static constexpr int WN = 8 / WM;                    // waves along N
-    static constexpr int NB = 8 / WN;                    // 32-pixel MFMA blocks per wave along N
+    static constexpr int TR = NPIX / TW;                 // output rows per tile (NPIX output pixels per workgroup)
+    // 8 waves as WM x WN over (MT / 32) x (NPIX / 32) MFMA blocks
+    static constexpr int WM = MT == 128 ? (NPIX == 256 ? 2 : 4) : MT == 64 ? (NPIX == 256 ? 1 : 2) : 1;
+    static constexpr int WN = 8 / WM;
+    static constexpr int MB = MT / 32 / WM;              // 32-row MFMA blocks per wave along M
+    static constexpr int NB = NPIX / 32 / WN;            // 32-pixel MFMA blocks per wave along N
+    static_assert(MB >= 1 && NB >= 1 && MB * WM * 32 == MT && NB * WN * 32 == NPIX, "wave layout");
     static constexpr int HALO = PAD > 0 ? 8 : 0;         // left / right margin of the staged rows, in pixels (keeps 8-pixel alignment)
     static constexpr int RI = (TR - 1) * S + KH;         // staged input rows
     static constexpr int LW = TW * S + 2 * HALO;         // staged input pixels per row
@@ -313,20 +315,31 @@ int launch_conv(const ConvParams& p, hipStream_t st, const char* name) {
     return 0;
 }
 
-struct Plan { int mt, kc, tw; };
+struct Plan { int mt, kc, tw, npix; };
 
-// Tile plan of a layer: M tile by output channels, channel chunk by kernel size, tile width by image width.
-bool conv_plan(int cin, int cout, int h, int w, int ksize, int stride, Plan* plan) {
+// Tile plan of a layer: M tile by output channels, channel chunk by kernel size, tile width by image width, pixels per
+// workgroup (256, 128 or 64) so that the grid fills the chip's 256 compute units when the layer is small.
+bool conv_plan(int batch, int cin, int cout, int h, int w, int ksize, int stride, Plan* plan) {
     if (!((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2))) return false;
-    const int kc = (ksize == 1 && stride == 1) ? 64 : 16;
+    const bool flat = ksize == 1 && stride == 1;      // pointwise: the image is one row of H*W pixels
+    const int kc = flat ? 64 : 16;
     if (cin % kc) return false;
     int mt = cout > 64 ? 128 : cout > 32 ? 64 : 32;
-    int tw = 64;
-    if (ksize == 1 && stride == 1) tw = 256;       // 1x1: the image is one row of H*W pixels
-    else if (stride == 1 && w <= 32) tw = 32;
-    if (stride == 2) { mt = cout > 64 ? 128 : 64; tw = 64; }
-    plan->mt = mt; plan->kc = kc; plan->tw = tw;
-    (void)h;
+    if (stride == 2) mt = cout > 64 ? 128 : 64;
+    const int pad = ksize / 2;
+    const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (w + 2 * pad - ksize) / stride + 1;
+    int npix = 256;
+    auto groups = [&](int np) {
+        const int tw = flat ? np : (stride == 1 && wo <= 32 ? 32 : 64);
+        const int64_t tiles = flat ? sis_cdiv((int64_t)ho * wo, np) : (int64_t)sis_cdiv(wo, tw) * sis_cdiv(ho, np / tw);
+        return (int64_t)(batch > 0 ? batch : 1) * tiles * sis_cdiv(cout, mt);
+    };
+    if (stride == 1 && mt >= 64) {
+        while (npix > (mt == 128 ? 64 : 128) && groups(npix) < 256) npix /= 2;
+        if (!flat && mt == 128 && npix == 64 && wo > 32) npix = 128;  // 64-pixel tiles exist as 32 x 2 only
+    }
+    plan->mt = mt; plan->kc = kc; plan->npix = npix;
+    plan->tw = flat ? npix : (stride == 1 && wo <= 32 ? 32 : 64);
     return true;
 }
 
@@ -334,13 +347,13 @@ bool conv_plan(int cin, int cout, int h, int w, int ksize, int stride, Plan* pla
 
 extern "C" int sis_conv_bf16_supported(int cin, int cout, int h, int w, int ksize, int stride) {
     Plan pl;
-    return conv_plan(cin, cout, h, w, ksize, stride, &pl) ? 1 : 0;
+    return conv_plan(1, cin, cout, h, w, ksize, stride, &pl) ? 1 : 0;
 }
 
 extern "C" int64_t sis_conv_bf16_packed_elems(int cin, int cout, int h, int w, int ksize, int stride, int adjoint) {
     const int M = adjoint ? cin : cout, K = adjoint ? cout : cin;
     Plan pl;
-    if (!conv_plan(K, M, h, w, ksize, stride, &pl)) return -1;
+    if (!conv_plan(1, K, M, h, w, ksize, stride, &pl)) return -1;  // (the packing depends on mt and kc only)
     const int64_t mtiles = (M + pl.mt - 1) / pl.mt;
     return mtiles * pl.mt * (int64_t)K * ksize * ksize;
 }
@@ -350,7 +363,7 @@ extern "C" int sis_conv_bf16_pack(void* packed, const void* weight, int weight_d
     SIS_REQUIRE(packed && weight, "sis_conv_bf16_pack: null pointer");
     const int M = adjoint ? cin : cout, K = adjoint ? cout : cin;
     Plan pl;
-    SIS_REQUIRE(conv_plan(K, M, h, w, ksize, stride, &pl), "sis_conv_bf16_pack: unsupported layer %d->%d k%d s%d", cin, cout, ksize, stride);
+    SIS_REQUIRE(conv_plan(1, K, M, h, w, ksize, stride, &pl), "sis_conv_bf16_pack: unsupported layer %d->%d k%d s%d", cin, cout, ksize, stride);
     SIS_REQUIRE(!(adjoint && stride != 1), "sis_conv_bf16_pack: the adjoint packing is for stride-1 layers");
     const int64_t total = sis_conv_bf16_packed_elems(cin, cout, h, w, ksize, stride, adjoint);
     hipStream_t st = (hipStream_t)stream;
@@ -372,7 +385,7 @@ extern "C" int sis_conv_bf16(void* y, const void* x, const void* packed, const f
     if (batch <= 0) return 0;
     SIS_REQUIRE(y && x && packed, "sis_conv_bf16: null pointer");
     Plan pl;
-    SIS_REQUIRE(conv_plan(cin, cout, h, w, ksize, stride, &pl), "sis_conv_bf16: unsupported layer %d->%d k%d s%d", cin, cout, ksize, stride);
+    SIS_REQUIRE(conv_plan(batch, cin, cout, h, w, ksize, stride, &pl), "sis_conv_bf16: unsupported layer %d->%d k%d s%d", cin, cout, ksize, stride);
     const int pad = ksize / 2;
     ConvParams p;
     p.x = (const u16*)x; p.wp = (const u16*)packed; p.bias = bias; p.y = (u16*)y;
@@ -383,18 +396,21 @@ extern "C" int sis_conv_bf16(void* y, const void* x, const void* packed, const f
         p.H = 1; p.W = h * w; p.Ho = 1; p.Wo = h * w;
     }
     SIS_REQUIRE((int64_t)cin * h * w < (1LL << 31) && (int64_t)cout * p.Ho * p.Wo < (1LL << 31), "sis_conv_bf16: image planes exceed 2^31 elements");
-    const int tr = 256 / pl.tw;
+    const int tr = pl.npix / pl.tw;
     p.tiles_x = sis_cdiv(p.Wo, pl.tw); p.tiles_y = sis_cdiv(p.Ho, tr);
     p.co_tiles = sis_cdiv(cout, pl.mt);
     p.aligned = (p.W % 4 == 0) && (((int64_t)p.H * p.W) % 4 == 0) && ((((uintptr_t)x) & 7) == 0);
     hipStream_t st = (hipStream_t)stream;
-#define CONV_CASE(MT, KC, KH, S, TW)                                                                         \
-    if (pl.mt == MT && pl.kc == KC && ksize == KH && stride == S && pl.tw == TW)                             \
-        return launch_conv<ConvCfg<MT, KC, KH, S, TW>>(p, st, "conv_bf16_kernel<" #MT "," #KC "," #KH "," #S "," #TW ">");
-    CONV_CASE(128, 16, 3, 1, 64) CONV_CASE(128, 16, 3, 1, 32) CONV_CASE(64, 16, 3, 1, 64) CONV_CASE(64, 16, 3, 1, 32)
-    CONV_CASE(32, 16, 3, 1, 64) CONV_CASE(32, 16, 3, 1, 32)
-    CONV_CASE(128, 64, 1, 1, 256) CONV_CASE(64, 64, 1, 1, 256) CONV_CASE(32, 64, 1, 1, 256)
-    CONV_CASE(128, 16, 3, 2, 64) CONV_CASE(64, 16, 3, 2, 64) CONV_CASE(128, 16, 1, 2, 64) CONV_CASE(64, 16, 1, 2, 64)
+#define CONV_CASE(MT, NPIX, KC, KH, S, TW)                                                                      \
+    if (pl.mt == MT && pl.npix == NPIX && pl.kc == KC && ksize == KH && stride == S && pl.tw == TW)            \
+        return launch_conv<ConvCfg<MT, NPIX, KC, KH, S, TW>>(p, st, "conv_bf16_kernel<" #MT "," #NPIX "," #KC "," #KH "," #S "," #TW ">");
+    CONV_CASE(128, 256, 16, 3, 1, 64) CONV_CASE(128, 256, 16, 3, 1, 32) CONV_CASE(128, 128, 16, 3, 1, 64)
+    CONV_CASE(128, 128, 16, 3, 1, 32) CONV_CASE(128, 64, 16, 3, 1, 32)
+    CONV_CASE(64, 256, 16, 3, 1, 64) CONV_CASE(64, 256, 16, 3, 1, 32) CONV_CASE(64, 128, 16, 3, 1, 64) CONV_CASE(64, 128, 16, 3, 1, 32)
+    CONV_CASE(32, 256, 16, 3, 1, 64) CONV_CASE(32, 256, 16, 3, 1, 32)
+    CONV_CASE(128, 256, 64, 1, 1, 256) CONV_CASE(128, 128, 64, 1, 1, 128) CONV_CASE(128, 64, 64, 1, 1, 64)
+    CONV_CASE(64, 256, 64, 1, 1, 256) CONV_CASE(64, 128, 64, 1, 1, 128) CONV_CASE(32, 256, 64, 1, 1, 256)
+    CONV_CASE(128, 256, 16, 3, 2, 64) CONV_CASE(64, 256, 16, 3, 2, 64) CONV_CASE(128, 256, 16, 1, 2, 64) CONV_CASE(64, 256, 16, 1, 2, 64)
 #undef CONV_CASE
-    return sis_fail("sis_conv_bf16: no kernel instance for tile plan mt=%d kc=%d k=%d s=%d tw=%d", pl.mt, pl.kc, ksize, stride, pl.tw);
+    return sis_fail("sis_conv_bf16: no kernel instance for tile plan mt=%d npix=%d kc=%d k=%d s=%d tw=%d", pl.mt, pl.npix, pl.kc, ksize, stride, pl.tw);
 }

@@ -27,9 +27,12 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef unsigned short u16;
 
-template <int WM_, int KS_>
+template <int WM_, int WN_, int KS_>
 struct WgCfg {
-    static constexpr int WM = WM_, WN = 8 / WM_, KS = KS_;   // waves along co / ci, 16-pixel K-steps per row step
+    // waves along co / ci / K (the K waves split a row step's 16-pixel K-steps and write partial tiles of their own:
+    // the narrow tail of the decoder, 16 or 3 output channels, has no other parallelism); K-steps per row step
+    static constexpr int WM = WM_, WN = WN_, WK = 8 / (WM_ * WN_), KS = KS_;
+    static_assert(WM * WN * WK == 8 && KS % WK == 0, "wave layout");
     static constexpr int MT = 32 * WM, NT = 32 * WN;         // co x ci tile of the workgroup
     static constexpr int SW = 16 * KS;                       // strip width in pixels
     static constexpr int DY_UNITS = SW / 8 + 1;              // 16-byte units per dY row (one pad unit)
@@ -69,6 +72,17 @@ __device__ __forceinline__ uint4 load_chunk(const u16* row, int x0, int W, bool 
     return make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
 }
 
+// the three kx taps of one input row and one 16-pixel K-step: centre group as is, its two neighbours funnel-shifted in
+__device__ __forceinline__ void tap_row(f32x16 (&acc)[9], int ky, bf16x8 a, uint4 lft, uint4 c, uint4 rgt) {
+    const unsigned t0 = __builtin_amdgcn_alignbit(c.x, lft.w, 16), t1 = __builtin_amdgcn_alignbit(c.y, c.x, 16);
+    const unsigned t2 = __builtin_amdgcn_alignbit(c.z, c.y, 16), t3 = __builtin_amdgcn_alignbit(c.w, c.z, 16);
+    const unsigned t4 = __builtin_amdgcn_alignbit(rgt.x, c.w, 16);
+    const uint4 b0 = make_uint4(t0, t1, t2, t3), b2 = make_uint4(t1, t2, t3, t4);
+    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b0), acc[ky * 3 + 0], 0, 0, 0);
+    acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, c), acc[ky * 3 + 1], 0, 0, 0);
+    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b2), acc[ky * 3 + 2], 0, 0, 0);
+}
+
 template <typename C, bool ALIGNED>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(WgParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -76,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(WgParams p) {
     unsigned char* const x_lds = lds + 2 * C::DY_BUF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int wm = wave % C::WM, wn = wave / C::WM;
+    const int wm = wave % C::WM, wn = (wave / C::WM) % C::WN, wk = wave / (C::WM * C::WN);
 
     int u = blockIdx.x;
     const int rb = u % p.row_blocks; u /= p.row_blocks;
@@ -157,27 +171,30 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(WgParams p) {
             load_dy(y + 1);
             load_x(y + 2);
         }
-        bf16x8 a[C::KS];
+        constexpr int KW = C::KS / C::WK;  // K-steps of this wave: wk, wk + WK, ...
+        bf16x8 a[KW];
 #pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks)
-            a[ks] = *reinterpret_cast<const bf16x8*>(a_base + (y & 1) * C::DY_BUF + ks * 32);
+        for (int i = 0; i < KW; ++i)
+            a[i] = *reinterpret_cast<const bf16x8*>(a_base + (y & 1) * C::DY_BUF + (wk + i * C::WK) * 32);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int slot = (y + ky) & 3;  // image row y + ky - 1
-            uint4 g[2 * C::KS + 1];          // groups h - 1 .. h + 2 KS - 1 of the strip (LDS group index + 1)
+            const unsigned char* row = b_base + slot * C::XR_UNITS * 16;
+            if constexpr (C::WK == 1) {
+                uint4 g[2 * C::KS + 1];      // groups h - 1 .. h + 2 KS - 1 of the strip (LDS group index + 1), each read once
 #pragma unroll
-            for (int i = 0; i < 2 * C::KS + 1; ++i)
-                g[i] = *reinterpret_cast<const uint4*>(b_base + (slot * C::XR_UNITS + i) * 16);
+                for (int i = 0; i < 2 * C::KS + 1; ++i) g[i] = *reinterpret_cast<const uint4*>(row + i * 16);
 #pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks) {
-                const uint4 lft = g[2 * ks], c = g[2 * ks + 1], rgt = g[2 * ks + 2];
-                const unsigned t0 = __builtin_amdgcn_alignbit(c.x, lft.w, 16), t1 = __builtin_amdgcn_alignbit(c.y, c.x, 16);
-                const unsigned t2 = __builtin_amdgcn_alignbit(c.z, c.y, 16), t3 = __builtin_amdgcn_alignbit(c.w, c.z, 16);
-                const unsigned t4 = __builtin_amdgcn_alignbit(rgt.x, c.w, 16);
-                const uint4 b0 = make_uint4(t0, t1, t2, t3), b2 = make_uint4(t1, t2, t3, t4);
-                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], __builtin_bit_cast(bf16x8, b0), acc[ky * 3 + 0], 0, 0, 0);
-                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], __builtin_bit_cast(bf16x8, c), acc[ky * 3 + 1], 0, 0, 0);
-                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], __builtin_bit_cast(bf16x8, b2), acc[ky * 3 + 2], 0, 0, 0);
+                for (int ks = 0; ks < C::KS; ++ks) tap_row(acc, ky, a[ks], g[2 * ks], g[2 * ks + 1], g[2 * ks + 2]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < KW; ++i) {
+                    const int ks = wk + i * C::WK;
+                    const uint4 lft = *reinterpret_cast<const uint4*>(row + (2 * ks) * 16);
+                    const uint4 c = *reinterpret_cast<const uint4*>(row + (2 * ks + 1) * 16);
+                    const uint4 rgt = *reinterpret_cast<const uint4*>(row + (2 * ks + 2) * 16);
+                    tap_row(acc, ky, a[i], lft, c, rgt);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -190,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(WgParams p) {
 
     // ---- partial tile -> slab[unit][tap][co][ci] (ci on the lanes: 128-byte runs)
     const int co_pad = p.co_tiles * C::MT, ci_pad = p.ci_tiles * C::NT;
-    float* out = p.slab + (int64_t)blockIdx.x * 9 * co_pad * ci_pad;
+    float* out = p.slab + ((int64_t)blockIdx.x * C::WK + wk) * 9 * co_pad * ci_pad;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -219,17 +236,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(T* __restrict__ 
     for (int t = 0; t < 9; ++t) sis_st(dw, (int64_t)idx * 9 + t, s[t]);
 }
 
-struct WgPlan { int wm, ks, strips, row_blocks, rows_per_block, co_tiles, ci_tiles, units; int64_t slab_bytes; };
+struct WgPlan { int wm, wn, ks, strips, row_blocks, rows_per_block, co_tiles, ci_tiles, units, partials; int64_t slab_bytes; };
 
 bool wgrad_plan(int batch, int cin, int cout, int h, int w, int64_t workspace_bytes, WgPlan* pl) {
-    if (cin < 32 || cout < 32) return false;          // the 16 / 3-channel tail of the decoder: library
-    pl->ks = w <= 32 ? 2 : 4;
+    if (cin % 8 || cin < 16) return false;
+    if (cout <= 32) {                 // narrow tail of the decoder: one co block, the spare waves split K
+        pl->wm = 1;
+        pl->wn = cin > 32 ? 2 : 1;
+        pl->ks = cin > 32 ? 4 : 8;
+    } else {
+        pl->wm = cout >= 128 ? 4 : 2;
+        pl->wn = 8 / pl->wm;
+        pl->ks = w <= 32 ? 2 : 4;
+    }
+    const int wk = 8 / (pl->wm * pl->wn);
     const int sw = 16 * pl->ks;
-    pl->wm = cout >= 128 ? 4 : 2;
-    const int mt = 32 * pl->wm, nt = 32 * (8 / pl->wm);
+    const int mt = 32 * pl->wm, nt = 32 * pl->wn;
     pl->co_tiles = sis_cdiv(cout, mt); pl->ci_tiles = sis_cdiv(cin, nt);
     pl->strips = sis_cdiv(w, sw);
-    const int64_t tile_bytes = (int64_t)9 * pl->co_tiles * mt * pl->ci_tiles * nt * 4;
+    const int64_t tile_bytes = (int64_t)9 * pl->co_tiles * mt * pl->ci_tiles * nt * 4 * wk;
     const int tiles = pl->co_tiles * pl->ci_tiles;
     // row blocks: enough workgroups to fill the chip (~2 per CU), at least 8 rows each, slabs within the workspace
     int rbk = 1;
@@ -238,6 +263,7 @@ bool wgrad_plan(int batch, int cin, int cout, int h, int w, int64_t workspace_by
     pl->rows_per_block = sis_cdiv(h, rbk);
     pl->row_blocks = sis_cdiv(h, pl->rows_per_block);
     pl->units = batch * pl->strips * pl->row_blocks;
+    pl->partials = pl->units * wk;
     pl->slab_bytes = (int64_t)pl->units * tile_bytes;
     return pl->slab_bytes <= workspace_bytes;
 }
@@ -286,19 +312,21 @@ extern "C" int sis_conv_bf16_wgrad(void* dw, int dw_dtype, const void* x, const 
     p.aligned = (w % 8 == 0) && ((((uintptr_t)x) | ((uintptr_t)grad_y)) & 15) == 0;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (pl.wm == 4 && pl.ks == 4) rc = launch_wgrad<WgCfg<4, 4>>(p, pl.units, st, "conv_wgrad_bf16_kernel<4,4>");
-    else if (pl.wm == 4 && pl.ks == 2) rc = launch_wgrad<WgCfg<4, 2>>(p, pl.units, st, "conv_wgrad_bf16_kernel<4,2>");
-    else if (pl.wm == 2 && pl.ks == 4) rc = launch_wgrad<WgCfg<2, 4>>(p, pl.units, st, "conv_wgrad_bf16_kernel<2,4>");
-    else rc = launch_wgrad<WgCfg<2, 2>>(p, pl.units, st, "conv_wgrad_bf16_kernel<2,2>");
+    if (pl.wm == 4 && pl.ks == 4) rc = launch_wgrad<WgCfg<4, 2, 4>>(p, pl.units, st, "conv_wgrad_bf16_kernel<4,2,4>");
+    else if (pl.wm == 4 && pl.ks == 2) rc = launch_wgrad<WgCfg<4, 2, 2>>(p, pl.units, st, "conv_wgrad_bf16_kernel<4,2,2>");
+    else if (pl.wm == 2 && pl.ks == 4) rc = launch_wgrad<WgCfg<2, 4, 4>>(p, pl.units, st, "conv_wgrad_bf16_kernel<2,4,4>");
+    else if (pl.wm == 2) rc = launch_wgrad<WgCfg<2, 4, 2>>(p, pl.units, st, "conv_wgrad_bf16_kernel<2,4,2>");
+    else if (pl.wn == 2) rc = launch_wgrad<WgCfg<1, 2, 4>>(p, pl.units, st, "conv_wgrad_bf16_kernel<1,2,4>");
+    else rc = launch_wgrad<WgCfg<1, 1, 8>>(p, pl.units, st, "conv_wgrad_bf16_kernel<1,1,8>");
     if (rc) return rc;
-    const int mt = 32 * pl.wm, nt = 32 * (8 / pl.wm);
+    const int mt = 32 * pl.wm, nt = 32 * pl.wn;
     const int blocks = sis_cdiv((int64_t)cout * cin, 256);
     if (dw_dtype == SIS_F32)
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (float*)dw, (const float*)workspace,
-                           pl.units, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt);
+                           pl.partials, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt);
     else
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel<__hip_bfloat16>, dim3(blocks), dim3(256), 0, st, (__hip_bfloat16*)dw,
-                           (const float*)workspace, pl.units, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt);
+                           (const float*)workspace, pl.partials, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt);
     SIS_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
     return 0;
 }
