@@ -207,33 +207,64 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(WgParams p) {
 
     // ---- partial tile -> slab[unit][tap][co][ci] (ci on the lanes: 128-byte runs)
     const int co_pad = p.co_tiles * C::MT, ci_pad = p.ci_tiles * C::NT;
-    float* out = p.slab + ((int64_t)blockIdx.x * C::WK + wk) * 9 * co_pad * ci_pad;
+    float* out = p.slab + (int64_t)blockIdx.x * 9 * co_pad * ci_pad;
+    if constexpr (C::WK == 1) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int co = co_t * C::MT + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            const int ci = ci_t * C::NT + wn * 32 + r;
-            out[((int64_t)t * co_pad + co) * ci_pad + ci] = acc[t][i];
+            for (int i = 0; i < 16; ++i) {
+                const int co = co_t * C::MT + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int ci = ci_t * C::NT + wn * 32 + r;
+                out[((int64_t)t * co_pad + co) * ci_pad + ci] = acc[t][i];
+            }
+    } else {
+        // the K waves of a (co, ci) block first add their tiles through the (now idle) staging LDS, tap by tap, in wave
+        // order; one partial tile per workgroup reaches the slab
+        constexpr int NP = C::WM * C::WN;
+        static_assert(C::WK * NP * 1024 * 4 <= C::LDS, "reduction scratch");
+        float* red = reinterpret_cast<float*>(lds);  // [WK][NP][16][64]
+        const int pair = wm + C::WM * wn;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            __syncthreads();  // everyone is out of the main loop / has read the previous tap
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[((wk * NP + pair) * 16 + i) * 64 + lane] = acc[t][i];
+            __syncthreads();
+            for (int e = tid; e < NP * 1024; e += 512) {
+                const int pr = e >> 10, i = (e >> 6) & 15, ln = e & 63;
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < C::WK; ++k) sum += red[((k * NP + pr) * 16 + i) * 64 + ln];
+                const int co = co_t * C::MT + (pr % C::WM) * 32 + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5);
+                const int ci = ci_t * C::NT + (pr / C::WM) * 32 + (ln & 31);
+                out[((int64_t)t * co_pad + co) * ci_pad + ci] = sum;
+            }
         }
+    }
 }
 
-// dW[co][ci][tap] = sum over units (in order) of slab[unit][tap][co][ci]; one thread per (co, ci)
+// dW[co][ci][tap] = sum over units of slab[unit][tap][co][ci].  One workgroup per (tap, co, 64 input channels): the
+// four waves add units w, w + 4, ... in order (coalesced 256-byte reads), then (s0 + s1) + (s2 + s3): a fixed order.
 template <typename T>
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(T* __restrict__ dw, const float* __restrict__ slab, int units,
                                                                 int Cout, int Cin, int co_pad, int ci_pad) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= Cout * Cin) return;
-    const int co = idx / Cin, ci = idx % Cin;
-    float s[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) s[t] = 0.f;
-    const int64_t stride = (int64_t)9 * co_pad * ci_pad;
-    for (int u = 0; u < units; ++u)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) s[t] += slab[u * stride + ((int64_t)t * co_pad + co) * ci_pad + ci];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) sis_st(dw, (int64_t)idx * 9 + t, s[t]);
+    __shared__ float red[4][64];
+    const int cchunks = (Cin + 63) / 64;
+    int b = blockIdx.x;
+    const int cc = b % cchunks; b /= cchunks;
+    const int co = b % Cout, t = b / Cout;
+    const int ln = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ci = cc * 64 + ln;
+    float s = 0.f;
+    if (ci < Cin) {
+        const float* src = slab + ((int64_t)t * co_pad + co) * ci_pad + ci;
+        const int64_t stride = (int64_t)9 * co_pad * ci_pad;
+#pragma unroll 4
+        for (int u = w; u < units; u += 4) s += src[u * stride];
+    }
+    red[w][ln] = s;
+    __syncthreads();
+    if (w == 0 && ci < Cin) sis_st(dw, ((int64_t)co * Cin + ci) * 9 + t, (red[0][ln] + red[1][ln]) + (red[2][ln] + red[3][ln]));
 }
 
 struct WgPlan { int wm, wn, ks, strips, row_blocks, rows_per_block, co_tiles, ci_tiles, units, partials; int64_t slab_bytes; };
@@ -249,12 +280,11 @@ bool wgrad_plan(int batch, int cin, int cout, int h, int w, int64_t workspace_by
         pl->wn = 8 / pl->wm;
         pl->ks = w <= 32 ? 2 : 4;
     }
-    const int wk = 8 / (pl->wm * pl->wn);
     const int sw = 16 * pl->ks;
     const int mt = 32 * pl->wm, nt = 32 * pl->wn;
     pl->co_tiles = sis_cdiv(cout, mt); pl->ci_tiles = sis_cdiv(cin, nt);
     pl->strips = sis_cdiv(w, sw);
-    const int64_t tile_bytes = (int64_t)9 * pl->co_tiles * mt * pl->ci_tiles * nt * 4 * wk;
+    const int64_t tile_bytes = (int64_t)9 * pl->co_tiles * mt * pl->ci_tiles * nt * 4;
     const int tiles = pl->co_tiles * pl->ci_tiles;
     // row blocks: enough workgroups to fill the chip (~2 per CU), at least 8 rows each, slabs within the workspace
     int rbk = 1;
@@ -263,7 +293,7 @@ bool wgrad_plan(int batch, int cin, int cout, int h, int w, int64_t workspace_by
     pl->rows_per_block = sis_cdiv(h, rbk);
     pl->row_blocks = sis_cdiv(h, pl->rows_per_block);
     pl->units = batch * pl->strips * pl->row_blocks;
-    pl->partials = pl->units * wk;
+    pl->partials = pl->units;
     pl->slab_bytes = (int64_t)pl->units * tile_bytes;
     return pl->slab_bytes <= workspace_bytes;
 }
@@ -320,7 +350,7 @@ extern "C" int sis_conv_bf16_wgrad(void* dw, int dw_dtype, const void* x, const 
     else rc = launch_wgrad<WgCfg<1, 1, 8>>(p, pl.units, st, "conv_wgrad_bf16_kernel<1,1,8>");
     if (rc) return rc;
     const int mt = 32 * pl.wm, nt = 32 * pl.wn;
-    const int blocks = sis_cdiv((int64_t)cout * cin, 256);
+    const int blocks = 9 * cout * sis_cdiv(cin, 64);
     if (dw_dtype == SIS_F32)
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (float*)dw, (const float*)workspace,
                            pl.partials, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt);
