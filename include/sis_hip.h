@@ -172,9 +172,11 @@ int sis_upsample_ce_bwd(float* grad_logits, const float* grad_loss, const float*
                         int out_w, int64_t ignore_index, void* stream);
 
 /* torch.optim.SGD(momentum, dampening 0, no nesterov) for every tensor of an optimizer in one launch
- * (training_builder/ema_net_train_builder.py:27-48).  `table` is a device array of n_chunks rows of four
- * int64: {param ptr, grad ptr, momentum-buffer ptr, count | (group << 48)}, count <= sis_sgd_chunk_elems().
- *   d = grad + wd[group]*p;  buf = first_step ? d : momentum*buf + d;  p -= lr[group]*buf
+ * (training_builder/ema_net_train_builder.py:27-48).  `table` is a device array of n_chunks rows of FIVE
+ * int64: {param ptr, grad ptr, momentum-buffer ptr, count | (group << 48), bf16 shadow ptr or 0}, count <=
+ * sis_sgd_chunk_elems().
+ *   d = grad + wd[group]*p;  buf = first_step ? d : momentum*buf + d;  p -= lr[group]*buf;  shadow = bf16(p) if given
+ * (the shadow is the bfloat16 copy of the fp32 master weight that bf16 layers read: no per-forward cast kernels)
  * lr / weight_decay are HOST arrays of n_groups (<= 4) floats. */
 int sis_sgd_chunk_elems(void);
 int sis_sgd_momentum(const int64_t* table, int n_chunks, const float* lr, const float* weight_decay,

@@ -134,16 +134,19 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(float* __restrict__ gx, con
 }
 
 // ---- multi-tensor SGD ----------------------------------------------------------------------
-// table: one row of 4 int64 per chunk: {param ptr, grad ptr, momentum-buffer ptr, count | group << 48}
+// table: one row of 5 int64 per chunk: {param ptr, grad ptr, momentum-buffer ptr, count | group << 48, bf16 shadow ptr | 0}
+// The optional shadow is a bfloat16 copy of the parameter kept current by this very launch: layers that compute in bf16
+// (TransUNet's encoder Linear layers under autocast) read it instead of casting the fp32 master weight every forward.
 constexpr int SGD_CHUNK = 65536;
 struct SgdGroups { float lr[4], wd[4]; float momentum; int first; };
 
 __global__ __launch_bounds__(256) void sgd_kernel(const int64_t* __restrict__ table, SgdGroups g) {
-    const int64_t* row = table + (int64_t)blockIdx.x * 4;
+    const int64_t* row = table + (int64_t)blockIdx.x * 5;
     float* __restrict__ p = reinterpret_cast<float*>(row[0]);
     const float* __restrict__ gr = reinterpret_cast<const float*>(row[1]);
     float* __restrict__ buf = reinterpret_cast<float*>(row[2]);
     const int n = (int)(row[3] & 0xffffffffll), grp = (int)(row[3] >> 48);
+    __hip_bfloat16* __restrict__ shadow = reinterpret_cast<__hip_bfloat16*>(row[4]);
     const float lr = g.lr[grp], wd = g.wd[grp];
     for (int i = threadIdx.x; i < n; i += 256) {
         const float pv = p[i];
@@ -151,18 +154,21 @@ __global__ __launch_bounds__(256) void sgd_kernel(const int64_t* __restrict__ ta
         if (wd != 0.f) d += wd * pv;
         const float bv = g.first ? d : g.momentum * buf[i] + d;
         buf[i] = bv;
-        p[i] = pv - lr * bv;
+        const float pn = pv - lr * bv;
+        p[i] = pn;
+        if (shadow) shadow[i] = __float2bfloat16(pn);
     }
 }
 
 // Same update with the hyper-parameters read from device memory: hyper = {lr[4], wd[4], momentum}.  Nothing but
 // pointers in the kernel arguments, so a captured launch (hipGraph) follows the LR schedule on replay.
 __global__ __launch_bounds__(256) void sgd_dev_kernel(const int64_t* __restrict__ table, const float* __restrict__ hyper) {
-    const int64_t* row = table + (int64_t)blockIdx.x * 4;
+    const int64_t* row = table + (int64_t)blockIdx.x * 5;
     float* __restrict__ p = reinterpret_cast<float*>(row[0]);
     const float* __restrict__ gr = reinterpret_cast<const float*>(row[1]);
     float* __restrict__ buf = reinterpret_cast<float*>(row[2]);
     const int n = (int)(row[3] & 0xffffffffll), grp = (int)(row[3] >> 48);
+    __hip_bfloat16* __restrict__ shadow = reinterpret_cast<__hip_bfloat16*>(row[4]);
     const float lr = hyper[grp], wd = hyper[4 + grp], momentum = hyper[8];
     for (int i = threadIdx.x; i < n; i += 256) {
         const float pv = p[i];
@@ -170,7 +176,9 @@ __global__ __launch_bounds__(256) void sgd_dev_kernel(const int64_t* __restrict_
         if (wd != 0.f) d += wd * pv;
         const float bv = momentum * buf[i] + d;
         buf[i] = bv;
-        p[i] = pv - lr * bv;
+        const float pn = pv - lr * bv;
+        p[i] = pn;
+        if (shadow) shadow[i] = __float2bfloat16(pn);
     }
 }
 

@@ -78,6 +78,91 @@ class _AmpLinearFn(Function):
 
 
 _AMP_LINEAR = os.environ.get('SIS_AMP_LINEAR', '1') != '0'
+_SHADOW = os.environ.get('SIS_LINEAR_SHADOW', '1') != '0'  # 0: cast (and concatenate) the fp32 weights every forward
+
+
+class _Bf16Shadow:
+    """bfloat16 copy of one or several fp32 parameters concatenated along dim 0 (query | key | value of an attention
+    block: ONE [3 hidden, hidden] GEMM operand without a per-forward ``torch.cat`` + cast).
+
+    Who keeps it current: ``FusedSGD`` when the copy is registered there (``bind``): the optimizer launch that updates the
+    fp32 master weights writes the rounded values into the copy as well.  Otherwise (plain ``torch.optim`` steps,
+    ``load_state_dict``, a FusedSGD the copy was never registered with) the copy is refreshed here whenever a parameter's
+    ``_version`` -- or the raw-update counter FusedSGD bumps, since its kernel writes bypass ``_version`` -- has moved."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        self.buf = None
+        self.key = None
+        self.bound = None  # the buffer object FusedSGD writes into
+
+    def _key(self):
+        if self.bound is not None and self.bound is self.buf:
+            return tuple(p._version for p in self.params)  # raw optimizer updates are mirrored into the copy by the optimizer
+        return tuple((p._version, getattr(p, '_sis_raw_updates', 0)) for p in self.params)
+
+    def tensor(self):
+        first = self.params[0]
+        if self.buf is None or self.buf.device != first.device:
+            rows = sum(p.shape[0] for p in self.params)
+            self.buf = torch.empty((rows,) + tuple(first.shape[1:]), dtype=torch.bfloat16, device=first.device)
+            self.key = None
+        key = self._key()
+        if key != self.key:
+            with torch.no_grad():
+                row = 0
+                for p in self.params:
+                    self.buf[row:row + p.shape[0]].copy_(p)
+                    row += p.shape[0]
+            self.key = key
+        return self.buf
+
+    def bind(self, optimizer):
+        buf = self.tensor()
+        row = 0
+        for p in self.params:
+            optimizer.register_shadow(p, buf[row:row + p.shape[0]])
+            row += p.shape[0]
+        self.bound = buf
+        self.key = self._key()
+
+
+class _ShadowLinearFn(Function):
+    """y = x W^T + b with W / b taken from bf16 shadow copies (``_Bf16Shadow``) of ``n`` fp32 weights / biases stacked
+    along the output axis; the gradients go to the fp32 parameters: dW as ONE bf16 x bf16 -> float32 GEMM, split by rows
+    (views, no copies), d(bias) by the column-sum kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w_lp, b_lp, n, *params):
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(x2, w_lp)
+        ctx.x_shape, ctx.n = x.shape, n
+        ctx.rows = [p.shape[0] for p in params[:n]]
+        return torch.addmm(b_lp, x2, w_lp.t()).view(*x.shape[:-1], w_lp.shape[0])
+
+    @staticmethod
+    def backward(ctx, grad):
+        x2, w_lp = ctx.saved_tensors
+        g2 = grad.reshape(-1, grad.shape[-1])
+        if g2.dtype != x2.dtype:
+            g2 = g2.to(x2.dtype)
+        g2 = g2.contiguous()
+        dx = torch.mm(g2, w_lp).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        dws = dbs = [None] * ctx.n
+        if any(ctx.needs_input_grad[4:4 + ctx.n]):
+            dws = list(torch.mm(g2.t(), x2, out_dtype=torch.float32).split(ctx.rows, 0))
+        if any(ctx.needs_input_grad[4 + ctx.n:]):
+            dbs = list(sis_hip.column_sum(g2).split(ctx.rows, 0))
+        return (dx, None, None, None, *dws, *dbs)
+
+
+def shadow_linear(x, w_shadow, b_shadow, weights, biases):
+    """``linear`` over stacked parameters through their bf16 shadows; None when the fast path does not apply."""
+    if not (_SHADOW and _AMP_LINEAR and x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.bfloat16
+            and torch.get_autocast_dtype('cuda') == torch.bfloat16 and x.is_contiguous()
+            and all(w.dtype == torch.float32 and w.is_cuda for w in weights) and sum(w.shape[0] for w in weights) % 4 == 0):
+        return None
+    return _ShadowLinearFn.apply(x, w_shadow.tensor(), b_shadow.tensor(), len(weights), *weights, *biases)
 
 
 def linear(x, weight, bias):
@@ -117,6 +202,32 @@ class Attention(nn.Module):
         self.attn_dropout = Dropout(config.transformer["attention_dropout_rate"])
         self.proj_dropout = Dropout(config.transformer["attention_dropout_rate"])
         self.softmax = Softmax(dim=-1)
+        self._lp = None  # bf16 shadows of (query | key | value) and out, built on first use (not part of the state_dict)
+
+    def _shadows(self):
+        if self._lp is None or self._lp[0].params[0] is not self.query.weight:
+            self._lp = (_Bf16Shadow([self.query.weight, self.key.weight, self.value.weight]),
+                        _Bf16Shadow([self.query.bias, self.key.bias, self.value.bias]),
+                        _Bf16Shadow([self.out.weight]), _Bf16Shadow([self.out.bias]))
+        return self._lp
+
+    def register_weight_shadows(self, optimizer):
+        """Called by the train builder: the fused optimizer keeps the bf16 copies current from now on."""
+        if _SHADOW and self.query.weight.is_cuda:
+            for sh in self._shadows():
+                sh.bind(optimizer)
+
+    def __deepcopy__(self, memo):  # the encoder deep-copies a prototype block: copies must not share shadow objects
+        lp, self._lp = self._lp, None
+        try:
+            cls = self.__class__
+            new = cls.__new__(cls)
+            memo[id(self)] = new
+            for k, v in self.__dict__.items():
+                setattr(new, k, copy.deepcopy(v, memo))
+            return new
+        finally:
+            self._lp = lp
 
     def transpose_for_scores(self, x):
         b, n, _ = x.shape
@@ -125,8 +236,12 @@ class Attention(nn.Module):
     def forward(self, hidden_states):
         # one [hidden -> 3 * hidden] GEMM instead of three (the parameters stay separate, as in the reference's
         # checkpoints): 8192 x 768 x 768 products run the bf16 matrix cores at ~7 % of peak, the fused one is 3x larger
-        qkv = linear(hidden_states, torch.cat([self.query.weight, self.key.weight, self.value.weight], 0),
-                     torch.cat([self.query.bias, self.key.bias, self.value.bias], 0))
+        lp = self._shadows()
+        qkv = shadow_linear(hidden_states, lp[0], lp[1], [self.query.weight, self.key.weight, self.value.weight],
+                            [self.query.bias, self.key.bias, self.value.bias])
+        if qkv is None:
+            qkv = linear(hidden_states, torch.cat([self.query.weight, self.key.weight, self.value.weight], 0),
+                         torch.cat([self.query.bias, self.key.bias, self.value.bias], 0))
         q, k, v = (self.transpose_for_scores(t) for t in qkv.split(self.all_head_size, dim=-1))
         weights = None
         if self.vis or (self.training and self.attn_dropout.p > 0):
@@ -138,7 +253,10 @@ class Attention(nn.Module):
             context = F.scaled_dot_product_attention(q, k, v)
         b, _, n, _ = context.shape
         context = context.permute(0, 2, 1, 3).reshape(b, n, self.all_head_size)
-        return self.proj_dropout(linear(context, self.out.weight, self.out.bias)), weights
+        out = shadow_linear(context, lp[2], lp[3], [self.out.weight], [self.out.bias])
+        if out is None:
+            out = linear(context, self.out.weight, self.out.bias)
+        return self.proj_dropout(out), weights
 
 
 class Mlp(nn.Module):
@@ -151,10 +269,28 @@ class Mlp(nn.Module):
         for fc in (self.fc1, self.fc2):
             nn.init.xavier_uniform_(fc.weight)
             nn.init.normal_(fc.bias, std=1e-6)
+        self._lp = None
+
+    def _shadows(self):
+        if self._lp is None or self._lp[0].params[0] is not self.fc1.weight:
+            self._lp = tuple(_Bf16Shadow([t]) for t in (self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias))
+        return self._lp
+
+    def register_weight_shadows(self, optimizer):
+        if _SHADOW and self.fc1.weight.is_cuda:
+            for sh in self._shadows():
+                sh.bind(optimizer)
+
+    __deepcopy__ = Attention.__deepcopy__
+
+    def _fc(self, x, i, fc):
+        lp = self._shadows()
+        y = shadow_linear(x, lp[2 * i], lp[2 * i + 1], [fc.weight], [fc.bias])
+        return y if y is not None else linear(x, fc.weight, fc.bias)
 
     def forward(self, x):
-        hidden = self.dropout(self.act_fn(linear(x, self.fc1.weight, self.fc1.bias)))
-        return self.dropout(linear(hidden, self.fc2.weight, self.fc2.bias))
+        hidden = self.dropout(self.act_fn(self._fc(x, 0, self.fc1)))
+        return self.dropout(self._fc(hidden, 1, self.fc2))
 
 
 class Embeddings(nn.Module):

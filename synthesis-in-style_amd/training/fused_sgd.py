@@ -39,7 +39,16 @@ class FusedSGD(Optimizer):
         self._hyper = None        # device float32[9]: lr[4], wd[4], momentum (capturable step)
         self._hyper_hosts = None  # pinned staging ring + the events guarding its reuse
         self._capture_host = None  # pinned source of the pointer-table copy recorded in a captured step
+        self._shadows = {}         # parameter -> bfloat16 copy this optimizer keeps current (register_shadow)
 
+    def register_shadow(self, param, shadow):
+        """``shadow``: a contiguous bfloat16 tensor (may be a slice of a larger buffer) with ``param``'s element count and
+        current value.  Every step rewrites it with the rounded new parameter in the SAME launch that updates the fp32
+        master weight, so bf16 layers (TransUNet's encoder Linear layers under autocast) never launch a cast."""
+        if shadow.dtype != torch.bfloat16 or not shadow.is_contiguous() or shadow.numel() != param.numel():
+            raise ValueError("shadow must be a contiguous bfloat16 tensor of the parameter's size")
+        self._shadows[param] = shadow
+        self._grad_key = None  # the pointer table gains a column entry
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)
 
@@ -61,9 +70,9 @@ class FusedSGD(Optimizer):
         # event recorded behind its last copy and is only rewritten after that event (as push_hyper() does)
         device = entries[0][1].device
         self._on_gpu = device.type == 'cuda'  # (host-only runs exist for the gloo rehearsal of the bucket aliasing logic)
-        self._hosts = [[self._staging((self._n_chunks, 4)), None] for _ in range(4)]
+        self._hosts = [[self._staging((self._n_chunks, 5)), None] for _ in range(4)]
         self._flip = 0
-        self._table = torch.empty((self._n_chunks, 4), dtype=torch.int64, device=device)
+        self._table = torch.empty((self._n_chunks, 5), dtype=torch.int64, device=device)
 
     def _staging(self, shape):
         host = torch.empty(shape, dtype=torch.int64)
@@ -78,7 +87,7 @@ class FusedSGD(Optimizer):
             self._hyper_hosts = [[torch.zeros(9, dtype=torch.float32).pin_memory(), None] for _ in range(4)]
             self._hyper_slot = 0
         if self._table is not None and (self._capture_host is None or self._capture_host.shape[0] != self._n_chunks):
-            self._capture_host = torch.empty((self._n_chunks, 4), dtype=torch.int64).pin_memory()
+            self._capture_host = torch.empty((self._n_chunks, 5), dtype=torch.int64).pin_memory()
         self._hyper_slot = (self._hyper_slot + 1) % len(self._hyper_hosts)
         slot = self._hyper_hosts[self._hyper_slot]
         if slot[1] is not None:
@@ -93,6 +102,7 @@ class FusedSGD(Optimizer):
 
     def _upload(self, entries, capturing=False):
         ptrs = np.asarray([(p.data_ptr(), g.data_ptr(), b.data_ptr()) for _, p, g, b in entries], dtype=np.int64)
+        shadow = np.asarray([self._shadows[p].data_ptr() if p in self._shadows else 0 for _, p, _, _ in entries], dtype=np.int64)
         if capturing:
             # the captured copy node re-reads its source on every replay: it gets a buffer nothing else writes
             # (allocated by push_hyper(): pinning memory is not allowed while a stream is capturing)
@@ -106,6 +116,8 @@ class FusedSGD(Optimizer):
         host = pinned.numpy()
         host[:, :3] = ptrs[self._owner] + self._offset[:, None]
         host[:, 3] = self._count
+        sh = shadow[self._owner]
+        host[:, 4] = np.where(sh != 0, sh + self._offset // 2, 0)  # bf16 elements: half the byte offset of the fp32 chunk
         self._table.copy_(pinned, non_blocking=True)
         if slot is not None and self._on_gpu:
             slot[1] = torch.cuda.current_stream(self._table.device).record_event()
@@ -142,6 +154,10 @@ class FusedSGD(Optimizer):
         capturing = self._on_gpu and torch.cuda.is_current_stream_capturing()
         if capturing and (fresh or self._hyper is None or self._capture_host is None):
             raise RuntimeError("FusedSGD: capture needs one eager step() and a push_hyper() call first")
+        for _, p, _, _ in entries:
+            # the update below bypasses torch's version counter: modules caching derived tensors (bf16 shadows that are
+            # NOT registered here) watch this counter next to ``param._version``
+            p._sis_raw_updates = getattr(p, '_sis_raw_updates', 0) + 1
         grad_key = tuple(g.data_ptr() for _, _, g, _ in entries) + tuple(p.data_ptr() for _, p, _, _ in entries)
         if grad_key != self._grad_key or capturing:
             self._upload(entries, capturing)

@@ -113,7 +113,14 @@ class BaseTrainBuilder:
     def get_optimizers(self) -> Dict:
         if self._optimizers is None:
             groups = self.parameter_groups(strip_parallel_module(self.segmentation_network))
-            self._optimizers = {'main': FusedSGD(groups, **self.optimizer_defaults())}
+            optimizer = FusedSGD(groups, **self.optimizer_defaults())
+            # layers holding bf16 copies of their fp32 weights (TransUNet's encoder Linear layers) hand them to the
+            # optimizer: its one launch per step then writes master weight and copy together
+            for module in strip_parallel_module(self.segmentation_network).modules():
+                register = getattr(module, 'register_weight_shadows', None)
+                if register is not None:
+                    register(optimizer)
+            self._optimizers = {'main': optimizer}
         return self._optimizers
 
     def get_updater(self):

@@ -121,7 +121,7 @@ def _host_sgd_kernel(table, n_chunks, lrs, wds, momentum, first_step):
     import ctypes
     import numpy as np
     rows = table.numpy()
-    for p_ptr, g_ptr, b_ptr, packed in rows[:n_chunks]:
+    for p_ptr, g_ptr, b_ptr, packed, _shadow in rows[:n_chunks]:
         n, gi = int(packed) & ((1 << 48) - 1), int(packed) >> 48
         view = lambda ptr: np.ctypeslib.as_array((ctypes.c_float * n).from_address(int(ptr)))  # noqa: E731
         p, g, b = view(p_ptr), view(g_ptr), view(b_ptr)

@@ -13,12 +13,15 @@ pytestmark = pytest.mark.gpu
 
 
 def _vit_like(sd, scale):
-    """Linear weights of the encoder scaled to the ViT initialisation's 0.02 standard deviation (the oracle's seeded stream
-    draws them at 0.05: attention scores of standard deviation ~2 after the 1/8, where one bf16 rounding of q and k moves
-    the softmax weights by several percent -- DESIGN.md §2)."""
+    """Well-conditioned variant of the seeded state: the last GroupNorm of every residual branch of the ResNetV2 trunk
+    (gn3) scaled by ``scale`` -- the usual small / zero initialisation of residual branches, the regime trained networks
+    live in.  With the oracle's plain random stream the 16-unit trunk is CHAOTIC: in pure fp32 on the CPU oracle a 0.4 %
+    perturbation of the input image grows 1.25x per unit to 26 % at the trunk's output (tools/bf16_drift.py on the GPU, the
+    same experiment on oracle/trans_u_net_ref.py on the host), so any rounding at all decorrelates single activations
+    while losses and gradient norms stay put.  scale 0.1 brings the growth down to ~1 % end to end."""
     if scale != 1.0:
         for k in sd:
-            if k.startswith("transformer.encoder.layer.") and k.endswith(".weight") and (".attn." in k or ".ffn.fc" in k):
+            if ".gn3." in k:
                 sd[k] = sd[k] * scale
     return sd
 
@@ -93,11 +96,11 @@ def test_trans_u_net_512_shapes(device):
 # weights, fp32 losses and SGD.  The stated tolerance of that path against the fp32 oracle, set at about
 # twice the deviations measured on MI355X (gpurun_out/transunet_bf16_parity_*.json keeps the measured values):
 #
-# The random-initialised fixture amplifies bf16 rounding far beyond one layer's 2^-9: attention scores have a standard
-# deviation of ~15 before the 1/8 scaling, so a 0.4 % rounding of q and k moves softmax weights by several percent, and
-# 12 such blocks feed a decoder of batch-normalised 3x3 convolutions.  The fp32 control below (the SAME product path
-# without autocast, same state, same batch) pins the kernels themselves three orders of magnitude tighter, so the
-# bf16 numbers are rounding, not arithmetic errors.  Aggregates (losses, gradient norms) agree far better than elements.
+# Fixture: the seeded state with small residual branches (``_vit_like``: gn3 x 0.1).  On the oracle's plain random stream
+# the trunk is chaotic -- a 0.4 % input perturbation becomes 26 % at its output in pure fp32 -- and element-wise
+# comparisons of ANY two arithmetics are meaningless there (that state is still run and recorded: losses, the fp32
+# control and the no-flip-beyond-margin rule must hold on it too).  The fp32 control (the SAME product path without
+# autocast) pins the kernels themselves three orders of magnitude tighter than the bf16 numbers.
 BF16_LOSS_RTOL = 2e-3          # combined / CE / Dice loss of an iteration                       (measured <= 3e-4)
 BF16_LOGITS_REL_L2 = 0.30      # ||logits - ref||_2 / ||ref||_2 over the whole map                (measured 0.18)
 BF16_LOGITS_MAX = 0.30         # worst single logit of 1.5 M, in units of max|ref|                (measured 0.15)
@@ -179,13 +182,13 @@ def test_trans_u_net_bf16_512_two_iterations_vs_fp32_oracle(device):
     """configs[4] geometry (512^2, R50-ViT-B/16, bf16 autocast, B = 2 of the 8): two TransUNetUpdater iterations against
     the fp32 oracle on the same seeded state and batches, within the stated bf16 tolerance."""
     import json
-    harsh = _bf16_two_iterations(device, 512, 2, wseed=3, bseed=40, lr=1e-4)  # the oracle's 0.05-scale stream: recorded, see above
+    harsh = _bf16_two_iterations(device, 512, 2, wseed=3, bseed=40, lr=1e-4)  # the chaotic plain stream: recorded, see _vit_like
     os.makedirs("gpurun_out", exist_ok=True)
     with open(os.path.join("gpurun_out", "transunet_bf16_parity_512_harsh.json"), "w") as f:
         json.dump(harsh, f, indent=1)
     assert harsh["fp32_control_logits_rel_l2"] < FP32_CONTROL_REL_L2 and max(harsh["loss0"] + harsh["loss1"]) < BF16_LOSS_RTOL
     assert harsh["label_mismatches_where_decided"] == 0
-    _check_bf16_report(_bf16_two_iterations(device, 512, 2, wseed=3, bseed=40, lr=1e-4, linear_scale=0.4), "512")
+    _check_bf16_report(_bf16_two_iterations(device, 512, 2, wseed=3, bseed=40, lr=1e-4, linear_scale=0.1), "512")
 
 
 def test_trans_u_net_bf16_224_vs_golden(device, golden_dir):
@@ -210,3 +213,51 @@ def test_trans_u_net_bf16_224_vs_golden(device, golden_dir):
     ce = torch.nn.functional.cross_entropy(pred, gt)
     dice = DiceLoss(classes)(pred, gt, softmax=True)
     np.testing.assert_allclose([(0.5 * ce + 0.5 * dice).item(), ce.item(), dice.item()], g["losses"], rtol=BF16_LOSS_RTOL)
+
+
+def test_linear_bf16_shadows_follow_the_master_weights(device):
+    """The encoder's Linear layers read bf16 copies of their fp32 weights; once registered with FusedSGD the copies are
+    written by the optimizer launch itself (csrc/seg_ops.hip sgd kernels, 5th table column).  After eager iterations AND
+    hipGraph replays every copy must equal the rounding of its master weight bit for bit -- exactly what a per-forward
+    cast would have produced -- and an out-of-band parameter change must be picked up."""
+    from networks.trans_u_net import vit_seg_configs
+    from networks.trans_u_net.vit_encoder import Attention, Mlp
+    from networks.trans_u_net.vit_seg_modeling import VisionTransformer
+    from training.fused_sgd import FusedSGD
+    from updater.segmentation_updater import TransUNetUpdater
+    cfg = vit_seg_configs.get_r50_b16_config()
+    cfg.hidden_size, cfg.transformer.mlp_dim, cfg.transformer.num_heads, cfg.transformer.num_layers = 64, 128, 4, 2
+    cfg.transformer.dropout_rate = 0.0
+    cfg.resnet.num_layers = (1, 1, 1)
+    cfg.n_classes, cfg.n_skip, cfg.patches.grid = 3, 3, (4, 4)
+    torch.manual_seed(0)
+    net = VisionTransformer(cfg, img_size=64, num_classes=3).to(device).train()
+    opt = FusedSGD(list(net.parameters()), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    holders = [m for m in net.modules() if isinstance(m, (Attention, Mlp))]
+    assert len(holders) == 4
+    for m in holders:
+        m.register_weight_shadows(opt)
+    batches = [E.seeded_batch(2, 64, 3, seed=70 + i) for i in range(6)]
+    upd = TransUNetUpdater(num_classes=3, amp="bf16", iterators={"images": batches}, networks={"segmentation": net},
+                           optimizers={"main": opt}, device=device)
+
+    def check():
+        torch.cuda.synchronize()
+        for m in holders:
+            for sh in m._lp:
+                assert sh.bound is sh.buf
+                assert torch.equal(sh.buf, torch.cat([p.detach() for p in sh.params], 0).bfloat16())
+
+    before = net.transformer.encoder.layer[0].ffn.fc1.weight.detach().clone()
+    for _ in range(2):
+        upd.update()  # eager
+    check()
+    for _ in range(3):
+        upd.update()  # capture + replays
+    assert upd._step_graph.graph is not None
+    check()
+    assert not torch.equal(before, net.transformer.encoder.layer[0].ffn.fc1.weight)
+    with torch.no_grad():  # out-of-band change: picked up through the version counter at the next use
+        net.transformer.encoder.layer[1].attn.key.weight.mul_(0.5)
+    sh = net.transformer.encoder.layer[1].attn._lp[0]
+    assert torch.equal(sh.tensor(), torch.cat([p.detach() for p in sh.params], 0).bfloat16())

@@ -22,7 +22,12 @@ def main():
     cfg.patches.grid = (32, 32)
     cfg.transformer.dropout_rate = 0.0
     net = VisionTransformer(cfg, img_size=512, num_classes=3)
-    net.load_state_dict(T.seeded_state_dict(512, 3, seed=3), strict=True)
+    sd = T.seeded_state_dict(512, 3, seed=3)
+    scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0  # residual-branch scale (tests/test_trans_u_net_gpu.py::_vit_like)
+    for k in sd:
+        if ".gn3." in k:
+            sd[k] = sd[k] * scale
+    net.load_state_dict(sd, strict=True)
     net = net.to(dev)
     net.train() if mode == "train" else net.eval()
     x = E.seeded_batch(2, 512, 3, seed=40)["images"].to(dev)
@@ -44,7 +49,10 @@ def main():
         with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
             net(x)
     print(f"{'module':60s} rel_l2   rms(ref)")
-    for name, (a, b) in store.items():
+    for name, outs in store.items():
+        if len(outs) != 2:
+            continue
+        a, b = outs
         if a.shape == b.shape:
             print(f"{name:60s} {((a - b).norm() / (a.norm() + 1e-20)).item():.4f}  {a.pow(2).mean().sqrt().item():.3g}")
 
