@@ -161,3 +161,48 @@ def test_label_and_encode_side_stream_is_bit_identical(device, monkeypatch):
         assert p1.dtype == torch.uint8 and torch.equal(p0, p1)
         for k in l0:
             assert torch.equal(l0[k], l1[k])
+
+
+def test_tensor_hand_off_equals_the_png_round_trip(device, tmp_path):
+    """the batch ``SynthesisSegmentationLoader`` hands to the trainer equals, bit for bit, what the
+    reference's PNG pipeline yields for the same sample: [image | label colours] PNG written as
+    create_dataset_for_segmentation.py:84-99 does, read back with PIL, split, ToTensor + Normalize(0.5, 0.5), colours ->
+    class ids, nearest resize (data/segmentation_dataset.py:44-63, restated here with numpy / PIL)."""
+    from PIL import Image
+    from data.device_dataset import SynthesisSegmentationLoader
+    from networks.stylegan2.model import Generator
+    from segmentation.gan_local_edit.factor_catalog import FactorCatalog
+    torch.manual_seed(4)
+    g = Generator(64, 64, 2, channel_multiplier=1).to(device).eval()
+    layer = 7  # [B, C, 32, 32]: the label map is resized to the image's 64 x 64
+    with torch.no_grad():
+        _, acts = g([torch.randn(1, 64, device=device)], return_intermediate_activations=True)
+    rng = np.random.RandomState(9)
+    catalogs = {layer: FactorCatalog(cluster_centers=rng.randn(6, acts[layer].shape[1]).astype(np.float32))}
+    class_of_cluster = torch.tensor([0, 1, 2, 1, 0, 2])
+    colours = np.array([[0, 0, 0], [255, 0, 0], [0, 0, 255]], dtype=np.uint8)  # class -> colour of the PNG's right half
+    loader = SynthesisSegmentationLoader(g, catalogs, layer, batch_size=3, class_of_cluster=class_of_cluster, image_size=64,
+                                         seed=11, num_batches=1)
+    torch.manual_seed(21)  # make_noise() draws from the device RNG
+    batch = next(iter(loader))
+    assert batch["images"].dtype == torch.float32 and tuple(batch["images"].shape) == (3, 3, 64, 64)
+    assert batch["segmented"].dtype == torch.int64 and tuple(batch["segmented"].shape) == (3, 1, 64, 64)
+    assert batch["images"].is_cuda and batch["images"].abs().max() <= 1
+    # the PNG path on the same sample
+    import sis_hip
+    torch.manual_seed(21)
+    z = torch.randn(3, 64, generator=torch.Generator().manual_seed(11)).to(device)
+    with torch.no_grad():
+        image, acts = g([z], noise=g.make_noise(), return_intermediate_activations=True)
+    rgb = sis_hip.make_image_u8(image).cpu().numpy()
+    classes = class_of_cluster[catalogs[layer].predict(acts[layer]).cpu()].numpy()
+    for i in range(3):
+        lab = colours[np.repeat(np.repeat(classes[i], 2, 0), 2, 1)]  # label image rendered at the image's resolution
+        Image.fromarray(np.concatenate([rgb[i], lab], axis=1)).save(tmp_path / f"{i}.png")
+        png = Image.open(tmp_path / f"{i}.png")
+        left = np.asarray(png.crop((0, 0, png.width // 2, png.height)))
+        right = np.asarray(png.crop((png.width // 2, 0, png.width, png.height)))
+        want_img = (torch.from_numpy(left.copy()).permute(2, 0, 1).float().div(255) - 0.5) / 0.5  # ToTensor + Normalize
+        want_cls = torch.from_numpy((right[..., None, :] == colours[None, None]).all(-1).argmax(-1))
+        assert torch.equal(batch["images"][i].cpu(), want_img)
+        assert torch.equal(batch["segmented"][i, 0].cpu(), want_cls)

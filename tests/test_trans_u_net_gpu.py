@@ -101,14 +101,19 @@ def test_trans_u_net_512_shapes(device):
 # comparisons of ANY two arithmetics are meaningless there (that state is still run and recorded: losses, the fp32
 # control and the no-flip-beyond-margin rule must hold on it too).  The fp32 control (the SAME product path without
 # autocast) pins the kernels themselves three orders of magnitude tighter than the bf16 numbers.
-BF16_LOSS_RTOL = 2e-3          # combined / CE / Dice loss of an iteration                       (measured <= 3e-4)
-BF16_LOGITS_REL_L2 = 0.30      # ||logits - ref||_2 / ||ref||_2 over the whole map                (measured 0.18)
-BF16_LOGITS_MAX = 0.30         # worst single logit of 1.5 M, in units of max|ref|                (measured 0.15)
-BF16_GRAD_NORM_RTOL = 0.20     # per-tensor gradient L2 norms, head + decoder (measured: convolutions <= 7e-3, norm scale / bias <= 0.11)
-BF16_GRAD_REL_L2 = 0.50        # ||g - g_ref|| / ||g_ref|| of the head / decoder convolution weight gradients
-BF16_LABEL_AGREEMENT = 0.85    # pixels whose argmax equals the fp32 oracle's (random-init logits: many near-ties; measured 0.92);
-#                                NO disagreement is allowed where the fp32 top-2 margin exceeds twice the measured max error
-FP32_CONTROL_REL_L2 = 2e-3     # the same path in fp32 against the oracle: logits relative L2
+# Stated tolerances = about twice the deviations measured on MI355X (gpurun_out/transunet_bf16_parity_512.json):
+BF16_LOSS_RTOL = 1e-3          # combined / CE / Dice loss of an iteration                       (measured <= 2.6e-4)
+BF16_LOGITS_REL_L2 = 0.08      # ||logits - ref||_2 / ||ref||_2 over the whole map                (measured 0.040)
+BF16_LOGITS_MAX = 0.08         # worst single logit of 1.5 M, in units of max|ref|                (measured 0.037)
+BF16_GRAD_NORM_RTOL = 0.08     # per-tensor gradient L2 norms, head + decoder                     (measured <= 0.033)
+BF16_GRAD_REL_L2 = 0.60        # ||g - g_ref|| / ||g_ref|| of the head / decoder convolution weight gradients: 0.001 at the
+#                                head, growing to 0.31 at conv_more -- every ReLU whose pre-activation moved across zero flips a
+#                                whole gradient element while the norms stay put
+BF16_LABEL_AGREEMENT = 0.96    # pixels whose argmax equals the fp32 oracle's (measured 0.981); NO disagreement is allowed
+#                                where the fp32 top-2 margin exceeds twice the measured max error (55 % of the pixels)
+FP32_CONTROL_REL_L2 = 1e-4     # the same product path in fp32 against the oracle: logits relative L2 (measured 1.0e-5 / 2.9e-5)
+# the plain (chaotic) stream, which the reference-made 224^2 golden uses: measured rel-L2 0.18, max 0.20, agreement 0.92
+HARSH_LOGITS_REL_L2, HARSH_LOGITS_MAX, HARSH_LABEL_AGREEMENT = 0.35, 0.40, 0.85
 
 
 def _bf16_two_iterations(device, size, batch, wseed, bseed, lr, linear_scale=1.0):
@@ -187,7 +192,7 @@ def test_trans_u_net_bf16_512_two_iterations_vs_fp32_oracle(device):
     with open(os.path.join("gpurun_out", "transunet_bf16_parity_512_harsh.json"), "w") as f:
         json.dump(harsh, f, indent=1)
     assert harsh["fp32_control_logits_rel_l2"] < FP32_CONTROL_REL_L2 and max(harsh["loss0"] + harsh["loss1"]) < BF16_LOSS_RTOL
-    assert harsh["label_mismatches_where_decided"] == 0
+    assert harsh["label_mismatches_where_decided"] == 0 and harsh["logits_rel_l2"] < HARSH_LOGITS_REL_L2
     _check_bf16_report(_bf16_two_iterations(device, 512, 2, wseed=3, bseed=40, lr=1e-4, linear_scale=0.1), "512")
 
 
@@ -202,12 +207,12 @@ def test_trans_u_net_bf16_224_vs_golden(device, golden_dir):
     pred = pred.float()
     scale = np.abs(g["logits_slice"]).max()
     diff = pred.detach()[:, :, ::8, ::8].cpu().numpy() - g["logits_slice"]
-    assert np.abs(diff).max() < BF16_LOGITS_MAX * scale
-    assert np.linalg.norm(diff) / np.linalg.norm(g["logits_slice"]) < BF16_LOGITS_REL_L2
+    assert np.abs(diff).max() < HARSH_LOGITS_MAX * scale
+    assert np.linalg.norm(diff) / np.linalg.norm(g["logits_slice"]) < HARSH_LOGITS_REL_L2
     labels = pred.argmax(1).cpu().numpy().astype(np.uint8)
-    decided = g["margin"].astype(np.float32) > 2 * BF16_LOGITS_MAX * scale
+    decided = g["margin"].astype(np.float32) > 2 * HARSH_LOGITS_MAX * scale
     assert (labels[decided] == g["labels"][decided]).all()
-    assert (labels == g["labels"]).mean() > BF16_LABEL_AGREEMENT
+    assert (labels == g["labels"]).mean() > HARSH_LABEL_AGREEMENT
     gt = b0["segmented"].squeeze(1).to(device)
     from networks.trans_u_net.utils import DiceLoss
     ce = torch.nn.functional.cross_entropy(pred, gt)
