@@ -348,6 +348,9 @@ int sis_conv_bf16_pack(void* packed, const void* weight, int weight_dtype, int c
                        int stride, int adjoint, void* stream);
 int sis_conv_bf16(void* y, const void* x, const void* packed, const float* bias, int batch, int cin, int cout, int h, int w,
                   int ksize, int stride, void* stream);
+/* forward and adjoint packing of a stride-1 layer's weight in one launch (training: both are needed every step) */
+int sis_conv_bf16_pack_both(void* packed, void* packed_adjoint, const void* weight, int weight_dtype, int cin, int cout, int h,
+                            int w, int ksize, void* stream);
 
 /* Weight gradient of a stride-1, padding-1 3x3 bf16 convolution (csrc/conv_bf16_wgrad.hip):
  * dw [cout][cin][3][3] (SIS_F32 or SIS_BF16) = sum_{n,y,x} grad_y[n][co][y][x] * x[n][ci][y+ky-1][x+kx-1], x / grad_y bf16

@@ -74,11 +74,14 @@ struct ConvParams {
 
 // ---------------------------------------------------------------------------------------------------- weight packing
 // w: [Mrole... see sis_conv_bf16_pack.  One thread per packed element.
+// (`out2` / `total2`: the adjoint packing of the same weight written by the same launch, MT2 = its M tile)
 template <typename T>
 __global__ __launch_bounds__(256) void conv_pack_kernel(u16* __restrict__ out, const T* __restrict__ w, int Cout, int Cin,
-                                                        int KH, int MT, int KC, int adjoint, int64_t total) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
+                                                        int KH, int MT, int KC, int adjoint, int64_t total,
+                                                        u16* __restrict__ out2, int MT2, int64_t total2) {
+    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total + total2) return;
+    if (e >= total) { e -= total; out = out2; MT = MT2; adjoint = 1; }
     const int taps = KH * KH, units = KC / 8;
     const int M = adjoint ? Cin : Cout, K = adjoint ? Cout : Cin;
     const int nchunks = K / KC;
@@ -160,12 +163,26 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_kernel(ConvParams p) {
                     for (int c = 0; c < 8; ++c) xr[i][c] = *reinterpret_cast<const uint2*>(g + (int64_t)c * plane);
                 } else {
                     const int mask = task_mask[i];
+                    if (mask == 15) {
+                        // odd planes / rows (127 x 127 maps): the 4 pixels start on any 2-byte boundary.  Three dword loads
+                        // from the address rounded down to 4 bytes, funnel-shifted by 16 bits when it was odd.
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const u16* gc = g + (int64_t)c * plane;
-                        const unsigned e0 = (mask & 1) ? gc[0] : 0, e1 = (mask & 2) ? gc[1] : 0;
-                        const unsigned e2 = (mask & 4) ? gc[2] : 0, e3 = (mask & 8) ? gc[3] : 0;
-                        xr[i][c] = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
+                        for (int c = 0; c < 8; ++c) {
+                            const u16* gc = g + (int64_t)c * plane;
+                            const bool odd = (reinterpret_cast<uintptr_t>(gc) & 2) != 0;
+                            const unsigned* d = reinterpret_cast<const unsigned*>(gc - (odd ? 1 : 0));
+                            const unsigned d0 = d[0], d1 = d[1], d2 = d[2];
+                            xr[i][c] = odd ? make_uint2(__builtin_amdgcn_alignbit(d1, d0, 16), __builtin_amdgcn_alignbit(d2, d1, 16))
+                                           : make_uint2(d0, d1);
+                        }
+                    } else {  // ragged group at a row end: element by element
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const u16* gc = g + (int64_t)c * plane;
+                            const unsigned e0 = (mask & 1) ? gc[0] : 0, e1 = (mask & 2) ? gc[1] : 0;
+                            const unsigned e2 = (mask & 4) ? gc[2] : 0, e3 = (mask & 8) ? gc[3] : 0;
+                            xr[i][c] = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
+                        }
                     }
                 }
             } else {
@@ -370,12 +387,34 @@ extern "C" int sis_conv_bf16_pack(void* packed, const void* weight, int weight_d
     const int blocks = sis_cdiv(total, 256);
     if (weight_dtype == SIS_F32)
         hipLaunchKernelGGL(conv_pack_kernel<float>, dim3(blocks), dim3(256), 0, st, (u16*)packed, (const float*)weight, cout, cin,
-                           ksize, pl.mt, pl.kc, adjoint, total);
+                           ksize, pl.mt, pl.kc, adjoint, total, (u16*)nullptr, 0, (int64_t)0);
     else if (weight_dtype == SIS_BF16)
         hipLaunchKernelGGL(conv_pack_kernel<__hip_bfloat16>, dim3(blocks), dim3(256), 0, st, (u16*)packed,
-                           (const __hip_bfloat16*)weight, cout, cin, ksize, pl.mt, pl.kc, adjoint, total);
+                           (const __hip_bfloat16*)weight, cout, cin, ksize, pl.mt, pl.kc, adjoint, total, (u16*)nullptr, 0, (int64_t)0);
     else
         return sis_fail("sis_conv_bf16_pack: weights must be float32 or bfloat16");
+    SIS_CHECK_LAUNCH("conv_pack_kernel");
+    return 0;
+}
+
+extern "C" int sis_conv_bf16_pack_both(void* packed, void* packed_adjoint, const void* weight, int weight_dtype, int cin, int cout,
+                                       int h, int w, int ksize, void* stream) {
+    SIS_REQUIRE(packed && packed_adjoint && weight, "sis_conv_bf16_pack_both: null pointer");
+    Plan pf, pa;
+    SIS_REQUIRE(conv_plan(1, cin, cout, h, w, ksize, 1, &pf) && conv_plan(1, cout, cin, h, w, ksize, 1, &pa) && pf.kc == pa.kc,
+                "sis_conv_bf16_pack_both: unsupported stride-1 layer %d->%d k%d", cin, cout, ksize);
+    const int64_t total = sis_conv_bf16_packed_elems(cin, cout, h, w, ksize, 1, 0);
+    const int64_t total2 = sis_conv_bf16_packed_elems(cin, cout, h, w, ksize, 1, 1);
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = sis_cdiv(total + total2, 256);
+    if (weight_dtype == SIS_F32)
+        hipLaunchKernelGGL(conv_pack_kernel<float>, dim3(blocks), dim3(256), 0, st, (u16*)packed, (const float*)weight, cout, cin,
+                           ksize, pf.mt, pf.kc, 0, total, (u16*)packed_adjoint, pa.mt, total2);
+    else if (weight_dtype == SIS_BF16)
+        hipLaunchKernelGGL(conv_pack_kernel<__hip_bfloat16>, dim3(blocks), dim3(256), 0, st, (u16*)packed,
+                           (const __hip_bfloat16*)weight, cout, cin, ksize, pf.mt, pf.kc, 0, total, (u16*)packed_adjoint, pa.mt, total2);
+    else
+        return sis_fail("sis_conv_bf16_pack_both: weights must be float32 or bfloat16");
     SIS_CHECK_LAUNCH("conv_pack_kernel");
     return 0;
 }

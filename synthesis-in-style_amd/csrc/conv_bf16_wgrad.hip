@@ -66,6 +66,17 @@ __device__ __forceinline__ uint4 load_chunk(const u16* row, int x0, int W, bool 
         if (x0 >= 0 && x0 + 8 <= W) v = *reinterpret_cast<const uint4*>(row + x0);
         return v;  // W % 8 == 0: a group is inside or outside as a whole
     }
+    if (x0 >= 0 && x0 + 8 <= W) {
+        // whole group inside the row but on an arbitrary 2-byte boundary (127-wide maps): five dword loads from the address
+        // rounded down to 4 bytes, funnel-shifted by 16 bits when it was odd
+        const u16* g = row + x0;
+        const bool odd = (reinterpret_cast<uintptr_t>(g) & 2) != 0;
+        const unsigned* d = reinterpret_cast<const unsigned*>(g - (odd ? 1 : 0));
+        const unsigned d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
+        return odd ? make_uint4(__builtin_amdgcn_alignbit(d1, d0, 16), __builtin_amdgcn_alignbit(d2, d1, 16),
+                                __builtin_amdgcn_alignbit(d3, d2, 16), __builtin_amdgcn_alignbit(d4, d3, 16))
+                   : make_uint4(d0, d1, d2, d3);
+    }
     unsigned e[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) e[j] = (x0 + j >= 0 && x0 + j < W) ? row[x0 + j] : 0u;

@@ -131,6 +131,100 @@ __global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(T* __restrict__ gx
     sis_st(gx, i, acc);
 }
 
+// Backward of the x2 case (oh = 2h, ow = 2w: every call of the TransUNet decoder), tiled through LDS: a workgroup owns an
+// 8 x 64 tile of grad_x of one plane.  The <= 22 x 144 grad_out window its footprint can touch arrives by 16-byte row loads
+// (coalesced; the gather kernel above issues up to 36 two-byte loads per input pixel and ran at ~0.6 TB/s), is reduced
+// along y with the row weights (8 x 144 partial sums in LDS), then along x.  Same fp32 weights as the gather kernel;
+// rows are summed before columns.
+constexpr int UB_TY = 8, UB_TX = 64, UB_OR = 2 * UB_TY + 6, UB_OC = 2 * UB_TX + 16;  // window rows / columns (8-aligned start)
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_up2_bwd_tiled_kernel(T* __restrict__ gx, const T* __restrict__ gout, int h, int w,
+                                                                     int oh, int ow, float sy, float sx, int tiles_x, int tiles_y) {
+    __shared__ float tile[UB_OR][UB_OC + 1];
+    __shared__ float tmp[UB_TY][UB_OC + 1];
+    __shared__ float wrow[UB_TY][UB_OR];
+    int b = blockIdx.x;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int64_t plane = b / tiles_y;
+    const int x0 = tx_i * UB_TX, y0 = ty_i * UB_TY;
+    const int oy0 = 2 * y0 - 3, ox0 = 2 * x0 - 8;  // first window row / column (ox0 is a multiple of 8)
+    const T* g = gout + plane * oh * (int64_t)ow;
+    // window -> LDS (fp32), zero outside the image
+    constexpr int GROUPS = UB_OC / 8;
+    for (int e = threadIdx.x; e < UB_OR * GROUPS; e += 256) {
+        const int r = e / GROUPS, cgrp = e % GROUPS;
+        const int oy = oy0 + r, ox = ox0 + 8 * cgrp;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        if (oy >= 0 && oy < oh && ox >= 0 && ox + 8 <= ow) {
+            const T* src = g + (int64_t)oy * ow + ox;
+            if constexpr (sizeof(T) == 2) {
+                const uint4 q = *reinterpret_cast<const uint4*>(src);
+                T t[8];
+                __builtin_memcpy(t, &q, 16);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = sis_ld(t, k);
+            } else {
+                const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[r][8 * cgrp + k] = v[k];
+    }
+    // row weights: wrow[ty][r] = weight of window row r for input row y0 + ty
+    for (int e = threadIdx.x; e < UB_TY * UB_OR; e += 256) {
+        const int ty = e / UB_OR, r = e % UB_OR;
+        const int oy = oy0 + r, y = y0 + ty;
+        float wgt = 0.f;
+        if (oy >= 0 && oy < oh && y < h) {
+            const Lerp1 ly = lerp1(oy, sy, h);
+            if (ly.i0 == y) wgt += ly.l0;
+            if (ly.i1 == y) wgt += ly.l1;
+        }
+        wrow[ty][r] = wgt;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < UB_TY * UB_OC; e += 256) {
+        const int ty = e / UB_OC, c = e % UB_OC;
+        // input row y0 + ty is touched by window rows 2 ty .. 2 ty + 5 (outputs 2y - 3 .. 2y + 2; all others have weight 0)
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc += wrow[ty][2 * ty + k] * tile[2 * ty + k][c];
+        tmp[ty][c] = acc;
+    }
+    __syncthreads();
+    const int ty = threadIdx.x >> 5, txl = (threadIdx.x & 31) * 2;
+    const int y = y0 + ty;
+    if (y >= h) return;
+    float out[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int x = x0 + txl + j;
+        float acc = 0.f;
+        if (x < w) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {  // outputs 2x - 3 .. 2x + 2
+                const int ox = 2 * x - 3 + k;
+                if (ox >= 0 && ox < ow) {
+                    const Lerp1 lx = lerp1(ox, sx, w);
+                    float wgt = 0.f;
+                    if (lx.i0 == x) wgt += lx.l0;
+                    if (lx.i1 == x) wgt += lx.l1;
+                    acc += wgt * tmp[ty][ox - ox0];
+                }
+            }
+        }
+        out[j] = acc;
+    }
+    T* dst = gx + (plane * h + y) * (int64_t)w + x0 + txl;
+    if (x0 + txl < w) sis_st(dst, 0, out[0]);
+    if (x0 + txl + 1 < w) sis_st(dst, 1, out[1]);
+}
+
 template <typename T>
 int launch_up(void* out, const void* x, int64_t planes, int h, int w, int oh, int ow, int backward, hipStream_t st) {
     const float sy = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.f;
@@ -141,6 +235,12 @@ int launch_up(void* out, const void* x, int64_t planes, int h, int w, int oh, in
         hipLaunchKernelGGL(bilinear_up_fwd_kernel<T>, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st,
                            (T*)out, (const T*)x, h, w, oh, ow, sy, sx, total4);
         SIS_CHECK_LAUNCH("bilinear_up_fwd_kernel");
+    } else if (oh == 2 * h && ow == 2 * w && ow % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+               planes * sis_cdiv(w, UB_TX) * sis_cdiv(h, UB_TY) < ((int64_t)1 << 31)) {
+        const int tiles_x = sis_cdiv(w, UB_TX), tiles_y = sis_cdiv(h, UB_TY);
+        hipLaunchKernelGGL(bilinear_up2_bwd_tiled_kernel<T>, dim3((unsigned)(planes * tiles_x * tiles_y)), dim3(256), 0, st,
+                           (T*)out, (const T*)x, h, w, oh, ow, sy, sx, tiles_x, tiles_y);
+        SIS_CHECK_LAUNCH("bilinear_up2_bwd_tiled_kernel");
     } else {  // out = grad_x [planes][h][w], x = grad_out [planes][oh][ow]
         const int64_t total = planes * h * w;
         hipLaunchKernelGGL(bilinear_up_bwd_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (T*)out,

@@ -193,16 +193,21 @@ class _ConvBf16Function(Function):
     @staticmethod
     def forward(ctx, input, weight, bias, stride):
         input = input.contiguous()
-        k = weight.shape[2]
-        packed = sis_hip.conv_bf16_pack(weight, input.shape[2], input.shape[3], stride)
-        ctx.save_for_backward(input, weight)
+        cout, cin, k, _ = weight.shape
+        h, w = input.shape[2], input.shape[3]
+        adjoint = None
+        if stride == 1 and ctx.needs_input_grad[0] and sis_hip.conv_bf16_supported(cout, cin, h, w, k, 1):
+            packed, adjoint = sis_hip.conv_bf16_pack_both(weight, h, w)  # one launch packs for forward AND data gradient
+        else:
+            packed = sis_hip.conv_bf16_pack(weight, h, w, stride)
+        ctx.save_for_backward(input, weight, adjoint)
         ctx.stride, ctx.has_bias = stride, bias is not None
-        return sis_hip.conv_bf16(input, packed, weight.shape[0], k, stride, bias)
+        return sis_hip.conv_bf16(input, packed, cout, k, stride, bias)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
-        input, weight = ctx.saved_tensors
+        input, weight, adjoint = ctx.saved_tensors
         b, cin, h, w = input.shape
         cout, _, k, _ = weight.shape
         s = ctx.stride
@@ -213,7 +218,9 @@ class _ConvBf16Function(Function):
         lib_weight = None
         if ctx.needs_input_grad[0]:
             if s == 1 and sis_hip.conv_bf16_supported(cout, cin, h, w, k, 1):
-                grad_input = sis_hip.conv_bf16(gy, sis_hip.conv_bf16_pack(weight, h, w, 1, adjoint=True), cin, k, 1)
+                if adjoint is None:
+                    adjoint = sis_hip.conv_bf16_pack(weight, h, w, 1, adjoint=True)
+                grad_input = sis_hip.conv_bf16(gy, adjoint, cin, k, 1)
             else:
                 lib_weight = weight if weight.dtype == torch.bfloat16 else weight.bfloat16()
                 grad_input = torch.ops.aten.convolution_backward(gy, input, lib_weight, None, (s, s), (k // 2, k // 2), (1, 1), False,

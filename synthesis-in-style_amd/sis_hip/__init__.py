@@ -81,6 +81,7 @@ _SIGNATURES = {
     "sis_conv_bf16_packed_elems": ([_i] * 7, _i64),
     "sis_conv_bf16_pack": ([_vp, _vp, _i] + [_i] * 7 + [_vp], _i),
     "sis_conv_bf16": ([_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp], _i),
+    "sis_conv_bf16_pack_both": ([_vp, _vp, _vp, _i] + [_i] * 5 + [_vp], _i),
     "sis_conv_bf16_wgrad_supported": ([_i] * 5 + [_i64], _i),
     "sis_conv_bf16_wgrad": ([_vp, _i, _vp, _vp] + [_i] * 5 + [_vp, _i64, _vp], _i),
 }
@@ -608,6 +609,22 @@ def conv_bf16_pack(weight, h, w, stride=1, adjoint=False):
         _check(lib().sis_conv_bf16_pack(_ptr(packed), _ptr(wt), _DTYPE_CODE[wt.dtype], cin, cout, h, w, k, stride,
                                         int(bool(adjoint)), _stream()), "sis_conv_bf16_pack")
     return packed
+
+
+def conv_bf16_pack_both(weight, h, w):
+    """Forward and adjoint packings of a stride-1 layer's weight from ONE launch -> (packed, packed_adjoint)."""
+    require_device(weight, "weight")
+    wt = weight.contiguous()
+    cout, cin, k, _ = wt.shape
+    n, na = (lib().sis_conv_bf16_packed_elems(cin, cout, h, w, k, 1, a) for a in (0, 1))
+    if wt.dtype not in (torch.float32, torch.bfloat16) or n < 0 or na < 0:
+        raise RuntimeError(f"conv_bf16_pack_both: unsupported layer {cin}->{cout} k{k} / dtype {wt.dtype}")
+    both = torch.empty(n + na, dtype=torch.bfloat16, device=wt.device)
+    packed, adjoint = both[:n], both[n:]
+    with torch.cuda.device(wt.device):
+        _check(lib().sis_conv_bf16_pack_both(_ptr(packed), _ptr(adjoint), _ptr(wt), _DTYPE_CODE[wt.dtype], cin, cout, h, w, k,
+                                             _stream()), "sis_conv_bf16_pack_both")
+    return packed, adjoint
 
 
 def conv_bf16(x, packed, cout, ksize, stride=1, bias=None):
