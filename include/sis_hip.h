@@ -360,6 +360,18 @@ int sis_conv_bf16_wgrad_supported(int batch, int cin, int cout, int h, int w, in
 int sis_conv_bf16_wgrad(void* dw, int dw_dtype, const void* x, const void* grad_y, int batch, int cin, int cout, int h, int w,
                         void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * fp32 pointwise (1x1, stride 1) convolution of the EMANet training step (csrc/conv1x1_f32.hip;
+ * networks/ema_net/network.py:24,29,106-107 Bottleneck conv1 / conv3 / downsample, :219-249 EMAU, :271-289 fc0 / fc1),
+ * exact fp32 on v_mfma_f32_32x32x2_f32, NCHW in and out.
+ *   data_gradient = 0:  y [batch][cout][hw] = weight [cout][cin] . x [batch][cin][hw] (+ bias[cout])
+ *   data_gradient = 1:  y = dL/dx [batch][cin][hw] = weight^T . x, x = dL/dy [batch][cout][hw] (the weight tensor itself is
+ *                       read as the k-major operand: no transposed copy)
+ * Contraction length % 32 == 0, output channels % 4 == 0, hw % 4 == 0, 16-byte aligned pointers. */
+int sis_conv1x1_f32_supported(int cin, int cout, int hw);
+int sis_conv1x1_f32(float* y, const float* x, const float* weight, const float* bias, int batch, int cin, int cout, int hw,
+                    int data_gradient, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

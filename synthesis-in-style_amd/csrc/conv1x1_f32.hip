@@ -1,0 +1,211 @@
+// fp32 pointwise (1x1, stride 1) convolution of the EMANet training step on the fp32 matrix cores, direct on NCHW
+// (reference call sites: networks/ema_net/network.py:24,29 Bottleneck conv1 / conv3, :106-107 downsample, :271-289 fc0 / fc1,
+// :219-249 EMAU conv1 / conv2), forward and data gradient.
+//
+//   y[n][m][p] = sum_k A[m][k] * x[n][k][p]          (forward: A = weight [Cout][Cin];  data gradient: A = weight^T)
+//
+// v_mfma_f32_32x32x2_f32 (exact fp32, one A and one B value per lane): the B operand is a row of the NCHW tensor
+// (lane = pixel), the A operand a row of the k-major weight image (lane = output channel) -- both conflict-free
+// ds_read_b32.  x rows arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, no registers).  The
+// weight chunk [32 k][MT m] is a plain row copy by LDS-DMA when the source is k-major (the data gradient reads the
+// weight tensor [Cout][Cin] as [k][m] directly); for the forward ([m][k] in memory) each lane loads one float4 of a
+// weight row and writes its four values down a column of the k-major image (lanes = consecutive m: conflict-free).
+// 32-channel chunks, double-buffered, ONE barrier per 64 MFMAs per wave.
+#include "sis_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int MT_, int NPIX_>
+struct PwCfg {
+    static constexpr int MT = MT_, NPIX = NPIX_, KC = 32;
+    static constexpr int WM = MT == 128 ? (NPIX == 256 ? 2 : 4) : 1;
+    static constexpr int WN = 8 / WM;
+    static constexpr int MB = MT / 32 / WM, NB = NPIX / 32 / WN;
+    static_assert(MB >= 1 && NB >= 1 && MB * WM * 32 == MT && NB * WN * 32 == NPIX, "wave layout");
+    static constexpr int A_FLOATS = KC * MT, X_FLOATS = KC * NPIX, STAGE = A_FLOATS + X_FLOATS;
+    static constexpr int LDS_BYTES = 2 * STAGE * 4;
+    static constexpr int X_PIECES = X_FLOATS * 4 / 1024;   // 1 KiB DMA pieces per chunk
+    static constexpr int A_PIECES = A_FLOATS * 4 / 1024;
+    static constexpr int A_VEC = A_FLOATS / 4 / 512;       // float4 loads per thread per chunk (register-staged weights)
+    static_assert(A_FLOATS % (4 * 512) == 0, "weight chunk must split evenly over the threads");
+};
+
+struct PwParams {
+    const float* x;     // [N][K][HW]
+    const float* a;     // A_KMAJOR: [K][Mtot], else [Mtot][K]
+    const float* bias;  // [Mtot] or null
+    float* y;           // [N][Mtot][HW]
+    int N, K, M, HW, px_tiles;
+};
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <typename C, bool A_KMAJOR>
+__global__ __launch_bounds__(512, 2) void conv1x1_f32_kernel(PwParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave % C::WM, wn = wave / C::WM;
+    const int n = blockIdx.x / p.px_tiles, pt = blockIdx.x % p.px_tiles;
+    const int p0 = pt * C::NPIX, m0 = blockIdx.y * C::MT;
+    const float* xin = p.x + (int64_t)n * p.K * p.HW;
+    const int nchunks = p.K / C::KC;
+
+    float4 areg[A_KMAJOR ? 1 : C::A_VEC];
+
+    auto dma_x = [&](int chunk, int stage) {
+        float* dst = lds + stage * C::STAGE + C::A_FLOATS;
+        for (int piece = wave; piece < C::X_PIECES; piece += 8) {
+            const int e = piece * 256 + lane * 4;          // float index inside the [KC][NPIX] chunk
+            const int row = e / C::NPIX, col = e % C::NPIX;
+            if (p0 + col + 3 < p.HW)
+                glds16(xin + (int64_t)(chunk * C::KC + row) * p.HW + p0 + col, dst + piece * 256);
+        }
+    };
+    auto dma_a = [&](int chunk, int stage) {  // k-major source: rows of Mtot floats
+        float* dst = lds + stage * C::STAGE;
+        for (int piece = wave; piece < C::A_PIECES; piece += 8) {
+            const int e = piece * 256 + lane * 4;
+            const int row = e / C::MT, col = e % C::MT;
+            if (m0 + col + 3 < p.M)
+                glds16(p.a + (int64_t)(chunk * C::KC + row) * p.M + m0 + col, dst + piece * 256);
+        }
+    };
+    auto load_a = [&](int chunk) {  // m-major source: thread -> (m = e % MT, k quad = e / MT)
+#pragma unroll
+        for (int i = 0; i < C::A_VEC; ++i) {
+            const int e = tid + i * 512;
+            const int m = e % C::MT, kq = e / C::MT;
+            areg[i] = (m0 + m < p.M) ? *reinterpret_cast<const float4*>(p.a + (int64_t)(m0 + m) * p.K + chunk * C::KC + 4 * kq)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_a = [&](int stage) {
+        float* dst = lds + stage * C::STAGE;
+#pragma unroll
+        for (int i = 0; i < C::A_VEC; ++i) {
+            const int e = tid + i * 512;
+            const int m = e % C::MT, kq = e / C::MT;
+            dst[(4 * kq + 0) * C::MT + m] = areg[i].x;
+            dst[(4 * kq + 1) * C::MT + m] = areg[i].y;
+            dst[(4 * kq + 2) * C::MT + m] = areg[i].z;
+            dst[(4 * kq + 3) * C::MT + m] = areg[i].w;
+        }
+    };
+
+    f32x16 acc[C::MB][C::NB];
+#pragma unroll
+    for (int mb = 0; mb < C::MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+    if constexpr (A_KMAJOR) dma_a(0, 0);
+    else { load_a(0); store_a(0); }
+    dma_x(0, 0);
+    __syncthreads();
+
+    const int a_off = h * C::MT + wm * (C::MB * 32) + r;                       // + kp * 2 * MT + mb * 32
+    const int b_off = C::A_FLOATS + h * C::NPIX + wn * (C::NB * 32) + r;       // + kp * 2 * NPIX + nb * 32
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int cur = chunk & 1;
+        const bool more = chunk + 1 < nchunks;
+        if (more) {
+            dma_x(chunk + 1, cur ^ 1);
+            if constexpr (A_KMAJOR) dma_a(chunk + 1, cur ^ 1);
+            else load_a(chunk + 1);
+        }
+        const float* st = lds + cur * C::STAGE;
+#pragma unroll
+        for (int kp = 0; kp < C::KC / 2; ++kp) {
+            float a[C::MB], b[C::NB];
+#pragma unroll
+            for (int mb = 0; mb < C::MB; ++mb) a[mb] = st[a_off + kp * 2 * C::MT + mb * 32];
+#pragma unroll
+            for (int nb = 0; nb < C::NB; ++nb) b[nb] = st[b_off + kp * 2 * C::NPIX + nb * 32];
+#pragma unroll
+            for (int mb = 0; mb < C::MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < C::NB; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+        }
+        if constexpr (!A_KMAJOR) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) store_a(cur ^ 1);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb) {
+        const int px = p0 + wn * (C::NB * 32) + nb * 32 + r;
+        if (px >= p.HW) continue;
+#pragma unroll
+        for (int mb = 0; mb < C::MB; ++mb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + wm * (C::MB * 32) + mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (m < p.M) {
+                    float v = acc[mb][nb][i];
+                    if (p.bias) v += p.bias[m];
+                    p.y[((int64_t)n * p.M + m) * p.HW + px] = v;
+                }
+            }
+    }
+}
+
+template <typename C>
+int launch_pw(const PwParams& p, int a_kmajor, hipStream_t st, const char* name) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_f32_kernel<C, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_f32_kernel<C, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return sis_fail("%s: cannot raise the LDS limit: %s", name, hipGetErrorString(e));
+        attr_set = true;
+    }
+    dim3 grid(p.N * p.px_tiles, sis_cdiv(p.M, C::MT));
+    if (a_kmajor) hipLaunchKernelGGL((conv1x1_f32_kernel<C, true>), grid, dim3(512), C::LDS_BYTES, st, p);
+    else hipLaunchKernelGGL((conv1x1_f32_kernel<C, false>), grid, dim3(512), C::LDS_BYTES, st, p);
+    SIS_CHECK_LAUNCH(name);
+    sis_kernel_name = name;
+    return 0;
+}
+
+bool pw_ok(int k, int m, int hw) { return k > 0 && m > 0 && hw > 0 && k % 32 == 0 && m % 4 == 0 && hw % 4 == 0; }
+
+}  // namespace
+
+extern "C" int sis_conv1x1_f32_supported(int cin, int cout, int hw) { return pw_ok(cin, cout, hw) && pw_ok(cout, cin, hw) ? 1 : 0; }
+
+extern "C" int sis_conv1x1_f32(float* y, const float* x, const float* weight, const float* bias, int batch, int cin, int cout,
+                               int hw, int data_gradient, void* stream) {
+    if (batch <= 0) return 0;
+    SIS_REQUIRE(y && x && weight, "sis_conv1x1_f32: null pointer");
+    // forward: contraction over cin, A = weight [cout][cin] (m-major).  data gradient: x is dL/dy [batch][cout][hw], the
+    // contraction runs over cout and A = the same weight tensor read as [k = cout][m = cin] (k-major); y is dL/dx.
+    PwParams p;
+    p.x = x; p.a = weight; p.bias = bias; p.y = y; p.N = batch; p.HW = hw;
+    p.K = data_gradient ? cout : cin;
+    p.M = data_gradient ? cin : cout;
+    SIS_REQUIRE(pw_ok(p.K, p.M, hw), "sis_conv1x1_f32: %d -> %d channels on %d pixels (K %% 32, M %% 4, pixels %% 4 must be 0)", p.K, p.M, hw);
+    SIS_REQUIRE((((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15) == 0, "sis_conv1x1_f32: pointers must be 16-byte aligned");
+    SIS_REQUIRE((int64_t)p.K * hw < (1LL << 31) && (int64_t)p.M * hw < (1LL << 31), "sis_conv1x1_f32: planes exceed 2^31 elements");
+    hipStream_t st = (hipStream_t)stream;
+    const int mt = p.M > 64 ? 128 : 64;
+    int npix = 256;
+    if (mt == 128 && (int64_t)batch * sis_cdiv(hw, 256) * sis_cdiv(p.M, 128) < 256) npix = 128;  // fill the 256 compute units
+    p.px_tiles = sis_cdiv(hw, npix);
+    if (mt == 128 && npix == 256) return launch_pw<PwCfg<128, 256>>(p, data_gradient, st, "conv1x1_f32_kernel<128,256>");
+    if (mt == 128) return launch_pw<PwCfg<128, 128>>(p, data_gradient, st, "conv1x1_f32_kernel<128,128>");
+    return launch_pw<PwCfg<64, 256>>(p, data_gradient, st, "conv1x1_f32_kernel<64,256>");
+}

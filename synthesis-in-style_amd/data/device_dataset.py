@@ -23,7 +23,10 @@ def encode_batch(pixels: torch.Tensor, labels: torch.Tensor, class_of_cluster: O
     (``images`` float32 [B,3,H,W] in [-1,1], ``segmented`` int64 [B,1,S,S]).  ``class_of_cluster`` [K] maps cluster ids to
     class ids (the reference's cluster -> class merge + colour map, applied as a lookup); ``image_size`` resizes the label
     map with nearest neighbours exactly as ``class_image_to_tensor`` does (segmentation_dataset.py:37-42)."""
-    images = pixels.permute(0, 3, 1, 2).to(torch.float32).div(255).sub(0.5).div(0.5).contiguous()
+    # divisors as tensors: ATen turns a division by a Python scalar into a multiplication by its reciprocal on the device,
+    # which is one ulp off the true division ToTensor performs on the host for some of the 256 byte values
+    d255 = torch.full((), 255.0, dtype=torch.float32, device=pixels.device)
+    images = pixels.permute(0, 3, 1, 2).to(torch.float32).div(d255).sub(0.5).div(0.5).contiguous()
     classes = labels if class_of_cluster is None else class_of_cluster.to(labels.device)[labels]
     classes = classes.unsqueeze(1)
     size = image_size if image_size is not None else images.shape[-1]

@@ -121,6 +121,9 @@ def conv3x3(input, weight, dilation=1):
     return _Conv3x3Function.apply(input, weight, dilation)
 
 
+_F32_POINTWISE = os.environ.get('SIS_F32_POINTWISE', '1') != '0'  # 0: fp32 1x1 convolutions stay on the library (A/B runs)
+
+
 class _Pointwise(Function):
     """1x1 stride-1 convolution whose weight gradient is issued as the batched GEMM it is on the NCHW tensors,
     dW = sum_b dy_b x_b^T (``bmm`` + sum over the batch): the library's weight-gradient path goes through NHWC kernels
@@ -131,6 +134,8 @@ class _Pointwise(Function):
     def forward(ctx, input, weight, bias):
         ctx.save_for_backward(input, weight)
         ctx.has_bias = bias is not None
+        if _F32_POINTWISE and sis_hip.conv1x1_f32_supported(input, weight):
+            return sis_hip.conv1x1_f32(input, weight, bias)  # fp32 MFMA kernel, csrc/conv1x1_f32.hip
         return F.conv2d(input, weight, bias)
 
     @staticmethod
@@ -141,8 +146,11 @@ class _Pointwise(Function):
         grad_output = grad_output.contiguous()
         grad_input = grad_weight = grad_bias = None
         if ctx.needs_input_grad[0]:
-            grad_input = torch.ops.aten.convolution_backward(grad_output, input, weight, None, (1, 1), (0, 0), (1, 1), False,
-                                                             (0, 0), 1, (True, False, False))[0]
+            if _F32_POINTWISE and sis_hip.conv1x1_f32_supported(grad_output, weight):
+                grad_input = sis_hip.conv1x1_f32(grad_output, weight, data_gradient=True)
+            else:
+                grad_input = torch.ops.aten.convolution_backward(grad_output, input, weight, None, (1, 1), (0, 0), (1, 1), False,
+                                                                 (0, 0), 1, (True, False, False))[0]
         g = grad_output.view(b, cout, h * w)
         if ctx.needs_input_grad[1]:
             grad_weight = torch.bmm(g, input.view(b, cin, h * w).transpose(1, 2)).sum(0).view(cout, cin, 1, 1)

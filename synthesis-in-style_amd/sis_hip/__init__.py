@@ -81,6 +81,8 @@ _SIGNATURES = {
     "sis_conv_bf16_packed_elems": ([_i] * 7, _i64),
     "sis_conv_bf16_pack": ([_vp, _vp, _i] + [_i] * 7 + [_vp], _i),
     "sis_conv_bf16": ([_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp], _i),
+    "sis_conv1x1_f32_supported": ([_i] * 3, _i),
+    "sis_conv1x1_f32": ([_vp, _vp, _vp, _vp] + [_i] * 5 + [_vp], _i),
     "sis_conv_bf16_pack_both": ([_vp, _vp, _vp, _i] + [_i] * 5 + [_vp], _i),
     "sis_conv_bf16_wgrad_supported": ([_i] * 5 + [_i64], _i),
     "sis_conv_bf16_wgrad": ([_vp, _i, _vp, _vp] + [_i] * 5 + [_vp, _i64, _vp], _i),
@@ -576,6 +578,34 @@ def make_image_u8(x):
     out = torch.empty((b, h, w, ch), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
         _check(lib().sis_make_image_u8(_ptr(out), _ptr(x), b, ch, h * w, _stream()), "sis_make_image_u8")
+    return out
+
+
+# ------------------------------------------------------------------------------ fp32 pointwise convolution (matrix cores, NCHW)
+
+
+def conv1x1_f32_supported(x, weight):
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and x.data_ptr() % 16 == 0
+            and bool(lib().sis_conv1x1_f32_supported(weight.shape[1], weight.shape[0], x.shape[2] * x.shape[3])))
+
+
+def conv1x1_f32(x, weight, bias=None, data_gradient=False):
+    """1x1 stride-1 fp32 convolution of x [B,Cin,H,W] with weight [Cout,Cin,1,1] (+ bias), or with ``data_gradient`` the
+    gradient w.r.t. the input from x = dL/dy [B,Cout,H,W]."""
+    x = _f32(x, "input")
+    w = _f32(weight, "weight")
+    b, cx, h, wd = x.shape
+    cout, cin = w.shape[0], w.shape[1]
+    if cx != (cout if data_gradient else cin):
+        raise RuntimeError(f"conv1x1_f32: input has {cx} channels, weight is {cout}x{cin}")
+    out = torch.empty((b, cin if data_gradient else cout, h, wd), dtype=torch.float32, device=x.device)
+    if bias is not None:
+        bias = _f32(bias, "bias")
+    with torch.cuda.device(x.device):
+        _check(_launch(None, 2.0 * b * cout * cin * h * wd, 4.0 * (x.numel() + out.numel() + w.numel()),
+                       lambda: lib().sis_conv1x1_f32(_ptr(out), _ptr(x), _ptr(w), _ptr(bias), b, cin, cout, h * wd,
+                                                     int(bool(data_gradient)), _stream())), "sis_conv1x1_f32")
     return out
 
 
