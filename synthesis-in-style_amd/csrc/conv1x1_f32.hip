@@ -17,9 +17,9 @@ namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-template <int MT_, int NPIX_>
+template <int MT_, int NPIX_, int KC_>
 struct PwCfg {
-    static constexpr int MT = MT_, NPIX = NPIX_, KC = 32;
+    static constexpr int MT = MT_, NPIX = NPIX_, KC = KC_;
     static constexpr int WM = MT == 128 ? (NPIX == 256 ? 2 : 4) : 1;
     static constexpr int WN = 8 / WM;
     static constexpr int MB = MT / 32 / WM, NB = NPIX / 32 / WN;
@@ -28,8 +28,8 @@ struct PwCfg {
     static constexpr int LDS_BYTES = 2 * STAGE * 4;
     static constexpr int X_PIECES = X_FLOATS * 4 / 1024;   // 1 KiB DMA pieces per chunk
     static constexpr int A_PIECES = A_FLOATS * 4 / 1024;
-    static constexpr int A_VEC = A_FLOATS / 4 / 512;       // float4 loads per thread per chunk (register-staged weights)
-    static_assert(A_FLOATS % (4 * 512) == 0, "weight chunk must split evenly over the threads");
+    static constexpr int A_VEC = (A_FLOATS / 4 + 511) / 512;  // float4 loads per thread per chunk (register-staged weights)
+    static constexpr int OCC = 2 * STAGE * 4 <= 52 * 1024 ? 4 : 2;  // waves per SIMD the LDS footprint allows (3 or 1 workgroups per CU)
 };
 
 struct PwParams {
@@ -46,7 +46,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 }
 
 template <typename C, bool A_KMAJOR>
-__global__ __launch_bounds__(512, 2) void conv1x1_f32_kernel(PwParams p) {
+__global__ __launch_bounds__(512, C::OCC) void conv1x1_f32_kernel(PwParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -81,8 +81,9 @@ __global__ __launch_bounds__(512, 2) void conv1x1_f32_kernel(PwParams p) {
         for (int i = 0; i < C::A_VEC; ++i) {
             const int e = tid + i * 512;
             const int m = e % C::MT, kq = e / C::MT;
-            areg[i] = (m0 + m < p.M) ? *reinterpret_cast<const float4*>(p.a + (int64_t)(m0 + m) * p.K + chunk * C::KC + 4 * kq)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            areg[i] = (e < C::A_FLOATS / 4 && m0 + m < p.M)
+                          ? *reinterpret_cast<const float4*>(p.a + (int64_t)(m0 + m) * p.K + chunk * C::KC + 4 * kq)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto store_a = [&](int stage) {
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_f32_kernel(PwParams p) {
 #pragma unroll
         for (int i = 0; i < C::A_VEC; ++i) {
             const int e = tid + i * 512;
+            if (e >= C::A_FLOATS / 4) continue;
             const int m = e % C::MT, kq = e / C::MT;
             dst[(4 * kq + 0) * C::MT + m] = areg[i].x;
             dst[(4 * kq + 1) * C::MT + m] = areg[i].y;
@@ -183,6 +185,17 @@ int launch_pw(const PwParams& p, int a_kmajor, hipStream_t st, const char* name)
 
 bool pw_ok(int k, int m, int hw) { return k > 0 && m > 0 && hw > 0 && k % 32 == 0 && m % 4 == 0 && hw % 4 == 0; }
 
+template <int KC>
+int dispatch_pw(PwParams& p, int batch, int data_gradient, hipStream_t st) {
+    const int mt = p.M > 64 ? 128 : 64;
+    int npix = 256;
+    if (mt == 128 && (int64_t)batch * sis_cdiv(p.HW, 256) * sis_cdiv(p.M, 128) < 256) npix = 128;  // fill the 256 compute units
+    p.px_tiles = sis_cdiv(p.HW, npix);
+    if (mt == 128 && npix == 256) return launch_pw<PwCfg<128, 256, KC>>(p, data_gradient, st, KC == 16 ? "conv1x1_f32_kernel<128,256,16>" : "conv1x1_f32_kernel<128,256,32>");
+    if (mt == 128) return launch_pw<PwCfg<128, 128, KC>>(p, data_gradient, st, KC == 16 ? "conv1x1_f32_kernel<128,128,16>" : "conv1x1_f32_kernel<128,128,32>");
+    return launch_pw<PwCfg<64, 256, KC>>(p, data_gradient, st, KC == 16 ? "conv1x1_f32_kernel<64,256,16>" : "conv1x1_f32_kernel<64,256,32>");
+}
+
 }  // namespace
 
 extern "C" int sis_conv1x1_f32_supported(int cin, int cout, int hw) { return pw_ok(cin, cout, hw) && pw_ok(cout, cin, hw) ? 1 : 0; }
@@ -201,11 +214,8 @@ extern "C" int sis_conv1x1_f32(float* y, const float* x, const float* weight, co
     SIS_REQUIRE((((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15) == 0, "sis_conv1x1_f32: pointers must be 16-byte aligned");
     SIS_REQUIRE((int64_t)p.K * hw < (1LL << 31) && (int64_t)p.M * hw < (1LL << 31), "sis_conv1x1_f32: planes exceed 2^31 elements");
     hipStream_t st = (hipStream_t)stream;
-    const int mt = p.M > 64 ? 128 : 64;
-    int npix = 256;
-    if (mt == 128 && (int64_t)batch * sis_cdiv(hw, 256) * sis_cdiv(p.M, 128) < 256) npix = 128;  // fill the 256 compute units
-    p.px_tiles = sis_cdiv(hw, npix);
-    if (mt == 128 && npix == 256) return launch_pw<PwCfg<128, 256>>(p, data_gradient, st, "conv1x1_f32_kernel<128,256>");
-    if (mt == 128) return launch_pw<PwCfg<128, 128>>(p, data_gradient, st, "conv1x1_f32_kernel<128,128>");
-    return launch_pw<PwCfg<64, 256>>(p, data_gradient, st, "conv1x1_f32_kernel<64,256>");
+    // 16-channel chunks: 24 KB per stage, three workgroups per compute unit cover each other's barriers and epilogues;
+    // 32-channel chunks (SIS_PW_KC=32): one workgroup per unit, half the barriers
+    static const int kc = getenv("SIS_PW_KC") ? atoi(getenv("SIS_PW_KC")) : 16;
+    return kc == 32 ? dispatch_pw<32>(p, batch, data_gradient, st) : dispatch_pw<16>(p, batch, data_gradient, st);
 }

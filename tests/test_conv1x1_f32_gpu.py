@@ -7,7 +7,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 CASES = [(2, 64, 256, 64, 64, False), (16, 256, 64, 64, 64, False), (3, 512, 128, 32, 32, False), (2, 1024, 256, 32, 32, False),
-         (2, 256, 1024, 32, 32, False), (1, 2048, 512, 32, 32, True), (2, 64, 64, 20, 12, True), (1, 128, 132, 8, 10, False),
+         (2, 256, 1024, 32, 32, False), (1, 2048, 512, 32, 32, True), (2, 64, 64, 20, 12, True), (1, 128, 160, 8, 10, False),
          (4, 512, 2048, 16, 16, False)]
 
 
