@@ -51,8 +51,16 @@ __global__ __launch_bounds__(512, C::OCC) void conv1x1_f32_kernel(PwParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave % C::WM, wn = wave / C::WM;
-    const int n = blockIdx.x / p.px_tiles, pt = blockIdx.x % p.px_tiles;
-    const int p0 = pt * C::NPIX, m0 = blockIdx.y * C::MT;
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (id % 8 = XCD group).  The n_m output-channel
+    // tiles that share an input tile take CONSECUTIVE slots of ONE group, so the tile is pulled into that XCD's L2 once and
+    // re-read there (with the output-channel tile as the slowest grid index it came from beyond L2 once per tile: 16x for
+    // 2048 output channels).
+    const int n_m = (p.M + C::MT - 1) / C::MT;
+    const int slot = blockIdx.x >> 3;
+    const int xt = (slot / n_m) * 8 + (blockIdx.x & 7);
+    if (xt >= p.N * p.px_tiles) return;
+    const int n = xt / p.px_tiles, pt = xt % p.px_tiles;
+    const int p0 = pt * C::NPIX, m0 = (slot % n_m) * C::MT;
     const float* xin = p.x + (int64_t)n * p.K * p.HW;
     const int nchunks = p.K / C::KC;
 
@@ -175,7 +183,7 @@ int launch_pw(const PwParams& p, int a_kmajor, hipStream_t st, const char* name)
         if (e != hipSuccess) return sis_fail("%s: cannot raise the LDS limit: %s", name, hipGetErrorString(e));
         attr_set = true;
     }
-    dim3 grid(p.N * p.px_tiles, sis_cdiv(p.M, C::MT));
+    dim3 grid(8 * sis_cdiv(p.M, C::MT) * sis_cdiv((int64_t)p.N * p.px_tiles, 8));
     if (a_kmajor) hipLaunchKernelGGL((conv1x1_f32_kernel<C, true>), grid, dim3(512), C::LDS_BYTES, st, p);
     else hipLaunchKernelGGL((conv1x1_f32_kernel<C, false>), grid, dim3(512), C::LDS_BYTES, st, p);
     SIS_CHECK_LAUNCH(name);

@@ -112,12 +112,16 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_kernel(ConvParams p) {
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave % C::WM, wn = wave / C::WM;
 
-    // tile decode: blockIdx.x = (image, tile_y, tile_x), blockIdx.y = output-channel tile
-    int t = blockIdx.x;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (id % 8 = XCD group).  The output-channel
+    // tiles that share an input tile take CONSECUTIVE slots of ONE group: the input tile is pulled into that XCD's L2 once
+    // (with the channel tile as the slowest grid index every channel tile re-fetched it from beyond L2).
+    const int slot = blockIdx.x >> 3;
+    int t = (slot / p.co_tiles) * 8 + (blockIdx.x & 7);
+    if (t >= p.N * p.tiles_y * p.tiles_x) return;
+    const int co_t = slot % p.co_tiles;
     const int tx_i = t % p.tiles_x; t /= p.tiles_x;
     const int ty_i = t % p.tiles_y; t /= p.tiles_y;
     const int n = t;
-    const int co_t = blockIdx.y;
     const int ox0 = tx_i * C::TW, oy0 = ty_i * C::TR;
     const int ix0 = ox0 * C::S - C::HALO, iy0 = oy0 * C::S - C::PAD;
     const int nchunks = p.Cin / C::KC;
@@ -324,7 +328,7 @@ int launch_conv(const ConvParams& p, hipStream_t st, const char* name) {
         if (e != hipSuccess) return sis_fail("%s: cannot raise the LDS limit: %s", name, hipGetErrorString(e));
         attr_set = true;
     }
-    dim3 grid(p.N * p.tiles_y * p.tiles_x, p.co_tiles);
+    dim3 grid(8 * p.co_tiles * sis_cdiv((int64_t)p.N * p.tiles_y * p.tiles_x, 8));
     if (p.aligned) hipLaunchKernelGGL((conv_bf16_kernel<C, true>), grid, dim3(512), 2 * C::STAGE, st, p);
     else hipLaunchKernelGGL((conv_bf16_kernel<C, false>), grid, dim3(512), 2 * C::STAGE, st, p);
     SIS_CHECK_LAUNCH(name);
