@@ -21,20 +21,22 @@ from oracle import load_reference  # noqa: E402
 from oracle import ema_net_ref as E  # noqa: E402
 
 
-def make_ema_net(ema, ema_utils):
+def make_ema_net(ema, ema_utils, residual_scale=1.0, lr=2e-5, out_name="ema_net_step.npz"):
+    """``residual_scale`` 0.1 / lr 0.009 (the shipped config's learning rate) -> ema_net_step_conditioned.npz: the
+    well-conditioned fixture (oracle/ema_net_ref.py::seeded_state_dict) on which gradients are pinned at 1e-3."""
     torch.manual_seed(0)
     net = ema.EMANet(3, 50, use_pretrained_resnet=False)
     schema = E.state_dict_schema(50, 3)
     assert [k for k, _ in schema] == list(net.state_dict().keys())
     for (k, s), v in zip(schema, net.state_dict().values()):
         assert tuple(s) == tuple(v.shape), k
-    net.load_state_dict(E.seeded_state_dict(50, 3, seed=7), strict=True)
+    net.load_state_dict(E.seeded_state_dict(50, 3, seed=7, residual_scale=residual_scale), strict=True)
     net.fc1[1].p = 0.0
     net.train()
     # wd / momenta of configs/segmenter/stylegan2_ema_net_segmenter.yaml:17-26; lr 2e-5 instead of 0.009: on this
     # randomly initialised net the first-step stem gradients are ~1000x the weights, so at lr 0.009 the second
     # iteration is chaotic (1e-7 perturbations change its loss by tens of percent) and pins nothing
-    lr, wd, mom, em_mom = 2e-5, 1e-4, 0.9, 0.9
+    wd, mom, em_mom = 1e-4, 0.9, 0.9
     opt = torch.optim.SGD([
         {"params": ema_utils.get_params(net, key="1x"), "lr": lr, "weight_decay": wd},
         {"params": ema_utils.get_params(net, key="1y"), "lr": lr, "weight_decay": 0},
@@ -49,7 +51,7 @@ def make_ema_net(ema, ema_utils):
         out["pred_labels"] = net.predict_classes(batch["images"]).numpy().astype(np.uint8)
         top2 = pred.topk(2, dim=1).values
         out["pred_margin"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float16)
-    net.load_state_dict(E.seeded_state_dict(50, 3, seed=7), strict=True)  # undo the running-stat updates
+    net.load_state_dict(E.seeded_state_dict(50, 3, seed=7, residual_scale=residual_scale), strict=True)  # undo the running-stat updates
     for it in range(2):
         batch = E.seeded_batch(2, 256, 3, seed=8 + it)
         loss, mu = net(batch["images"], torch.squeeze(batch["segmented"], dim=1))
@@ -70,17 +72,21 @@ def make_ema_net(ema, ema_utils):
             out["grad_names"] = np.array(names)
             out["grad_fc2_weight"] = net.fc2.weight.grad.numpy()
             out["grad_stem0_slice"] = net.extractor[0][0].weight.grad[::8].numpy()
+            out["grad_l4"] = net.extractor[7][2].conv3.weight.grad[::64, ::16].numpy().copy()
         opt.step()
         out[f"loss_mean_{it}"] = total.detach().numpy()
     sd = net.state_dict()
     out["after_names"] = np.array(list(sd.keys()))
     out["after_abs_sums"] = np.array([v.double().abs().sum().item() for v in sd.values()])
     out["after_emau_mu_slice"] = sd["emau.mu"][0, ::32, ::8].numpy()
-    init = E.seeded_state_dict(50, 3, seed=7)
+    init = E.seeded_state_dict(50, 3, seed=7, residual_scale=residual_scale)
     for k in ("fc2.weight", "fc2.bias", "fc1.0.bn.weight"):  # two-step parameter deltas
         out["delta_" + k] = (sd[k] - init[k]).numpy()
+    out["delta_layer4_conv3_slice"] = (sd["extractor.7.2.conv3.weight"] - init["extractor.7.2.conv3.weight"])[::64, ::16].numpy().copy()
+    out["delta_stem0_slice"] = (sd["extractor.0.0.weight"] - init["extractor.0.0.weight"])[::8].numpy().copy()
     out["after_bn_running_var_fc0"] = sd["fc0.bn.running_var"].numpy()
-    np.savez_compressed(os.path.join(HERE, "ema_net_step.npz"), **out)
+    out["grad_layer4_conv3_slice"] = np.zeros(1) if "grad_l4" not in out else out.pop("grad_l4")
+    np.savez_compressed(os.path.join(HERE, out_name), **out)
 
 
 def make_trans_u_net(vit, tu_utils):
@@ -134,6 +140,7 @@ if __name__ == "__main__":
     ema, vit, tu_utils, ema_utils = load_reference.load_reference_segmenters()
     torch.set_num_threads(8)
     make_ema_net(ema, ema_utils)
+    make_ema_net(ema, ema_utils, residual_scale=0.1, lr=0.009, out_name="ema_net_step_conditioned.npz")
     make_trans_u_net(vit, tu_utils)
     for f in sorted(os.listdir(HERE)):
         if f.endswith("_step.npz"):

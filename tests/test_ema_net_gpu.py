@@ -113,3 +113,64 @@ def test_ema_net_step_vs_oracle_fresh_seed(device):
         else:
             ref = grads_o[name].double().norm().item()
             assert abs(p.grad.double().norm().item() - ref) <= 2e-2 * ref + 1e-7, name
+
+
+def _rel_l2(a, b):
+    return float(np.linalg.norm(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)) / np.linalg.norm(np.asarray(b, dtype=np.float64)))
+
+
+def test_ema_net_conditioned_fixture_tight(device, golden_dir):
+    """the same two iterations on the well-conditioned fixture (small residual branches, the SHIPPED
+    learning rate 0.009), where tolerances mean something: loss 1e-5, every gradient norm 1e-3, gradient tensors 1e-3 /
+    5e-3 in relative L2 (a ReLU network's gradient moves by ~sqrt(fraction of flipped units): 1e-3 is the fp32 floor for
+    the deep layers), second-iteration loss 1e-4, two-step parameter deltas 1e-2 element-wise."""
+    from networks.ema_net.network import EMANet
+    from networks.ema_net.utils import get_params
+    from training.fused_sgd import FusedSGD
+    from training.loop import get_current_reporter
+    from updater.segmentation_updater import EMANetUpdater
+    g = np.load(os.path.join(golden_dir, "ema_net_step_conditioned.npz"))
+    n_layers, classes, wseed, bseed, batch, size = g["cfg"].tolist()
+
+    def fresh():
+        net = EMANet(3, 50, use_pretrained_resnet=False)
+        net.load_state_dict(E.seeded_state_dict(50, 3, seed=wseed, residual_scale=0.1), strict=True)
+        net.fc1[1].p = 0.0
+        return net.to(device).train()
+
+    net = fresh()
+    batches = [E.seeded_batch(batch, size, classes, seed=bseed + i) for i in range(2)]
+    b0 = {k: v.to(device) for k, v in batches[0].items()}
+    loss, mu = net(b0["images"], b0["segmented"].squeeze(1))
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), g["loss"], rtol=1e-5)
+    np.testing.assert_allclose(mu[:, ::32, ::8].cpu().numpy(), g["mu_slice"], rtol=1e-3, atol=1e-6)
+    loss.mean().backward()
+    grads = {n: p.grad for n, p in net.named_parameters()}
+    for name, ref in zip(g["grad_names"], g["grad_norms"]):
+        if ref >= 0:
+            np.testing.assert_allclose(grads[str(name)].double().norm().item(), ref, rtol=1e-3, err_msg=str(name))
+    assert _rel_l2(grads["fc2.weight"].cpu().numpy(), g["grad_fc2_weight"]) < 1e-4
+    assert _rel_l2(grads["extractor.7.2.conv3.weight"][::64, ::16].cpu().numpy(), g["grad_layer4_conv3_slice"]) < 1e-3
+    assert _rel_l2(grads["extractor.0.0.weight"][::8].cpu().numpy(), g["grad_stem0_slice"]) < 5e-3
+    # the updater, at the shipped learning rate
+    net = fresh()
+    lr = 0.009
+    opt = FusedSGD([{"params": list(get_params(net, "1x")), "lr": lr, "weight_decay": 1e-4},
+                    {"params": list(get_params(net, "1y")), "lr": lr, "weight_decay": 0},
+                    {"params": list(get_params(net, "2x")), "lr": 2 * lr, "weight_decay": 0.0}], momentum=0.9)
+    upd = EMANetUpdater(em_mom=0.9, iterators={"images": batches}, networks={"segmentation": net}, optimizers={"main": opt},
+                        device=device)
+    upd.update()
+    np.testing.assert_allclose(float(get_current_reporter().scalars()["loss/softmax"]), g["loss_mean_0"], rtol=1e-5)
+    upd.update()
+    np.testing.assert_allclose(float(get_current_reporter().scalars()["loss/softmax"]), g["loss_mean_1"], rtol=1e-4)
+    sd = net.state_dict()
+    init = E.seeded_state_dict(50, 3, seed=wseed, residual_scale=0.1)
+    for k in ("fc2.weight", "fc2.bias", "fc1.0.bn.weight"):
+        ref = g["delta_" + k]
+        np.testing.assert_allclose((sd[k].cpu() - init[k]).numpy(), ref, rtol=1e-2, atol=2e-3 * np.abs(ref).max(), err_msg=k)
+    assert _rel_l2((sd["extractor.7.2.conv3.weight"].cpu() - init["extractor.7.2.conv3.weight"])[::64, ::16].numpy(),
+                   g["delta_layer4_conv3_slice"]) < 2e-3
+    assert _rel_l2((sd["extractor.0.0.weight"].cpu() - init["extractor.0.0.weight"])[::8].numpy(), g["delta_stem0_slice"]) < 1e-2
+    for name, ref in zip(g["after_names"], g["after_abs_sums"]):
+        np.testing.assert_allclose(sd[str(name)].double().abs().sum().item(), ref, rtol=1e-4, err_msg=str(name))

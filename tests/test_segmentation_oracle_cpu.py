@@ -91,3 +91,25 @@ def test_trans_u_net_train_step_vs_golden(golden_dir):
               "transformer.encoder.encoder_norm.weight"):
         ref = g["delta_" + k]
         np.testing.assert_allclose((sd[k] - init[k]).numpy(), ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max(), err_msg=k)
+
+
+def test_ema_net_conditioned_fixture_vs_golden(golden_dir):
+    """The well-conditioned fixture (bn3 x 0.1 -- oracle/ema_net_ref.py::seeded_state_dict) at the SHIPPED learning rate
+    0.009: the oracle against the reference's own two iterations (tests/golden/ema_net_step_conditioned.npz)."""
+    g = np.load(os.path.join(golden_dir, "ema_net_step_conditioned.npz"))
+    n_layers, classes, wseed, bseed, batch, size = g["cfg"].tolist()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    sd = E.seeded_state_dict(n_layers, classes, seed=wseed, residual_scale=0.1)
+    bufs = {}
+    total, loss, mu, grads = E.train_step(sd, bufs, E.seeded_batch(batch, size, classes, seed=bseed), lr=0.009)
+    np.testing.assert_allclose(loss.numpy(), g["loss"], rtol=2e-5)
+    for name, ref in zip(g["grad_names"], g["grad_norms"]):
+        if ref >= 0:
+            np.testing.assert_allclose(grads[str(name)].double().norm().item(), ref, rtol=1e-3, err_msg=str(name))
+    np.testing.assert_allclose(grads["fc2.weight"].numpy(), g["grad_fc2_weight"], rtol=1e-3, atol=1e-6)
+    total1, _, _, _ = E.train_step(sd, bufs, E.seeded_batch(batch, size, classes, seed=bseed + 1), lr=0.009)
+    np.testing.assert_allclose(total1.numpy(), g["loss_mean_1"], rtol=1e-4)
+    init = E.seeded_state_dict(n_layers, classes, seed=wseed, residual_scale=0.1)
+    for k in ("fc2.weight", "fc2.bias", "fc1.0.bn.weight"):
+        ref = g["delta_" + k]
+        np.testing.assert_allclose((sd[k] - init[k]).numpy(), ref, rtol=1e-2, atol=1e-3 * np.abs(ref).max(), err_msg=k)
