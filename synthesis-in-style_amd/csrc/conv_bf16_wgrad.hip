@@ -160,7 +160,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(WgParams p) {
         }
     };
 
-    unsigned sink = 0;
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -193,21 +192,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(WgParams p) {
             const int slot = (y + ky) & 3;  // image row y + ky - 1
             const unsigned char* row = b_base + slot * C::XR_UNITS * 16;
             if constexpr (C::WK == 1) {
-                // two K-steps at a time: groups h - 1 + 4 j .. h + 3 + 4 j of the strip (five ds_read_b128, the shared
-                // edge group read twice: 20 registers instead of 36 for the whole row)
+                uint4 g[2 * C::KS + 1];      // groups h - 1 .. h + 2 KS - 1 of the strip (LDS group index + 1), each read once
 #pragma unroll
-                for (int j = 0; j < C::KS / 2; ++j) {
-                    uint4 g[5];
+                for (int i = 0; i < 2 * C::KS + 1; ++i) g[i] = *reinterpret_cast<const uint4*>(row + i * 16);
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) g[i] = *reinterpret_cast<const uint4*>(row + (4 * j + i) * 16);
-                    // Only one dword of a neighbour group is used, and the compiler then narrows its ds_read_b128 to
-                    // ds_read2_b32 -- whose 32-bank rule turns the odd 16-byte pitch that keeps ds_read_b128 conflict
-                    // free into a 4-way conflict (PMC: 52 % of the LDS cycles were conflict cycles).  Keeping every dword
-                    // observably live (a store that never executes) keeps the reads whole.
-                    sink |= g[0].x | g[0].y | g[0].z | g[2].y | g[2].z | g[4].y | g[4].z | g[4].w;
-                    tap_row(acc, ky, a[2 * j], g[0], g[1], g[2]);
-                    tap_row(acc, ky, a[2 * j + 1], g[2], g[3], g[4]);
-                }
+                for (int ks = 0; ks < C::KS; ++ks) tap_row(acc, ky, a[ks], g[2 * ks], g[2 * ks + 1], g[2 * ks + 2]);
             } else {
 #pragma unroll
                 for (int i = 0; i < KW; ++i) {
@@ -230,7 +219,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(WgParams p) {
     // ---- partial tile -> slab[unit][tap][co][ci] (ci on the lanes: 128-byte runs)
     const int co_pad = p.co_tiles * C::MT, ci_pad = p.ci_tiles * C::NT;
     float* out = p.slab + (int64_t)blockIdx.x * 9 * co_pad * ci_pad;
-    if (p.N < 0) out[tid] = __uint_as_float(sink);  // never taken (see the main loop)
     if constexpr (C::WK == 1) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
