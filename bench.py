@@ -509,12 +509,20 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a HIP device (the product path has no CPU fallback)")
+    # Rehearsal switches (one-GPU boxes): SIS_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and SIS_BENCH_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device); the driver's multi-GPU runs use neither.
+    if os.environ.get("SIS_BENCH_SHARE_GPU", "0") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("SIS_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     if args.workload == "dataset":
         result = bench_dataset(args, world, rank, device, distributed)
