@@ -40,6 +40,17 @@ __device__ __forceinline__ float2 lds_ld2(const float* p) {
     const f32x2 d = *reinterpret_cast<const f32x2*>(p);
     return make_float2(d.x, d.y);
 }
+// LDS-DMA through a buffer descriptor: address = descriptor base + per-lane byte offset (VGPR) + wave-uniform byte
+// offset (SGPR), so the per-chunk address arithmetic is scalar (no 64-bit VALU adds, which a SIMD partner's MFMA stream
+// throttles to one instruction per ~10 cycles), and a lane whose offset is >= num_records gets ZEROS written to its
+// LDS slot (tools/micro/buffer_lds_oob.hip): image halos and partial blocks need neither exec masks nor a zero fill.
+constexpr unsigned BUF_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ void bufld16(__amdgpu_buffer_rsrc_t r, float* l, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
+}
 __device__ __forceinline__ void glds4(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 4, 0, 0);
@@ -285,11 +296,29 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams
     }
 }
 
+#ifdef SIS_WINO_TRACE
+// Development build only (tools/wino_trace.sh): per-wave cycle stamps of the steady-state chunk loop of 4 workgroups.
+constexpr int TR_WG0 = 500, TR_NWG = 4, TR_CHUNKS = 64, TR_SLOTS = 4;
+__device__ unsigned int sis_wino_trace[TR_NWG][8][TR_CHUNKS][TR_SLOTS];
+#define WINO_TRACE(slot)                                                                                          \
+    do {                                                                                                          \
+        if (tr_on && c < TR_CHUNKS) {                                                                             \
+            const unsigned int now_ = (unsigned int)__builtin_readcyclecounter();                                 \
+            if (lane == 0) sis_wino_trace[blockIdx.x - TR_WG0][wave][c][slot] = now_;                             \
+        }                                                                                                         \
+    } while (0)
+#else
+#define WINO_TRACE(slot) do {} while (0)
+#endif
+
 // Pipelined variant (default when its 158 KB of LDS fit): the input transform is done ONCE per (channel, tile) --
 // one patch per lane per chunk, 512 lanes = 8 channels x 64 tiles -- into a second LDS image V[xi][channel][tile],
 // one chunk ahead of the MFMAs, so the matrix loop is nothing but ds_read_b32 pairs and MFMAs (in the kernel above
 // every patch is re-read and re-transformed by the 4 waves that share it: 48.5 % MFMA-busy measured).  Per
 // iteration c: DMA weights(c+1), DMA input(c+2), transform(c+1) -> V, MFMA(c); one barrier.
+// Template: XI = 64-lane parts of the input tile (power of two >= xt / 256), STYLED = modulated (style rows in LDS),
+// PIPE = single-phase software-pipelined chunk loop (see the loop) instead of the staggered two-phase one.
+template <int XI, bool STYLED, bool PIPE>
 __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParams p, const int xt_max, const int tiles_per_wg, const int xcd_group) {
     constexpr int WF = WCC * 16 * WMBLK;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -303,10 +332,9 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     float* Bl = Dl + p.nb_max * WMBLK;   //   [WMBLK]     bias
     float* Nl = Bl + WMBLK;              //   [WTILES][4] noise_weight * noise of the tile's pixels
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int q = __builtin_amdgcn_readfirstlane(wave & 1), wn = (wave >> 1) & 1, wm = wave >> 2;
-    const int wbase = tid & ~63;
+    const int q = wave & 1, wn = (wave >> 1) & 1, wm = wave >> 2;
 
     // XCD-aware order: output-channel block fastest.  Workgroups are dealt round-robin over the 8 XCDs, so with
     // n_co = Cout / MBLK in {2,4,8} every XCD keeps working on the same weight slice (<= 2.4 MB: stays in its
@@ -335,46 +363,52 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     // first-touch latency is paid once per `tiles_per_wg` tiles instead of once per tile (7 us against 16 chunks
     // x 2.5 us on the 128-channel 256^2 layer).
     int b0, h0, w0;
-    int st_goff;  // one float4 chunk of the tile per lane per channel (<= 512 chunks: host-checked); -1: outside
+    // Input tile DMA: the tile is xt / 4 float4 per channel, cut into XI parts of 64 lanes (XI rounded up to a power of
+    // two); wave w moves part w % XI of the channels w / XI + k * (8 / XI) -- every wave issues the same number of DMA
+    // instructions (issue back-pressure on two waves was the critical path of the chunk) from one offset register.
+    constexpr int x_chstep = WCC / XI;
+    const int x_part = wave & (XI - 1), x_ch0 = wave / XI;
+    // The last part is shifted back so that it ends with the tile (it overlaps its neighbour, which writes the same
+    // values): every lane of every DMA instruction owns a float4 of the tile -- no exec mask, no branch in the loop.
+    const int x_base = min(x_part * 256, xt - 256);  // floats; xt >= 256 (a tile has 64 patches) and xt % 4 == 0
+    const int x_f4 = (x_base >> 2) + lane;  // this lane's float4 of the tile
+    unsigned x_voff;                // byte offset of that float4 inside the channel plane, from the tile's first sample
+    __amdgpu_buffer_rsrc_t x_rsrc;  // descriptor based at the tile's first sample
     auto tile_setup = [&](int pt) {
         const int twi = pt % tc.ntw; pt /= tc.ntw;
         const int thi = pt % tc.nth;
         b0 = (pt / tc.nth) * tc.nb; h0 = thi << thl; w0 = twi << twl;
-        st_goff = -1;
+        x_voff = BUF_OOB;
         const int ew4 = ew >> 2;
-        if (tid < (xt >> 2)) {
-            const int n = tid / (eh * ew4), rem = tid - n * (eh * ew4);
+        {
+            const int n = x_f4 / (eh * ew4), rem = x_f4 - n * (eh * ew4);
             const int r = rem / ew4, c4 = rem - r * ew4;
             const int b = b0 + n, h = h0 - 1 + r, w = w0 - 4 + 4 * c4;
-            if (b < p.B && h >= 0 && h < p.H && w >= 0 && w < p.W) st_goff = b * p.Cin * HW + h * p.W + w;
+            if (b < p.B && h >= 0 && h < p.H && w >= 0 && w < p.W) x_voff = (unsigned)(n * p.Cin * HW + h * p.W + w) * 4u;
         }
+        x_rsrc = dma_rsrc(p.x + (int64_t)b0 * p.Cin * HW);
     };
     // Tile k of workgroup g is pixel tile g + k * (#workgroups per channel block): the workgroups running at the same
     // time cover NEIGHBOURING tiles, whose halos they share through L2 (consecutive tiles per workgroup measured 57 %
     // more fetched bytes).
     const int pt_first = wg / n_co, pt_step = gridDim.x / n_co;
     tile_setup(pt_first);
-    constexpr int WV4 = WF / 4, WIT = WV4 / WNTHR;  // 4 float4 per lane per chunk
-    int w_goff[WIT];
-#pragma unroll
-    for (int it = 0; it < WIT; ++it) {
-        const int e = it * WNTHR + tid;
-        const int row = e / (WMBLK / 4), qq = e - row * (WMBLK / 4);
-        w_goff[it] = (o0 + qq * 4 < p.Cout) ? row * p.Cout + o0 + qq * 4 : -1;
-    }
+    // weights: chunk = 128 rows (ci, xi) x 64 co = 2048 float4; lane e = it * 512 + tid takes row e / 16, float4 e % 16
+    constexpr int WIT = WF / 4 / WNTHR;
+    const __amdgpu_buffer_rsrc_t u_rsrc = dma_rsrc(p.wpk + o0);
+    const unsigned u_voff = (o0 + (tid & 15) * 4 < p.Cout) ? (unsigned)((tid >> 4) * p.Cout + (tid & 15) * 4) * 4u : BUF_OOB;
     auto stage_u = [&](int ci0, int buf) {
-        const float* usrc = p.wpk + (int64_t)ci0 * 16 * p.Cout;
-        float* udst = Ul + buf * WF + wbase * 4;
+        float* udst = Ul + buf * WF + wave * 256;
 #pragma unroll
         for (int it = 0; it < WIT; ++it)
-            if (w_goff[it] >= 0) glds16(usrc + w_goff[it], udst + it * WNTHR * 4);
+            bufld16(u_rsrc, udst + it * WNTHR * 4, u_voff, (unsigned)((ci0 * 16 + it * (WNTHR / 16)) * p.Cout) * 4u);
     };
     auto stage_x = [&](int ci0, int buf) {
-        const float* xsrc = p.x + (int64_t)ci0 * HW;
-        float* xdst = Xl + buf * WCC * xt + wbase * 4;
-        if (st_goff >= 0) {
+        float* xdst = Xl + buf * WCC * xt + x_base;
 #pragma unroll
-            for (int j = 0; j < WCC; ++j) glds16(xsrc + st_goff + j * HW, xdst + j * xt);
+        for (int k = 0; k < XI; ++k) {
+            const int j = x_ch0 + k * x_chstep;
+            bufld16(x_rsrc, xdst + j * xt, x_voff, (unsigned)((ci0 + j) * HW) * 4u);
         }
     };
     // Input transform, ONE patch per lane per chunk: lane = tile (0..63), wave = channel of the chunk.  V = B^T d B
@@ -385,7 +419,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     const int txo = min(ttn, tc.nb - 1) * eh * ew + 2 * tty * ew + 2 * ttx + 2 + tch * xt;
     const int tso = min(ttn, tc.nb - 1) * p.Cin + tch;
     auto transform = [&](int ci0, int xbuf, int vbuf) {
-        const float sv = p.s ? Sl[tso + ci0] : 1.f;
+        const float sv = STYLED ? Sl[tso + ci0] : 1.f;
         const float* xb = Xl + xbuf * WCC * xt + txo;
         float d[4][4];
 #pragma unroll
@@ -424,21 +458,19 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     // B operand of this lane in the V image: [xi][channel 2cp + half][tile wn*32 + l31]
     const int voff = half * WTILES + wn * 32 + l31 + 2 * q * WCC * WTILES;  // + (4 i + jj) * WCC*WTILES + 2cp*WTILES
     const bool partial = p.ksplit > 1;
-    const bool late_transform = __builtin_amdgcn_readfirstlane(wave) >= 4;
+#ifdef SIS_WINO_NOSTAGGER
+    const bool late_transform = false;
+#else
+    const bool late_transform = wave >= 4;
+#endif
 
     // First DMA of a tile: every global access of the start-up is in flight before the first wait (one memory
-    // round trip).  The DMA never writes out-of-image float4 slots, so the lanes owning such slots store the zeros
-    // themselves (disjoint from every DMA destination: no ordering needed).
+    // round trip).  Out-of-image float4 slots get their zeros from the DMA itself (out-of-range buffer offsets).
     auto tile_first_dma = [&]() {
         stage_u(k_lo, 0);
         stage_x(k_lo, 0);
         if (k_lo + WCC < k_hi) stage_x(k_lo + WCC, 1);
-        if (tid < (xt >> 2) && st_goff < 0) {
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int j = 0; j < 2 * WCC; ++j) *reinterpret_cast<float4*>(Xl + j * xt + tid * 4) = z;
-        }
-        for (int e = tid; e < (p.s ? tc.nb * p.Cin : 0); e += WNTHR) {  // plain convolution (p.s == nullptr): no style rows
+        for (int e = tid; e < (STYLED ? tc.nb * p.Cin : 0); e += WNTHR) {  // plain convolution (p.s == nullptr): no style rows
             const int n = e / p.Cin, ci = e - n * p.Cin;
             Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
         }
@@ -485,13 +517,95 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
                 for (int j = 0; j < 16; ++j) acc[i][jj][j] = 0.f;
 
         int c = 0;
+#ifdef SIS_WINO_TRACE
+        const bool tr_on = k == 1 && blockIdx.y == 0 && blockIdx.x >= TR_WG0 && blockIdx.x < TR_WG0 + TR_NWG;
+#endif
+        // Single-phase software-pipelined chunk (PIPE).  Measured on the staggered loop below (tools/wino_trace.py): a wave
+        // that transforms while its SIMD partner streams MFMAs needs ~2800 cycles for ~60 instructions (LDS round trips
+        // and VALU issue both crawl), so the two waves of a SIMD ended up multiplying one after the other.  Here every
+        // wave runs ONE straight-line block per chunk: DMA (scalar address arithmetic only), the 12 patch reads of its
+        // transform (their latency hides under the first multiplies), then 16 steps of { operand reads of the next step,
+        // 2 MFMAs, a slice of the transform arithmetic / its LDS writes }.  No branch, no wait that is not covered.
+        // The last chunks clamp their prefetch indices: they re-stage the final chunk into buffers nobody reads any more.
+        if (PIPE) {
+            const int k_last = k_hi - WCC;
+            const float* xbt = Xl + txo;
+            float* vbt = Vl + tch * WTILES + ttile;
+            for (int ci0 = k_lo; ci0 < k_hi; ci0 += WCC, ++c) {
+                const int cur = c & 1, nxt = cur ^ 1;
+                WINO_TRACE(0);
+                const int tci = min(ci0 + WCC, k_last);
+                const float* xb = xbt + nxt * WCC * xt;
+                const float* Ub = Ul + cur * WF + aoff;
+                const float* Vb = Vl + cur * VF + voff;
+                float* vw = vbt + nxt * VF;
+                float ou[3][2], ov[3][2];
+                auto operands = [&](int st, int slot) {  // step st = (cp, i): two MFMAs (jj = 0, 1)
+                    const int cp = st >> 2, i = st & 3;
+                    ou[slot][0] = Ub[2 * cp * 16 * WMBLK + (4 * i) * WMBLK];
+                    ou[slot][1] = Ub[2 * cp * 16 * WMBLK + (4 * i + 1) * WMBLK];
+                    ov[slot][0] = Vb[2 * cp * WTILES + (4 * i) * WCC * WTILES];
+                    ov[slot][1] = Vb[2 * cp * WTILES + (4 * i + 1) * WCC * WTILES];
+                };
+                float sv = 1.f, d[4][4], tt[4];
+                operands(0, 0);  // operands run two steps ahead of their MFMAs
+                operands(1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                WINO_TRACE(1);
+#pragma unroll
+                for (int st = 0; st < 16; ++st) {
+                    if (st < 14) operands(st + 2, (st + 2) % 3);
+                    const int i = st & 3, sl = st % 3;
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ou[sl][0], ov[sl][0], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ou[sl][1], ov[sl][1], acc[i][1], 0, 0, 0);
+                    if (st == 0) stage_u(min(ci0 + WCC, k_last), nxt);
+                    if (st == 1) stage_x(min(ci0 + 2 * WCC, k_last), cur);
+                    if (st == 2 || st == 3) {  // patch rows 2(st-2), 2(st-2)+1: columns 1..4 of the 8-byte aligned row start
+                        if (st == 2 && STYLED) sv = Sl[tso + tci];
+#pragma unroll
+                        for (int r = 2 * (st - 2); r < 2 * (st - 2) + 2; ++r) {
+                            d[r][0] = xb[r * ew + 1];
+                            const float2 mid = lds_ld2(xb + r * ew + 2);
+                            d[r][1] = mid.x; d[r][2] = mid.y;
+                            d[r][3] = xb[r * ew + 4];
+                        }
+                    }
+                    if (st >= 7 && st < 11) {  // patch row r, scaled by the style
+                        const int r = st - 7;
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) d[r][cc] *= sv;
+                    }
+                    if (st >= 11 && st < 15) {  // row r of B^T d, times B, into the V image of the next chunk
+                        const int r = st - 11;
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc)
+                            tt[cc] = r == 0 ? d[0][cc] - d[2][cc] : r == 1 ? d[1][cc] + d[2][cc] : r == 2 ? d[2][cc] - d[1][cc] : d[1][cc] - d[3][cc];
+                        vw[(r * 4 + 0) * WCC * WTILES] = tt[0] - tt[2];
+                        vw[(r * 4 + 1) * WCC * WTILES] = tt[1] + tt[2];
+                        vw[(r * 4 + 2) * WCC * WTILES] = tt[2] - tt[1];
+                        vw[(r * 4 + 3) * WCC * WTILES] = tt[1] - tt[3];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                WINO_TRACE(2);
+                WINO_TRACE(3);
+                __syncthreads();  // V(c+1) written, DMA retired, everyone done with U(c) / V(c)
+            }
+        } else
         for (int ci0 = k_lo; ci0 < k_hi; ci0 += WCC, ++c) {
             const int cur = c & 1, nxt = cur ^ 1;
+            WINO_TRACE(0);
             if (ci0 + WCC < k_hi) stage_u(ci0 + WCC, nxt);          // weights lead by one chunk
+#ifndef SIS_WINO_XLATE
             if (ci0 + 2 * WCC < k_hi) stage_x(ci0 + 2 * WCC, cur);   // input leads by two (its transform sits in between)
+#endif
             // Stagger the two waves that share a SIMD (waves w and w+4): one transforms first and multiplies second,
             // its partner the other way round, so the matrix pipe is not left idle while both do their transform.
             if (!late_transform && ci0 + WCC < k_hi) transform(ci0 + WCC, nxt, nxt);
+            WINO_TRACE(1);
+#ifdef SIS_WINO_XLATE
+            if (ci0 + 2 * WCC < k_hi) stage_x(ci0 + 2 * WCC, cur);
+#endif
             const float* Ub = Ul + cur * WF + aoff;
             const float* Vb = Vl + cur * VF + voff;
 #pragma unroll
@@ -504,7 +618,9 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
                     acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[(4 * i + 1) * WMBLK], vb[(4 * i + 1) * WCC * WTILES], acc[i][1], 0, 0, 0);
                 }
             }
+            WINO_TRACE(2);
             if (late_transform && ci0 + WCC < k_hi) transform(ci0 + WCC, nxt, nxt);
+            WINO_TRACE(3);
             __syncthreads();  // V(c+1) written, DMA retired, everyone done with U(c) / V(c)
         }
 
@@ -598,6 +714,12 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
 
 }  // namespace
 
+#ifdef SIS_WINO_TRACE
+extern "C" int sis_wino_trace_read(unsigned int* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sis_wino_trace), sizeof(unsigned int) * TR_NWG * 8 * TR_CHUNKS * TR_SLOTS);
+}
+#endif
+
 extern "C" int sis_modconv_prepack_wino(float* u, const float* w, int cout, int cin, void* stream) {
     SIS_REQUIRE(u && w, "sis_modconv_prepack_wino: null pointer");
     SIS_REQUIRE(cout > 0 && cin > 0, "sis_modconv_prepack_wino: bad sizes");
@@ -651,14 +773,11 @@ int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t 
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_wino_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_wino2_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return sis_fail("modconv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         attr_set = true;
     }
     static const bool pipelined = !(getenv("SIS_WINO_PIPE") && getenv("SIS_WINO_PIPE")[0] == '0');
-    if (pipelined && lds2 <= 160 * 1024) {
+    if (pipelined && lds2 <= 160 * 1024 && tc.xt >= 256) {
         sis_kernel_name = "modconv_wino2_kernel";
         // pixel tiles per workgroup: as many as keep >= 1024 workgroups (4 per CU) in flight
         static const int tpw_cap = getenv("SIS_WINO_TPW") ? atoi(getenv("SIS_WINO_TPW")) : 16;
@@ -670,7 +789,28 @@ int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t 
         const int64_t grid = blocks / tpw;
         const int n_co_h = (p.Cout + WMBLK - 1) / WMBLK;
         const int xcd_group = (double)p.Cin * p.Cout * 16 * sizeof(float) <= swz_mb * 1048576.0 && n_co_h > 1 && grid % (8 * n_co_h) == 0;
-        hipLaunchKernelGGL(modconv_wino2_kernel, dim3((unsigned)grid, p.ksplit), dim3(WNTHR), lds2, st, p, tc.xt, tpw, xcd_group);
+        // single-phase software-pipelined chunk loop (default) or the staggered two-phase loop (SIS_WINO_PHASES=2)
+        static const bool one_phase = !(getenv("SIS_WINO_PHASES") && getenv("SIS_WINO_PHASES")[0] == '2');
+        typedef void (*kern_t)(const ConvParams, const int, const int, const int);
+        static const kern_t table[4][2][2] = {
+            {{modconv_wino2_kernel<1, false, false>, modconv_wino2_kernel<1, false, true>},
+             {modconv_wino2_kernel<1, true, false>, modconv_wino2_kernel<1, true, true>}},
+            {{modconv_wino2_kernel<2, false, false>, modconv_wino2_kernel<2, false, true>},
+             {modconv_wino2_kernel<2, true, false>, modconv_wino2_kernel<2, true, true>}},
+            {{modconv_wino2_kernel<4, false, false>, modconv_wino2_kernel<4, false, true>},
+             {modconv_wino2_kernel<4, true, false>, modconv_wino2_kernel<4, true, true>}},
+            {{modconv_wino2_kernel<8, false, false>, modconv_wino2_kernel<8, false, true>},
+             {modconv_wino2_kernel<8, true, false>, modconv_wino2_kernel<8, true, true>}}};
+        static bool table_attr[4][2][2] = {};
+        const int xi_log2 = tc.xt <= 256 ? 0 : tc.xt <= 512 ? 1 : tc.xt <= 1024 ? 2 : 3;
+        const kern_t kern = table[xi_log2][p.s ? 1 : 0][one_phase ? 1 : 0];
+        bool& have_attr = table_attr[xi_log2][p.s ? 1 : 0][one_phase ? 1 : 0];
+        if (!have_attr) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return sis_fail("modconv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+            have_attr = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid, p.ksplit), dim3(WNTHR), lds2, st, p, tc.xt, tpw, xcd_group);
     } else {
         sis_kernel_name = "modconv_wino_kernel";
         hipLaunchKernelGGL(modconv_wino_kernel, dim3((unsigned)blocks, p.ksplit), dim3(WNTHR), lds, st, p, tc.xt);
