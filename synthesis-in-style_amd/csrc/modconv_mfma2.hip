@@ -49,6 +49,15 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+// LDS-DMA through a buffer descriptor (see modconv_wino.hip): per-lane byte offset in a VGPR, wave-uniform offset in an
+// SGPR -- the per-chunk address arithmetic is scalar -- and out-of-range lanes get zeros written to their LDS slot.
+constexpr unsigned BUF_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ void bufld16(__amdgpu_buffer_rsrc_t r, float* l, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
+}
 
 template <int MODE, int KS, typename C>
 __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const ConvParams p, const int xt_max) {
@@ -61,11 +70,15 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
     float* Xl = lds + 2 * WF;          // [2][CC * xt]
     float* Sl = Xl + 2 * CC * xt_max;  // [nb][Cin]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave / C::WN;
     const int wn = wave % C::WN;
-    const int wbase = tid & ~63;  // wave-uniform: LDS-DMA destinations are base + lane * size
+    const int wbase = wave * 64;  // wave-uniform: LDS-DMA destinations are base + lane * size
+    // 8-wave layouts stage through buffer descriptors with the DMA instructions dealt evenly over the waves (BUF); the
+    // 4-wave layouts keep the flat-address DMA below.
+    constexpr bool BUF = NTHR == 512;
+    constexpr int NWAVES = NTHR / 64;
 
     // XCD-aware order: output-channel block fastest.  Workgroups are dealt round-robin over the 8 XCDs, so with
     // n_co = Cout / MBLK in {2,4,8} every XCD keeps working on the same weight slice (<= 2.4 MB: stays in its
@@ -127,7 +140,39 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
         w_goff[it] = (e < WV4 && o0 + q * 4 < p.Cout) ? row * p.Cout + o0 + q * 4 : -1;
     }
 
+    // BUF: input tile = xt / 4 float4 per channel in `xparts` parts of 64 lanes (power of two <= 8); wave w moves part
+    // w % xparts of the channels w / xparts + k * (8 / xparts).  One offset register, the same DMA count for every wave
+    // (with all input DMA on the first waves their SIMD finished each chunk last and the other three idled at the barrier).
+    const int xparts = xt <= 256 ? 1 : xt <= 512 ? 2 : xt <= 1024 ? 4 : 8;
+    const int x_part = wave & (xparts - 1), x_ch0 = wave / xparts, x_chstep = NWAVES / xparts;
+    const int x_f4 = x_part * 64 + lane;
+    const bool x_lane = x_f4 < (xt >> 2);
+    unsigned x_voff = BUF_OOB;
+    if (BUF && x_lane) {
+        const int ew4 = ew >> 2;
+        const int n = x_f4 / (eh * ew4), rem = x_f4 - n * (eh * ew4);
+        const int r = rem / ew4, c4 = rem - r * ew4;
+        const int b = b0 + n, h = h0 - C::PAD_LO + r, w = w0 - LP + 4 * c4;
+        if (b < p.B && h >= 0 && h < p.H && w >= 0 && w < p.W) x_voff = (unsigned)(n * p.Cin * HW + h * p.W + w) * 4u;
+    }
+    const __amdgpu_buffer_rsrc_t x_rsrc = dma_rsrc(p.x + (int64_t)b0 * p.Cin * HW);
+    const __amdgpu_buffer_rsrc_t w_rsrc = dma_rsrc(p.wpk + o0);
+    constexpr int WROW4 = C::MBLK / 4;  // float4 per weight row
+    static_assert(!BUF || ((C::CC * C::NTAPS * C::MBLK / 4) % 64 == 0 && NTHR % WROW4 == 0), "weight chunk must split into whole waves / rows");
+    const unsigned w_voff = (o0 + (tid % WROW4) * 4 < p.Cout) ? (unsigned)((tid / WROW4) * p.Cout + (tid % WROW4) * 4) * 4u : BUF_OOB;
+    auto stage_buf = [&](int ci0, int buf) {
+        float* wdst = Wl + buf * WF + wbase * 4;
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            if (it * NTHR + wbase < WV4)  // wave-uniform (WV4 % 64 == 0)
+                bufld16(w_rsrc, wdst + it * NTHR * 4, w_voff, (unsigned)((ci0 * C::NTAPS + it * (NTHR / WROW4)) * p.Cout) * 4u);
+        float* xdst = Xl + buf * CC * xt + x_part * 256;
+        if (x_lane) {
+            for (int j = x_ch0; j < CC; j += x_chstep) bufld16(x_rsrc, xdst + j * xt, x_voff, (unsigned)((ci0 + j) * HW) * 4u);
+        }
+    };
     auto stage = [&](int ci0, int buf) {
+        if (BUF) { stage_buf(ci0, buf); return; }
         const float* wsrc = p.wpk + (int64_t)ci0 * C::NTAPS * p.Cout;
         float* wdst = Wl + buf * WF + wbase * 4;
 #pragma unroll

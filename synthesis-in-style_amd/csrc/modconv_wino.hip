@@ -300,6 +300,14 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams
 // Development build only (tools/wino_trace.sh): per-wave cycle stamps of the steady-state chunk loop of 4 workgroups.
 constexpr int TR_WG0 = 500, TR_NWG = 4, TR_CHUNKS = 64, TR_SLOTS = 4;
 __device__ unsigned int sis_wino_trace[TR_NWG][8][TR_CHUNKS][TR_SLOTS];
+__device__ unsigned int sis_wino_trace_tile[TR_NWG][8][16][3];
+#define WINO_TRACE_TILE(slot)                                                                                     \
+    do {                                                                                                          \
+        if (blockIdx.y == 0 && blockIdx.x >= TR_WG0 && blockIdx.x < TR_WG0 + TR_NWG && k < 16) {                    \
+            const unsigned int now_ = (unsigned int)__builtin_readcyclecounter();                                 \
+            if (lane == 0) sis_wino_trace_tile[blockIdx.x - TR_WG0][wave][k][slot] = now_;                        \
+        }                                                                                                         \
+    } while (0)
 #define WINO_TRACE(slot)                                                                                          \
     do {                                                                                                          \
         if (tr_on && c < TR_CHUNKS) {                                                                             \
@@ -309,6 +317,7 @@ __device__ unsigned int sis_wino_trace[TR_NWG][8][TR_CHUNKS][TR_SLOTS];
     } while (0)
 #else
 #define WINO_TRACE(slot) do {} while (0)
+#define WINO_TRACE_TILE(slot) do {} while (0)
 #endif
 
 // Pipelined variant (default when its 158 KB of LDS fit): the input transform is done ONCE per (channel, tile) --
@@ -517,6 +526,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
                 for (int j = 0; j < 16; ++j) acc[i][jj][j] = 0.f;
 
         int c = 0;
+        WINO_TRACE_TILE(0);
 #ifdef SIS_WINO_TRACE
         const bool tr_on = k == 1 && blockIdx.y == 0 && blockIdx.x >= TR_WG0 && blockIdx.x < TR_WG0 + TR_NWG;
 #endif
@@ -624,6 +634,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
             __syncthreads();  // V(c+1) written, DMA retired, everyone done with U(c) / V(c)
         }
 
+        WINO_TRACE_TILE(1);
         // All staging buffers are idle now.  Start the next tile's first DMA before this tile's epilogue; the output
         // coordinates of THIS tile were taken above, its tail operands sit in LDS.
         const bool has_next = k + 1 < tiles_per_wg;
@@ -709,6 +720,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
         tail_store();
         transform(k_lo, 0, 0);
         __syncthreads();  // V(0) visible
+        WINO_TRACE_TILE(2);
     }
 }
 
@@ -717,6 +729,9 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
 #ifdef SIS_WINO_TRACE
 extern "C" int sis_wino_trace_read(unsigned int* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sis_wino_trace), sizeof(unsigned int) * TR_NWG * 8 * TR_CHUNKS * TR_SLOTS);
+}
+extern "C" int sis_wino_trace_tile_read(unsigned int* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sis_wino_trace_tile), sizeof(unsigned int) * TR_NWG * 8 * 16 * 3);
 }
 #endif
 
