@@ -51,6 +51,33 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const float* base) {
 __device__ __forceinline__ void bufld16(__amdgpu_buffer_rsrc_t r, float* l, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
 }
+// Packed fp32 VALU (two lanes of work per instruction), written as assembly because the compiler splits v2f32 arithmetic
+// back into scalar instructions.  np = (-1, 1).
+__device__ __forceinline__ f32x2 pk_lo_np_plus(f32x2 y, f32x2 np, f32x2 x) {  // (x.lo - y.lo, x.hi + y.lo)
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(y), "v"(np), "v"(x));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_hi_np_cross(f32x2 x, f32x2 np, f32x2 y) {  // (y.lo - x.hi, x.hi - y.hi)
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(np), "v"(y));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_scale(f32x2 a, f32x2 s_lo) {  // a * s_lo.lo
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(s_lo));
+    return r;
+}
 __device__ __forceinline__ void glds4(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 4, 0, 0);
@@ -325,6 +352,16 @@ __device__ unsigned int sis_wino_trace_tile[TR_NWG][8][16][3];
 // one chunk ahead of the MFMAs, so the matrix loop is nothing but ds_read_b32 pairs and MFMAs (in the kernel above
 // every patch is re-read and re-transformed by the 4 waves that share it: 48.5 % MFMA-busy measured).  Per
 // iteration c: DMA weights(c+1), DMA input(c+2), transform(c+1) -> V, MFMA(c); one barrier.
+// Step (0..15, one per MFMA pair) at which arithmetic slice `sl` of the pipelined transform is issued.
+#ifndef SIS_WINO_SCHED
+#define SIS_WINO_SCHED 0
+#endif
+__device__ constexpr int slice_step(int sl) {
+    return SIS_WINO_SCHED == 0   ? (sl < 4 ? 7 + sl / 2 : 10 + (sl - 4) / 4)   // bursts: steps 7, 8 | 10, 11
+           : SIS_WINO_SCHED == 1 ? 4 + sl                                       // one slice per step, steps 4..15
+           : SIS_WINO_SCHED == 2 ? (sl < 4 ? 14 : 15)                           // everything after the multiplies
+                                 : (sl < 4 ? 6 + sl / 2 : 8 + (sl - 4));        // A in two bursts, B one per step
+}
 // Template: XI = 64-lane parts of the input tile (power of two >= xt / 256), STYLED = modulated (style rows in LDS),
 // PIPE = single-phase software-pipelined chunk loop (see the loop) instead of the staggered two-phase one.
 template <int XI, bool STYLED, bool PIPE>
@@ -557,7 +594,14 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
                     ov[slot][0] = Vb[2 * cp * WTILES + (4 * i) * WCC * WTILES];
                     ov[slot][1] = Vb[2 * cp * WTILES + (4 * i + 1) * WCC * WTILES];
                 };
-                float sv = 1.f, d[4][4], tt[4];
+                // Transform of the next chunk's patch in packed fp32 (v_pk_*: two values per VALU instruction; VALU work is
+                // NOT hidden under a SIMD's MFMAs -- tools/micro/mfma_valu_overlap.hip -- so its instruction count is what
+                // costs).  Per patch ROW r the pairs X = (d_r0, d_r1), Y = (d_r2, d_r3) come from LDS (one ds_read2_b32 each):
+                // (d B)[r][0..1] = X + Y.lo * (-1, 1),  (d B)[r][2..3] = X.hi * (-1, 1) + (Y.lo, -Y.hi);  B^T then mixes the
+                // rows on those column pairs and the style scales the 8 output pairs: 24 VALU instructions per patch (48 scalar).
+                f32x2 sv2 = {1.f, 1.f};
+                f32x2 px[4], py[4], t01[4], t23[4];
+                const f32x2 negpos = {-1.f, 1.f};
                 operands(0, 0);  // operands run two steps ahead of their MFMAs
                 operands(1, 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -568,38 +612,46 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
                     const int i = st & 3, sl = st % 3;
                     acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ou[sl][0], ov[sl][0], acc[i][0], 0, 0, 0);
                     acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ou[sl][1], ov[sl][1], acc[i][1], 0, 0, 0);
+#ifndef SIS_WINO_NODMA
                     if (st == 0) stage_u(min(ci0 + WCC, k_last), nxt);
                     if (st == 1) stage_x(min(ci0 + 2 * WCC, k_last), cur);
-                    if (st == 2 || st == 3) {  // patch rows 2(st-2), 2(st-2)+1: columns 1..4 of the 8-byte aligned row start
-                        if (st == 2 && STYLED) sv = Sl[tso + tci];
+#endif
+#ifndef SIS_WINO_NOTRANSFORM
+                    if (st == 2 || st == 3) {  // patch rows 2(st-2), 2(st-2)+1 (the patch starts at column 1 of the aligned row)
+                        if (st == 2 && STYLED) sv2.x = Sl[tso + tci];
 #pragma unroll
                         for (int r = 2 * (st - 2); r < 2 * (st - 2) + 2; ++r) {
-                            d[r][0] = xb[r * ew + 1];
-                            const float2 mid = lds_ld2(xb + r * ew + 2);
-                            d[r][1] = mid.x; d[r][2] = mid.y;
-                            d[r][3] = xb[r * ew + 4];
+                            const float* row = xb + r * ew + 1;
+                            px[r] = f32x2{row[0], row[1]};
+                            py[r] = f32x2{row[2], row[3]};
                         }
                     }
-                    if (st >= 7 && st < 11) {  // patch row r, scaled by the style
-                        const int r = st - 7;
+                    // 12 arithmetic slices: 0..3 = d B of patch row r (2 VALU); 4..11 = one row i of B^T (d B) for the column
+                    // pair (0,1) / (2,3), scaled and written to the next chunk's V image (2 VALU + 1 LDS write)
 #pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) d[r][cc] *= sv;
+                    for (int sl_ = 0; sl_ < 12; ++sl_) {
+                        if (slice_step(sl_) != st) continue;
+                        if (sl_ < 4) {
+                            t01[sl_] = pk_lo_np_plus(py[sl_], negpos, px[sl_]);
+                            t23[sl_] = pk_hi_np_cross(px[sl_], negpos, py[sl_]);
+                        } else {
+                            const int h = (sl_ - 4) >> 2, i2 = (sl_ - 4) & 3, q0 = 2 * h;
+                            const f32x2* tq = h == 0 ? t01 : t23;
+                            const f32x2 o = pk_scale(i2 == 0 ? pk_sub(tq[0], tq[2]) : i2 == 1 ? pk_add(tq[1], tq[2]) : i2 == 2 ? pk_sub(tq[2], tq[1]) : pk_sub(tq[1], tq[3]), sv2);
+                            vw[(i2 * 4 + q0) * WCC * WTILES] = o.x;
+                            vw[(i2 * 4 + q0 + 1) * WCC * WTILES] = o.y;
+                        }
                     }
-                    if (st >= 11 && st < 15) {  // row r of B^T d, times B, into the V image of the next chunk
-                        const int r = st - 11;
-#pragma unroll
-                        for (int cc = 0; cc < 4; ++cc)
-                            tt[cc] = r == 0 ? d[0][cc] - d[2][cc] : r == 1 ? d[1][cc] + d[2][cc] : r == 2 ? d[2][cc] - d[1][cc] : d[1][cc] - d[3][cc];
-                        vw[(r * 4 + 0) * WCC * WTILES] = tt[0] - tt[2];
-                        vw[(r * 4 + 1) * WCC * WTILES] = tt[1] + tt[2];
-                        vw[(r * 4 + 2) * WCC * WTILES] = tt[2] - tt[1];
-                        vw[(r * 4 + 3) * WCC * WTILES] = tt[1] - tt[3];
-                    }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 WINO_TRACE(2);
                 WINO_TRACE(3);
+#ifdef SIS_WINO_NOBARRIER  // timing experiment only (results are garbage): what does the per-chunk barrier cost?
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
                 __syncthreads();  // V(c+1) written, DMA retired, everyone done with U(c) / V(c)
+#endif
             }
         } else
         for (int ci0 = k_lo; ci0 < k_hi; ci0 += WCC, ++c) {
@@ -643,6 +695,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
         if (has_next) {
             tile_setup(pt_first + (k + 1) * pt_step);
             tile_first_dma();
+            tail_load();  // its global-load latency hides under this tile's epilogue
         }
 
         // ---- epilogue.  m[r][jj] = (A^T M)[r][column 2q+jj];  Y[r][0] = m0 + m1 + m2,  Y[r][1] = m1 - m2 - m3.
@@ -715,7 +768,6 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
             }
         }
         if (!has_next) break;
-        tail_load();
         __syncthreads();  // next tile: chunk 0 (and input chunk 1) landed; everyone is done with the exchange area
         tail_store();
         transform(k_lo, 0, 0);

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "synthesis-in-style_amd"))
 import torch  # noqa: E402
 import sis_hip  # noqa: E402
 
-sis_hip.LIB_PATH = os.path.join(ROOT, "synthesis-in-style_amd", "lib", "libsis_hip_trace.so")
+sis_hip.LIB_PATH = os.path.join(ROOT, "synthesis-in-style_amd", "lib", "libsis_hip_trace%s.so" % os.environ.get("SIS_TRACE_SUFFIX", ""))
 h = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 cin = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 cout = int(sys.argv[3]) if len(sys.argv) > 3 else 512
