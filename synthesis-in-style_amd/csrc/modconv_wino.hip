@@ -4,7 +4,9 @@
 // the remaining lever is the amount of MFMA work: F(2x2,3x3) produces a 2x2 output tile from 16 multiplies per
 // (co, ci) instead of 36, i.e. 2.25x fewer matrix FLOPs for the 7 stride-1 layers (64.4 of the 90.2 GFLOP/image).
 //
-//   U[ci][xi][co] = (G g G^T)[xi]        prepacked once per checkpoint (sis_modconv_prepack_wino)
+//   U[ci][xi][co] = (G g G^T)[xi]        prepacked once per checkpoint (sis_modconv_prepack_wino); stored as
+//                                        [ci][q][ih][co][il][jj] with xi = 4 (2 ih + il) + 2 q + jj, so that the four
+//                                        A operands a lane needs for two Winograd rows sit in ONE 16-byte LDS read
 //   V[xi]         = (B^T d B)[xi]        per lane, in registers: the lane owning tile t (= MFMA column) and
 //                                        channel 2cp + (lane>>5) reads its 4x4 input patch d from the raw LDS
 //                                        tile (8 x ds_read_b64), scales it by the style s[b,ci] and does the
@@ -36,6 +38,9 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 // info is what tells it otherwise -- float2 (a struct) aliases everything, which stalled every chunk on the DMA it
 // had just issued; float and double reads do not.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 lds_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }  // ds_read_b128, typed like lds_ld2
+__device__ __forceinline__ void lds_st4(float* p, f32x2 a, f32x2 b) { *reinterpret_cast<f32x4*>(p) = f32x4{a.x, a.y, b.x, b.y}; }
 __device__ __forceinline__ float2 lds_ld2(const float* p) {
     const f32x2 d = *reinterpret_cast<const f32x2*>(p);
     return make_float2(d.x, d.y);
@@ -83,7 +88,7 @@ __device__ __forceinline__ void glds4(const float* g, float* l) {
                                      (__attribute__((address_space(3))) void*)l, 4, 0, 0);
 }
 
-// u[ci][xi][co] from w[co][ci][3][3]
+// u[ci][q][ih][co][il][jj] (xi = 4 (2 ih + il) + 2 q + jj) from w[co][ci][3][3]
 // ADJOINT = true builds the weights of the data gradient instead: the convolution that maps dL/dy back to dL/dx
 // uses w'[ci][co][r][c] = w[co][ci][2-r][2-c] (roles of the channel axes swapped, taps rotated by 180 degrees);
 // `cout` / `cin` are then the output / input channels of THAT convolution (= cin / cout of w's own layout).
@@ -111,7 +116,8 @@ __global__ __launch_bounds__(256) void wino_prepack_kernel(float* __restrict__ u
         const float a = t[r][0], b = t[r][1], c = t[r][2];
         const float o[4] = {a, 0.5f * (a + b + c), 0.5f * (a - b + c), c};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) u[((int64_t)ci * 16 + r * 4 + q) * cout + co] = o[q];
+        for (int j = 0; j < 4; ++j)  // xi = 4 r + j;  r = 2 ih + il,  j = 2 q + jj  ->  [ci][q][ih][co][il][jj]
+            u[(((int64_t)ci * 2 + (j >> 1)) * 2 + (r >> 1)) * cout * 4 + (int64_t)co * 4 + (r & 1) * 2 + (j & 1)] = o[j];
     }
 }
 
@@ -172,13 +178,14 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams
             if (b < p.B && h >= 0 && h < p.H && w >= 0 && w < p.W) st_goff = b * p.Cin * HW + h * p.W + w;
         }
     }
+    // weights of a chunk: 32 rows (ci, q, ih) x 64 co x 4 floats; float4 e = it * 512 + tid sits in row e / 64 at co e % 64
     constexpr int WV4 = WF / 4, WIT = WV4 / WNTHR;  // 4 float4 per lane per chunk
     int w_goff[WIT];
 #pragma unroll
     for (int it = 0; it < WIT; ++it) {
         const int e = it * WNTHR + tid;
-        const int row = e / (WMBLK / 4), qq = e - row * (WMBLK / 4);
-        w_goff[it] = (o0 + qq * 4 < p.Cout) ? row * p.Cout + o0 + qq * 4 : -1;
+        const int row = e / WMBLK, co = e - row * WMBLK;
+        w_goff[it] = (o0 + co < p.Cout) ? (row * p.Cout + o0 + co) * 4 : -1;
     }
     auto stage = [&](int ci0, int buf) {
         const float* usrc = p.wpk + (int64_t)ci0 * 16 * p.Cout;
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams
     const int ty = trem >> (twl - 1), tx = trem & ((tw >> 1) - 1);
     const int xo = min(tn, tc.nb - 1) * eh * ew + 2 * ty * ew + 2 * tx + 2 + half * xt;  // even: 8-byte aligned reads
     const int so = min(tn, tc.nb - 1) * p.Cin + half;
-    const int aoff = half * 16 * WMBLK + wm * 32 + l31 + 2 * q * WMBLK;  // + (4 i + jj) * WMBLK
+    const int aoff = (half * 4 + q * 2) * (WMBLK * 4) + (wm * 32 + l31) * 4;  // + (8 cp + ih) * WMBLK * 4: float4 (il, jj)
 
     f32x16 acc[4][2];  // [row i of M][column jj of this wave's pair]
 #pragma unroll
@@ -239,7 +246,9 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams
                 tt[2][c] = d[2][c] - d[1][c];
                 tt[3][c] = d[1][c] - d[3][c];
             }
-            const float* ub = Ub + 2 * cp * 16 * WMBLK;
+            const f32x4 ua0 = lds_ld4(Ub + (8 * cp) * WMBLK * 4);      // rows i = 0, 1
+            const f32x4 ua1 = lds_ld4(Ub + (8 * cp + 1) * WMBLK * 4);  // rows i = 2, 3
+            const float ua[4][2] = {{ua0.x, ua0.y}, {ua0.z, ua0.w}, {ua1.x, ua1.y}, {ua1.z, ua1.w}};
             float v0[4], v1[4];
             if (q == 0) {  // wave-uniform: this wave's two columns of (B^T d) B, scaled by the style
 #pragma unroll
@@ -250,8 +259,8 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[(4 * i) * WMBLK], v0[i], acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[(4 * i + 1) * WMBLK], v1[i], acc[i][1], 0, 0, 0);
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[i][0], v0[i], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[i][1], v1[i], acc[i][1], 0, 0, 0);
             }
         }
         __syncthreads();
@@ -352,23 +361,12 @@ __device__ unsigned int sis_wino_trace_tile[TR_NWG][8][16][3];
 // one chunk ahead of the MFMAs, so the matrix loop is nothing but ds_read_b32 pairs and MFMAs (in the kernel above
 // every patch is re-read and re-transformed by the 4 waves that share it: 48.5 % MFMA-busy measured).  Per
 // iteration c: DMA weights(c+1), DMA input(c+2), transform(c+1) -> V, MFMA(c); one barrier.
-// Step (0..15, one per MFMA pair) at which arithmetic slice `sl` of the pipelined transform is issued.
-#ifndef SIS_WINO_SCHED
-#define SIS_WINO_SCHED 0
-#endif
-__device__ constexpr int slice_step(int sl) {
-    return SIS_WINO_SCHED == 0   ? (sl < 4 ? 7 + sl / 2 : 10 + (sl - 4) / 4)   // bursts: steps 7, 8 | 10, 11
-           : SIS_WINO_SCHED == 1 ? 4 + sl                                       // one slice per step, steps 4..15
-           : SIS_WINO_SCHED == 2 ? (sl < 4 ? 14 : 15)                           // everything after the multiplies
-                                 : (sl < 4 ? 6 + sl / 2 : 8 + (sl - 4));        // A in two bursts, B one per step
-}
-// Template: XI = 64-lane parts of the input tile (power of two >= xt / 256), STYLED = modulated (style rows in LDS),
-// PIPE = single-phase software-pipelined chunk loop (see the loop) instead of the staggered two-phase one.
-template <int XI, bool STYLED, bool PIPE>
+// Template: XI = 64-lane parts of the input tile (power of two >= xt / 256), STYLED = modulated (style rows in LDS).
+template <int XI, bool STYLED>
 __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParams p, const int xt_max, const int tiles_per_wg, const int xcd_group) {
     constexpr int WF = WCC * 16 * WMBLK;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int VF = 16 * WCC * WTILES;  // transformed input of one chunk: [xi][channel][tile]
+    constexpr int VF = 16 * WCC * WTILES;  // transformed input of one chunk: [channel][q][ih][tile][il][jj] (as the weights)
     float* Ul = lds;                    // [2][WF]   (64 KB)
     float* Vl = lds + 2 * WF;           // [2][VF]   (64 KB; reused for the column exchange in the epilogue)
     float* Xl = Vl + 2 * VF;            // [2][WCC * xt]
@@ -439,15 +437,17 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     // more fetched bytes).
     const int pt_first = wg / n_co, pt_step = gridDim.x / n_co;
     tile_setup(pt_first);
-    // weights: chunk = 128 rows (ci, xi) x 64 co = 2048 float4; lane e = it * 512 + tid takes row e / 16, float4 e % 16
+    // weights: chunk = 32 rows (ci, q, ih) of 64 co x 4 floats = one 1 KB DMA instruction per row, 4 rows per wave
+    // (row = it * 8 + wave); every lane moves the float4 of output channel o0 + lane
     constexpr int WIT = WF / 4 / WNTHR;
-    const __amdgpu_buffer_rsrc_t u_rsrc = dma_rsrc(p.wpk + o0);
-    const unsigned u_voff = (o0 + (tid & 15) * 4 < p.Cout) ? (unsigned)((tid >> 4) * p.Cout + (tid & 15) * 4) * 4u : BUF_OOB;
+    const __amdgpu_buffer_rsrc_t u_rsrc = dma_rsrc(p.wpk + (int64_t)o0 * 4);
+    const unsigned u_voff = (o0 + lane < p.Cout) ? (unsigned)lane * 16u : BUF_OOB;
+    const unsigned u_row_bytes = (unsigned)p.Cout * 16u;
     auto stage_u = [&](int ci0, int buf) {
         float* udst = Ul + buf * WF + wave * 256;
+        const unsigned s0 = (unsigned)(ci0 * 4 + wave) * u_row_bytes;
 #pragma unroll
-        for (int it = 0; it < WIT; ++it)
-            bufld16(u_rsrc, udst + it * WNTHR * 4, u_voff, (unsigned)((ci0 * 16 + it * (WNTHR / 16)) * p.Cout) * 4u);
+        for (int it = 0; it < WIT; ++it) bufld16(u_rsrc, udst + it * 8 * 256, u_voff, s0 + (unsigned)(it * 8) * u_row_bytes);
     };
     auto stage_x = [&](int ci0, int buf) {
         float* xdst = Xl + buf * WCC * xt + x_base;
@@ -457,39 +457,41 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
             bufld16(x_rsrc, xdst + j * xt, x_voff, (unsigned)((ci0 + j) * HW) * 4u);
         }
     };
+    auto stage_u_piece = [&](int ci0, int buf, int it) {  // one 1 KB DMA instruction of stage_u
+        bufld16(u_rsrc, Ul + buf * WF + wave * 256 + it * 8 * 256, u_voff, (unsigned)(ci0 * 4 + wave + it * 8) * u_row_bytes);
+    };
+    auto stage_x_piece = [&](int ci0, int buf, int k) {  // one DMA instruction of stage_x
+        const int j = x_ch0 + k * x_chstep;
+        bufld16(x_rsrc, Xl + buf * WCC * xt + x_base + j * xt, x_voff, (unsigned)((ci0 + j) * HW) * 4u);
+    };
     // Input transform, ONE patch per lane per chunk: lane = tile (0..63), wave = channel of the chunk.  V = B^T d B
-    // scaled by the style of the tile's sample, written as [xi][channel][tile] (lane-contiguous ds_write_b32).
+    // scaled by the style of the tile's sample, written as [channel][q][ih][tile][il][jj] (xi = 4 (2 ih + il) + 2 q + jj):
+    // four 16-byte LDS writes per patch, lane-contiguous.  Packed fp32 arithmetic, see the chunk loop.
     const int ttile = lane, tch = wave;
     const int ttn = ttile >> tpl0, ttrem = ttile & ((1 << tpl0) - 1);
     const int tty = ttrem >> (twl - 1), ttx = ttrem & ((tw >> 1) - 1);
     const int txo = min(ttn, tc.nb - 1) * eh * ew + 2 * tty * ew + 2 * ttx + 2 + tch * xt;
     const int tso = min(ttn, tc.nb - 1) * p.Cin + tch;
+    const int tvo = tch * (16 * WTILES) + ttile * 4;  // + (2 q + ih) * WTILES * 4
+    const f32x2 negpos = {-1.f, 1.f};
     auto transform = [&](int ci0, int xbuf, int vbuf) {
-        const float sv = STYLED ? Sl[tso + ci0] : 1.f;
-        const float* xb = Xl + xbuf * WCC * xt + txo;
-        float d[4][4];
+        f32x2 sv2 = {1.f, 1.f};
+        if (STYLED) sv2.x = Sl[tso + ci0];
+        const float* xb = Xl + xbuf * WCC * xt + txo + 1;
+        f32x2 t01[4], t23[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float2 a0 = lds_ld2(xb + r * ew);
-            const float2 a1 = lds_ld2(xb + r * ew + 2);
-            const float2 a2 = lds_ld2(xb + r * ew + 4);
-            d[r][0] = a0.y * sv; d[r][1] = a1.x * sv; d[r][2] = a1.y * sv; d[r][3] = a2.x * sv;
+            const f32x2 px = {xb[r * ew], xb[r * ew + 1]}, py = {xb[r * ew + 2], xb[r * ew + 3]};
+            t01[r] = pk_lo_np_plus(py, negpos, px);
+            t23[r] = pk_hi_np_cross(px, negpos, py);
         }
-        float tt[4][4];
+        float* vb = Vl + vbuf * VF + tvo;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            tt[0][c] = d[0][c] - d[2][c];
-            tt[1][c] = d[1][c] + d[2][c];
-            tt[2][c] = d[2][c] - d[1][c];
-            tt[3][c] = d[1][c] - d[3][c];
-        }
-        float* vb = Vl + vbuf * VF + tch * WTILES + ttile;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            vb[(r * 4 + 0) * WCC * WTILES] = tt[r][0] - tt[r][2];
-            vb[(r * 4 + 1) * WCC * WTILES] = tt[r][1] + tt[r][2];
-            vb[(r * 4 + 2) * WCC * WTILES] = tt[r][2] - tt[r][1];
-            vb[(r * 4 + 3) * WCC * WTILES] = tt[r][1] - tt[r][3];
+        for (int h = 0; h < 2; ++h) {  // column pair (2h, 2h+1) = q
+            const f32x2* tq = h == 0 ? t01 : t23;
+            const f32x2 a0_ = pk_sub(tq[0], tq[2]), a1_ = pk_add(tq[1], tq[2]), a2_ = pk_sub(tq[2], tq[1]), a3_ = pk_sub(tq[1], tq[3]);
+            lds_st4(vb + (2 * h) * WTILES * 4, pk_scale(a0_, sv2), pk_scale(a1_, sv2));      // rows i = 0, 1
+            lds_st4(vb + (2 * h + 1) * WTILES * 4, pk_scale(a2_, sv2), pk_scale(a3_, sv2));  // rows i = 2, 3
         }
     };
 
@@ -497,18 +499,12 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     const int t = wn * 32 + l31;
     const int tn = t >> tpl, trem = t & ((1 << tpl) - 1);
     const int ty = trem >> (twl - 1), tx = trem & ((tw >> 1) - 1);
-    const int aoff = half * 16 * WMBLK + wm * 32 + l31 + 2 * q * WMBLK;  // + (4 i + jj) * WMBLK
+    // A / B operands of this lane: float4 (il, jj) of row (channel 2 cp + half, q, ih) at column co / tile
+    const int aoff = (half * 4 + q * 2) * (WMBLK * 4) + (wm * 32 + l31) * 4;    // + (8 cp + ih) * WMBLK * 4
+    const int voff = (half * 4 + q * 2) * (WTILES * 4) + (wn * 32 + l31) * 4;   // + (8 cp + ih) * WTILES * 4
 
     f32x16 acc[4][2];  // [row i of M][column jj of this wave's pair]
-
-    // B operand of this lane in the V image: [xi][channel 2cp + half][tile wn*32 + l31]
-    const int voff = half * WTILES + wn * 32 + l31 + 2 * q * WCC * WTILES;  // + (4 i + jj) * WCC*WTILES + 2cp*WTILES
     const bool partial = p.ksplit > 1;
-#ifdef SIS_WINO_NOSTAGGER
-    const bool late_transform = false;
-#else
-    const bool late_transform = wave >= 4;
-#endif
 
     // First DMA of a tile: every global access of the start-up is in flight before the first wait (one memory
     // round trip).  Out-of-image float4 slots get their zeros from the DMA itself (out-of-range buffer offsets).
@@ -562,128 +558,118 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[i][jj][j] = 0.f;
 
-        int c = 0;
         WINO_TRACE_TILE(0);
 #ifdef SIS_WINO_TRACE
         const bool tr_on = k == 1 && blockIdx.y == 0 && blockIdx.x >= TR_WG0 && blockIdx.x < TR_WG0 + TR_NWG;
 #endif
-        // Single-phase software-pipelined chunk (PIPE).  Measured on the staggered loop below (tools/wino_trace.py): a wave
-        // that transforms while its SIMD partner streams MFMAs needs ~2800 cycles for ~60 instructions (LDS round trips
-        // and VALU issue both crawl), so the two waves of a SIMD ended up multiplying one after the other.  Here every
-        // wave runs ONE straight-line block per chunk: DMA (scalar address arithmetic only), the 12 patch reads of its
-        // transform (their latency hides under the first multiplies), then 16 steps of { operand reads of the next step,
-        // 2 MFMAs, a slice of the transform arithmetic / its LDS writes }.  No branch, no wait that is not covered.
+        // Single-phase software-pipelined chunk.  Measured (tools/wino_trace.py, tools/micro/mfma_valu_overlap.hip): on this
+        // SIMD nothing a wave issues is hidden under the matrix pipe -- a chunk costs 64 MFMAs x 64 cycles plus ~5 cycles
+        // for EVERY other instruction of its two waves -- and a wave that transforms while its partner multiplies crawls
+        // (the staggered two-phase loop of round 1 had the partners multiplying one after the other).  So every wave runs
+        // ONE straight-line block per chunk with as few instructions as the data flow allows: 16-byte operand reads (one
+        // per operand per two MFMA pairs), the DMA with scalar addressing, the transform in packed fp32 with 16-byte
+        // writes, buffer parity known at compile time (two chunks per loop trip: LDS addresses are immediates).
         // The last chunks clamp their prefetch indices: they re-stage the final chunk into buffers nobody reads any more.
-        if (PIPE) {
-            const int k_last = k_hi - WCC;
-            const float* xbt = Xl + txo;
-            float* vbt = Vl + tch * WTILES + ttile;
-            for (int ci0 = k_lo; ci0 < k_hi; ci0 += WCC, ++c) {
-                const int cur = c & 1, nxt = cur ^ 1;
-                WINO_TRACE(0);
-                const int tci = min(ci0 + WCC, k_last);
-                const float* xb = xbt + nxt * WCC * xt;
-                const float* Ub = Ul + cur * WF + aoff;
-                const float* Vb = Vl + cur * VF + voff;
-                float* vw = vbt + nxt * VF;
-                float ou[3][2], ov[3][2];
-                auto operands = [&](int st, int slot) {  // step st = (cp, i): two MFMAs (jj = 0, 1)
-                    const int cp = st >> 2, i = st & 3;
-                    ou[slot][0] = Ub[2 * cp * 16 * WMBLK + (4 * i) * WMBLK];
-                    ou[slot][1] = Ub[2 * cp * 16 * WMBLK + (4 * i + 1) * WMBLK];
-                    ov[slot][0] = Vb[2 * cp * WTILES + (4 * i) * WCC * WTILES];
-                    ov[slot][1] = Vb[2 * cp * WTILES + (4 * i + 1) * WCC * WTILES];
-                };
-                // Transform of the next chunk's patch in packed fp32 (v_pk_*: two values per VALU instruction; VALU work is
-                // NOT hidden under a SIMD's MFMAs -- tools/micro/mfma_valu_overlap.hip -- so its instruction count is what
-                // costs).  Per patch ROW r the pairs X = (d_r0, d_r1), Y = (d_r2, d_r3) come from LDS (one ds_read2_b32 each):
-                // (d B)[r][0..1] = X + Y.lo * (-1, 1),  (d B)[r][2..3] = X.hi * (-1, 1) + (Y.lo, -Y.hi);  B^T then mixes the
-                // rows on those column pairs and the style scales the 8 output pairs: 24 VALU instructions per patch (48 scalar).
-                f32x2 sv2 = {1.f, 1.f};
-                f32x2 px[4], py[4], t01[4], t23[4];
-                const f32x2 negpos = {-1.f, 1.f};
-                operands(0, 0);  // operands run two steps ahead of their MFMAs
-                operands(1, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                WINO_TRACE(1);
-#pragma unroll
-                for (int st = 0; st < 16; ++st) {
-                    if (st < 14) operands(st + 2, (st + 2) % 3);
-                    const int i = st & 3, sl = st % 3;
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ou[sl][0], ov[sl][0], acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ou[sl][1], ov[sl][1], acc[i][1], 0, 0, 0);
-#ifndef SIS_WINO_NODMA
-                    if (st == 0) stage_u(min(ci0 + WCC, k_last), nxt);
-                    if (st == 1) stage_x(min(ci0 + 2 * WCC, k_last), cur);
-#endif
-#ifndef SIS_WINO_NOTRANSFORM
-                    if (st == 2 || st == 3) {  // patch rows 2(st-2), 2(st-2)+1 (the patch starts at column 1 of the aligned row)
-                        if (st == 2 && STYLED) sv2.x = Sl[tso + tci];
-#pragma unroll
-                        for (int r = 2 * (st - 2); r < 2 * (st - 2) + 2; ++r) {
-                            const float* row = xb + r * ew + 1;
-                            px[r] = f32x2{row[0], row[1]};
-                            py[r] = f32x2{row[2], row[3]};
-                        }
-                    }
-                    // 12 arithmetic slices: 0..3 = d B of patch row r (2 VALU); 4..11 = one row i of B^T (d B) for the column
-                    // pair (0,1) / (2,3), scaled and written to the next chunk's V image (2 VALU + 1 LDS write)
-#pragma unroll
-                    for (int sl_ = 0; sl_ < 12; ++sl_) {
-                        if (slice_step(sl_) != st) continue;
-                        if (sl_ < 4) {
-                            t01[sl_] = pk_lo_np_plus(py[sl_], negpos, px[sl_]);
-                            t23[sl_] = pk_hi_np_cross(px[sl_], negpos, py[sl_]);
-                        } else {
-                            const int h = (sl_ - 4) >> 2, i2 = (sl_ - 4) & 3, q0 = 2 * h;
-                            const f32x2* tq = h == 0 ? t01 : t23;
-                            const f32x2 o = pk_scale(i2 == 0 ? pk_sub(tq[0], tq[2]) : i2 == 1 ? pk_add(tq[1], tq[2]) : i2 == 2 ? pk_sub(tq[2], tq[1]) : pk_sub(tq[1], tq[3]), sv2);
-                            vw[(i2 * 4 + q0) * WCC * WTILES] = o.x;
-                            vw[(i2 * 4 + q0 + 1) * WCC * WTILES] = o.y;
-                        }
-                    }
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                WINO_TRACE(2);
-                WINO_TRACE(3);
-#ifdef SIS_WINO_NOBARRIER  // timing experiment only (results are garbage): what does the per-chunk barrier cost?
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-                __syncthreads();  // V(c+1) written, DMA retired, everyone done with U(c) / V(c)
-#endif
-            }
-        } else
-        for (int ci0 = k_lo; ci0 < k_hi; ci0 += WCC, ++c) {
-            const int cur = c & 1, nxt = cur ^ 1;
+        const int k_last = k_hi - WCC;
+        // One slot after each of the 32 MFMAs.  Issue costs add up inside an MFMA gap and only ~48 cycles of them hide under a
+        // 64-cycle MFMA (MI355X_MICROARCH.md, constants: an LDS-DMA piece costs 60-185 cycles to issue, a packed-f32 VALU
+        // instruction ~3x a scalar one), so the side work is spread one expensive item per slot, and the two waves of a SIMD
+        // (w, w + 4) run different placements (`late`): one issues its DMA while the other is between its own pieces.
+        auto chunk = [&](auto parity, auto late_c, const int ci0, const int c) {
+            constexpr int cur = decltype(parity)::value, nxt = cur ^ 1;
+            constexpr bool LATE = decltype(late_c)::value;
             WINO_TRACE(0);
-            if (ci0 + WCC < k_hi) stage_u(ci0 + WCC, nxt);          // weights lead by one chunk
-#ifndef SIS_WINO_XLATE
-            if (ci0 + 2 * WCC < k_hi) stage_x(ci0 + 2 * WCC, cur);   // input leads by two (its transform sits in between)
-#endif
-            // Stagger the two waves that share a SIMD (waves w and w+4): one transforms first and multiplies second,
-            // its partner the other way round, so the matrix pipe is not left idle while both do their transform.
-            if (!late_transform && ci0 + WCC < k_hi) transform(ci0 + WCC, nxt, nxt);
-            WINO_TRACE(1);
-#ifdef SIS_WINO_XLATE
-            if (ci0 + 2 * WCC < k_hi) stage_x(ci0 + 2 * WCC, cur);
-#endif
+            const int tci = min(ci0 + WCC, k_last);
+            const int uci = min(ci0 + WCC, k_last), xci = min(ci0 + 2 * WCC, k_last);
+            const float* xb = Xl + nxt * WCC * xt + txo + 1;
             const float* Ub = Ul + cur * WF + aoff;
             const float* Vb = Vl + cur * VF + voff;
+            float* vw = Vl + nxt * VF + tvo;
+            f32x4 ou[3], ov[3];
+            auto operands = [&](int g, int slot) {  // group g = (cp, ih): MFMA rows i = 2 ih, 2 ih + 1, both jj
+                ou[slot] = lds_ld4(Ub + (8 * (g >> 1) + (g & 1)) * WMBLK * 4);
+                ov[slot] = lds_ld4(Vb + (8 * (g >> 1) + (g & 1)) * WTILES * 4);
+            };
+            float sv = 1.f, d[4][4], e[4][4], o[4][4];  // patch, d B, B^T (d B) scaled
+            // slot tables: first slot of each kind of side work
+            constexpr int X_STEP = XI > 2 ? 1 : 2;  // input pieces every (second) slot, weight pieces every second slot
+            constexpr int S_XDMA = LATE ? 16 : 8, S_UDMA = LATE ? S_XDMA + X_STEP * XI : 0;
+            static_assert(S_UDMA + 2 * (WIT - 1) < 32 && S_XDMA + X_STEP * (XI - 1) < 32, "DMA pieces must fit the 32 slots");
+            constexpr int S_READ = LATE ? 0 : 1;    // patch rows: 4 slots, every second slot for the early half
+            constexpr int S_RSTEP = LATE ? 1 : 2;
+            constexpr int S_A = LATE ? 4 : 11;      // d B: 4 slots
+            constexpr int S_B = LATE ? 8 : 15;      // B^T (d B) and scale, column j: slots S_B + 2 j, S_B + 2 j + 1; writes follow
+            operands(0, 0);  // operands run two groups (four MFMA pairs) ahead
+            operands(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            WINO_TRACE(1);
 #pragma unroll
-            for (int cp = 0; cp < WCC / 2; ++cp) {
-                const float* ub = Ub + 2 * cp * 16 * WMBLK;
-                const float* vb = Vb + 2 * cp * WTILES;
+            for (int sl = 0; sl < 32; ++sl) {
+                const int g = sl >> 2, part = sl & 3, slot = g % 3;
+                const int i = 2 * (g & 1) + (part >> 1), jj = part & 1;
+                const float ua = part == 0 ? ou[slot].x : part == 1 ? ou[slot].y : part == 2 ? ou[slot].z : ou[slot].w;
+                const float va = part == 0 ? ov[slot].x : part == 1 ? ov[slot].y : part == 2 ? ov[slot].z : ov[slot].w;
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua, va, acc[i][jj], 0, 0, 0);
+                if (part == 1 && g < 6) operands(g + 2, (g + 2) % 3);
+#ifndef SIS_WINO_NODMA
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[(4 * i) * WMBLK], vb[(4 * i) * WCC * WTILES], acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[(4 * i + 1) * WMBLK], vb[(4 * i + 1) * WCC * WTILES], acc[i][1], 0, 0, 0);
+                for (int it = 0; it < WIT; ++it)
+                    if (sl == S_UDMA + 2 * it) stage_u_piece(uci, nxt, it);
+#pragma unroll
+                for (int kx = 0; kx < XI; ++kx)
+                    if (sl == S_XDMA + X_STEP * kx) stage_x_piece(xci, cur, kx);
+#endif
+#ifndef SIS_WINO_NOTRANSFORM
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (sl == S_READ + S_RSTEP * r) {  // patch row r: columns 1..4 of the 8-byte aligned row start
+                        if (r == 0 && STYLED) sv = Sl[tso + tci];
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) d[r][cc] = xb[r * ew + cc];
+                    }
+                    if (sl == S_A + r) {  // (d B)[r][.]
+                        e[r][0] = d[r][0] - d[r][2]; e[r][1] = d[r][1] + d[r][2]; e[r][2] = d[r][2] - d[r][1]; e[r][3] = d[r][1] - d[r][3];
+                    }
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (sl == S_B + 2 * j) {
+                        o[0][j] = e[0][j] - e[2][j]; o[1][j] = e[1][j] + e[2][j]; o[2][j] = e[2][j] - e[1][j]; o[3][j] = e[1][j] - e[3][j];
+                    }
+                    if (sl == S_B + 2 * j + 1) {
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii) o[ii][j] *= sv;
+                        if (j & 1) {  // column pair q = j / 2 complete: rows (0,1) and (2,3) as two 16-byte writes
+                            const int qq = j >> 1;
+                            *reinterpret_cast<f32x4*>(vw + (2 * qq) * WTILES * 4) = f32x4{o[0][j - 1], o[0][j], o[1][j - 1], o[1][j]};
+                            *reinterpret_cast<f32x4*>(vw + (2 * qq + 1) * WTILES * 4) = f32x4{o[2][j - 1], o[2][j], o[3][j - 1], o[3][j]};
+                        }
+                    }
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
             }
             WINO_TRACE(2);
-            if (late_transform && ci0 + WCC < k_hi) transform(ci0 + WCC, nxt, nxt);
             WINO_TRACE(3);
+#ifdef SIS_WINO_NOBARRIER  // timing experiment only (results are garbage): what does the per-chunk barrier cost?
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
             __syncthreads();  // V(c+1) written, DMA retired, everyone done with U(c) / V(c)
+#endif
+        };
+        // (Giving waves 4-7 the `late` placement -- their DMA in the second half of the chunk, while their SIMD partners are
+        // between pieces -- measured 6-8 % SLOWER on the same device: the late pieces are not landed at the barrier.)
+#ifdef SIS_WINO_STAGGER
+        if (wave >= 4) {
+            for (int ci0 = k_lo, c = 0; ci0 < k_hi; ci0 += 2 * WCC, c += 2) {
+                chunk(std::integral_constant<int, 0>(), std::true_type(), ci0, c);
+                if (ci0 + WCC < k_hi) chunk(std::integral_constant<int, 1>(), std::true_type(), ci0 + WCC, c + 1);
+            }
+        } else
+#endif
+        for (int ci0 = k_lo, c = 0; ci0 < k_hi; ci0 += 2 * WCC, c += 2) {
+            chunk(std::integral_constant<int, 0>(), std::false_type(), ci0, c);
+            if (ci0 + WCC < k_hi) chunk(std::integral_constant<int, 1>(), std::false_type(), ci0 + WCC, c + 1);
         }
 
         WINO_TRACE_TILE(1);
@@ -856,22 +842,15 @@ int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t 
         const int64_t grid = blocks / tpw;
         const int n_co_h = (p.Cout + WMBLK - 1) / WMBLK;
         const int xcd_group = (double)p.Cin * p.Cout * 16 * sizeof(float) <= swz_mb * 1048576.0 && n_co_h > 1 && grid % (8 * n_co_h) == 0;
-        // single-phase software-pipelined chunk loop (default) or the staggered two-phase loop (SIS_WINO_PHASES=2)
-        static const bool one_phase = !(getenv("SIS_WINO_PHASES") && getenv("SIS_WINO_PHASES")[0] == '2');
         typedef void (*kern_t)(const ConvParams, const int, const int, const int);
-        static const kern_t table[4][2][2] = {
-            {{modconv_wino2_kernel<1, false, false>, modconv_wino2_kernel<1, false, true>},
-             {modconv_wino2_kernel<1, true, false>, modconv_wino2_kernel<1, true, true>}},
-            {{modconv_wino2_kernel<2, false, false>, modconv_wino2_kernel<2, false, true>},
-             {modconv_wino2_kernel<2, true, false>, modconv_wino2_kernel<2, true, true>}},
-            {{modconv_wino2_kernel<4, false, false>, modconv_wino2_kernel<4, false, true>},
-             {modconv_wino2_kernel<4, true, false>, modconv_wino2_kernel<4, true, true>}},
-            {{modconv_wino2_kernel<8, false, false>, modconv_wino2_kernel<8, false, true>},
-             {modconv_wino2_kernel<8, true, false>, modconv_wino2_kernel<8, true, true>}}};
-        static bool table_attr[4][2][2] = {};
+        static const kern_t table[4][2] = {{modconv_wino2_kernel<1, false>, modconv_wino2_kernel<1, true>},
+                                           {modconv_wino2_kernel<2, false>, modconv_wino2_kernel<2, true>},
+                                           {modconv_wino2_kernel<4, false>, modconv_wino2_kernel<4, true>},
+                                           {modconv_wino2_kernel<8, false>, modconv_wino2_kernel<8, true>}};
+        static bool table_attr[4][2] = {};
         const int xi_log2 = tc.xt <= 256 ? 0 : tc.xt <= 512 ? 1 : tc.xt <= 1024 ? 2 : 3;
-        const kern_t kern = table[xi_log2][p.s ? 1 : 0][one_phase ? 1 : 0];
-        bool& have_attr = table_attr[xi_log2][p.s ? 1 : 0][one_phase ? 1 : 0];
+        const kern_t kern = table[xi_log2][p.s ? 1 : 0];
+        bool& have_attr = table_attr[xi_log2][p.s ? 1 : 0];
         if (!have_attr) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return sis_fail("modconv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));

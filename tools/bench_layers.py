@@ -8,6 +8,9 @@ sys.path.insert(0, os.path.join(ROOT, "synthesis-in-style_amd"))
 import torch  # noqa: E402
 import sis_hip  # noqa: E402
 
+if os.environ.get("SIS_HIP_LIB"):  # same-box A/B of kernel builds (tools/build_variant.sh)
+    sis_hip.LIB_PATH = os.path.join(ROOT, "synthesis-in-style_amd", "lib", os.environ["SIS_HIP_LIB"])
+
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 only = sys.argv[3] if len(sys.argv) > 3 else ""
