@@ -388,8 +388,14 @@ extern "C" int sis_modconv2d_up(float* t, const float* x, const float* wpk, cons
         p.npos_tiles = 0; p.ncls = 0; p.nb_max = 0;
         mc_add_class(p, np, 1, batch, 0, h, 0, w, 32, 8);          // interior positions
         mc_add_class(p, np, 1, batch, h, h + 1, 0, w, np, 8);      // last row  (T[2H, 0..2W-1])
-        mc_add_class(p, np, 1, batch, 0, h, w, w + 1, 1, 8);       // last col  (T[0..2H-1, 2W])
-        mc_add_class(p, np, 1, batch, h, h + 1, w, w + 1, 1, 8);   // corner    (T[2H, 2W])
+        // last col (T[0..2H-1, 2W]): one position per row, each staged as a padded 8-float row, and the corner: capped at
+        // 64 rows / 4 samples per tile.  The grid's LDS size follows its LARGEST class: uncapped, the last column's staging
+        // area (2 x 65 x 8 floats per channel) and the corner's 8 style rows made it 120 KB -- one workgroup per CU for
+        // every tile of the layer (measured with hipOccupancyMaxActiveBlocksPerMultiprocessor; 74-80 KB now: two per CU).
+        // (4x4 and 8x8 layers keep 8 samples per edge tile: they are split-K / launch bound, more tiles cost them 30-50 %.)
+        const int edge_nb = h >= 16 ? 4 : 8;
+        mc_add_class(p, np < 64 ? np : 64, 1, batch, 0, h, w, w + 1, 1, edge_nb);
+        mc_add_class(p, np, 1, batch, h, h + 1, w, w + 1, 1, edge_nb);   // corner    (T[2H, 2W])
         if (pass == 0) {
             const int rc = modconv_v2_launch(p, 1, 3, (hipStream_t)stream, workspace, workspace_bytes);
             if (rc >= 0) return rc;

@@ -59,6 +59,24 @@ __device__ __forceinline__ void bufld16(__amdgpu_buffer_rsrc_t r, float* l, unsi
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
 }
 
+#ifdef SIS_V2_TRACE
+// Development build only (tools/v2_trace.py): cycle stamps of the chunk loop of 4 workgroups of the transposed kernel.
+constexpr int V2TR_WG0 = 2000, V2TR_NWG = 4, V2TR_CHUNKS = 64, V2TR_SLOTS = 4;
+__device__ unsigned int sis_v2_trace[V2TR_NWG][8][V2TR_CHUNKS][V2TR_SLOTS];
+#define V2_TRACE(slot)                                                                                            \
+    do {                                                                                                          \
+        if (MODE == 1 && blockIdx.y == 0 && blockIdx.x >= V2TR_WG0 && blockIdx.x < V2TR_WG0 + V2TR_NWG && tc_ < V2TR_CHUNKS) { \
+            const unsigned int now_ = (unsigned int)__builtin_readcyclecounter();                                 \
+            if (lane == 0) sis_v2_trace[blockIdx.x - V2TR_WG0][wave][tc_][slot] = now_;                           \
+        }                                                                                                         \
+    } while (0)
+extern "C" int sis_v2_trace_read(unsigned int* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sis_v2_trace), sizeof(unsigned int) * V2TR_NWG * 8 * V2TR_CHUNKS * V2TR_SLOTS);
+}
+#else
+#define V2_TRACE(slot) do {} while (0)
+#endif
+
 template <int MODE, int KS, typename C>
 __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const ConvParams p, const int xt_max) {
     constexpr int CC = C::CC;
@@ -212,8 +230,13 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
     __syncthreads();  // vmcnt(0) + barrier: chunk 0 landed
 
     int buf = 0;
+#ifdef SIS_V2_TRACE
+    int tc_ = 0;
+#endif
     for (int ci0 = k_lo; ci0 < k_hi; ci0 += CC, buf ^= 1) {
+        V2_TRACE(0);
         if (ci0 + CC < k_hi) stage(ci0 + CC, buf ^ 1);
+        V2_TRACE(1);
         const float* Wb = Wl + buf * WF;
         const float* Xb = Xl + buf * CC * xt;
         float sv[CC / 2][C::NT];
@@ -264,7 +287,11 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
                 }
             }
         }
+        V2_TRACE(2);
         __syncthreads();  // next chunk's DMA retired (vmcnt 0) and everyone is done with this buffer
+#ifdef SIS_V2_TRACE
+        ++tc_;
+#endif
     }
 
     // ---- epilogue (ksplit > 1: raw partial sums to this slice's slab)
@@ -376,6 +403,14 @@ int launch_v2(ConvParams& p, hipStream_t st) {
     const int64_t bx = (int64_t)p.npos_tiles * sis_cdiv(p.Cout, C::MBLK);
     SIS_REQUIRE(bx > 0 && bx < ((int64_t)1 << 31), "modconv: bad grid");
     sis_kernel_name = MODE == 1 ? "modconv_v2_kernel<1, 3>" : KS == 3 ? "modconv_v2_kernel<0, 3>" : "modconv_v2_kernel<0, 1>";
+    if (getenv("SIS_V2_OCC")) {  // development: what does the runtime think fits on a CU?
+        int nb = -1;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, modconv_v2_kernel<MODE, KS, C>, C::THREADS, lds);
+        hipFuncAttributes fa;
+        hipError_t e2 = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&modconv_v2_kernel<MODE, KS, C>));
+        fprintf(stderr, "[v2 occ] mode %d threads %d lds %zu -> blocks/CU %d (%s); regs %d static lds %zu scratch %zu (%s)\n", MODE, C::THREADS, lds, nb,
+                hipGetErrorString(e), fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, hipGetErrorString(e2));
+    }
     hipLaunchKernelGGL((modconv_v2_kernel<MODE, KS, C>), dim3((unsigned)bx, p.ksplit), dim3(C::THREADS), lds, st, p, xt_max);
     SIS_CHECK_LAUNCH("modconv_v2_kernel");
     if (p.ksplit > 1) {
