@@ -96,9 +96,14 @@ def build_dataset(args, creation_config, rank=0, world_size=1):
             a, b = max(first, lo), min(first + n, hi)
             if a >= b:
                 continue
-            z = z[a - first:b - first].to(device)
-            image, acts = g([z], noise=noise, return_intermediate_activations=True,
+            # A batch that straddles a shard boundary is synthesised WHOLE by both of its owners and then cut: the kernels'
+            # split-K / tile plans follow the batch size, so only the same batch gives the same bits -- the bytes an image id
+            # maps to must not depend on the world size (at most one redundant partial batch per shard boundary).
+            image, acts = g([z.to(device)], noise=noise, return_intermediate_activations=True,
                             truncation=0.7 if mean_latent is not None else 1, truncation_latent=mean_latent)
+            if (a, b) != (first, first + n):
+                image = image[a - first:b - first]
+                acts = {k: v[a - first:b - first] for k, v in acts.items()}
             job = (a,) + label_and_encode(image, acts, catalogs)  # side stream; the next batch's forward is issued first
             if pending is not None:
                 flush(pending)
