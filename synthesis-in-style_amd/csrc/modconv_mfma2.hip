@@ -216,6 +216,10 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
         so[t] = min(n, tc.nb - 1) * p.Cin + half;
     }
     const int aoff = half * C::NTAPS * C::MBLK + wm * C::MT * 32 + l31;
+    // Transposed kernel: a wave whose 32 positions all lie outside its tile's samples (edge classes: the last column holds
+    // 64 of the 128 positions of a tile, the corner 4) still stages and keeps the barriers but issues no multiplies -- the
+    // matrix pipe of its SIMD goes to the other workgroup on the CU (edge tiles are 5 % of the 64x64 layer, 27 % of 16x16).
+    const bool wave_live = MODE == 0 || ((wn * 32) >> (thl + twl)) < tc.nb;
 
     f32x16 acc[C::MT][C::NACC];
 #pragma unroll
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
                             acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[t], acc[m][t], 0, 0, 0);
                 }
             }
-        } else {
+        } else if (wave_live) {
 #pragma unroll
             for (int cp = 0; cp < CC / 2; ++cp) {
                 const float* xb = Xb + 2 * cp * xt + xo[0];
@@ -435,8 +439,10 @@ void modconv_splitk_finish_launch(const ConvParams& p, hipStream_t st) {
 static void plan_splitk(ConvParams& p, int mblk, int cc, int64_t workspace_bytes) {
     p.ksplit = 1; p.kchunk = p.Cin; p.slab = nullptr;
     const int64_t blocks = (int64_t)p.npos_tiles * sis_cdiv(p.Cout, mblk);
-    if (blocks >= 384 || p.Cin < 4 * cc) return;
-    int want = (int)((512 + blocks - 1) / blocks);
+    static const int min_blocks = getenv("SIS_SPLITK_MIN_BLOCKS") ? atoi(getenv("SIS_SPLITK_MIN_BLOCKS")) : 384;
+    static const int target = getenv("SIS_SPLITK_TARGET") ? atoi(getenv("SIS_SPLITK_TARGET")) : 512;
+    if (blocks >= min_blocks || p.Cin < 4 * cc) return;
+    int want = (int)((target + blocks - 1) / blocks);
     const int max_split = p.Cin / (2 * cc);
     if (want > max_split) want = max_split;
     const int64_t out_bytes = (int64_t)p.B * p.Cout * p.OH * p.ORS * 4;
