@@ -123,8 +123,10 @@ int sis_modconv2d(float* out, const float* x, const float* wpk, const float* s,
                   int64_t workspace_bytes, void* stream);
 
 /* Winograd F(2x2,3x3) weight transform for sis_modconv2d's optional `wino_u` argument (ksize 3, even H and W,
- * Cin % 8 == 0): u[ci][xi][co] = (G w[co,ci] G^T)[xi], xi = 0..15.  With wino_u the stride-1 3x3 layers run
- * 16 multiplies per 2x2 output tile instead of 36 (2.25x fewer MFMA FLOPs); NULL selects the direct kernel. */
+ * Cin % 8 == 0): cin * 16 * cout floats holding (G w[co,ci] G^T)[xi], xi = 0..15, in the kernels' private operand order
+ * [ci][q][ih][co][il][jj] with xi = 4 (2 ih + il) + 2 q + jj (opaque to the caller: only these kernels read it).  With
+ * wino_u the stride-1 3x3 layers run 16 multiplies per 2x2 output tile instead of 36 (2.25x fewer MFMA FLOPs); NULL
+ * selects the direct kernel. */
 int sis_modconv_prepack_wino(float* u, const float* w, int cout, int cin, void* stream);
 
 /* Modulated transposed convolution, stride 2, no padding, ks = 3: model.py:251-261 up to (not
