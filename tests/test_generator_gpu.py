@@ -29,7 +29,7 @@ def _mk(gen, *shape):
 
 @pytest.mark.parametrize("b,cin,cout,h,w", [(2, 16, 32, 8, 8), (3, 24, 136, 16, 16), (5, 64, 128, 4, 4),
                                              (2, 32, 64, 32, 32), (1, 40, 256, 40, 72), (17, 8, 8, 4, 4),
-                                             (2, 512, 512, 8, 8)])
+                                             (2, 512, 512, 8, 8), (3, 64, 64, 64, 8), (6, 24, 96, 8, 8), (1, 16, 64, 2, 128)])
 @pytest.mark.parametrize("fuse", [False, True])
 @pytest.mark.parametrize("wino", [False, True])
 def test_modconv3x3_vs_oracle(device, b, cin, cout, h, w, fuse, wino):

@@ -9,7 +9,9 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(2, 64, 128, 32, 32), (2, 128, 64, 16, 32), (3, 64, 64, 64, 64), (3, 128, 64, 16, 24), (1, 256, 8, 8, 8), (16, 64, 64, 64, 64), (2, 2048, 512, 32, 32),
-          (5, 8, 8, 2, 4)]
+          (5, 8, 8, 2, 4),
+          # round-2 chunk loop: 4 / 8 DMA parts per input tile (tall, narrow and multi-sample tiles), odd chunk counts, partial co block
+          (3, 64, 64, 64, 8), (2, 64, 64, 8, 8), (1, 16, 64, 2, 128), (2, 24, 96, 32, 32), (9, 40, 72, 4, 8)]
 
 
 @pytest.mark.parametrize("batch,cin,cout,h,w,dil", [s + (1,) for s in SHAPES] + [(2, 64, 32, 32, 32, 2), (3, 256, 256, 32, 32, 2),
