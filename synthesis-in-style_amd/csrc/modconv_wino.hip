@@ -336,7 +336,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams
 // Development build only (tools/wino_trace.sh): per-wave cycle stamps of the steady-state chunk loop of 4 workgroups.
 constexpr int TR_WG0 = 500, TR_NWG = 4, TR_CHUNKS = 64, TR_SLOTS = 4;
 __device__ unsigned int sis_wino_trace[TR_NWG][8][TR_CHUNKS][TR_SLOTS];
-__device__ unsigned int sis_wino_trace_tile[TR_NWG][8][16][3];
+__device__ unsigned int sis_wino_trace_tile[TR_NWG][8][16][8];
 #define WINO_TRACE_TILE(slot)                                                                                     \
     do {                                                                                                          \
         if (blockIdx.y == 0 && blockIdx.x >= TR_WG0 && blockIdx.x < TR_WG0 + TR_NWG && k < 16) {                    \
@@ -418,18 +418,16 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     const int x_f4 = (x_base >> 2) + lane;  // this lane's float4 of the tile
     unsigned x_voff;                // byte offset of that float4 inside the channel plane, from the tile's first sample
     __amdgpu_buffer_rsrc_t x_rsrc;  // descriptor based at the tile's first sample
+    // (sample, row, float4 column) of this lane's float4 inside a tile: the same for every tile (the divisions are hoisted:
+    // next-tile setup + first DMA issue measured 4-5 k cycles per tile on the waves that also fetched the style rows)
+    const int ew4_ = ew >> 2;
+    const int xl_n = x_f4 / (eh * ew4_), xl_r = (x_f4 - xl_n * (eh * ew4_)) / ew4_, xl_c4 = x_f4 - xl_n * (eh * ew4_) - xl_r * ew4_;
     auto tile_setup = [&](int pt) {
         const int twi = pt % tc.ntw; pt /= tc.ntw;
         const int thi = pt % tc.nth;
         b0 = (pt / tc.nth) * tc.nb; h0 = thi << thl; w0 = twi << twl;
-        x_voff = BUF_OOB;
-        const int ew4 = ew >> 2;
-        {
-            const int n = x_f4 / (eh * ew4), rem = x_f4 - n * (eh * ew4);
-            const int r = rem / ew4, c4 = rem - r * ew4;
-            const int b = b0 + n, h = h0 - 1 + r, w = w0 - 4 + 4 * c4;
-            if (b < p.B && h >= 0 && h < p.H && w >= 0 && w < p.W) x_voff = (unsigned)(n * p.Cin * HW + h * p.W + w) * 4u;
-        }
+        const int b = b0 + xl_n, h = h0 - 1 + xl_r, w = w0 - 4 + 4 * xl_c4;
+        x_voff = (b < p.B && h >= 0 && h < p.H && w >= 0 && w < p.W) ? (unsigned)(xl_n * p.Cin * HW + h * p.W + w) * 4u : BUF_OOB;
         x_rsrc = dma_rsrc(p.x + (int64_t)b0 * p.Cin * HW);
     };
     // Tile k of workgroup g is pixel tile g + k * (#workgroups per channel block): the workgroups running at the same
@@ -508,14 +506,36 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
 
     // First DMA of a tile: every global access of the start-up is in flight before the first wait (one memory
     // round trip).  Out-of-image float4 slots get their zeros from the DMA itself (out-of-range buffer offsets).
+    // Style rows of the tile's samples: nb * Cin consecutive floats of p.s.  Up to 1024 of them travel through two registers
+    // per lane: loaded BEFORE the tile's first DMA (a wait for them must not cover the DMA issued after them) and parked in
+    // LDS by style_store() once nobody reads the previous tile's rows any more.
+    const int sl_n = STYLED ? tc.nb * p.Cin : 0;
+    const bool sl_in_regs = sl_n <= 2 * WNTHR;
+    float sl_reg[2] = {0.f, 0.f};
+    auto style_load = [&]() {
+        const int avail = (p.B - b0) * p.Cin;  // rows of samples beyond the batch read as zero
+        const float* src = p.s + (int64_t)b0 * p.Cin;
+        if (sl_in_regs) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = tid + i * WNTHR;
+                sl_reg[i] = (e < sl_n && e < avail) ? src[e] : 0.f;
+            }
+        } else {
+            for (int e = tid; e < sl_n; e += WNTHR) Sl[e] = e < avail ? src[e] : 0.f;
+        }
+    };
+    auto style_store = [&]() {
+        if (!sl_in_regs) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (tid + i * WNTHR < sl_n) Sl[tid + i * WNTHR] = sl_reg[i];
+    };
     auto tile_first_dma = [&]() {
+        if (STYLED) style_load();
         stage_u(k_lo, 0);
         stage_x(k_lo, 0);
         if (k_lo + WCC < k_hi) stage_x(k_lo + WCC, 1);
-        for (int e = tid; e < (STYLED ? tc.nb * p.Cin : 0); e += WNTHR) {  // plain convolution (p.s == nullptr): no style rows
-            const int n = e / p.Cin, ci = e - n * p.Cin;
-            Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
-        }
     };
     // Layer-tail operands (demodulation, bias, noise) of a tile: fetched into registers a whole tile ahead, parked in
     // LDS once nobody reads the previous tile's any more, read back in the epilogue -- no dependent global loads
@@ -545,7 +565,8 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
 
     tile_first_dma();
     tail_load();
-    __syncthreads();  // chunk 0 (and input chunk 1) landed, styles and zeros visible
+    style_store();
+    __syncthreads();  // chunk 0 (and input chunk 1) landed, styles visible
     tail_store();
     transform(k_lo, 0, 0);
     __syncthreads();  // V(0) visible
@@ -683,6 +704,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
             tile_first_dma();
             tail_load();  // its global-load latency hides under this tile's epilogue
         }
+        WINO_TRACE_TILE(3);
 
         // ---- epilogue.  m[r][jj] = (A^T M)[r][column 2q+jj];  Y[r][0] = m0 + m1 + m2,  Y[r][1] = m1 - m2 - m3.
         // q = 0 contributes (m0 + m1, m1), q = 1 contributes (m2, -m2 - m3).  The two waves of a pair swap halves:
@@ -717,7 +739,9 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
         };
         if (q == 0) reduce_and_send(std::integral_constant<int, 0>());
         else reduce_and_send(std::integral_constant<int, 1>());
+        WINO_TRACE_TILE(4);
         __syncthreads();
+        WINO_TRACE_TILE(5);
 
         if (live) {
             float* obase = (partial ? p.slab + (int64_t)blockIdx.y * p.B * p.Cout * HW : p.out) +
@@ -754,7 +778,10 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
             }
         }
         if (!has_next) break;
-        __syncthreads();  // next tile: chunk 0 (and input chunk 1) landed; everyone is done with the exchange area
+        WINO_TRACE_TILE(6);
+        style_store();    // (the old rows' last readers, the previous tile's transforms, finished before its chunk loop ended)
+        __syncthreads();  // next tile: chunk 0 (and input chunk 1) landed, styles visible; everyone is done with the exchange area
+        WINO_TRACE_TILE(7);
         tail_store();
         transform(k_lo, 0, 0);
         __syncthreads();  // V(0) visible
@@ -769,7 +796,7 @@ extern "C" int sis_wino_trace_read(unsigned int* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sis_wino_trace), sizeof(unsigned int) * TR_NWG * 8 * TR_CHUNKS * TR_SLOTS);
 }
 extern "C" int sis_wino_trace_tile_read(unsigned int* host) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sis_wino_trace_tile), sizeof(unsigned int) * TR_NWG * 8 * 16 * 3);
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sis_wino_trace_tile), sizeof(unsigned int) * TR_NWG * 8 * 16 * 8);
 }
 #endif
 

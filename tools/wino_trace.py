@@ -61,15 +61,17 @@ for g in range(4):
         for wv in range(8):
             print("   ", wv, r[wv].tolist(), " next top:", int(t[wv, 11, 0] - t[:, 10, :].min()))
 
-tb = np.zeros((4, 8, 16, 3), dtype=np.uint32)
+tb = np.zeros((4, 8, 16, 8), dtype=np.uint32)
 L.sis_wino_trace_tile_read.argtypes = [ctypes.c_void_p]
 assert L.sis_wino_trace_tile_read(tb.ctypes.data) == 0
 t = tb[0].astype(np.int64)
-print("tile-level (workgroup 0, wave 0 / wave 7): chunk loop, epilogue + next tile's prologue, in cycles")
+print("tile-level (workgroup 0), cycles, wave 0 / wave 7: chunk loop | next tile's setup + first DMA issue | reduce + LDS send | barrier | "
+      "finalise + stores | barrier (DMA landed) | tail store + first transform + barrier")
+order = [0, 1, 3, 4, 5, 6, 7, 2]  # stamp slots in program order
 for kk in range(16):
-    if t[0, kk, 1] == 0:
+    if t[0, kk, 1] == 0 or t[0, kk, 2] == 0:
         break
-    loop0, loop7 = (t[0, kk, 1] - t[0, kk, 0]) & 0xFFFFFFFF, (t[7, kk, 1] - t[7, kk, 0]) & 0xFFFFFFFF
-    epi0 = (t[0, kk, 2] - t[0, kk, 1]) & 0xFFFFFFFF if t[0, kk, 2] else -1
-    epi7 = (t[7, kk, 2] - t[7, kk, 1]) & 0xFFFFFFFF if t[7, kk, 2] else -1
-    print(f"  tile {kk}: loop {loop0} / {loop7}   epilogue+prologue {epi0} / {epi7}")
+    segs = []
+    for a, b in zip(order[:-1], order[1:]):
+        segs.append(f"{(t[0, kk, b] - t[0, kk, a]) & 0xFFFFFFFF}/{(t[7, kk, b] - t[7, kk, a]) & 0xFFFFFFFF}")
+    print(f"  tile {kk}: " + " | ".join(segs))
