@@ -406,7 +406,6 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     // tiles): the next tile's first DMA flies under the current tile's epilogue, and the per-workgroup launch /
     // first-touch latency is paid once per `tiles_per_wg` tiles instead of once per tile (7 us against 16 chunks
     // x 2.5 us on the 128-channel 256^2 layer).
-    int b0, h0, w0;
     // Input tile DMA: the tile is xt / 4 float4 per channel, cut into XI parts of 64 lanes (XI rounded up to a power of
     // two); wave w moves part w % XI of the channels w / XI + k * (8 / XI) -- every wave issues the same number of DMA
     // instructions (issue back-pressure on two waves was the critical path of the chunk) from one offset register.
@@ -416,25 +415,29 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     // values): every lane of every DMA instruction owns a float4 of the tile -- no exec mask, no branch in the loop.
     const int x_base = min(x_part * 256, xt - 256);  // floats; xt >= 256 (a tile has 64 patches) and xt % 4 == 0
     const int x_f4 = (x_base >> 2) + lane;  // this lane's float4 of the tile
-    unsigned x_voff;                // byte offset of that float4 inside the channel plane, from the tile's first sample
-    __amdgpu_buffer_rsrc_t x_rsrc;  // descriptor based at the tile's first sample
-    // (sample, row, float4 column) of this lane's float4 inside a tile: the same for every tile (the divisions are hoisted:
-    // next-tile setup + first DMA issue measured 4-5 k cycles per tile on the waves that also fetched the style rows)
+    // Tile state: the tile being multiplied and (from the top of its chunk loop on) the next one of this workgroup, whose
+    // first chunks are staged by the current tile's LAST chunks -- one flat (tile, chunk) pipeline, no start-up per tile.
+    struct TileState {
+        int b0, h0, w0;
+        unsigned x_voff;                // byte offset of this lane's float4 inside the channel plane, from the tile's first sample
+        __amdgpu_buffer_rsrc_t x_rsrc;  // descriptor based at the tile's first sample
+    } T, Tn;
+    // (sample, row, float4 column) of this lane's float4 inside a tile: the same for every tile
     const int ew4_ = ew >> 2;
     const int xl_n = x_f4 / (eh * ew4_), xl_r = (x_f4 - xl_n * (eh * ew4_)) / ew4_, xl_c4 = x_f4 - xl_n * (eh * ew4_) - xl_r * ew4_;
-    auto tile_setup = [&](int pt) {
+    auto tile_setup = [&](int pt, TileState& S) {
         const int twi = pt % tc.ntw; pt /= tc.ntw;
         const int thi = pt % tc.nth;
-        b0 = (pt / tc.nth) * tc.nb; h0 = thi << thl; w0 = twi << twl;
-        const int b = b0 + xl_n, h = h0 - 1 + xl_r, w = w0 - 4 + 4 * xl_c4;
-        x_voff = (b < p.B && h >= 0 && h < p.H && w >= 0 && w < p.W) ? (unsigned)(xl_n * p.Cin * HW + h * p.W + w) * 4u : BUF_OOB;
-        x_rsrc = dma_rsrc(p.x + (int64_t)b0 * p.Cin * HW);
+        S.b0 = (pt / tc.nth) * tc.nb; S.h0 = thi << thl; S.w0 = twi << twl;
+        const int b = S.b0 + xl_n, h = S.h0 - 1 + xl_r, w = S.w0 - 4 + 4 * xl_c4;
+        S.x_voff = (b < p.B && h >= 0 && h < p.H && w >= 0 && w < p.W) ? (unsigned)(xl_n * p.Cin * HW + h * p.W + w) * 4u : BUF_OOB;
+        S.x_rsrc = dma_rsrc(p.x + (int64_t)S.b0 * p.Cin * HW);
     };
     // Tile k of workgroup g is pixel tile g + k * (#workgroups per channel block): the workgroups running at the same
     // time cover NEIGHBOURING tiles, whose halos they share through L2 (consecutive tiles per workgroup measured 57 %
     // more fetched bytes).
     const int pt_first = wg / n_co, pt_step = gridDim.x / n_co;
-    tile_setup(pt_first);
+    tile_setup(pt_first, T);
     // weights: chunk = 32 rows (ci, q, ih) of 64 co x 4 floats = one 1 KB DMA instruction per row, 4 rows per wave
     // (row = it * 8 + wave); every lane moves the float4 of output channel o0 + lane
     constexpr int WIT = WF / 4 / WNTHR;
@@ -447,20 +450,20 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
 #pragma unroll
         for (int it = 0; it < WIT; ++it) bufld16(u_rsrc, udst + it * 8 * 256, u_voff, s0 + (unsigned)(it * 8) * u_row_bytes);
     };
-    auto stage_x = [&](int ci0, int buf) {
+    auto stage_x = [&](int ci0, int buf, const TileState& S) {
         float* xdst = Xl + buf * WCC * xt + x_base;
 #pragma unroll
         for (int k = 0; k < XI; ++k) {
             const int j = x_ch0 + k * x_chstep;
-            bufld16(x_rsrc, xdst + j * xt, x_voff, (unsigned)((ci0 + j) * HW) * 4u);
+            bufld16(S.x_rsrc, xdst + j * xt, S.x_voff, (unsigned)((ci0 + j) * HW) * 4u);
         }
     };
     auto stage_u_piece = [&](int ci0, int buf, int it) {  // one 1 KB DMA instruction of stage_u
         bufld16(u_rsrc, Ul + buf * WF + wave * 256 + it * 8 * 256, u_voff, (unsigned)(ci0 * 4 + wave + it * 8) * u_row_bytes);
     };
-    auto stage_x_piece = [&](int ci0, int buf, int k) {  // one DMA instruction of stage_x
+    auto stage_x_piece = [&](int ci0, int buf, int k, __amdgpu_buffer_rsrc_t rsrc, unsigned voff) {  // one DMA instruction of stage_x
         const int j = x_ch0 + k * x_chstep;
-        bufld16(x_rsrc, Xl + buf * WCC * xt + x_base + j * xt, x_voff, (unsigned)((ci0 + j) * HW) * 4u);
+        bufld16(rsrc, Xl + buf * WCC * xt + x_base + j * xt, voff, (unsigned)((ci0 + j) * HW) * 4u);
     };
     // Input transform, ONE patch per lane per chunk: lane = tile (0..63), wave = channel of the chunk.  V = B^T d B
     // scaled by the style of the tile's sample, written as [channel][q][ih][tile][il][jj] (xi = 4 (2 ih + il) + 2 q + jj):
@@ -512,9 +515,9 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     const int sl_n = STYLED ? tc.nb * p.Cin : 0;
     const bool sl_in_regs = sl_n <= 2 * WNTHR;
     float sl_reg[2] = {0.f, 0.f};
-    auto style_load = [&]() {
-        const int avail = (p.B - b0) * p.Cin;  // rows of samples beyond the batch read as zero
-        const float* src = p.s + (int64_t)b0 * p.Cin;
+    auto style_load = [&](const TileState& S) {
+        const int avail = (p.B - S.b0) * p.Cin;  // rows of samples beyond the batch read as zero
+        const float* src = p.s + (int64_t)S.b0 * p.Cin;
         if (sl_in_regs) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -531,29 +534,29 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
         for (int i = 0; i < 2; ++i)
             if (tid + i * WNTHR < sl_n) Sl[tid + i * WNTHR] = sl_reg[i];
     };
-    auto tile_first_dma = [&]() {
-        if (STYLED) style_load();
+    auto tile_first_dma = [&]() {  // the workgroup's first tile only
+        if (STYLED) style_load(T);
         stage_u(k_lo, 0);
-        stage_x(k_lo, 0);
-        if (k_lo + WCC < k_hi) stage_x(k_lo + WCC, 1);
+        stage_x(k_lo, 0, T);
+        if (k_lo + WCC < k_hi) stage_x(k_lo + WCC, 1, T);
     };
     // Layer-tail operands (demodulation, bias, noise) of a tile: fetched into registers a whole tile ahead, parked in
     // LDS once nobody reads the previous tile's any more, read back in the epilogue -- no dependent global loads
     // in the tail and no registers held across the matrix loop.
     float t_noise = 0.f, t_scale = 1.f, t_bias = 0.f;
-    auto tail_load = [&]() {
+    auto tail_load = [&](const TileState& S) {
         t_noise = 0.f; t_scale = 1.f; t_bias = 0.f;
         if (partial) return;
         if (p.fuse && p.noise && tid < WTILES * 4) {
             const int tt_ = tid >> 2, e = tid & 3;
             const int n = tt_ >> tpl0, rem = tt_ & ((1 << tpl0) - 1);
-            const int yy = h0 + 2 * (rem >> (twl - 1)) + (e >> 1), xx = w0 + 2 * (rem & ((tw >> 1) - 1)) + (e & 1);
-            if (n < tc.nb && b0 + n < p.B && yy < p.H && xx < p.W)
-                t_noise = p.noise_w[0] * p.noise[(int64_t)(b0 + n) * p.noise_bstride + yy * p.W + xx];
+            const int yy = S.h0 + 2 * (rem >> (twl - 1)) + (e >> 1), xx = S.w0 + 2 * (rem & ((tw >> 1) - 1)) + (e & 1);
+            if (n < tc.nb && S.b0 + n < p.B && yy < p.H && xx < p.W)
+                t_noise = p.noise_w[0] * p.noise[(int64_t)(S.b0 + n) * p.noise_bstride + yy * p.W + xx];
         }
         if (tid < tc.nb * WMBLK) {
             const int n = tid / WMBLK, co = o0 + tid % WMBLK;
-            if (p.dscale && b0 + n < p.B && co < p.Cout) t_scale = p.dscale[(int64_t)(b0 + n) * p.Cout + co];
+            if (p.dscale && S.b0 + n < p.B && co < p.Cout) t_scale = p.dscale[(int64_t)(S.b0 + n) * p.Cout + co];
             if (n == 0 && p.fuse && p.bias && co < p.Cout) t_bias = p.bias[co];
         }
     };
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     };
 
     tile_first_dma();
-    tail_load();
+    tail_load(T);
     style_store();
     __syncthreads();  // chunk 0 (and input chunk 1) landed, styles visible
     tail_store();
@@ -583,25 +586,37 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
 #ifdef SIS_WINO_TRACE
         const bool tr_on = k == 1 && blockIdx.y == 0 && blockIdx.x >= TR_WG0 && blockIdx.x < TR_WG0 + TR_NWG;
 #endif
+        // The next tile of this workgroup: its descriptor now, its first two input chunks by DMA from this tile's last two
+        // chunks, its first transform in this tile's last chunk (style factor from a register), its weights for free (chunk
+        // 0 of the weights is the same for every tile: the last chunk's prefetch index wraps).  Measured before this: 4-5 k
+        // cycles per tile for the next tile's setup + first DMA burst, 1.7 k for its first transform and the barriers around it.
+        const bool has_next = k + 1 < tiles_per_wg;  // (the host keeps tiles_per_wg at 1 when a tile has a single chunk)
+        float sv_next = 1.f;
+        if (has_next) {
+            tile_setup(pt_first + (k + 1) * pt_step, Tn);
+            if (STYLED) sv_next = (Tn.b0 + ttn < p.B) ? p.s[(int64_t)(Tn.b0 + min(ttn, tc.nb - 1)) * p.Cin + k_lo + tch] : 0.f;
+        }
         // Single-phase software-pipelined chunk.  Measured (tools/wino_trace.py, tools/micro/mfma_valu_overlap.hip): on this
         // SIMD nothing a wave issues is hidden under the matrix pipe -- a chunk costs 64 MFMAs x 64 cycles plus ~5 cycles
         // for EVERY other instruction of its two waves -- and a wave that transforms while its partner multiplies crawls
         // (the staggered two-phase loop of round 1 had the partners multiplying one after the other).  So every wave runs
         // ONE straight-line block per chunk with as few instructions as the data flow allows: 16-byte operand reads (one
-        // per operand per two MFMA pairs), the DMA with scalar addressing, the transform in packed fp32 with 16-byte
-        // writes, buffer parity known at compile time (two chunks per loop trip: LDS addresses are immediates).
-        // The last chunks clamp their prefetch indices: they re-stage the final chunk into buffers nobody reads any more.
-        const int k_last = k_hi - WCC;
+        // per operand per two MFMA pairs), the DMA with scalar addressing, the transform with 16-byte writes, buffer
+        // parity a compile-time constant (LDS addresses are immediates).
+        const int k_last = k_hi - WCC, k_len = k_hi - k_lo;
         // One slot after each of the 32 MFMAs.  Issue costs add up inside an MFMA gap and only ~48 cycles of them hide under a
         // 64-cycle MFMA (MI355X_MICROARCH.md, constants: an LDS-DMA piece costs 60-185 cycles to issue, a packed-f32 VALU
-        // instruction ~3x a scalar one), so the side work is spread one expensive item per slot, and the two waves of a SIMD
-        // (w, w + 4) run different placements (`late`): one issues its DMA while the other is between its own pieces.
+        // instruction ~3x a scalar one), so the side work is spread one expensive item per slot.
         auto chunk = [&](auto parity, auto late_c, const int ci0, const int c) {
             constexpr int cur = decltype(parity)::value, nxt = cur ^ 1;
             constexpr bool LATE = decltype(late_c)::value;
             WINO_TRACE(0);
-            const int tci = min(ci0 + WCC, k_last);
-            const int uci = min(ci0 + WCC, k_last), xci = min(ci0 + 2 * WCC, k_last);
+            const bool last = ci0 + WCC >= k_hi;          // the transform below then works for the next tile's chunk 0
+            const int uci = last ? k_lo : ci0 + WCC;      // weights: the same for every tile
+            const bool x_next = ci0 + 2 * WCC >= k_hi && has_next;  // input chunk c + 2 belongs to the next tile
+            const int xci = x_next ? ci0 + 2 * WCC - k_len : min(ci0 + 2 * WCC, k_last);
+            const __amdgpu_buffer_rsrc_t xr = x_next ? Tn.x_rsrc : T.x_rsrc;
+            const unsigned xv = x_next ? Tn.x_voff : T.x_voff;
             const float* xb = Xl + nxt * WCC * xt + txo + 1;
             const float* Ub = Ul + cur * WF + aoff;
             const float* Vb = Vl + cur * VF + voff;
@@ -638,13 +653,13 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
                     if (sl == S_UDMA + 2 * it) stage_u_piece(uci, nxt, it);
 #pragma unroll
                 for (int kx = 0; kx < XI; ++kx)
-                    if (sl == S_XDMA + X_STEP * kx) stage_x_piece(xci, cur, kx);
+                    if (sl == S_XDMA + X_STEP * kx) stage_x_piece(xci, cur, kx, xr, xv);
 #endif
 #ifndef SIS_WINO_NOTRANSFORM
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (sl == S_READ + S_RSTEP * r) {  // patch row r: columns 1..4 of the 8-byte aligned row start
-                        if (r == 0 && STYLED) sv = Sl[tso + tci];
+                        if (r == 0 && STYLED) { const float sv_here = Sl[tso + min(ci0 + WCC, k_last)]; sv = last ? sv_next : sv_here; }
 #pragma unroll
                         for (int cc = 0; cc < 4; ++cc) d[r][cc] = xb[r * ew + cc];
                     }
@@ -680,30 +695,20 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
         };
         // (Giving waves 4-7 the `late` placement -- their DMA in the second half of the chunk, while their SIMD partners are
         // between pieces -- measured 6-8 % SLOWER on the same device: the late pieces are not landed at the barrier.)
-#ifdef SIS_WINO_STAGGER
-        if (wave >= 4) {
-            for (int ci0 = k_lo, c = 0; ci0 < k_hi; ci0 += 2 * WCC, c += 2) {
-                chunk(std::integral_constant<int, 0>(), std::true_type(), ci0, c);
-                if (ci0 + WCC < k_hi) chunk(std::integral_constant<int, 1>(), std::true_type(), ci0 + WCC, c + 1);
-            }
-        } else
-#endif
+        // Buffer parity is a compile-time constant: a tile starts on parity 0 -- workgroups that walk several tiles have an
+        // even chunk count per tile (host-checked) -- and the loop body is a pair of chunks.
         for (int ci0 = k_lo, c = 0; ci0 < k_hi; ci0 += 2 * WCC, c += 2) {
             chunk(std::integral_constant<int, 0>(), std::false_type(), ci0, c);
             if (ci0 + WCC < k_hi) chunk(std::integral_constant<int, 1>(), std::false_type(), ci0 + WCC, c + 1);
         }
 
         WINO_TRACE_TILE(1);
-        // All staging buffers are idle now.  Start the next tile's first DMA before this tile's epilogue; the output
-        // coordinates of THIS tile were taken above, its tail operands sit in LDS.
-        const bool has_next = k + 1 < tiles_per_wg;
-        const int ob = b0 + tn, oh = h0 + 2 * ty, ow = w0 + 2 * tx;  // this tile's output pixel, before b0/h0/w0 move on
-        const bool live = tn < tc.nb && ob < p.B && oh < p.H && ow < p.W;
-        if (has_next) {
-            tile_setup(pt_first + (k + 1) * pt_step);
-            tile_first_dma();
-            tail_load();  // its global-load latency hides under this tile's epilogue
+        if (has_next) {  // the next tile's style rows and tail operands: global loads that land under this tile's epilogue
+            if (STYLED) style_load(Tn);
+            tail_load(Tn);
         }
+        const int ob = T.b0 + tn, oh = T.h0 + 2 * ty, ow = T.w0 + 2 * tx;  // this tile's output pixel
+        const bool live = tn < tc.nb && ob < p.B && oh < p.H && ow < p.W;
         WINO_TRACE_TILE(3);
 
         // ---- epilogue.  m[r][jj] = (A^T M)[r][column 2q+jj];  Y[r][0] = m0 + m1 + m2,  Y[r][1] = m1 - m2 - m3.
@@ -711,7 +716,10 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
         // wave q finalises accumulator rows j in [8q, 8q+8) and hands its partial sums of the other 8 rows to its
         // partner through the (by now idle) V image LDS, so both run the layer tail and the stores.
         float mine[8][4];
-        float* xch = Vl + (wave >> 1) * (64 * 64);  // [sender q][8 rows][4][64 lanes] per wave pair
+        // Exchange area: the weight and V buffers of the chunk just finished (the last chunk's parity; the other pair already holds the
+        // next tile's chunk 0): wave pairs 0, 1 in the weight buffer, 2, 3 in the V buffer, 16 KB each.
+        const int pl = ((k_len / WCC) - 1) & 1, pair = wave >> 1;
+        float* xch = (pair < 2 ? Ul + pl * WF : Vl + pl * VF) + (pair & 1) * (64 * 64);  // [sender q][8 rows][4][64 lanes]
         auto reduce_and_send = [&](auto qc) {
             constexpr int Q = decltype(qc)::value;
 #pragma unroll
@@ -779,12 +787,12 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
         }
         if (!has_next) break;
         WINO_TRACE_TILE(6);
-        style_store();    // (the old rows' last readers, the previous tile's transforms, finished before its chunk loop ended)
-        __syncthreads();  // next tile: chunk 0 (and input chunk 1) landed, styles visible; everyone is done with the exchange area
+        __syncthreads();  // everyone is done with the exchange area and with this tile's tail operands
         WINO_TRACE_TILE(7);
         tail_store();
-        transform(k_lo, 0, 0);
-        __syncthreads();  // V(0) visible
+        style_store();  // (the old rows' last readers were this tile's transforms)
+        T = Tn;
+        __syncthreads();  // tail operands and style rows of the next tile visible
         WINO_TRACE_TILE(2);
     }
 }
@@ -863,7 +871,9 @@ int modconv_wino_launch(ConvParams& p, hipStream_t st, void* workspace, int64_t 
         static const int tpw_cap = getenv("SIS_WINO_TPW") ? atoi(getenv("SIS_WINO_TPW")) : 16;
         int tpw = 1;
         static const int min_wg = getenv("SIS_WINO_MINWG") ? atoi(getenv("SIS_WINO_MINWG")) : 1024;
-        while (tpw * 2 <= tpw_cap && p.npos_tiles % (tpw * 2) == 0 && blocks / (tpw * 2) >= min_wg) tpw *= 2;
+        // (the tile-to-tile pipeline stages the next tile from the last two chunks and keeps the buffer parity: an even number of
+        // chunks per tile, otherwise one tile per workgroup)
+        while (p.kchunk % (2 * WCC) == 0 && tpw * 2 <= tpw_cap && p.npos_tiles % (tpw * 2) == 0 && blocks / (tpw * 2) >= min_wg) tpw *= 2;
         // all co-blocks of a pixel tile on one XCD when the whole transformed weight tensor stays L2-resident there
         static const double swz_mb = getenv("SIS_WINO_XCD_MB") ? atof(getenv("SIS_WINO_XCD_MB")) : 5.0;
         const int64_t grid = blocks / tpw;
