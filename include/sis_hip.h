@@ -70,6 +70,10 @@ int sis_upfirdn2d(void* out, const void* in, const void* taps, int dtype, int ma
 /* PixelNorm, model.py:19-20: out[b,:] = x[b,:] * rsqrt(mean(x[b,:]^2) + 1e-8). */
 int sis_pixel_norm(float* out, const float* x, int batch, int dim, void* stream);
 
+/* Output features per workgroup of the three head GEMMs below (EqualLinear, batched modulation, batched demodulation:
+ * 32 batch rows x this many outputs on the fp32 matrix cores); the batched launches' tables count blocks in this unit. */
+int sis_head_gemm_tile(void);
+
 /* EqualLinear, model.py:152-162: out[b,o] = sum_i x[b,i] * w[o,i] * scale + bias[o]*lr_mul, then
  * (activation != 0) leaky-relu(0.2) * sqrt(2) as fused_leaky_relu does (fused_act.py:85-86).
  * x rows are x_row_stride floats apart (lets a [B, n_latent, D] latent be indexed in place). */
@@ -81,13 +85,13 @@ int sis_equal_linear(float* out, const float* x, int64_t x_row_stride, const flo
  * layer): out_base[row.out_offset + b*out_dim + o] = scale * <latent[b, row.latent_index, :], w[o, :]> + bias[o].
  * latent is [B, n_latent, dim]; table is a device array of n_layers rows of 8 int64:
  * {weight ptr, bias ptr, out offset (floats), latent index, out_dim, first_block, 0, 0}, first_block = running
- * sum of ceil(out_dim / 4); total_blocks = the final sum. */
+ * sum of ceil(out_dim / sis_head_gemm_tile()); total_blocks = the final sum. */
 int sis_modulation_batch(float* out_base, const float* latent, const int64_t* table, int n_layers,
                          int total_blocks, int batch, int n_latent, int dim, float scale, void* stream);
 
 /* Every demodulation-coefficient row of one forward in ONE launch (see sis_modconv_demod); table rows of 8
  * int64: {wsq ptr, float bits of the conv scale, s offset, dscale offset, cout, first_block, cin, demodulate},
- * first_block = running sum of ceil(batch * cout / 4). */
+ * first_block = running sum of ceil(cout / sis_head_gemm_tile()). */
 int sis_demod_batch(float* dscale_base, const float* s_base, const int64_t* table, int n_layers,
                     int total_blocks, int batch, void* stream);
 

@@ -184,6 +184,7 @@ int launch_pw(const PwParams& p, int a_kmajor, hipStream_t st, const char* name)
         attr_set = true;
     }
     dim3 grid(8 * sis_cdiv(p.M, C::MT) * sis_cdiv((int64_t)p.N * p.px_tiles, 8));
+    SIS_OCC_REPORT((conv1x1_f32_kernel<C, true>), 512, C::LDS_BYTES);
     if (a_kmajor) hipLaunchKernelGGL((conv1x1_f32_kernel<C, true>), grid, dim3(512), C::LDS_BYTES, st, p);
     else hipLaunchKernelGGL((conv1x1_f32_kernel<C, false>), grid, dim3(512), C::LDS_BYTES, st, p);
     SIS_CHECK_LAUNCH(name);

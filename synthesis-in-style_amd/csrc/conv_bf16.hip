@@ -329,6 +329,7 @@ int launch_conv(const ConvParams& p, hipStream_t st, const char* name) {
         attr_set = true;
     }
     dim3 grid(8 * p.co_tiles * sis_cdiv((int64_t)p.N * p.tiles_y * p.tiles_x, 8));
+    SIS_OCC_REPORT((conv_bf16_kernel<C, true>), 512, 2 * C::STAGE);
     if (p.aligned) hipLaunchKernelGGL((conv_bf16_kernel<C, true>), grid, dim3(512), 2 * C::STAGE, st, p);
     else hipLaunchKernelGGL((conv_bf16_kernel<C, false>), grid, dim3(512), 2 * C::STAGE, st, p);
     SIS_CHECK_LAUNCH(name);

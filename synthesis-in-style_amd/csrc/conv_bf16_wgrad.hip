@@ -322,6 +322,7 @@ int launch_wgrad(const WgParams& p, int units, hipStream_t st, const char* name)
         attr_set = true;
     }
     dim3 grid(units, p.co_tiles * p.ci_tiles);
+    SIS_OCC_REPORT((conv_wgrad_bf16_kernel<C, true>), 512, C::LDS);
     if (p.aligned) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<C, true>), grid, dim3(512), C::LDS, st, p);
     else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<C, false>), grid, dim3(512), C::LDS, st, p);
     SIS_CHECK_LAUNCH(name);

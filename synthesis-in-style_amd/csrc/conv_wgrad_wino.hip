@@ -264,6 +264,7 @@ extern "C" int sis_conv3x3_wgrad(float* dw, const float* x, const float* gy, int
         attr_set = true;
     }
     sis_kernel_name = "conv_wgrad_wino_kernel";
+    SIS_OCC_REPORT(conv_wgrad_wino_kernel, GTHR, lds);
     hipLaunchKernelGGL(conv_wgrad_wino_kernel, dim3((cin / GBLK) * (cout / GBLK), ksplit), dim3(GTHR), lds,
                        (hipStream_t)stream, p);
     SIS_CHECK_LAUNCH("conv_wgrad_wino_kernel");

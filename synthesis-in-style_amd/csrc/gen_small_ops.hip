@@ -73,81 +73,131 @@ __global__ __launch_bounds__(256) void equal_linear_kernel(float* __restrict__ o
     }
 }
 
-// All modulation EqualLinears (20 at 256^2) + all demodulation coefficient rows (13) of one forward in two
-// launches.  table rows (8 x int64): {weight ptr, bias ptr, out offset (floats), latent index, out_dim,
-// first_block, aux ptr, aux int}.
-struct BatchHdr { int n_layers, batch, dim, n_latent; float scale; };
+// ---- The batched "head" GEMMs of a forward (modulation, demodulation; MODE 0 = a single EqualLinear) on the fp32 matrix cores.
+// out[r][o] = epilogue(sum_k A[r][k] * W[o][k]) with r = batch row (32 per tile = one MFMA M block), W rows k-contiguous
+// as torch stores nn.Linear weights.  Workgroup = 4 waves = 32 rows x 128 outputs (wave w: outputs 32 w .. 32 w + 31),
+// K in 64-wide chunks staged through LDS with coalesced 16-byte loads (row stride 66 floats: 8-byte aligned, at most
+// 2-way bank conflicts on the b32 operand reads).  These layers are tiny (<= 0.3 GFLOP together); as one-wave-per-output
+// dot-product kernels the two batched launches took 104 us + 83 us (profiles/r02_k_step_timeline.txt); here 41 + 39 us.
+// (The 8 mapping layers stay on equal_linear_kernel: 32 x 512 x 512 gives this tile shape 4 workgroups and a serial chain
+// of 8 load latencies -- 24 us against 14.)
+constexpr int HG_ROWS = 32, HG_COLS = 128, HG_KC = 64, HG_LD = 66;
+typedef __attribute__((ext_vector_type(16))) float hg_f32x16;
 
-__global__ __launch_bounds__(256) void modulation_batch_kernel(float* __restrict__ out_base,
-                                                               const float* __restrict__ latent,
-                                                               const int64_t* __restrict__ table, BatchHdr h) {
-    int layer = 0;
-    for (int l = 1; l < h.n_layers; ++l)
-        if ((int)blockIdx.x >= (int)table[l * 8 + 5]) layer = l;
-    const int64_t* row = table + layer * 8;
-    const float* w = reinterpret_cast<const float*>(row[0]);
-    const float* bias = reinterpret_cast<const float*>(row[1]);
-    float* out = out_base + row[2];
-    const int lat = (int)row[3], out_dim = (int)row[4];
-    const int o = ((int)blockIdx.x - (int)row[5]) * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (o >= out_dim) return;
-    float wr[ELW];
-#pragma unroll
-    for (int j = 0; j < ELW; ++j) {
-        const int i = lane + 64 * j;
-        wr[j] = (i < h.dim) ? w[(int64_t)o * h.dim + i] : 0.f;
-    }
-    const float b = bias ? bias[o] : 0.f;
-    const int r0 = blockIdx.y * EL_ROWS;
-    float acc[EL_ROWS];
-#pragma unroll
-    for (int rr = 0; rr < EL_ROWS; ++rr) {
-        acc[rr] = 0.f;
-        const int r = r0 + rr;
-        if (r < h.batch) {
-            const float* xr = latent + ((int64_t)r * h.n_latent + lat) * h.dim;
-#pragma unroll
-            for (int j = 0; j < ELW; ++j) {
-                const int i = lane + 64 * j;
-                if (i < h.dim) acc[rr] += xr[i] * wr[j];
-            }
+struct HeadArgs {
+    // MODE 0 (EqualLinear): a/w/bias/out direct.  MODE 1 (modulation) / 2 (demodulation): table rows, see the launchers.
+    float* out; const float* a; const float* w; const float* bias; const int64_t* table;
+    int64_t a_row_stride;
+    int batch, k_dim, out_dim, n_layers, n_latent, activation;
+    float scale, lr_mul;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void head_gemm_kernel(const HeadArgs h) {
+    __shared__ __attribute__((aligned(16))) float Al[HG_ROWS * HG_LD];
+    __shared__ __attribute__((aligned(16))) float Wl[HG_COLS * HG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const float* a = h.a; const float* w = h.w; const float* bias = h.bias; float* out = h.out;
+    int k_dim = h.k_dim, out_dim = h.out_dim, tile = blockIdx.x, demodulate = 1;
+    int64_t a_stride = h.a_row_stride;
+    float scale = h.scale;
+    if (MODE != 0) {
+        int layer = 0;
+        for (int l = 1; l < h.n_layers; ++l)
+            if ((int)blockIdx.x >= (int)h.table[l * 8 + 5]) layer = l;
+        const int64_t* row = h.table + layer * 8;
+        w = reinterpret_cast<const float*>(row[0]);
+        tile = (int)blockIdx.x - (int)row[5];
+        out_dim = (int)row[4];
+        if (MODE == 1) {
+            bias = reinterpret_cast<const float*>(row[1]);
+            out = h.out + row[2];
+            a = h.a + row[3] * h.k_dim;                 // latent[:, index, :]
+            a_stride = (int64_t)h.n_latent * h.k_dim;
+        } else {
+            scale = __int_as_float((int)row[1]);
+            k_dim = (int)row[6]; demodulate = (int)row[7];
+            a = h.a + row[2]; a_stride = k_dim;         // s[b, :] of this layer
+            out = h.out + row[3];
         }
     }
-#pragma unroll
-    for (int rr = 0; rr < EL_ROWS; ++rr) acc[rr] = wave_sum(acc[rr]);
-    if (lane == 0) {
-#pragma unroll
-        for (int rr = 0; rr < EL_ROWS; ++rr)
-            if (r0 + rr < h.batch) out[(int64_t)(r0 + rr) * out_dim + o] = acc[rr] * h.scale + b;
+    const int r0 = blockIdx.y * HG_ROWS, o0 = tile * HG_COLS;
+    if (MODE == 2 && !demodulate) {
+        for (int e = tid; e < HG_ROWS * HG_COLS; e += 256) {
+            const int r = r0 + e / HG_COLS, o = o0 + e % HG_COLS;
+            if (r < h.batch && o < out_dim) out[(int64_t)r * out_dim + o] = scale;
+        }
+        return;
     }
-}
-
-// table rows (8 x int64): {wsq ptr, unused, s offset, dscale offset, cout, first_block (units of 4 (b,co) pairs), cin, demodulate};
-// conv scale = 1/sqrt(cin * taps) is passed as a float bit pattern in row[1].
-__global__ __launch_bounds__(256) void demod_batch_kernel(float* __restrict__ dscale_base,
-                                                          const float* __restrict__ s_base,
-                                                          const int64_t* __restrict__ table, int n_layers, int batch) {
-    int layer = 0;
-    for (int l = 1; l < n_layers; ++l)
-        if ((int)blockIdx.x >= (int)table[l * 8 + 5]) layer = l;
-    const int64_t* row = table + layer * 8;
-    const float* wsq = reinterpret_cast<const float*>(row[0]);
-    const float scale = __int_as_float((int)row[1]);
-    const float* s = s_base + row[2];
-    float* dscale = dscale_base + row[3];
-    const int cout = (int)row[4], cin = (int)row[6], demodulate = (int)row[7];
-    const int64_t idx = ((int64_t)blockIdx.x - row[5]) * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (idx >= (int64_t)batch * cout) return;
-    const int b = (int)(idx / cout), co = (int)(idx % cout);
-    if (!demodulate) { if (lane == 0) dscale[idx] = scale; return; }
-    const float* sr = s + (int64_t)b * cin;
-    const float* wr = wsq + (int64_t)co * cin;
-    float acc = 0.f;
-    for (int i = lane; i < cin; i += 64) { const float sv = sr[i] * scale; acc += sv * sv * wr[i]; }
-    acc = wave_sum(acc);
-    if (lane == 0) dscale[idx] = scale * rsqrtf(acc + 1e-8f);
+    hg_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int srow = tid >> 3, sk = (tid & 7) * 8;  // staging: 8 consecutive k of one row per thread and pass
+    float av[8], wv[4][8];
+    auto load_chunk = [&](int k0) {  // global -> registers (the next chunk's loads fly under this chunk's MFMAs)
+        {
+            const int r = r0 + srow;
+            const float* src = a + (int64_t)r * a_stride + k0 + sk;
+            const bool full = r < h.batch && k0 + sk + 8 <= k_dim && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+            if (full) {
+                const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+                av[0] = v0.x; av[1] = v0.y; av[2] = v0.z; av[3] = v0.w; av[4] = v1.x; av[5] = v1.y; av[6] = v1.z; av[7] = v1.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) av[j] = (r < h.batch && k0 + sk + j < k_dim) ? src[j] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int pss = 0; pss < 4; ++pss) {
+            const int o = o0 + pss * 32 + srow;
+            const float* src = w + (int64_t)o * k_dim + k0 + sk;
+            const bool full = o < out_dim && k0 + sk + 8 <= k_dim && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+            if (full) {
+                const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+                wv[pss][0] = v0.x; wv[pss][1] = v0.y; wv[pss][2] = v0.z; wv[pss][3] = v0.w;
+                wv[pss][4] = v1.x; wv[pss][5] = v1.y; wv[pss][6] = v1.z; wv[pss][7] = v1.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wv[pss][j] = (o < out_dim && k0 + sk + j < k_dim) ? src[j] : 0.f;
+            }
+        }
+    };
+    load_chunk(0);
+    for (int k0 = 0; k0 < k_dim; k0 += HG_KC) {
+        if (MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float t = av[j] * scale; av[j] = t * t; }
+        }
+        __syncthreads();  // the previous chunk's operand reads are done
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) *reinterpret_cast<float2*>(Al + srow * HG_LD + sk + j) = make_float2(av[j], av[j + 1]);
+#pragma unroll
+        for (int pss = 0; pss < 4; ++pss)
+#pragma unroll
+            for (int j = 0; j < 8; j += 2)
+                *reinterpret_cast<float2*>(Wl + (pss * 32 + srow) * HG_LD + sk + j) = make_float2(wv[pss][j], wv[pss][j + 1]);
+        __syncthreads();
+        if (k0 + HG_KC < k_dim) load_chunk(k0 + HG_KC);
+        const float* ap = Al + l31 * HG_LD + half;
+        const float* wp = Wl + (wave * 32 + l31) * HG_LD + half;
+#pragma unroll
+        for (int st = 0; st < HG_KC / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * st], wp[2 * st], acc, 0, 0, 0);
+    }
+    const int o = o0 + wave * 32 + l31;
+    if (o >= out_dim) return;
+    float b = 0.f;
+    if (MODE == 0) b = bias ? bias[o] * h.lr_mul : 0.f;
+    if (MODE == 1) b = bias ? bias[o] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+        if (r >= h.batch) continue;
+        float v;
+        if (MODE == 2) v = scale * rsqrtf(acc[i] + 1e-8f);
+        else v = acc[i] * scale + b;
+        if (MODE == 0 && h.activation) v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
+        out[(int64_t)r * out_dim + o] = v;
+    }
 }
 
 __global__ __launch_bounds__(256) void truncate_kernel(float* __restrict__ out, const float* __restrict__ w,
@@ -304,14 +354,23 @@ extern "C" int sis_pixel_norm(float* out, const float* x, int batch, int dim, vo
     return 0;
 }
 
+extern "C" int sis_head_gemm_tile() { return HG_COLS; }
+
 extern "C" int sis_equal_linear(float* out, const float* x, int64_t x_row_stride, const float* w, const float* bias,
                                 int batch, int in_dim, int out_dim, float scale, float lr_mul, int activation,
                                 void* stream) {
     if (batch <= 0 || out_dim <= 0) return 0;
     SIS_REQUIRE(out && x && w, "sis_equal_linear: null pointer");
-    SIS_REQUIRE(in_dim > 0 && in_dim <= 64 * ELW, "sis_equal_linear: in_dim %d outside 1..%d", in_dim, 64 * ELW);
-    hipLaunchKernelGGL(equal_linear_kernel, dim3(sis_cdiv(out_dim, 4), sis_cdiv(batch, EL_ROWS)), dim3(256), 0, (hipStream_t)stream, out, x,
-                       x_row_stride, w, bias, batch, in_dim, out_dim, scale, lr_mul, activation);
+    SIS_REQUIRE(in_dim > 0, "sis_equal_linear: in_dim %d", in_dim);
+    if (in_dim <= 64 * ELW) {
+        hipLaunchKernelGGL(equal_linear_kernel, dim3(sis_cdiv(out_dim, 4), sis_cdiv(batch, EL_ROWS)), dim3(256), 0, (hipStream_t)stream, out, x,
+                           x_row_stride, w, bias, batch, in_dim, out_dim, scale, lr_mul, activation);
+    } else {  // wider than a wave's register row: the matrix-core tile kernel takes any in_dim
+        HeadArgs h = {};
+        h.out = out; h.a = x; h.w = w; h.bias = bias; h.a_row_stride = x_row_stride; h.batch = batch; h.k_dim = in_dim;
+        h.out_dim = out_dim; h.scale = scale; h.lr_mul = lr_mul; h.activation = activation;
+        hipLaunchKernelGGL(head_gemm_kernel<0>, dim3(sis_cdiv(out_dim, HG_COLS), sis_cdiv(batch, HG_ROWS)), dim3(256), 0, (hipStream_t)stream, h);
+    }
     SIS_CHECK_LAUNCH("sis_equal_linear");
     return 0;
 }
@@ -320,11 +379,11 @@ extern "C" int sis_modulation_batch(float* out_base, const float* latent, const 
                                     int total_blocks, int batch, int n_latent, int dim, float scale, void* stream) {
     if (n_layers <= 0 || batch <= 0) return 0;
     SIS_REQUIRE(out_base && latent && table, "sis_modulation_batch: null pointer");
-    SIS_REQUIRE(dim > 0 && dim <= 64 * ELW, "sis_modulation_batch: style dim %d outside 1..%d", dim, 64 * ELW);
-    BatchHdr h;
-    h.n_layers = n_layers; h.batch = batch; h.dim = dim; h.n_latent = n_latent; h.scale = scale;
-    hipLaunchKernelGGL(modulation_batch_kernel, dim3(total_blocks, sis_cdiv(batch, EL_ROWS)), dim3(256), 0,
-                       (hipStream_t)stream, out_base, latent, table, h);
+    SIS_REQUIRE(dim > 0, "sis_modulation_batch: style dim %d", dim);
+    HeadArgs h = {};
+    h.out = out_base; h.a = latent; h.table = table; h.batch = batch; h.k_dim = dim; h.n_layers = n_layers; h.n_latent = n_latent;
+    h.scale = scale;
+    hipLaunchKernelGGL(head_gemm_kernel<1>, dim3(total_blocks, sis_cdiv(batch, HG_ROWS)), dim3(256), 0, (hipStream_t)stream, h);
     SIS_CHECK_LAUNCH("sis_modulation_batch");
     return 0;
 }
@@ -333,8 +392,9 @@ extern "C" int sis_demod_batch(float* dscale_base, const float* s_base, const in
                                int total_blocks, int batch, void* stream) {
     if (n_layers <= 0 || batch <= 0) return 0;
     SIS_REQUIRE(dscale_base && s_base && table, "sis_demod_batch: null pointer");
-    hipLaunchKernelGGL(demod_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, dscale_base, s_base,
-                       table, n_layers, batch);
+    HeadArgs h = {};
+    h.out = dscale_base; h.a = s_base; h.table = table; h.batch = batch; h.n_layers = n_layers;
+    hipLaunchKernelGGL(head_gemm_kernel<2>, dim3(total_blocks, sis_cdiv(batch, HG_ROWS)), dim3(256), 0, (hipStream_t)stream, h);
     SIS_CHECK_LAUNCH("sis_demod_batch");
     return 0;
 }

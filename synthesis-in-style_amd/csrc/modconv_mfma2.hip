@@ -407,14 +407,7 @@ int launch_v2(ConvParams& p, hipStream_t st) {
     const int64_t bx = (int64_t)p.npos_tiles * sis_cdiv(p.Cout, C::MBLK);
     SIS_REQUIRE(bx > 0 && bx < ((int64_t)1 << 31), "modconv: bad grid");
     sis_kernel_name = MODE == 1 ? "modconv_v2_kernel<1, 3>" : KS == 3 ? "modconv_v2_kernel<0, 3>" : "modconv_v2_kernel<0, 1>";
-    if (getenv("SIS_V2_OCC")) {  // development: what does the runtime think fits on a CU?
-        int nb = -1;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, modconv_v2_kernel<MODE, KS, C>, C::THREADS, lds);
-        hipFuncAttributes fa;
-        hipError_t e2 = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&modconv_v2_kernel<MODE, KS, C>));
-        fprintf(stderr, "[v2 occ] mode %d threads %d lds %zu -> blocks/CU %d (%s); regs %d static lds %zu scratch %zu (%s)\n", MODE, C::THREADS, lds, nb,
-                hipGetErrorString(e), fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, hipGetErrorString(e2));
-    }
+    SIS_OCC_REPORT((modconv_v2_kernel<MODE, KS, C>), C::THREADS, lds);
     hipLaunchKernelGGL((modconv_v2_kernel<MODE, KS, C>), dim3((unsigned)bx, p.ksplit), dim3(C::THREADS), lds, st, p, xt_max);
     SIS_CHECK_LAUNCH("modconv_v2_kernel");
     if (p.ksplit > 1) {

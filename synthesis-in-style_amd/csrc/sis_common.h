@@ -21,6 +21,18 @@ static inline int sis_fail(const char* fmt, ...) {
 }
 
 // Launch-error check: no host sync, just the launch status.
+// Development aid (SIS_OCC=1): what the runtime says fits on a CU for this launch -- a kernel's dynamic LDS size or register
+// count can silently halve the workgroups per CU its design assumes (the transposed modconv ran one per CU for a round).
+#define SIS_OCC_REPORT(kernel, threads, lds_bytes)                                                                      \
+    do {                                                                                                                \
+        static const bool occ_on_ = getenv("SIS_OCC") != nullptr;                                                       \
+        if (occ_on_) {                                                                                                  \
+            int nb_ = -1;                                                                                               \
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, kernel, (int)(threads), (size_t)(lds_bytes));      \
+            fprintf(stderr, "[occ] %s: %d threads, %zu B LDS -> %d workgroups per CU\n", #kernel, (int)(threads), (size_t)(lds_bytes), nb_); \
+        }                                                                                                               \
+    } while (0)
+
 #define SIS_CHECK_LAUNCH(name)                                                                   \
     do {                                                                                         \
         hipError_t e_ = hipGetLastError();                                                       \

@@ -423,6 +423,7 @@ class Generator(nn.Module):
         if getattr(self, '_plan_key', None) == key:
             return self._plan
         mod_rows, dem_rows, s_off, d_off, mblocks, dblocks = [], [], 0, 0, 0, 0
+        tile = sis_hip.head_gemm_tile()
         s_slices, d_slices = [], []
         for m, lat in seq:
             conv = m.conv
@@ -430,13 +431,13 @@ class Generator(nn.Module):
             lin = conv.modulation
             mod_rows.append([lin.weight.data_ptr(), lin.bias.data_ptr(), s_off, lat, cin, mblocks, 0, 0])
             s_slices.append((s_off, cin))
-            mblocks += (cin + 3) // 4
+            mblocks += (cin + tile - 1) // tile
             if isinstance(m, StyledConv):
                 _, wsq = conv.packed_weights()
                 bits = struct.unpack('<i', struct.pack('<f', conv.scale))[0]
                 dem_rows.append([wsq.data_ptr(), bits, s_off, d_off, cout, dblocks, cin, int(conv.demodulate)])
                 d_slices.append((d_off, cout))
-                dblocks += (batch * cout + 3) // 4
+                dblocks += (cout + tile - 1) // tile
                 d_off += batch * cout
             else:
                 d_slices.append(None)

@@ -39,6 +39,7 @@ _SIGNATURES = {
     "sis_modconv_prepack": ([_vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "sis_modconv_demod": ([_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp], _i),
     "sis_modconv2d": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 7 + [_vp, _vp, _i64, _vp], _i),
+    "sis_head_gemm_tile": ([], _i),
     "sis_modconv_prepack_wino": ([_vp, _vp, _i, _i, _vp], _i),
     "sis_last_kernel": ([], ctypes.c_char_p),
     "sis_conv3x3_prepack": ([_vp, _vp, _i, _i, _i, _vp], _i),
@@ -248,6 +249,11 @@ def equal_linear(x, weight, bias, scale, lr_mul, activation, row_stride=None, ba
                                       float(scale), float(lr_mul), int(bool(activation)), _stream()),
                "sis_equal_linear")
     return out
+
+
+def head_gemm_tile():
+    """Output features per workgroup of the batched modulation / demodulation launches (their tables count blocks in it)."""
+    return int(lib().sis_head_gemm_tile())
 
 
 def modulation_batch(out_flat, latent, table, n_layers, total_blocks, scale):
