@@ -607,9 +607,8 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
         // One slot after each of the 32 MFMAs.  Issue costs add up inside an MFMA gap and only ~48 cycles of them hide under a
         // 64-cycle MFMA (MI355X_MICROARCH.md, constants: an LDS-DMA piece costs 60-185 cycles to issue, a packed-f32 VALU
         // instruction ~3x a scalar one), so the side work is spread one expensive item per slot.
-        auto chunk = [&](auto parity, auto late_c, const int ci0, const int c) {
+        auto chunk = [&](auto parity, const int ci0, const int c) {
             constexpr int cur = decltype(parity)::value, nxt = cur ^ 1;
-            constexpr bool LATE = decltype(late_c)::value;
             WINO_TRACE(0);
             const bool last = ci0 + WCC >= k_hi;          // the transform below then works for the next tile's chunk 0
             const int uci = last ? k_lo : ci0 + WCC;      // weights: the same for every tile
@@ -629,12 +628,11 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
             float sv = 1.f, d[4][4], e[4][4], o[4][4];  // patch, d B, B^T (d B) scaled
             // slot tables: first slot of each kind of side work
             constexpr int X_STEP = XI > 2 ? 1 : 2;  // input pieces every (second) slot, weight pieces every second slot
-            constexpr int S_XDMA = LATE ? 16 : 8, S_UDMA = LATE ? S_XDMA + X_STEP * XI : 0;
-            static_assert(S_UDMA + 2 * (WIT - 1) < 32 && S_XDMA + X_STEP * (XI - 1) < 32, "DMA pieces must fit the 32 slots");
-            constexpr int S_READ = LATE ? 0 : 1;    // patch rows: 4 slots, every second slot for the early half
-            constexpr int S_RSTEP = LATE ? 1 : 2;
-            constexpr int S_A = LATE ? 4 : 11;      // d B: 4 slots
-            constexpr int S_B = LATE ? 8 : 15;      // B^T (d B) and scale, column j: slots S_B + 2 j, S_B + 2 j + 1; writes follow
+            constexpr int S_UDMA = 0, S_XDMA = 8;
+            static_assert(S_UDMA + 2 * (WIT - 1) < S_XDMA && S_XDMA + X_STEP * (XI - 1) < 32, "DMA pieces must fit the 32 slots");
+            constexpr int S_READ = 1, S_RSTEP = 2;  // patch rows: every second slot from slot 1
+            constexpr int S_A = 11;                 // d B: 4 slots
+            constexpr int S_B = 15;                 // B^T (d B) and scale, column j: slots S_B + 2 j, S_B + 2 j + 1; writes follow
             operands(0, 0);  // operands run two groups (four MFMA pairs) ahead
             operands(1, 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -693,13 +691,13 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
             __syncthreads();  // V(c+1) written, DMA retired, everyone done with U(c) / V(c)
 #endif
         };
-        // (Giving waves 4-7 the `late` placement -- their DMA in the second half of the chunk, while their SIMD partners are
-        // between pieces -- measured 6-8 % SLOWER on the same device: the late pieces are not landed at the barrier.)
+        // (A `late` placement for waves 4-7 -- their DMA in the second half of the chunk, while their SIMD partners are between
+        // pieces -- measured 6-8 % SLOWER on the same device: the late pieces are not landed at the barrier.)
         // Buffer parity is a compile-time constant: a tile starts on parity 0 -- workgroups that walk several tiles have an
         // even chunk count per tile (host-checked) -- and the loop body is a pair of chunks.
         for (int ci0 = k_lo, c = 0; ci0 < k_hi; ci0 += 2 * WCC, c += 2) {
-            chunk(std::integral_constant<int, 0>(), std::false_type(), ci0, c);
-            if (ci0 + WCC < k_hi) chunk(std::integral_constant<int, 1>(), std::false_type(), ci0 + WCC, c + 1);
+            chunk(std::integral_constant<int, 0>(), ci0, c);
+            if (ci0 + WCC < k_hi) chunk(std::integral_constant<int, 1>(), ci0 + WCC, c + 1);
         }
 
         WINO_TRACE_TILE(1);

@@ -50,11 +50,11 @@ for g in range(4):
     t = (t - t0) & 0xFFFFFFFF
     per_chunk = np.diff(t[:, :, 0], axis=1)            # [wave][chunk] loop-top to loop-top
     print(f"workgroup {g}: cycles per chunk (median over chunks 4..{nch - 2}) by wave:", np.median(per_chunk[:, 4:nch - 1], axis=1).astype(int))
-    seg = np.stack([t[:, :, 1] - t[:, :, 0], t[:, :, 2] - t[:, :, 1], t[:, :, 3] - t[:, :, 2]], axis=-1)  # early tf+dma issue, mfma, late tf
+    seg = np.stack([t[:, :, 1] - t[:, :, 0], t[:, :, 2] - t[:, :, 1], t[:, :, 3] - t[:, :, 2]], axis=-1)  # first operand reads, the 32 slots, tail
     wait = t[:, 1:, 0] - t[:, :-1, 3]                 # barrier wait (incl. vmcnt(0))
     for wv in range(8):
         m = np.median(seg[wv, 4:nch - 1], axis=0).astype(int)
-        print(f"  wave {wv}: issue+early-transform {m[0]:5d}  mfma phase {m[1]:5d}  late transform {m[2]:5d}  barrier wait {int(np.median(wait[wv, 4:nch - 2])):5d}")
+        print(f"  wave {wv}: top to first MFMA {m[0]:5d}  32 MFMA slots {m[1]:5d}  tail {m[2]:5d}  barrier wait {int(np.median(wait[wv, 4:nch - 2])):5d}")
     if g == 0:
         print("  chunk 10 raw (wave x stamp), relative to the earliest stamp of the chunk:")
         r = t[:, 10, :] - t[:, 10, :].min()
