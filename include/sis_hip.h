@@ -321,6 +321,16 @@ int sis_upsample_bilinear(void* out, const void* x, int dtype, int64_t planes, i
                           int backward, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * nn.MaxPool2d / F.max_pool2d of the segmentation backbones (ceil_mode false, dilation 1): EMANet stem (3, 2, 1)
+ * (networks/ema_net/network.py:66), TransUNet root (3, 2, 0) (vit_seg_modeling_resnet_skip.py:146); f32 / f16 / bf16.
+ * backward = 0: out [planes][out_h][out_w] and argmax (one byte per output: kh * kernel + kw of the FIRST maximum in
+ *               row-major window order, ATen's tie rule) from x [planes][h][w].
+ * backward = 1: out = grad_x [planes][h][w] from x = grad_out [planes][out_h][out_w] and the forward's argmax (gather,
+ *               deterministic, bit-equal to ATen's max_pool2d_with_indices_backward). */
+int sis_max_pool2d(void* out, unsigned char* argmax, const void* x, int dtype, int64_t planes, int h, int w, int out_h,
+                   int out_w, int kernel, int stride, int padding, int backward, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Patch-wise page inference.  The patch grid is the product of `nx` left edges `xs` and
  * `ny` top edges `ys` (device int32 arrays, ascending), patch n = yi * nx + xi, as
  * segmentation/analysis_segmenter.py:83-113 enumerates them.

@@ -28,6 +28,7 @@ from torch.nn.modules.batchnorm import _BatchNorm
 import sis_hip
 from networks.base_segmenter import BaseSegmenter
 from networks.hip_conv import HipConv2d
+from networks.hip_pool import HipMaxPool2d
 
 BN_MOM = 3e-4
 RESNET_BLOCKS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
@@ -129,7 +130,7 @@ class ResNet(nn.Module):
             HipConv2d(64, 128, 3, 1, 1, bias=False))
         self.bn1 = norm_layer(self.inplanes)
         self.relu = nn.ReLU(inplace=True)
-        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.maxpool = HipMaxPool2d(kernel_size=3, stride=2, padding=1)
         self.layer1 = self._make_layer(block, 64, layers[0])
         self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
         if stride == 16:

@@ -22,6 +22,7 @@ from torch.autograd import Function
 
 import sis_hip
 from networks.hip_conv import _BF16_CONV, _Pointwise, conv_bf16, conv_bf16_applicable
+from networks.hip_pool import max_pool2d
 
 
 def np2th(weights, conv=False):
@@ -189,7 +190,7 @@ class ResNetV2(nn.Module):
         in_size = x.size(2)
         x = self.root(x)
         skips = [x]
-        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=0)
+        x = max_pool2d(x, kernel_size=3, stride=2, padding=0)
         for i, stage in enumerate(self.body):
             x = stage(x)  # possibly (fp32, 16-bit) pairs between the units; everything outside the trunk reads the 16-bit copy
             feat = x[1] if isinstance(x, tuple) else x

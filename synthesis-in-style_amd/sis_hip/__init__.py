@@ -63,6 +63,7 @@ _SIGNATURES = {
     "sis_modconv2d_up": ([_vp] * 5 + [_i] * 6 + [_vp, _i64, _vp], _i),
     "sis_blur_noise_act": ([_vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 10 + [_vp], _i),
     "sis_to_rgb": ([_vp] * 7 + [_i] * 9 + [_f, _vp], _i),
+    "sis_max_pool2d": ([_vp, _vp, _vp, _i, _i64] + [_i] * 8 + [_vp], _i),
     "sis_upsample_ce_workspace": ([_i] * 3, _i),
     "sis_upsample_ce_fwd": ([_vp] * 4 + [_i] * 6 + [_i64, _vp], _i),
     "sis_upsample_ce_bwd": ([_vp] * 4 + [_i] * 6 + [_i64, _vp], _i),
@@ -895,6 +896,36 @@ def upsample_bilinear(x, out_h, out_w, grad_output=None):
         _check(lib().sis_upsample_bilinear(_ptr(out), _ptr(src), _DTYPE_CODE[x.dtype], b * c, h, w, out_h, out_w, backward,
                                            _stream()), "sis_upsample_bilinear")
     return out
+
+
+# ------------------------------------------------------------------------------ max pooling
+
+
+def max_pool2d(x, kernel, stride, padding):
+    """x [B,C,H,W] -> (out [B,C,Ho,Wo], argmax uint8 [B,C,Ho,Wo]); floor mode, dilation 1 (ATen's output size rule)."""
+    require_device(x, "input")
+    if x.dtype not in _DTYPE_CODE or x.dtype == torch.float64:
+        raise RuntimeError(f"max_pool2d: dtype {x.dtype} not supported")
+    b, c, h, w = x.shape
+    oh, ow = (h + 2 * padding - kernel) // stride + 1, (w + 2 * padding - kernel) // stride + 1
+    x = x.contiguous()
+    out = torch.empty((b, c, oh, ow), dtype=x.dtype, device=x.device)
+    arg = torch.empty((b, c, oh, ow), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_max_pool2d(_ptr(out), _ptr(arg), _ptr(x), _DTYPE_CODE[x.dtype], b * c, h, w, oh, ow, kernel, stride,
+                                    padding, 0, _stream()), "sis_max_pool2d")
+    return out, arg
+
+
+def max_pool2d_backward(grad_output, argmax, in_h, in_w, kernel, stride, padding):
+    require_device(grad_output, "grad_output")
+    b, c, oh, ow = grad_output.shape
+    g = grad_output.contiguous()
+    dx = torch.empty((b, c, in_h, in_w), dtype=g.dtype, device=g.device)
+    with torch.cuda.device(g.device):
+        _check(lib().sis_max_pool2d(_ptr(dx), _ptr(argmax), _ptr(g), _DTYPE_CODE[g.dtype], b * c, in_h, in_w, oh, ow, kernel,
+                                    stride, padding, 1, _stream()), "sis_max_pool2d")
+    return dx
 
 
 # ------------------------------------------------------------------------------ patch-wise page inference
