@@ -192,8 +192,9 @@ class _ConvBf16Function(Function):
     kernel reads the fp32 master weight or the bf16 standardised weight directly).
 
     forward        sis_conv_bf16 on the packed weight
-    dL/dx          the same kernel on the adjoint packing (stride 1); the library for the four stride-2 layers
-    dL/dw          3x3: sis_conv_bf16_wgrad where its tile plan applies, the library otherwise; 1x1 stride 1: one batched
+    dL/dx          the same kernel on the adjoint packing; 3x3 stride 2: on dL/dy zero-stuffed to the input's size
+    dL/dw          3x3: sis_conv_bf16_wgrad where its tile plan applies (stride 2: on the zero-stuffed dL/dy), the library
+                   otherwise; 1x1 stride 1: one batched
                    GEMM dy_b x_b^T on the NCHW tensors + sum over the batch
     dL/dbias       fp32 sum of dL/dy
     """
@@ -224,6 +225,13 @@ class _ConvBf16Function(Function):
             gy = gy.bfloat16()
         grad_input = grad_weight = grad_bias = None
         lib_weight = None
+        if s == 2 and k == 3 and _STRIDE2_OWN and sis_hip.conv_bf16_supported(cout, cin, h, w, k, 1):
+            # A stride-2 convolution is the stride-1 convolution sampled at the even pixels, so its gradients are the
+            # stride-1 gradients of dL/dy written into a zero map of the input's size: 4x the multiplies of a dedicated
+            # stride-2 backward, on kernels that run several times the rate of the library's (three layers of the net).
+            g_full = gy.new_zeros((b, cout, h, w))
+            g_full[:, :, ::2, ::2] = gy
+            gy, s = g_full, 1
         if ctx.needs_input_grad[0]:
             if s == 1 and sis_hip.conv_bf16_supported(cout, cin, h, w, k, 1):
                 if adjoint is None:
@@ -258,6 +266,7 @@ def conv_bf16(input, weight, bias=None, stride=1):
 
 
 _BF16_CONV = os.environ.get('SIS_BF16_CONV', '1') != '0'  # 0: bf16 convolutions stay on the library (A/B runs)
+_STRIDE2_OWN = os.environ.get('SIS_STRIDE2_OWN', '1') != '0'  # 0: stride-2 layers (their backward under bf16) stay on the library
 
 
 class HipConv2d(nn.Conv2d):
@@ -285,10 +294,27 @@ class HipConv2d(nn.Conv2d):
         return (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.groups == 1
                 and input.is_cuda and input.dim() == 4 and input.is_contiguous())
 
+    def _stride2(self, input):
+        """fp32 stride-2 layers (EMANet: layer2's 3x3 and its 1x1 shortcut) on the stride-1 kernels: a strided convolution
+        is the dense one sampled at the even pixels (3x3, padding 1: 4x the multiplies on a kernel several times faster than
+        the library's; autograd's slice backward zero-fills the gradient) or the dense 1x1 on the sampled input."""
+        if not (_STRIDE2_OWN and self.stride == (2, 2) and self.dilation == (1, 1) and self.groups == 1 and self.bias is None
+                and self.padding_mode == 'zeros' and not torch.is_autocast_enabled() and input.is_cuda and input.dim() == 4
+                and input.dtype == torch.float32 and input.is_contiguous()):
+            return None
+        if self.kernel_size == (3, 3) and self.padding == (1, 1) and sis_hip.conv3x3_supported(input, self.weight, 1):
+            return conv3x3(input, self.weight, 1)[:, :, ::2, ::2].contiguous()
+        if self.kernel_size == (1, 1) and self.padding == (0, 0):
+            return _Pointwise.apply(input[:, :, ::2, ::2].contiguous(), self.weight, None)
+        return None
+
     def forward(self, input):
         x = self._bf16(input)
         if x is not None:
             return conv_bf16(x, self.weight, self.bias, self.stride[0])
+        y = self._stride2(input)
+        if y is not None:
+            return y
         if self._pointwise(input):
             return _Pointwise.apply(input, self.weight, self.bias)
         if self._half_image_dilation(input):

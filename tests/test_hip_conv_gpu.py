@@ -66,9 +66,10 @@ def test_module_dispatch_and_fallback(device):
     assert [r[0] for r in rec] == ["modconv_wino2_kernel"], "the 3x3 layer did not run on the HIP kernel"
     np.testing.assert_allclose(y.detach().cpu().numpy(), F.conv2d(x, conv.weight, padding=1).detach().cpu().numpy(),
                                atol=2e-5 * float(y.detach().abs().max()))
-    # not eligible: dilation 2, stride 2, odd width, bias -> ATen, same result as nn.Conv2d
+    # not eligible: dilation that does not divide the image, padding != dilation, stride 2 on an odd height, odd width -> ATen,
+    # same result as nn.Conv2d
     for kwargs, shape in (({"dilation": 3, "padding": 3}, (2, 64, 32, 32)), ({"dilation": 2, "padding": 1}, (2, 64, 16, 16)),
-                          ({"stride": 2, "padding": 1}, (2, 64, 16, 16)),
+                          ({"stride": 2, "padding": 1}, (2, 64, 15, 16)),
                           ({"padding": 1}, (2, 64, 16, 15))):
         c = HipConv2d(64, 32, 3, bias=False, **kwargs).to(device)
         xi = torch.randn(*shape, device=device)
@@ -123,3 +124,29 @@ def test_pointwise_convolution_is_a_batched_gemm(device):
             b = b.detach().float()
             assert (a - b).abs().max().item() < 2e-5 * b.abs().max().item()
     assert not HipConv2d(8, 8, 1, stride=2)._pointwise(torch.zeros(1, 8, 4, 4, device=device))
+
+
+@pytest.mark.parametrize("batch,cin,cout,h,w,k", [(4, 128, 128, 64, 64, 3), (2, 64, 64, 34, 48, 3), (3, 256, 512, 64, 64, 1), (2, 64, 128, 17, 20, 1)])
+def test_stride_2_layers_run_on_the_stride_1_kernels(device, batch, cin, cout, h, w, k):
+    """EMANet's fp32 stride-2 convolutions (layer2: 3x3 padding 1 and the 1x1 shortcut) as HipConv2d dispatches them:
+    dense kernel + even-pixel sampling.  Same tolerances as the stride-1 tests."""
+    import sis_hip
+    from networks.hip_conv import HipConv2d
+    g = torch.Generator().manual_seed(batch + cin + h)
+    conv = HipConv2d(cin, cout, k, 2, k // 2, bias=False).to(device)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(cout, cin, k, k, generator=g) * (cin * k * k) ** -0.5)
+    x = torch.randn(batch, cin, h, w, generator=g).to(device).requires_grad_(True)
+    assert conv._stride2(x) is not None
+    y = conv(x)
+    gy = torch.randn(y.shape, generator=g).to(device)
+    y.backward(gy)
+    gx, gw = x.grad.clone(), conv.weight.grad.clone()
+    x.grad = conv.weight.grad = None
+    ref = F.conv2d(x.double(), conv.weight.double(), stride=2, padding=k // 2)
+    assert ref.shape == y.shape
+    ref.backward(gy.double())
+    for got, want, name in ((y, ref, "y"), (gx, x.grad, "dx"), (gw, conv.weight.grad, "dw")):
+        want = want.detach().float()
+        err = (got.detach() - want).abs().max().item() / want.abs().max().item()
+        assert err < (2e-5 if name != "dw" else 2e-4), (name, err)
