@@ -320,6 +320,16 @@ int sis_layer_norm_bwd(void* dx, float* dgamma, float* dbeta, float* workspace, 
 int sis_upsample_bilinear(void* out, const void* x, int dtype, int64_t planes, int h, int w, int out_h, int out_w,
                           int backward, void* stream);
 
+/* Weight gradient of the same 1x1 convolutions (networks/hip_conv.py::_Pointwise.backward; reference layers as for
+ * sis_conv1x1_f32): dw[co][ci] = sum_{b, p} gy[b][co][p] * x[b][ci][p], fp32 on the matrix cores, NCHW rows straight from
+ * HBM by LDS-DMA, split-K over the (sample, pixel) stream with an ordered (deterministic) reduction through `workspace`
+ * (sis_conv1x1_wgrad_f32_workspace bytes; fewer bytes = fewer slices, NULL = one).  Supported: hw % 64 == 0 and
+ * (cout % 128 == 0 and cin % 64 == 0) or (cout % 64 == 0 and cin % 128 == 0) or (cout % 256 == 0 and cin % 32 == 0). */
+int sis_conv1x1_wgrad_f32_supported(int batch, int cin, int cout, int hw);
+int64_t sis_conv1x1_wgrad_f32_workspace(int batch, int cin, int cout, int hw);
+int sis_conv1x1_wgrad_f32(float* dw, const float* gy, const float* x, int batch, int cin, int cout, int hw,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * nn.MaxPool2d / F.max_pool2d of the segmentation backbones (ceil_mode false, dilation 1): EMANet stem (3, 2, 1)
  * (networks/ema_net/network.py:66), TransUNet root (3, 2, 0) (vit_seg_modeling_resnet_skip.py:146); f32 / f16 / bf16.

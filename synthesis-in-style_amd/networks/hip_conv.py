@@ -153,7 +153,10 @@ class _Pointwise(Function):
                                                                  (0, 0), 1, (True, False, False))[0]
         g = grad_output.view(b, cout, h * w)
         if ctx.needs_input_grad[1]:
-            grad_weight = torch.bmm(g, input.view(b, cin, h * w).transpose(1, 2)).sum(0).view(cout, cin, 1, 1)
+            if _F32_POINTWISE and sis_hip.conv1x1_wgrad_f32_supported(grad_output, input):
+                grad_weight = sis_hip.conv1x1_wgrad_f32(grad_output, input)  # csrc/conv1x1_wgrad_f32.hip
+            else:
+                grad_weight = torch.bmm(g, input.view(b, cin, h * w).transpose(1, 2)).sum(0).view(cout, cin, 1, 1)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = g.sum((0, 2))
         return grad_input, grad_weight, grad_bias

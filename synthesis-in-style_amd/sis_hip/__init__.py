@@ -63,6 +63,9 @@ _SIGNATURES = {
     "sis_modconv2d_up": ([_vp] * 5 + [_i] * 6 + [_vp, _i64, _vp], _i),
     "sis_blur_noise_act": ([_vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 10 + [_vp], _i),
     "sis_to_rgb": ([_vp] * 7 + [_i] * 9 + [_f, _vp], _i),
+    "sis_conv1x1_wgrad_f32_supported": ([_i] * 4, _i),
+    "sis_conv1x1_wgrad_f32_workspace": ([_i] * 4, _i64),
+    "sis_conv1x1_wgrad_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp], _i),
     "sis_max_pool2d": ([_vp, _vp, _vp, _i, _i64] + [_i] * 8 + [_vp], _i),
     "sis_upsample_ce_workspace": ([_i] * 3, _i),
     "sis_upsample_ce_fwd": ([_vp] * 4 + [_i] * 6 + [_i64, _vp], _i),
@@ -896,6 +899,28 @@ def upsample_bilinear(x, out_h, out_w, grad_output=None):
         _check(lib().sis_upsample_bilinear(_ptr(out), _ptr(src), _DTYPE_CODE[x.dtype], b * c, h, w, out_h, out_w, backward,
                                            _stream()), "sis_upsample_bilinear")
     return out
+
+
+def conv1x1_wgrad_f32_supported(grad_output, input):
+    return bool(grad_output.is_cuda and input.is_cuda and grad_output.dtype == torch.float32 and input.dtype == torch.float32
+                and grad_output.dim() == 4 and input.dim() == 4 and grad_output.is_contiguous() and input.is_contiguous()
+                and lib().sis_conv1x1_wgrad_f32_supported(input.shape[0], input.shape[1], grad_output.shape[1],
+                                                         input.shape[2] * input.shape[3]))
+
+
+def conv1x1_wgrad_f32(grad_output, input):
+    """dW [Cout, Cin, 1, 1] of a 1x1 stride-1 convolution from dL/dy [B,Cout,H,W] and x [B,Cin,H,W] (fp32, NCHW)."""
+    require_device(input, "input")
+    b, cin, h, w = input.shape
+    cout = grad_output.shape[1]
+    L = lib()
+    dw = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=input.device)
+    ws_bytes = int(L.sis_conv1x1_wgrad_f32_workspace(b, cin, cout, h * w))
+    ws = torch.empty(max(ws_bytes // 4, 4), dtype=torch.float32, device=input.device)
+    with torch.cuda.device(input.device):
+        _check(L.sis_conv1x1_wgrad_f32(_ptr(dw), _ptr(grad_output), _ptr(input), b, cin, cout, h * w, _ptr(ws) if ws_bytes else None,
+                                       ws_bytes, _stream()), "sis_conv1x1_wgrad_f32")
+    return dw
 
 
 # ------------------------------------------------------------------------------ max pooling

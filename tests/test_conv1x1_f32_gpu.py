@@ -43,3 +43,21 @@ def test_pointwise_autograd_path(device):
     F.conv2d(xr, wr).backward(gy)
     for got, ref in ((x.grad, xr.grad), (conv.weight.grad, wr.grad)):
         assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("batch,cin,cout,h,w", [(16, 64, 256, 64, 64), (16, 256, 64, 64, 64), (16, 512, 2048, 32, 32), (16, 2048, 512, 32, 32),
+                                                (3, 128, 128, 8, 8), (2, 32, 256, 16, 16), (5, 192, 384, 8, 16), (2, 1024, 1024, 8, 8), (1, 64, 128, 8, 8)])
+def test_weight_gradient_kernel(device, batch, cin, cout, h, w):
+    """dW = sum_b dy_b x_b^T on the fp32 matrix cores against the fp64 product; split-K slices are added in a fixed order:
+    two runs are bit-equal."""
+    import sis_hip
+    g = torch.Generator().manual_seed(batch * 7 + cin + cout)
+    x = torch.randn(batch, cin, h, w, generator=g).to(device)
+    gy = torch.randn(batch, cout, h, w, generator=g).to(device)
+    assert sis_hip.conv1x1_wgrad_f32_supported(gy, x)
+    dw = sis_hip.conv1x1_wgrad_f32(gy, x)
+    ref = torch.einsum("bop,bip->oi", gy.double().flatten(2), x.double().flatten(2)).view(cout, cin, 1, 1)
+    err = ((dw.double() - ref).abs().max() / ref.abs().max()).item()
+    assert err < 2e-5, err
+    assert torch.equal(dw, sis_hip.conv1x1_wgrad_f32(gy, x))
+    assert not sis_hip.conv1x1_wgrad_f32_supported(gy[:, :, :1, :7].contiguous(), x[:, :, :1, :7].contiguous())  # pixels % 64
