@@ -49,10 +49,14 @@ def _conv3x3_dgrad(grad_output, weight, d):
     return _batch_to_space(sis_hip.conv3x3(_space_to_batch(grad_output, d), sis_hip.conv3x3_prepack(weight, adjoint=True)), d)
 
 
-def _conv3x3_wgrad(input, grad_output, weight_shape, d):
+def _conv3x3_wgrad(input, grad_output, weight_shape, d, input_s=None, grad_output_s=None):
+    """``input_s`` / ``grad_output_s``: the sub-image forms of the two tensors when the caller already has them (a dilated
+    layer's forward keeps its permuted input, its backward permutes dL/dy once for both gradients: 4 permute copies per
+    layer and step instead of 6)."""
     b, cin, h, w = input.shape
     if sis_hip.conv3x3_wgrad_supported(b * d * d, cin, weight_shape[0], h // d, w // d):
-        return sis_hip.conv3x3_wgrad(_space_to_batch(input, d), _space_to_batch(grad_output, d))
+        return sis_hip.conv3x3_wgrad(_space_to_batch(input, d) if input_s is None else input_s,
+                                     _space_to_batch(grad_output, d) if grad_output_s is None else grad_output_s)
     # narrow sub-images / channel counts below a 64 x 64 tile / too little work: the library's kernel
     return torch.ops.aten.convolution_backward(grad_output, input, input.new_empty(weight_shape), None, (1, 1), (d, d), (d, d),
                                                False, (0, 0), 1, (False, True, False))[1]
@@ -61,15 +65,16 @@ def _conv3x3_wgrad(input, grad_output, weight_shape, d):
 class _Conv3x3Function(Function):
     @staticmethod
     def forward(ctx, input, weight, dilation):
-        ctx.save_for_backward(input, weight)
+        input_s = _space_to_batch(input, dilation)
+        ctx.save_for_backward(input, weight, input_s if dilation > 1 and ctx.needs_input_grad[1] else None)
         ctx.dilation = dilation
-        return _conv3x3_fwd(input, weight, dilation)
+        return _batch_to_space(sis_hip.conv3x3(input_s, sis_hip.conv3x3_prepack(weight)), dilation)
 
     @staticmethod
     def backward(ctx, grad_output):
-        input, weight = ctx.saved_tensors
+        input, weight, input_s = ctx.saved_tensors
         grad_input, grad_weight = _Conv3x3Backward.apply(grad_output.contiguous(), input, weight, ctx.dilation,
-                                                         ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+                                                         ctx.needs_input_grad[0], ctx.needs_input_grad[1], input_s)
         return grad_input, grad_weight, None
 
 
@@ -82,11 +87,15 @@ class _Conv3x3Backward(Function):
     all three on the same Winograd kernels as the first-order pass."""
 
     @staticmethod
-    def forward(ctx, grad_output, input, weight, dilation, want_input, want_weight):
+    def forward(ctx, grad_output, input, weight, dilation, want_input, want_weight, input_s=None):
         ctx.save_for_backward(grad_output, input, weight)
         ctx.dilation = dilation
-        grad_input = _conv3x3_dgrad(grad_output, weight, dilation) if want_input else None
-        grad_weight = _conv3x3_wgrad(input, grad_output, weight.shape, dilation) if want_weight else None
+        grad_output_s = _space_to_batch(grad_output, dilation)  # once, for both gradients
+        grad_input = grad_weight = None
+        if want_input:
+            grad_input = _batch_to_space(sis_hip.conv3x3(grad_output_s, sis_hip.conv3x3_prepack(weight, adjoint=True)), dilation)
+        if want_weight:
+            grad_weight = _conv3x3_wgrad(input, grad_output, weight.shape, dilation, input_s, grad_output_s)
         return grad_input, grad_weight
 
     @staticmethod
@@ -106,7 +115,7 @@ class _Conv3x3Backward(Function):
             d_x = _conv3x3_dgrad(grad_output, gg_weight.contiguous(), d)
         if need_w and gg_input is not None:
             d_w = _conv3x3_wgrad(gg_input.contiguous(), grad_output, weight.shape, d)
-        return d_gy, d_x, d_w, None, None, None
+        return d_gy, d_x, d_w, None, None, None, None
 
 
 def gan_winograd_enabled():
