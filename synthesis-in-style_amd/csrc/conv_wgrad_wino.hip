@@ -8,22 +8,25 @@
 // Per Winograd point xi this is a GEMM  S[xi] (co x ci) += E[xi] (co x tiles) * V[xi] (tiles x ci)  whose reduction
 // axis is the tile index.  Workgroup = 8 waves = 64 co x 64 ci x 16 xi (same accumulator split over wave pairs as
 // the forward kernel), K chunk = 8 consecutive tiles of the flattened (sample, row, column) tile order; per chunk every lane loads ONE dY tile and ONE input
-// patch from global memory into registers (one chunk ahead), transforms both and writes them into two LDS images
-// E / V [xi][tile][channel] (row stride 72 floats: the 8 tiles x 8 channels of a wave land 2-way on the banks,
-// which costs a ds_write_b32 nothing); the MFMA operands are then plain conflict-free ds_read_b32.  The two waves
-// sharing a SIMD are staggered (transform first / MFMA first) like in the forward kernel.
+// patch from global memory into registers (two chunks ahead), transforms both and writes them into two LDS images
+// E / V [xi][k slot half][channel][step kp]: tile 2 kp + half of the chunk, so that ONE ds_read_b128 of a lane (its channel,
+// its k slot) delivers the operands of the four MFMA steps of a Winograd point (lane-contiguous: conflict free; the
+// transform's b32 writes land 2-way, which costs a ds_write_b32 nothing).  Round 2: one straight-line block per chunk --
+// round 1's loop staggered the two waves of a SIMD (transform first / MFMA first), which on this SIMD makes them multiply
+// one after the other (tools/wino_trace.py on the forward kernel) -- with the loads, the two transforms and their 32 LDS
+// writes spread over the slots between the 32 MFMAs.
 // Split-K over tile ranges (blockIdx.y) writes raw S slabs; conv_wgrad_finish adds them in slice order
 // (deterministic) and applies G^T . G.
 #include "sis_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int GK = 8;     // tiles per chunk (MFMA K = 2 per instruction: 4 instructions per xi per chunk)
 constexpr int GBLK = 64;  // channels per workgroup on both GEMM axes
-constexpr int GLD = 72;   // LDS row stride of the E / V images in floats
 constexpr int GTHR = 512;
 
 struct WgradParams {
@@ -33,7 +36,7 @@ struct WgradParams {
 };
 
 __global__ __launch_bounds__(GTHR, 2) void conv_wgrad_wino_kernel(const WgradParams p) {
-    constexpr int IMG = 16 * GK * GLD;  // floats per image buffer
+    constexpr int IMG = 16 * 2 * GBLK * 4;  // floats per image buffer: [xi][half][channel][kp]
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* El = lds;            // [2][IMG]
     float* Vl = lds + 2 * IMG;  // [2][IMG]
@@ -73,40 +76,47 @@ __global__ __launch_bounds__(GTHR, 2) void conv_wgrad_wino_kernel(const WgradPar
         gr[0] = *reinterpret_cast<const f32x2*>(gb);
         gr[1] = *reinterpret_cast<const f32x2*>(gb + p.W);
     };
-    auto transform = [&](int buf) {
-        float* eb = El + buf * IMG + tk * GLD + ch;
-        float* vb = Vl + buf * IMG + tk * GLD + ch;
-        {   // E = A dY A^T,  A = [[1,0],[1,1],[1,-1],[0,-1]]
-            const float a = gr[0].x, b = gr[0].y, c = gr[1].x, d = gr[1].y;
-            const float rp[4] = {a, a + c, a - c, -c}, rq[4] = {b, b + d, b - d, -d};
+    // image offset of this lane's (tile, channel): [xi][half = tk & 1][ch][kp = tk >> 1]
+    const int img_off = ((tk & 1) * GBLK + ch) * 4 + (tk >> 1);  // + xi * 2 * GBLK * 4
+    constexpr int XI_STRIDE = 2 * GBLK * 4;
+    float ev[16], vv[16];  // transformed values of the chunk in flight (registers between their slots)
+    auto transform_e = [&]() {  // E = A dY A^T,  A = [[1,0],[1,1],[1,-1],[0,-1]]
+        const float a = gr[0].x, b = gr[0].y, c = gr[1].x, d = gr[1].y;
+        const float rp[4] = {a, a + c, a - c, -c}, rq[4] = {b, b + d, b - d, -d};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                eb[(r * 4 + 0) * GK * GLD] = rp[r];
-                eb[(r * 4 + 1) * GK * GLD] = rp[r] + rq[r];
-                eb[(r * 4 + 2) * GK * GLD] = rp[r] - rq[r];
-                eb[(r * 4 + 3) * GK * GLD] = -rq[r];
-            }
+        for (int r = 0; r < 4; ++r) {
+            ev[r * 4 + 0] = rp[r]; ev[r * 4 + 1] = rp[r] + rq[r]; ev[r * 4 + 2] = rp[r] - rq[r]; ev[r * 4 + 3] = -rq[r];
         }
-        {   // V = B^T d B
-            float dd[4][4];
+    };
+    float tt[4][4];
+    auto transform_v_rows = [&]() {  // B^T d
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { dd[r][0] = xr[r][0].y; dd[r][1] = xr[r][1].x; dd[r][2] = xr[r][1].y; dd[r][3] = xr[r][2].x; }
-            float tt[4][4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                tt[0][c] = dd[0][c] - dd[2][c];
-                tt[1][c] = dd[1][c] + dd[2][c];
-                tt[2][c] = dd[2][c] - dd[1][c];
-                tt[3][c] = dd[1][c] - dd[3][c];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                vb[(r * 4 + 0) * GK * GLD] = tt[r][0] - tt[r][2];
-                vb[(r * 4 + 1) * GK * GLD] = tt[r][1] + tt[r][2];
-                vb[(r * 4 + 2) * GK * GLD] = tt[r][2] - tt[r][1];
-                vb[(r * 4 + 3) * GK * GLD] = tt[r][1] - tt[r][3];
-            }
+        for (int c = 0; c < 4; ++c) {
+            const float d0 = c == 0 ? xr[0][0].y : c == 1 ? xr[0][1].x : c == 2 ? xr[0][1].y : xr[0][2].x;
+            const float d1 = c == 0 ? xr[1][0].y : c == 1 ? xr[1][1].x : c == 2 ? xr[1][1].y : xr[1][2].x;
+            const float d2 = c == 0 ? xr[2][0].y : c == 1 ? xr[2][1].x : c == 2 ? xr[2][1].y : xr[2][2].x;
+            const float d3 = c == 0 ? xr[3][0].y : c == 1 ? xr[3][1].x : c == 2 ? xr[3][1].y : xr[3][2].x;
+            tt[0][c] = d0 - d2; tt[1][c] = d1 + d2; tt[2][c] = d2 - d1; tt[3][c] = d1 - d3;
         }
+    };
+    auto transform_v_cols = [&](int r) {  // (B^T d) B, row r
+        vv[r * 4 + 0] = tt[r][0] - tt[r][2]; vv[r * 4 + 1] = tt[r][1] + tt[r][2];
+        vv[r * 4 + 2] = tt[r][2] - tt[r][1]; vv[r * 4 + 3] = tt[r][1] - tt[r][3];
+    };
+    auto write_images = [&](int buf, int r) {  // Winograd row r of both images
+        float* eb = El + buf * IMG + img_off;
+        float* vb = Vl + buf * IMG + img_off;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            eb[(r * 4 + q4) * XI_STRIDE] = ev[r * 4 + q4];
+            vb[(r * 4 + q4) * XI_STRIDE] = vv[r * 4 + q4];
+        }
+    };
+    auto transform = [&](int buf) {  // whole chunk at once (prologue)
+        transform_e();
+        transform_v_rows();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { transform_v_cols(r); write_images(buf, r); }
     };
 
     f32x16 acc[4][2];  // [row i of the 4x4 Winograd point grid][column jj of this wave's pair]
@@ -117,9 +127,9 @@ __global__ __launch_bounds__(GTHR, 2) void conv_wgrad_wino_kernel(const WgradPar
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[i][jj][j] = 0.f;
 
-    // MFMA operands: A[m = co][k = tile 2kp + half] from E, B[k][n = ci] from V; xi = 4 i + 2 q + jj
-    const int aoff = (2 * q * GK + half) * GLD + wm * 32 + l31;  // + (4 i + jj) * GK * GLD + 2 kp * GLD
-    const int boff = (2 * q * GK + half) * GLD + wn * 32 + l31;
+    // MFMA operands: A[m = co][k = tile 2kp + half] from E, B[k][n = ci] from V; xi = 4 i + 2 q + jj; one float4 = kp 0..3
+    const int aoff = (half * GBLK + wm * 32 + l31) * 4;  // + xi * XI_STRIDE
+    const int boff = (half * GBLK + wn * 32 + l31) * 4;
 
     if (c_lo < c_hi) {
         load(c_lo);
@@ -128,28 +138,35 @@ __global__ __launch_bounds__(GTHR, 2) void conv_wgrad_wino_kernel(const WgradPar
     }
     __syncthreads();
 
-    const bool late_transform = __builtin_amdgcn_readfirstlane(wave) >= 4;
     int it = 0;
     for (int chunk = c_lo; chunk < c_hi; ++chunk, ++it) {
         const int cur = it & 1, nxt = cur ^ 1;
         const bool more = chunk + 1 < c_hi;
-        if (!late_transform && more) {
-            transform(nxt);                       // registers hold chunk + 1 (loaded one iteration ago)
-            if (chunk + 2 < c_hi) load(chunk + 2);
-        }
         const float* Eb = El + cur * IMG + aoff;
         const float* Vb = Vl + cur * IMG + boff;
+        // registers hold chunk + 1 (loaded one iteration ago); its transform and LDS writes are spread over this chunk's
+        // MFMA slots, the loads of chunk + 2 follow once the registers are free.  (`more` is wave-uniform: the side work of
+        // the last chunk is skipped by scalar branches around straight-line code.)
 #pragma unroll
-        for (int kp = 0; kp < GK / 2; ++kp) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Eb[((4 * i) * GK + 2 * kp) * GLD], Vb[((4 * i) * GK + 2 * kp) * GLD], acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Eb[((4 * i + 1) * GK + 2 * kp) * GLD], Vb[((4 * i + 1) * GK + 2 * kp) * GLD], acc[i][1], 0, 0, 0);
+        for (int g = 0; g < 8; ++g) {  // Winograd point xi = 4 (g >> 1) + 2 q + (g & 1): four MFMA steps from one float4 pair
+            const int i = g >> 1, jj = g & 1, xi = 4 * i + 2 * q + jj;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(Eb + xi * XI_STRIDE);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(Vb + xi * XI_STRIDE);
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[i][jj], 0, 0, 0);
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[i][jj], 0, 0, 0);
+            if (more) {
+                if (g == 0) transform_e();
+                if (g == 1) transform_v_rows();
+                if (g >= 2 && g < 6) transform_v_cols(g - 2);
             }
-        }
-        if (late_transform && more) {
-            transform(nxt);
-            if (chunk + 2 < c_hi) load(chunk + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[i][jj], 0, 0, 0);
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[i][jj], 0, 0, 0);
+            if (more) {
+                if (g >= 3 && g < 7) write_images(nxt, g - 3);
+                if (g == 7 && chunk + 2 < c_hi) load(chunk + 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -255,7 +272,7 @@ extern "C" int sis_conv3x3_wgrad(float* dw, const float* x, const float* gy, int
                 "sis_conv3x3_wgrad: needs even H and W, B*H*W/4 %% 8 == 0, channels %% 64 == 0 and a workspace of at least "
                 "64 * Cin * Cout bytes (got %d x %dx%d, %d -> %d)", batch, h, w, cin, cout);
     p.x = x; p.gy = gy; p.slab = (float*)workspace;
-    const size_t lds = (size_t)4 * 16 * GK * GLD * sizeof(float);
+    const size_t lds = (size_t)4 * 16 * 2 * GBLK * 4 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_wino_kernel),

@@ -6,6 +6,9 @@ sys.path.insert(0, os.path.join(ROOT, "synthesis-in-style_amd"))
 import sis_hip
 from networks.hip_conv import _space_to_batch
 
+if os.environ.get("SIS_HIP_LIB"):  # same-box A/B of kernel builds (tools/build_variant.sh)
+    sis_hip.LIB_PATH = os.path.join(ROOT, "synthesis-in-style_amd", "lib", os.environ["SIS_HIP_LIB"])
+
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 dev = torch.device("cuda")
 shapes = [(2048, 512, 32, 1, 1), (512, 256, 32, 1, 1), (64, 64, 128, 1, 1), (64, 128, 128, 1, 1), (64, 64, 64, 1, 3),
