@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void equal_linear_kernel(float* __restrict__ o
 // as torch stores nn.Linear weights.  Workgroup = 4 waves = 32 rows x 128 outputs (wave w: outputs 32 w .. 32 w + 31),
 // K in 64-wide chunks staged through LDS with coalesced 16-byte loads (row stride 66 floats: 8-byte aligned, at most
 // 2-way bank conflicts on the b32 operand reads).  These layers are tiny (<= 0.3 GFLOP together); as one-wave-per-output
-// dot-product kernels the two batched launches took 104 us + 83 us (profiles/r02_m_step_timeline.txt); here 41 + 39 us.
+// dot-product kernels the two batched launches took 104 us + 83 us (profiles/r02_z_step_timeline.txt); here 41 + 39 us.
 // (The 8 mapping layers stay on equal_linear_kernel: 32 x 512 x 512 gives this tile shape 4 workgroups and a serial chain
 // of 8 load latencies -- 24 us against 14.)
 constexpr int HG_ROWS = 32, HG_COLS = 128, HG_KC = 64, HG_LD = 66;
