@@ -497,8 +497,13 @@ class Generator(nn.Module):
             # HBM-bound passes overlap the MFMA-bound convolutions of the next resolution.
             main, side = torch.cuda.current_stream(latent.device), self._rgb_stream(latent.device)
 
-            def rgb_branch(layer, x, style, prev):
+            def rgb_branch(layer, x, style, prev, last=False):
                 if side is None:
+                    return layer.forward_s(x, style, prev)
+                if last:  # nothing left to overlap it with: on the main stream, behind the side chain (no fork / join gap)
+                    main.wait_event(side.record_event())
+                    if prev is not None:
+                        prev.record_stream(main)  # allocated on the side stream, read here
                     return layer.forward_s(x, style, prev)
                 ready = main.record_event()
                 x.record_stream(side)
@@ -516,9 +521,10 @@ class Generator(nn.Module):
                 tap(i + 1, out)
                 out = conv.forward_s(out, conv.conv.packed_weights()[0], s[j + 1], d[j + 1], noise[2 + 2 * r])
                 tap(i + 2, out)
-                skip = rgb_branch(rgb, out, s[j + 2], skip)
-            if side is not None:
+                skip = rgb_branch(rgb, out, s[j + 2], skip, last=r == self.log_size - 3)
+            if side is not None and self.log_size == 2:  # 4 x 4 generator: to_rgb1 is the only (side-stream) ToRGB
                 main.wait_event(side.record_event())
+                skip.record_stream(main)
             if return_latents:
                 return skip, latent
             return (skip, acts) if return_intermediate_activations else (skip, None)
