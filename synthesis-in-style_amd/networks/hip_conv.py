@@ -244,6 +244,13 @@ class _ConvBf16Function(Function):
             g_full = gy.new_zeros((b, cout, h, w))
             g_full[:, :, ::2, ::2] = gy
             gy, s = g_full, 1
+        scatter = None
+        if s == 2 and k == 1 and _STRIDE2_OWN and sis_hip.conv_bf16_supported(cout, cin, gy.shape[2], gy.shape[3], 1, 1):
+            # 1x1 stride 2 (the bottlenecks' projection shortcuts) = the dense 1x1 layer on the even pixels of its input: both
+            # gradients on the sampled tensors, dL/dx scattered back into a zero map.
+            scatter = (h, w)
+            input = input[:, :, ::2, ::2].contiguous()
+            h, w, s, adjoint = input.shape[2], input.shape[3], 1, None
         if ctx.needs_input_grad[0]:
             if s == 1 and sis_hip.conv_bf16_supported(cout, cin, h, w, k, 1):
                 if adjoint is None:
@@ -268,6 +275,10 @@ class _ConvBf16Function(Function):
                 grad_weight = grad_weight.to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = gy.sum((0, 2, 3), dtype=torch.float32)
+        if scatter is not None and grad_input is not None:
+            full = grad_input.new_zeros((b, cin) + scatter)
+            full[:, :, ::2, ::2] = grad_input
+            grad_input = full
         return grad_input, grad_weight, grad_bias, None
 
 

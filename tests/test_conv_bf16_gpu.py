@@ -104,3 +104,27 @@ def test_conv_bf16_autograd_function(device):
     for got, ref, tol in ((x.grad, xr.grad, 1e-2), (w.grad, wr.grad, 2e-3), (b.grad, br.grad, 1e-3)):
         assert (got.float() - ref).abs().max().item() <= tol * ref.abs().max().item()
     assert w.grad.dtype == torch.float32 and x.grad.dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("cin,cout,h,w,k", [(64, 128, 32, 32, 3), (128, 128, 31, 31, 3), (256, 512, 32, 32, 1), (64, 256, 63, 63, 1)])
+def test_stride_2_backward_on_the_stride_1_kernels(device, cin, cout, h, w, k):
+    """Stride-2 layers of TransUNet's ResNetV2 (3x3 in the bottlenecks, 1x1 projection shortcuts; odd map sizes occur):
+    forward on the strided kernel, both gradients on the stride-1 kernels (zero-stuffed dL/dy, or sampled input)."""
+    from networks.hip_conv import conv_bf16, conv_bf16_applicable
+    gen = torch.Generator().manual_seed(cin + h + k)
+    x = torch.randn(2, cin, h, w, generator=gen).to(device).bfloat16().requires_grad_(True)
+    wt = (torch.randn(cout, cin, k, k, generator=gen) * (cin * k * k) ** -0.5).to(device).requires_grad_(True)
+    assert conv_bf16_applicable(x, wt, (2, 2), (k // 2, k // 2), (1, 1), 1)
+    y = conv_bf16(x, wt, None, 2)
+    gy = torch.randn(y.shape, generator=gen).to(device).bfloat16()
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_(True)
+    wr = wt.detach().bfloat16().float().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, stride=2, padding=k // 2)
+    assert ref.shape == y.shape
+    ref.backward(gy.float())
+    assert (y.float() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
+    # (1x1: the per-sample products dy_b x_b^T leave the library GEMM in bf16 before the fp32 sum over the batch: 2^-8 relative)
+    for got, want, tol in ((x.grad, xr.grad, 1e-2), (wt.grad, wr.grad, 2e-3 if k == 3 else 5e-3)):
+        assert got.shape == want.shape
+        assert (got.float() - want).abs().max().item() <= tol * want.abs().max().item()
