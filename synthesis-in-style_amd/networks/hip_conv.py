@@ -244,6 +244,15 @@ class _ConvBf16Function(Function):
             g_full = gy.new_zeros((b, cout, h, w))
             g_full[:, :, ::2, ::2] = gy
             gy, s = g_full, 1
+        pad_out = 0
+        if s == 1 and k == 3 and cout % 16 and not sis_hip.conv_bf16_supported(cout, cin, h, w, k, 1) \
+                and sis_hip.conv_bf16_supported(-(-cout // 16) * 16, cin, h, w, k, 1):
+            # a layer with a handful of output channels (the segmentation head: Cout = classes): its gradients contract over
+            # Cout, which the kernels take in chunks of 16 -- zero channels are appended to dL/dy and zero filters to W
+            pad_out = -(-cout // 16) * 16 - cout
+            gy = F.pad(gy, (0, 0, 0, 0, 0, pad_out))
+            weight = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, pad_out))
+            cout, adjoint = cout + pad_out, None
         scatter = None
         if s == 2 and k == 1 and _STRIDE2_OWN and sis_hip.conv_bf16_supported(cout, cin, gy.shape[2], gy.shape[3], 1, 1):
             # 1x1 stride 2 (the bottlenecks' projection shortcuts) = the dense 1x1 layer on the even pixels of its input: both
@@ -275,6 +284,9 @@ class _ConvBf16Function(Function):
                 grad_weight = grad_weight.to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = gy.sum((0, 2, 3), dtype=torch.float32)
+        if pad_out:
+            grad_weight = None if grad_weight is None else grad_weight[:cout - pad_out]
+            grad_bias = None if grad_bias is None else grad_bias[:cout - pad_out]
         if scatter is not None and grad_input is not None:
             full = grad_input.new_zeros((b, cin) + scatter)
             full[:, :, ::2, ::2] = grad_input

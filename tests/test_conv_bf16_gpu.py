@@ -128,3 +128,30 @@ def test_stride_2_backward_on_the_stride_1_kernels(device, cin, cout, h, w, k):
     for got, want, tol in ((x.grad, xr.grad, 1e-2), (wt.grad, wr.grad, 2e-3 if k == 3 else 5e-3)):
         assert got.shape == want.shape
         assert (got.float() - want).abs().max().item() <= tol * want.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,h,w", [(16, 3, 64, 64), (16, 9, 40, 56), (32, 2, 32, 32)])
+def test_narrow_output_layer_backward(device, cin, cout, h, w):
+    """The segmentation head (3x3, Cout = number of classes): its gradients contract over Cout, which the kernels take in chunks
+    of 16, so dL/dy and the filters get zero channels appended; the gradients must not change (reference:
+    stylegan_code_finder/networks/trans_u_net/vit_seg_modeling.py:324-330, SegmentationHead)."""
+    import sis_hip
+    from networks.hip_conv import conv_bf16, conv_bf16_applicable
+    gen = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(2, cin, h, w, generator=gen).to(device).bfloat16().requires_grad_(True)
+    wt = (torch.randn(cout, cin, 3, 3, generator=gen) * (cin * 9) ** -0.5).to(device).requires_grad_(True)
+    bias = torch.randn(cout, generator=gen).to(device).requires_grad_(True)
+    assert conv_bf16_applicable(x, wt, (1, 1), (1, 1), (1, 1), 1)
+    assert not sis_hip.conv_bf16_supported(cout, cin, h, w, 3, 1)
+    y = conv_bf16(x, wt, bias, 1)
+    gy = torch.randn(y.shape, generator=gen).to(device).bfloat16()
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_(True)
+    wr = wt.detach().bfloat16().float().requires_grad_(True)
+    br = bias.detach().clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br, padding=1)
+    ref.backward(gy.float())
+    for got, want, tol in ((x.grad, xr.grad, 1e-2), (wt.grad, wr.grad, 2e-3), (bias.grad, br.grad, 1e-3)):
+        assert got.shape == want.shape
+        assert (got.float() - want).abs().max().item() <= tol * want.abs().max().item()
