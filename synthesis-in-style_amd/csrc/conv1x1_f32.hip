@@ -11,6 +11,7 @@
 // weight tensor [Cout][Cin] as [k][m] directly); for the forward ([m][k] in memory) each lane loads one float4 of a
 // weight row and writes its four values down a column of the k-major image (lanes = consecutive m: conflict-free).
 // 32-channel chunks, double-buffered, ONE barrier per 64 MFMAs per wave.
+#include <type_traits>
 #include "sis_common.h"
 
 namespace {
@@ -153,22 +154,36 @@ __global__ __launch_bounds__(512, C::OCC) void conv1x1_f32_kernel(PwParams p) {
         __syncthreads();
     }
 
+    // ---- epilogue.  The bias of this wave's rows is fetched once (not per element), a row's address is the tile's base plus a
+    // multiple of the plane stride, and full tiles (the usual case) carry no per-row bounds checks.
+    const int mrow0 = m0 + wm * (C::MB * 32) + 4 * h;  // row (mb, i) = mrow0 + mb * 32 + (i & 3) + 8 * (i >> 2)
+    float bv[C::MB][16];
 #pragma unroll
-    for (int nb = 0; nb < C::NB; ++nb) {
-        const int px = p0 + wn * (C::NB * 32) + nb * 32 + r;
-        if (px >= p.HW) continue;
+    for (int mb = 0; mb < C::MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bv[mb][i] = 0.f;
+    if (p.bias) {
 #pragma unroll
         for (int mb = 0; mb < C::MB; ++mb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int m = m0 + wm * (C::MB * 32) + mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (m < p.M) {
-                    float v = acc[mb][nb][i];
-                    if (p.bias) v += p.bias[m];
-                    p.y[((int64_t)n * p.M + m) * p.HW + px] = v;
-                }
-            }
+            for (int i = 0; i < 16; ++i) bv[mb][i] = p.bias[min(mrow0 + mb * 32 + (i & 3) + 8 * (i >> 2), p.M - 1)];  // (rows >= M are not stored)
     }
+    float* ybase = p.y + ((int64_t)n * p.M + mrow0) * p.HW + p0 + wn * (C::NB * 32) + r;
+    auto store_tile = [&](auto checked) {
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb) {
+            if (p0 + wn * (C::NB * 32) + nb * 32 + r >= p.HW) continue;
+#pragma unroll
+            for (int mb = 0; mb < C::MB; ++mb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ro = mb * 32 + (i & 3) + 8 * (i >> 2);
+                    if (!decltype(checked)::value || mrow0 + ro < p.M) ybase[ro * p.HW + nb * 32] = acc[mb][nb][i] + bv[mb][i];
+                }
+        }
+    };
+    if (m0 + C::MT <= p.M) store_tile(std::false_type());
+    else store_tile(std::true_type());
 }
 
 template <typename C>

@@ -22,6 +22,7 @@
 //
 // The data gradient is the same kernel on adjoint-packed weights (channel roles swapped, taps rotated by 180 degrees);
 // stride-2 layers read their B fragments at a pixel stride of two units.
+#include <type_traits>
 #include "sis_common.h"
 
 namespace {
@@ -294,26 +295,40 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_kernel(ConvParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: bias, bf16, NCHW stores (lanes 0-31 of a register write 32 consecutive pixels of one channel row)
+    // ---- epilogue: bias, bf16, NCHW stores (lanes 0-31 of a register write 32 consecutive pixels of one channel row).  The
+    // bias of a wave's rows is fetched once per 32-row block, a row's address is the block's base plus a multiple of the plane
+    // stride, and full channel tiles (the usual case) carry no per-row bounds checks.
+    const int plane = p.Ho * p.Wo;
+    auto store_tile = [&](auto checked) {
 #pragma unroll
-    for (int mb = 0; mb < C::MB; ++mb) {
+        for (int mb = 0; mb < C::MB; ++mb) {
+            const int co0 = co_t * C::MT + (wm * C::MB + mb) * 32 + 4 * h;  // row i = co0 + (i & 3) + 8 * (i >> 2)
+            float bv[16];
 #pragma unroll
-        for (int nb = 0; nb < C::NB; ++nb) {
-            const int blk = wn * C::NB + nb;
-            const int oy = oy0 + blk / (C::TW / 32), ox = ox0 + (blk % (C::TW / 32)) * 32 + r;
-            if (oy >= p.Ho || ox >= p.Wo) continue;
+            for (int i = 0; i < 16; ++i) bv[i] = 0.f;
+            if (p.bias) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int co = co_t * C::MT + (wm * C::MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (co < p.Cout) {
-                    float v = acc[mb][nb][i];
-                    if (p.bias) v += p.bias[co];
-                    __hip_bfloat16 bv = __float2bfloat16(v);
-                    p.y[(((int64_t)n * p.Cout + co) * p.Ho + oy) * p.Wo + ox] = *reinterpret_cast<u16*>(&bv);
+                for (int i = 0; i < 16; ++i) bv[i] = p.bias[min(co0 + (i & 3) + 8 * (i >> 2), p.Cout - 1)];  // (rows >= Cout are not stored)
+            }
+#pragma unroll
+            for (int nb = 0; nb < C::NB; ++nb) {
+                const int blk = wn * C::NB + nb;
+                const int oy = oy0 + blk / (C::TW / 32), ox = ox0 + (blk % (C::TW / 32)) * 32 + r;
+                if (oy >= p.Ho || ox >= p.Wo) continue;
+                u16* yb = p.y + ((int64_t)n * p.Cout + co0) * plane + oy * p.Wo + ox;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ro = (i & 3) + 8 * (i >> 2);
+                    if (!decltype(checked)::value || co0 + ro < p.Cout) {
+                        __hip_bfloat16 bvv = __float2bfloat16(acc[mb][nb][i] + bv[i]);
+                        yb[ro * plane] = *reinterpret_cast<u16*>(&bvv);
+                    }
                 }
             }
         }
-    }
+    };
+    if ((co_t + 1) * C::MT <= p.Cout) store_tile(std::false_type());
+    else store_tile(std::true_type());
 }
 
 template <typename C>

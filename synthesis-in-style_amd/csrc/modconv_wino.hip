@@ -78,6 +78,11 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ f32x2 pk_neg_sub(f32x2 a, f32x2 b) {  // -a - b
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[1,1] neg_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ f32x2 pk_scale(f32x2 a, f32x2 s_lo) {  // a * s_lo.lo
     f32x2 r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(s_lo));
@@ -387,6 +392,9 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     // When ALL the transformed weights fit one L2 (128 / 256 channels: 1 / 4 MB) the order is the other way
     // round (xcd_group): logical workgroup id = (hardware id % 8) * (grid / 8) + hardware id / 8, so the n_co
     // workgroups of a pixel tile sit on ONE XCD and the input tile is fetched once instead of n_co times.
+#ifdef SIS_WINO_STAGGER  // experiment: workgroups start out of phase so their epilogue store bursts do not coincide
+    for (int i = ((int)(blockIdx.x >> 3) & 7) * SIS_WINO_STAGGER; i > 0; --i) __builtin_amdgcn_s_sleep(127);
+#endif
     const int n_co = (p.Cout + WMBLK - 1) / WMBLK;
     const int wg = xcd_group ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int o0 = (wg % n_co) * WMBLK;
@@ -543,7 +551,10 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     // Layer-tail operands (demodulation, bias, noise) of a tile: fetched into registers a whole tile ahead, parked in
     // LDS once nobody reads the previous tile's any more, read back in the epilogue -- no dependent global loads
     // in the tail and no registers held across the matrix loop.
+    // (Nothing here may USE a loaded value -- a use is a wait for every load in flight, the next tile's input DMA included:
+    // the noise is scaled when it is parked.)
     float t_noise = 0.f, t_scale = 1.f, t_bias = 0.f;
+    const float noise_w0 = (!partial && p.fuse && p.noise) ? p.noise_w[0] : 0.f;
     auto tail_load = [&](const TileState& S) {
         t_noise = 0.f; t_scale = 1.f; t_bias = 0.f;
         if (partial) return;
@@ -552,7 +563,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
             const int n = tt_ >> tpl0, rem = tt_ & ((1 << tpl0) - 1);
             const int yy = S.h0 + 2 * (rem >> (twl - 1)) + (e >> 1), xx = S.w0 + 2 * (rem & ((tw >> 1) - 1)) + (e & 1);
             if (n < tc.nb && S.b0 + n < p.B && yy < p.H && xx < p.W)
-                t_noise = p.noise_w[0] * p.noise[(int64_t)(S.b0 + n) * p.noise_bstride + yy * p.W + xx];
+                t_noise = p.noise[(int64_t)(S.b0 + n) * p.noise_bstride + yy * p.W + xx];
         }
         if (tid < tc.nb * WMBLK) {
             const int n = tid / WMBLK, co = o0 + tid % WMBLK;
@@ -561,7 +572,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
         }
     };
     auto tail_store = [&]() {
-        if (tid < WTILES * 4) Nl[tid] = t_noise;
+        if (tid < WTILES * 4) Nl[tid] = noise_w0 * t_noise;
         if (tid < tc.nb * WMBLK) Dl[tid] = t_scale;
         if (tid < WMBLK) Bl[tid] = t_bias;
     };
@@ -718,28 +729,40 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
         // next tile's chunk 0): wave pairs 0, 1 in the weight buffer, 2, 3 in the V buffer, 16 KB each.
         const int pl = ((k_len / WCC) - 1) & 1, pair = wave >> 1;
         float* xch = (pair < 2 ? Ul + pl * WF : Vl + pl * VF) + (pair & 1) * (64 * 64);  // [sender q][8 rows][4][64 lanes]
+        // (Packed fp32 over accumulator-row pairs (j, j+1): no MFMA is in flight on the CU here, so v_pk_add_f32 is two results per
+        // issue slot; same operations in the same order as the scalar form.)
         auto reduce_and_send = [&](auto qc) {
             constexpr int Q = decltype(qc)::value;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                float m[2][2];
+            for (int j = 0; j < 16; j += 2) {
+                f32x2 m[2][2];
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
-                    m[0][jj] = acc[0][jj][j] + acc[1][jj][j] + acc[2][jj][j];
-                    m[1][jj] = acc[1][jj][j] - acc[2][jj][j] - acc[3][jj][j];
+                    const f32x2 a0 = {acc[0][jj][j], acc[0][jj][j + 1]};
+                    const f32x2 a1 = {acc[1][jj][j], acc[1][jj][j + 1]};
+                    const f32x2 a2 = {acc[2][jj][j], acc[2][jj][j + 1]};
+                    const f32x2 a3 = {acc[3][jj][j], acc[3][jj][j + 1]};
+                    m[0][jj] = pk_add(pk_add(a0, a1), a2);
+                    m[1][jj] = pk_sub(pk_sub(a1, a2), a3);
                 }
-                float pr[4];
+                f32x2 pr[4];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    pr[2 * r] = Q == 0 ? m[r][0] + m[r][1] : m[r][0];
-                    pr[2 * r + 1] = Q == 0 ? m[r][1] : -m[r][0] - m[r][1];
+                    pr[2 * r] = Q == 0 ? pk_add(m[r][0], m[r][1]) : m[r][0];
+                    pr[2 * r + 1] = Q == 0 ? m[r][1] : pk_neg_sub(m[r][0], m[r][1]);
                 }
                 if ((j >> 3) == Q) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) mine[j & 7][e] = pr[e];
+                    for (int e = 0; e < 4; ++e) {
+                        mine[j & 7][e] = pr[e].x;
+                        mine[(j & 7) + 1][e] = pr[e].y;
+                    }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) xch[(Q * 32 + (j & 7) * 4 + e) * 64 + lane] = pr[e];
+                    for (int e = 0; e < 4; ++e) {
+                        xch[(Q * 32 + (j & 7) * 4 + e) * 64 + lane] = pr[e].x;
+                        xch[(Q * 32 + ((j & 7) + 1) * 4 + e) * 64 + lane] = pr[e].y;
+                    }
                 }
             }
         };
@@ -750,38 +773,51 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
         WINO_TRACE_TILE(5);
 
         if (live) {
-            float* obase = (partial ? p.slab + (int64_t)blockIdx.y * p.B * p.Cout * HW : p.out) +
-                           (int64_t)ob * p.Cout * HW + oh * p.W + ow;
-            const float* xin = xch + (1 - q) * 32 * 64 + lane;
+            // One straight-line path for the three output kinds (split-K slab: raw sums; plain; fused layer tail).  The parked tail
+            // operands are already neutral where a kind does not use them (scale 1, bias 0, noise 0: tail_load), so the kind
+            // only selects the two activation constants: no branches, every LDS read issued before the first use.
+            const bool tail_on = !partial && p.fuse;
+            const float slope = tail_on ? 0.2f : 1.f, gain = tail_on ? 1.4142135623730951f : 1.f;
             const int cl0 = wm * 32 + 16 * q + 4 * half;  // row j = 8 q + jj sits at channel cl0 + (jj & 3) + 8 * (jj >> 2)
-            float nz[4];
+            float* obase = (partial ? p.slab + (int64_t)blockIdx.y * p.B * p.Cout * HW : p.out) +
+                           ((int64_t)ob * p.Cout + o0 + cl0) * HW + oh * p.W + ow;
+            const float* xin = xch + (1 - q) * 32 * 64 + lane;
+            float y[8][4], dd[8], bbv[8], nz[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) nz[e] = Nl[t * 4 + e];
+            for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[jj][e] = xin[(jj * 4 + e) * 64];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                const int cl = cl0 + (jj & 3) + 8 * (jj >> 2), co = o0 + cl;
-                if (co < p.Cout) {
-                    const float dd = Dl[tn * WMBLK + cl], bbv = Bl[cl];
-                    float y[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] = mine[jj][e] + xin[(jj * 4 + e) * 64];
-                    if (!partial) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float val = y[e] * dd;
-                            if (p.fuse) {
-                                val += nz[e];
-                                val += bbv;
-                                val = (val > 0.f ? val : val * 0.2f) * 1.4142135623730951f;
-                            }
-                            y[e] = val;
-                        }
-                    }
-                    float* oc = obase + (int64_t)co * HW;
-                    *reinterpret_cast<float2*>(oc) = make_float2(y[0], y[1]);
-                    *reinterpret_cast<float2*>(oc + p.W) = make_float2(y[2], y[3]);
-                }
+                const int cl = cl0 + (jj & 3) + 8 * (jj >> 2);
+                dd[jj] = Dl[tn * WMBLK + cl];
+                bbv[jj] = Bl[cl];
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) nz[e] = Nl[t * 4 + e];
+            auto finalise = [&](auto checked) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float val = (mine[jj][e] + y[jj][e]) * dd[jj];
+                        val += nz[e];
+                        val += bbv[jj];
+                        y[jj][e] = fmaxf(val, val * slope) * gain;  // = (val > 0 ? val : 0.2 val) * sqrt(2) when the tail is on
+                    }
+                    const int ro = (jj & 3) + 8 * (jj >> 2);
+                    if (!decltype(checked)::value || o0 + cl0 + ro < p.Cout) {
+                        float* oc = obase + ro * HW;
+#ifdef SIS_WINO_NOSTORE  // ablation: the epilogue without its global stores (results wrong)
+                        if (y[jj][0] + y[jj][1] + y[jj][2] + y[jj][3] != 12345.678f) continue;
+#endif
+                        *reinterpret_cast<float2*>(oc) = make_float2(y[jj][0], y[jj][1]);
+                        *reinterpret_cast<float2*>(oc + p.W) = make_float2(y[jj][2], y[jj][3]);
+                    }
+                }
+            };
+            if (o0 + WMBLK <= p.Cout) finalise(std::false_type());
+            else finalise(std::true_type());
         }
         if (!has_next) break;
         WINO_TRACE_TILE(6);

@@ -16,7 +16,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsis_hip.so")
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", os.environ.get("SIS_HIP_LIB", "libsis_hip.so"))  # (override: same-box A/B
+# timing of another build of the same library, tools/build_variant.sh)
 
 _lib = None
 
