@@ -229,6 +229,22 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[m][a][j] = 0.f;
 
+    // Transposed kernel: the demodulation factors of this lane's 16 * MT output channels are fetched here, under the matrix loop
+    // (fetched in the epilogue they were 16 dependent round trips to L2 per tile).
+    const bool partial = p.ksplit > 1;
+    float dsc[MODE == 1 ? C::MT : 1][16];
+    if (MODE == 1) {
+        const int n = (wn * 32 + l31) >> (thl + twl);
+        const float* db = p.dscale + (int64_t)min(b0 + n, p.B - 1) * p.Cout;
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int co = o0 + (wm * C::MT + m) * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
+                dsc[m][j] = partial ? 1.f : db[min(co, p.Cout - 1)];
+            }
+    }
+
     __syncthreads();  // zeros and style rows are in LDS before any DMA may land on them
     stage(k_lo, 0);
     __syncthreads();  // vmcnt(0) + barrier: chunk 0 landed
@@ -299,7 +315,6 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
     }
 
     // ---- epilogue (ksplit > 1: raw partial sums to this slice's slab)
-    const bool partial = p.ksplit > 1;
     if (MODE == 0) {
         float nw = 0.f;
         if (!partial && p.fuse && p.noise) nw = p.noise_w[0];
@@ -340,15 +355,29 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
         if (n < tc.nb && b < p.B && h < tc.h1 && w < tc.w1) {
             const int OHW = p.OH * p.ORS;
             float* ob = (partial ? p.slab + (int64_t)blockIdx.y * p.B * p.Cout * OHW : p.out) + (int64_t)b * p.Cout * OHW;
-            const float* db = p.dscale + (int64_t)b * p.Cout;
             const bool pair = (p.ORS & 1) == 0 && 2 * w + 1 < p.OW;  // both column phases valid, 8-byte aligned
+            // Interior tiles (all four phases of every position exist, rows 8-byte aligned) of a full channel block: two 8-byte
+            // stores per channel at the tile's base plus a multiple of the plane stride, no per-element checks.
+            if (tc.h1 <= p.H && tc.w1 <= p.W && (p.ORS & 1) == 0 && o0 + C::MBLK <= p.Cout) {
+                float* o00 = ob + (int64_t)(o0 + wm * C::MT * 32 + 4 * half) * OHW + (int64_t)(2 * h) * p.ORS + 2 * w;
+#pragma unroll
+                for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        float* oc = o00 + (m * 32 + (j & 3) + 8 * (j >> 2)) * OHW;
+                        const float d = dsc[m][j];
+                        *reinterpret_cast<float2*>(oc) = make_float2(acc[m][0][j] * d, acc[m][1][j] * d);
+                        *reinterpret_cast<float2*>(oc + p.ORS) = make_float2(acc[m][2][j] * d, acc[m][3][j] * d);
+                    }
+                return;
+            }
 #pragma unroll
             for (int m = 0; m < C::MT; ++m)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const int co = o0 + (wm * C::MT + m) * 32 + (j & 3) + 8 * (j >> 2) + 4 * half;
                     if (co < p.Cout) {
-                        const float d = partial ? 1.f : db[co];
+                        const float d = dsc[m][j];
                         float* oc = ob + (int64_t)co * OHW;
 #pragma unroll
                         for (int a = 0; a < 2; ++a) {
