@@ -17,6 +17,7 @@
 // writes spread over the slots between the 32 MFMAs.
 // Split-K over tile ranges (blockIdx.y) writes raw S slabs; conv_wgrad_finish adds them in slice order
 // (deterministic) and applies G^T . G.
+#include <type_traits>
 #include "sis_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -52,71 +53,88 @@ __global__ __launch_bounds__(GTHR, 2) void conv_wgrad_wino_kernel(const WgradPar
 
     // transform role: tile k of the chunk, channel ch of the workgroup's 64 (on both axes)
     const int tk = lane & 7, ch = tid >> 3;
-    const float* xplane = p.x + (int64_t)(i0 + ch) * HW;
-    const float* gplane = p.gy + (int64_t)(o0 + ch) * HW;
 
-    f32x2 xr[4][3];  // input patch rows 2ty-1 .. 2ty+2, columns 2tx-2 .. 2tx+3 as three aligned pairs
-    f32x2 gr[2];     // dY tile rows
-    auto load = [&](int chunk) {  // tile t = chunk * GK + tk of the flattened (sample, tile row, tile column) order
+    // Two register sets of raw tiles: while chunk c multiplies, set (c + 1) & 1 (loaded during chunk c - 1: a whole chunk of
+    // latency cover) is transformed and written to LDS and set c & 1 is refilled with chunk c + 2.
+    float xl[2][4], xh[2][4];  // input patch rows 2ty-1 .. 2ty+2: columns 2tx-1 and 2tx+2 ...
+    f32x2 xm[2][4];            // ... and the aligned pair (2tx, 2tx+1) between them
+    f32x2 gr[2][2];            // dY tile rows
+    // Tile t = chunk * GK + tk of the flattened (sample, tile row, tile column) order.  The two divisions go through the float
+    // reciprocal with one correction step (exact: t < 2^24, host-checked).
+    const float inv_tps = 1.f / (float)p.tiles_per_sample, inv_tpr = 1.f / (float)p.tiles_per_row;
+    // Loads go through buffer descriptors: a masked element gets an out-of-range offset and the hardware returns 0 -- the mask
+    // selects an ADDRESS, so nothing waits for loaded data before the transform a chunk later (a select on the loaded value is
+    // a wait for every load in flight, at the slot where the load was issued).
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.gy, 0, 0x7FFFFFFF, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned g_xo = 0, g_go = 0;  // byte offsets of (patch row 0, column 2tx) and of the dY tile
+    bool g_left = false, g_right = false;
+    int g_y0 = 0;
+    auto geo = [&](int chunk, bool valid = true) {  // (!valid: every load of the tile masked -- the refill of the last two chunks)
         const int t = chunk * GK + tk;
-        const int b = t / p.tiles_per_sample, rem = t - b * p.tiles_per_sample;
-        const int ty = rem / p.tiles_per_row, tx = rem - ty * p.tiles_per_row;
-        const float* xb = xplane + (int64_t)b * p.Cin * HW + (2 * ty - 1) * p.W + 2 * tx - 2;
-        const float* gb = gplane + (int64_t)b * p.Cout * HW + 2 * ty * p.W + 2 * tx;
-        const bool left = tx > 0, right = 2 * tx + 2 < p.W;
+        int b = (int)((float)t * inv_tps), rem = t - b * p.tiles_per_sample;
+        if (rem < 0) { --b; rem += p.tiles_per_sample; } else if (rem >= p.tiles_per_sample) { ++b; rem -= p.tiles_per_sample; }
+        int ty = (int)((float)rem * inv_tpr), tx = rem - ty * p.tiles_per_row;
+        if (tx < 0) { --ty; tx += p.tiles_per_row; } else if (tx >= p.tiles_per_row) { ++ty; tx -= p.tiles_per_row; }
+        g_xo = (unsigned)(((b * p.Cin + i0 + ch) * HW + (2 * ty - 1) * p.W + 2 * tx) * 4);
+        g_go = (unsigned)(((b * p.Cout + o0 + ch) * HW + 2 * ty * p.W + 2 * tx) * 4);
+        g_left = tx > 0; g_right = 2 * tx + 2 < p.W; g_y0 = valid ? 2 * ty - 1 : -8;
+        if (!valid) g_go = OOB;
+    };
+    auto ld1 = [&](__amdgpu_buffer_rsrc_t rsrc, unsigned off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0)); };
+    auto ld2 = [&](__amdgpu_buffer_rsrc_t rsrc, unsigned off) { return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0)); };
+    auto load_x = [&](auto setc, int r) {  // patch row r of the tile geo() described
+        constexpr int S = decltype(setc)::value;
+        const int y = g_y0 + r;
+        const bool row = y >= 0 && y < p.H;
+        const unsigned o = g_xo + (unsigned)(r * p.W * 4);
+        xl[S][r] = ld1(x_rsrc, (row && g_left) ? o - 4u : OOB);
+        xm[S][r] = ld2(x_rsrc, row ? o : OOB);
+        xh[S][r] = ld1(x_rsrc, (row && g_right) ? o + 8u : OOB);
+    };
+    auto load_g = [&](auto setc) {
+        constexpr int S = decltype(setc)::value;
+        gr[S][0] = ld2(g_rsrc, g_go);
+        gr[S][1] = ld2(g_rsrc, g_go + (unsigned)(p.W * 4));  // (a masked offset stays beyond the 2^31 - 1 bytes of the descriptor)
+    };
+    auto load = [&](auto setc, int chunk, bool valid) {  // whole tile at once (prologue)
+        geo(chunk, valid);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int y = 2 * ty - 1 + r;
-            const bool row = y >= 0 && y < p.H;
-            const f32x2 z = {0.f, 0.f};
-            xr[r][0] = (row && left) ? *reinterpret_cast<const f32x2*>(xb + r * p.W) : z;
-            xr[r][1] = row ? *reinterpret_cast<const f32x2*>(xb + r * p.W + 2) : z;
-            xr[r][2] = (row && right) ? *reinterpret_cast<const f32x2*>(xb + r * p.W + 4) : z;
-        }
-        gr[0] = *reinterpret_cast<const f32x2*>(gb);
-        gr[1] = *reinterpret_cast<const f32x2*>(gb + p.W);
+        for (int r = 0; r < 4; ++r) load_x(setc, r);
+        load_g(setc);
     };
     // image offset of this lane's (tile, channel): [xi][half = tk & 1][ch][kp = tk >> 1]
     const int img_off = ((tk & 1) * GBLK + ch) * 4 + (tk >> 1);  // + xi * 2 * GBLK * 4
     constexpr int XI_STRIDE = 2 * GBLK * 4;
-    float ev[16], vv[16];  // transformed values of the chunk in flight (registers between their slots)
-    auto transform_e = [&]() {  // E = A dY A^T,  A = [[1,0],[1,1],[1,-1],[0,-1]]
-        const float a = gr[0].x, b = gr[0].y, c = gr[1].x, d = gr[1].y;
-        const float rp[4] = {a, a + c, a - c, -c}, rq[4] = {b, b + d, b - d, -d};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            ev[r * 4 + 0] = rp[r]; ev[r * 4 + 1] = rp[r] + rq[r]; ev[r * 4 + 2] = rp[r] - rq[r]; ev[r * 4 + 3] = -rq[r];
-        }
+    // Transforms write their Winograd rows as soon as they exist (few values live between slots).
+    float rp[4], rq[4];
+    auto transform_e_cols = [&](auto setc) {  // A dY: E = A dY A^T,  A = [[1,0],[1,1],[1,-1],[0,-1]]
+        constexpr int S = decltype(setc)::value;
+        const float a = gr[S][0].x, b = gr[S][0].y, c = gr[S][1].x, d = gr[S][1].y;
+        rp[0] = a; rp[1] = a + c; rp[2] = a - c; rp[3] = -c;
+        rq[0] = b; rq[1] = b + d; rq[2] = b - d; rq[3] = -d;
+    };
+    auto write_e = [&](int buf, int r) {  // Winograd row r of the E image
+        float* eb = El + buf * IMG + img_off + r * 4 * XI_STRIDE;
+        eb[0] = rp[r]; eb[XI_STRIDE] = rp[r] + rq[r]; eb[2 * XI_STRIDE] = rp[r] - rq[r]; eb[3 * XI_STRIDE] = -rq[r];
     };
     float tt[4][4];
-    auto transform_v_rows = [&]() {  // B^T d
+    auto transform_v_rows = [&](auto setc) {  // B^T d
+        constexpr int S = decltype(setc)::value;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float d0 = c == 0 ? xr[0][0].y : c == 1 ? xr[0][1].x : c == 2 ? xr[0][1].y : xr[0][2].x;
-            const float d1 = c == 0 ? xr[1][0].y : c == 1 ? xr[1][1].x : c == 2 ? xr[1][1].y : xr[1][2].x;
-            const float d2 = c == 0 ? xr[2][0].y : c == 1 ? xr[2][1].x : c == 2 ? xr[2][1].y : xr[2][2].x;
-            const float d3 = c == 0 ? xr[3][0].y : c == 1 ? xr[3][1].x : c == 2 ? xr[3][1].y : xr[3][2].x;
+            const float d0 = c == 0 ? xl[S][0] : c == 1 ? xm[S][0].x : c == 2 ? xm[S][0].y : xh[S][0];
+            const float d1 = c == 0 ? xl[S][1] : c == 1 ? xm[S][1].x : c == 2 ? xm[S][1].y : xh[S][1];
+            const float d2 = c == 0 ? xl[S][2] : c == 1 ? xm[S][2].x : c == 2 ? xm[S][2].y : xh[S][2];
+            const float d3 = c == 0 ? xl[S][3] : c == 1 ? xm[S][3].x : c == 2 ? xm[S][3].y : xh[S][3];
             tt[0][c] = d0 - d2; tt[1][c] = d1 + d2; tt[2][c] = d2 - d1; tt[3][c] = d1 - d3;
         }
     };
-    auto transform_v_cols = [&](int r) {  // (B^T d) B, row r
-        vv[r * 4 + 0] = tt[r][0] - tt[r][2]; vv[r * 4 + 1] = tt[r][1] + tt[r][2];
-        vv[r * 4 + 2] = tt[r][2] - tt[r][1]; vv[r * 4 + 3] = tt[r][1] - tt[r][3];
-    };
-    auto write_images = [&](int buf, int r) {  // Winograd row r of both images
-        float* eb = El + buf * IMG + img_off;
-        float* vb = Vl + buf * IMG + img_off;
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            eb[(r * 4 + q4) * XI_STRIDE] = ev[r * 4 + q4];
-            vb[(r * 4 + q4) * XI_STRIDE] = vv[r * 4 + q4];
-        }
-    };
-    auto transform = [&](int buf) {  // whole chunk at once (prologue)
-        transform_e();
-        transform_v_rows();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { transform_v_cols(r); write_images(buf, r); }
+    auto write_v = [&](int buf, int r) {  // (B^T d) B, row r, into the V image
+        float* vb = Vl + buf * IMG + img_off + r * 4 * XI_STRIDE;
+        vb[0] = tt[r][0] - tt[r][2]; vb[XI_STRIDE] = tt[r][1] + tt[r][2];
+        vb[2 * XI_STRIDE] = tt[r][2] - tt[r][1]; vb[3 * XI_STRIDE] = tt[r][1] - tt[r][3];
     };
 
     f32x16 acc[4][2];  // [row i of the 4x4 Winograd point grid][column jj of this wave's pair]
@@ -130,45 +148,87 @@ __global__ __launch_bounds__(GTHR, 2) void conv_wgrad_wino_kernel(const WgradPar
     // MFMA operands: A[m = co][k = tile 2kp + half] from E, B[k][n = ci] from V; xi = 4 i + 2 q + jj; one float4 = kp 0..3
     const int aoff = (half * GBLK + wm * 32 + l31) * 4;  // + xi * XI_STRIDE
     const int boff = (half * GBLK + wn * 32 + l31) * 4;
+    const std::integral_constant<int, 0> set0;
+    const std::integral_constant<int, 1> set1;
 
     if (c_lo < c_hi) {
-        load(c_lo);
-        transform(0);
-        if (c_lo + 1 < c_hi) load(c_lo + 1);
+        load(set0, c_lo, true);
+        transform_e_cols(set0);
+        transform_v_rows(set0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { write_e(0, r); write_v(0, r); }
+        load(set1, c_lo + 1, c_lo + 1 < c_hi);
+        load(set0, c_lo + 2, c_lo + 2 < c_hi);
     }
     __syncthreads();
 
-    int it = 0;
-    for (int chunk = c_lo; chunk < c_hi; ++chunk, ++it) {
-        const int cur = it & 1, nxt = cur ^ 1;
+    // One chunk: 32 MFMAs in eight groups (one Winograd point each: four steps from one float4 pair, the next group's pair
+    // requested first), the side work of the chunk in the sixteen half-group slots between them: set P ^ 1 (chunk c + 1,
+    // loaded during chunk c - 2) is transformed and written to LDS, then refilled with chunk c + 3 -- a load has a chunk and
+    // a half (3-4 us) before its first use, and nearly every 64-lane load here includes a line that comes from HBM (x and dL/dy
+    // are each read by 8-32 workgroups: 9 % of the L2 requests miss, ~20 lines per instruction).  P is the chunk's parity inside the
+    // slice, a compile-time constant (the loop body is a pair of chunks).  Loads are unconditional (masked past the slice end):
+    // a branch around loads makes every later wait a wait for ALL loads, the counter state of the two paths differs.
+    auto chunk_body = [&](auto parity, int chunk) {
+        constexpr int P = decltype(parity)::value;
+        const std::integral_constant<int, P ^ 1> setT;
         const bool more = chunk + 1 < c_hi;
-        const float* Eb = El + cur * IMG + aoff;
-        const float* Vb = Vl + cur * IMG + boff;
-        // registers hold chunk + 1 (loaded one iteration ago); its transform and LDS writes are spread over this chunk's
-        // MFMA slots, the loads of chunk + 2 follow once the registers are free.  (`more` is wave-uniform: the side work of
-        // the last chunk is skipped by scalar branches around straight-line code.)
+        const float* Eb = El + P * IMG + aoff;
+        const float* Vb = Vl + P * IMG + boff;
+        const int xi0 = 2 * q;
+        f32x4 a = *reinterpret_cast<const f32x4*>(Eb + xi0 * XI_STRIDE);
+        f32x4 b = *reinterpret_cast<const f32x4*>(Vb + xi0 * XI_STRIDE);
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {  // Winograd point xi = 4 (g >> 1) + 2 q + (g & 1): four MFMA steps from one float4 pair
-            const int i = g >> 1, jj = g & 1, xi = 4 * i + 2 * q + jj;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(Eb + xi * XI_STRIDE);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(Vb + xi * XI_STRIDE);
+        for (int g = 0; g < 8; ++g) {  // Winograd point xi = 4 (g >> 1) + 2 q + (g & 1)
+            const int i = g >> 1, jj = g & 1;
+            f32x4 an = a, bn = b;
+            if (g < 7) {
+                const int xin = 4 * ((g + 1) >> 1) + 2 * q + ((g + 1) & 1);
+                an = *reinterpret_cast<const f32x4*>(Eb + xin * XI_STRIDE);
+                bn = *reinterpret_cast<const f32x4*>(Vb + xin * XI_STRIDE);
+            }
             acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[i][jj], 0, 0, 0);
             acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[i][jj], 0, 0, 0);
+#ifndef SIS_WG_NOTRANSFORM  // (ablation switches for timing experiments: results wrong)
             if (more) {
-                if (g == 0) transform_e();
-                if (g == 1) transform_v_rows();
-                if (g >= 2 && g < 6) transform_v_cols(g - 2);
+                if (g == 1) { transform_e_cols(setT); write_e(P ^ 1, 0); }
+                if (g == 2) write_e(P ^ 1, 2);
+                if (g == 3) transform_v_rows(setT);
+                if (g == 4) write_v(P ^ 1, 1);
+                if (g == 5) write_v(P ^ 1, 3);
             }
+#endif
+#ifndef SIS_WG_NOLOAD
+            if (g == 0) geo(chunk + 3, chunk + 3 < c_hi);
+            if (g == 4) load_x(setT, 1);
+            if (g == 5) load_x(setT, 3);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[i][jj], 0, 0, 0);
             acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[i][jj], 0, 0, 0);
+#ifndef SIS_WG_NOTRANSFORM
             if (more) {
-                if (g >= 3 && g < 7) write_images(nxt, g - 3);
-                if (g == 7 && chunk + 2 < c_hi) load(chunk + 2);
+                if (g == 1) write_e(P ^ 1, 1);
+                if (g == 2) write_e(P ^ 1, 3);
+                if (g == 3) write_v(P ^ 1, 0);
+                if (g == 4) write_v(P ^ 1, 2);
             }
+#endif
+#ifndef SIS_WG_NOLOAD
+            if (g == 2) load_g(setT);
+            if (g == 3) load_x(setT, 0);
+            if (g == 4) load_x(setT, 2);
+#endif
             __builtin_amdgcn_sched_barrier(0);
+            a = an; b = bn;
         }
+#ifndef SIS_WG_NOBARRIER
         __syncthreads();
+#endif
+    };
+    for (int chunk = c_lo; chunk < c_hi; chunk += 2) {
+        chunk_body(set0, chunk);
+        if (chunk + 1 < c_hi) chunk_body(set1, chunk + 1);
     }
 
     // raw partial sums: slab[slice][xi][co][ci]
@@ -237,7 +297,8 @@ int wgrad_plan(WgradParams& p, int* ksplit, int batch, int cin, int cout, int h,
     if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return -1;
     if (h % 2 || w % 2 || cin % GBLK || cout % GBLK) return -1;
     if (((int64_t)batch * (h / 2) * (w / 2)) % GK) return -1;  // whole chunks of GK tiles
-    if ((int64_t)batch * (cin > cout ? cin : cout) * h * w >= ((int64_t)1 << 31)) return -1;
+    if ((int64_t)batch * (cin > cout ? cin : cout) * h * w >= ((int64_t)1 << 29)) return -1;  // 32-bit byte offsets below 2^31
+    if ((int64_t)batch * (h / 2) * (w / 2) >= (1 << 24)) return -1;  // tile indices are divided through float reciprocals
     p.B = batch; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w;
     p.tiles_per_row = w / 2;
     p.tiles_per_sample = (h / 2) * (w / 2);
