@@ -17,6 +17,7 @@
 // writes spread over the slots between the 32 MFMAs.
 // Split-K over tile ranges (blockIdx.y) writes raw S slabs; conv_wgrad_finish adds them in slice order
 // (deterministic) and applies G^T . G.
+#include <cstdlib>
 #include <type_traits>
 #include "sis_common.h"
 
@@ -305,7 +306,12 @@ int wgrad_plan(WgradParams& p, int* ksplit, int batch, int cin, int cout, int h,
     p.chunks_total = (int)((int64_t)batch * p.tiles_per_sample / GK);
     const int64_t blocks = (int64_t)(cin / GBLK) * (cout / GBLK);
     const int64_t slab_bytes = (int64_t)16 * cin * cout * 4;
-    int want = (int)((512 + blocks - 1) / blocks);            // ~2 workgroup rounds over 256 CUs
+    // One workgroup per CU fits (128 KB of LDS): ONE round of workgroups over the 256 CUs.  (Two rounds, the round-1 plan, halve
+    // every slice -- twice the slab traffic and twice the prologues for the same multiplies: 256 -> 256 channels on 16 x 16 sub-images
+    // went from 127 to 151 TF with one round, 320 workgroups -- a second round for a quarter of the CUs -- fell to 106.)
+    static const int target_wgs = getenv("SIS_WGRAD_WGS") ? atoi(getenv("SIS_WGRAD_WGS")) : 256;
+    int want = (int)((target_wgs + blocks - 1) / blocks);
+    while (want > 1 && want * blocks > target_wgs) --want;    // never past one round
     if (want > p.chunks_total / 4) want = p.chunks_total / 4;  // at least 4 chunks per slice
     if (want < 1) want = 1;
     if ((int64_t)want * slab_bytes > workspace_bytes) want = (int)(workspace_bytes / slab_bytes);
