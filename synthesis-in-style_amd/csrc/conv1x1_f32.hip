@@ -11,6 +11,7 @@
 // weight tensor [Cout][Cin] as [k][m] directly); for the forward ([m][k] in memory) each lane loads one float4 of a
 // weight row and writes its four values down a column of the k-major image (lanes = consecutive m: conflict-free).
 // 32-channel chunks, double-buffered, ONE barrier per 64 MFMAs per wave.
+#include <cstdlib>
 #include <type_traits>
 #include "sis_common.h"
 
@@ -21,7 +22,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 template <int MT_, int NPIX_, int KC_>
 struct PwCfg {
     static constexpr int MT = MT_, NPIX = NPIX_, KC = KC_;
-    static constexpr int WM = MT == 128 ? (NPIX == 256 ? 2 : 4) : 1;
+    static constexpr int WM = MT == 128 ? (NPIX == 256 ? 2 : 4) : (NPIX == 256 ? 1 : 2);
     static constexpr int WN = 8 / WM;
     static constexpr int MB = MT / 32 / WM, NB = NPIX / 32 / WN;
     static_assert(MB >= 1 && NB >= 1 && MB * WM * 32 == MT && NB * WN * 32 == NPIX, "wave layout");
@@ -211,13 +212,22 @@ bool pw_ok(int k, int m, int hw) { return k > 0 && m > 0 && hw > 0 && k % 32 == 
 
 template <int KC>
 int dispatch_pw(PwParams& p, int batch, int data_gradient, hipStream_t st) {
-    const int mt = p.M > 64 ? 128 : 64;
-    int npix = 256;
-    if (mt == 128 && (int64_t)batch * sis_cdiv(p.HW, 256) * sis_cdiv(p.M, 128) < 256) npix = 128;  // fill the 256 compute units
-    p.px_tiles = sis_cdiv(p.HW, npix);
-    if (mt == 128 && npix == 256) return launch_pw<PwCfg<128, 256, KC>>(p, data_gradient, st, KC == 16 ? "conv1x1_f32_kernel<128,256,16>" : "conv1x1_f32_kernel<128,256,32>");
-    if (mt == 128) return launch_pw<PwCfg<128, 128, KC>>(p, data_gradient, st, KC == 16 ? "conv1x1_f32_kernel<128,128,16>" : "conv1x1_f32_kernel<128,128,32>");
-    return launch_pw<PwCfg<64, 256, KC>>(p, data_gradient, st, KC == 16 ? "conv1x1_f32_kernel<64,256,16>" : "conv1x1_f32_kernel<64,256,32>");
+    // Tile: the largest of 128x256, 128x128, 64x256, 64x128 (output channels x pixels) that still gives one workgroup per CU
+    // (narrow layers -- 512 -> 128 channels on 32 x 32 maps -- had 128 tiles of 128 x 128 for 256 CUs), else the smallest.
+    static const int mts[4] = {128, 128, 64, 64}, nps[4] = {256, 128, 256, 128};
+    int pick = 3;
+    for (int i = 0; i < 4; ++i) {
+        if (mts[i] == 128 && p.M <= 64) continue;
+        static const int min_tiles = getenv("SIS_PW_MIN_TILES") ? atoi(getenv("SIS_PW_MIN_TILES")) : 256;
+        if ((int64_t)batch * sis_cdiv(p.HW, nps[i]) * sis_cdiv(p.M, mts[i]) >= min_tiles) { pick = i; break; }
+    }
+    p.px_tiles = sis_cdiv(p.HW, nps[pick]);
+    switch (pick) {
+        case 0: return launch_pw<PwCfg<128, 256, KC>>(p, data_gradient, st, KC == 16 ? "conv1x1_f32_kernel<128,256,16>" : "conv1x1_f32_kernel<128,256,32>");
+        case 1: return launch_pw<PwCfg<128, 128, KC>>(p, data_gradient, st, KC == 16 ? "conv1x1_f32_kernel<128,128,16>" : "conv1x1_f32_kernel<128,128,32>");
+        case 2: return launch_pw<PwCfg<64, 256, KC>>(p, data_gradient, st, KC == 16 ? "conv1x1_f32_kernel<64,256,16>" : "conv1x1_f32_kernel<64,256,32>");
+        default: return launch_pw<PwCfg<64, 128, KC>>(p, data_gradient, st, KC == 16 ? "conv1x1_f32_kernel<64,128,16>" : "conv1x1_f32_kernel<64,128,32>");
+    }
 }
 
 }  // namespace
