@@ -42,7 +42,7 @@ for cin, cout, hw, dil, count in shapes:
         td = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (dil, dil), (dil, dil), False, (0, 0), 1,
                                                                 (True, False, False)))
     ours = float("nan")
-    if sis_hip.conv3x3_wgrad_supported(B * dil * dil, cin, cout, hw // dil, hw // dil):
+    if sis_hip.conv3x3_wgrad_supported(B * dil * dil, cin, cout, hw // dil, hw // dil, min_work=0):  # (capability only: the policy threshold is what this tool is for)
         ref = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (dil, dil), (dil, dil), False, (0, 0), 1, (False, True, False))[1]
         got = sis_hip.conv3x3_wgrad(_space_to_batch(x, dil), _space_to_batch(gy, dil))
         err = ((got - ref).abs().max() / ref.abs().max()).item()

@@ -11,7 +11,10 @@ names = [r["Kernel_Name"] for r in rows]
 starts = [i for i, n in enumerate(names) if "pixel_norm" in n]
 if len(starts) < 3:
     sys.exit("need at least 3 steps in the trace")
-a, b = starts[-2], starts[-1]
+# (a step of the timed region: of all consecutive pairs of step starts, the one with the median span -- the trace also holds
+# warm-up, parity and CPU-baseline stages with the same first kernel)
+pairs = sorted(zip(starts[:-1], starts[1:]), key=lambda ab: int(rows[ab[1]]["Start_Timestamp"]) - int(rows[ab[0]]["Start_Timestamp"]))
+a, b = pairs[len(pairs) // 2]
 step = rows[a:b]
 t0 = int(step[0]["Start_Timestamp"])
 t1 = max(int(r["End_Timestamp"]) for r in step)
