@@ -365,11 +365,12 @@ def conv3x3(x, u):
     return out
 
 
-def conv3x3_wgrad_supported(batch, cin, cout, h, w, min_work=2e8):
-    """Capability (tile plan: channels % 64, even H / W, whole 8-tile chunks, workspace) and policy: below ~2e8 multiply-accumulates per tap
-    the split-K reduction outweighs the MFMA time and the library's kernel is as fast or faster (measured on
-    EMANet-50's layers, tools/bench_wgrad_shapes.py: since the round-2 loop and the one-round split-K plan 64->64 @64^2 and
-    128->128 @32^2 (2.7e8) win as well, 0.065 / 0.057 ms against 0.073 / 0.080)."""
+def conv3x3_wgrad_supported(batch, cin, cout, h, w, min_work=0.0):
+    """Capability (tile plan: channels % 64, even H / W, whole 8-tile chunks, workspace).  No size policy any more (``min_work`` =
+    multiply-accumulates per tap below which the library would keep the layer): since the round-2 loop and the one-round split-K
+    plan the kernel wins from 5e6 upwards (tools/bench_wgrad_small.py: 5x64->64 @16^2 0.025 vs 0.030 ms, 16x128->128 @32^2 0.056 vs
+    0.079) and loses 14 us on 512-channel 4^2 / 8^2 maps (0.033 vs 0.019 ms) -- where the library's kernel adds its K slices with
+    atomics and returns different bits from run to run (tools/check_conv_determinism.py); this one is deterministic."""
     if float(batch) * h * w * cin * cout < min_work:
         return False
     return bool(lib().sis_conv3x3_wgrad_eligible(batch, cin, cout, h, w, WORKSPACE_BYTES))

@@ -11,8 +11,9 @@ import sis_hip  # noqa: E402
 dev = torch.device("cuda")
 bad = 0
 for (b, cin, cout, h, w) in [(8, 64, 64, 4, 4), (8, 128, 128, 8, 8), (4, 64, 128, 16, 16), (8, 64, 64, 32, 32), (2, 64, 64, 4, 8),
-                             (16, 512, 512, 32, 32), (3, 64, 64, 64, 48), (16, 128, 64, 2, 2), (8, 256, 256, 4, 4), (5, 64, 64, 8, 8)]:
-    if not sis_hip.conv3x3_wgrad_supported(b, cin, cout, h, w):
+                             (16, 512, 512, 32, 32), (3, 64, 64, 64, 48), (16, 128, 64, 2, 2), (8, 256, 256, 4, 4), (5, 64, 64, 8, 8),
+                             (8, 512, 512, 16, 16), (4, 512, 512, 32, 32), (8, 512, 512, 8, 8), (4, 256, 512, 16, 16), (6, 64, 64, 4, 4)]:
+    if not sis_hip.conv3x3_wgrad_supported(b, cin, cout, h, w, min_work=0):
         print("unsupported", b, cin, cout, h, w)
         continue
     x = torch.randn(b, cin, h, w, device=dev)
