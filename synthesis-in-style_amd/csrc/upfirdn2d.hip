@@ -152,11 +152,21 @@ struct BlurRowParams {
 };
 constexpr int BR_ROWS = 8;
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// Round 2: every load of the lane's 8 + 3 input rows (and of its 8 noise rows) is in flight before the first one is used.
+// The first version waited after each row's float4 (the halo shuffles consume it at once, and the edge lanes' scalar loads sat
+// behind branches): one 16-byte load in flight per lane, 32 KB per CU -- by Little's law about the 4.8 TB/s it measured.  Loads go
+// through buffer descriptors so that a masked element (row outside the image, lane that takes its halo from a neighbour) is an
+// out-of-range OFFSET, not a branch and not a select on loaded data.
 template <bool FUSE>
 __global__ __launch_bounds__(256) void blur_rows_kernel(float* __restrict__ out, const float* __restrict__ in,
                                                         const float* __restrict__ taps, const float* __restrict__ noise,
                                                         const float* __restrict__ noise_w, const float* __restrict__ bias,
                                                         BlurRowParams p) {
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NR = BR_ROWS + 3;
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool active = g < p.total;
     const int64_t gg = active ? g : p.total - 1;
@@ -170,39 +180,54 @@ __global__ __launch_bounds__(256) void blur_rows_kernel(float* __restrict__ out,
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) k[a][b] = taps[(3 - a) * 4 + (3 - b)];  // flipped taps
-    const float* src = in + (int64_t)plane * p.in_h * p.in_rs;
-    const int x0 = 4 * xi - p.pad_x0;  // first input column of this lane's window (x0 .. x0+6)
+    // The wave's descriptor starts at the plane of its first lane (a wave of a narrow map spans a few planes: small offsets).
+    const int plane0 = __builtin_amdgcn_readfirstlane(plane);
+    const int64_t plane_elems = (int64_t)p.in_h * p.in_rs;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(in + plane0 * plane_elems), 0, 0x7FFFFFFF, 0x00020000);
+    const unsigned base = (unsigned)(((int64_t)(plane - plane0) * plane_elems + 4 * xi) * 4);  // bytes: row 0, column 4 xi
     const int oy0 = rg * BR_ROWS;
     const bool left_edge = xi == 0, right_edge = xi == p.cols4 - 1;
-    // pad_x0 == 1: own aligned float4 covers window columns 1..4, left neighbour gives column 0, right one 5..6
-    float win[4][7];
-    auto load_row = [&](int iy, float* w) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool row_ok = iy >= 0 && iy < p.in_h;
-        const float* rowp = src + (int64_t)iy * p.in_rs;
-        if (row_ok) a = *reinterpret_cast<const float4*>(rowp + 4 * xi);
-        float l = __shfl_up(a.w, 1, 64);
-        float r0 = __shfl_down(a.x, 1, 64), r1v = __shfl_down(a.y, 1, 64);
-        if (left_edge) l = 0.f;
-        else if (lane == 0) l = row_ok ? rowp[4 * xi - 1] : 0.f;
-        if (right_edge) {
-            r0 = (row_ok && 4 * xi + 4 < p.in_w) ? rowp[4 * xi + 4] : 0.f;
-            r1v = (row_ok && 4 * xi + 5 < p.in_w) ? rowp[4 * xi + 5] : 0.f;
-        } else if (lane == 63) {
-            r0 = row_ok ? rowp[4 * xi + 4] : 0.f;
-            r1v = row_ok ? rowp[4 * xi + 5] : 0.f;
-        }
-        w[0] = l; w[1] = a.x; w[2] = a.y; w[3] = a.z; w[4] = a.w; w[5] = r0; w[6] = r1v;
-    };
-    (void)x0;
+    // pad_x0 == 1: the lane's aligned float4 covers window columns 1..4; column 0 is the left neighbour's .w, columns 5..6 the right
+    // neighbour's .x / .y -- by shuffle, except at wave edges (from memory) and image edges (zero / from memory up to in_w).
+    const bool mem_l = lane == 0 && !left_edge, mem_r = lane == 63 || right_edge;
+    f32x4_t ra[NR];
+    float rl[NR];
+    f32x2_t rr[NR];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) load_row(oy0 - p.pad_y0 + t, win[t + 1]);
-    float nw = 0.f, bb = 0.f;
-    const float* nz = nullptr;
-    if (FUSE) {
-        if (noise) { nw = noise_w[0]; nz = noise + (int64_t)(plane / p.channels) * p.noise_bstride; }
-        if (bias) bb = bias[plane % p.channels];
+    for (int t = 0; t < NR; ++t) {
+        const int iy = oy0 - p.pad_y0 + t;
+        const bool ok = iy >= 0 && iy < p.in_h;
+        const unsigned ro = base + (unsigned)(iy * p.in_rs * 4);
+        ra[t] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? ro : OOB, 0, 0));
+        rl[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (ok && mem_l) ? ro - 4u : OOB, 0, 0));
+        rr[t] = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rs, (ok && mem_r) ? ro + 16u : OOB, 0, 0));
     }
+    float nw = 0.f, bb = 0.f;
+    f32x4_t nz[BR_ROWS];
+    if (FUSE) {
+        const bool has_noise = noise != nullptr;
+        if (has_noise) nw = noise_w[0];
+        if (bias) bb = bias[plane % p.channels];
+        const int b0 = __builtin_amdgcn_readfirstlane(plane / p.channels);
+        const __amdgpu_buffer_rsrc_t ns = __builtin_amdgcn_make_buffer_rsrc((void*)(noise + (has_noise ? b0 * p.noise_bstride : 0)), 0, 0x7FFFFFFF, 0x00020000);
+        const unsigned nbase = (unsigned)(((int64_t)(plane / p.channels - b0) * p.noise_bstride + 4 * xi) * 4);
+#pragma unroll
+        for (int j = 0; j < BR_ROWS; ++j) {
+            const int oy = oy0 + j;
+            nz[j] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ns, (has_noise && oy < p.out_h) ? nbase + (unsigned)(oy * p.out_w * 4) : OOB, 0, 0));
+        }
+    }
+    const bool r0_ok = 4 * xi + 4 < p.in_w, r1_ok = 4 * xi + 5 < p.in_w;  // (only the image's right edge can fail these)
+    float win[4][7];
+    auto window_row = [&](int t, float* w) {
+        const float sl = __shfl_up(ra[t].w, 1, 64), s0 = __shfl_down(ra[t].x, 1, 64), s1 = __shfl_down(ra[t].y, 1, 64);
+        w[0] = left_edge ? 0.f : (lane == 0 ? rl[t] : sl);
+        w[1] = ra[t].x; w[2] = ra[t].y; w[3] = ra[t].z; w[4] = ra[t].w;
+        w[5] = mem_r ? (r0_ok ? rr[t].x : 0.f) : s0;
+        w[6] = mem_r ? (r1_ok ? rr[t].y : 0.f) : s1;
+    };
+#pragma unroll
+    for (int t = 0; t < 3; ++t) window_row(t, win[t + 1]);
     float* dst = out + (int64_t)plane * p.out_h * p.out_w;
 #pragma unroll
     for (int j = 0; j < BR_ROWS; ++j) {
@@ -210,7 +235,7 @@ __global__ __launch_bounds__(256) void blur_rows_kernel(float* __restrict__ out,
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int c = 0; c < 7; ++c) win[t][c] = win[t + 1][c];
-        load_row(oy0 - p.pad_y0 + j + 3, win[3]);
+        window_row(j + 3, win[3]);
         float o[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
@@ -222,19 +247,14 @@ __global__ __launch_bounds__(256) void blur_rows_kernel(float* __restrict__ out,
             o[x] = v;
         }
         const int oy = oy0 + j;
-        if (active && oy < p.out_h) {
-            if (FUSE) {
-                float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (nz) n4 = *reinterpret_cast<const float4*>(nz + (int64_t)oy * p.out_w + 4 * xi);
-                const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
+        if (FUSE) {
 #pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    float v = o[x] + nw * nn[x] + bb;
-                    o[x] = (v > 0.f ? v : v * p.slope) * p.ascale;
-                }
+            for (int x = 0; x < 4; ++x) {
+                float v = o[x] + nw * nz[j][x] + bb;
+                o[x] = (v > 0.f ? v : v * p.slope) * p.ascale;
             }
-            *reinterpret_cast<float4*>(dst + (int64_t)oy * p.out_w + 4 * xi) = make_float4(o[0], o[1], o[2], o[3]);
         }
+        if (active && oy < p.out_h) *reinterpret_cast<float4*>(dst + (int64_t)oy * p.out_w + 4 * xi) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
