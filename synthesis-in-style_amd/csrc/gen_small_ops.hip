@@ -73,6 +73,50 @@ __global__ __launch_bounds__(256) void equal_linear_kernel(float* __restrict__ o
     }
 }
 
+// The same layer when in_dim is exactly NJ * 64 (the 512-wide mapping network): every load of the wave -- its weight row and
+// EL_ROWS input rows -- is requested before the first one is used.  In the general kernel above the predicated loads became
+// load - wait - multiply per element, 32 dependent L2 round trips per wave: 14.5 us for a 32 x 512 x 512 layer.
+template <int NJ>
+__global__ __launch_bounds__(256) void equal_linear_full_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                                int64_t x_row_stride, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, int batch, int out_dim,
+                                                                float scale, float lr_mul, int activation) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (o >= out_dim) return;
+    const int r0 = blockIdx.y * EL_ROWS;
+    float wr[NJ], xv[EL_ROWS][NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) wr[j] = w[(int64_t)o * (NJ * 64) + lane + 64 * j];
+#pragma unroll
+    for (int rr = 0; rr < EL_ROWS; ++rr) {
+        const float* xr = x + (int64_t)min(r0 + rr, batch - 1) * x_row_stride;  // (rows past the batch: recomputed, not stored)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) xv[rr][j] = xr[lane + 64 * j];
+    }
+    const float b = bias ? bias[o] * lr_mul : 0.f;
+    float acc[EL_ROWS];
+#pragma unroll
+    for (int rr = 0; rr < EL_ROWS; ++rr) {
+        acc[rr] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[rr] += xv[rr][j] * wr[j];  // (same order as the general kernel: j ascending)
+    }
+#pragma unroll
+    for (int rr = 0; rr < EL_ROWS; ++rr) acc[rr] = wave_sum(acc[rr]);
+    if (lane == 0) {
+#pragma unroll
+        for (int rr = 0; rr < EL_ROWS; ++rr) {
+            const int r = r0 + rr;
+            if (r < batch) {
+                float v = acc[rr] * scale + b;
+                if (activation) v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
+                out[(int64_t)r * out_dim + o] = v;
+            }
+        }
+    }
+}
+
 // ---- The batched "head" GEMMs of a forward (modulation, demodulation; MODE 0 = a single EqualLinear) on the fp32 matrix cores.
 // out[r][o] = epilogue(sum_k A[r][k] * W[o][k]) with r = batch row (32 per tile = one MFMA M block), W rows k-contiguous
 // as torch stores nn.Linear weights.  Workgroup = 4 waves = 32 rows x 128 outputs (wave w: outputs 32 w .. 32 w + 31),
@@ -362,8 +406,15 @@ extern "C" int sis_equal_linear(float* out, const float* x, int64_t x_row_stride
     if (batch <= 0 || out_dim <= 0) return 0;
     SIS_REQUIRE(out && x && w, "sis_equal_linear: null pointer");
     SIS_REQUIRE(in_dim > 0, "sis_equal_linear: in_dim %d", in_dim);
-    if (in_dim <= 64 * ELW) {
-        hipLaunchKernelGGL(equal_linear_kernel, dim3(sis_cdiv(out_dim, 4), sis_cdiv(batch, EL_ROWS)), dim3(256), 0, (hipStream_t)stream, out, x,
+    const dim3 grid(sis_cdiv(out_dim, 4), sis_cdiv(batch, EL_ROWS));
+    if (in_dim == 512) {
+        hipLaunchKernelGGL(equal_linear_full_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, out, x, x_row_stride, w, bias, batch, out_dim,
+                           scale, lr_mul, activation);
+    } else if (in_dim == 256) {
+        hipLaunchKernelGGL(equal_linear_full_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, out, x, x_row_stride, w, bias, batch, out_dim,
+                           scale, lr_mul, activation);
+    } else if (in_dim <= 64 * ELW) {
+        hipLaunchKernelGGL(equal_linear_kernel, grid, dim3(256), 0, (hipStream_t)stream, out, x,
                            x_row_stride, w, bias, batch, in_dim, out_dim, scale, lr_mul, activation);
     } else {  // wider than a wave's register row: the matrix-core tile kernel takes any in_dim
         HeadArgs h = {};
