@@ -1,6 +1,7 @@
 // Small generator-side kernels (fp32): mapping network pieces, weight prepack, demodulation
 // coefficients and the ToRGB / skip accumulation.  None of these is on the MFMA roofline; they
 // are latency- or HBM-bound and written so that each reads its operands exactly once.
+#include <type_traits>
 #include "sis_common.h"
 
 namespace {
@@ -177,18 +178,38 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const HeadArgs h) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const int srow = tid >> 3, sk = (tid & 7) * 8;  // staging: 8 consecutive k of one row per thread and pass
-    float av[8], wv[4][8];
-    auto load_chunk = [&](int k0) {  // global -> registers (the next chunk's loads fly under this chunk's MFMAs)
+    // Two register sets: chunk c + 2 is requested while chunk c multiplies (one chunk ahead, the 1 us MFMA phase of a chunk did
+    // not cover the loads' latency: ~4.5 us per 64-wide chunk, 41 us for the modulation launch).
+    float av[2][8], wv[2][4][8];
+    // Interior tiles (whole rows, whole output block, whole aligned chunks -- wave-uniform) load without predicates: a branch
+    // around a load makes the next wait a wait for every load in flight, the set requested two chunks ahead included.
+    const bool interior = r0 + HG_ROWS <= h.batch && o0 + HG_COLS <= out_dim && k_dim % HG_KC == 0 && a_stride % 4 == 0 &&
+                          ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w)) & 15) == 0;
+    auto load_chunk = [&](auto setc, int k0) {  // global -> registers
+        constexpr int S = decltype(setc)::value;
+        if (interior) {
+            const float* src = a + (int64_t)(r0 + srow) * a_stride + k0 + sk;
+            const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+            av[S][0] = v0.x; av[S][1] = v0.y; av[S][2] = v0.z; av[S][3] = v0.w; av[S][4] = v1.x; av[S][5] = v1.y; av[S][6] = v1.z; av[S][7] = v1.w;
+#pragma unroll
+            for (int pss = 0; pss < 4; ++pss) {
+                const float* ws = w + (int64_t)(o0 + pss * 32 + srow) * k_dim + k0 + sk;
+                const float4 w0 = *reinterpret_cast<const float4*>(ws), w1 = *reinterpret_cast<const float4*>(ws + 4);
+                wv[S][pss][0] = w0.x; wv[S][pss][1] = w0.y; wv[S][pss][2] = w0.z; wv[S][pss][3] = w0.w;
+                wv[S][pss][4] = w1.x; wv[S][pss][5] = w1.y; wv[S][pss][6] = w1.z; wv[S][pss][7] = w1.w;
+            }
+            return;
+        }
         {
             const int r = r0 + srow;
             const float* src = a + (int64_t)r * a_stride + k0 + sk;
             const bool full = r < h.batch && k0 + sk + 8 <= k_dim && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
             if (full) {
                 const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
-                av[0] = v0.x; av[1] = v0.y; av[2] = v0.z; av[3] = v0.w; av[4] = v1.x; av[5] = v1.y; av[6] = v1.z; av[7] = v1.w;
+                av[S][0] = v0.x; av[S][1] = v0.y; av[S][2] = v0.z; av[S][3] = v0.w; av[S][4] = v1.x; av[S][5] = v1.y; av[S][6] = v1.z; av[S][7] = v1.w;
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) av[j] = (r < h.batch && k0 + sk + j < k_dim) ? src[j] : 0.f;
+                for (int j = 0; j < 8; ++j) av[S][j] = (r < h.batch && k0 + sk + j < k_dim) ? src[j] : 0.f;
             }
         }
 #pragma unroll
@@ -198,34 +219,42 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const HeadArgs h) {
             const bool full = o < out_dim && k0 + sk + 8 <= k_dim && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
             if (full) {
                 const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
-                wv[pss][0] = v0.x; wv[pss][1] = v0.y; wv[pss][2] = v0.z; wv[pss][3] = v0.w;
-                wv[pss][4] = v1.x; wv[pss][5] = v1.y; wv[pss][6] = v1.z; wv[pss][7] = v1.w;
+                wv[S][pss][0] = v0.x; wv[S][pss][1] = v0.y; wv[S][pss][2] = v0.z; wv[S][pss][3] = v0.w;
+                wv[S][pss][4] = v1.x; wv[S][pss][5] = v1.y; wv[S][pss][6] = v1.z; wv[S][pss][7] = v1.w;
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) wv[pss][j] = (o < out_dim && k0 + sk + j < k_dim) ? src[j] : 0.f;
+                for (int j = 0; j < 8; ++j) wv[S][pss][j] = (o < out_dim && k0 + sk + j < k_dim) ? src[j] : 0.f;
             }
         }
     };
-    load_chunk(0);
-    for (int k0 = 0; k0 < k_dim; k0 += HG_KC) {
+    auto chunk = [&](auto setc, int k0) {
+        constexpr int S = decltype(setc)::value;
         if (MODE == 2) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float t = av[j] * scale; av[j] = t * t; }
+            for (int j = 0; j < 8; ++j) { const float t = av[S][j] * scale; av[S][j] = t * t; }
         }
         __syncthreads();  // the previous chunk's operand reads are done
 #pragma unroll
-        for (int j = 0; j < 8; j += 2) *reinterpret_cast<float2*>(Al + srow * HG_LD + sk + j) = make_float2(av[j], av[j + 1]);
+        for (int j = 0; j < 8; j += 2) *reinterpret_cast<float2*>(Al + srow * HG_LD + sk + j) = make_float2(av[S][j], av[S][j + 1]);
 #pragma unroll
         for (int pss = 0; pss < 4; ++pss)
 #pragma unroll
             for (int j = 0; j < 8; j += 2)
-                *reinterpret_cast<float2*>(Wl + (pss * 32 + srow) * HG_LD + sk + j) = make_float2(wv[pss][j], wv[pss][j + 1]);
+                *reinterpret_cast<float2*>(Wl + (pss * 32 + srow) * HG_LD + sk + j) = make_float2(wv[S][pss][j], wv[S][pss][j + 1]);
         __syncthreads();
-        if (k0 + HG_KC < k_dim) load_chunk(k0 + HG_KC);
+        if (k0 + 2 * HG_KC < k_dim) load_chunk(setc, k0 + 2 * HG_KC);  // this set is free again
         const float* ap = Al + l31 * HG_LD + half;
         const float* wp = Wl + (wave * 32 + l31) * HG_LD + half;
 #pragma unroll
         for (int st = 0; st < HG_KC / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * st], wp[2 * st], acc, 0, 0, 0);
+    };
+    const std::integral_constant<int, 0> set0;
+    const std::integral_constant<int, 1> set1;
+    load_chunk(set0, 0);
+    if (HG_KC < k_dim) load_chunk(set1, HG_KC);
+    for (int k0 = 0; k0 < k_dim; k0 += 2 * HG_KC) {
+        chunk(set0, k0);
+        if (k0 + HG_KC < k_dim) chunk(set1, k0 + HG_KC);
     }
     const int o = o0 + wave * 32 + l31;
     if (o >= out_dim) return;
