@@ -347,15 +347,15 @@ __global__ __launch_bounds__(256) void to_rgb_kernel(float* __restrict__ out, co
                                                      const float* __restrict__ bias, const float* __restrict__ skip,
                                                      const float* __restrict__ taps, RgbParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* weff = smem;                       // [cout][cin]: scale * w[c,ci] * s[b,ci]
-    float* part = smem + p.cout * p.cin;      // [3 waves][RGB_MAXC][VEC][64]
+    float* weff = smem;                       // [RGB_MAXC][cin]: scale * w[c,ci] * s[b,ci], zero rows past cout
+    float* part = smem + RGB_MAXC * p.cin;    // [3 waves][RGB_MAXC][VEC][64]
     const int hw = p.h * p.w;
     const int groups = (hw + 64 * VEC - 1) / (64 * VEC);
     const int b = blockIdx.x / groups, g = blockIdx.x % groups;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int e = threadIdx.x; e < p.cout * p.cin; e += 256) {
+    for (int e = threadIdx.x; e < RGB_MAXC * p.cin; e += 256) {
         const int ci = e % p.cin;
-        weff[e] = p.scale * w[e] * s[(int64_t)b * p.cin + ci];
+        weff[e] = e < p.cout * p.cin ? p.scale * w[e] * s[(int64_t)b * p.cin + ci] : 0.f;
     }
     __syncthreads();
     const int pix = (g * 64 + lane) * VEC;
@@ -366,22 +366,34 @@ __global__ __launch_bounds__(256) void to_rgb_kernel(float* __restrict__ out, co
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[c][v] = 0.f;
     if (live) {
+        // Eight channels of the wave per trip, their loads requested before the first multiply (with `if (c < cout)` inside the
+        // loop every channel was load - wait - multiply: one 16-byte load in flight per lane).  All RGB_MAXC output rows are formed
+        // (zero weights past cout); a trip's channels past cin re-read the last one with weight 0.
+        constexpr int U = 8;
         const float* xb = x + (int64_t)b * p.cin * hw + pix;
-#pragma unroll 8
-        for (int ci = wave; ci < p.cin; ci += 4) {
-            float xv[4];
-            if (VEC == 4) {
-                const float4 t = *reinterpret_cast<const float4*>(xb + (int64_t)ci * hw);
-                xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
-            } else {
-                xv[0] = xb[(int64_t)ci * hw];
+        for (int ci0 = wave; ci0 < p.cin; ci0 += 4 * U) {
+            float xv[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ci = min(ci0 + 4 * u, p.cin - 1);
+                if (VEC == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(xb + (int64_t)ci * hw);
+                    xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][3] = t.w;
+                } else {
+                    xv[u][0] = xb[(int64_t)ci * hw];
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);  // all eight requests before the first multiply
 #pragma unroll
-            for (int c = 0; c < RGB_MAXC; ++c) {
-                if (c < p.cout) {
-                    const float wv = weff[c * p.cin + ci];
+            for (int u = 0; u < U; ++u) {
+                const int ci = ci0 + 4 * u;
+                const int cc = min(ci, p.cin - 1);
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) acc[c][v] += wv * xv[v];
+                for (int c = 0; c < RGB_MAXC; ++c) {
+                    const float wl = weff[c * p.cin + cc];
+                    const float wv = ci < p.cin ? wl : 0.f;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[c][v] += wv * xv[u][v];
                 }
             }
         }
@@ -516,7 +528,7 @@ extern "C" int sis_to_rgb(float* out, const float* x, const float* w, const floa
     if (batch <= 0 || h <= 0 || wd <= 0) return 0;
     SIS_REQUIRE(out && x && w && s, "sis_to_rgb: null pointer");
     SIS_REQUIRE(cout >= 1 && cout <= RGB_MAXC, "sis_to_rgb: cout %d outside 1..%d", cout, RGB_MAXC);
-    SIS_REQUIRE(cin >= 1 && (size_t)cin * cout * 4 <= 48 * 1024, "sis_to_rgb: cin too large");
+    SIS_REQUIRE(cin >= 1 && (size_t)cin * RGB_MAXC * 4 <= 48 * 1024, "sis_to_rgb: cin too large");
     RgbParams p;
     p.batch = batch; p.cin = cin; p.cout = cout; p.h = h; p.w = wd; p.kh = kh; p.kw = kw; p.pad0 = pad0;
     p.sh = 0; p.sw = 0; p.scale = scale;
@@ -531,11 +543,11 @@ extern "C" int sis_to_rgb(float* out, const float* x, const float* w, const floa
     const int hw = h * wd;
     hipStream_t st = (hipStream_t)stream;
     if (hw % 4 == 0 && hw >= 256 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
-        const size_t lds = ((size_t)cin * cout + 3 * RGB_MAXC * 4 * 64) * sizeof(float);
+        const size_t lds = ((size_t)cin * RGB_MAXC + 3 * RGB_MAXC * 4 * 64) * sizeof(float);
         hipLaunchKernelGGL(to_rgb_kernel<4>, dim3(batch * sis_cdiv(hw, 256)), dim3(256), lds, st, out, x, w, s, bias, skip,
                            taps, p);
     } else {
-        const size_t lds = ((size_t)cin * cout + 3 * RGB_MAXC * 64) * sizeof(float);
+        const size_t lds = ((size_t)cin * RGB_MAXC + 3 * RGB_MAXC * 64) * sizeof(float);
         hipLaunchKernelGGL(to_rgb_kernel<1>, dim3(batch * sis_cdiv(hw, 64)), dim3(256), lds, st, out, x, w, s, bias, skip,
                            taps, p);
     }
