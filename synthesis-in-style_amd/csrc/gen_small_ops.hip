@@ -406,19 +406,57 @@ __global__ __launch_bounds__(256) void to_rgb_kernel(float* __restrict__ out, co
     }
     __syncthreads();
     if (wave != 0 || !live) return;
+    // Upsampled skip image, taps <= 4 x 4 (two per dimension after the polyphase split): per output channel the 4 * VEC skip
+    // values and tap weights are requested together with clamped indices, then masked and added in skip_up2's order (the
+    // per-tap `continue`s of skip_up2 made every tap a dependent round trip: 24 per lane, as long as the channel loop itself).
+    const bool skip_fast = skip && p.kh <= 4 && p.kw <= 4;
+    int s_off[VEC][4], t_off[VEC][4];
+    unsigned s_ok = 0;
+    if (skip_fast) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int y = (pix + v) / p.w, xx = (pix + v) % p.w;
+            const int mid_x = xx + 1 - p.pad0, mid_y = y + 1 - p.pad0;
+            const int ix0 = (mid_x >= 0) ? mid_x / 2 : -((1 - mid_x) / 2);
+            const int iy0 = (mid_y >= 0) ? mid_y / 2 : -((1 - mid_y) / 2);
+            const int kx0 = (ix0 + 1) * 2 - mid_x - 1, ky0 = (iy0 + 1) * 2 - mid_y - 1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int iy = iy0 + (t >> 1), ix = ix0 + (t & 1), fy = ky0 + 2 * (t >> 1), fx = kx0 + 2 * (t & 1);
+                const bool ok = iy >= 0 && iy < p.sh && ix >= 0 && ix < p.sw && fy < p.kh && fx < p.kw;
+                s_ok |= (ok ? 1u : 0u) << (v * 4 + t);
+                s_off[v][t] = min(max(iy, 0), p.sh - 1) * p.sw + min(max(ix, 0), p.sw - 1);
+                t_off[v][t] = (p.kh - 1 - min(fy, p.kh - 1)) * p.kw + (p.kw - 1 - min(fx, p.kw - 1));
+            }
+        }
+    }
 #pragma unroll
     for (int c = 0; c < RGB_MAXC; ++c) {
         if (c >= p.cout) continue;
         const float bb = bias ? bias[c] : 0.f;
         float* o = out + ((int64_t)b * p.cout + c) * hw + pix;
         float r[VEC];
+        float sv[VEC][4], tv[VEC][4];
+        if (skip_fast) {
+            const float* sp = skip + ((int64_t)b * p.cout + c) * p.sh * p.sw;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { sv[v][t] = sp[s_off[v][t]]; tv[v][t] = taps[t_off[v][t]]; }
+        }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             float a = acc[c][v];
 #pragma unroll
             for (int ww = 0; ww < 3; ++ww) a += part[((ww * RGB_MAXC + c) * VEC + v) * 64 + lane];
             a += bb;
-            if (skip) {
+            if (skip_fast) {
+                float u = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if ((s_ok >> (v * 4 + t)) & 1u) u += sv[v][t] * tv[v][t];
+                a += u;
+            } else if (skip) {
                 const int y = (pix + v) / p.w, xx = (pix + v) % p.w;
                 a += skip_up2(skip + ((int64_t)b * p.cout + c) * p.sh * p.sw, taps, p, y, xx);
             }
