@@ -126,9 +126,22 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
 
     // ---- one-time LDS init: zeros under the input tiles, style rows of this tile's samples
     for (int e = tid; e < 2 * CC * xt; e += NTHR) Xl[e] = 0.f;
-    for (int e = tid; e < tc.nb * p.Cin; e += NTHR) {
-        const int n = e / p.Cin, ci = e - n * p.Cin;
-        Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
+    {  // four elements per lane and trip, requested together (clamped; a predicated load per trip was one round trip per element)
+        const int sl_total = tc.nb * p.Cin;
+        for (int e0 = tid; e0 < sl_total; e0 += 4 * NTHR) {
+            float sv4[4];
+            bool in_batch[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + u * NTHR, sl_total - 1);
+                const int n = e / p.Cin, ci = e - n * p.Cin;
+                in_batch[u] = b0 + n < p.B;
+                sv4[u] = p.s[(int64_t)min(b0 + n, p.B - 1) * p.Cin + ci];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + u * NTHR < sl_total) Sl[e0 + u * NTHR] = in_batch[u] ? sv4[u] : 0.f;
+        }
     }
 
     // ---- per-lane DMA source offsets for the input tile, one float4 chunk each (-1: outside the image, never

@@ -168,9 +168,22 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino_kernel(const ConvParams
     const int k_hi = min(p.Cin, k_lo + p.kchunk);
 
     for (int e = tid; e < 2 * WCC * xt; e += WNTHR) Xl[e] = 0.f;
-    for (int e = tid; e < (p.s ? tc.nb * p.Cin : 0); e += WNTHR) {  // plain convolution (p.s == nullptr): no style rows
-        const int n = e / p.Cin, ci = e - n * p.Cin;
-        Sl[e] = (b0 + n < p.B) ? p.s[(int64_t)(b0 + n) * p.Cin + ci] : 0.f;
+    {  // four elements per lane and trip, requested together (clamped; a predicated load per trip was one round trip per element)
+        const int sl_total = p.s ? tc.nb * p.Cin : 0;  // plain convolution (p.s == nullptr): no style rows
+        for (int e0 = tid; e0 < sl_total; e0 += 4 * WNTHR) {
+            float sv4[4];
+            bool in_batch[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + u * WNTHR, sl_total - 1);
+                const int n = e / p.Cin, ci = e - n * p.Cin;
+                in_batch[u] = b0 + n < p.B;
+                sv4[u] = p.s[(int64_t)min(b0 + n, p.B - 1) * p.Cin + ci];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + u * WNTHR < sl_total) Sl[e0 + u * WNTHR] = in_batch[u] ? sv4[u] : 0.f;
+        }
     }
     // one float4 chunk of the tile per lane per channel (<= 512 chunks: host-checked)
     int st_goff = -1;
