@@ -10,9 +10,33 @@
 //  * sis_make_image_u8   float image in [-1,1] (NCHW) -> uint8 NHWC, the conversion in front of the PNG writer
 //                        (create_dataset_for_segmentation.py:135; third-party make_image: clamp, add 1, div 2, mul 255,
 //                        truncating cast; every step a separate fp32 operation as in the oracle: bytes are bit-exact).
+#include <type_traits>
 #include "sis_common.h"
 
 namespace {
+
+typedef float km_f32x2 __attribute__((ext_vector_type(2)));
+typedef float km_f32x4 __attribute__((ext_vector_type(4)));
+// Packed fp32 forms of the three separately rounded operations of a k-means term, two pixels per instruction (IEEE add / mul
+// per half: the same bits as the scalar instructions; inline assembly, so no contraction either).  The centre is one half
+// of a register pair as ds_read_b128 delivers it, broadcast to both pixels by op_sel.
+template <int HI>
+__device__ __forceinline__ km_f32x2 km_sub_bcast(km_f32x2 x, km_f32x2 cpair) {  // x - cpair[HI]
+    km_f32x2 r;
+    if constexpr (HI == 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(cpair));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(cpair));
+    return r;
+}
+__device__ __forceinline__ km_f32x2 km_sq(km_f32x2 d) {
+    km_f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %1" : "=v"(r) : "v"(d));
+    return r;
+}
+__device__ __forceinline__ km_f32x2 km_add(km_f32x2 a, km_f32x2 b) {
+    km_f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // Summation order (documented, bit-exact contract).  The reference evaluates ``((A - B) ** 2.0).sum(dim=-1)`` with
 // torch's CPU reduction (factor_catalog.py:55-59), whose result for near-ties depends on the association of the fp32
@@ -68,8 +92,105 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(int64_t* __restrict_
 #pragma unroll
         for (int v = 0; v < VEC; ++v) fin[k][v] = 0.f;
     const int nvec = C >> 3, rows = nvec >> 2;
-    for (int c = nvec << 3; c < C; ++c) accumulate(c, fin);  // scalar tail first
-    for (int l = 0; l < 8; ++l) {
+    // Fast path (C a multiple of 128, no second cascade level: the generator's 128- and 512-channel keys): the SAME sequence of
+    // channels and adds, but the loads of eight steps are requested while the previous eight multiply (the plain loop below
+    // waits for every channel's load before its 3 * K VALU operations: with 2-3 waves per SIMD the kernel sat at a third of
+    // the VALU rate that bounds it).  A lane position l has 4 * rows steps p = part * rows + r (channel ((4 r + part) * 8) + l),
+    // taken in groups of eight; two register sets, the set parity a compile-time constant (rows / 2 groups per l: even).
+    const bool fast = !CASCADE && (C & 127) == 0;
+    if (fast) {
+        float xs[2][8][VEC];
+        km_f32x2 a2[KMAX], l2[KMAX], f2[KMAX];  // (VEC == 2: the accumulators as register pairs)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { a2[k] = km_f32x2{0.f, 0.f}; l2[k] = a2[k]; f2[k] = a2[k]; }
+        constexpr bool PK = VEC == 2 && KMAX % 4 == 0;
+        const int ng = rows >> 1;  // groups of eight steps per lane position
+        auto chan = [&](int l, int p) { const int part = p / rows, r = p - part * rows; return (((r << 2) + part) << 3) + l; };
+        auto request = [&](auto setc, int l, int g) {
+            constexpr int S = decltype(setc)::value;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = chan(l, g * 8 + u);
+                if constexpr (VEC == 2) {
+                    const float2 t = *reinterpret_cast<const float2*>(xb + (int64_t)c * HW);
+                    xs[S][u][0] = t.x; xs[S][u][1] = t.y;
+                } else {
+                    xs[S][u][0] = xb[(int64_t)c * HW];
+                }
+            }
+        };
+        auto group = [&](auto setc, int l, int g) {
+            constexpr int S = decltype(setc)::value;
+            // the next group (past the end: the last one again, unused) -- requested before this group's arithmetic
+            int ln = l, gn = g + 1;
+            if (gn == ng) { gn = 0; ++ln; }
+            if (ln == 8) { ln = 7; gn = ng - 1; }
+            request(std::integral_constant<int, S ^ 1>(), ln, gn);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = g * 8 + u;
+                const int part = p / rows, r = p - part * rows;
+                if (r == 0) {
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) {
+                        if constexpr (PK) a2[k] = km_f32x2{0.f, 0.f};
+                        else
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) acc0[k][v] = 0.f;
+                    }
+                }
+                const float* cc = cen + ((((r << 2) + part) << 3) + l) * KMAX;
+                if constexpr (VEC == 2 && KMAX % 4 == 0) {  // two pixels per instruction
+                    const km_f32x2 xp = {xs[S][u][0], xs[S][u][1]};
+#pragma unroll
+                    for (int k4 = 0; k4 < KMAX; k4 += 4) {
+                        const km_f32x4 c4 = *reinterpret_cast<const km_f32x4*>(cc + k4);
+                        const km_f32x2 c01 = {c4.x, c4.y}, c23 = {c4.z, c4.w};
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const km_f32x2 cp = kk < 2 ? c01 : c23;
+                            const km_f32x2 d = (kk & 1) ? km_sub_bcast<1>(xp, cp) : km_sub_bcast<0>(xp, cp);
+                            a2[k4 + kk] = km_add(a2[k4 + kk], km_sq(d));
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            const float diff = xs[S][u][v] - cc[k];
+                            acc0[k][v] = acc0[k][v] + diff * diff;
+                        }
+                }
+                if (r == rows - 1) {  // end of the run of `part`: p[part] joins the lane total, the lane total the result
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) {
+                        if constexpr (PK) {
+                            l2[k] = part == 0 ? a2[k] : km_add(l2[k], a2[k]);
+                            if (part == 3) f2[k] = km_add(f2[k], l2[k]);
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) {
+                                lt[k][v] = part == 0 ? acc0[k][v] : lt[k][v] + acc0[k][v];
+                                if (part == 3) fin[k][v] = fin[k][v] + lt[k][v];
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        const std::integral_constant<int, 0> set0;
+        const std::integral_constant<int, 1> set1;
+        request(set0, 0, 0);
+        for (int l = 0; l < 8; ++l)
+            for (int g = 0; g < ng; g += 2) { group(set0, l, g); group(set1, l, g + 1); }
+        if constexpr (PK) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) { fin[k][0] = f2[k].x; fin[k][VEC - 1] = f2[k].y; }
+        }
+    }
+    for (int c = nvec << 3; c < C && !fast; ++c) accumulate(c, fin);  // scalar tail first
+    for (int l = 0; l < 8 && !fast; ++l) {
         for (int part = 0; part < 4; ++part) {
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
