@@ -261,6 +261,35 @@ __global__ __launch_bounds__(256) void make_image_kernel(uint8_t* __restrict__ o
     }
 }
 
+// RGB fast path: four consecutive pixels per lane -- three float4 loads (one per channel plane), twelve bytes as three
+// 4-byte stores (the general kernel writes single bytes at stride 3: 0.3 TB/s).  Same per-element arithmetic.
+__global__ __launch_bounds__(256) void make_image_rgb4_kernel(uint32_t* __restrict__ out, const float* __restrict__ x, int HW,
+                                                              int64_t quads) {
+#pragma clang fp contract(off)
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;  // pixel quad: pixels 4q .. 4q+3 of the flattened [B][HW]
+    if (q >= quads) return;
+    const int64_t i = 4 * q, b = i / HW, p = i - b * HW;
+    float4 ch[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ch[c] = *reinterpret_cast<const float4*>(x + (b * 3 + c) * HW + p);
+    uint8_t by[12];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float in[4] = {ch[c].x, ch[c].y, ch[c].z, ch[c].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = fminf(fmaxf(in[e], -1.f), 1.f);
+            v = v + 1.f;
+            v = v / 2.f;
+            v = v * 255.f;
+            by[e * 3 + c] = (uint8_t)v;
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+        out[3 * q + w] = (uint32_t)by[4 * w] | ((uint32_t)by[4 * w + 1] << 8) | ((uint32_t)by[4 * w + 2] << 16) | ((uint32_t)by[4 * w + 3] << 24);
+}
+
 template <int KMAX, int VEC, bool CASCADE>
 int launch_kmeans(int64_t* labels, const float* x, const float* centres, int batch, int C, int HW, int K, hipStream_t st) {
     const int groups = sis_cdiv(HW, 256 * VEC);
@@ -308,8 +337,13 @@ extern "C" int sis_make_image_u8(uint8_t* out, const float* x, int batch, int ch
     const int64_t total = (int64_t)batch * hw;
     if (total <= 0) return 0;
     SIS_REQUIRE(out && x, "sis_make_image_u8: null pointer");
-    hipLaunchKernelGGL(make_image_kernel, dim3(sis_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, out, x, channels, hw,
-                       total);
+    if (channels == 3 && hw % 4 == 0 && ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)out) & 3) == 0)) {
+        hipLaunchKernelGGL(make_image_rgb4_kernel, dim3(sis_cdiv(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, (uint32_t*)out, x, hw,
+                           total / 4);
+    } else {
+        hipLaunchKernelGGL(make_image_kernel, dim3(sis_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, out, x, channels, hw,
+                           total);
+    }
     SIS_CHECK_LAUNCH("make_image_kernel");
     return 0;
 }
