@@ -387,7 +387,7 @@ extern "C" int sis_modconv2d_up(float* t, const float* x, const float* wpk, cons
         const int np = pass == 0 ? npos : 128;
         p.npos_tiles = 0; p.ncls = 0; p.nb_max = 0;
         mc_add_class(p, np, 1, batch, 0, h, 0, w, 32, 8);          // interior positions
-        mc_add_class(p, np, 1, batch, h, h + 1, 0, w, np, 8);      // last row  (T[2H, 0..2W-1])
+        mc_add_class(p, np, 1, batch, h, h + 1, 0, w, np, h >= 16 ? 4 : 8);  // last row (T[2H, 0..2W-1]); 16 x 16: 8 style rows here made the grid's LDS 86 KB, one workgroup per CU
         // last col (T[0..2H-1, 2W]): one position per row, each staged as a padded 8-float row, and the corner: capped at
         // 64 rows / 4 samples per tile.  The grid's LDS size follows its LARGEST class: uncapped, the last column's staging
         // area (2 x 65 x 8 floats per channel) and the corner's 8 style rows made it 120 KB -- one workgroup per CU for
