@@ -243,8 +243,9 @@ int sis_make_image_u8(uint8_t* out, const float* x, int batch, int channels, int
 int sis_conv3x3_eligible(int batch, int cin, int cout, int h, int w); /* 1 if sis_conv3x3 takes this shape */
 /* Weight gradient of the same convolution in the Winograd domain (csrc/conv_wgrad_wino.hip):
  *   dw [Cout][Cin][3][3] = d/dw of <gy, conv(x, w)>,  x [B,Cin,H,W], gy [B,Cout,H,W].
- * Needs even H and W, (B*H*W/4) % 8 == 0, Cin % 64 == 0, Cout % 64 == 0 and a workspace of >= 64 * Cin * Cout bytes (split-K
- * slabs, added in slice order: deterministic).  sis_conv3x3_wgrad_eligible returns 1 when the call would be taken. */
+ * Needs even H and W, (B*H*W/4) % 8 == 0, Cin % 64 == 0, Cout % 64 == 0, tensors below 2^29 elements (32-bit byte offsets of
+ * the masked buffer loads), fewer than 2^24 2x2 tiles and a workspace of >= 64 * Cin * Cout bytes (split-K slabs, added in
+ * slice order: deterministic).  sis_conv3x3_wgrad_eligible returns 1 when the call would be taken. */
 int sis_conv3x3_wgrad_eligible(int batch, int cin, int cout, int h, int w, int64_t workspace_bytes);
 int sis_conv3x3_wgrad(float* dw, const float* x, const float* gy, int batch, int cin, int cout, int h, int w,
                       void* workspace, int64_t workspace_bytes, void* stream);
