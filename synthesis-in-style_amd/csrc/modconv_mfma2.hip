@@ -20,6 +20,7 @@
 // Split-K (ksplit > 1): blockIdx.y owns a slice of input channels and writes raw partial sums to
 // slab[slice]; modconv_splitk_finish adds the slices in fixed order (bitwise reproducible, no
 // atomics) and applies the epilogue.  Used when position-tiles x oc-blocks < ~2 per CU (4^2..16^2).
+#include <type_traits>
 #include "modconv_common.h"
 
 namespace {
@@ -266,6 +267,13 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
 #ifdef SIS_V2_TRACE
     int tc_ = 0;
 #endif
+    // Transposed kernel: the four output phases of a position are (2h, 2w), (2h, 2w+1), (2h+1, 2w), (2h+1, 2w+1).  The edge tile
+    // classes (positions h = H or w = W) have no second row / column: their phases' multiplies (3 of 9 per channel pair for the last
+    // row or column, 5 of 9 for the corner) are skipped -- a compile-time choice per copy of the chunk loop, so interior tiles run
+    // the loop they always ran.  (An edge tile is a whole pass of a wave's MFMA chain behind the last full round of workgroups:
+    // 18 % of the 16 x 16 layer's time.)
+    auto chunk_loop = [&](auto col1c, auto row1c) {
+    constexpr bool COL1 = decltype(col1c)::value, ROW1 = decltype(row1c)::value;
     for (int ci0 = k_lo; ci0 < k_hi; ci0 += CC, buf ^= 1) {
         V2_TRACE(0);
         if (ci0 + CC < k_hi) stage(ci0 + CC, buf ^ 1);
@@ -312,11 +320,15 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
                     acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[6], x_u, acc[m][0], 0, 0, 0);
                     acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], x_l, acc[m][0], 0, 0, 0);
                     acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8], x_ul, acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], x_c, acc[m][1], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[7], x_u, acc[m][1], 0, 0, 0);
-                    acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], x_c, acc[m][2], 0, 0, 0);
-                    acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[5], x_l, acc[m][2], 0, 0, 0);
-                    acc[m][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4], x_c, acc[m][3], 0, 0, 0);
+                    if constexpr (COL1) {
+                        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], x_c, acc[m][1], 0, 0, 0);
+                        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[7], x_u, acc[m][1], 0, 0, 0);
+                    }
+                    if constexpr (ROW1) {
+                        acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], x_c, acc[m][2], 0, 0, 0);
+                        acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[5], x_l, acc[m][2], 0, 0, 0);
+                    }
+                    if constexpr (COL1 && ROW1) acc[m][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4], x_c, acc[m][3], 0, 0, 0);
                 }
             }
         }
@@ -325,6 +337,14 @@ __global__ __launch_bounds__(C::THREADS, C::OCC) void modconv_v2_kernel(const Co
 #ifdef SIS_V2_TRACE
         ++tc_;
 #endif
+    }
+    };
+    {
+        const bool col1 = MODE == 0 || tc.w1 <= p.W, row1 = MODE == 0 || tc.h1 <= p.H;  // (MODE 1: does the class have 2w+1 / 2h+1 outputs)
+        if (MODE == 0 || (col1 && row1)) chunk_loop(std::true_type(), std::true_type());
+        else if (row1) chunk_loop(std::false_type(), std::true_type());
+        else if (col1) chunk_loop(std::true_type(), std::false_type());
+        else chunk_loop(std::false_type(), std::false_type());
     }
 
     // ---- epilogue (ksplit > 1: raw partial sums to this slice's slab)
