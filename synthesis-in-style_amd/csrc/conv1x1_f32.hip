@@ -17,6 +17,9 @@
 
 namespace {
 
+#ifndef PW_OCC
+#define PW_OCC 4  // waves per SIMD the register allocation aims at (2 workgroups per CU).  6 (three per CU, 80 VGPRs) measured 527 against 541 images/s on EMANet.
+#endif
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 template <int MT_, int NPIX_, int KC_>
@@ -31,7 +34,7 @@ struct PwCfg {
     static constexpr int X_PIECES = X_FLOATS * 4 / 1024;   // 1 KiB DMA pieces per chunk
     static constexpr int A_PIECES = A_FLOATS * 4 / 1024;
     static constexpr int A_VEC = (A_FLOATS / 4 + 511) / 512;  // float4 loads per thread per chunk (register-staged weights)
-    static constexpr int OCC = 2 * STAGE * 4 <= 52 * 1024 ? 4 : 2;  // waves per SIMD the LDS footprint allows (3 or 1 workgroups per CU)
+    static constexpr int OCC = 2 * STAGE * 4 <= 52 * 1024 ? PW_OCC : 2;  // waves per SIMD the LDS footprint allows (3 or 1 workgroups per CU)
 };
 
 struct PwParams {
@@ -47,7 +50,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <typename C, bool A_KMAJOR>
+template <typename C, bool A_KMAJOR, bool HAS_BIAS>
 __global__ __launch_bounds__(512, C::OCC) void conv1x1_f32_kernel(PwParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -158,12 +161,10 @@ __global__ __launch_bounds__(512, C::OCC) void conv1x1_f32_kernel(PwParams p) {
     // ---- epilogue.  The bias of this wave's rows is fetched once (not per element), a row's address is the tile's base plus a
     // multiple of the plane stride, and full tiles (the usual case) carry no per-row bounds checks.
     const int mrow0 = m0 + wm * (C::MB * 32) + 4 * h;  // row (mb, i) = mrow0 + mb * 32 + (i & 3) + 8 * (i >> 2)
-    float bv[C::MB][16];
-#pragma unroll
-    for (int mb = 0; mb < C::MB; ++mb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bv[mb][i] = 0.f;
-    if (p.bias) {
+    // (HAS_BIAS is a template parameter: the 16 * MB bias registers of the biased instance would cost the unbiased one -- nearly
+    // every layer of the network -- a workgroup per CU: 112 instead of 84 VGPRs)
+    float bv[HAS_BIAS ? C::MB : 1][16];
+    if constexpr (HAS_BIAS) {
 #pragma unroll
         for (int mb = 0; mb < C::MB; ++mb)
 #pragma unroll
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(512, C::OCC) void conv1x1_f32_kernel(PwParams p) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int ro = mb * 32 + (i & 3) + 8 * (i >> 2);
-                    if (!decltype(checked)::value || mrow0 + ro < p.M) ybase[ro * p.HW + nb * 32] = acc[mb][nb][i] + bv[mb][i];
+                    if (!decltype(checked)::value || mrow0 + ro < p.M) ybase[ro * p.HW + nb * 32] = HAS_BIAS ? acc[mb][nb][i] + bv[mb][i] : acc[mb][nb][i];
                 }
         }
     };
@@ -189,20 +190,21 @@ __global__ __launch_bounds__(512, C::OCC) void conv1x1_f32_kernel(PwParams p) {
 
 template <typename C>
 int launch_pw(const PwParams& p, int a_kmajor, hipStream_t st, const char* name) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_f32_kernel<C, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_f32_kernel<C, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    typedef void (*kern_t)(PwParams);
+    static const kern_t table[2][2] = {{conv1x1_f32_kernel<C, false, false>, conv1x1_f32_kernel<C, false, true>},
+                                       {conv1x1_f32_kernel<C, true, false>, conv1x1_f32_kernel<C, true, true>}};
+    static bool attr_set[2][2] = {};
+    const int km = a_kmajor ? 1 : 0, hb = p.bias ? 1 : 0;
+    const kern_t kern = table[km][hb];
+    if (!attr_set[km][hb]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return sis_fail("%s: cannot raise the LDS limit: %s", name, hipGetErrorString(e));
-        attr_set = true;
+        attr_set[km][hb] = true;
     }
     dim3 grid(8 * sis_cdiv(p.M, C::MT) * sis_cdiv((int64_t)p.N * p.px_tiles, 8));
-    SIS_OCC_REPORT((conv1x1_f32_kernel<C, true>), 512, C::LDS_BYTES);
-    if (a_kmajor) hipLaunchKernelGGL((conv1x1_f32_kernel<C, true>), grid, dim3(512), C::LDS_BYTES, st, p);
-    else hipLaunchKernelGGL((conv1x1_f32_kernel<C, false>), grid, dim3(512), C::LDS_BYTES, st, p);
+    if (a_kmajor) { SIS_OCC_REPORT((conv1x1_f32_kernel<C, true, false>), 512, C::LDS_BYTES); }
+    else { SIS_OCC_REPORT((conv1x1_f32_kernel<C, false, false>), 512, C::LDS_BYTES); }
+    hipLaunchKernelGGL(kern, grid, dim3(512), C::LDS_BYTES, st, p);
     SIS_CHECK_LAUNCH(name);
     sis_kernel_name = name;
     return 0;
