@@ -489,6 +489,23 @@ def bench_synthesis(args, world, rank, device, distributed):
     return result
 
 
+def launch_ranks(n):
+    """One child process group of ``n`` ranks through ``python -m torch.distributed.run`` (one rank per GPU, rendezvous on
+    127.0.0.1 at a free port), this script and its arguments unchanged.  The parent never initialises the GPU; the children's
+    stdout / stderr pass straight through (rank 0 prints the one JSON line).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="all", choices=["all", "synthesis", "emanet", "transunet", "dataset", "gan"],
@@ -504,7 +521,15 @@ def main():
                     help="training workloads: MIOpen solver search for the library convolutions (minutes at start-up)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher: start the N ranks ourselves (the reference spawns its own workers too,
+        # train.py:185-187), BEFORE anything in this process touches the GPU, relay rank 0's JSON line and exit with the
+        # launcher's code.  Under torch.distributed.run (WORLD_SIZE set) this branch is skipped.
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1

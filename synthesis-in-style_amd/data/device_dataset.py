@@ -64,5 +64,8 @@ class SynthesisSegmentationLoader:
                                                          {self.label_layer: self.catalogs[self.label_layer]})
                 if ready is not None:
                     torch.cuda.current_stream(device).wait_event(ready)
-                yield encode_batch(pixels, labels[self.label_layer], self.class_of_cluster, self.image_size)
+                batch = encode_batch(pixels, labels[self.label_layer], self.class_of_cluster, self.image_size)
+            # yielded OUTSIDE the no_grad block: a generator suspended inside it would leave grad mode off in the consumer
+            # (the updater keeps this iterator alive across its forward / backward)
+            yield batch
             i += 1

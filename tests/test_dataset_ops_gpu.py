@@ -207,3 +207,41 @@ def test_tensor_hand_off_equals_the_png_round_trip(device, tmp_path):
         want_cls = torch.from_numpy((right[..., None, :] == colours[None, None]).all(-1).argmax(-1))
         assert torch.equal(batch["images"][i].cpu(), want_img)
         assert torch.equal(batch["segmented"][i, 0].cpu(), want_cls)
+
+
+def test_loader_leaves_grad_mode_on_and_feeds_an_updater(device):
+    """The loader's generator body synthesises under ``no_grad`` but must hand the batch over OUTSIDE it: the updater keeps the
+    iterator suspended at its ``yield`` across forward / backward (updater/segmentation_updater.py:47-73 in the reference
+    holds its iterators the same way), and a generator suspended inside ``no_grad`` leaves grad mode off in the consumer."""
+    import yaml
+    from data.device_dataset import SynthesisSegmentationLoader
+    from networks.stylegan2.model import Generator
+    from segmentation.gan_local_edit.factor_catalog import FactorCatalog
+    from training_builder.ema_net_train_builder import EMANetTrainBuilder
+    torch.manual_seed(4)
+    g = Generator(64, 64, 2, channel_multiplier=1).to(device).eval()
+    layer = 7
+    with torch.no_grad():
+        _, acts = g([torch.randn(1, 64, device=device)], return_intermediate_activations=True)
+    rng = np.random.RandomState(9)
+    catalogs = {layer: FactorCatalog(cluster_centers=rng.randn(6, acts[layer].shape[1]).astype(np.float32))}
+    loader = SynthesisSegmentationLoader(g, catalogs, layer, batch_size=2, class_of_cluster=torch.tensor([0, 1, 2, 1, 0, 2]),
+                                         image_size=64, seed=11)
+    it = iter(loader)
+    next(it)
+    assert torch.is_grad_enabled(), "the suspended loader left grad mode off"
+    next(it)
+    assert torch.is_grad_enabled()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "synthesis-in-style_amd", "configs", "segmenter", "ema_net_resnet50_256.yaml")))
+    cfg.update(fine_tune=None, batch_size=2, image_size=64)
+    torch.manual_seed(0)
+    builder = EMANetTrainBuilder(cfg, loader, None, rank=0, world_size=1)
+    updater = builder.get_updater()
+    before = [p.detach().clone() for p in builder.get_network().parameters()][:4]
+    for _ in range(4):  # two eager iterations, the graph capture, one replay
+        updater.update()
+    torch.cuda.synchronize()
+    after = list(builder.get_network().parameters())[:4]
+    assert all(torch.isfinite(a).all() for a in after)
+    assert any(not torch.equal(a, b) for a, b in zip(after, before)), "the step fed by the loader did not train"

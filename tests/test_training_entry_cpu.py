@@ -9,6 +9,7 @@ import ast
 import importlib.util
 import math
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -190,3 +191,19 @@ def test_generator_factories_under_the_reference_names(tmp_path):
     plain = tmp_path / "plain.pt"  # load_weights without a key takes the dict as the state_dict (networks/__init__.py:26-28)
     torch.save(g.state_dict(), plain)
     networks.load_weights(g2, plain, key="g_ema")
+
+
+def test_bench_gpus_flag_launches_ranks_or_rejects_a_mismatch():
+    """`python bench.py --gpus N` must start N ranks itself (no launcher in the driver's command) and fail loudly when it
+    cannot: here, without a HIP device, every rank raises, and the launcher's exit code comes back non-zero; a WORLD_SIZE
+    that disagrees with --gpus is refused before anything runs."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       env=dict(env, WORLD_SIZE="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--workload", "synthesis"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "local_rank: 1" in r.stderr  # two ranks were started, both failed loudly
