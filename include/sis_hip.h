@@ -399,6 +399,47 @@ int sis_conv1x1_f32_supported(int cin, int cout, int hw);
 int sis_conv1x1_f32(float* y, const float* x, const float* weight, const float* bias, int batch, int cin, int cout, int hw,
                     int data_gradient, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * bf16 GEMM with the Linear layers' element-wise tail fused into the epilogue (csrc/gemm_bf16.hip): the ViT encoder of
+ * TransUNet under bf16 autocast -- Attention.query/key/value/out (networks/trans_u_net/vit_seg_modeling.py:60-67,76-96),
+ * Mlp fc1 / GELU / dropout / fc2 / dropout (:104-122), the Block residual adds (:181-189); replaces F.linear (a library
+ * GEMM) + separate bias / GELU / dropout / add / cast kernels, forward and backward.
+ *   C[m][n] = epilogue( sum_k opA[m][k] * opB[k][n] ),  bf16 operands, fp32 accumulation, row-major C with leading dim ldc
+ *   layout 0 (NT): A [m][k] (lda), B [n][k] (ldb)        forward:          y  = x W^T
+ *   layout 1 (NN): A [m][k] (lda), B [k][n] (ldb)        data gradient:    dx = g W
+ *   layout 2 (TN): A [k][m] (lda), B [k][n] (ldb)        weight gradient:  dW = g^T x   (k = tokens; any k >= 1)
+ * epilogue:
+ *   SIS_GEMM_EPI_NONE             C bf16 = acc
+ *   SIS_GEMM_EPI_BIAS             C bf16 = acc + bias[n]
+ *   SIS_GEMM_EPI_BIAS_GELU_DROP   C2 bf16 = h = acc + bias (the pre-activation);  C bf16 = dropout(gelu(h))     (erf GELU)
+ *   SIS_GEMM_EPI_BIAS_DROP_RESID  C fp32 = resid[m][n] + dropout(acc + bias)      (resid fp32, leading dim ldc)
+ *   SIS_GEMM_EPI_GELU_BWD         C bf16 = acc * dropout_factor * gelu'(pre[m][n])  (pre bf16, leading dim ldc)
+ *   SIS_GEMM_EPI_F32              C fp32 = acc; with splits > 1 the K range is cut into `splits` slices whose partial results
+ *                                 go through `workspace` and are added in slice order (deterministic)
+ * dropout: element (m, n) of site `site` is dropped iff hash(seed word, site, m * n_cols + n) < drop_p * 2^32, else scaled by
+ * 1 / (1 - drop_p); the forward and the backward launch of a site evaluate the same function (no stored mask).  `seed`
+ * points to a 64-bit device word (sis_dropout_advance steps it once per iteration).  drop_p = 0: no dropout.
+ * tile: 0 = 128x128 (256 threads), 1 = 256x128, 2 = 128x256, 3 = 256x256.  NT / NN need k % 64 == 0; n, ldc % 4 == 0;
+ * lda, ldb % 8 == 0; 16-byte aligned pointers.  m (and k for TN) need not be tile multiples. */
+#define SIS_GEMM_EPI_NONE 0
+#define SIS_GEMM_EPI_BIAS 1
+#define SIS_GEMM_EPI_BIAS_GELU_DROP 2
+#define SIS_GEMM_EPI_BIAS_DROP_RESID 3
+#define SIS_GEMM_EPI_GELU_BWD 4
+#define SIS_GEMM_EPI_F32 5
+int64_t sis_gemm_bf16_workspace_bytes(int m, int n, int splits);
+int sis_gemm_bf16(void* c, void* c2, const void* a, const void* b, int layout, int epilogue, int m, int n, int k, int lda,
+                  int ldb, int ldc, const float* bias, const float* resid, const void* pre, const void* seed, int site,
+                  float drop_p, int splits, void* workspace, int64_t workspace_bytes, int tile, void* stream);
+
+/* Dropout stream of the fused ViT-encoder kernels (csrc/vit_elementwise.hip; nn.Dropout of vit_seg_modeling.py:70-71,108,138).
+ *   sis_dropout_advance   steps the 64-bit device seed word once per training iteration (graph-capturable).
+ *   sis_dropout_bwd_cast  out bf16[numel] = grad fp32[numel] * dropout_factor(seed, site, element index): the gradient of
+ *                         `resid + dropout(y)` w.r.t. y for a site whose forward ran as SIS_GEMM_EPI_BIAS_DROP_RESID with the
+ *                         same site id and a dense [m][n] output (element index = m * n_cols + n). */
+int sis_dropout_advance(void* seed, void* stream);
+int sis_dropout_bwd_cast(void* out, const float* grad, int64_t numel, const void* seed, int site, float drop_p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

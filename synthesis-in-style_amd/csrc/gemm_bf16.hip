@@ -1,0 +1,435 @@
+// bf16 GEMM of the TransUNet ViT encoder on the CDNA4 matrix cores, with the element-wise tail of every Linear layer
+// fused into the epilogue (BASELINE.json configs[4]: 12 blocks x 4 Linear layers at 8 192 tokens, forward, data
+// gradient, weight gradient).
+//
+// Reference call sites (networks/trans_u_net/vit_seg_modeling.py): Attention.query/key/value/out :60-67,76-96,
+// Mlp.fc1 / act_fn / dropout / fc2 / dropout :104-122, Block residual adds :181-189.  torch runs each of them as a
+// library GEMM followed by separate bias / GELU / dropout / add / cast kernels; here one launch does
+//     C = epilogue(op(A) op(B)),  fp32 accumulation on v_mfma_f32_16x16x32_bf16
+// for the three operand layouts a Linear layer's three GEMMs have:
+//     NT  forward            y[M,N]   = x[M,K]  W[N,K]^T       both operands K-contiguous ("row operands")
+//     NN  data gradient      dx[M,N]  = g[M,K]  W[K,N]         W is K-major
+//     TN  weight gradient    dW[M,N]  = g[K,M]^T x[K,N]        both K-major (K = tokens), fp32 output, split over K
+//
+// Tile: BM x BN x 64, one wave per 64 x 64 sub-tile (4 x 4 MFMA blocks, 64 accumulator registers), 2 LDS stages filled
+// by LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction, range-checked by the buffer descriptor: rows past the
+// end of a tensor read as zeros, so M and the TN contraction length need not be tile multiples).  One barrier per
+// 64-deep K step: wait for the stage's DMA, barrier, issue the next stage's DMA, then fragments + 32 MFMAs.
+// LDS images (the DMA writes linearly, so the swizzle is applied to the per-lane SOURCE address and again on the read):
+//   row operand [rows][64 k] = 128-B rows, 16-B chunk c of row r at position c ^ (r & 7): every ds_read_b128 lane group
+//     of a fragment (16 rows x 4 chunks) falls on 16 different 16-B slots of the 256-B bank row;
+//   K-major operand [64 k][cols] = 2*cols-B rows, chunk c of k-row r at c ^ f(r), f(r) = ((r & 3) << 2) | ((r >> 2) & 3):
+//     fragments come out of ds_read_b64_tr_b16 (hardware transpose: 4 k-rows x 16 columns per 16 lanes), whose 32-lane
+//     half reads 8 rows x 32 B spread over all 64 banks.
+// MFMA orientation: D = Bfrag x Afrag, i.e. the accumulator's lane index is the output ROW m and its 4 registers are 4
+// CONSECUTIVE columns n: the epilogue loads / stores 8 or 16 contiguous bytes per lane and block (bias, residual,
+// pre-activation), no LDS round trip.
+// Workgroup order: id % 8 = XCD group (round-robin dispatch); the column tiles that share an A row tile take consecutive
+// slots of one group, so each A tile is fetched into one XCD's L2 once; the weights (<= 4.7 MB) stay L2 / MALL resident.
+#include <type_traits>
+#include "vit_common.h"
+
+namespace {
+
+typedef unsigned short u16;
+typedef sis_bf16x8 bf16x8;
+typedef sis_bf16x4 bf16x4;
+typedef sis_f32x4 f32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+
+enum { LAYOUT_NT = 0, LAYOUT_NN = 1, LAYOUT_TN = 2 };
+
+struct GemmParams {
+    const void* A; const void* B;
+    int lda, ldb;                 // elements
+    unsigned a_bytes, b_bytes;    // extent of each operand from its base pointer (range check of the DMA)
+    int M, N, K;
+    void* C; void* C2; int ldc;
+    const float* bias; const float* resid; const u16* pre;
+    const unsigned long long* seed; unsigned site, drop_thr; float drop_scale;
+    int m_tiles, n_tiles, splits, ksteps_per_split;
+    long long slab_stride;        // elements between the fp32 partial slabs of a split-K run
+};
+
+template <int BM_, int BN_, bool AKM_, bool BKM_>
+struct GemmCfg {
+    static constexpr int BM = BM_, BN = BN_, BK = 64;
+    static constexpr bool AKM = AKM_, BKM = BKM_;       // operand is K-major in memory
+    static constexpr int WM = BM / 64, WN = BN / 64, WAVES = WM * WN, THREADS = WAVES * 64;
+    static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    static constexpr int A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024;
+    static constexpr int PA = (A_PIECES + WAVES - 1) / WAVES, PB = (B_PIECES + WAVES - 1) / WAVES;  // per wave
+    static constexpr int LDS = 2 * STAGE;
+    static_assert(!AKM || BM >= 128, "K-major tiles need >= 16 chunks per row");
+    static_assert(!BKM || BN >= 128, "K-major tiles need >= 16 chunks per row");
+    static_assert(A_PIECES % WAVES == 0 && B_PIECES % WAVES == 0, "pieces must divide over the waves");
+};
+
+__device__ __forceinline__ int kmaj_f(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }
+
+template <typename C, int EPI>
+__global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass has no buffer-resource type: it only needs the launch stub)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    const int wm = wave % C::WM, wn = wave / C::WM;
+
+    // ---- which tile (and K slice) this workgroup computes
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int mt, nt, split = 0;
+    if (p.splits == 1) {
+        mt = (slot / p.n_tiles) * 8 + xcd;
+        nt = slot % p.n_tiles;
+        if (mt >= p.m_tiles) return;
+    } else {
+        int tile;
+        if (p.splits >= 8) {
+            const int per = p.splits >> 3;
+            split = xcd + 8 * (slot % per);
+            tile = slot / per;
+        } else {
+            const int sub = 8 / p.splits;
+            split = xcd % p.splits;
+            tile = slot * sub + xcd / p.splits;
+        }
+        if (tile >= p.m_tiles * p.n_tiles) return;
+        mt = tile / p.n_tiles;
+        nt = tile % p.n_tiles;
+    }
+    const int m0 = mt * C::BM, n0 = nt * C::BN;
+    const int ks_total = (p.K + 63) >> 6;
+    const int ks_begin = split * p.ksteps_per_split;
+    const int T = min(p.ksteps_per_split, ks_total - ks_begin);   // K steps of this workgroup (>= 1 by construction)
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+
+    // ---- DMA source offsets of this lane (bytes from the operand base, K step 0), fixed over the loop
+    int a_src[C::PA], b_src[C::PB];
+#pragma unroll
+    for (int i = 0; i < C::PA; ++i) {
+        const int q = wave + i * C::WAVES;
+        if constexpr (!C::AKM) {
+            const int row = m0 + 8 * q + (lane >> 3);
+            const int ch = (lane & 7) ^ ((lane >> 3) & 7);
+            a_src[i] = (row * p.lda + ch * 8) * 2;
+        } else {
+            constexpr int RB = 2 * C::BM;
+            const int lin = 1024 * q + 16 * lane;
+            const int krow = lin / RB, pos = (lin % RB) >> 4;
+            a_src[i] = (krow * p.lda + m0 + ((pos ^ kmaj_f(krow)) << 3)) * 2;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < C::PB; ++i) {
+        const int q = wave + i * C::WAVES;
+        if constexpr (!C::BKM) {
+            const int row = n0 + 8 * q + (lane >> 3);
+            const int ch = (lane & 7) ^ ((lane >> 3) & 7);
+            b_src[i] = (row * p.ldb + ch * 8) * 2;
+        } else {
+            constexpr int RB = 2 * C::BN;
+            const int lin = 1024 * q + 16 * lane;
+            const int krow = lin / RB, pos = (lin % RB) >> 4;
+            b_src[i] = (krow * p.ldb + n0 + ((pos ^ kmaj_f(krow)) << 3)) * 2;
+        }
+    }
+    const int a_step = C::AKM ? 64 * p.lda * 2 : 128;   // bytes per K step
+    const int b_step = C::BKM ? 64 * p.ldb * 2 : 128;
+
+    auto issue = [&](int t, int stage) {
+        const int ks = ks_begin + t;
+        unsigned char* dst = lds + stage * C::STAGE;
+        const int sa = ks * a_step, sb = ks * b_step;
+#pragma unroll
+        for (int i = 0; i < C::PA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dst + (wave + i * C::WAVES) * 1024), 16, a_src[i], sa, 0, 0);
+#pragma unroll
+        for (int i = 0; i < C::PB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(dst + C::A_BYTES + (wave + i * C::WAVES) * 1024), 16, b_src[i], sb, 0, 0);
+    };
+
+    // ---- fragment read offsets (bytes inside a stage)
+    // row operand: block b (16 rows), k-step ks: (base + 16 b + i16) * 128 + (((4 ks + g) ^ (i16 & 7)) << 4)
+    // K-major operand: block b (16 columns), k-step ks, half t: (32 ks + 8 g + 4 t + q) * RB + (((2 cb + (p >> 1)) ^ f) << 4) + 8 (p & 1)
+    int a_off[C::AKM ? 8 : 2], b_off[C::BKM ? 8 : 2];
+    if constexpr (!C::AKM) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a_off[ks] = (wm * 64 + i16) * 128 + (((4 * ks + g) ^ (i16 & 7)) << 4);
+    } else {
+        constexpr int RB = 2 * C::BM;
+        const int q = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int krow = 8 * g + 4 * t + q;   // (+ 32 ks: f unchanged, RB * 32 ks added as an immediate)
+                const int ch = 2 * (wm * 4 + b) + (pp >> 1);
+                a_off[b * 2 + t] = krow * RB + ((ch ^ kmaj_f(krow)) << 4) + 8 * (pp & 1);
+            }
+    }
+    if constexpr (!C::BKM) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) b_off[ks] = C::A_BYTES + (wn * 64 + i16) * 128 + (((4 * ks + g) ^ (i16 & 7)) << 4);
+    } else {
+        constexpr int RB = 2 * C::BN;
+        const int q = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int krow = 8 * g + 4 * t + q;
+                const int ch = 2 * (wn * 4 + b) + (pp >> 1);
+                b_off[b * 2 + t] = C::A_BYTES + krow * RB + ((ch ^ kmaj_f(krow)) << 4) + 8 * (pp & 1);
+            }
+    }
+
+    f32x4 acc[4][4];   // [n block][m block]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto frag = [&](const unsigned char* st, auto kmajor, const int* off, int rb_bytes, int b, int ks) -> bf16x8 {
+        if constexpr (!decltype(kmajor)::value) {
+            return *reinterpret_cast<const bf16x8*>(st + off[ks] + b * 2048);
+        } else {
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (__attribute__((address_space(3))) bf16x4*)(st + off[b * 2] + ks * 32 * rb_bytes));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (__attribute__((address_space(3))) bf16x4*)(st + off[b * 2 + 1] + ks * 32 * rb_bytes));
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
+
+    issue(0, 0);
+    for (int t = 0; t < T; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage t have landed
+        __builtin_amdgcn_s_barrier();                       // ... everybody's; and everybody is done reading the other stage
+        if (t + 1 < T) issue(t + 1, (t + 1) & 1);
+        const unsigned char* st = lds + (t & 1) * C::STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) a[x] = frag(st, std::integral_constant<bool, C::AKM>(), a_off, 2 * C::BM, x, ks);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) b[x] = frag(st, std::integral_constant<bool, C::BKM>(), b_off, 2 * C::BN, x, ks);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[tn], a[tm], acc[tn][tm], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane = output row m (per m block), registers = 4 consecutive columns n.  Interior tiles (the usual
+    // case) run without bounds checks; per column block all loads (residual / pre-activation) are issued before the
+    // arithmetic and the stores.
+    SisDropKey key{0u, 0u};
+    constexpr bool HAS_BIAS = EPI == SIS_GEMM_EPI_BIAS || EPI == SIS_GEMM_EPI_BIAS_GELU_DROP || EPI == SIS_GEMM_EPI_BIAS_DROP_RESID;
+    constexpr bool HAS_DROP = EPI == SIS_GEMM_EPI_BIAS_GELU_DROP || EPI == SIS_GEMM_EPI_BIAS_DROP_RESID || EPI == SIS_GEMM_EPI_GELU_BWD;
+    if constexpr (HAS_DROP)
+        if (p.drop_thr) key = sis_drop_key(p.seed, p.site);
+    auto epilogue = [&](auto checked_t) {
+        constexpr bool CHECKED = decltype(checked_t)::value;
+        float4 bq[4];
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int n = n0 + wn * 64 + 16 * tn + 4 * g;
+            bq[tn] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (HAS_BIAS)
+                if (!CHECKED || n < p.N) bq[tn] = *reinterpret_cast<const float4*>(p.bias + n);
+        }
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int n = n0 + wn * 64 + 16 * tn + 4 * g;
+            const bool n_ok = !CHECKED || n < p.N;
+            float4 r[4];
+            uint2 h[4];
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+                const int m = m0 + wm * 64 + 16 * tm + i16;
+                const long long at = (long long)(CHECKED ? min(m, p.M - 1) : m) * p.ldc + (CHECKED ? min(n, p.N - 4) : n);
+                if constexpr (EPI == SIS_GEMM_EPI_BIAS_DROP_RESID) r[tm] = *reinterpret_cast<const float4*>(p.resid + at);
+                if constexpr (EPI == SIS_GEMM_EPI_GELU_BWD) h[tm] = *reinterpret_cast<const uint2*>(p.pre + at);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+                const int m = m0 + wm * 64 + 16 * tm + i16;
+                const bool ok = n_ok && (!CHECKED || m < p.M);
+                const long long at = (long long)m * p.ldc + n;
+                const unsigned idx = (unsigned)m * (unsigned)p.N + (unsigned)n;   // dropout stream position of v[0]
+                float v[4] = {acc[tn][tm][0] + bq[tn].x, acc[tn][tm][1] + bq[tn].y, acc[tn][tm][2] + bq[tn].z, acc[tn][tm][3] + bq[tn].w};
+                if constexpr (EPI == SIS_GEMM_EPI_NONE || EPI == SIS_GEMM_EPI_BIAS) {
+                    if (ok) *reinterpret_cast<uint2*>((u16*)p.C + at) = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
+                } else if constexpr (EPI == SIS_GEMM_EPI_BIAS_GELU_DROP) {
+                    // pre-activation (bf16, what the backward differentiates at) and dropout(gelu(pre))
+                    const uint2 hp = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
+                    float y[4] = {sis_gelu(sis_bf16_lo(hp.x)), sis_gelu(sis_bf16_hi(hp.x)), sis_gelu(sis_bf16_lo(hp.y)), sis_gelu(sis_bf16_hi(hp.y))};
+                    if (p.drop_thr) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] *= sis_drop_factor(key, idx + e, p.drop_thr, p.drop_scale);
+                    }
+                    if (ok) {
+                        *reinterpret_cast<uint2*>((u16*)p.C2 + at) = hp;
+                        *reinterpret_cast<uint2*>((u16*)p.C + at) = make_uint2(sis_pack_bf16x2(y[0], y[1]), sis_pack_bf16x2(y[2], y[3]));
+                    }
+                } else if constexpr (EPI == SIS_GEMM_EPI_BIAS_DROP_RESID) {
+                    if (p.drop_thr) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= sis_drop_factor(key, idx + e, p.drop_thr, p.drop_scale);
+                    }
+                    if (ok) *reinterpret_cast<float4*>((float*)p.C + at) = make_float4(r[tm].x + v[0], r[tm].y + v[1], r[tm].z + v[2], r[tm].w + v[3]);
+                } else if constexpr (EPI == SIS_GEMM_EPI_GELU_BWD) {
+                    // gradient w.r.t. the pre-activation: acc * dropout factor * gelu'(pre)
+                    const float d[4] = {sis_gelu_grad(sis_bf16_lo(h[tm].x)), sis_gelu_grad(sis_bf16_hi(h[tm].x)),
+                                        sis_gelu_grad(sis_bf16_lo(h[tm].y)), sis_gelu_grad(sis_bf16_hi(h[tm].y))};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] *= d[e];
+                        if (p.drop_thr) v[e] *= sis_drop_factor(key, idx + e, p.drop_thr, p.drop_scale);
+                    }
+                    if (ok) *reinterpret_cast<uint2*>((u16*)p.C + at) = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
+                } else {  // SIS_GEMM_EPI_F32: fp32 result or partial slab of a split-K run
+                    if (ok) *reinterpret_cast<float4*>((float*)p.C + (long long)split * p.slab_stride + at) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    };
+    if (m0 + C::BM <= p.M && n0 + C::BN <= p.N) epilogue(std::false_type());
+    else epilogue(std::true_type());
+#endif
+}
+
+// partial slabs of a split-K run -> result, added in slab order (deterministic)
+__global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(float* __restrict__ out, const float* __restrict__ slabs, long long quads,
+                                                               int splits, long long slab_stride) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= quads) return;
+    float4 s = *reinterpret_cast<const float4*>(slabs + 4 * i);
+    for (int k = 1; k < splits; ++k) {
+        const float4 q = *reinterpret_cast<const float4*>(slabs + k * slab_stride + 4 * i);
+        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+    }
+    *reinterpret_cast<float4*>(out + 4 * i) = s;
+}
+
+template <typename C, int EPI>
+int launch_gemm(const GemmParams& p, hipStream_t st, const char* name) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<C, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        if (e != hipSuccess) return sis_fail("%s: cannot raise the LDS limit: %s", name, hipGetErrorString(e));
+        attr_set = true;
+    }
+    int groups;
+    if (p.splits == 1) groups = p.n_tiles * sis_cdiv(p.m_tiles, 8);
+    else if (p.splits >= 8) groups = p.m_tiles * p.n_tiles * (p.splits / 8);
+    else groups = sis_cdiv((int64_t)p.m_tiles * p.n_tiles, 8 / p.splits);
+    SIS_OCC_REPORT((gemm_bf16_kernel<C, EPI>), C::THREADS, C::LDS);
+    hipLaunchKernelGGL((gemm_bf16_kernel<C, EPI>), dim3(8 * groups), dim3(C::THREADS), C::LDS, st, p);
+    SIS_CHECK_LAUNCH(name);
+    sis_kernel_name = name;
+    return 0;
+}
+
+// the epilogues each layout is built with: what the three GEMMs of a Linear layer need
+template <int BM, int BN>
+int dispatch(const GemmParams& p, int layout, int epi, hipStream_t st) {
+    if (layout == LAYOUT_NT) {
+        typedef GemmCfg<BM, BN, false, false> C;
+        switch (epi) {
+            case SIS_GEMM_EPI_NONE: return launch_gemm<C, SIS_GEMM_EPI_NONE>(p, st, "gemm_bf16_kernel<NT>");
+            case SIS_GEMM_EPI_BIAS: return launch_gemm<C, SIS_GEMM_EPI_BIAS>(p, st, "gemm_bf16_kernel<NT,bias>");
+            case SIS_GEMM_EPI_BIAS_GELU_DROP: return launch_gemm<C, SIS_GEMM_EPI_BIAS_GELU_DROP>(p, st, "gemm_bf16_kernel<NT,bias+gelu+dropout>");
+            case SIS_GEMM_EPI_BIAS_DROP_RESID: return launch_gemm<C, SIS_GEMM_EPI_BIAS_DROP_RESID>(p, st, "gemm_bf16_kernel<NT,bias+dropout+residual>");
+            case SIS_GEMM_EPI_F32: return launch_gemm<C, SIS_GEMM_EPI_F32>(p, st, "gemm_bf16_kernel<NT,f32>");
+        }
+    } else if (layout == LAYOUT_NN) {
+        typedef GemmCfg<BM, BN, false, true> C;
+        switch (epi) {
+            case SIS_GEMM_EPI_NONE: return launch_gemm<C, SIS_GEMM_EPI_NONE>(p, st, "gemm_bf16_kernel<NN>");
+            case SIS_GEMM_EPI_GELU_BWD: return launch_gemm<C, SIS_GEMM_EPI_GELU_BWD>(p, st, "gemm_bf16_kernel<NN,gelu'+dropout>");
+        }
+    } else {
+        typedef GemmCfg<BM, BN, true, true> C;
+        if (epi == SIS_GEMM_EPI_F32) return launch_gemm<C, SIS_GEMM_EPI_F32>(p, st, "gemm_bf16_kernel<TN,f32>");
+    }
+    return sis_fail("sis_gemm_bf16: epilogue %d is not built for layout %d", epi, layout);
+}
+
+}  // namespace
+
+extern "C" int64_t sis_gemm_bf16_workspace_bytes(int m, int n, int splits) {
+    return splits > 1 ? (int64_t)splits * m * n * 4 : 0;
+}
+
+extern "C" int sis_gemm_bf16(void* c, void* c2, const void* a, const void* b, int layout, int epilogue, int m, int n, int k,
+                             int lda, int ldb, int ldc, const float* bias, const float* resid, const void* pre,
+                             const void* seed, int site, float drop_p, int splits, void* workspace, int64_t workspace_bytes,
+                             int tile, void* stream) {
+    if (m <= 0 || n <= 0) return 0;
+    SIS_REQUIRE(c && a && b, "sis_gemm_bf16: null pointer");
+    SIS_REQUIRE(layout >= 0 && layout <= 2, "sis_gemm_bf16: layout %d (0 NT, 1 NN, 2 TN)", layout);
+    SIS_REQUIRE(k > 0 && n % 4 == 0 && ldc % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0,
+                "sis_gemm_bf16: n, ldc must be multiples of 4 and lda, ldb of 8 (n=%d ldc=%d lda=%d ldb=%d)", n, ldc, lda, ldb);
+    SIS_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0, "sis_gemm_bf16: operands must be 16-byte aligned");
+    if (layout != LAYOUT_TN) SIS_REQUIRE(k % 64 == 0, "sis_gemm_bf16: k = %d must be a multiple of 64 for the NT / NN layouts", k);
+    const bool has_bias = epilogue == SIS_GEMM_EPI_BIAS || epilogue == SIS_GEMM_EPI_BIAS_GELU_DROP || epilogue == SIS_GEMM_EPI_BIAS_DROP_RESID;
+    SIS_REQUIRE(!has_bias || bias, "sis_gemm_bf16: the epilogue needs a bias");
+    SIS_REQUIRE(epilogue != SIS_GEMM_EPI_BIAS_DROP_RESID || resid, "sis_gemm_bf16: the epilogue needs the residual");
+    SIS_REQUIRE(epilogue != SIS_GEMM_EPI_BIAS_GELU_DROP || c2, "sis_gemm_bf16: the epilogue needs the pre-activation output");
+    SIS_REQUIRE(epilogue != SIS_GEMM_EPI_GELU_BWD || pre, "sis_gemm_bf16: the epilogue needs the pre-activation");
+    SIS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "sis_gemm_bf16: dropout probability %f", drop_p);
+    SIS_REQUIRE(drop_p == 0.f || seed, "sis_gemm_bf16: dropout needs the seed word");
+    SIS_REQUIRE((int64_t)m * n < (1LL << 32), "sis_gemm_bf16: more than 2^32 outputs");
+    if (splits < 1) splits = 1;
+    SIS_REQUIRE(splits == 1 || epilogue == SIS_GEMM_EPI_F32, "sis_gemm_bf16: split-K needs the fp32 epilogue");
+    SIS_REQUIRE(splits == 1 || splits == 2 || splits == 4 || splits % 8 == 0, "sis_gemm_bf16: splits must be 1, 2, 4 or a multiple of 8");
+
+    GemmParams p;
+    p.A = a; p.B = b; p.lda = lda; p.ldb = ldb; p.M = m; p.N = n; p.K = k;
+    // operand extents: row operand [rows][k] -> (rows - 1) * ld + k elements; K-major [k][cols] -> (k - 1) * ld + cols
+    const int64_t ae = layout == LAYOUT_TN ? (int64_t)(k - 1) * lda + m : (int64_t)(m - 1) * lda + k;
+    const int64_t be = layout == LAYOUT_NT ? (int64_t)(n - 1) * ldb + k : (int64_t)(k - 1) * ldb + n;
+    SIS_REQUIRE(ae * 2 < (1LL << 31) && be * 2 < (1LL << 31), "sis_gemm_bf16: operands above 2 GiB");
+    p.a_bytes = (unsigned)(ae * 2); p.b_bytes = (unsigned)(be * 2);
+    p.C = c; p.C2 = c2; p.ldc = ldc; p.bias = bias; p.resid = resid; p.pre = (const u16*)pre;
+    p.seed = (const unsigned long long*)seed; p.site = (unsigned)site;
+    p.drop_thr = drop_p > 0.f ? (unsigned)((double)drop_p * 4294967296.0) : 0u;
+    p.drop_scale = drop_p > 0.f ? (float)(1.0 / (1.0 - (double)p.drop_thr / 4294967296.0)) : 1.f;
+    int bm = 128, bn = 128;
+    if (tile == 1) { bm = 256; bn = 128; }
+    else if (tile == 2) { bm = 128; bn = 256; }
+    else if (tile == 3) { bm = 256; bn = 256; }
+    p.m_tiles = sis_cdiv(m, bm); p.n_tiles = sis_cdiv(n, bn);
+    const int ksteps = sis_cdiv(k, 64);
+    if (splits > ksteps) splits = 1;
+    p.ksteps_per_split = sis_cdiv(ksteps, splits);
+    SIS_REQUIRE((splits - 1) * p.ksteps_per_split < ksteps, "sis_gemm_bf16: %d splits leave an empty slice of %d K steps", splits, ksteps);
+    p.splits = splits; p.slab_stride = (long long)m * ldc;
+    hipStream_t st = (hipStream_t)stream;
+    float* result = (float*)c;
+    if (splits > 1) {
+        SIS_REQUIRE(ldc == n, "sis_gemm_bf16: split-K writes a dense result (ldc == n)");
+        SIS_REQUIRE(workspace && workspace_bytes >= sis_gemm_bf16_workspace_bytes(m, n, splits), "sis_gemm_bf16: workspace too small");
+        p.C = workspace;
+    }
+    int rc;
+if (bm == 128 && bn == 128) rc = dispatch<128, 128>(p, layout, epilogue, st);
+    else if (bm == 256 && bn == 128) rc = dispatch<256, 128>(p, layout, epilogue, st);
+    else if (bm == 128 && bn == 256) rc = dispatch<128, 256>(p, layout, epilogue, st);
+    else rc = dispatch<256, 256>(p, layout, epilogue, st);
+    if (rc) return rc;
+    if (splits > 1) {
+        const long long quads = (long long)m * n / 4;
+        hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3(sis_cdiv(quads, 256)), dim3(256), 0, st, result, (const float*)workspace,
+                           quads, splits, p.slab_stride);
+        SIS_CHECK_LAUNCH("gemm_slab_reduce_kernel");
+    }
+    return 0;
+}

@@ -46,6 +46,10 @@ _SIGNATURES = {
     "sis_conv3x3_prepack": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "sis_conv3x3_eligible": ([_i] * 5, _i),
     "sis_upsample_bilinear": ([_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp], _i),
+    "sis_gemm_bf16_workspace_bytes": ([_i, _i, _i], _i64),
+    "sis_gemm_bf16": ([_vp] * 4 + [_i] * 8 + [_vp] * 4 + [_i, _f, _i, _vp, _i64, _i, _vp], _i),
+    "sis_dropout_advance": ([_vp, _vp], _i),
+    "sis_dropout_bwd_cast": ([_vp, _vp, _i64, _vp, _i, _f, _vp], _i),
     "sis_layer_norm_workspace_floats": ([_i], _i),
     "sis_column_sum_workspace_floats": ([_i], _i64),
     "sis_column_sum": ([_vp, _vp, _vp, _i, _i, _i, _vp], _i),
@@ -706,6 +710,91 @@ def conv_bf16_wgrad(x, grad_output, out_dtype=torch.float32):
                        lambda: lib().sis_conv_bf16_wgrad(_ptr(dw), _DTYPE_CODE[out_dtype], _ptr(x), _ptr(grad_output), b, cin, cout,
                                                          h, w, _ptr(ws), ws.numel(), _stream())), "sis_conv_bf16_wgrad")
     return dw
+
+
+# ------------------------------------------------------------------------------ bf16 GEMM with fused epilogues (ViT encoder)
+
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_DROP, EPI_BIAS_DROP_RESID, EPI_GELU_BWD, EPI_F32 = range(6)
+_GEMM_TILES = {0: (128, 128), 1: (256, 128), 2: (128, 256), 3: (256, 256)}
+
+
+def _rows2d(t, name):
+    if t.dim() != 2 or t.dtype != torch.bfloat16 or t.stride(1) != 1 or t.stride(0) % 8 or t.data_ptr() % 16:
+        raise RuntimeError(f"gemm_bf16: {name} must be a 2-D bfloat16 tensor with unit column stride, a row stride that is a "
+                           "multiple of 8 and a 16-byte aligned base")
+    return t
+
+
+def gemm_bf16(a, b, layout, epilogue=EPI_NONE, bias=None, resid=None, pre=None, seed=None, site=0, drop_p=0.0, splits=1, tile=0):
+    """C = epilogue(op(a) op(b)) on the bf16 matrix cores (csrc/gemm_bf16.hip), fp32 accumulation.
+      GEMM_NT  a [m,k], b [n,k]   (forward of a Linear layer: x, weight)
+      GEMM_NN  a [m,k], b [k,n]   (data gradient: grad, weight)
+      GEMM_TN  a [k,m], b [k,n]   (weight gradient: grad, x; EPI_F32, optionally split over k)
+    Row-strided views are taken as they are (row stride % 8 == 0).  Returns C (bf16, or fp32 for EPI_BIAS_DROP_RESID /
+    EPI_F32); EPI_BIAS_GELU_DROP returns (dropout(gelu(h)), h)."""
+    require_device(a, "a")
+    a, b = _rows2d(a, "a"), _rows2d(b, "b")
+    if layout == GEMM_NT:
+        (m, k), (n, k2) = a.shape, b.shape
+    elif layout == GEMM_NN:
+        (m, k), (k2, n) = a.shape, b.shape
+    else:
+        (k, m), (k2, n) = a.shape, b.shape
+    if k != k2:
+        raise RuntimeError(f"gemm_bf16: contraction lengths differ ({k} vs {k2})")
+    f32_out = epilogue in (EPI_BIAS_DROP_RESID, EPI_F32)
+    c = torch.empty((m, n), dtype=torch.float32 if f32_out else torch.bfloat16, device=a.device)
+    c2 = torch.empty((m, n), dtype=torch.bfloat16, device=a.device) if epilogue == EPI_BIAS_GELU_DROP else None
+    if bias is not None:
+        bias = _f32(bias, "bias")
+    if resid is not None:
+        resid = _f32(resid, "residual")
+        if tuple(resid.shape) != (m, n):
+            raise RuntimeError("gemm_bf16: the residual must have the output's shape")
+    if pre is not None and (pre.dtype != torch.bfloat16 or tuple(pre.shape) != (m, n) or not pre.is_contiguous()):
+        raise RuntimeError("gemm_bf16: the pre-activation must be a contiguous bfloat16 tensor of the output's shape")
+    ws, ws_bytes = None, 0
+    if splits > 1:
+        ws = _workspace(a.device)
+        ws_bytes = ws.numel()
+    bm, bn = _GEMM_TILES[tile]
+    name = f"gemm_bf16<{('NT', 'NN', 'TN')[layout]},{epilogue}>"
+    with torch.cuda.device(a.device):
+        _check(_launch(name, 2.0 * m * n * k, 2.0 * (m * k + n * k) + c.element_size() * m * n,
+                       lambda: lib().sis_gemm_bf16(_ptr(c), _ptr(c2), _ptr(a), _ptr(b), layout, epilogue, m, n, k, a.stride(0),
+                                                   b.stride(0), n, _ptr(bias), _ptr(resid), _ptr(pre), _ptr(seed), int(site),
+                                                   float(drop_p), int(splits), _ptr(ws), ws_bytes, int(tile), _stream())),
+               "sis_gemm_bf16")
+    return (c, c2) if c2 is not None else c
+
+
+_drop_seeds = {}
+
+
+def dropout_seed(device):
+    """The device seed word (int64 [1]) every dropout site of the fused ViT kernels reads; initialised from torch's seed."""
+    device = torch.device(device)
+    t = _drop_seeds.get(device)
+    if t is None:
+        t = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device)
+        _drop_seeds[device] = t
+    return t
+
+
+def dropout_advance(seed):
+    with torch.cuda.device(seed.device):
+        _check(lib().sis_dropout_advance(_ptr(seed), _stream()), "sis_dropout_advance")
+
+
+def dropout_bwd_cast(grad, seed, site, drop_p):
+    """bf16(grad * dropout factor): gradient of ``resid + dropout(y)`` w.r.t. y (y dense, row-major, grad fp32)."""
+    grad = _f32(grad, "grad")
+    out = torch.empty(grad.shape, dtype=torch.bfloat16, device=grad.device)
+    with torch.cuda.device(grad.device):
+        _check(lib().sis_dropout_bwd_cast(_ptr(out), _ptr(grad), grad.numel(), _ptr(seed), int(site), float(drop_p), _stream()),
+               "sis_dropout_bwd_cast")
+    return out
 
 
 # ------------------------------------------------------------------------------ layer norm

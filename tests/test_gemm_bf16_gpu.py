@@ -1,0 +1,153 @@
+"""GPU parity: the bf16 GEMM with fused epilogues (csrc/gemm_bf16.hip) through the C ABI against fp32 CPU arithmetic on the same
+bf16-rounded operands (the oracle for the ViT encoder's Linear layers is plain ``x @ W.T + b`` etc.,
+networks/trans_u_net/vit_seg_modeling.py:60-67,76-96,104-122,181-189).
+
+Stated tolerances: fp32 accumulation in a different association than the CPU's, then ONE rounding to bf16 (2^-9 relative) for
+the bf16 outputs -> |err| <= 1e-2 * max|ref|; fp32 outputs (residual stream, weight gradients) -> |err| <= 2e-4 * max|ref|
+(K up to 8192 products of bf16 values accumulated in fp32)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16_TOL, F32_TOL = 1e-2, 2e-4
+
+
+def _rand(shape, gen, scale=1.0):
+    return (torch.randn(*shape, generator=gen) * scale).bfloat16()
+
+
+def _close(got, ref, tol):
+    err = (got.float().cpu() - ref).abs().max().item()
+    assert err <= tol * ref.abs().max().item(), (err, ref.abs().max().item())
+
+
+def _gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+def _gelu_grad(x):
+    return 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+NT_CASES = [(256, 256, 128), (128, 384, 64), (392, 768, 768), (1000, 2304, 768), (512, 768, 3072), (130, 132, 192)]
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("m,n,k", NT_CASES)
+def test_gemm_nt_epilogues(device, m, n, k, tile):
+    import sis_hip as S
+    gen = torch.Generator().manual_seed(m * 7 + n * 3 + k + tile)
+    x, w = _rand((m, k), gen), _rand((n, k), gen, k ** -0.5)
+    bias = torch.randn(n, generator=gen)
+    resid = torch.randn(m, n, generator=gen)
+    xd, wd, bd, rd = x.to(device), w.to(device), bias.to(device), resid.to(device)
+    y = x.float() @ w.float().t()
+    _close(S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_NONE, tile=tile), y, BF16_TOL)
+    _close(S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS, bias=bd, tile=tile), y + bias, BF16_TOL)
+    out, pre = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_GELU_DROP, bias=bd, tile=tile)
+    _close(pre, y + bias, BF16_TOL)
+    _close(out, _gelu(pre.float().cpu()), BF16_TOL)            # the activation is evaluated AT the stored bf16 pre-activation
+    res = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=bd, resid=rd, tile=tile)
+    assert res.dtype == torch.float32
+    _close(res, resid + y + bias, F32_TOL * 4)
+    _close(S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_F32, tile=tile), y, F32_TOL)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (392, 768, 2304), (640, 3072, 768), (200, 136, 64)])
+def test_gemm_nn_data_gradient(device, m, n, k, tile):
+    """dx = g W (W [k = out features][n = in features], read K-major through the transposing LDS reads)."""
+    import sis_hip as S
+    gen = torch.Generator().manual_seed(m + n + k + tile)
+    g, w = _rand((m, k), gen), _rand((k, n), gen, k ** -0.5)
+    pre = _rand((m, n), gen)
+    gd, wd, pd = g.to(device), w.to(device), pre.to(device)
+    y = g.float() @ w.float()
+    _close(S.gemm_bf16(gd, wd, S.GEMM_NN, S.EPI_NONE, tile=tile), y, BF16_TOL)
+    _close(S.gemm_bf16(gd, wd, S.GEMM_NN, S.EPI_GELU_BWD, pre=pd, tile=tile), y * _gelu_grad(pre.float()), BF16_TOL)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("m,n,k,splits", [(256, 256, 128, 1), (768, 768, 392, 1), (2304, 768, 2048, 4), (768, 3072, 1024, 8),
+                                          (136, 264, 200, 2), (768, 768, 8192, 16)])
+def test_gemm_tn_weight_gradient(device, m, n, k, splits, tile):
+    """dW[m = out][n = in] = sum_tokens g[token][m] x[token][n]: both operands K-major, fp32 result, split over the tokens;
+    the token count need not be a multiple of the 64-deep K step (rows past the end read as zeros)."""
+    import sis_hip as S
+    gen = torch.Generator().manual_seed(m + n + k + splits + tile)
+    g, x = _rand((k, m), gen), _rand((k, n), gen)
+    ref = g.float().t() @ x.float()
+    got = S.gemm_bf16(g.to(device), x.to(device), S.GEMM_TN, S.EPI_F32, splits=splits, tile=tile)
+    assert got.dtype == torch.float32
+    _close(got, ref, F32_TOL)
+    again = S.gemm_bf16(g.to(device), x.to(device), S.GEMM_TN, S.EPI_F32, splits=splits, tile=tile)
+    assert torch.equal(got, again), "split-K partial sums are added in slab order: bitwise repeatable"
+
+
+def test_gemm_strided_views(device):
+    """Operands are taken as row-strided views: q / k / v column blocks of the fused projection, no copies."""
+    import sis_hip as S
+    gen = torch.Generator().manual_seed(5)
+    qkv, w = _rand((512, 2304), gen), _rand((768, 768), gen, 768 ** -0.5)
+    qd = qkv.to(device)
+    for c0 in (0, 768, 1536):
+        _close(S.gemm_bf16(qd[:, c0:c0 + 768], w.to(device), S.GEMM_NT), qkv[:, c0:c0 + 768].float() @ w.float().t(), BF16_TOL)
+        ref = qkv[:, c0:c0 + 768].float().t() @ qkv[:, :768].float()
+        _close(S.gemm_bf16(qd[:, c0:c0 + 768], qd[:, :768], S.GEMM_TN, S.EPI_F32, splits=2), ref, F32_TOL)
+
+
+def test_gemm_dropout_stream(device):
+    """Dropout in the epilogues: the dropped fraction is p, survivors are scaled by 1 / (1 - p), forward and backward of a
+    site see the same mask (nothing is stored), two sites and two steps (seed words) see different ones."""
+    import sis_hip as S
+    m, n, k, p = 1024, 768, 128, 0.1
+    gen = torch.Generator().manual_seed(11)
+    x, w = _rand((m, k), gen), _rand((n, k), gen, k ** -0.5)
+    xd, wd = x.to(device), w.to(device)
+    zero_b, zero_r = torch.zeros(n, device=device), torch.zeros(m, n, device=device)
+    seed = torch.tensor([12345], dtype=torch.int64, device=device)
+    plain = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=zero_b, resid=zero_r)
+    drop = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=zero_b, resid=zero_r, seed=seed, site=3, drop_p=p)
+    assert (plain == 0).sum().item() == 0
+    mask = drop != 0
+    frac = 1 - mask.float().mean().item()
+    assert abs(frac - p) < 5e-3, frac
+    thr = int(p * 2 ** 32)
+    scale = 1 / (1 - thr / 2 ** 32)
+    assert torch.allclose(drop[mask], plain[mask] * scale, rtol=1e-6, atol=0)
+    # the backward of the same site: bf16(g * factor) with the identical mask
+    g = torch.randn(m, n, generator=gen).to(device)
+    gb = S.dropout_bwd_cast(g, seed, 3, p)
+    assert torch.equal(gb == 0, ~mask | (g.bfloat16() == 0))
+    _close(gb[mask], (g[mask] * scale).cpu(), BF16_TOL)
+    other_site = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=zero_b, resid=zero_r, seed=seed, site=4, drop_p=p) != 0
+    S.dropout_advance(seed)
+    assert seed.item() != 12345
+    other_step = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=zero_b, resid=zero_r, seed=seed, site=3, drop_p=p) != 0
+    for other in (other_site, other_step):
+        agree = (other == mask).float().mean().item()
+        assert abs(agree - (p * p + (1 - p) ** 2)) < 1e-2, agree    # independent masks agree on p^2 + (1-p)^2 of the elements
+    # fc1 forward (GELU + dropout) and the fc2 data gradient's epilogue (dropout * gelu') share a site and a mask
+    seed2 = torch.tensor([777], dtype=torch.int64, device=device)
+    out, pre = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_GELU_DROP, bias=zero_b, seed=seed2, site=9, drop_p=p)
+    gy, w2 = _rand((m, k), gen).to(device), _rand((k, n), gen, k ** -0.5).to(device)
+    dpre = S.gemm_bf16(gy, w2, S.GEMM_NN, S.EPI_GELU_BWD, pre=pre, seed=seed2, site=9, drop_p=p)
+    dpre0 = S.gemm_bf16(gy, w2, S.GEMM_NN, S.EPI_GELU_BWD, pre=pre)
+    fwd_dropped = (out == 0) & (_gelu(pre.float()).bfloat16() != 0)
+    bwd_dropped = (dpre == 0) & (dpre0 != 0)
+    assert fwd_dropped.float().mean().item() > 0.08
+    assert torch.equal(fwd_dropped & (dpre0 != 0), bwd_dropped & (_gelu(pre.float()).bfloat16() != 0))
+
+
+def test_gemm_full_size_qkv(device):
+    """configs[4] size: 8 192 tokens x (768 -> 2304), every tile of the grid against the CPU."""
+    import sis_hip as S
+    gen = torch.Generator().manual_seed(99)
+    x, w, b = _rand((8192, 768), gen), _rand((2304, 768), gen, 768 ** -0.5), torch.randn(2304, generator=gen)
+    torch.set_num_threads(16)
+    ref = x.float() @ w.float().t() + b
+    for tile in (0, 1, 2, 3):
+        _close(S.gemm_bf16(x.to(device), w.to(device), S.GEMM_NT, S.EPI_BIAS, bias=b.to(device), tile=tile), ref, BF16_TOL)
