@@ -419,7 +419,10 @@ int sis_conv1x1_f32(float* y, const float* x, const float* weight, const float* 
  * dropout: element (m, n) of site `site` is dropped iff hash(seed word, site, m * n_cols + n) < drop_p * 2^32, else scaled by
  * 1 / (1 - drop_p); the forward and the backward launch of a site evaluate the same function (no stored mask).  `seed`
  * points to a 64-bit device word (sis_dropout_advance steps it once per iteration).  drop_p = 0: no dropout.
- * tile: 0 = 128x128 (256 threads), 1 = 256x128, 2 = 128x256, 3 = 256x256.  NT / NN need k % 64 == 0; n, ldc % 4 == 0;
+ * bias_seg > 0: the bias is three vectors of bias_seg = n / 3 entries (bias, bias1, bias2: the query | key | value biases of the
+ * fused projection stay three parameters); bias_seg = 0: one vector `bias`.
+ * tile (BM x BN x BK, LDS stages): 0 = 128x128x64 / 2, 1 = 256x128x64 / 2, 2 = 128x256x64 / 2, 3 = 256x256x64 / 2,
+ * 4 = 128x128x32 / 3, 5 = 128x128x32 / 4, 6 = 128x128x64 / 3, 7 = 256x128x64 / 3 (one wave per 64x64 sub-tile).  NT / NN need k % 64 == 0; n, ldc % 4 == 0;
  * lda, ldb % 8 == 0; 16-byte aligned pointers.  m (and k for TN) need not be tile multiples. */
 #define SIS_GEMM_EPI_NONE 0
 #define SIS_GEMM_EPI_BIAS 1
@@ -429,8 +432,9 @@ int sis_conv1x1_f32(float* y, const float* x, const float* weight, const float* 
 #define SIS_GEMM_EPI_F32 5
 int64_t sis_gemm_bf16_workspace_bytes(int m, int n, int splits);
 int sis_gemm_bf16(void* c, void* c2, const void* a, const void* b, int layout, int epilogue, int m, int n, int k, int lda,
-                  int ldb, int ldc, const float* bias, const float* resid, const void* pre, const void* seed, int site,
-                  float drop_p, int splits, void* workspace, int64_t workspace_bytes, int tile, void* stream);
+                  int ldb, int ldc, const float* bias, const float* bias1, const float* bias2, int bias_seg, const float* resid,
+                  const void* pre, const void* seed, int site, float drop_p, int splits, void* workspace,
+                  int64_t workspace_bytes, int tile, void* stream);
 
 /* Dropout stream of the fused ViT-encoder kernels (csrc/vit_elementwise.hip; nn.Dropout of vit_seg_modeling.py:70-71,108,138).
  *   sis_dropout_advance   steps the 64-bit device seed word once per training iteration (graph-capturable).
@@ -439,6 +443,39 @@ int sis_gemm_bf16(void* c, void* c2, const void* a, const void* b, int layout, i
  *                         same site id and a dense [m][n] output (element index = m * n_cols + n). */
 int sis_dropout_advance(void* seed, void* stream);
 int sis_dropout_bwd_cast(void* out, const float* grad, int64_t numel, const void* seed, int site, float drop_p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused multi-head self-attention of the ViT encoder, head size 64 (csrc/attention_bf16.hip).
+ * Replaces Attention.forward's  softmax(q k^T / sqrt(d)) v  with its transposes / permutes
+ * (networks/trans_u_net/vit_seg_modeling.py:71-74,83-94; attention dropout rate 0.0, vit_seg_configs.py:16) and its backward.
+ *   qkv    bf16 [batch][n][3 * heads * 64]   the fused query | key | value projection, read in place (head h = columns h*64..)
+ *   ctx    bf16 [batch][n][heads * 64]       context, heads merged (what Attention.out consumes)
+ *   lse    fp32 [batch][heads][n]            log-sum-exp of the scaled scores (saved for the backward)
+ *   d_qkv  bf16, layout of qkv; d_ctx bf16, layout of ctx; delta fp32 [batch][heads][n] scratch (rowsum(d_ctx o ctx))
+ * No [n][n] tensor is written; the backward accumulates nothing across workgroups (no atomics: bitwise reproducible). */
+/* LayerNorm backward (csrc/layer_norm.hip) with the residual-block fusions of the ViT encoder (vit_seg_modeling.py:181-189):
+ * dx = residual_grad + LN'(grad_y) (residual_grad fp32 or NULL), and optionally cast_out bf16 = dx * dropout factor of the
+ * dropout site the previous residual add used (what sis_dropout_bwd_cast computes, without its pass over memory). */
+int sis_layer_norm_bwd_fused(void* dx, float* dgamma, float* dbeta, float* workspace, const void* grad_y, const void* x,
+                             const float* mean, const float* rstd, const float* gamma, int x_dtype, int g_dtype, int rows, int n,
+                             const float* residual_grad, void* cast_out, const void* seed, int site, float drop_p, void* stream);
+int sis_attention_fwd(void* ctx, float* lse, const void* qkv, int batch, int n, int heads, void* stream);
+int sis_attention_bwd(void* d_qkv, float* delta, const void* d_ctx, const void* qkv, const void* ctx, const float* lse, int batch,
+                      int n, int heads, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * TransUNet objective, fused (csrc/loss_ops.hip):  0.5 * CrossEntropy + 0.5 * Dice(softmax)  of
+ * updater/segmentation_updater.py:95-102 with networks/trans_u_net/utils.py:7-42 (DiceLoss, smooth 1e-5, sums over the batch).
+ *   logits [batch][classes][hw] (SIS_F32 or SIS_BF16), labels int64 [batch][hw]; 2 <= classes <= 8, hw % 4 == 0.
+ *   fwd: out3 = {combined, cross entropy, dice}; stats (1 + 2 * classes floats) = constants for the backward;
+ *        workspace: sis_ce_dice_workspace_floats(classes) floats (per-workgroup partial sums, added in order: deterministic).
+ *   bwd: grad_logits (dtype of logits) = d combined / d logits * grad_loss[0] (grad_loss NULL = 1).
+ * Labels outside [0, classes) are ignored by the cross entropy and are an all-zero one-hot row for the Dice sums. */
+int sis_ce_dice_workspace_floats(int classes);
+int sis_ce_dice_fwd(float* out3, float* stats, float* workspace, const void* logits, int dtype, const int64_t* labels, int batch,
+                    int classes, int hw, void* stream);
+int sis_ce_dice_bwd(void* grad_logits, const void* logits, int dtype, const int64_t* labels, const float* stats,
+                    const float* grad_loss, int batch, int classes, int hw, void* stream);
 
 #ifdef __cplusplus
 }

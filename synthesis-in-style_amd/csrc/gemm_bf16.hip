@@ -45,25 +45,34 @@ struct GemmParams {
     unsigned a_bytes, b_bytes;    // extent of each operand from its base pointer (range check of the DMA)
     int M, N, K;
     void* C; void* C2; int ldc;
-    const float* bias; const float* resid; const u16* pre;
-    const unsigned long long* seed; unsigned site, drop_thr; float drop_scale;
+    const float* bias; const float* bias1; const float* bias2; int bias_seg;   // bias_seg > 0: columns [k * seg, (k + 1) * seg) take bias k
+    const float* resid; const u16* pre;
+    const unsigned long long* seed; unsigned site, drop_thr; float drop_scale;   // drop_thr: 16-bit threshold
     int m_tiles, n_tiles, splits, ksteps_per_split;
     long long slab_stride;        // elements between the fp32 partial slabs of a split-K run
 };
 
-template <int BM_, int BN_, bool AKM_, bool BKM_>
+template <int BM_, int BN_, bool AKM_, bool BKM_, int BK_ = 64, int NS_ = 2>
 struct GemmCfg {
-    static constexpr int BM = BM_, BN = BN_, BK = 64;
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, NS = NS_;   // NS LDS stages: the DMA runs NS - 1 K steps ahead
     static constexpr bool AKM = AKM_, BKM = BKM_;       // operand is K-major in memory
     static constexpr int WM = BM / 64, WN = BN / 64, WAVES = WM * WN, THREADS = WAVES * 64;
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
     static constexpr int A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024;
     static constexpr int PA = (A_PIECES + WAVES - 1) / WAVES, PB = (B_PIECES + WAVES - 1) / WAVES;  // per wave
-    static constexpr int LDS = 2 * STAGE;
+    static constexpr int LDS = NS * STAGE;
+    static constexpr int RROW = BK * 2;                 // bytes of a row-operand row in LDS (128 or 64)
+    static constexpr int KSUB = BK / 32;                // MFMA k-steps per stage
+    static_assert(BK == 64 || BK == 32, "K step");
     static_assert(!AKM || BM >= 128, "K-major tiles need >= 16 chunks per row");
     static_assert(!BKM || BN >= 128, "K-major tiles need >= 16 chunks per row");
     static_assert(A_PIECES % WAVES == 0 && B_PIECES % WAVES == 0, "pieces must divide over the waves");
+    static_assert(LDS <= 160 * 1024, "stages exceed the LDS");
 };
+
+// swizzle of a row operand's 16-B chunks: 128-B rows (BK 64): c ^ (r & 7); 64-B rows (BK 32): c ^ ((-(r >> 2)) & 3) -- both
+// put the 16 rows x 4 chunks of every ds_read_b128 lane group on 16 different 16-B slots of the 256-B bank row
+template <int BK> __device__ __forceinline__ int row_f(int row) { return BK == 64 ? (row & 7) : ((-(row >> 2)) & 3); }
 
 __device__ __forceinline__ int kmaj_f(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }
 
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
         nt = tile % p.n_tiles;
     }
     const int m0 = mt * C::BM, n0 = nt * C::BN;
-    const int ks_total = (p.K + 63) >> 6;
+    const int ks_total = (p.K + C::BK - 1) / C::BK;
     const int ks_begin = split * p.ksteps_per_split;
     const int T = min(p.ksteps_per_split, ks_total - ks_begin);   // K steps of this workgroup (>= 1 by construction)
 
@@ -112,9 +121,10 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
     for (int i = 0; i < C::PA; ++i) {
         const int q = wave + i * C::WAVES;
         if constexpr (!C::AKM) {
-            const int row = m0 + 8 * q + (lane >> 3);
-            const int ch = (lane & 7) ^ ((lane >> 3) & 7);
-            a_src[i] = (row * p.lda + ch * 8) * 2;
+            constexpr int CPR = C::RROW / 16, RPP = 1024 / C::RROW;   // chunks per row, rows per 1 KiB piece
+            const int r = RPP * q + lane / CPR;
+            const int ch = (lane % CPR) ^ row_f<C::BK>(r);
+            a_src[i] = ((m0 + r) * p.lda + ch * 8) * 2;
         } else {
             constexpr int RB = 2 * C::BM;
             const int lin = 1024 * q + 16 * lane;
@@ -126,9 +136,10 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
     for (int i = 0; i < C::PB; ++i) {
         const int q = wave + i * C::WAVES;
         if constexpr (!C::BKM) {
-            const int row = n0 + 8 * q + (lane >> 3);
-            const int ch = (lane & 7) ^ ((lane >> 3) & 7);
-            b_src[i] = (row * p.ldb + ch * 8) * 2;
+            constexpr int CPR = C::RROW / 16, RPP = 1024 / C::RROW;
+            const int r = RPP * q + lane / CPR;
+            const int ch = (lane % CPR) ^ row_f<C::BK>(r);
+            b_src[i] = ((n0 + r) * p.ldb + ch * 8) * 2;
         } else {
             constexpr int RB = 2 * C::BN;
             const int lin = 1024 * q + 16 * lane;
@@ -136,8 +147,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
             b_src[i] = (krow * p.ldb + n0 + ((pos ^ kmaj_f(krow)) << 3)) * 2;
         }
     }
-    const int a_step = C::AKM ? 64 * p.lda * 2 : 128;   // bytes per K step
-    const int b_step = C::BKM ? 64 * p.ldb * 2 : 128;
+    const int a_step = C::AKM ? C::BK * p.lda * 2 : C::RROW;   // bytes per K step
+    const int b_step = C::BKM ? C::BK * p.ldb * 2 : C::RROW;
 
     auto issue = [&](int t, int stage) {
         const int ks = ks_begin + t;
@@ -157,7 +168,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
     int a_off[C::AKM ? 8 : 2], b_off[C::BKM ? 8 : 2];
     if constexpr (!C::AKM) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) a_off[ks] = (wm * 64 + i16) * 128 + (((4 * ks + g) ^ (i16 & 7)) << 4);
+        for (int ks = 0; ks < C::KSUB; ++ks) a_off[ks] = (wm * 64 + i16) * C::RROW + (((4 * ks + g) ^ row_f<C::BK>(i16)) << 4);
     } else {
         constexpr int RB = 2 * C::BM;
         const int q = i16 >> 2, pp = i16 & 3;
@@ -172,7 +183,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
     }
     if constexpr (!C::BKM) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) b_off[ks] = C::A_BYTES + (wn * 64 + i16) * 128 + (((4 * ks + g) ^ (i16 & 7)) << 4);
+        for (int ks = 0; ks < C::KSUB; ++ks) b_off[ks] = C::A_BYTES + (wn * 64 + i16) * C::RROW + (((4 * ks + g) ^ row_f<C::BK>(i16)) << 4);
     } else {
         constexpr int RB = 2 * C::BN;
         const int q = i16 >> 2, pp = i16 & 3;
@@ -194,7 +205,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
 
     auto frag = [&](const unsigned char* st, auto kmajor, const int* off, int rb_bytes, int b, int ks) -> bf16x8 {
         if constexpr (!decltype(kmajor)::value) {
-            return *reinterpret_cast<const bf16x8*>(st + off[ks] + b * 2048);
+            return *reinterpret_cast<const bf16x8*>(st + off[ks] + b * (16 * C::RROW));
         } else {
             const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                 (__attribute__((address_space(3))) bf16x4*)(st + off[b * 2] + ks * 32 * rb_bytes));
@@ -204,14 +215,23 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
         }
     };
 
-    issue(0, 0);
-    for (int t = 0; t < T; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage t have landed
-        __builtin_amdgcn_s_barrier();                       // ... everybody's; and everybody is done reading the other stage
-        if (t + 1 < T) issue(t + 1, (t + 1) & 1);
-        const unsigned char* st = lds + (t & 1) * C::STAGE;
+    // ---- main loop: the DMA of K step t + NS - 1 is issued right after the barrier of step t (its stage was read in step
+    // t - 1); the wait in front of the barrier leaves the NS - 2 younger stages in flight (counted vmcnt, raw s_barrier)
+    constexpr int NS = C::NS, PW = C::PA + C::PB;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < T) issue(s, s);
+    int stage = 0;
+    for (int t = 0; t < T; ++t) {
+        const int ahead = min(NS - 2, T - 1 - t);   // K steps after t whose DMA is already in flight
+        if (NS >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+        else if (NS >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of step t have landed
+        __builtin_amdgcn_s_barrier();                           // ... everybody's; and everybody is done reading step t - 1's stage
+        if (t + NS - 1 < T) issue(t + NS - 1, stage == 0 ? NS - 1 : stage - 1);
+        const unsigned char* st = lds + stage * C::STAGE;
+#pragma unroll
+        for (int ks = 0; ks < C::KSUB; ++ks) {
             bf16x8 a[4], b[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x) a[x] = frag(st, std::integral_constant<bool, C::AKM>(), a_off, 2 * C::BM, x, ks);
@@ -223,6 +243,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
                 for (int tm = 0; tm < 4; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[tn], a[tm], acc[tn][tm], 0, 0, 0);
         }
+        stage = stage + 1 == NS ? 0 : stage + 1;
     }
 
     // ---- epilogue: lane = output row m (per m block), registers = 4 consecutive columns n.  Interior tiles (the usual
@@ -241,7 +262,14 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
             const int n = n0 + wn * 64 + 16 * tn + 4 * g;
             bq[tn] = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (HAS_BIAS)
-                if (!CHECKED || n < p.N) bq[tn] = *reinterpret_cast<const float4*>(p.bias + n);
+                if (!CHECKED || n < p.N) {
+                    const float* bp = p.bias + n;
+                    if (p.bias_seg) {   // query | key | value biases stay three parameters (a lane's 4 columns never straddle two)
+                        if (n >= 2 * p.bias_seg) bp = p.bias2 + (n - 2 * p.bias_seg);
+                        else if (n >= p.bias_seg) bp = p.bias1 + (n - p.bias_seg);
+                    }
+                    bq[tn] = *reinterpret_cast<const float4*>(bp);
+                }
         }
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) {
@@ -261,7 +289,9 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
                 const int m = m0 + wm * 64 + 16 * tm + i16;
                 const bool ok = n_ok && (!CHECKED || m < p.M);
                 const long long at = (long long)m * p.ldc + n;
-                const unsigned idx = (unsigned)m * (unsigned)p.N + (unsigned)n;   // dropout stream position of v[0]
+                float keep[4] = {1.f, 1.f, 1.f, 1.f};
+                if constexpr (HAS_DROP)
+                    if (p.drop_thr) sis_drop_quad(key, ((unsigned)m * (unsigned)p.N + (unsigned)n) >> 2, p.drop_thr, p.drop_scale, keep);
                 float v[4] = {acc[tn][tm][0] + bq[tn].x, acc[tn][tm][1] + bq[tn].y, acc[tn][tm][2] + bq[tn].z, acc[tn][tm][3] + bq[tn].w};
                 if constexpr (EPI == SIS_GEMM_EPI_NONE || EPI == SIS_GEMM_EPI_BIAS) {
                     if (ok) *reinterpret_cast<uint2*>((u16*)p.C + at) = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
@@ -269,29 +299,22 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
                     // pre-activation (bf16, what the backward differentiates at) and dropout(gelu(pre))
                     const uint2 hp = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
                     float y[4] = {sis_gelu(sis_bf16_lo(hp.x)), sis_gelu(sis_bf16_hi(hp.x)), sis_gelu(sis_bf16_lo(hp.y)), sis_gelu(sis_bf16_hi(hp.y))};
-                    if (p.drop_thr) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] *= sis_drop_factor(key, idx + e, p.drop_thr, p.drop_scale);
-                    }
+                    for (int e = 0; e < 4; ++e) y[e] *= keep[e];
                     if (ok) {
                         *reinterpret_cast<uint2*>((u16*)p.C2 + at) = hp;
                         *reinterpret_cast<uint2*>((u16*)p.C + at) = make_uint2(sis_pack_bf16x2(y[0], y[1]), sis_pack_bf16x2(y[2], y[3]));
                     }
                 } else if constexpr (EPI == SIS_GEMM_EPI_BIAS_DROP_RESID) {
-                    if (p.drop_thr) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= sis_drop_factor(key, idx + e, p.drop_thr, p.drop_scale);
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] *= keep[e];
                     if (ok) *reinterpret_cast<float4*>((float*)p.C + at) = make_float4(r[tm].x + v[0], r[tm].y + v[1], r[tm].z + v[2], r[tm].w + v[3]);
                 } else if constexpr (EPI == SIS_GEMM_EPI_GELU_BWD) {
                     // gradient w.r.t. the pre-activation: acc * dropout factor * gelu'(pre)
                     const float d[4] = {sis_gelu_grad(sis_bf16_lo(h[tm].x)), sis_gelu_grad(sis_bf16_hi(h[tm].x)),
                                         sis_gelu_grad(sis_bf16_lo(h[tm].y)), sis_gelu_grad(sis_bf16_hi(h[tm].y))};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] *= d[e];
-                        if (p.drop_thr) v[e] *= sis_drop_factor(key, idx + e, p.drop_thr, p.drop_scale);
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] *= d[e] * keep[e];
                     if (ok) *reinterpret_cast<uint2*>((u16*)p.C + at) = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
                 } else {  // SIS_GEMM_EPI_F32: fp32 result or partial slab of a split-K run
                     if (ok) *reinterpret_cast<float4*>((float*)p.C + (long long)split * p.slab_stride + at) = make_float4(v[0], v[1], v[2], v[3]);
@@ -338,10 +361,10 @@ int launch_gemm(const GemmParams& p, hipStream_t st, const char* name) {
 }
 
 // the epilogues each layout is built with: what the three GEMMs of a Linear layer need
-template <int BM, int BN>
+template <int BM, int BN, int BK, int NS>
 int dispatch(const GemmParams& p, int layout, int epi, hipStream_t st) {
     if (layout == LAYOUT_NT) {
-        typedef GemmCfg<BM, BN, false, false> C;
+        typedef GemmCfg<BM, BN, false, false, BK, NS> C;
         switch (epi) {
             case SIS_GEMM_EPI_NONE: return launch_gemm<C, SIS_GEMM_EPI_NONE>(p, st, "gemm_bf16_kernel<NT>");
             case SIS_GEMM_EPI_BIAS: return launch_gemm<C, SIS_GEMM_EPI_BIAS>(p, st, "gemm_bf16_kernel<NT,bias>");
@@ -350,17 +373,23 @@ int dispatch(const GemmParams& p, int layout, int epi, hipStream_t st) {
             case SIS_GEMM_EPI_F32: return launch_gemm<C, SIS_GEMM_EPI_F32>(p, st, "gemm_bf16_kernel<NT,f32>");
         }
     } else if (layout == LAYOUT_NN) {
-        typedef GemmCfg<BM, BN, false, true> C;
+        typedef GemmCfg<BM, BN, false, true, BK, NS> C;
         switch (epi) {
             case SIS_GEMM_EPI_NONE: return launch_gemm<C, SIS_GEMM_EPI_NONE>(p, st, "gemm_bf16_kernel<NN>");
             case SIS_GEMM_EPI_GELU_BWD: return launch_gemm<C, SIS_GEMM_EPI_GELU_BWD>(p, st, "gemm_bf16_kernel<NN,gelu'+dropout>");
         }
     } else {
-        typedef GemmCfg<BM, BN, true, true> C;
+        typedef GemmCfg<BM, BN, true, true, BK, NS> C;
         if (epi == SIS_GEMM_EPI_F32) return launch_gemm<C, SIS_GEMM_EPI_F32>(p, st, "gemm_bf16_kernel<TN,f32>");
     }
     return sis_fail("sis_gemm_bf16: epilogue %d is not built for layout %d", epi, layout);
 }
+
+struct TilePlan { int bm, bn, bk, ns; };
+// tile codes of the C ABI: (BM, BN, BK, LDS stages)
+constexpr TilePlan TILE_PLANS[] = {{128, 128, 64, 2}, {256, 128, 64, 2}, {128, 256, 64, 2}, {256, 256, 64, 2},
+                                   {128, 128, 32, 3}, {128, 128, 32, 4}, {128, 128, 64, 3}, {256, 128, 64, 3}};
+constexpr int N_TILE_PLANS = sizeof(TILE_PLANS) / sizeof(TILE_PLANS[0]);
 
 }  // namespace
 
@@ -369,7 +398,8 @@ extern "C" int64_t sis_gemm_bf16_workspace_bytes(int m, int n, int splits) {
 }
 
 extern "C" int sis_gemm_bf16(void* c, void* c2, const void* a, const void* b, int layout, int epilogue, int m, int n, int k,
-                             int lda, int ldb, int ldc, const float* bias, const float* resid, const void* pre,
+                             int lda, int ldb, int ldc, const float* bias, const float* bias1, const float* bias2, int bias_seg,
+                             const float* resid, const void* pre,
                              const void* seed, int site, float drop_p, int splits, void* workspace, int64_t workspace_bytes,
                              int tile, void* stream) {
     if (m <= 0 || n <= 0) return 0;
@@ -398,16 +428,16 @@ extern "C" int sis_gemm_bf16(void* c, void* c2, const void* a, const void* b, in
     const int64_t be = layout == LAYOUT_NT ? (int64_t)(n - 1) * ldb + k : (int64_t)(k - 1) * ldb + n;
     SIS_REQUIRE(ae * 2 < (1LL << 31) && be * 2 < (1LL << 31), "sis_gemm_bf16: operands above 2 GiB");
     p.a_bytes = (unsigned)(ae * 2); p.b_bytes = (unsigned)(be * 2);
-    p.C = c; p.C2 = c2; p.ldc = ldc; p.bias = bias; p.resid = resid; p.pre = (const u16*)pre;
+    SIS_REQUIRE(bias_seg == 0 || (bias_seg % 4 == 0 && bias1 && bias2 && n == 3 * bias_seg), "sis_gemm_bf16: three bias segments of n / 3 columns each");
+    p.C = c; p.C2 = c2; p.ldc = ldc; p.bias = bias; p.bias1 = bias1; p.bias2 = bias2; p.bias_seg = bias_seg; p.resid = resid; p.pre = (const u16*)pre;
     p.seed = (const unsigned long long*)seed; p.site = (unsigned)site;
-    p.drop_thr = drop_p > 0.f ? (unsigned)((double)drop_p * 4294967296.0) : 0u;
-    p.drop_scale = drop_p > 0.f ? (float)(1.0 / (1.0 - (double)p.drop_thr / 4294967296.0)) : 1.f;
-    int bm = 128, bn = 128;
-    if (tile == 1) { bm = 256; bn = 128; }
-    else if (tile == 2) { bm = 128; bn = 256; }
-    else if (tile == 3) { bm = 256; bn = 256; }
+    p.drop_thr = sis_drop_thr16(drop_p);
+    p.drop_scale = sis_drop_scale(p.drop_thr);
+    SIS_REQUIRE(p.drop_thr == 0 || ((int64_t)n % 4 == 0), "sis_gemm_bf16: dropout quads need n % 4 == 0");
+    SIS_REQUIRE(tile >= 0 && tile < N_TILE_PLANS, "sis_gemm_bf16: tile code %d (0..%d)", tile, N_TILE_PLANS - 1);
+    const int bm = TILE_PLANS[tile].bm, bn = TILE_PLANS[tile].bn, bk = TILE_PLANS[tile].bk;
     p.m_tiles = sis_cdiv(m, bm); p.n_tiles = sis_cdiv(n, bn);
-    const int ksteps = sis_cdiv(k, 64);
+    const int ksteps = sis_cdiv(k, bk);
     if (splits > ksteps) splits = 1;
     p.ksteps_per_split = sis_cdiv(ksteps, splits);
     SIS_REQUIRE((splits - 1) * p.ksteps_per_split < ksteps, "sis_gemm_bf16: %d splits leave an empty slice of %d K steps", splits, ksteps);
@@ -420,10 +450,16 @@ extern "C" int sis_gemm_bf16(void* c, void* c2, const void* a, const void* b, in
         p.C = workspace;
     }
     int rc;
-if (bm == 128 && bn == 128) rc = dispatch<128, 128>(p, layout, epilogue, st);
-    else if (bm == 256 && bn == 128) rc = dispatch<256, 128>(p, layout, epilogue, st);
-    else if (bm == 128 && bn == 256) rc = dispatch<128, 256>(p, layout, epilogue, st);
-    else rc = dispatch<256, 256>(p, layout, epilogue, st);
+switch (tile) {
+        case 0: rc = dispatch<128, 128, 64, 2>(p, layout, epilogue, st); break;
+        case 1: rc = dispatch<256, 128, 64, 2>(p, layout, epilogue, st); break;
+        case 2: rc = dispatch<128, 256, 64, 2>(p, layout, epilogue, st); break;
+        case 3: rc = dispatch<256, 256, 64, 2>(p, layout, epilogue, st); break;
+        case 4: rc = dispatch<128, 128, 32, 3>(p, layout, epilogue, st); break;
+        case 5: rc = dispatch<128, 128, 32, 4>(p, layout, epilogue, st); break;
+        case 6: rc = dispatch<128, 128, 64, 3>(p, layout, epilogue, st); break;
+        default: rc = dispatch<256, 128, 64, 3>(p, layout, epilogue, st); break;
+    }
     if (rc) return rc;
     if (splits > 1) {
         const long long quads = (long long)m * n / 4;

@@ -6,7 +6,7 @@
 // Backward: dx per row as usual; d(gamma) / d(beta) are column sums over all rows -- every workgroup walks a strip
 // of rows, keeps its column sums in registers, writes one partial row per workgroup; ln_param_reduce adds the partials
 // in fixed order (deterministic, no atomics).
-#include "sis_common.h"
+#include "vit_common.h"
 
 namespace {
 
@@ -78,11 +78,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(TO* __restrict__ y, float* 
     }
 }
 
+// Optional fusions for the pre-norm residual blocks of the ViT encoder (x_out = x + f(LN(x))): `radd` (fp32, x's shape) is
+// the gradient arriving over the skip connection, added to dx; `cast_out` receives bf16(dx_total * dropout factor) -- the
+// gradient w.r.t. the Linear output that the PREVIOUS residual add dropped out and added (site / threshold / scale of that
+// dropout, stream position = element index), i.e. what sis_dropout_bwd_cast would compute in a pass of its own.
+struct LnBwdExtra {
+    const float* radd; unsigned short* cast_out; const unsigned long long* seed; unsigned site, thr; float scale;
+};
+
 template <typename TI, typename TG, int NJ>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(TI* __restrict__ dx, float* __restrict__ part, const TG* __restrict__ g,
                                                      const TI* __restrict__ x, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const float* __restrict__ gamma,
-                                                     int rows) {
+                                                     int rows, LnBwdExtra ex) {
     constexpr int N = NJ * 256;
     __shared__ float red[2][4][N];  // per-wave column sums, merged by wave 0 at the end
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -120,7 +128,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(TI* __restrict__ dx, float*
             float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = rstd * (gv[j][e] - m1 - xh[j][e] * m2);
-            ln_store4(dr + 4 * (lane + 64 * j), o);
+            const int col = 4 * (lane + 64 * j);
+            if (ex.radd) {
+                const float4 r = *reinterpret_cast<const float4*>(ex.radd + (int64_t)row * N + col);
+                o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+            }
+            ln_store4(dr + col, o);
+            if (ex.cast_out) {
+                float f[4] = {o[0], o[1], o[2], o[3]};
+                if (ex.thr) {
+                    float keep[4];
+                    sis_drop_quad(sis_drop_key(ex.seed, ex.site), ((unsigned)row * (unsigned)N + (unsigned)col) >> 2, ex.thr, ex.scale, keep);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] *= keep[e];
+                }
+                *reinterpret_cast<uint2*>(ex.cast_out + (int64_t)row * N + col) =
+                    make_uint2(sis_pack_bf16x2(f[0], f[1]), sis_pack_bf16x2(f[2], f[3]));
+            }
         }
     }
 #pragma unroll
@@ -188,9 +212,9 @@ extern "C" int sis_layer_norm_fwd(void* y, float* mean, float* rstd, const void*
     return 0;
 }
 
-extern "C" int sis_layer_norm_bwd(void* dx, float* dgamma, float* dbeta, float* workspace, const void* grad_y, const void* x,
-                                  const float* mean, const float* rstd, const float* gamma, int x_dtype, int g_dtype, int rows,
-                                  int n, void* stream) {
+static int ln_bwd_impl(void* dx, float* dgamma, float* dbeta, float* workspace, const void* grad_y, const void* x,
+                       const float* mean, const float* rstd, const float* gamma, int x_dtype, int g_dtype, int rows,
+                       int n, LnBwdExtra ex, void* stream) {
     if (rows == 0) return 0;
     SIS_REQUIRE(dx && dgamma && dbeta && workspace && grad_y && x && mean && rstd && gamma, "sis_layer_norm_bwd: null pointer");
     SIS_REQUIRE(rows > 0 && n > 0 && n % 256 == 0, "sis_layer_norm_bwd: row length %d must be a multiple of 256", n);
@@ -200,7 +224,7 @@ extern "C" int sis_layer_norm_bwd(void* dx, float* dgamma, float* dbeta, float* 
     int blocks = sis_cdiv(rows, 4);
     if (blocks > LN_BWD_BLOCKS) blocks = LN_BWD_BLOCKS;
     const dim3 grid(blocks);
-#define LN_BWD(TI, TG) hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, NJ>), grid, dim3(256), 0, st, (TI*)dx, workspace, (const TG*)grad_y, (const TI*)x, mean, rstd, gamma, rows)
+#define LN_BWD(TI, TG) hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, NJ>), grid, dim3(256), 0, st, (TI*)dx, workspace, (const TG*)grad_y, (const TI*)x, mean, rstd, gamma, rows, ex)
     if (x_dtype == SIS_F32 && g_dtype == SIS_F32) { LN_SWITCH_NJ(n / 256, LN_BWD(float, float)) }
     else if (x_dtype == SIS_F32) { LN_SWITCH_NJ(n / 256, LN_BWD(float, __hip_bfloat16)) }
     else if (g_dtype == SIS_F32) { LN_SWITCH_NJ(n / 256, LN_BWD(__hip_bfloat16, float)) }
@@ -210,4 +234,25 @@ extern "C" int sis_layer_norm_bwd(void* dx, float* dgamma, float* dbeta, float* 
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(sis_cdiv(n, 64)), dim3(256), 0, st, dgamma, dbeta, workspace, blocks, n);
     SIS_CHECK_LAUNCH("ln_param_reduce_kernel");
     return 0;
+}
+
+extern "C" int sis_layer_norm_bwd(void* dx, float* dgamma, float* dbeta, float* workspace, const void* grad_y, const void* x,
+                                  const float* mean, const float* rstd, const float* gamma, int x_dtype, int g_dtype, int rows,
+                                  int n, void* stream) {
+    return ln_bwd_impl(dx, dgamma, dbeta, workspace, grad_y, x, mean, rstd, gamma, x_dtype, g_dtype, rows, n,
+                       LnBwdExtra{nullptr, nullptr, nullptr, 0u, 0u, 1.f}, stream);
+}
+
+extern "C" int sis_layer_norm_bwd_fused(void* dx, float* dgamma, float* dbeta, float* workspace, const void* grad_y, const void* x,
+                                        const float* mean, const float* rstd, const float* gamma, int x_dtype, int g_dtype,
+                                        int rows, int n, const float* residual_grad, void* cast_out, const void* seed, int site,
+                                        float drop_p, void* stream) {
+    SIS_REQUIRE(!(residual_grad || cast_out) || x_dtype == SIS_F32, "sis_layer_norm_bwd_fused: the fusions are for an fp32 residual stream");
+    SIS_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sis_layer_norm_bwd_fused: dropout probability %f / seed word", drop_p);
+    SIS_REQUIRE((int64_t)rows * n < (1LL << 32), "sis_layer_norm_bwd_fused: more than 2^32 elements");
+    LnBwdExtra ex;
+    ex.radd = residual_grad; ex.cast_out = (unsigned short*)cast_out; ex.seed = (const unsigned long long*)seed; ex.site = (unsigned)site;
+    ex.thr = sis_drop_thr16(drop_p);
+    ex.scale = sis_drop_scale(ex.thr);
+    return ln_bwd_impl(dx, dgamma, dbeta, workspace, grad_y, x, mean, rstd, gamma, x_dtype, g_dtype, rows, n, ex, stream);
 }

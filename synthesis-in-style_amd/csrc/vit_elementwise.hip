@@ -21,9 +21,10 @@ __global__ __launch_bounds__(256) void dropout_bwd_cast_kernel(unsigned short* _
     const float4 v = *reinterpret_cast<const float4*>(g + 4 * i);
     float f[4] = {v.x, v.y, v.z, v.w};
     if (thr) {
-        const SisDropKey key = sis_drop_key(seed, site);
+        float keep[4];
+        sis_drop_quad(sis_drop_key(seed, site), (unsigned)i, thr, scale, keep);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) f[e] *= sis_drop_factor(key, (unsigned)(4 * i + e), thr, scale);
+        for (int e = 0; e < 4; ++e) f[e] *= keep[e];
     }
     *reinterpret_cast<uint2*>(out + 4 * i) = make_uint2(sis_pack_bf16x2(f[0], f[1]), sis_pack_bf16x2(f[2], f[3]));
 }
@@ -42,8 +43,8 @@ extern "C" int sis_dropout_bwd_cast(void* out, const float* grad, int64_t numel,
     SIS_REQUIRE(out && grad, "sis_dropout_bwd_cast: null pointer");
     SIS_REQUIRE(numel % 4 == 0 && numel < (1LL << 32), "sis_dropout_bwd_cast: element count %lld must be a multiple of 4 below 2^32", (long long)numel);
     SIS_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sis_dropout_bwd_cast: dropout probability %f / seed word", drop_p);
-    const unsigned thr = drop_p > 0.f ? (unsigned)((double)drop_p * 4294967296.0) : 0u;
-    const float scale = drop_p > 0.f ? (float)(1.0 / (1.0 - (double)thr / 4294967296.0)) : 1.f;
+    const unsigned thr = sis_drop_thr16(drop_p);
+    const float scale = sis_drop_scale(thr);
     hipLaunchKernelGGL(dropout_bwd_cast_kernel, dim3(sis_cdiv(numel / 4, 256)), dim3(256), 0, (hipStream_t)stream, (unsigned short*)out,
                        grad, (long long)(numel / 4), (const unsigned long long*)seed, (unsigned)site, thr, scale);
     SIS_CHECK_LAUNCH("dropout_bwd_cast_kernel");

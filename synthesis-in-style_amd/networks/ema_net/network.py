@@ -12,8 +12,11 @@ Differences in execution:
 * "SynchronizedBatchNorm2d" is what it effectively is under the reference's DistributedDataParallel launch:
   per-GPU ``F.batch_norm`` with momentum 3e-4 (bn_lib/nn/modules/batchnorm.py:51-56); the DataParallel-era
   synchronisation machinery is not carried over (never active under train.py);
-* convolutions / batch norm / pooling / bmm run on the ROCm libraries through ATen for now (DESIGN.md lists
-  them as the next kernels to hand-write).
+* 3x3 (Winograd forward / data gradient / weight gradient), 1x1 and stride-2 convolutions, batch norm (+ ReLU, + residual),
+  max pooling and the EM iterations run on the hand-written kernels of csrc/ (``networks/hip_conv.py``, ``sis_bn_*``,
+  ``sis_max_pool2d``, ``sis_ema_*``); what stays on the ROCm libraries through ATen is the 3-channel stem convolution, the
+  dilation-16 layers whose 2x2 sub-images the tile plan rejects, and the EMAU's small bmm (0.9 of 29.9 ms per step,
+  profiles/r02_z_emanet_step_breakdown.txt).
 """
 import math
 import pathlib

@@ -6,8 +6,10 @@ with aligned shapes, and ATen otherwise.  Dilation d is run as the d*d ordinary 
 sub-images (EMANet's output-stride-8 trunk: d = 2 at 32^2 -> 16^2 sub-images; d = 8 / 16 leave 4^2 / 2^2
 sub-images, which the tile plan rejects: ATen).  Measured on EMANet-50's shapes (B = 16, tools/bench_conv_shapes.py) the
 kernel is 1.5-1.9x faster than the library's fp32 path (2048->512 @32^2: 1.70 vs 2.48 ms; 64->128 @128^2: 0.22 vs
-0.37 ms).  1x1 stride-1 convolutions keep the library's forward / data gradient (plain GEMMs already) and get their
-weight gradient as a batched GEMM on the NCHW tensors (1.6x faster than the library's NHWC path, no layout transposes).
+0.37 ms).  fp32 1x1 stride-1 convolutions run forward and data gradient on ``sis_conv1x1_f32`` (csrc/conv1x1_f32.hip, exact
+fp32 MFMA, the weight read K-major for the data gradient) and their weight gradient on ``sis_conv1x1_wgrad_f32``
+(csrc/conv1x1_wgrad_f32.hip: a batched GEMM on the NCHW tensors, deterministic split-K); stride-2 3x3 layers take the dense
+kernel and sample its output; only the 3-channel stem and layers the tile plans reject fall through to ATen.
 
 Autograd: the data gradient is the same kernel with adjoint weights (``sis_conv3x3_prepack(adjoint=1)``: channel
 axes swapped, taps rotated by 180 degrees); the weight gradient is ``sis_conv3x3_wgrad`` (Winograd-domain GEMM over

@@ -293,6 +293,91 @@ class Mlp(nn.Module):
         return self.dropout(self._fc(hidden, 1, self.fc2))
 
 
+_FUSED_BLOCK = os.environ.get('SIS_FUSED_VIT', '1') != '0'  # 0: the module-by-module path (library GEMMs / attention)
+
+
+def _wgrad_splits(out_features, in_features):
+    """K slices of a weight-gradient GEMM (contraction over the tokens): enough 128 x 128 tiles x slices to fill 256 CUs twice."""
+    tiles = ((out_features + 127) // 128) * ((in_features + 127) // 128)
+    splits = 1
+    while splits < 8 and tiles * splits * 2 <= 512:
+        splits *= 2
+    return splits
+
+
+class _FusedBlockFn(Function):
+    """One pre-norm transformer block (reference: Block.forward, vit_seg_modeling.py:181-189, with Attention.forward :76-96
+    and Mlp.forward :116-122) as seven launches forward and their hand-written backward:
+
+        h1 = LN1(x)                     csrc/layer_norm.hip          (bf16 out)
+        qkv = h1 Wqkv^T + b             gemm NT, bias epilogue       (query | key | value in one product)
+        ctx = softmax(q k^T / 8) v      csrc/attention_bf16.hip      (reads qkv in place, writes [B, N, hidden])
+        x2 = x + dropout(ctx Wo^T + b)  gemm NT, bias + dropout + residual epilogue (fp32 residual stream)
+        h2 = LN2(x2)
+        a = dropout(gelu(h2 W1^T + b))  gemm NT, bias + GELU + dropout epilogue (pre-activation kept for the backward)
+        x3 = x2 + dropout(a W2^T + b)   gemm NT, bias + dropout + residual epilogue
+
+    Dropout masks are functions of (step seed word, site id, element index): nothing is stored, the backward recomputes
+    them in its epilogues (csrc/vit_common.h).  Weight gradients are fp32 (bf16 x bf16 products, fp32 sums, split over the
+    tokens with an ordered reduction); bias gradients are column sums (csrc/column_sum.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, wqkv, wo, w1, w2, ln1_w, ln1_b, q_w, k_w, v_w, q_b, k_b, v_b, o_w, o_b, ln2_w, ln2_b,
+                f1_w, f1_b, f2_w, f2_b):
+        S = sis_hip
+        heads, eps, p_proj, p_mlp, site, seed = cfg
+        b, n, hid = x.shape
+        m = b * n
+        x2d = x.reshape(m, hid)
+        h1, mean1, rstd1 = S.layer_norm_fwd(x2d, ln1_w, ln1_b, eps, torch.bfloat16)
+        qkv = S.gemm_bf16(h1, wqkv, S.GEMM_NT, S.EPI_BIAS, bias=(q_b, k_b, v_b))
+        att, lse = S.attention_fwd(qkv.view(b, n, 3 * hid), heads)
+        att2d = att.view(m, hid)
+        x2 = S.gemm_bf16(att2d, wo, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=o_b, resid=x2d, seed=seed, site=site, drop_p=p_proj)
+        h2, mean2, rstd2 = S.layer_norm_fwd(x2, ln2_w, ln2_b, eps, torch.bfloat16)
+        act, pre = S.gemm_bf16(h2, w1, S.GEMM_NT, S.EPI_BIAS_GELU_DROP, bias=f1_b, seed=seed, site=site + 1, drop_p=p_mlp)
+        x3 = S.gemm_bf16(act, w2, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=f2_b, resid=x2, seed=seed, site=site + 2, drop_p=p_mlp)
+        ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, pre, act, wqkv, wo, w1, w2, ln1_w, ln2_w)
+        ctx.cfg, ctx.shape = cfg, (b, n, hid)
+        return x3.view(b, n, hid)
+
+    @staticmethod
+    def backward(ctx, grad):
+        S = sis_hip
+        x2d, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, pre, act, wqkv, wo, w1, w2, ln1_w, ln2_w = ctx.saved_tensors
+        heads, eps, p_proj, p_mlp, site, seed = ctx.cfg
+        b, n, hid = ctx.shape
+        m = b * n
+        g3 = grad.reshape(m, hid)
+        if g3.dtype != torch.float32 or not g3.is_contiguous():
+            g3 = g3.float().contiguous()
+        mlp = w1.shape[0]
+        # ---- MLP
+        gl2 = S.dropout_bwd_cast(g3, seed, site + 2, p_mlp)                                   # d(fc2 output), bf16
+        d_w2 = S.gemm_bf16(gl2, act, S.GEMM_TN, S.EPI_F32, splits=_wgrad_splits(hid, mlp))
+        d_b2 = S.column_sum(gl2)
+        d_pre = S.gemm_bf16(gl2, w2, S.GEMM_NN, S.EPI_GELU_BWD, pre=pre, seed=seed, site=site + 1, drop_p=p_mlp)
+        d_w1 = S.gemm_bf16(d_pre, h2, S.GEMM_TN, S.EPI_F32, splits=_wgrad_splits(mlp, hid))
+        d_b1 = S.column_sum(d_pre)
+        d_h2 = S.gemm_bf16(d_pre, w1, S.GEMM_NN, S.EPI_NONE)
+        # LN2 backward + the skip connection's gradient, and d(out-projection output) = that sum through the proj dropout
+        g2, d_ln2_w, d_ln2_b, gl1 = S.layer_norm_bwd_fused(d_h2, x2, mean2, rstd2, ln2_w, residual_grad=g3, cast_seed=seed,
+                                                           cast_site=site, cast_p=p_proj)
+        # ---- attention
+        d_wo = S.gemm_bf16(gl1, att.view(m, hid), S.GEMM_TN, S.EPI_F32, splits=_wgrad_splits(hid, hid))
+        d_bo = S.column_sum(gl1)
+        d_att = S.gemm_bf16(gl1, wo, S.GEMM_NN, S.EPI_NONE)
+        d_qkv = S.attention_bwd(d_att.view(b, n, hid), qkv.view(b, n, 3 * hid), att, lse, heads).view(m, 3 * hid)
+        d_wqkv = S.gemm_bf16(d_qkv, h1, S.GEMM_TN, S.EPI_F32, splits=_wgrad_splits(3 * hid, hid))
+        d_bqkv = S.column_sum(d_qkv)
+        d_h1 = S.gemm_bf16(d_qkv, wqkv, S.GEMM_NN, S.EPI_NONE)
+        g1, d_ln1_w, d_ln1_b, _ = S.layer_norm_bwd_fused(d_h1, x2d, mean1, rstd1, ln1_w, residual_grad=g2)
+        d_q, d_k, d_v = d_wqkv.split(hid, 0)
+        d_qb, d_kb, d_vb = d_bqkv.split(hid, 0)
+        return (g1.view(b, n, hid), None, None, None, None, None, d_ln1_w, d_ln1_b, d_q, d_k, d_v, d_qb, d_kb, d_vb, d_wo, d_bo,
+                d_ln2_w, d_ln2_b, d_w1, d_b1, d_w2, d_b2)
+
+
 class Embeddings(nn.Module):
     """Patch + position embeddings; in hybrid mode the "patches" are 1x1 (or p x p) cells of the ResNetV2
     stride-16 feature map and the stem's intermediate maps are returned as decoder skips."""
@@ -341,7 +426,28 @@ class Block(nn.Module):
         self.ffn = Mlp(config)
         self.attn = Attention(config, vis)
 
+    block_index = 0   # set by the Encoder: numbers the block's three dropout sites (4 * index + 0 / 1 / 2)
+
+    def _fused_ok(self, x):
+        a, f = self.attn, self.ffn
+        return (_FUSED_BLOCK and _SHADOW and _AMP_LINEAR and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3
+                and x.is_contiguous() and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
+                and not a.vis and a.attention_head_size == 64 and not (self.training and a.attn_dropout.p > 0)
+                and a.query.weight.dtype == torch.float32 and self.hidden_size % 256 == 0 and f.fc1.out_features % 64 == 0
+                and f.act_fn is F.gelu and isinstance(self.attention_norm, LayerNorm))
+
     def forward(self, x):
+        if self._fused_ok(x):
+            a, f = self.attn, self.ffn
+            la, lf = a._shadows(), f._shadows()
+            training = self.training
+            cfg = (a.num_attention_heads, self.attention_norm.eps, a.proj_dropout.p if training else 0.0,
+                   f.dropout.p if training else 0.0, 4 * self.block_index, sis_hip.dropout_seed(x.device))
+            y = _FusedBlockFn.apply(x, cfg, la[0].tensor(), la[2].tensor(), lf[0].tensor(), lf[2].tensor(),
+                                    self.attention_norm.weight, self.attention_norm.bias, a.query.weight, a.key.weight,
+                                    a.value.weight, a.query.bias, a.key.bias, a.value.bias, a.out.weight, a.out.bias,
+                                    self.ffn_norm.weight, self.ffn_norm.bias, f.fc1.weight, f.fc1.bias, f.fc2.weight, f.fc2.bias)
+            return y, None
         a, weights = self.attn(self.attention_norm(x))
         x = x + a
         return x + self.ffn(self.ffn_norm(x)), weights
@@ -358,11 +464,17 @@ class Encoder(nn.Module):
         self.layer = nn.ModuleList()
         self.encoder_norm = LayerNorm(config.hidden_size, eps=1e-6)
         prototype = Block(config, vis)
-        for _ in range(config.transformer["num_layers"]):
-            self.layer.append(copy.deepcopy(prototype))
+        for i in range(config.transformer["num_layers"]):
+            block = copy.deepcopy(prototype)
+            block.block_index = i
+            self.layer.append(block)
 
     def forward(self, hidden_states):
         attn_weights = []
+        if self.training and hidden_states.is_cuda and _FUSED_BLOCK:
+            # one step of the device seed word per forward: every dropout site of the fused blocks reads it (and their
+            # backward reads it again); a captured hipGraph of the iteration replays this launch too
+            sis_hip.dropout_advance(sis_hip.dropout_seed(hidden_states.device))
         for block in self.layer:
             hidden_states, weights = block(hidden_states)
             if self.vis:

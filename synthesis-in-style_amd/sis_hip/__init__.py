@@ -47,7 +47,13 @@ _SIGNATURES = {
     "sis_conv3x3_eligible": ([_i] * 5, _i),
     "sis_upsample_bilinear": ([_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp], _i),
     "sis_gemm_bf16_workspace_bytes": ([_i, _i, _i], _i64),
-    "sis_gemm_bf16": ([_vp] * 4 + [_i] * 8 + [_vp] * 4 + [_i, _f, _i, _vp, _i64, _i, _vp], _i),
+    "sis_gemm_bf16": ([_vp] * 4 + [_i] * 8 + [_vp] * 3 + [_i] + [_vp] * 3 + [_i, _f, _i, _vp, _i64, _i, _vp], _i),
+    "sis_layer_norm_bwd_fused": ([_vp] * 9 + [_i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp], _i),
+    "sis_attention_fwd": ([_vp, _vp, _vp, _i, _i, _i, _vp], _i),
+    "sis_attention_bwd": ([_vp] * 6 + [_i, _i, _i, _vp], _i),
+    "sis_ce_dice_workspace_floats": ([_i], _i),
+    "sis_ce_dice_fwd": ([_vp] * 4 + [_i, _vp, _i, _i, _i, _vp], _i),
+    "sis_ce_dice_bwd": ([_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "sis_dropout_advance": ([_vp, _vp], _i),
     "sis_dropout_bwd_cast": ([_vp, _vp, _i64, _vp, _i, _f, _vp], _i),
     "sis_layer_norm_workspace_floats": ([_i], _i),
@@ -716,7 +722,6 @@ def conv_bf16_wgrad(x, grad_output, out_dtype=torch.float32):
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_DROP, EPI_BIAS_DROP_RESID, EPI_GELU_BWD, EPI_F32 = range(6)
-_GEMM_TILES = {0: (128, 128), 1: (256, 128), 2: (128, 256), 3: (256, 256)}
 
 
 def _rows2d(t, name):
@@ -746,8 +751,12 @@ def gemm_bf16(a, b, layout, epilogue=EPI_NONE, bias=None, resid=None, pre=None, 
     f32_out = epilogue in (EPI_BIAS_DROP_RESID, EPI_F32)
     c = torch.empty((m, n), dtype=torch.float32 if f32_out else torch.bfloat16, device=a.device)
     c2 = torch.empty((m, n), dtype=torch.bfloat16, device=a.device) if epilogue == EPI_BIAS_GELU_DROP else None
-    if bias is not None:
-        bias = _f32(bias, "bias")
+    b0, b1, b2, seg = bias, None, None, 0
+    if isinstance(bias, (tuple, list)):   # query | key | value: three parameters, one fused projection
+        b0, b1, b2 = (_f32(t, "bias") for t in bias)
+        seg = b0.numel()
+    elif bias is not None:
+        b0 = _f32(bias, "bias")
     if resid is not None:
         resid = _f32(resid, "residual")
         if tuple(resid.shape) != (m, n):
@@ -758,15 +767,77 @@ def gemm_bf16(a, b, layout, epilogue=EPI_NONE, bias=None, resid=None, pre=None, 
     if splits > 1:
         ws = _workspace(a.device)
         ws_bytes = ws.numel()
-    bm, bn = _GEMM_TILES[tile]
     name = f"gemm_bf16<{('NT', 'NN', 'TN')[layout]},{epilogue}>"
     with torch.cuda.device(a.device):
         _check(_launch(name, 2.0 * m * n * k, 2.0 * (m * k + n * k) + c.element_size() * m * n,
                        lambda: lib().sis_gemm_bf16(_ptr(c), _ptr(c2), _ptr(a), _ptr(b), layout, epilogue, m, n, k, a.stride(0),
-                                                   b.stride(0), n, _ptr(bias), _ptr(resid), _ptr(pre), _ptr(seed), int(site),
+                                                   b.stride(0), n, _ptr(b0), _ptr(b1), _ptr(b2), seg, _ptr(resid), _ptr(pre), _ptr(seed), int(site),
                                                    float(drop_p), int(splits), _ptr(ws), ws_bytes, int(tile), _stream())),
                "sis_gemm_bf16")
     return (c, c2) if c2 is not None else c
+
+
+def attention_fwd(qkv, heads):
+    """qkv bf16 [B, N, 3 * heads * 64] (query | key | value) -> (context bf16 [B, N, heads * 64], lse fp32 [B, heads, N])."""
+    require_device(qkv, "qkv")
+    if qkv.dtype != torch.bfloat16 or qkv.dim() != 3 or not qkv.is_contiguous() or qkv.shape[2] != 3 * heads * 64:
+        raise RuntimeError("attention_fwd: qkv must be a contiguous bfloat16 [B, N, 3 * heads * 64] tensor")
+    b, n, _ = qkv.shape
+    ctx = torch.empty((b, n, heads * 64), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((b, heads, n), dtype=torch.float32, device=qkv.device)
+    flops = 4.0 * b * heads * n * n * 64
+    with torch.cuda.device(qkv.device):
+        _check(_launch("attn_fwd_kernel", flops, 2.0 * (qkv.numel() + ctx.numel()),
+                       lambda: lib().sis_attention_fwd(_ptr(ctx), _ptr(lse), _ptr(qkv), b, n, heads, _stream())), "sis_attention_fwd")
+    return ctx, lse
+
+
+def attention_bwd(d_ctx, qkv, ctx, lse, heads):
+    """Gradient of ``attention_fwd`` w.r.t. qkv (bf16, qkv's layout)."""
+    if d_ctx.dtype != torch.bfloat16 or not d_ctx.is_contiguous() or d_ctx.shape != ctx.shape:
+        raise RuntimeError("attention_bwd: d_ctx must be a contiguous bfloat16 tensor of the context's shape")
+    b, n, _ = qkv.shape
+    d_qkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    flops = 14.0 * b * heads * n * n * 64   # 7 products (S and dP are recomputed by both kernels)
+    with torch.cuda.device(qkv.device):
+        _check(_launch("attn_bwd_kernels", flops, 2.0 * (2 * qkv.numel() + 2 * ctx.numel()),
+                       lambda: lib().sis_attention_bwd(_ptr(d_qkv), _ptr(delta), _ptr(d_ctx), _ptr(qkv), _ptr(ctx), _ptr(lse), b, n,
+                                                       heads, _stream())), "sis_attention_bwd")
+    return d_qkv
+
+
+def ce_dice_supported(logits, labels):
+    return (logits.is_cuda and logits.dtype in (torch.float32, torch.bfloat16) and logits.dim() >= 3 and 2 <= logits.shape[1] <= 8
+            and labels.dtype == torch.int64 and (logits[0, 0].numel() % 4 == 0))
+
+
+def ce_dice_fwd(logits, labels):
+    """logits [B,C,...] (f32 / bf16), labels int64 [B,...] -> (out3 = [0.5 ce + 0.5 dice, ce, dice], stats for the backward)."""
+    require_device(logits, "logits")
+    logits, labels = logits.contiguous(), labels.contiguous()
+    b, c = logits.shape[:2]
+    hw = logits[0, 0].numel()
+    out = torch.empty(3, dtype=torch.float32, device=logits.device)
+    stats = torch.empty(1 + 2 * c, dtype=torch.float32, device=logits.device)
+    ws = torch.empty(lib().sis_ce_dice_workspace_floats(c), dtype=torch.float32, device=logits.device)
+    with torch.cuda.device(logits.device):
+        _check(lib().sis_ce_dice_fwd(_ptr(out), _ptr(stats), _ptr(ws), _ptr(logits), _DTYPE_CODE[logits.dtype], _ptr(labels), b, c, hw,
+                                     _stream()), "sis_ce_dice_fwd")
+    return out, stats
+
+
+def ce_dice_bwd(grad_loss, logits, labels, stats):
+    logits, labels = logits.contiguous(), labels.contiguous()
+    b, c = logits.shape[:2]
+    hw = logits[0, 0].numel()
+    grad = torch.empty_like(logits)
+    if grad_loss is not None:
+        grad_loss = _f32(grad_loss, "grad_loss").reshape(1)
+    with torch.cuda.device(logits.device):
+        _check(lib().sis_ce_dice_bwd(_ptr(grad), _ptr(logits), _DTYPE_CODE[logits.dtype], _ptr(labels), _ptr(stats), _ptr(grad_loss), b, c,
+                                     hw, _stream()), "sis_ce_dice_bwd")
+    return grad
 
 
 _drop_seeds = {}
@@ -819,6 +890,28 @@ def layer_norm_fwd(x, gamma, beta, eps, out_dtype=None):
                                         _ptr(_f32(beta, "bias")), _DTYPE_CODE[x.dtype], _DTYPE_CODE[out_dtype], rows, n,
                                         float(eps), _stream()), "sis_layer_norm_fwd")
     return y, mean, rstd
+
+
+def layer_norm_bwd_fused(grad_y, x, mean, rstd, gamma, residual_grad=None, cast_seed=None, cast_site=None, cast_p=0.0):
+    """LayerNorm backward of a pre-norm residual block: dx = residual_grad + LN'(grad_y); with ``cast_site`` also returns
+    bf16(dx * dropout factor of that site) -> (dx, dgamma, dbeta, cast or None)."""
+    x = x.contiguous()
+    g = grad_y.contiguous()
+    n = x.shape[-1]
+    rows = x.numel() // n
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(n, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty_like(dgamma)
+    cast = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if cast_site is not None else None
+    if residual_grad is not None:
+        residual_grad = _f32(residual_grad, "residual_grad")
+    ws = torch.empty(lib().sis_layer_norm_workspace_floats(n), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_layer_norm_bwd_fused(_ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _ptr(g), _ptr(x), _ptr(mean), _ptr(rstd),
+                                              _ptr(gamma), _DTYPE_CODE[x.dtype], _DTYPE_CODE[g.dtype], rows, n, _ptr(residual_grad),
+                                              _ptr(cast), _ptr(cast_seed), int(cast_site or 0), float(cast_p), _stream()),
+               "sis_layer_norm_bwd_fused")
+    return dx, dgamma, dbeta, cast
 
 
 def layer_norm_bwd(grad_y, x, mean, rstd, gamma):

@@ -13,6 +13,8 @@ create, gradients are all-reduced by DistributedDataParallel over RCCL while bac
 Single-process training replays the whole iteration as a hipGraph after two eager iterations
 (training/graph_step.py; keyword ``hip_graph=False`` or SIS_STEP_GRAPH=0 keeps it eager).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -20,6 +22,9 @@ import sis_hip
 from networks.trans_u_net.utils import DiceLoss
 from training.graph_step import StepGraph
 from training.loop import GradientApplier, Updater, get_current_reporter
+
+
+_FUSED_LOSS = os.environ.get('SIS_FUSED_LOSS', '1') != '0'
 
 
 def _unwrap(network):
@@ -79,6 +84,24 @@ class EMANetUpdater(_GraphedUpdater):
         return {'softmax': loss.detach()}
 
 
+class _CeDiceFn(torch.autograd.Function):
+    """0.5 * CrossEntropy + 0.5 * Dice(softmax) on the logits as the segmentation head wrote them (bf16 under autocast), one
+    pass over them per direction (csrc/loss_ops.hip) -> (combined, CE, Dice); only ``combined`` carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        out, stats = sis_hip.ce_dice_fwd(logits, labels)
+        ctx.save_for_backward(logits, labels, stats)
+        ctx.mark_non_differentiable(out)
+        combined = out[0].clone()
+        return combined, out
+
+    @staticmethod
+    def backward(ctx, grad_combined, _grad_out):
+        logits, labels, stats = ctx.saved_tensors
+        return sis_hip.ce_dice_bwd(grad_combined, logits, labels, stats), None
+
+
 class TransUNetUpdater(_GraphedUpdater):
     def __init__(self, *args, **kwargs):
         num_classes = kwargs.pop('num_classes')
@@ -97,11 +120,15 @@ class TransUNetUpdater(_GraphedUpdater):
             with torch.autocast(device_type='cuda', dtype=self.amp_dtype or torch.bfloat16,
                                 enabled=self.amp_dtype is not None):
                 prediction = network(batch['images'])
-            prediction = prediction.float()
-            ground_truth = torch.squeeze(batch['segmented'], dim=1)
-            loss_ce = self.ce_loss(prediction, ground_truth.long())
-            loss_dice = self.dice_loss(prediction, ground_truth, softmax=True)
-            loss = 0.5 * loss_ce + 0.5 * loss_dice
+            ground_truth = torch.squeeze(batch['segmented'], dim=1).long()
+            if _FUSED_LOSS and sis_hip.ce_dice_supported(prediction, ground_truth) and prediction.shape[1] == self.dice_loss.n_classes:
+                loss, parts = _CeDiceFn.apply(prediction, ground_truth)   # the logits stay in the head's dtype
+                loss_ce, loss_dice = parts[1], parts[2]
+            else:
+                prediction = prediction.float()
+                loss_ce = self.ce_loss(prediction, ground_truth)
+                loss_dice = self.dice_loss(prediction, ground_truth, softmax=True)
+                loss = 0.5 * loss_ce + 0.5 * loss_dice
             loss.backward()
 
         return {'combined': loss.detach(), 'CE': loss_ce.detach(), 'Dice': loss_dice.detach()}

@@ -35,7 +35,7 @@ def _gelu_grad(x):
 NT_CASES = [(256, 256, 128), (128, 384, 64), (392, 768, 768), (1000, 2304, 768), (512, 768, 3072), (130, 132, 192)]
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("m,n,k", NT_CASES)
 def test_gemm_nt_epilogues(device, m, n, k, tile):
     import sis_hip as S
@@ -56,7 +56,7 @@ def test_gemm_nt_epilogues(device, m, n, k, tile):
     _close(S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_F32, tile=tile), y, F32_TOL)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (392, 768, 2304), (640, 3072, 768), (200, 136, 64)])
 def test_gemm_nn_data_gradient(device, m, n, k, tile):
     """dx = g W (W [k = out features][n = in features], read K-major through the transposing LDS reads)."""
@@ -70,7 +70,7 @@ def test_gemm_nn_data_gradient(device, m, n, k, tile):
     _close(S.gemm_bf16(gd, wd, S.GEMM_NN, S.EPI_GELU_BWD, pre=pd, tile=tile), y * _gelu_grad(pre.float()), BF16_TOL)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("m,n,k,splits", [(256, 256, 128, 1), (768, 768, 392, 1), (2304, 768, 2048, 4), (768, 3072, 1024, 8),
                                           (136, 264, 200, 2), (768, 768, 8192, 16)])
 def test_gemm_tn_weight_gradient(device, m, n, k, splits, tile):
@@ -115,8 +115,8 @@ def test_gemm_dropout_stream(device):
     mask = drop != 0
     frac = 1 - mask.float().mean().item()
     assert abs(frac - p) < 5e-3, frac
-    thr = int(p * 2 ** 32)
-    scale = 1 / (1 - thr / 2 ** 32)
+    thr = int(p * 65536 + 0.5)            # the probability is realised to 2^-16 (csrc/vit_common.h)
+    scale = 65536 / (65536 - thr)
     assert torch.allclose(drop[mask], plain[mask] * scale, rtol=1e-6, atol=0)
     # the backward of the same site: bf16(g * factor) with the identical mask
     g = torch.randn(m, n, generator=gen).to(device)
@@ -149,5 +149,5 @@ def test_gemm_full_size_qkv(device):
     x, w, b = _rand((8192, 768), gen), _rand((2304, 768), gen, 768 ** -0.5), torch.randn(2304, generator=gen)
     torch.set_num_threads(16)
     ref = x.float() @ w.float().t() + b
-    for tile in (0, 1, 2, 3):
+    for tile in range(8):
         _close(S.gemm_bf16(x.to(device), w.to(device), S.GEMM_NT, S.EPI_BIAS, bias=b.to(device), tile=tile), ref, BF16_TOL)
