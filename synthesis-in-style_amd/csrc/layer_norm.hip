@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(float* __restrict_
     }
 }
 
-constexpr int LN_BWD_BLOCKS = 128;  // workgroups of the backward pass = partial rows to add afterwards
+constexpr int LN_BWD_BLOCKS = 512;  // workgroups of the backward pass = partial rows to add afterwards
 
 }  // namespace
 

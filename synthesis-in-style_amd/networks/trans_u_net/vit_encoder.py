@@ -296,13 +296,64 @@ class Mlp(nn.Module):
 _FUSED_BLOCK = os.environ.get('SIS_FUSED_VIT', '1') != '0'  # 0: the module-by-module path (library GEMMs / attention)
 
 
-def _wgrad_splits(out_features, in_features):
-    """K slices of a weight-gradient GEMM (contraction over the tokens): enough 128 x 128 tiles x slices to fill 256 CUs twice."""
+def _wgrad_plan(out_features, in_features):
+    """(K slices, tile code) of a weight-gradient GEMM (contraction over the tokens), from tools/bench_gemm.py on MI355X at
+    8 192 tokens: enough 128 x 128 tiles x slices to fill the 256 CUs about twice; the 3072-wide MLP weights run faster on the
+    32-deep, 3-stage tile (three workgroups per CU) with 4 slices (68 vs 77-80 us)."""
     tiles = ((out_features + 127) // 128) * ((in_features + 127) // 128)
+    if tiles >= 128:
+        return 4, 4
     splits = 1
     while splits < 8 and tiles * splits * 2 <= 512:
         splits *= 2
-    return splits
+    return splits, 0
+
+
+_WGRAD_STREAMS = {}  # device -> side stream of the weight-gradient GEMMs (process-wide, like the generator's ToRGB stream)
+_WGRAD_SIDE = os.environ.get('SIS_WGRAD_STREAM', '0') != '0'   # measured: 273 vs 277 images/s with the side stream on -> off
+
+
+def _wgrad_stream(device):
+    if not _WGRAD_SIDE:
+        return None
+    st = _WGRAD_STREAMS.get(device)
+    if st is None:
+        st = _WGRAD_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+class _SideWgrads:
+    """Weight / bias gradients of a block's Linear layers on a side stream: they depend on the backward's activations'
+    gradients but nothing in the block's backward depends on them, so they fill the compute units the data-gradient GEMMs,
+    the attention backward and the LayerNorm kernels leave idle (tile-count tails of 8 192-token GEMMs on 256 CUs).  The main
+    stream joins once, before the gradients are handed to autograd.  Under hipGraph capture the fork / join become graph
+    edges."""
+
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        self.side = _wgrad_stream(device)
+        self.outputs = []
+
+    def run(self, grad, inp, out_features, in_features):
+        """(dW fp32 [out, in], db fp32 [out]) of y = inp W^T + b from grad = dL/dy (bf16 [tokens, out]), inp bf16 [tokens, in]."""
+        S = sis_hip
+        splits, tile = _wgrad_plan(out_features, in_features)
+        if self.side is None:
+            return S.gemm_bf16(grad, inp, S.GEMM_TN, S.EPI_F32, splits=splits, tile=tile), S.column_sum(grad)
+        self.side.wait_event(self.main.record_event())   # grad (and inp) are complete on the main stream
+        grad.record_stream(self.side)
+        inp.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            dw = S.gemm_bf16(grad, inp, S.GEMM_TN, S.EPI_F32, splits=splits, tile=tile)
+            db = S.column_sum(grad)
+        self.outputs += [dw, db]
+        return dw, db
+
+    def join(self):
+        if self.side is not None and self.outputs:
+            self.main.wait_event(self.side.record_event())
+            for t in self.outputs:
+                t.record_stream(self.main)   # allocated on the side stream, consumed (optimizer, all-reduce) on the main one
 
 
 class _FusedBlockFn(Function):
@@ -352,26 +403,24 @@ class _FusedBlockFn(Function):
         if g3.dtype != torch.float32 or not g3.is_contiguous():
             g3 = g3.float().contiguous()
         mlp = w1.shape[0]
+        wg = _SideWgrads(g3.device)
         # ---- MLP
         gl2 = S.dropout_bwd_cast(g3, seed, site + 2, p_mlp)                                   # d(fc2 output), bf16
-        d_w2 = S.gemm_bf16(gl2, act, S.GEMM_TN, S.EPI_F32, splits=_wgrad_splits(hid, mlp))
-        d_b2 = S.column_sum(gl2)
+        d_w2, d_b2 = wg.run(gl2, act, hid, mlp)
         d_pre = S.gemm_bf16(gl2, w2, S.GEMM_NN, S.EPI_GELU_BWD, pre=pre, seed=seed, site=site + 1, drop_p=p_mlp)
-        d_w1 = S.gemm_bf16(d_pre, h2, S.GEMM_TN, S.EPI_F32, splits=_wgrad_splits(mlp, hid))
-        d_b1 = S.column_sum(d_pre)
+        d_w1, d_b1 = wg.run(d_pre, h2, mlp, hid)
         d_h2 = S.gemm_bf16(d_pre, w1, S.GEMM_NN, S.EPI_NONE)
         # LN2 backward + the skip connection's gradient, and d(out-projection output) = that sum through the proj dropout
         g2, d_ln2_w, d_ln2_b, gl1 = S.layer_norm_bwd_fused(d_h2, x2, mean2, rstd2, ln2_w, residual_grad=g3, cast_seed=seed,
                                                            cast_site=site, cast_p=p_proj)
         # ---- attention
-        d_wo = S.gemm_bf16(gl1, att.view(m, hid), S.GEMM_TN, S.EPI_F32, splits=_wgrad_splits(hid, hid))
-        d_bo = S.column_sum(gl1)
+        d_wo, d_bo = wg.run(gl1, att.view(m, hid), hid, hid)
         d_att = S.gemm_bf16(gl1, wo, S.GEMM_NN, S.EPI_NONE)
         d_qkv = S.attention_bwd(d_att.view(b, n, hid), qkv.view(b, n, 3 * hid), att, lse, heads).view(m, 3 * hid)
-        d_wqkv = S.gemm_bf16(d_qkv, h1, S.GEMM_TN, S.EPI_F32, splits=_wgrad_splits(3 * hid, hid))
-        d_bqkv = S.column_sum(d_qkv)
+        d_wqkv, d_bqkv = wg.run(d_qkv, h1, 3 * hid, hid)
         d_h1 = S.gemm_bf16(d_qkv, wqkv, S.GEMM_NN, S.EPI_NONE)
         g1, d_ln1_w, d_ln1_b, _ = S.layer_norm_bwd_fused(d_h1, x2d, mean1, rstd1, ln1_w, residual_grad=g2)
+        wg.join()
         d_q, d_k, d_v = d_wqkv.split(hid, 0)
         d_qb, d_kb, d_vb = d_bqkv.split(hid, 0)
         return (g1.view(b, n, hid), None, None, None, None, None, d_ln1_w, d_ln1_b, d_q, d_k, d_v, d_qb, d_kb, d_vb, d_wo, d_bo,

@@ -765,7 +765,15 @@ def gemm_bf16(a, b, layout, epilogue=EPI_NONE, bias=None, resid=None, pre=None, 
         raise RuntimeError("gemm_bf16: the pre-activation must be a contiguous bfloat16 tensor of the output's shape")
     ws, ws_bytes = None, 0
     if splits > 1:
-        ws = _workspace(a.device)
+        # split-K slabs: one scratch buffer per (device, stream) -- the encoder's weight gradients run on a side stream while
+        # the main stream's convolution weight gradients use the per-device buffer
+        stream = torch.cuda.current_stream(a.device)
+        if stream == torch.cuda.default_stream(a.device):
+            ws = _workspace(a.device)
+        else:
+            ws = _workspaces.get((a.device, stream.cuda_stream))
+            if ws is None:
+                ws = _workspaces[(a.device, stream.cuda_stream)] = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=a.device)
         ws_bytes = ws.numel()
     name = f"gemm_bf16<{('NT', 'NN', 'TN')[layout]},{epilogue}>"
     with torch.cuda.device(a.device):
