@@ -205,15 +205,20 @@ int sis_ema_update(float* mu, const float* mu_batch, float momentum, float one_m
  *   sis_bn_stats    mean[c], invstd[c] = 1/sqrt(var_biased + eps)   (+ running stats with `momentum`)
  *   sis_bn_act_fwd  y = [relu]( gamma*(x-mean)*invstd + beta [+ residual] )     (eval: pass running statistics)
  *   sis_bn_act_bwd  dy' = dy*[y>0] (when relu); dbeta = sum dy'; dgamma = sum dy'*xhat;
- *                   dx = gamma*invstd*(dy' - mean(dy') - xhat*mean(dy'*xhat)); dresidual = dy' (when not NULL). */
+ *                   dx = gamma*invstd*(dy' - mean(dy') - xhat*mean(dy'*xhat)); dresidual = dy' (when not NULL).
+ * relu_mask (may be NULL): sis_bn_mask_words(batch, channels, hw) 64-bit words, one sign bit per element of y, written by
+ * sis_bn_act_fwd (relu != 0) and read by sis_bn_act_bwd INSTEAD of y (y may then be NULL): 1/8 byte per element for the ReLU
+ * gate in both backward passes instead of 4. */
 int64_t sis_bn_workspace_floats(int batch, int channels, int hw);
+int64_t sis_bn_mask_words(int batch, int channels, int hw);
 int sis_bn_stats(float* mean, float* invstd, float* running_mean, float* running_var, const float* x,
                  float* workspace, int batch, int channels, int hw, float eps, float momentum, void* stream);
 int sis_bn_act_fwd(float* y, const float* x, const float* residual, const float* mean, const float* invstd,
-                   const float* gamma, const float* beta, int batch, int channels, int hw, int relu, void* stream);
+                   const float* gamma, const float* beta, int batch, int channels, int hw, int relu, void* relu_mask,
+                   void* stream);
 int sis_bn_act_bwd(float* dx, float* dresidual, float* dgamma, float* dbeta, const float* dy, const float* y,
                    const float* x, const float* mean, const float* invstd, const float* gamma, float* workspace,
-                   int batch, int channels, int hw, int relu, void* stream);
+                   int batch, int channels, int hw, int relu, const void* relu_mask, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dataset-loop neighbours of Generator.forward (SURVEY.md §8f "next" rows 1 and 2).

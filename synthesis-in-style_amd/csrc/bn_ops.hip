@@ -15,6 +15,9 @@
 //
 // Algorithmic HBM bytes per element: forward 4*(2 reads + 1 write) (+4 with residual), backward 4*(6 reads + 1 write)
 // (+4 for the residual gradient); unfused ATen does forward BN (2r+1w) + ReLU (1r+1w) + add (2r+1w) + ReLU (1r+1w).
+// ReLU gate as a bit mask: the backward needs y only for its sign.  The forward apply pass can leave one bit per element
+// (four 64-bit ballots per wave and float4 column: word (i / 64) * 4 + e, bit i % 64 for component e of float4 i), and both
+// backward passes then read 1/8 byte instead of 4 bytes per element for the gate: backward 4*(4 reads + 1 write) + 2/8.
 #include "sis_common.h"
 
 namespace {
@@ -106,11 +109,16 @@ __global__ __launch_bounds__(64) void bn_stats_finish_kernel(float* __restrict__
     }
 }
 
+__device__ __forceinline__ bool gate_bit(const unsigned long long* __restrict__ mask, int64_t i4, int e) {
+    return (mask[(i4 >> 6) * 4 + e] >> (i4 & 63)) & 1ull;
+}
+
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(float4* __restrict__ y, const float4* __restrict__ x,
                                                          const float4* __restrict__ res, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, int C, int HW4, int64_t total4) {
+                                                         const float* __restrict__ beta, int C, int HW4, int64_t total4,
+                                                         unsigned long long* __restrict__ mask) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
         const int c = (int)((i / HW4) % C);
@@ -121,6 +129,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(float4* __restrict__ y,
         if (RES) { const float4 r = res[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
         if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         y[i] = v;
+        if (RELU && mask) {   // (i - lane is a multiple of 64: the wave's 64 float4s fill one group of four words)
+            const unsigned long long b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);
+            if ((threadIdx.x & 63) == 0) {
+                unsigned long long* m = mask + (i >> 6) * 4;
+                m[0] = b0; m[1] = b1; m[2] = b2; m[3] = b3;
+            }
+        }
     }
 }
 
@@ -128,7 +143,8 @@ template <bool RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(float* __restrict__ partial, const float* __restrict__ dy,
                                                             const float* __restrict__ y, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                            int C, int HW, int64_t n, int S) {
+                                                            int C, int HW, int64_t n, int S,
+                                                            const unsigned long long* __restrict__ mask) {
     __shared__ float red[4];
     const int c = blockIdx.x / S, s = blockIdx.x % S;
     const int64_t lo = (int64_t)s * BN_SLICE, hi = min(n, lo + BN_SLICE);
@@ -138,11 +154,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(float* __restrict__ 
         const int64_t a = w.addr();
         float4 g = *reinterpret_cast<const float4*>(dy + a);
         if (RELU) {
-            const float4 o = *reinterpret_cast<const float4*>(y + a);
-            if (!(o.x > 0.f)) g.x = 0.f;
-            if (!(o.y > 0.f)) g.y = 0.f;
-            if (!(o.z > 0.f)) g.z = 0.f;
-            if (!(o.w > 0.f)) g.w = 0.f;
+            if (mask) {
+                const int64_t i4 = a >> 2;
+                if (!gate_bit(mask, i4, 0)) g.x = 0.f;
+                if (!gate_bit(mask, i4, 1)) g.y = 0.f;
+                if (!gate_bit(mask, i4, 2)) g.z = 0.f;
+                if (!gate_bit(mask, i4, 3)) g.w = 0.f;
+            } else {
+                const float4 o = *reinterpret_cast<const float4*>(y + a);
+                if (!(o.x > 0.f)) g.x = 0.f;
+                if (!(o.y > 0.f)) g.y = 0.f;
+                if (!(o.z > 0.f)) g.z = 0.f;
+                if (!(o.w > 0.f)) g.w = 0.f;
+            }
         }
         const float4 xv = *reinterpret_cast<const float4*>(x + a);
         s1 += (g.x + g.y) + (g.z + g.w);
@@ -169,7 +193,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float4* __restrict__ 
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ sum_dy,
                                                            const float* __restrict__ sum_dy_xhat, int C, int HW4,
-                                                           int64_t total4, float inv_n) {
+                                                           int64_t total4, float inv_n,
+                                                           const unsigned long long* __restrict__ mask) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
         const int c = (int)((i / HW4) % C);
@@ -178,11 +203,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float4* __restrict__ 
         const float m1 = sum_dy[c] * inv_n, m2 = sum_dy_xhat[c] * inv_n;
         float4 g = dy[i];
         if (RELU) {
-            const float4 o = y[i];
-            if (!(o.x > 0.f)) g.x = 0.f;
-            if (!(o.y > 0.f)) g.y = 0.f;
-            if (!(o.z > 0.f)) g.z = 0.f;
-            if (!(o.w > 0.f)) g.w = 0.f;
+            if (mask) {
+                if (!gate_bit(mask, i, 0)) g.x = 0.f;
+                if (!gate_bit(mask, i, 1)) g.y = 0.f;
+                if (!gate_bit(mask, i, 2)) g.z = 0.f;
+                if (!gate_bit(mask, i, 3)) g.w = 0.f;
+            } else {
+                const float4 o = y[i];
+                if (!(o.x > 0.f)) g.x = 0.f;
+                if (!(o.y > 0.f)) g.y = 0.f;
+                if (!(o.z > 0.f)) g.z = 0.f;
+                if (!(o.w > 0.f)) g.w = 0.f;
+            }
         }
         if (RES) dres[i] = g;
         const float4 xv = x[i];
@@ -225,9 +257,13 @@ extern "C" int sis_bn_stats(float* mean, float* invstd, float* running_mean, flo
     return 0;
 }
 
+extern "C" int64_t sis_bn_mask_words(int batch, int channels, int hw) {
+    return (((int64_t)batch * channels * hw / 4 + 63) / 64) * 4;
+}
+
 extern "C" int sis_bn_act_fwd(float* y, const float* x, const float* residual, const float* mean, const float* invstd,
                               const float* gamma, const float* beta, int batch, int channels, int hw, int relu,
-                              void* stream) {
+                              void* relu_mask, void* stream) {
     if (check_geom("sis_bn_act_fwd", batch, channels, hw)) return 1;
     SIS_REQUIRE(y && x && mean && invstd, "sis_bn_act_fwd: null pointer");
     SIS_REQUIRE((((uintptr_t)y | (uintptr_t)x | (uintptr_t)residual) & 15) == 0, "sis_bn_act_fwd: 16-byte alignment");
@@ -236,7 +272,7 @@ extern "C" int sis_bn_act_fwd(float* y, const float* x, const float* residual, c
     const dim3 grid(ew_blocks(total4)), blk(256);
 #define SIS_BN_FWD(R, S_)                                                                                              \
     hipLaunchKernelGGL((bn_act_fwd_kernel<R, S_>), grid, blk, 0, st, (float4*)y, (const float4*)x, (const float4*)residual, \
-                       mean, invstd, gamma, beta, channels, hw / 4, total4)
+                       mean, invstd, gamma, beta, channels, hw / 4, total4, (unsigned long long*)relu_mask)
     if (relu && residual) SIS_BN_FWD(true, true);
     else if (relu) SIS_BN_FWD(true, false);
     else if (residual) SIS_BN_FWD(false, true);
@@ -248,10 +284,11 @@ extern "C" int sis_bn_act_fwd(float* y, const float* x, const float* residual, c
 
 extern "C" int sis_bn_act_bwd(float* dx, float* dresidual, float* dgamma, float* dbeta, const float* dy, const float* y,
                               const float* x, const float* mean, const float* invstd, const float* gamma, float* workspace,
-                              int batch, int channels, int hw, int relu, void* stream) {
+                              int batch, int channels, int hw, int relu, const void* relu_mask, void* stream) {
     if (check_geom("sis_bn_act_bwd", batch, channels, hw)) return 1;
     SIS_REQUIRE(dx && dgamma && dbeta && dy && x && mean && invstd && workspace, "sis_bn_act_bwd: null pointer");
-    SIS_REQUIRE(!relu || y, "sis_bn_act_bwd: the ReLU gate needs the forward output");
+    SIS_REQUIRE(!relu || y || relu_mask, "sis_bn_act_bwd: the ReLU gate needs the forward output or its sign mask");
+    const unsigned long long* mk = (const unsigned long long*)relu_mask;
     SIS_REQUIRE((((uintptr_t)dx | (uintptr_t)dresidual | (uintptr_t)dy | (uintptr_t)y | (uintptr_t)x) & 15) == 0,
                 "sis_bn_act_bwd: 16-byte alignment");
     const int64_t n = (int64_t)batch * hw;
@@ -259,10 +296,10 @@ extern "C" int sis_bn_act_bwd(float* dx, float* dresidual, float* dgamma, float*
     hipStream_t st = (hipStream_t)stream;
     if (relu)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(channels * S), dim3(256), 0, st, workspace, dy, y, x, mean, invstd,
-                           channels, hw, n, S);
+                           channels, hw, n, S, mk);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(channels * S), dim3(256), 0, st, workspace, dy, y, x, mean,
-                           invstd, channels, hw, n, S);
+                           invstd, channels, hw, n, S, mk);
     SIS_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(sis_cdiv(channels, 64)), dim3(64), 0, st, dbeta, dgamma, workspace, channels, S);
     SIS_CHECK_LAUNCH("bn_bwd_finish_kernel");
@@ -271,7 +308,7 @@ extern "C" int sis_bn_act_bwd(float* dx, float* dresidual, float* dgamma, float*
     const float inv_n = 1.f / (float)n;
 #define SIS_BN_BWD(R, S_)                                                                                              \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<R, S_>), grid, blk, 0, st, (float4*)dx, (float4*)dresidual, (const float4*)dy, \
-                       (const float4*)y, (const float4*)x, mean, invstd, gamma, dbeta, dgamma, channels, hw / 4, total4, inv_n)
+                       (const float4*)y, (const float4*)x, mean, invstd, gamma, dbeta, dgamma, channels, hw / 4, total4, inv_n, mk)
     if (relu && dresidual) SIS_BN_BWD(true, true);
     else if (relu) SIS_BN_BWD(true, false);
     else if (dresidual) SIS_BN_BWD(false, true);

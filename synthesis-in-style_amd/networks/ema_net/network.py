@@ -19,6 +19,7 @@ Differences in execution:
   profiles/r02_z_emanet_step_breakdown.txt).
 """
 import math
+import os
 import pathlib
 from functools import partial
 
@@ -34,6 +35,7 @@ from networks.hip_conv import HipConv2d
 from networks.hip_pool import HipMaxPool2d
 
 BN_MOM = 3e-4
+_RELU_MASK = os.environ.get('SIS_BN_RELU_MASK', '1') != '0'
 RESNET_BLOCKS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
 
 
@@ -47,8 +49,14 @@ class _FusedBatchNormAct(Function):
             mean, invstd = sis_hip.bn_stats(x, running_mean, running_var, eps, momentum)
         else:
             mean, invstd = running_mean, torch.rsqrt(running_var + eps)
-        y = sis_hip.bn_act_fwd(x, residual, mean, invstd, weight, bias, relu)
-        ctx.save_for_backward(x, y, mean, invstd, weight)
+        # with a ReLU the backward only needs the SIGN of y: the apply pass leaves one bit per element (csrc/bn_ops.hip) and
+        # both backward passes read that instead of the fp32 tensor
+        mask = None
+        if relu and training and _RELU_MASK:
+            y, mask = sis_hip.bn_act_fwd(x, residual, mean, invstd, weight, bias, relu, want_mask=True)
+        else:
+            y = sis_hip.bn_act_fwd(x, residual, mean, invstd, weight, bias, relu)
+        ctx.save_for_backward(x, None if mask is not None else y, mean, invstd, weight, mask)
         ctx.relu, ctx.training, ctx.has_residual = relu, training, residual is not None
         return y
 
@@ -56,9 +64,9 @@ class _FusedBatchNormAct(Function):
     def backward(ctx, dy):
         if not ctx.training:
             raise RuntimeError("fused batch norm: backward through evaluation-mode statistics is not implemented")
-        x, y, mean, invstd, weight = ctx.saved_tensors
+        x, y, mean, invstd, weight, mask = ctx.saved_tensors
         need_res = ctx.has_residual and ctx.needs_input_grad[1]
-        dx, dres, dgamma, dbeta = sis_hip.bn_act_bwd(dy.contiguous(), y, x, mean, invstd, weight, ctx.relu, need_res)
+        dx, dres, dgamma, dbeta = sis_hip.bn_act_bwd(dy.contiguous(), y, x, mean, invstd, weight, ctx.relu, need_res, mask=mask)
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None
 
 

@@ -87,8 +87,9 @@ _SIGNATURES = {
     "sis_ema_update": ([_vp, _vp, _f, _f, _i, _i, _vp], _i),
     "sis_bn_workspace_floats": ([_i, _i, _i], _i64),
     "sis_bn_stats": ([_vp] * 6 + [_i, _i, _i, _f, _f, _vp], _i),
-    "sis_bn_act_fwd": ([_vp] * 7 + [_i, _i, _i, _i, _vp], _i),
-    "sis_bn_act_bwd": ([_vp] * 11 + [_i, _i, _i, _i, _vp], _i),
+    "sis_bn_mask_words": ([_i, _i, _i], _i64),
+    "sis_bn_act_fwd": ([_vp] * 7 + [_i, _i, _i, _i, _vp, _vp], _i),
+    "sis_bn_act_bwd": ([_vp] * 11 + [_i, _i, _i, _i, _vp, _vp], _i),
     "sis_kmeans_assign": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "sis_make_image_u8": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "sis_crop_patches_u8": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -1204,16 +1205,20 @@ def bn_stats(x, running_mean, running_var, eps, momentum):
     return mean, invstd
 
 
-def bn_act_fwd(x, residual, mean, invstd, gamma, beta, relu):
+def bn_act_fwd(x, residual, mean, invstd, gamma, beta, relu, want_mask=False):
+    """y = [relu](bn(x) [+ residual]); ``want_mask`` (with relu): also the 1-bit-per-element sign mask the backward can read
+    instead of y -> (y, mask)."""
     b, c, h, w = x.shape
     y = torch.empty_like(x)
+    mask = torch.empty(lib().sis_bn_mask_words(b, c, h * w), dtype=torch.int64, device=x.device) if (want_mask and relu) else None
     with torch.cuda.device(x.device):
         _check(lib().sis_bn_act_fwd(_ptr(y), _ptr(x), _ptr(residual), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), b, c,
-                                    h * w, int(bool(relu)), _stream()), "sis_bn_act_fwd")
-    return y
+                                    h * w, int(bool(relu)), _ptr(mask), _stream()), "sis_bn_act_fwd")
+    return (y, mask) if want_mask else y
 
 
-def bn_act_bwd(dy, y, x, mean, invstd, gamma, relu, want_residual_grad):
+def bn_act_bwd(dy, y, x, mean, invstd, gamma, relu, want_residual_grad, mask=None):
+    """``mask`` (from ``bn_act_fwd(..., want_mask=True)``) replaces ``y`` as the ReLU gate (y may be None)."""
     b, c, h, w = x.shape
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_residual_grad else None
@@ -1222,6 +1227,6 @@ def bn_act_bwd(dy, y, x, mean, invstd, gamma, relu, want_residual_grad):
     ws = torch.empty(lib().sis_bn_workspace_floats(b, c, h * w), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _check(lib().sis_bn_act_bwd(_ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(dy), _ptr(y), _ptr(x), _ptr(mean),
-                                    _ptr(invstd), _ptr(gamma), _ptr(ws), b, c, h * w, int(bool(relu)), _stream()),
+                                    _ptr(invstd), _ptr(gamma), _ptr(ws), b, c, h * w, int(bool(relu)), _ptr(mask), _stream()),
                "sis_bn_act_bwd")
     return dx, dres, dgamma, dbeta

@@ -252,6 +252,36 @@ def test_full_size_winograd_agrees_with_direct_kernel(device, cin, cout, hw):
     assert err < 2e-5, err
 
 
+@pytest.mark.parametrize("cin,cout,hw", [(512, 512, 64), (128, 128, 256)])
+def test_full_size_layer_slice_vs_oracle(device, cin, cout, hw):
+    """BASELINE configs[1] layer sizes at B = 32 against the ORACLE (not against the build's other kernel): the batch-32
+    launch runs the persistent-workgroup / XCD-placement path; samples 0 and 31 of its output are compared with
+    ``R.modulated_conv2d`` (reference model.py:237-278 restated) evaluated on those two samples alone -- every sample of a
+    modulated convolution depends only on its own input and style, so the slice is exact, and it costs seconds of CPU."""
+    import sis_hip
+    g = torch.Generator().manual_seed(cin * 3 + hw)
+    b = 32
+    x = torch.randn(b, cin, hw, hw, generator=g)
+    style = torch.randn(b, 64, generator=g)
+    weight = torch.randn(1, cout, cin, 3, 3, generator=g)
+    mod_w, mod_b = torch.randn(cin, 64, generator=g), 1 + 0.1 * torch.randn(cin, generator=g)
+    noise, nw, bias = torch.randn(1, 1, hw, hw, generator=g), torch.tensor([0.1]), 0.1 * torch.randn(cout, generator=g)
+    pick = [0, 31]
+    with torch.no_grad():
+        torch.set_num_threads(16)
+        ref = R.modulated_conv2d(x[pick], style[pick], weight, mod_w, mod_b, demodulate=True)
+        ref = ops_ref.fused_leaky_relu(ref + nw * noise, bias)
+        d = lambda t: t.to(device)
+        wpk, wsq = sis_hip.modconv_prepack(d(weight))
+        s = sis_hip.equal_linear(d(style), d(mod_w), d(mod_b), 1 / 64 ** 0.5, 1.0, False)
+        ds = sis_hip.modconv_demod(s, wsq, 1 / (cin * 9) ** 0.5, True)
+        u = sis_hip.modconv_prepack_wino(d(weight))
+        for wino_u in (u, None):   # the Winograd kernel (what the generator runs at these sizes) and the direct one
+            y = sis_hip.modconv2d(d(x), wpk, s, ds, 3, d(noise), d(nw), d(bias), fuse_act=True, wino_u=wino_u)
+            assert tuple(y.shape) == (b, cout, hw, hw)
+            assert _rel(y[pick], ref) < 2e-5, (wino_u is not None, _rel(y[pick], ref))
+
+
 @pytest.mark.parametrize("size,cm,batch", [(512, 2, 3), (1024, 1, 1), (128, 2, 5), (64, 1, 1)])
 def test_generator_other_resolutions_vs_oracle(device, size, cm, batch):
     """Every size of ``get_channels`` (model.py:443-455) beyond the benchmarked 256: the narrow tails (64 / 32 / 16

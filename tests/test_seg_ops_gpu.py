@@ -139,3 +139,23 @@ def test_fused_batch_norm_act(device, b, c, h, w, relu, use_res):
         ye = bn(x.to(device), relu=relu)
         re = F.batch_norm(x.double(), rm, rv, gamma.double(), beta.double(), False, 3e-4, 1e-5)
         assert torch.allclose(ye.cpu().double(), F.relu(re) if relu else re, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,c,h,w,use_res", [(2, 8, 16, 16, False), (3, 5, 12, 20, True), (16, 64, 32, 32, True), (1, 3, 6, 6, False)])
+def test_batch_norm_relu_sign_mask_equals_the_output_gate(device, b, c, h, w, use_res):
+    """The 1-bit-per-element ReLU gate written by the forward apply pass gives bit-for-bit the backward that reads y itself
+    (csrc/bn_ops.hip: same arithmetic, only the source of [y > 0] differs), ragged last ballot group included."""
+    import sis_hip
+    gen = torch.Generator().manual_seed(b * 7 + c + h)
+    x = (torch.randn(b, c, h, w, generator=gen) * 2 + 0.5).to(device)
+    res = torch.randn(b, c, h, w, generator=gen).to(device) if use_res else None
+    dy = torch.randn(b, c, h, w, generator=gen).to(device)
+    gamma, beta = (1 + 0.1 * torch.randn(c, generator=gen)).to(device), (0.1 * torch.randn(c, generator=gen)).to(device)
+    mean, invstd = sis_hip.bn_stats(x, None, None, 1e-5, 3e-4)
+    y0 = sis_hip.bn_act_fwd(x, res, mean, invstd, gamma, beta, True)
+    y1, mask = sis_hip.bn_act_fwd(x, res, mean, invstd, gamma, beta, True, want_mask=True)
+    assert torch.equal(y0, y1) and mask.numel() == (((b * c * h * w) // 4 + 63) // 64) * 4
+    want = sis_hip.bn_act_bwd(dy, y0, x, mean, invstd, gamma, True, use_res)
+    got = sis_hip.bn_act_bwd(dy, None, x, mean, invstd, gamma, True, use_res, mask=mask)
+    for g, w_ in zip(got, want):
+        assert (g is None and w_ is None) or torch.equal(g, w_)
