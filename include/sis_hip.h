@@ -427,7 +427,8 @@ int sis_conv1x1_f32(float* y, const float* x, const float* weight, const float* 
  * bias_seg > 0: the bias is three vectors of bias_seg = n / 3 entries (bias, bias1, bias2: the query | key | value biases of the
  * fused projection stay three parameters); bias_seg = 0: one vector `bias`.
  * tile (BM x BN x BK, LDS stages): 0 = 128x128x64 / 2, 1 = 256x128x64 / 2, 2 = 128x256x64 / 2, 3 = 256x256x64 / 2,
- * 4 = 128x128x32 / 3, 5 = 128x128x32 / 4, 6 = 128x128x64 / 3, 7 = 256x128x64 / 3 (one wave per 64x64 sub-tile).  NT / NN need k % 64 == 0; n, ldc % 4 == 0;
+ * 4 = 128x128x32 / 3, 5 = 128x128x32 / 4, 6 = 128x128x64 / 3, 7 = 256x128x64 / 3 (one wave per 64x64 sub-tile),
+ * 8 = 128x96x64 / 2 (NT only; waves of 64x48: n = 768 / 2304 give 512 / 1536 tiles = whole rounds of 2 workgroups per CU).  NT / NN need k % 64 == 0; n, ldc % 4 == 0;
  * lda, ldb % 8 == 0; 16-byte aligned pointers.  m (and k for TN) need not be tile multiples. */
 #define SIS_GEMM_EPI_NONE 0
 #define SIS_GEMM_EPI_BIAS 1

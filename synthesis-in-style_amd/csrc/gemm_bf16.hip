@@ -56,7 +56,9 @@ template <int BM_, int BN_, bool AKM_, bool BKM_, int BK_ = 64, int NS_ = 2>
 struct GemmCfg {
     static constexpr int BM = BM_, BN = BN_, BK = BK_, NS = NS_;   // NS LDS stages: the DMA runs NS - 1 K steps ahead
     static constexpr bool AKM = AKM_, BKM = BKM_;       // operand is K-major in memory
-    static constexpr int WM = BM / 64, WN = BN / 64, WAVES = WM * WN, THREADS = WAVES * 64;
+    static constexpr int WNC = BN % 64 == 0 ? 64 : 48;   // columns of a wave's sub-tile: 64, or 48 for the 96-wide tile
+    static constexpr int NBK = WNC / 16;                 // 16-column MFMA blocks of a wave along N
+    static constexpr int WM = BM / 64, WN = BN / WNC, WAVES = WM * WN, THREADS = WAVES * 64;
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
     static constexpr int A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024;
     static constexpr int PA = (A_PIECES + WAVES - 1) / WAVES, PB = (B_PIECES + WAVES - 1) / WAVES;  // per wave
@@ -65,8 +67,9 @@ struct GemmCfg {
     static constexpr int KSUB = BK / 32;                // MFMA k-steps per stage
     static_assert(BK == 64 || BK == 32, "K step");
     static_assert(!AKM || BM >= 128, "K-major tiles need >= 16 chunks per row");
-    static_assert(!BKM || BN >= 128, "K-major tiles need >= 16 chunks per row");
+    static_assert(!BKM || BN >= 128, "K-major tiles need >= 16 chunks per row (the 96-wide tile is for row operands)");
     static_assert(A_PIECES % WAVES == 0 && B_PIECES % WAVES == 0, "pieces must divide over the waves");
+    static_assert(WN * WNC == BN && WM * 64 == BM, "wave layout");
     static_assert(LDS <= 160 * 1024, "stages exceed the LDS");
 };
 
@@ -183,23 +186,23 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
     }
     if constexpr (!C::BKM) {
 #pragma unroll
-        for (int ks = 0; ks < C::KSUB; ++ks) b_off[ks] = C::A_BYTES + (wn * 64 + i16) * C::RROW + (((4 * ks + g) ^ row_f<C::BK>(i16)) << 4);
+        for (int ks = 0; ks < C::KSUB; ++ks) b_off[ks] = C::A_BYTES + (wn * C::WNC + i16) * C::RROW + (((4 * ks + g) ^ row_f<C::BK>(wn * C::WNC + i16)) << 4);
     } else {
         constexpr int RB = 2 * C::BN;
         const int q = i16 >> 2, pp = i16 & 3;
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < C::NBK; ++b)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int krow = 8 * g + 4 * t + q;
-                const int ch = 2 * (wn * 4 + b) + (pp >> 1);
+                const int ch = 2 * (wn * C::NBK + b) + (pp >> 1);
                 b_off[b * 2 + t] = C::A_BYTES + krow * RB + ((ch ^ kmaj_f(krow)) << 4) + 8 * (pp & 1);
             }
     }
 
-    f32x4 acc[4][4];   // [n block][m block]
+    f32x4 acc[C::NBK][4];   // [n block][m block]
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < C::NBK; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -232,13 +235,13 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
         const unsigned char* st = lds + stage * C::STAGE;
 #pragma unroll
         for (int ks = 0; ks < C::KSUB; ++ks) {
-            bf16x8 a[4], b[4];
+            bf16x8 a[4], b[C::NBK];
 #pragma unroll
             for (int x = 0; x < 4; ++x) a[x] = frag(st, std::integral_constant<bool, C::AKM>(), a_off, 2 * C::BM, x, ks);
 #pragma unroll
-            for (int x = 0; x < 4; ++x) b[x] = frag(st, std::integral_constant<bool, C::BKM>(), b_off, 2 * C::BN, x, ks);
+            for (int x = 0; x < C::NBK; ++x) b[x] = frag(st, std::integral_constant<bool, C::BKM>(), b_off, 2 * C::BN, x, ks);
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
+            for (int tn = 0; tn < C::NBK; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[tn], a[tm], acc[tn][tm], 0, 0, 0);
@@ -256,10 +259,10 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
         if (p.drop_thr) key = sis_drop_key(p.seed, p.site);
     auto epilogue = [&](auto checked_t) {
         constexpr bool CHECKED = decltype(checked_t)::value;
-        float4 bq[4];
+        float4 bq[C::NBK];
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            const int n = n0 + wn * 64 + 16 * tn + 4 * g;
+        for (int tn = 0; tn < C::NBK; ++tn) {
+            const int n = n0 + wn * C::WNC + 16 * tn + 4 * g;
             bq[tn] = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (HAS_BIAS)
                 if (!CHECKED || n < p.N) {
@@ -272,8 +275,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
                 }
         }
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            const int n = n0 + wn * 64 + 16 * tn + 4 * g;
+        for (int tn = 0; tn < C::NBK; ++tn) {
+            const int n = n0 + wn * C::WNC + 16 * tn + 4 * g;
             const bool n_ok = !CHECKED || n < p.N;
             float4 r[4];
             uint2 h[4];
@@ -385,10 +388,23 @@ int dispatch(const GemmParams& p, int layout, int epi, hipStream_t st) {
     return sis_fail("sis_gemm_bf16: epilogue %d is not built for layout %d", epi, layout);
 }
 
+template <int BM, int BN, int BK, int NS>
+int dispatch_nt_only(const GemmParams& p, int epi, hipStream_t st) {
+    typedef GemmCfg<BM, BN, false, false, BK, NS> C;
+    switch (epi) {
+        case SIS_GEMM_EPI_NONE: return launch_gemm<C, SIS_GEMM_EPI_NONE>(p, st, "gemm_bf16_kernel<NT,128x96>");
+        case SIS_GEMM_EPI_BIAS: return launch_gemm<C, SIS_GEMM_EPI_BIAS>(p, st, "gemm_bf16_kernel<NT,128x96,bias>");
+        case SIS_GEMM_EPI_BIAS_GELU_DROP: return launch_gemm<C, SIS_GEMM_EPI_BIAS_GELU_DROP>(p, st, "gemm_bf16_kernel<NT,128x96,bias+gelu+dropout>");
+        case SIS_GEMM_EPI_BIAS_DROP_RESID: return launch_gemm<C, SIS_GEMM_EPI_BIAS_DROP_RESID>(p, st, "gemm_bf16_kernel<NT,128x96,bias+dropout+residual>");
+        case SIS_GEMM_EPI_F32: return launch_gemm<C, SIS_GEMM_EPI_F32>(p, st, "gemm_bf16_kernel<NT,128x96,f32>");
+    }
+    return sis_fail("sis_gemm_bf16: epilogue %d is not built for the 128 x 96 tile", epi);
+}
+
 struct TilePlan { int bm, bn, bk, ns; };
 // tile codes of the C ABI: (BM, BN, BK, LDS stages)
 constexpr TilePlan TILE_PLANS[] = {{128, 128, 64, 2}, {256, 128, 64, 2}, {128, 256, 64, 2}, {256, 256, 64, 2},
-                                   {128, 128, 32, 3}, {128, 128, 32, 4}, {128, 128, 64, 3}, {256, 128, 64, 3}};
+                                   {128, 128, 32, 3}, {128, 128, 32, 4}, {128, 128, 64, 3}, {256, 128, 64, 3}, {128, 96, 64, 2}};
 constexpr int N_TILE_PLANS = sizeof(TILE_PLANS) / sizeof(TILE_PLANS[0]);
 
 }  // namespace
@@ -458,7 +474,11 @@ switch (tile) {
         case 4: rc = dispatch<128, 128, 32, 3>(p, layout, epilogue, st); break;
         case 5: rc = dispatch<128, 128, 32, 4>(p, layout, epilogue, st); break;
         case 6: rc = dispatch<128, 128, 64, 3>(p, layout, epilogue, st); break;
-        default: rc = dispatch<256, 128, 64, 3>(p, layout, epilogue, st); break;
+        case 7: rc = dispatch<256, 128, 64, 3>(p, layout, epilogue, st); break;
+        default:   // 128 x 96: divides N = 768 and 2304 into tile counts that fill 2 workgroups per CU evenly (row operands only)
+            SIS_REQUIRE(layout == LAYOUT_NT, "sis_gemm_bf16: the 128 x 96 tile is built for the NT layout");
+            rc = dispatch_nt_only<128, 96, 64, 2>(p, epilogue, st);
+            break;
     }
     if (rc) return rc;
     if (splits > 1) {

@@ -384,10 +384,13 @@ class _FusedBlockFn(Function):
         qkv = S.gemm_bf16(h1, wqkv, S.GEMM_NT, S.EPI_BIAS, bias=(q_b, k_b, v_b))
         att, lse = S.attention_fwd(qkv.view(b, n, 3 * hid), heads)
         att2d = att.view(m, hid)
-        x2 = S.gemm_bf16(att2d, wo, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=o_b, resid=x2d, seed=seed, site=site, drop_p=p_proj)
+        # (N = hidden = 768 outputs: the 128 x 96 tile gives 512 tiles at 8 192 tokens = one full round of 2 workgroups per CU;
+        # 128 x 128 leaves a quarter of the slots empty: 46 vs 52 us for fc2, 21.7 vs 23.0 for the projection)
+        t96 = 8 if hid % 96 == 0 else 0
+        x2 = S.gemm_bf16(att2d, wo, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=o_b, resid=x2d, seed=seed, site=site, drop_p=p_proj, tile=t96)
         h2, mean2, rstd2 = S.layer_norm_fwd(x2, ln2_w, ln2_b, eps, torch.bfloat16)
         act, pre = S.gemm_bf16(h2, w1, S.GEMM_NT, S.EPI_BIAS_GELU_DROP, bias=f1_b, seed=seed, site=site + 1, drop_p=p_mlp)
-        x3 = S.gemm_bf16(act, w2, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=f2_b, resid=x2, seed=seed, site=site + 2, drop_p=p_mlp)
+        x3 = S.gemm_bf16(act, w2, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=f2_b, resid=x2, seed=seed, site=site + 2, drop_p=p_mlp, tile=t96)
         ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, pre, act, wqkv, wo, w1, w2, ln1_w, ln2_w)
         ctx.cfg, ctx.shape = cfg, (b, n, hid)
         return x3.view(b, n, hid)

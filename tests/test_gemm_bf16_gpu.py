@@ -35,7 +35,7 @@ def _gelu_grad(x):
 NT_CASES = [(256, 256, 128), (128, 384, 64), (392, 768, 768), (1000, 2304, 768), (512, 768, 3072), (130, 132, 192)]
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("m,n,k", NT_CASES)
 def test_gemm_nt_epilogues(device, m, n, k, tile):
     import sis_hip as S
@@ -149,5 +149,5 @@ def test_gemm_full_size_qkv(device):
     x, w, b = _rand((8192, 768), gen), _rand((2304, 768), gen, 768 ** -0.5), torch.randn(2304, generator=gen)
     torch.set_num_threads(16)
     ref = x.float() @ w.float().t() + b
-    for tile in range(8):
+    for tile in range(9):
         _close(S.gemm_bf16(x.to(device), w.to(device), S.GEMM_NT, S.EPI_BIAS, bias=b.to(device), tile=tile), ref, BF16_TOL)
