@@ -403,6 +403,11 @@ int sis_conv_bf16_wgrad(void* dw, int dw_dtype, const void* x, const void* grad_
 int sis_conv1x1_f32_supported(int cin, int cout, int hw);
 int sis_conv1x1_f32(float* y, const float* x, const float* weight, const float* bias, int batch, int cin, int cout, int hw,
                     int data_gradient, void* stream);
+/* dx [batch][cin][hw] = weight^T . dy + skip_grad: the data gradient of a bottleneck's first 1x1 convolution with the gradient
+ * that arrives over the identity shortcut (networks/ema_net/network.py:37-56: out = relu(bn3(...) + x)) added in the epilogue
+ * instead of by a separate element-wise pass. */
+int sis_conv1x1_f32_dgrad_add(float* dx, const float* dy, const float* weight, const float* skip_grad, int batch, int cin, int cout,
+                              int hw, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * bf16 GEMM with the Linear layers' element-wise tail fused into the epilogue (csrc/gemm_bf16.hip): the ViT encoder of

@@ -59,23 +59,36 @@ struct ChanWalk {
     }
 };
 
+// One workgroup per (channel, slice): a thread's 16 float4s of the slice are ALL requested before the first is used (one
+// memory latency per workgroup instead of 16 dependent ones: these workgroups are short, the pass is latency-bound), then the
+// mean and the centred second moment come out of the registers -- the slice is read once.
 __global__ __launch_bounds__(256) void bn_stats_kernel(float* __restrict__ partial, const float* __restrict__ x, int C,
                                                        int HW, int64_t n, int S) {
     __shared__ float red[4];
+    constexpr int PER = BN_SLICE / 1024;   // float4s per thread and slice
     const int c = blockIdx.x / S, s = blockIdx.x % S;
     const int64_t lo = (int64_t)s * BN_SLICE, hi = min(n, lo + BN_SLICE);
-    float sum = 0.f;
-    for (ChanWalk w(lo, hi, c, C, HW); w.valid(); w.next()) {
-        const float4 v = *reinterpret_cast<const float4*>(x + w.addr());
-        sum += (v.x + v.y) + (v.z + v.w);
+    float4 v[PER];
+    {
+        ChanWalk w(lo, hi, c, C, HW);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            v[k] = w.valid() ? *reinterpret_cast<const float4*>(x + w.addr()) : make_float4(0.f, 0.f, 0.f, 0.f);
+            w.next();
+        }
     }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
     const float cnt = (float)(hi - lo);
     const float mean = block_sum(sum, red) / cnt;
     float m2 = 0.f;
-    for (ChanWalk w(lo, hi, c, C, HW); w.valid(); w.next()) {
-        const float4 v = *reinterpret_cast<const float4*>(x + w.addr());
-        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-        m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (lo + (int64_t)threadIdx.x * 4 + (int64_t)k * 1024 < hi) {
+            const float d0 = v[k].x - mean, d1 = v[k].y - mean, d2 = v[k].z - mean, d3 = v[k].w - mean;
+            m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
     }
     m2 = block_sum(m2, red);
     if (threadIdx.x == 0) {
@@ -150,27 +163,43 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(float* __restrict__ 
     const int64_t lo = (int64_t)s * BN_SLICE, hi = min(n, lo + BN_SLICE);
     const float mu = mean[c], is = invstd[c];
     float s1 = 0.f, s2 = 0.f;
-    for (ChanWalk w(lo, hi, c, C, HW); w.valid(); w.next()) {
-        const int64_t a = w.addr();
-        float4 g = *reinterpret_cast<const float4*>(dy + a);
-        if (RELU) {
-            if (mask) {
-                const int64_t i4 = a >> 2;
-                if (!gate_bit(mask, i4, 0)) g.x = 0.f;
-                if (!gate_bit(mask, i4, 1)) g.y = 0.f;
-                if (!gate_bit(mask, i4, 2)) g.z = 0.f;
-                if (!gate_bit(mask, i4, 3)) g.w = 0.f;
-            } else {
-                const float4 o = *reinterpret_cast<const float4*>(y + a);
-                if (!(o.x > 0.f)) g.x = 0.f;
-                if (!(o.y > 0.f)) g.y = 0.f;
-                if (!(o.z > 0.f)) g.z = 0.f;
-                if (!(o.w > 0.f)) g.w = 0.f;
-            }
+    constexpr int UN = 4;   // float4 pairs requested before the first is used (memory-level parallelism, as in bn_stats_kernel)
+    for (ChanWalk w(lo, hi, c, C, HW); w.valid();) {
+        float4 gq[UN], xq[UN];
+        int64_t aq[UN];
+        bool ok[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            ok[u] = w.valid();
+            aq[u] = ok[u] ? w.addr() : 0;
+            gq[u] = ok[u] ? *reinterpret_cast<const float4*>(dy + aq[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xq[u] = ok[u] ? *reinterpret_cast<const float4*>(x + aq[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            w.next();
         }
-        const float4 xv = *reinterpret_cast<const float4*>(x + a);
-        s1 += (g.x + g.y) + (g.z + g.w);
-        s2 += (g.x * ((xv.x - mu) * is) + g.y * ((xv.y - mu) * is)) + (g.z * ((xv.z - mu) * is) + g.w * ((xv.w - mu) * is));
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (!ok[u]) continue;
+            float4 g = gq[u];
+            const float4 xv = xq[u];
+            const int64_t a = aq[u];
+            if (RELU) {
+                if (mask) {
+                    const int64_t i4 = a >> 2;
+                    if (!gate_bit(mask, i4, 0)) g.x = 0.f;
+                    if (!gate_bit(mask, i4, 1)) g.y = 0.f;
+                    if (!gate_bit(mask, i4, 2)) g.z = 0.f;
+                    if (!gate_bit(mask, i4, 3)) g.w = 0.f;
+                } else {
+                    const float4 o = *reinterpret_cast<const float4*>(y + a);
+                    if (!(o.x > 0.f)) g.x = 0.f;
+                    if (!(o.y > 0.f)) g.y = 0.f;
+                    if (!(o.z > 0.f)) g.z = 0.f;
+                    if (!(o.w > 0.f)) g.w = 0.f;
+                }
+            }
+            s1 += (g.x + g.y) + (g.z + g.w);
+            s2 += (g.x * ((xv.x - mu) * is) + g.y * ((xv.y - mu) * is)) + (g.z * ((xv.z - mu) * is) + g.w * ((xv.w - mu) * is));
+        }
     }
     s1 = block_sum(s1, red);
     s2 = block_sum(s2, red);

@@ -42,6 +42,7 @@ struct PwParams {
     const float* a;     // A_KMAJOR: [K][Mtot], else [Mtot][K]
     const float* bias;  // [Mtot] or null
     float* y;           // [N][Mtot][HW]
+    const float* accum; // [N][Mtot][HW] added to the result (data gradient + the skip connection's gradient) or null
     int N, K, M, HW, px_tiles;
 };
 
@@ -50,7 +51,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <typename C, bool A_KMAJOR, bool HAS_BIAS>
+template <typename C, bool A_KMAJOR, bool HAS_BIAS, bool HAS_ACC = false>
 __global__ __launch_bounds__(512, C::OCC) void conv1x1_f32_kernel(PwParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(512, C::OCC) void conv1x1_f32_kernel(PwParams p) {
             for (int i = 0; i < 16; ++i) bv[mb][i] = p.bias[min(mrow0 + mb * 32 + (i & 3) + 8 * (i >> 2), p.M - 1)];  // (rows >= M are not stored)
     }
     float* ybase = p.y + ((int64_t)n * p.M + mrow0) * p.HW + p0 + wn * (C::NB * 32) + r;
+    const float* abase = HAS_ACC ? p.accum + ((int64_t)n * p.M + mrow0) * p.HW + p0 + wn * (C::NB * 32) + r : nullptr;
     auto store_tile = [&](auto checked) {
 #pragma unroll
         for (int nb = 0; nb < C::NB; ++nb) {
@@ -180,7 +182,11 @@ __global__ __launch_bounds__(512, C::OCC) void conv1x1_f32_kernel(PwParams p) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int ro = mb * 32 + (i & 3) + 8 * (i >> 2);
-                    if (!decltype(checked)::value || mrow0 + ro < p.M) ybase[ro * p.HW + nb * 32] = HAS_BIAS ? acc[mb][nb][i] + bv[mb][i] : acc[mb][nb][i];
+                    if (!decltype(checked)::value || mrow0 + ro < p.M) {
+                        float v = HAS_BIAS ? acc[mb][nb][i] + bv[mb][i] : acc[mb][nb][i];
+                        if constexpr (HAS_ACC) v += abase[ro * p.HW + nb * 32];
+                        ybase[ro * p.HW + nb * 32] = v;
+                    }
                 }
         }
     };
@@ -191,10 +197,11 @@ __global__ __launch_bounds__(512, C::OCC) void conv1x1_f32_kernel(PwParams p) {
 template <typename C>
 int launch_pw(const PwParams& p, int a_kmajor, hipStream_t st, const char* name) {
     typedef void (*kern_t)(PwParams);
-    static const kern_t table[2][2] = {{conv1x1_f32_kernel<C, false, false>, conv1x1_f32_kernel<C, false, true>},
-                                       {conv1x1_f32_kernel<C, true, false>, conv1x1_f32_kernel<C, true, true>}};
-    static bool attr_set[2][2] = {};
-    const int km = a_kmajor ? 1 : 0, hb = p.bias ? 1 : 0;
+    static const kern_t table[3][2] = {{conv1x1_f32_kernel<C, false, false>, conv1x1_f32_kernel<C, false, true>},
+                                       {conv1x1_f32_kernel<C, true, false>, conv1x1_f32_kernel<C, true, true>},
+                                       {conv1x1_f32_kernel<C, true, false, true>, conv1x1_f32_kernel<C, true, false, true>}};
+    static bool attr_set[3][2] = {};
+    const int km = p.accum ? 2 : (a_kmajor ? 1 : 0), hb = p.bias ? 1 : 0;
     const kern_t kern = table[km][hb];
     if (!attr_set[km][hb]) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -236,14 +243,15 @@ int dispatch_pw(PwParams& p, int batch, int data_gradient, hipStream_t st) {
 
 extern "C" int sis_conv1x1_f32_supported(int cin, int cout, int hw) { return pw_ok(cin, cout, hw) && pw_ok(cout, cin, hw) ? 1 : 0; }
 
-extern "C" int sis_conv1x1_f32(float* y, const float* x, const float* weight, const float* bias, int batch, int cin, int cout,
-                               int hw, int data_gradient, void* stream) {
+static int conv1x1_impl(float* y, const float* x, const float* weight, const float* bias, const float* accum, int batch, int cin,
+                        int cout, int hw, int data_gradient, void* stream) {
     if (batch <= 0) return 0;
     SIS_REQUIRE(y && x && weight, "sis_conv1x1_f32: null pointer");
+    SIS_REQUIRE(!accum || (data_gradient && !bias && (((uintptr_t)accum) & 15) == 0), "sis_conv1x1_f32: the accumulate input is for the data gradient (no bias), 16-byte aligned");
     // forward: contraction over cin, A = weight [cout][cin] (m-major).  data gradient: x is dL/dy [batch][cout][hw], the
     // contraction runs over cout and A = the same weight tensor read as [k = cout][m = cin] (k-major); y is dL/dx.
     PwParams p;
-    p.x = x; p.a = weight; p.bias = bias; p.y = y; p.N = batch; p.HW = hw;
+    p.x = x; p.a = weight; p.bias = bias; p.y = y; p.accum = accum; p.N = batch; p.HW = hw;
     p.K = data_gradient ? cout : cin;
     p.M = data_gradient ? cin : cout;
     SIS_REQUIRE(pw_ok(p.K, p.M, hw), "sis_conv1x1_f32: %d -> %d channels on %d pixels (K %% 32, M %% 4, pixels %% 4 must be 0)", p.K, p.M, hw);
@@ -254,4 +262,15 @@ extern "C" int sis_conv1x1_f32(float* y, const float* x, const float* weight, co
     // 32-channel chunks (SIS_PW_KC=32): one workgroup per unit, half the barriers
     static const int kc = getenv("SIS_PW_KC") ? atoi(getenv("SIS_PW_KC")) : 16;
     return kc == 32 ? dispatch_pw<32>(p, batch, data_gradient, st) : dispatch_pw<16>(p, batch, data_gradient, st);
+}
+
+extern "C" int sis_conv1x1_f32(float* y, const float* x, const float* weight, const float* bias, int batch, int cin, int cout,
+                               int hw, int data_gradient, void* stream) {
+    return conv1x1_impl(y, x, weight, bias, nullptr, batch, cin, cout, hw, data_gradient, stream);
+}
+
+extern "C" int sis_conv1x1_f32_dgrad_add(float* dx, const float* dy, const float* weight, const float* skip_grad, int batch, int cin,
+                                         int cout, int hw, void* stream) {
+    SIS_REQUIRE(skip_grad, "sis_conv1x1_f32_dgrad_add: null pointer");
+    return conv1x1_impl(dx, dy, weight, nullptr, skip_grad, batch, cin, cout, hw, 1, stream);
 }

@@ -31,7 +31,7 @@ from torch.nn.modules.batchnorm import _BatchNorm
 
 import sis_hip
 from networks.base_segmenter import BaseSegmenter
-from networks.hip_conv import HipConv2d
+from networks.hip_conv import HipConv2d, pointwise_with_skip
 from networks.hip_pool import HipMaxPool2d
 
 BN_MOM = 3e-4
@@ -123,8 +123,13 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        shortcut = x if self.downsample is None else self.downsample(x)
-        y = self.bn1(self.conv1(x), relu=True)
+        fused = pointwise_with_skip(self.conv1, x) if self.downsample is None else None
+        if fused is not None:
+            y, shortcut = fused   # conv1(x) and the identity shortcut: their two gradients are summed in conv1's data-gradient kernel
+        else:
+            shortcut = x if self.downsample is None else self.downsample(x)
+            y = self.conv1(x)
+        y = self.bn1(y, relu=True)
         y = self.bn2(self.conv2(y), relu=True)
         return self.bn3(self.conv3(y), residual=shortcut, relu=True)
 

@@ -173,6 +173,54 @@ class _Pointwise(Function):
         return grad_input, grad_weight, grad_bias
 
 
+class _PointwiseWithSkip(Function):
+    """A bottleneck's first 1x1 convolution together with the identity shortcut that leaves from the same tensor:
+    forward(x, w) -> (conv1x1(x, w), x).  The shortcut output goes into the block's residual add, so the backward receives BOTH
+    gradients of x's two uses and the data-gradient kernel adds the shortcut's in its epilogue (``sis_conv1x1_f32_dgrad_add``)
+    -- the separate element-wise sum autograd would launch for a tensor with two consumers disappears (13 of EMANet-50's 16
+    bottlenecks; reference networks/ema_net/network.py:37-56)."""
+
+    @staticmethod
+    def forward(ctx, input, weight):
+        ctx.save_for_backward(input, weight)
+        ctx.set_materialize_grads(False)
+        return sis_hip.conv1x1_f32(input, weight), input.view_as(input)
+
+    @staticmethod
+    def backward(ctx, grad_output, grad_skip):
+        input, weight = ctx.saved_tensors
+        grad_input = grad_weight = None
+        if grad_output is None:
+            return grad_skip, None
+        grad_output = grad_output.contiguous()
+        if ctx.needs_input_grad[0]:
+            if grad_skip is not None:
+                grad_input = sis_hip.conv1x1_f32_dgrad_add(grad_output, weight, grad_skip.contiguous())
+            else:
+                grad_input = sis_hip.conv1x1_f32(grad_output, weight, data_gradient=True)
+        if ctx.needs_input_grad[1]:
+            if sis_hip.conv1x1_wgrad_f32_supported(grad_output, input):
+                grad_weight = sis_hip.conv1x1_wgrad_f32(grad_output, input)
+            else:
+                b, cin, h, w = input.shape
+                cout = weight.shape[0]
+                grad_weight = torch.bmm(grad_output.view(b, cout, h * w), input.view(b, cin, h * w).transpose(1, 2)).sum(0).view(cout, cin, 1, 1)
+        return grad_input, grad_weight
+
+
+def pointwise_with_skip(conv, input):
+    """(conv(input), input-as-shortcut) through ``_PointwiseWithSkip`` when ``conv`` is a plain fp32 1x1 layer the MFMA kernel
+    takes; None otherwise (the caller then runs conv and shortcut separately)."""
+    if (_F32_POINTWISE and _FUSE_SKIP_GRAD and isinstance(conv, HipConv2d) and conv._pointwise(input) and conv.bias is None
+            and not torch.is_autocast_enabled() and input.dtype == torch.float32 and torch.is_grad_enabled() and input.requires_grad
+            and sis_hip.conv1x1_f32_supported(input, conv.weight)):
+        return _PointwiseWithSkip.apply(input, conv.weight)   # (the support check covers forward and data gradient)
+    return None
+
+
+_FUSE_SKIP_GRAD = os.environ.get('SIS_FUSE_SKIP_GRAD', '1') != '0'
+
+
 def conv3x3_half_image_dilation(input, weight):
     """3x3 convolution whose dilation is half the image side (padding = dilation): every output pixel (u*d + p,
     v*d + q) only sees the 2 x 2 pixels {(u'*d + p, v'*d + q)} -- EMANet's last bottleneck (dilation 16 on 32 x 32).

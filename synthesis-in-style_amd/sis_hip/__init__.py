@@ -100,6 +100,7 @@ _SIGNATURES = {
     "sis_conv_bf16": ([_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp], _i),
     "sis_conv1x1_f32_supported": ([_i] * 3, _i),
     "sis_conv1x1_f32": ([_vp, _vp, _vp, _vp] + [_i] * 5 + [_vp], _i),
+    "sis_conv1x1_f32_dgrad_add": ([_vp, _vp, _vp, _vp] + [_i] * 4 + [_vp], _i),
     "sis_conv_bf16_pack_both": ([_vp, _vp, _vp, _i] + [_i] * 5 + [_vp], _i),
     "sis_conv_bf16_wgrad_supported": ([_i] * 5 + [_i64], _i),
     "sis_conv_bf16_wgrad": ([_vp, _i, _vp, _vp] + [_i] * 5 + [_vp, _i64, _vp], _i),
@@ -630,6 +631,23 @@ def conv1x1_f32(x, weight, bias=None, data_gradient=False):
         _check(_launch(None, 2.0 * b * cout * cin * h * wd, 4.0 * (x.numel() + out.numel() + w.numel()),
                        lambda: lib().sis_conv1x1_f32(_ptr(out), _ptr(x), _ptr(w), _ptr(bias), b, cin, cout, h * wd,
                                                      int(bool(data_gradient)), _stream())), "sis_conv1x1_f32")
+    return out
+
+
+def conv1x1_f32_dgrad_add(grad_output, weight, skip_grad):
+    """dL/dx of a 1x1 stride-1 fp32 convolution plus ``skip_grad`` (same shape as the result), one launch."""
+    g = _f32(grad_output, "grad_output")
+    w = _f32(weight, "weight")
+    skip = _f32(skip_grad, "skip_grad")
+    b, cout, h, wd = g.shape
+    cin = w.shape[1]
+    if tuple(skip.shape) != (b, cin, h, wd):
+        raise RuntimeError("conv1x1_f32_dgrad_add: skip_grad must have the input's shape")
+    out = torch.empty((b, cin, h, wd), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        _check(_launch(None, 2.0 * b * cout * cin * h * wd, 4.0 * (g.numel() + 2 * out.numel() + w.numel()),
+                       lambda: lib().sis_conv1x1_f32_dgrad_add(_ptr(out), _ptr(g), _ptr(w), _ptr(skip), b, cin, cout, h * wd, _stream())),
+               "sis_conv1x1_f32_dgrad_add")
     return out
 
 

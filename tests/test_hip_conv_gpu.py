@@ -150,3 +150,39 @@ def test_stride_2_layers_run_on_the_stride_1_kernels(device, batch, cin, cout, h
         want = want.detach().float()
         err = (got.detach() - want).abs().max().item() / want.abs().max().item()
         assert err < (2e-5 if name != "dw" else 2e-4), (name, err)
+
+
+def test_bottleneck_shortcut_gradient_is_summed_in_the_data_gradient_kernel(device, monkeypatch):
+    """EMANet bottleneck with an identity shortcut (networks/ema_net/network.py:37-56): the first 1x1 convolution's data
+    gradient adds the shortcut's gradient in its epilogue (csrc/conv1x1_f32.hip, ``sis_conv1x1_f32_dgrad_add``).  Output and
+    every gradient must equal the unfused block (autograd's separate sum) -- same kernels, the sum is the only difference, so
+    the input gradient agrees to fp32 round-off of one addition and everything else bitwise."""
+    import networks.hip_conv as hc
+    from networks.ema_net.network import Bottleneck
+    torch.manual_seed(3)
+    block = Bottleneck(256, 64).to(device).train()
+    x = torch.randn(4, 256, 32, 32, device=device)
+    gy = torch.randn(4, 256, 32, 32, device=device)
+
+    def run(fuse):
+        monkeypatch.setattr(hc, "_FUSE_SKIP_GRAD", fuse)
+        for p in block.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        y = block(xi)
+        y.backward(gy)
+        return y.detach(), xi.grad, [p.grad.clone() for p in block.parameters()]
+
+    y0, dx0, g0 = run(False)
+    y1, dx1, g1 = run(True)
+    assert torch.equal(y0, y1)
+    assert (dx0 - dx1).abs().max().item() <= 1e-6 * dx0.abs().max().item()
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    # and against plain torch modules in fp64 on the CPU (the reference's own composition)
+    import copy
+    ref = copy.deepcopy(block).cpu().double()
+    xr = x.cpu().double().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(gy.cpu().double())
+    assert (dx1.cpu().double() - xr.grad).abs().max().item() <= 2e-4 * xr.grad.abs().max().item()
