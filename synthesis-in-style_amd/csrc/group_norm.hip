@@ -67,7 +67,11 @@ __device__ __forceinline__ void gn_span(int64_t base, int lo, int hi, FS scalar,
         a0 = lo + (int)((VEC - ((base + lo) & (VEC - 1))) & (VEC - 1));
         if (a0 > hi) a0 = hi;
         a1 = a0 + ((hi - a0) & ~(VEC - 1));
-        for (int i = a0 + threadIdx.x * VEC; i < a1; i += 256 * VEC) vec(i);
+        // four vectors per trip: their loads are requested together (these workgroups are short and latency-bound, a dependent
+        // load-use chain per vector cost the statistics / reduction passes half their bandwidth)
+        int i = a0 + threadIdx.x * VEC;
+        for (; i + 3 * 256 * VEC < a1; i += 4 * 256 * VEC) { vec(i); vec(i + 256 * VEC); vec(i + 2 * 256 * VEC); vec(i + 3 * 256 * VEC); }
+        for (; i < a1; i += 256 * VEC) vec(i);
     }
     const int nh = a0 - lo, nt = hi - a1;
     for (int j = threadIdx.x; j < nh + nt; j += 256) scalar(j < nh ? lo + j : a1 + (j - nh));
