@@ -161,20 +161,40 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(TI* __restrict__ dx, float*
     }
 }
 
-// 64 columns per workgroup; wave w adds the partials k = w, w + 4, ... (fixed order), then the four are combined
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              const float* __restrict__ part, int n_part, int n) {
-    __shared__ float red[2][4][64];
+// 64 columns per workgroup of 16 waves; wave w adds the partials k = w, w + 16, ... (fixed order, 8 loads requested per trip),
+// then the sixteen are combined in a fixed tree: deterministic, and ~3 us for 512 partial rows instead of one chain of
+// dependent-latency loads per wave
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               const float* __restrict__ part, int n_part, int n) {
+    __shared__ float red[2][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float a = 0.f, b = 0.f;
-    if (c < n)
-        for (int k = wave; k < n_part; k += 4) { a += part[((int64_t)k * 2) * n + c]; b += part[((int64_t)k * 2 + 1) * n + c]; }
+    if (c < n) {
+        int k = wave;
+        for (; k + 7 * 16 < n_part; k += 8 * 16) {
+            float pa[8], pb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                pa[u] = part[((int64_t)(k + 16 * u) * 2) * n + c];
+                pb[u] = part[((int64_t)(k + 16 * u) * 2 + 1) * n + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += pa[u]; b += pb[u]; }
+        }
+        for (; k < n_part; k += 16) { a += part[((int64_t)k * 2) * n + c]; b += part[((int64_t)k * 2 + 1) * n + c]; }
+    }
     red[0][wave][lane] = a; red[1][wave][lane] = b;
     __syncthreads();
-    if (wave == 0 && c < n) {
-        dgamma[c] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
-        dbeta[c] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    if (wave < 2 && c < n) {   // wave 0: d(gamma), wave 1: d(beta)
+        float s[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s[w] = red[wave][w][lane];
+#pragma unroll
+        for (int st = 1; st < 16; st <<= 1)
+#pragma unroll
+            for (int w = 0; w < 16; w += 2 * st) s[w] += s[w + st];
+        (wave == 0 ? dgamma : dbeta)[c] = s[0];
     }
 }
 
@@ -231,7 +251,7 @@ static int ln_bwd_impl(void* dx, float* dgamma, float* dbeta, float* workspace, 
     else { LN_SWITCH_NJ(n / 256, LN_BWD(__hip_bfloat16, __hip_bfloat16)) }
 #undef LN_BWD
     SIS_CHECK_LAUNCH("ln_bwd_kernel");
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(sis_cdiv(n, 64)), dim3(256), 0, st, dgamma, dbeta, workspace, blocks, n);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(sis_cdiv(n, 64)), dim3(1024), 0, st, dgamma, dbeta, workspace, blocks, n);
     SIS_CHECK_LAUNCH("ln_param_reduce_kernel");
     return 0;
 }
