@@ -225,28 +225,59 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
     for (int s = 0; s < NS - 1; ++s)
         if (s < T) issue(s, s);
     int stage = 0;
-    for (int t = 0; t < T; ++t) {
+    // One K step.  All fragment reads of the step are requested up front (the second k-step's land behind the first one's
+    // MFMAs instead of each group of MFMAs waiting for the read issued just before it) and the DMA instructions of the next
+    // stage are spread between the MFMAs (sched_group_barrier: 1 DMA per 32 / PW MFMAs), so that their issue slots -- an
+    // LDS-DMA holds the wave's issue for tens of cycles -- fall under matrix work instead of in front of it.
+    auto step = [&](auto with_dma, int t) {
+        const unsigned char* st = lds + stage * C::STAGE;
+        bf16x8 a[C::KSUB][4], b[C::KSUB][C::NBK];
+#pragma unroll
+        for (int ks = 0; ks < C::KSUB; ++ks) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) a[ks][x] = frag(st, std::integral_constant<bool, C::AKM>(), a_off, 2 * C::BM, x, ks);
+#pragma unroll
+            for (int x = 0; x < C::NBK; ++x) b[ks][x] = frag(st, std::integral_constant<bool, C::BKM>(), b_off, 2 * C::BN, x, ks);
+        }
+        if constexpr (decltype(with_dma)::value) issue(t + NS - 1, stage == 0 ? NS - 1 : stage - 1);
+#pragma unroll
+        for (int ks = 0; ks < C::KSUB; ++ks)
+#pragma unroll
+            for (int tn = 0; tn < C::NBK; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ks][tn], a[ks][tm], acc[tn][tm], 0, 0, 0);
+        constexpr int READS = C::KSUB * ((C::AKM ? 8 : 4) + (C::BKM ? 2 : 1) * C::NBK);
+        constexpr int MFMAS = C::KSUB * 4 * C::NBK;
+        __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);   // every ds_read of the step first
+        if constexpr (decltype(with_dma)::value) {
+            constexpr int PER = (MFMAS / 2) / PW > 0 ? (MFMAS / 2) / PW : 1;   // the DMAs go under the FIRST half of the MFMAs:
+#pragma unroll                                                                  // the data then has the rest of the step to land
+            for (int i = 0; i < PW; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // one LDS-DMA (VMEM read)
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, MFMAS - PER * PW, 0);
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, MFMAS, 0);
+        }
+        stage = stage + 1 == NS ? 0 : stage + 1;
+    };
+    auto arrive = [&](int t) {
         const int ahead = min(NS - 2, T - 1 - t);   // K steps after t whose DMA is already in flight
         if (NS >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
         else if (NS >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of step t have landed
         __builtin_amdgcn_s_barrier();                           // ... everybody's; and everybody is done reading step t - 1's stage
-        if (t + NS - 1 < T) issue(t + NS - 1, stage == 0 ? NS - 1 : stage - 1);
-        const unsigned char* st = lds + stage * C::STAGE;
-#pragma unroll
-        for (int ks = 0; ks < C::KSUB; ++ks) {
-            bf16x8 a[4], b[C::NBK];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) a[x] = frag(st, std::integral_constant<bool, C::AKM>(), a_off, 2 * C::BM, x, ks);
-#pragma unroll
-            for (int x = 0; x < C::NBK; ++x) b[x] = frag(st, std::integral_constant<bool, C::BKM>(), b_off, 2 * C::BN, x, ks);
-#pragma unroll
-            for (int tn = 0; tn < C::NBK; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
-                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[tn], a[tm], acc[tn][tm], 0, 0, 0);
-        }
-        stage = stage + 1 == NS ? 0 : stage + 1;
+    };
+    int t = 0;
+    for (; t + NS - 1 < T; ++t) {   // steps that still have a stage to prefetch
+        arrive(t);
+        step(std::true_type(), t);
+    }
+    for (; t < T; ++t) {
+        arrive(t);
+        step(std::false_type(), t);
     }
 
     // ---- epilogue: lane = output row m (per m block), registers = 4 consecutive columns n.  Interior tiles (the usual

@@ -44,7 +44,7 @@ for name, n, k in (("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), (
     lib_fwd = timed(lambda: torch.addmm(b.bfloat16(), x, w.t()))
     lib_dx = timed(lambda: torch.mm(g, w))
     lib_dw = timed(lambda: torch.mm(g.t(), x, out_dtype=torch.float32))
-    for tile in (0, 8):
+    for tile in (0, 4):
         epi = {"qkv": S.EPI_BIAS, "fc1": S.EPI_BIAS_GELU_DROP}.get(name, S.EPI_BIAS_DROP_RESID)
         kw = dict(bias=b, tile=tile)
         if epi == S.EPI_BIAS_DROP_RESID:
