@@ -108,7 +108,11 @@ class _Bf16Shadow:
             self.buf = torch.empty((rows,) + tuple(first.shape[1:]), dtype=torch.bfloat16, device=first.device)
             self.key = None
         key = self._key()
-        if key != self.key:
+        # While a stream is being captured into a hipGraph, a copy nobody else keeps current is ALWAYS refreshed: the cast then
+        # becomes part of the graph and every replay re-derives it from the master weights (a replayed optimizer launch moves
+        # the weights without touching ``_version`` or the Python-side counter, so a key match at capture time proves nothing).
+        capturing = first.is_cuda and torch.cuda.is_current_stream_capturing() and not (self.bound is not None and self.bound is self.buf)
+        if key != self.key or capturing:
             with torch.no_grad():
                 row = 0
                 for p in self.params:

@@ -49,6 +49,7 @@ class FusedSGD(Optimizer):
             raise ValueError("shadow must be a contiguous bfloat16 tensor of the parameter's size")
         self._shadows[param] = shadow
         self._grad_key = None  # the pointer table gains a column entry
+
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)
 

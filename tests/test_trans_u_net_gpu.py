@@ -109,6 +109,9 @@ BF16_GRAD_NORM_RTOL = 0.08     # per-tensor gradient L2 norms, head + decoder   
 BF16_GRAD_REL_L2 = 0.60        # ||g - g_ref|| / ||g_ref|| of the head / decoder convolution weight gradients: 0.001 at the
 #                                head, growing to 0.31 at conv_more -- every ReLU whose pre-activation moved across zero flips a
 #                                whole gradient element while the norms stay put
+BF16_HEAD_GRAD_REL_L2 = 6e-3   # the segmentation head's weight gradient, element-wise relative L2 (measured 2.6e-3): error model =
+#                                one bf16 rounding of the logits' gradient (2^-9) x sqrt(2) for the two operands of the weight-gradient
+#                                product, ~3e-3; a kernel whose error doubled fails here although its norm stays inside the 8 % above
 BF16_LABEL_AGREEMENT = 0.96    # pixels whose argmax equals the fp32 oracle's (measured 0.981); NO disagreement is allowed
 #                                where the fp32 top-2 margin exceeds twice the measured max error (55 % of the pixels)
 FP32_CONTROL_REL_L2 = 1e-4     # the same product path in fp32 against the oracle: logits relative L2 (measured 1.0e-5 / 2.9e-5)
@@ -179,6 +182,11 @@ def _check_bf16_report(report, tag):
     worst = max(report["grad_norm_rel"].items(), key=lambda kv: kv[1])
     assert worst[1] < BF16_GRAD_NORM_RTOL, worst
     assert max(report["grad_rel_l2"].values()) < BF16_GRAD_REL_L2, report["grad_rel_l2"]
+    # tight where no ReLU flip can hide a wrong gradient: the segmentation head sits directly under the loss (measured 2.6e-3),
+    # the last decoder convolution one ReLU below it (measured 2.7e-2); the transformer blocks are pinned separately, per
+    # block and without any ReLU in the way, by tests/test_vit_block_gpu.py
+    assert report["grad_rel_l2"]["segmentation_head.0.weight"] < BF16_HEAD_GRAD_REL_L2, report["grad_rel_l2"]
+    assert report["grad_rel_l2"]["decoder.blocks.3.conv2.0.weight"] < 0.06, report["grad_rel_l2"]
     assert report["label_mismatches_where_decided"] == 0 and report["label_agreement"] > BF16_LABEL_AGREEMENT, report
     assert report["fp32_control_logits_rel_l2"] < FP32_CONTROL_REL_L2, report["fp32_control_logits_rel_l2"]
 
