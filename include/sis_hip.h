@@ -447,6 +447,19 @@ int sis_gemm_bf16(void* c, void* c2, const void* a, const void* b, int layout, i
                   const void* pre, const void* seed, int site, float drop_p, int splits, void* workspace,
                   int64_t workspace_bytes, int tile, void* stream);
 
+/* The same kernel over `batches` problems (grid.y): A / B / C of entry i start i * {a,b,c}_batch_stride elements after the base
+ * pointers (stride 0 = shared operand).  With sum_over_batches != 0 the entries are the K slices of ONE result instead
+ * (C fp32 [m][n] = sum_i op(A_i) op(B_i), ordered slab reduction through `workspace`; batches must be 1, 2, 4 or a multiple
+ * of 8).  This is how the bf16 1x1 convolutions of TransUNet's ResNetV2 trunk run on NCHW tensors
+ * (networks/trans_u_net/vit_seg_modeling_resnet_skip.py:30-37 conv1x1 / StdConv2d): per image
+ *   forward          y_i [cout][hw] = W [cout][cin] . x_i [cin][hw]        layout NN, A shared
+ *   data gradient    dx_i [cin][hw] = W^T . dy_i                           layout TN, A = W read K-major, shared
+ *   weight gradient  dW [cout][cin] = sum_i dy_i [cout][hw] . x_i^T        layout NT, summed over the images
+ * epilogue: SIS_GEMM_EPI_NONE (bf16) or SIS_GEMM_EPI_F32. */
+int sis_gemm_bf16_batched(void* c, const void* a, const void* b, int layout, int epilogue, int m, int n, int k, int lda, int ldb,
+                          int ldc, int batches, int64_t a_batch_stride, int64_t b_batch_stride, int64_t c_batch_stride,
+                          int sum_over_batches, void* workspace, int64_t workspace_bytes, int tile, void* stream);
+
 /* Dropout stream of the fused ViT-encoder kernels (csrc/vit_elementwise.hip; nn.Dropout of vit_seg_modeling.py:70-71,108,138).
  *   sis_dropout_advance   steps the 64-bit device seed word once per training iteration (graph-capturable).
  *   sis_dropout_bwd_cast  out bf16[numel] = grad fp32[numel] * dropout_factor(seed, site, element index): the gradient of

@@ -150,7 +150,7 @@ __device__ __forceinline__ bool map_block(const AttnParams& p, int& pair, int& b
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     int pair, blk;
@@ -187,14 +187,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         if (t + 1 < tiles) issue(t + 1, (t + 1) & 1);
         const unsigned char* kt = lds + (t & 1) * STAGE_BYTES;
         const unsigned char* vt = kt + TILE_BYTES;
+        // Every fragment of a phase is requested before the phase's first MFMA (left to itself the compiler reads one fragment,
+        // waits for it, multiplies, reads the next: eight exposed LDS latencies per product); the V^T fragments of the second
+        // product are requested before the softmax arithmetic, which does not need them, and land underneath it.
         f32x16 s[2];
+        bf16x8 kfr[2][4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kfr[kb][ks] = row_frag(kt, io, kb, ks);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, io, kb, ks), qf[ks], s[kb], 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][ks], qf[ks], s[kb], 0, 0, 0);
         }
+        bf16x8 vfr[2][4];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) vfr[db][kk] = tr_frag(vt, io, db, kk);
+        __builtin_amdgcn_sched_barrier(0);
         if (t * 64 + 64 > p.N) {   // last, partial tile: keys past the end do not exist
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int sx = 0; sx < 2; ++sx)
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(vt, io, db, 2 * kb + sx), pf[kb][sx], oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[db][2 * kb + sx], pf[kb][sx], oacc[db], 0, 0, 0);
     }
     const float l_tot = half_sum(l_run);
     const int q = q0 + r32;
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     int pair, blk;
@@ -302,10 +317,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
             f32x16 s, dp;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[i] = s_init; dp[i] = -dl; }
+            bf16x8 kfr[4], vfr[4];   // all eight row fragments of this key block before its first MFMA
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, io, kb, ks), qf[ks], s, 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) { kfr[ks] = row_frag(kt, io, kb, ks); vfr[ks] = row_frag(vt, io, kb, ks); }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(vt, io, kb, ks), gf[ks], dp, 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[ks], s, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ks], gf[ks], dp, 0, 0, 0);
             const bool partial = t * 64 + 64 > p.N;
 #pragma unroll
             for (int sx = 0; sx < 2; ++sx) {
@@ -320,13 +339,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
                 dsf[kb][sx] = pack8(e);
             }
         }
+        bf16x8 ktr[2][4];   // K^T fragments of the third product, all requested first
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) ktr[db][kk] = tr_frag(kt, io, db, kk);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int sx = 0; sx < 2; ++sx)
-                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(kt, io, db, 2 * kb + sx), dsf[kb][sx], dq[db], 0, 0, 0);
+                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktr[db][2 * kb + sx], dsf[kb][sx], dq[db], 0, 0, 0);
     }
     __builtin_amdgcn_s_barrier();
     store_rows(lds + wave * 4096, dq, p.scale, p.d_qkv + ((long long)b * p.N) * ldq + hd * HD, ldq, q0, p.N, lane);
@@ -395,10 +420,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
                 s[4 * g4] = -l4.x * inv_scale; s[4 * g4 + 1] = -l4.y * inv_scale; s[4 * g4 + 2] = -l4.z * inv_scale; s[4 * g4 + 3] = -l4.w * inv_scale;
                 dp[4 * g4] = -d4.x; dp[4 * g4 + 1] = -d4.y; dp[4 * g4 + 2] = -d4.z; dp[4 * g4 + 3] = -d4.w;
             }
+            bf16x8 qfr[4], gfr[4];   // all eight row fragments of this query block before its first MFMA
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(qt, io, qb, ks), kf[ks], s, 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) { qfr[ks] = row_frag(qt, io, qb, ks); gfr[ks] = row_frag(gt, io, qb, ks); }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(gt, io, qb, ks), vf[ks], dp, 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[ks], kf[ks], s, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[ks], vf[ks], dp, 0, 0, 0);
+            bf16x8 gtr[2][2], qtr[2][2];   // the transposed fragments of the two gradient products: requested before the
+#pragma unroll                                // exponentials, which do not need them
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) { gtr[db][sx] = tr_frag(gt, io, db, 2 * qb + sx); qtr[db][sx] = tr_frag(qt, io, db, 2 * qb + sx); }
+            __builtin_amdgcn_sched_barrier(0);
             const bool partial = t * 64 + 64 > p.N;
             bf16x8 pf[2], dsf[2];
 #pragma unroll
@@ -419,8 +454,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
             for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int sx = 0; sx < 2; ++sx) {
-                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(gt, io, db, 2 * qb + sx), pf[sx], dv[db], 0, 0, 0);
-                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(qt, io, db, 2 * qb + sx), dsf[sx], dk[db], 0, 0, 0);
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtr[db][sx], pf[sx], dv[db], 0, 0, 0);
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtr[db][sx], dsf[sx], dk[db], 0, 0, 0);
                 }
         }
     }

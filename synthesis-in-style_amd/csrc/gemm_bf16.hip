@@ -50,6 +50,11 @@ struct GemmParams {
     const unsigned long long* seed; unsigned site, drop_thr; float drop_scale;   // drop_thr: 16-bit threshold
     int m_tiles, n_tiles, splits, ksteps_per_split;
     long long slab_stride;        // elements between the fp32 partial slabs of a split-K run
+    // batches (grid.y): independent problems with their own A / B / C (element strides; 0 = shared operand).  batch_k != 0:
+    // the batch index is the split index instead -- every slice contracts ONE batch entry's whole K and the slabs are summed
+    // (sum over the images of a convolution's weight gradient)
+    int batch_k, grid_batches;
+    long long a_bstride, b_bstride, c_bstride;
 };
 
 template <int BM_, int BN_, bool AKM_, bool BKM_, int BK_ = 64, int NS_ = 2>
@@ -112,11 +117,15 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
     }
     const int m0 = mt * C::BM, n0 = nt * C::BN;
     const int ks_total = (p.K + C::BK - 1) / C::BK;
-    const int ks_begin = split * p.ksteps_per_split;
+    const int ks_begin = p.batch_k ? 0 : split * p.ksteps_per_split;
     const int T = min(p.ksteps_per_split, ks_total - ks_begin);   // K steps of this workgroup (>= 1 by construction)
 
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+    const long long bidx = p.batch_k ? split : (long long)blockIdx.y;
+    const u16* Ab = (const u16*)p.A + bidx * p.a_bstride;
+    const u16* Bb = (const u16*)p.B + bidx * p.b_bstride;
+    const long long c_batch = p.batch_k ? 0 : (long long)blockIdx.y * p.c_bstride;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(Ab), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(Bb), 0, p.b_bytes, 0x00020000);
 
     // ---- DMA source offsets of this lane (bytes from the operand base, K step 0), fixed over the loop
     int a_src[C::PA], b_src[C::PB];
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
             for (int tm = 0; tm < 4; ++tm) {
                 const int m = m0 + wm * 64 + 16 * tm + i16;
                 const bool ok = n_ok && (!CHECKED || m < p.M);
-                const long long at = (long long)m * p.ldc + n;
+                const long long at = c_batch + (long long)m * p.ldc + n;
                 float keep[4] = {1.f, 1.f, 1.f, 1.f};
                 if constexpr (HAS_DROP)
                     if (p.drop_thr) sis_drop_quad(key, ((unsigned)m * (unsigned)p.N + (unsigned)n) >> 2, p.drop_thr, p.drop_scale, keep);
@@ -388,7 +397,7 @@ int launch_gemm(const GemmParams& p, hipStream_t st, const char* name) {
     else if (p.splits >= 8) groups = p.m_tiles * p.n_tiles * (p.splits / 8);
     else groups = sis_cdiv((int64_t)p.m_tiles * p.n_tiles, 8 / p.splits);
     SIS_OCC_REPORT((gemm_bf16_kernel<C, EPI>), C::THREADS, C::LDS);
-    hipLaunchKernelGGL((gemm_bf16_kernel<C, EPI>), dim3(8 * groups), dim3(C::THREADS), C::LDS, st, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<C, EPI>), dim3(8 * groups, p.batch_k ? 1 : p.grid_batches), dim3(C::THREADS), C::LDS, st, p);
     SIS_CHECK_LAUNCH(name);
     sis_kernel_name = name;
     return 0;
@@ -415,6 +424,7 @@ int dispatch(const GemmParams& p, int layout, int epi, hipStream_t st) {
     } else {
         typedef GemmCfg<BM, BN, true, true, BK, NS> C;
         if (epi == SIS_GEMM_EPI_F32) return launch_gemm<C, SIS_GEMM_EPI_F32>(p, st, "gemm_bf16_kernel<TN,f32>");
+        if (epi == SIS_GEMM_EPI_NONE) return launch_gemm<C, SIS_GEMM_EPI_NONE>(p, st, "gemm_bf16_kernel<TN>");
     }
     return sis_fail("sis_gemm_bf16: epilogue %d is not built for layout %d", epi, layout);
 }
@@ -444,11 +454,11 @@ extern "C" int64_t sis_gemm_bf16_workspace_bytes(int m, int n, int splits) {
     return splits > 1 ? (int64_t)splits * m * n * 4 : 0;
 }
 
-extern "C" int sis_gemm_bf16(void* c, void* c2, const void* a, const void* b, int layout, int epilogue, int m, int n, int k,
-                             int lda, int ldb, int ldc, const float* bias, const float* bias1, const float* bias2, int bias_seg,
-                             const float* resid, const void* pre,
-                             const void* seed, int site, float drop_p, int splits, void* workspace, int64_t workspace_bytes,
-                             int tile, void* stream) {
+static int gemm_impl(void* c, void* c2, const void* a, const void* b, int layout, int epilogue, int m, int n, int k,
+                     int lda, int ldb, int ldc, const float* bias, const float* bias1, const float* bias2, int bias_seg,
+                     const float* resid, const void* pre,
+                     const void* seed, int site, float drop_p, int splits, void* workspace, int64_t workspace_bytes,
+                     int tile, int batches, int batch_k, int64_t a_bstride, int64_t b_bstride, int64_t c_bstride, void* stream) {
     if (m <= 0 || n <= 0) return 0;
     SIS_REQUIRE(c && a && b, "sis_gemm_bf16: null pointer");
     SIS_REQUIRE(layout >= 0 && layout <= 2, "sis_gemm_bf16: layout %d (0 NT, 1 NN, 2 TN)", layout);
@@ -485,10 +495,17 @@ extern "C" int sis_gemm_bf16(void* c, void* c2, const void* a, const void* b, in
     const int bm = TILE_PLANS[tile].bm, bn = TILE_PLANS[tile].bn, bk = TILE_PLANS[tile].bk;
     p.m_tiles = sis_cdiv(m, bm); p.n_tiles = sis_cdiv(n, bn);
     const int ksteps = sis_cdiv(k, bk);
-    if (splits > ksteps) splits = 1;
+    if (splits > ksteps && !batch_k) splits = 1;
     p.ksteps_per_split = sis_cdiv(ksteps, splits);
     SIS_REQUIRE((splits - 1) * p.ksteps_per_split < ksteps, "sis_gemm_bf16: %d splits leave an empty slice of %d K steps", splits, ksteps);
     p.splits = splits; p.slab_stride = (long long)m * ldc;
+    p.batch_k = batch_k; p.grid_batches = batches; p.a_bstride = a_bstride; p.b_bstride = b_bstride; p.c_bstride = c_bstride;
+    if (batch_k) {   // one slice per batch entry, each over the whole K
+        SIS_REQUIRE(epilogue == SIS_GEMM_EPI_F32 && (batches == 1 || batches == 2 || batches == 4 || batches % 8 == 0),
+                    "sis_gemm_bf16_batched: summing over %d batch entries needs the fp32 epilogue and 1, 2, 4 or a multiple of 8 entries", batches);
+        p.splits = splits = batches;
+        p.ksteps_per_split = ksteps;
+    }
     hipStream_t st = (hipStream_t)stream;
     float* result = (float*)c;
     if (splits > 1) {
@@ -519,4 +536,25 @@ switch (tile) {
         SIS_CHECK_LAUNCH("gemm_slab_reduce_kernel");
     }
     return 0;
+}
+
+extern "C" int sis_gemm_bf16(void* c, void* c2, const void* a, const void* b, int layout, int epilogue, int m, int n, int k,
+                             int lda, int ldb, int ldc, const float* bias, const float* bias1, const float* bias2, int bias_seg,
+                             const float* resid, const void* pre,
+                             const void* seed, int site, float drop_p, int splits, void* workspace, int64_t workspace_bytes,
+                             int tile, void* stream) {
+    return gemm_impl(c, c2, a, b, layout, epilogue, m, n, k, lda, ldb, ldc, bias, bias1, bias2, bias_seg, resid, pre, seed, site, drop_p,
+                     splits, workspace, workspace_bytes, tile, 1, 0, 0, 0, 0, stream);
+}
+
+extern "C" int sis_gemm_bf16_batched(void* c, const void* a, const void* b, int layout, int epilogue, int m, int n, int k, int lda,
+                                     int ldb, int ldc, int batches, int64_t a_batch_stride, int64_t b_batch_stride,
+                                     int64_t c_batch_stride, int sum_over_batches, void* workspace, int64_t workspace_bytes, int tile,
+                                     void* stream) {
+    if (batches <= 0) return 0;
+    SIS_REQUIRE(epilogue == SIS_GEMM_EPI_NONE || epilogue == SIS_GEMM_EPI_F32, "sis_gemm_bf16_batched: epilogue %d (plain bf16 or fp32 results only)", epilogue);
+    SIS_REQUIRE(batches < 65536, "sis_gemm_bf16_batched: %d batch entries", batches);
+    SIS_REQUIRE(a_batch_stride % 8 == 0 && b_batch_stride % 8 == 0 && c_batch_stride % 4 == 0, "sis_gemm_bf16_batched: batch strides must keep 16-byte alignment");
+    return gemm_impl(c, nullptr, a, b, layout, epilogue, m, n, k, lda, ldb, ldc, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0.f,
+                     1, workspace, workspace_bytes, tile, batches, sum_over_batches ? 1 : 0, a_batch_stride, b_batch_stride, c_batch_stride, stream);
 }

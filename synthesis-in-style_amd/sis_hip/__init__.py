@@ -48,6 +48,7 @@ _SIGNATURES = {
     "sis_upsample_bilinear": ([_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp], _i),
     "sis_gemm_bf16_workspace_bytes": ([_i, _i, _i], _i64),
     "sis_gemm_bf16": ([_vp] * 4 + [_i] * 8 + [_vp] * 3 + [_i] + [_vp] * 3 + [_i, _f, _i, _vp, _i64, _i, _vp], _i),
+    "sis_gemm_bf16_batched": ([_vp] * 3 + [_i] * 9 + [_i64] * 3 + [_i, _vp, _i64, _i, _vp], _i),
     "sis_layer_norm_bwd_fused": ([_vp] * 9 + [_i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp], _i),
     "sis_attention_fwd": ([_vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "sis_attention_bwd": ([_vp] * 6 + [_i, _i, _i, _vp], _i),
@@ -802,6 +803,48 @@ def gemm_bf16(a, b, layout, epilogue=EPI_NONE, bias=None, resid=None, pre=None, 
                                                    float(drop_p), int(splits), _ptr(ws), ws_bytes, int(tile), _stream())),
                "sis_gemm_bf16")
     return (c, c2) if c2 is not None else c
+
+
+def _batched_operand(t, name):
+    """[batches, rows, cols] (or [rows, cols], shared by every batch entry) -> (tensor, rows, cols, row stride, batch stride)."""
+    if t.dim() == 2:
+        t = _rows2d(t, name)
+        return t, t.shape[0], t.shape[1], t.stride(0), 0, 1
+    if t.dim() != 3 or t.dtype != torch.bfloat16 or t.stride(2) != 1 or t.stride(1) % 8 or t.data_ptr() % 16 or t.stride(0) % 8:
+        raise RuntimeError(f"gemm_bf16_batched: {name} must be [batches, rows, cols] bfloat16 with unit column stride and 16-byte aligned rows")
+    return t, t.shape[1], t.shape[2], t.stride(1), t.stride(0), t.shape[0]
+
+
+def gemm_bf16_batched(a, b, layout, epilogue=EPI_NONE, sum_over_batches=False, tile=0):
+    """``gemm_bf16`` over a batch of problems in one launch; 2-D operands are shared by all entries.  ``sum_over_batches``:
+    one fp32 result = the sum of the entries' products (EPI_F32; 1, 2, 4 or a multiple of 8 entries)."""
+    require_device(a, "a")
+    a, ar, ac, lda, abs_, na = _batched_operand(a, "a")
+    b, br, bc, ldb, bbs, nb = _batched_operand(b, "b")
+    batches = max(na, nb)
+    if (na not in (1, batches)) or (nb not in (1, batches)):
+        raise RuntimeError("gemm_bf16_batched: batch counts differ")
+    if layout == GEMM_NT:
+        (m, k), (n, k2) = (ar, ac), (br, bc)
+    elif layout == GEMM_NN:
+        (m, k), (k2, n) = (ar, ac), (br, bc)
+    else:
+        (k, m), (k2, n) = (ar, ac), (br, bc)
+    if k != k2:
+        raise RuntimeError(f"gemm_bf16_batched: contraction lengths differ ({k} vs {k2})")
+    dtype = torch.float32 if epilogue == EPI_F32 else torch.bfloat16
+    c = torch.empty((m, n) if sum_over_batches else (batches, m, n), dtype=dtype, device=a.device)
+    ws, ws_bytes = None, 0
+    if sum_over_batches and batches > 1:
+        ws = _workspace(a.device)
+        ws_bytes = ws.numel()
+    with torch.cuda.device(a.device):
+        _check(_launch(f"gemm_bf16_batched<{('NT', 'NN', 'TN')[layout]}>", 2.0 * batches * m * n * k,
+                       2.0 * batches * (m * k + n * k) + c.element_size() * c.numel(),
+                       lambda: lib().sis_gemm_bf16_batched(_ptr(c), _ptr(a), _ptr(b), layout, epilogue, m, n, k, lda, ldb, n, batches,
+                                                           abs_, bbs, 0 if sum_over_batches else m * n, int(bool(sum_over_batches)),
+                                                           _ptr(ws), ws_bytes, int(tile), _stream())), "sis_gemm_bf16_batched")
+    return c
 
 
 def attention_fwd(qkv, heads):

@@ -151,3 +151,32 @@ def test_gemm_full_size_qkv(device):
     ref = x.float() @ w.float().t() + b
     for tile in range(9):
         _close(S.gemm_bf16(x.to(device), w.to(device), S.GEMM_NT, S.EPI_BIAS, bias=b.to(device), tile=tile), ref, BF16_TOL)
+
+
+@pytest.mark.parametrize("batch,cin,cout,hw", [(2, 128, 256, 1024), (8, 512, 128, 4096), (3, 256, 1024, 1024), (4, 64, 72, 256)])
+def test_gemm_batched_as_pointwise_convolution(device, batch, cin, cout, hw):
+    """The three GEMMs of a bf16 1x1 convolution on NCHW tensors, one launch each (sis_gemm_bf16_batched): forward (NN, the
+    weight shared by the images), data gradient (TN: the same weight tensor read K-major), weight gradient (NT summed over the
+    images), against fp32 CPU arithmetic on the bf16-rounded operands (F.conv2d and its autograd: the reference's
+    vit_seg_modeling_resnet_skip.py:30-37 conv1x1)."""
+    import torch.nn.functional as F
+    import sis_hip as S
+    gen = torch.Generator().manual_seed(batch + cin + cout)
+    x = torch.randn(batch, cin, hw, generator=gen).bfloat16()
+    w = (torch.randn(cout, cin, generator=gen) * cin ** -0.5).bfloat16()
+    gy = torch.randn(batch, cout, hw, generator=gen).bfloat16()
+    xr = x.float().view(batch, cin, hw, 1).requires_grad_(True)
+    wr = w.float().view(cout, cin, 1, 1).requires_grad_(True)
+    yr = F.conv2d(xr, wr)
+    yr.backward(gy.float().view(batch, cout, hw, 1))
+    xd, wd, gd = x.to(device), w.to(device), gy.to(device)
+    y = S.gemm_bf16_batched(wd, xd, S.GEMM_NN)
+    assert tuple(y.shape) == (batch, cout, hw)
+    _close(y, yr.detach().view(batch, cout, hw), BF16_TOL)
+    dx = S.gemm_bf16_batched(wd, gd, S.GEMM_TN)
+    _close(dx, xr.grad.view(batch, cin, hw), BF16_TOL)
+    if batch in (1, 2, 4) or batch % 8 == 0:
+        dw = S.gemm_bf16_batched(gd, xd, S.GEMM_NT, S.EPI_F32, sum_over_batches=True)
+        assert dw.dtype == torch.float32 and tuple(dw.shape) == (cout, cin)
+        _close(dw, wr.grad.view(cout, cin), F32_TOL)
+        assert torch.equal(dw, S.gemm_bf16_batched(gd, xd, S.GEMM_NT, S.EPI_F32, sum_over_batches=True))
