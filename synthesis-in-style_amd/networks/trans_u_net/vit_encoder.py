@@ -314,7 +314,7 @@ def _wgrad_plan(out_features, in_features):
 
 
 _WGRAD_STREAMS = {}  # device -> side stream of the weight-gradient GEMMs (process-wide, like the generator's ToRGB stream)
-_WGRAD_SIDE = os.environ.get('SIS_WGRAD_STREAM', '0') != '0'   # measured: 273 vs 277 images/s with the side stream on -> off
+_WGRAD_SIDE = int(os.environ.get('SIS_WGRAD_STREAM', '0'))   # 1: weight-gradient GEMMs + column sums on a side stream (measured 273 vs 277 images/s: off); 2: column sums only
 
 
 def _wgrad_stream(device):
@@ -346,6 +346,12 @@ class _SideWgrads:
             return S.gemm_bf16(grad, inp, S.GEMM_TN, S.EPI_F32, splits=splits, tile=tile), S.column_sum(grad)
         self.side.wait_event(self.main.record_event())   # grad (and inp) are complete on the main stream
         grad.record_stream(self.side)
+        if _WGRAD_SIDE == 2:   # only the small column-sum kernels leave the main stream
+            dw = S.gemm_bf16(grad, inp, S.GEMM_TN, S.EPI_F32, splits=splits, tile=tile)
+            with torch.cuda.stream(self.side):
+                db = S.column_sum(grad)
+            self.outputs += [db]
+            return dw, db
         inp.record_stream(self.side)
         with torch.cuda.stream(self.side):
             dw = S.gemm_bf16(grad, inp, S.GEMM_TN, S.EPI_F32, splits=splits, tile=tile)
@@ -385,12 +391,13 @@ class _FusedBlockFn(Function):
         m = b * n
         x2d = x.reshape(m, hid)
         h1, mean1, rstd1 = S.layer_norm_fwd(x2d, ln1_w, ln1_b, eps, torch.bfloat16)
-        qkv = S.gemm_bf16(h1, wqkv, S.GEMM_NT, S.EPI_BIAS, bias=(q_b, k_b, v_b))
+        # (128 x 96 tiles where the output width divides by 96: 768 -> 512 tiles, 2304 -> 1536 tiles at 8 192 tokens = whole
+        # rounds of 2 workgroups per CU; 128 x 128 leaves the last round a quarter full: 42.6 vs 46.3 us for the projection
+        # below, 46 vs 52 us for fc2, 21.7 vs 23.0 for the output projection)
+        t96 = 8 if hid % 96 == 0 else 0
+        qkv = S.gemm_bf16(h1, wqkv, S.GEMM_NT, S.EPI_BIAS, bias=(q_b, k_b, v_b), tile=t96)
         att, lse = S.attention_fwd(qkv.view(b, n, 3 * hid), heads)
         att2d = att.view(m, hid)
-        # (N = hidden = 768 outputs: the 128 x 96 tile gives 512 tiles at 8 192 tokens = one full round of 2 workgroups per CU;
-        # 128 x 128 leaves a quarter of the slots empty: 46 vs 52 us for fc2, 21.7 vs 23.0 for the projection)
-        t96 = 8 if hid % 96 == 0 else 0
         x2 = S.gemm_bf16(att2d, wo, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=o_b, resid=x2d, seed=seed, site=site, drop_p=p_proj, tile=t96)
         h2, mean2, rstd2 = S.layer_norm_fwd(x2, ln2_w, ln2_b, eps, torch.bfloat16)
         act, pre = S.gemm_bf16(h2, w1, S.GEMM_NT, S.EPI_BIAS_GELU_DROP, bias=f1_b, seed=seed, site=site + 1, drop_p=p_mlp)
