@@ -4,11 +4,13 @@
 // moments, normalise, (ReLU), cast back -- and twice that in backward; here one launch per direction reads the
 // convolution's bf16 output and writes what the next convolution consumes.
 //
-// Three launches per direction, each fully parallel: (1) one workgroup per (sample, channel) plane reduces it -- mean /
-// M2 forward, sum(g') / sum(g' * xhat) backward (g' = g masked by the recomputed ReLU: nothing but x is saved);
-// (2) a tiny per-group kernel merges the planes of a group (Chan's formula, fixed order: deterministic) into per-plane
-// scale / shift coefficients; (3) a grid-strided element-wise kernel applies them (4 elements per lane when HW % 4 == 0).
-// d(gamma) / d(beta) = plane sums added over the batch in fixed order.
+// Two launches per direction, each fully parallel: (1) one workgroup per (sample, channel) plane reduces it -- mean /
+// M2 forward, sum(g') / sum(g' * xhat) backward (g' = g masked by the recomputed ReLU: nothing but x is saved); the
+// workgroup that completes a group (a device-scope counter per group, left at zero again) merges the group's planes
+// (Chan's formula, in channel order whichever workgroup does it: deterministic) into per-plane scale / shift
+// coefficients; (2) a grid-strided element-wise kernel applies them (4 elements per lane when HW % 4 == 0), and its first
+// workgroup adds the plane sums over the batch in fixed order: d(gamma) / d(beta).  (Batch-norm mode and callers without a
+// counter buffer keep the merge as a launch of its own.)
 #include "sis_common.h"
 
 namespace {
@@ -81,9 +83,24 @@ __device__ __forceinline__ void gn_span(int64_t base, int lo, int hi, FS scalar,
 // planes of a group with Chan's formula in channel order (no E[x^2] - E[x]^2 cancellation, deterministic).
 // Planes are cut into S slices of `sl` elements (blockIdx.y) so that few-channel, high-resolution tensors (the decoder's
 // 16 x 512^2 maps) still fill the chip; part[plane][slice] = (count, mean, M2).
+__device__ __forceinline__ void gn_publish(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float gn_peek(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void gn_row_finish(int row, int lane, int lanes, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                              float* __restrict__ ab, const float* __restrict__ part, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, int groups, int cpg, int S, float eps);
+__device__ __forceinline__ void gn_bwd_row(int row, int lane, int lanes, float* __restrict__ coef, float* __restrict__ psum,
+                                           const float* __restrict__ part, const float* __restrict__ rstd_in,
+                                           const float* __restrict__ gamma, int groups, int cpg, int hw, int S);
+__device__ __forceinline__ bool gn_group_complete(int* counter, int count);
+
+struct GnFinish {   // counters == nullptr: no merge in the statistics kernel
+    int* counters; float* mean; float* rstd; float* ab; const float* gamma; const float* beta; int groups, cpg; float eps;
+};
+
 template <typename TI, int VEC>
 __global__ __launch_bounds__(256) void gn_plane_stats_kernel(float* __restrict__ part, const TI* __restrict__ x, int hw,
-                                                             int sl) {
+                                                             int sl, GnFinish fin) {
     __shared__ float red[4];
     const int lo = blockIdx.y * sl, hi = min(hw, lo + sl);
     const int64_t base = (int64_t)blockIdx.x * hw;
@@ -107,33 +124,79 @@ __global__ __launch_bounds__(256) void gn_plane_stats_kernel(float* __restrict__
     m2 = gn_block_sum(m2, red);
     if (threadIdx.x == 0) {
         float* o = part + 3 * ((int64_t)blockIdx.x * gridDim.y + blockIdx.y);
-        o[0] = cnt; o[1] = mean; o[2] = m2;
+        gn_publish(o, cnt); gn_publish(o + 1, mean); gn_publish(o + 2, m2);
+    }
+    if (fin.counters) {
+        const int row = blockIdx.x / fin.cpg;
+        if (gn_group_complete(fin.counters + row, fin.cpg * gridDim.y) && threadIdx.x < 64)
+            gn_row_finish(row, threadIdx.x, 64, fin.mean, fin.rstd, fin.ab, part, fin.gamma, fin.beta, fin.groups, fin.cpg, gridDim.y, fin.eps);
     }
 }
 
-// per (sample, channel): a = rstd_row * gamma_c, b = beta_c - mean_row * a  (the apply kernel's scale / shift)
+// per (sample, channel): a = rstd_row * gamma_c, b = beta_c - mean_row * a  (the apply kernel's scale / shift).
+// `lane` / `lanes`: the channels of the group are spread over the calling lanes, the merge itself is done by each of them.
+__device__ __forceinline__ void gn_row_finish(int row, int lane, int lanes, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                              float* __restrict__ ab, const float* __restrict__ part, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, int groups, int cpg, int S, float eps) {
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    auto merge = [&](float nb, float mb, float m2b) {
+        const float nt = n + nb, delta = mb - mean;
+        mean += delta * (nb / nt);
+        m2 += m2b + delta * delta * (n * nb / nt);
+        n = nt;
+    };
+    // the group's planes are adjacent: (row * cpg + c) * S + slice
+    if (lanes == 64) {   // one wave: 64 partial results per round trip to memory, merged in the same (index) order
+        for (int j0 = 0; j0 < cpg * S; j0 += 64) {
+            const int j = j0 + lane, cnt = min(64, cpg * S - j0);
+            float pn = 0.f, pm = 0.f, p2 = 0.f;
+            if (j < cpg * S) {
+                const float* p = part + 3 * ((int64_t)row * cpg * S + j);
+                pn = gn_peek(p); pm = gn_peek(p + 1); p2 = gn_peek(p + 2);
+            }
+            for (int t = 0; t < cnt; ++t) merge(__shfl(pn, t, 64), __shfl(pm, t, 64), __shfl(p2, t, 64));
+        }
+    } else {
+        for (int j = 0; j < cpg * S; ++j) {
+            const float* p = part + 3 * ((int64_t)row * cpg * S + j);
+            merge(gn_peek(p), gn_peek(p + 1), gn_peek(p + 2));
+        }
+    }
+    const float rstd = rsqrtf(m2 / n + eps);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    const int c0 = (row % groups) * cpg;
+    for (int c = lane; c < cpg; c += lanes) {
+        const float a = rstd * gamma[c0 + c];
+        ab[2 * ((int64_t)row * cpg + c)] = a;
+        ab[2 * ((int64_t)row * cpg + c) + 1] = beta[c0 + c] - mean * a;
+    }
+}
+
 __global__ __launch_bounds__(64) void gn_row_finish_kernel(float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                            float* __restrict__ ab, const float* __restrict__ part,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            int rows, int groups, int cpg, int S, float eps) {
     const int row = blockIdx.x * 64 + threadIdx.x;
     if (row >= rows) return;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int j = 0; j < cpg * S; ++j) {  // the group's planes are adjacent: (row * cpg + c) * S + slice
-        const float* p = part + 3 * ((int64_t)row * cpg * S + j);
-        const float nb = p[0], nt = n + nb, delta = p[1] - mean;
-        mean += delta * (nb / nt);
-        m2 += p[2] + delta * delta * (n * nb / nt);
-        n = nt;
+    gn_row_finish(row, 0, 1, mean_out, rstd_out, ab, part, gamma, beta, groups, cpg, S, eps);
+}
+
+// The workgroup that finds a group's counter at `count - 1` is the one that completed it.  Partial results travel between
+// workgroups (possibly on different XCDs = different L2s) as device-scope relaxed atomics: gn_publish writes through to the
+// device's coherence point, the increment is issued once that store has completed, gn_peek reads past the non-coherent
+// caches.  No device-scope FENCE anywhere: a release / acquire fence writes back / invalidates the whole L2 of the XCD, and
+// with one per workgroup the trunk's norms ran 15 ms per step slower than with the merge as a launch of its own.
+// The completing workgroup puts the counter back to zero for the next launch on this stream.
+__device__ __forceinline__ bool gn_group_complete(int* counter, int count) {
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's gn_publish stores have completed; no cache maintenance
+        last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == count - 1;
     }
-    const float rstd = rsqrtf(m2 / n + eps);
-    mean_out[row] = mean; rstd_out[row] = rstd;
-    const int c0 = (row % groups) * cpg;
-    for (int c = 0; c < cpg; ++c) {
-        const float a = rstd * gamma[c0 + c];
-        ab[2 * ((int64_t)row * cpg + c)] = a;
-        ab[2 * ((int64_t)row * cpg + c) + 1] = beta[c0 + c] - mean * a;
-    }
+    __syncthreads();
+    if (!last) return false;
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
 }
 
 // y = relu?(x * a[plane] + b[plane] (+ residual)); VEC elements per lane.  FLAT: hw is not a multiple of VEC, a lane's
@@ -171,7 +234,8 @@ __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ p
                                                            const TI* __restrict__ g_lp, const TI* __restrict__ x, const float* __restrict__ mean_in,
                                                            const float* __restrict__ rstd_in, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ ymask, int C,
-                                                           int cpg, int hw, int sl, int relu) {
+                                                           int cpg, int hw, int sl, int relu, int* __restrict__ counters,
+                                                           float* __restrict__ coef, float* __restrict__ psum) {
     __shared__ float red[4];
     const int64_t plane = blockIdx.x;
     const int c = (int)(plane % C);
@@ -203,34 +267,70 @@ __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ p
     sgx = gn_block_sum(sgx, red);
     if (threadIdx.x == 0) {
         float* o = part + 2 * (plane * gridDim.y + blockIdx.y);
-        o[0] = sg; o[1] = sgx;
+        gn_publish(o, sg); gn_publish(o + 1, sgx);
+    }
+    if (counters) {   // (group-norm mode only: cpg > 0)
+        if (gn_group_complete(counters + row, cpg * gridDim.y) && threadIdx.x < 64)
+            gn_bwd_row((int)row, threadIdx.x, 64, coef, psum, part, rstd_in, gamma, C / cpg, cpg, hw, gridDim.y);
     }
 }
 
 // per row: m1 = mean(g'*gamma), m2 = mean(g'*gamma*xhat) -> per plane coefficients (k1, k2, k3) with
 // dx = k1 * g' - k2 - k3 * xhat;  k1 = rstd*gamma_c, k2 = rstd*m1, k3 = rstd*m2
+__device__ __forceinline__ void gn_bwd_row(int row, int lane, int lanes, float* __restrict__ coef, float* __restrict__ psum,
+                                           const float* __restrict__ part, const float* __restrict__ rstd_in,
+                                           const float* __restrict__ gamma, int groups, int cpg, int hw, int S) {
+    const int c0 = (row % groups) * cpg;
+    float s1 = 0.f, s2 = 0.f;
+    if (lanes == 64) {   // lane = channel: its S slices summed in slice order, then the channels in channel order
+        for (int cb = 0; cb < cpg; cb += 64) {
+            const int c = cb + lane, cnt = min(64, cpg - cb);
+            float a = 0.f, b = 0.f, gm = 0.f;
+            if (c < cpg) {
+                for (int k = 0; k < S; ++k) {
+                    const float* p = part + 2 * (((int64_t)row * cpg + c) * S + k);
+                    a += gn_peek(p); b += gn_peek(p + 1);
+                }
+                psum[2 * ((int64_t)row * cpg + c)] = a; psum[2 * ((int64_t)row * cpg + c) + 1] = b;  // plane sums (for d gamma / beta)
+                gm = gamma[c0 + c];
+            }
+            for (int t = 0; t < cnt; ++t) { s1 += __shfl(gm, t, 64) * __shfl(a, t, 64); s2 += __shfl(gm, t, 64) * __shfl(b, t, 64); }
+        }
+    } else {
+        for (int c = 0; c < cpg; ++c) {
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < S; ++k) {
+                const float* p = part + 2 * (((int64_t)row * cpg + c) * S + k);
+                a += gn_peek(p); b += gn_peek(p + 1);
+            }
+            if (c % lanes == lane) {  // plane sums (for d gamma / beta)
+                psum[2 * ((int64_t)row * cpg + c)] = a; psum[2 * ((int64_t)row * cpg + c) + 1] = b;
+            }
+            s1 += gamma[c0 + c] * a; s2 += gamma[c0 + c] * b;
+        }
+    }
+    const float n = (float)cpg * (float)hw, rstd = rstd_in[row];
+    for (int c = lane; c < cpg; c += lanes) {
+        float* k = coef + 3 * ((int64_t)row * cpg + c);
+        k[0] = rstd * gamma[c0 + c]; k[1] = rstd * s1 / n; k[2] = rstd * s2 / n;
+    }
+}
+
 __global__ __launch_bounds__(64) void gn_bwd_row_kernel(float* __restrict__ coef, float* __restrict__ psum,
                                                         const float* __restrict__ part, const float* __restrict__ rstd_in,
                                                         const float* __restrict__ gamma, int rows, int groups, int cpg, int hw,
                                                         int S) {
     const int row = blockIdx.x * 64 + threadIdx.x;
     if (row >= rows) return;
-    const int c0 = (row % groups) * cpg;
-    float s1 = 0.f, s2 = 0.f;
-    for (int c = 0; c < cpg; ++c) {
-        float a = 0.f, b = 0.f;
-        for (int k = 0; k < S; ++k) {
-            const float* p = part + 2 * (((int64_t)row * cpg + c) * S + k);
-            a += p[0]; b += p[1];
-        }
-        psum[2 * ((int64_t)row * cpg + c)] = a; psum[2 * ((int64_t)row * cpg + c) + 1] = b;  // plane sums (for d gamma / beta)
-        s1 += gamma[c0 + c] * a; s2 += gamma[c0 + c] * b;
-    }
-    const float n = (float)cpg * (float)hw, rstd = rstd_in[row];
-    for (int c = 0; c < cpg; ++c) {
-        float* k = coef + 3 * ((int64_t)row * cpg + c);
-        k[0] = rstd * gamma[c0 + c]; k[1] = rstd * s1 / n; k[2] = rstd * s2 / n;
-    }
+    gn_bwd_row(row, 0, 1, coef, psum, part, rstd_in, gamma, groups, cpg, hw, S);
+}
+
+// d(gamma) / d(beta) of channel c = its plane sums over the batch, in sample order
+__device__ __forceinline__ void gn_param_reduce(int c, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                const float* __restrict__ psum, int batch, int C) {
+    float a = 0.f, b = 0.f;
+    for (int n = 0; n < batch; ++n) { b += psum[2 * ((int64_t)n * C + c)]; a += psum[2 * ((int64_t)n * C + c) + 1]; }
+    dgamma[c] = a; dbeta[c] = b;
 }
 
 template <typename TI, typename TG, int VEC, bool FLAT>
@@ -240,7 +340,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(TI* __restrict__ dx, 
                                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ ymask, float* __restrict__ dres, int C,
-                                                           int cpg, int hw, int64_t total, int relu) {
+                                                           int cpg, int hw, int64_t total, int relu, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, const float* __restrict__ psum, int batch) {
+    if (dgamma && blockIdx.x == 0)   // the plane sums are complete since the previous launch
+        for (int c = threadIdx.x; c < C; c += 256) gn_param_reduce(c, dgamma, dbeta, psum, batch, C);
     struct PlaneCoef { float mean, rstd, gm, bt, k1, k2, k3; };
     auto coefs = [&](int64_t plane) {
         const int c = (int)(plane % C);
@@ -276,10 +379,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(TI* __restrict__ dx, 
 __global__ __launch_bounds__(256) void gn_param_reduce_kernel(float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               const float* __restrict__ part, int batch, int C) {
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float a = 0.f, b = 0.f;
-    for (int n = 0; n < batch; ++n) { b += part[2 * ((int64_t)n * C + c)]; a += part[2 * ((int64_t)n * C + c) + 1]; }
-    dgamma[c] = a; dbeta[c] = b;
+    if (c < C) gn_param_reduce(c, dgamma, dbeta, part, batch, C);
 }
 
 // ---- batch-norm mode (statistics per channel over the batch): the planes of channel c are n * C + c.
@@ -354,37 +454,42 @@ inline bool gn_aligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) &
     } while (0)
 
 template <typename TI>
-void gn_launch_stats(float* part, const void* x, int64_t planes, int hw, hipStream_t st) {
+void gn_launch_stats(float* part, const void* x, int64_t planes, int hw, hipStream_t st, GnFinish fin = GnFinish{}) {
     const int S = gn_slices(hw), sl = gn_slice_len(hw);
     if (gn_aligned(x))
-        hipLaunchKernelGGL((gn_plane_stats_kernel<TI, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl);
+        hipLaunchKernelGGL((gn_plane_stats_kernel<TI, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl, fin);
     else
-        hipLaunchKernelGGL((gn_plane_stats_kernel<TI, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl);
+        hipLaunchKernelGGL((gn_plane_stats_kernel<TI, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TI*)x, hw, sl, fin);
 }
 
 template <typename TI, typename TG>
 void gn_launch_bwd_plane(float* part, const void* g, const void* g_lp, const void* x, const float* mean, const float* rstd, const float* gamma,
-                         const float* beta, const float* ymask, int64_t planes, int C, int cpg, int hw, int relu, hipStream_t st) {
+                         const float* beta, const float* ymask, int64_t planes, int C, int cpg, int hw, int relu, hipStream_t st,
+                         int* counters = nullptr, float* coef = nullptr, float* psum = nullptr) {
     const int S = gn_slices(hw), sl = gn_slice_len(hw);
     if (gn_aligned(x) && gn_aligned(g) && gn_aligned(g_lp) && gn_aligned(ymask))
         hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
-                           (const TI*)g_lp, (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu);
+                           (const TI*)g_lp, (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu, counters, coef, psum);
     else
         hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
-                           (const TI*)g_lp, (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu);
+                           (const TI*)g_lp, (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu, counters, coef, psum);
 }
 
 template <typename TI, typename TO>
 void gn_fwd_run(void* y, void* y_lp, float* mean, float* rstd, float* ws, const void* x, const float* res, const float* gamma,
-                const float* beta, int batch, int C, int hw, int groups, float eps, int relu, hipStream_t st) {
+                const float* beta, int batch, int C, int hw, int groups, float eps, int relu, int* counters, hipStream_t st) {
     const int cpg = C / groups, rows = batch * groups;
     const int64_t planes = (int64_t)batch * C, total = planes * hw;
     const int S = gn_slices(hw);
     float* ab = ws;                // [planes][2]
     float* part = ws + 5 * planes; // [planes][S][3]
-    gn_launch_stats<TI>(part, x, planes, hw, st);
-    hipLaunchKernelGGL(gn_row_finish_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, mean, rstd, ab, part, gamma, beta, rows,
-                       groups, cpg, S, eps);
+    if (counters) {
+        gn_launch_stats<TI>(part, x, planes, hw, st, GnFinish{counters, mean, rstd, ab, gamma, beta, groups, cpg, eps});
+    } else {
+        gn_launch_stats<TI>(part, x, planes, hw, st);
+        hipLaunchKernelGGL(gn_row_finish_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, mean, rstd, ab, part, gamma, beta, rows,
+                           groups, cpg, S, eps);
+    }
     GN_DISPATCH_APPLY(gn_apply_kernel, TI, TO, gn_aligned(x) && gn_aligned(y) && gn_aligned(y_lp) && gn_aligned(res), (TO*)y,
                       (TI*)y_lp, (const TI*)x, ab, res, hw, total, relu);
 }
@@ -392,20 +497,26 @@ void gn_fwd_run(void* y, void* y_lp, float* mean, float* rstd, float* ws, const 
 template <typename TI, typename TG>
 void gn_bwd_run(void* dx, float* dres, float* dgamma, float* dbeta, float* ws, const void* g, const void* g_lp, const void* x,
                 const float* ymask, const float* mean, const float* rstd, const float* gamma, const float* beta, int batch, int C,
-                int hw, int groups, int relu, hipStream_t st) {
+                int hw, int groups, int relu, int* counters, hipStream_t st) {
     const int cpg = C / groups, rows = batch * groups;
     const int64_t planes = (int64_t)batch * C, total = planes * hw;
     const int S = gn_slices(hw);
     float* psum = ws;              // [planes][2]
     float* coef = ws + 2 * planes; // [planes][3]
     float* part = ws + 5 * planes; // [planes][S][2]
-    gn_launch_bwd_plane<TI, TG>(part, g, g_lp, x, mean, rstd, gamma, beta, ymask, planes, C, cpg, hw, relu, st);
-    hipLaunchKernelGGL(gn_bwd_row_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, coef, psum, part, rstd, gamma, rows, groups,
-                       cpg, hw, S);
+    float* no_param = nullptr;
+    if (counters) {
+        gn_launch_bwd_plane<TI, TG>(part, g, g_lp, x, mean, rstd, gamma, beta, ymask, planes, C, cpg, hw, relu, st, counters, coef, psum);
+    } else {
+        gn_launch_bwd_plane<TI, TG>(part, g, g_lp, x, mean, rstd, gamma, beta, ymask, planes, C, cpg, hw, relu, st);
+        hipLaunchKernelGGL(gn_bwd_row_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, coef, psum, part, rstd, gamma, rows, groups,
+                           cpg, hw, S);
+    }
     GN_DISPATCH_APPLY(gn_bwd_apply_kernel, TI, TG,
                       gn_aligned(dx) && gn_aligned(g) && gn_aligned(g_lp) && gn_aligned(x) && gn_aligned(ymask) && gn_aligned(dres),
-                      (TI*)dx, (const TG*)g, (const TI*)g_lp, (const TI*)x, coef, mean, rstd, gamma, beta, ymask, dres, C, cpg, hw, total, relu);
-    hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(sis_cdiv(C, 256)), dim3(256), 0, st, dgamma, dbeta, psum, batch, C);
+                      (TI*)dx, (const TG*)g, (const TI*)g_lp, (const TI*)x, coef, mean, rstd, gamma, beta, ymask, dres, C, cpg, hw, total, relu,
+                      counters ? dgamma : no_param, dbeta, (const float*)psum, batch);
+    if (!counters) hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(sis_cdiv(C, 256)), dim3(256), 0, st, dgamma, dbeta, psum, batch, C);
 }
 
 template <typename TI, typename TO>
@@ -436,7 +547,8 @@ void bn_bwd_run(void* dx, float* dgamma, float* dbeta, float* ws, const void* g,
     hipLaunchKernelGGL(bn_bwd_chan_kernel, dim3(sis_cdiv(C, 64)), dim3(64), 0, st, coef, dgamma, dbeta, part, rstd, gamma, batch,
                        C, hw, S);
     GN_DISPATCH_APPLY(gn_bwd_apply_kernel, TI, TG, gn_aligned(dx) && gn_aligned(g) && gn_aligned(x), (TI*)dx, (const TG*)g,
-                      (const TI*)nullptr, (const TI*)x, coef, mean, rstd, gamma, beta, none, no_dres, C, 0, hw, total, relu);
+                      (const TI*)nullptr, (const TI*)x, coef, mean, rstd, gamma, beta, none, no_dres, C, 0, hw, total, relu, no_dres, no_dres,
+                      none, batch);
 }
 
 }  // namespace
@@ -448,7 +560,7 @@ extern "C" int64_t sis_group_norm_workspace_floats(int batch, int channels, int 
 extern "C" int sis_group_norm_fwd(void* y, void* y_lp, float* mean, float* rstd, float* workspace, const void* x,
                                   const float* residual,
                                   const float* gamma, const float* beta, int x_dtype, int y_dtype, int batch, int channels,
-                                  int hw, int groups, float eps, int relu, void* stream) {
+                                  int hw, int groups, float eps, int relu, int* counters, void* stream) {
     if (batch == 0) return 0;
     SIS_REQUIRE(y && mean && rstd && workspace && x && gamma && beta, "sis_group_norm_fwd: null pointer");
     SIS_REQUIRE(batch > 0 && channels > 0 && hw > 0 && groups > 0 && channels % groups == 0,
@@ -459,8 +571,8 @@ extern "C" int sis_group_norm_fwd(void* y, void* y_lp, float* mean, float* rstd,
                 "sis_group_norm_fwd: the 16-bit copy goes with a float32 output of a 16-bit input");
     hipStream_t st = (hipStream_t)stream;
 #define GN_FWD(TI)                                                                                                       \
-    if (y_dtype == SIS_F32) gn_fwd_run<TI, float>(y, y_lp, mean, rstd, workspace, x, residual, gamma, beta, batch, channels, hw, groups, eps, relu, st); \
-    else gn_fwd_run<TI, TI>(y, nullptr, mean, rstd, workspace, x, nullptr, gamma, beta, batch, channels, hw, groups, eps, relu, st);
+    if (y_dtype == SIS_F32) gn_fwd_run<TI, float>(y, y_lp, mean, rstd, workspace, x, residual, gamma, beta, batch, channels, hw, groups, eps, relu, counters, st); \
+    else gn_fwd_run<TI, TI>(y, nullptr, mean, rstd, workspace, x, nullptr, gamma, beta, batch, channels, hw, groups, eps, relu, counters, st);
     switch (x_dtype) {
         case SIS_F32: GN_FWD(float) break;
         case SIS_F16: GN_FWD(__half) break;
@@ -475,7 +587,7 @@ extern "C" int sis_group_norm_fwd(void* y, void* y_lp, float* mean, float* rstd,
 extern "C" int sis_group_norm_bwd(void* dx, float* dresidual, float* dgamma, float* dbeta, float* workspace, const void* grad_y,
                                   const void* grad_y_lp, const void* x, const float* y_mask, const float* mean, const float* rstd, const float* gamma,
                                   const float* beta, int x_dtype, int g_dtype, int batch, int channels, int hw, int groups,
-                                  int relu, void* stream) {
+                                  int relu, int* counters, void* stream) {
     if (batch == 0) return 0;
     SIS_REQUIRE(dx && dgamma && dbeta && workspace && grad_y && x && mean && rstd && gamma && beta,
                 "sis_group_norm_bwd: null pointer");
@@ -486,8 +598,8 @@ extern "C" int sis_group_norm_bwd(void* dx, float* dresidual, float* dgamma, flo
                 "sis_group_norm_bwd: the 16-bit gradient goes with a float32 gradient of a 16-bit input");
     hipStream_t st = (hipStream_t)stream;
 #define GN_BWD(TI)                                                                                                        \
-    if (g_dtype == SIS_F32) gn_bwd_run<TI, float>(dx, dresidual, dgamma, dbeta, workspace, grad_y, grad_y_lp, x, y_mask, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, st); \
-    else gn_bwd_run<TI, TI>(dx, dresidual, dgamma, dbeta, workspace, grad_y, nullptr, x, y_mask, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, st);
+    if (g_dtype == SIS_F32) gn_bwd_run<TI, float>(dx, dresidual, dgamma, dbeta, workspace, grad_y, grad_y_lp, x, y_mask, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, counters, st); \
+    else gn_bwd_run<TI, TI>(dx, dresidual, dgamma, dbeta, workspace, grad_y, nullptr, x, y_mask, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, counters, st);
     switch (x_dtype) {
         case SIS_F32: GN_BWD(float) break;
         case SIS_F16: GN_BWD(__half) break;

@@ -63,11 +63,11 @@ _SIGNATURES = {
     "sis_layer_norm_fwd": ([_vp] * 6 + [_i, _i, _i, _i, _f, _vp], _i),
     "sis_layer_norm_bwd": ([_vp] * 9 + [_i, _i, _i, _i, _vp], _i),
     "sis_weight_std_fwd": ([_vp, _vp, _vp, _i, _i, _i, _f, _vp], _i),
-    "sis_group_norm_fwd": ([_vp] * 9 + [_i, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
+    "sis_group_norm_fwd": ([_vp] * 9 + [_i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp], _i),
     "sis_group_norm_workspace_floats": ([_i, _i, _i], _i64),
     "sis_batch_norm_fwd": ([_vp] * 9 + [_i] * 5 + [_f, _f, _i, _vp], _i),
     "sis_batch_norm_bwd": ([_vp] * 10 + [_i] * 6 + [_vp], _i),
-    "sis_group_norm_bwd": ([_vp] * 13 + [_i] * 7 + [_vp], _i),
+    "sis_group_norm_bwd": ([_vp] * 13 + [_i] * 7 + [_vp, _vp], _i),
     "sis_weight_std_bwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp], _i),
     "sis_conv3x3_wgrad_eligible": ([_i] * 5 + [_i64], _i),
     "sis_conv3x3_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
@@ -1017,6 +1017,21 @@ def column_sum(x):
 # ------------------------------------------------------------------------------ group norm (+ ReLU)
 
 
+_GROUP_COUNTERS = {}  # device -> int32 zeros: completion counters of the norm kernels (each launch leaves them zero)
+_GN_FUSED_FINISH = os.environ.get("SIS_GN_FUSED_FINISH", "1") != "0"  # 0: the per-group merges as launches of their own
+
+
+def _group_counters(device, n):
+    """One buffer per device, like the split-K scratch: the norm launches of a device are stream-ordered (eager steps and
+    graph replays of a training loop never overlap).  Launches on OTHER streams at the same time need SIS_GN_FUSED_FINISH=0."""
+    if not _GN_FUSED_FINISH:
+        return None
+    buf = _GROUP_COUNTERS.get(device)
+    if buf is None or buf.numel() < n:
+        buf = _GROUP_COUNTERS[device] = torch.zeros(max(n, 16384), dtype=torch.int32, device=device)
+    return buf
+
+
 def group_norm_fwd(x, gamma, beta, groups, eps, relu, out_dtype=None, residual=None, low_precision_copy=False):
     """x [B,C,...] (f32 / f16 / bf16) -> (y in ``out_dtype`` (default: x's), mean [B*groups], rstd [B*groups]).
     ``residual`` (float32, x's shape) is added before the ReLU; the output is then float32.
@@ -1042,7 +1057,8 @@ def group_norm_fwd(x, gamma, beta, groups, eps, relu, out_dtype=None, residual=N
     with torch.cuda.device(x.device):
         _check(lib().sis_group_norm_fwd(_ptr(y), _ptr(y_lp), _ptr(mean), _ptr(rstd), _ptr(ws), _ptr(x), _ptr(residual),
                                         _ptr(_f32(gamma, "weight")), _ptr(_f32(beta, "bias")), _DTYPE_CODE[x.dtype],
-                                        _DTYPE_CODE[out_dtype], b, c, hw, groups, float(eps), int(bool(relu)), _stream()),
+                                        _DTYPE_CODE[out_dtype], b, c, hw, groups, float(eps), int(bool(relu)),
+                                        _ptr(_group_counters(x.device, b * groups)), _stream()),
                "sis_group_norm_fwd")
     return (y, mean, rstd, y_lp) if low_precision_copy else (y, mean, rstd)
 
@@ -1069,7 +1085,8 @@ def group_norm_bwd(grad_y, x, mean, rstd, gamma, beta, groups, relu, y_mask=None
     with torch.cuda.device(x.device):
         _check(lib().sis_group_norm_bwd(_ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _ptr(g), _ptr(grad_y_lp), _ptr(x),
                                         _ptr(y_mask), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _DTYPE_CODE[x.dtype],
-                                        _DTYPE_CODE[g.dtype], b, c, hw, groups, int(bool(relu)), _stream()), "sis_group_norm_bwd")
+                                        _DTYPE_CODE[g.dtype], b, c, hw, groups, int(bool(relu)),
+                                        _ptr(_group_counters(x.device, b * groups)), _stream()), "sis_group_norm_bwd")
     return (dx, dgamma, dbeta, dres) if want_residual_grad else (dx, dgamma, dbeta)
 
 

@@ -105,6 +105,33 @@ def test_group_norm_relu(device, shape, groups, relu):
     np.testing.assert_allclose(dxb.float().cpu().numpy(), xq.grad.float().cpu().numpy(), rtol=2e-2, atol=1e-2 * scale)
 
 
+@pytest.mark.parametrize("shape,groups", [((8, 256, 32, 32), 32), ((2, 64, 200, 200), 32), ((3, 96, 5, 5), 96), ((8, 1024, 8, 8), 32)])
+def test_group_norm_merge_inside_the_statistics_launch(device, shape, groups, monkeypatch):
+    """The per-group merge done by the workgroup that completes the group (device-scope counters, csrc/group_norm.hip) gives
+    bitwise the results of the merge as a launch of its own, call after call (the counters are left at zero), incl. planes cut
+    into several slices (200 x 200 > 16 384 elements) and one-channel groups."""
+    import sis_hip
+    g = torch.Generator().manual_seed(shape[1] + shape[2])
+    x = (torch.randn(*shape, generator=g) * 2 + 0.5).to(device).bfloat16()
+    gamma = (1 + 0.2 * torch.randn(shape[1], generator=g)).to(device)
+    beta = (0.3 * torch.randn(shape[1], generator=g)).to(device)
+    gy = torch.randn(*shape, generator=g).to(device).bfloat16()
+
+    def run():
+        y, mean, rstd = sis_hip.group_norm_fwd(x, gamma, beta, groups, 1e-6, True)
+        return (y, mean, rstd) + tuple(sis_hip.group_norm_bwd(gy, x, mean, rstd, gamma, beta, groups, True))
+
+    monkeypatch.setattr(sis_hip, "_GN_FUSED_FINISH", False)
+    want = run()
+    monkeypatch.setattr(sis_hip, "_GN_FUSED_FINISH", True)
+    for _ in range(3):
+        got = run()
+        for u, v in zip(got, want):
+            assert torch.equal(u, v)
+    counters = sis_hip._group_counters(x.device, shape[0] * groups)
+    assert int(counters.abs().sum()) == 0
+
+
 @pytest.mark.parametrize("shape,relu", [((4, 16, 12, 12), True), ((2, 64, 33, 31), False), ((8, 256, 16, 16), True)])
 def test_batch_norm_train_relu(device, shape, relu):
     """Batch-norm mode of csrc/group_norm.hip against F.batch_norm(training=True) (+ relu), incl. running statistics."""
