@@ -395,6 +395,13 @@ int sis_conv_bf16_pack_both(void* packed, void* packed_adjoint, const void* weig
 int sis_conv_bf16_wgrad_supported(int batch, int cin, int cout, int h, int w, int64_t workspace_bytes);
 int sis_conv_bf16_wgrad(void* dw, int dw_dtype, const void* x, const void* grad_y, int batch, int cin, int cout, int h, int w,
                         void* workspace, int64_t workspace_bytes, void* stream);
+/* The 1x1 stride-1 layers (conv1x1 / StdConv2d 1x1 of every bottleneck, vit_seg_modeling_resnet_skip.py:30-37,40-75; the
+ * reference's autograd runs convolution_backward): dw [cout][cin] (SIS_F32 or SIS_BF16) = sum_{n,p} grad_y[n][co][p] * x[n][ci][p],
+ * x [batch][cin][pixels] / grad_y [batch][cout][pixels] bf16 (NCHW with the plane flattened; any plane size, odd ones take a
+ * funnel-shift load path), fp32 accumulation, unit slabs through `workspace` added in unit order (deterministic). */
+int sis_conv1x1_bf16_wgrad_supported(int batch, int cin, int cout, int pixels, int64_t workspace_bytes);
+int sis_conv1x1_bf16_wgrad(void* dw, int dw_dtype, const void* x, const void* grad_y, int batch, int cin, int cout, int pixels,
+                           void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * fp32 pointwise (1x1, stride 1) convolution of the EMANet training step (csrc/conv1x1_f32.hip;

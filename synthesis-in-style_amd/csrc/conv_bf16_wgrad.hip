@@ -19,6 +19,7 @@
 // barriers, loads issued before the MFMAs and written to LDS after them.
 // Split-K over (image, strip, row block): every unit writes its partial [tap][co][ci] tile to a slab; a second kernel
 // adds the slabs in unit order (deterministic, no atomics) and writes dW[co][ci][3][3].
+#include <algorithm>
 #include "sis_common.h"
 
 namespace {
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(WgParams p) {
 // four waves add units w, w + 4, ... in order (coalesced 256-byte reads), then (s0 + s1) + (s2 + s3): a fixed order.
 template <typename T>
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(T* __restrict__ dw, const float* __restrict__ slab, int units,
-                                                                int Cout, int Cin, int co_pad, int ci_pad) {
+                                                                int Cout, int Cin, int co_pad, int ci_pad, int taps) {
     __shared__ float red[4][64];
     const int cchunks = (Cin + 63) / 64;
     int b = blockIdx.x;
@@ -269,13 +270,188 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(T* __restrict__ 
     float s = 0.f;
     if (ci < Cin) {
         const float* src = slab + ((int64_t)t * co_pad + co) * ci_pad + ci;
-        const int64_t stride = (int64_t)9 * co_pad * ci_pad;
+        const int64_t stride = (int64_t)taps * co_pad * ci_pad;
 #pragma unroll 4
         for (int u = w; u < units; u += 4) s += src[u * stride];
     }
     red[w][ln] = s;
     __syncthreads();
-    if (w == 0 && ci < Cin) sis_st(dw, ((int64_t)co * Cin + ci) * 9 + t, (red[0][ln] + red[1][ln]) + (red[2][ln] + red[3][ln]));
+    if (w == 0 && ci < Cin) sis_st(dw, ((int64_t)co * Cin + ci) * taps + t, (red[0][ln] + red[1][ln]) + (red[2][ln] + red[3][ln]));
+}
+
+// ---------------------------------------------------------------------------------------------------- 1 x 1 layers
+// dW[co][ci] = sum_{n,p} dY[n][co][p] * X[n][ci][p]: a GEMM whose reduction axis (the pixels of a plane) is the contiguous
+// axis of BOTH NCHW operands, so both LDS images are copies of plane segments and every fragment is one ds_read_b128 (8
+// consecutive pixels of a channel).  (reference call sites: the backward of conv1x1 / StdConv2d 1x1 in every bottleneck,
+// vit_seg_modeling_resnet_skip.py:30-37,40-75.)  These layers are memory-bound (co ci / (co + ci) FLOP per byte, 25-100),
+// so the workgroup tile is as large as the layer allows -- 64 x 64 per wave = 2 x 2 MFMA blocks, WM x WN waves, the
+// remaining 8 / (WM WN) waves split the 16-pixel K-steps of a stage -- and units = (image, pixel range) fill the chip;
+// unit slabs are added in unit order by conv_wgrad_reduce_kernel (deterministic).  Planes of odd size (127 x 127: 2-byte
+// aligned rows) go through load_chunk's funnel-shift path.
+template <int WM_, int WN_, int KSW_>
+struct PwCfg {
+    static constexpr int WM = WM_, WN = WN_, WK = 8 / (WM_ * WN_), KSW = KSW_;   // KSW: K-steps per wave and stage
+    static_assert(WM * WN * WK == 8, "wave layout");
+    static constexpr int MT = 64 * WM, NT = 64 * WN;
+    static constexpr int KP = 16 * WK * KSW;                 // pixels per stage
+    static constexpr int PITCH = KP * 2 + 16;                // bytes per staged channel row (+1 unit: conflict-free b128 reads)
+    static constexpr int A_BYTES = MT * PITCH, STAGE = (MT + NT) * PITCH, LDS = 2 * STAGE;
+    static constexpr int A_CHUNKS = MT * (KP / 8), B_CHUNKS = NT * (KP / 8);
+    static constexpr int NA = (A_CHUNKS + 511) / 512, NB = (B_CHUNKS + 511) / 512;
+    static_assert(LDS <= 160 * 1024 && WK * WM * WN * 4096 <= LDS, "LDS");
+};
+
+struct PwParams {
+    const u16* x; const u16* gy; float* slab;
+    int N, Cin, Cout, P;              // P = pixels per plane
+    int units_per_image, unit_len;    // unit u: image u / units_per_image, pixels [k * unit_len, min(P, (k + 1) * unit_len))
+    int co_tiles, ci_tiles;
+};
+
+template <typename C, bool ALIGNED>
+__global__ __launch_bounds__(512, 2) void conv1x1_wgrad_bf16_kernel(PwParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave % C::WM, wn = (wave / C::WM) % C::WN, wk = wave / (C::WM * C::WN);
+    const int n = blockIdx.x / p.units_per_image, uk = blockIdx.x % p.units_per_image;
+    const int co_t = blockIdx.y % p.co_tiles, ci_t = blockIdx.y / p.co_tiles;
+    const int p_begin = uk * p.unit_len, p_end = min(p.P, p_begin + p.unit_len);
+    const u16* gy_base = p.gy + ((int64_t)n * p.Cout + co_t * C::MT) * p.P;
+    const u16* x_base = p.x + ((int64_t)n * p.Cin + ci_t * C::NT) * p.P;
+    const int stages = (p_end - p_begin + C::KP - 1) / C::KP;
+
+    uint4 ar[C::NA], br[C::NB];
+    auto load = [&](int s) {   // pixels beyond the unit's end read as zeros (p_end plays the row width)
+        const int p0 = p_begin + s * C::KP;
+#pragma unroll
+        for (int i = 0; i < C::NA; ++i) {
+            const int c = tid + i * 512;
+            if (C::A_CHUNKS % 512 == 0 || c < C::A_CHUNKS) {
+                const int ch = c / (C::KP / 8), g = c % (C::KP / 8);
+                ar[i] = load_chunk(gy_base + (int64_t)ch * p.P, p0 + 8 * g, p_end, co_t * C::MT + ch < p.Cout, ALIGNED);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::NB; ++i) {
+            const int c = tid + i * 512;
+            if (C::B_CHUNKS % 512 == 0 || c < C::B_CHUNKS) {
+                const int ch = c / (C::KP / 8), g = c % (C::KP / 8);
+                br[i] = load_chunk(x_base + (int64_t)ch * p.P, p0 + 8 * g, p_end, ci_t * C::NT + ch < p.Cin, ALIGNED);
+            }
+        }
+    };
+    auto store = [&](int buf) {
+        unsigned char* a = lds + buf * C::STAGE;
+        unsigned char* b = a + C::A_BYTES;
+#pragma unroll
+        for (int i = 0; i < C::NA; ++i) {
+            const int c = tid + i * 512;
+            if (C::A_CHUNKS % 512 == 0 || c < C::A_CHUNKS) *reinterpret_cast<uint4*>(a + (c / (C::KP / 8)) * C::PITCH + (c % (C::KP / 8)) * 16) = ar[i];
+        }
+#pragma unroll
+        for (int i = 0; i < C::NB; ++i) {
+            const int c = tid + i * 512;
+            if (C::B_CHUNKS % 512 == 0 || c < C::B_CHUNKS) *reinterpret_cast<uint4*>(b + (c / (C::KP / 8)) * C::PITCH + (c % (C::KP / 8)) * 16) = br[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    load(0); store(0);
+    __syncthreads();
+    const int a_off = (wm * 64 + r) * C::PITCH + h * 16, b_off = C::A_BYTES + (wn * 64 + r) * C::PITCH + h * 16;
+    for (int s = 0; s < stages; ++s) {
+        const bool more = s + 1 < stages;
+        if (more) load(s + 1);
+        const unsigned char* st = lds + (s & 1) * C::STAGE;
+#pragma unroll
+        for (int i = 0; i < C::KSW; ++i) {
+            const int ks = wk + i * C::WK;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(st + a_off + ks * 32);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(st + a_off + 32 * C::PITCH + ks * 32);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(st + b_off + ks * 32);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(st + b_off + 32 * C::PITCH + ks * 32);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) store((s + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- the K waves add their tiles through the staging LDS in wave order, block by block; one tile per unit reaches the slab
+    const int co_pad = p.co_tiles * C::MT, ci_pad = p.ci_tiles * C::NT;
+    float* out = p.slab + (int64_t)blockIdx.x * co_pad * ci_pad;
+    constexpr int NP = C::WM * C::WN;
+    float* red = reinterpret_cast<float*>(lds);  // [WK][NP][16][64]
+    const int pair = wm + C::WM * wn;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ba = t >> 1, bb = t & 1;
+        if (t) __syncthreads();   // the previous block has been read
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[((wk * NP + pair) * 16 + i) * 64 + lane] = acc[ba][bb][i];
+        __syncthreads();
+        for (int e = tid; e < NP * 1024; e += 512) {
+            const int pr = e >> 10, i = (e >> 6) & 15, ln = e & 63;
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < C::WK; ++k) sum += red[((k * NP + pr) * 16 + i) * 64 + ln];
+            const int co = co_t * C::MT + (pr % C::WM) * 64 + ba * 32 + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5);
+            const int ci = ci_t * C::NT + (pr / C::WM) * 64 + bb * 32 + (ln & 31);
+            out[(int64_t)co * ci_pad + ci] = sum;
+        }
+    }
+}
+
+struct PwPlan { int wm, wn, units_per_image, unit_len, co_tiles, ci_tiles, units; int64_t slab_bytes; };
+
+bool pw_plan(int batch, int cin, int cout, int pixels, int64_t workspace_bytes, PwPlan* pl) {
+    if (cin < 8 || cout < 8 || pixels < 8 || batch < 1) return false;
+    pl->wm = cout > 64 ? 2 : 1;
+    pl->wn = cin > 64 ? 2 : 1;
+    const int kp = pl->wm * pl->wn == 1 ? 128 : 64;
+    const int mt = 64 * pl->wm, nt = 64 * pl->wn;
+    pl->co_tiles = sis_cdiv(cout, mt); pl->ci_tiles = sis_cdiv(cin, nt);
+    const int64_t tile_bytes = (int64_t)pl->co_tiles * mt * pl->ci_tiles * nt * 4;
+    const int tiles = pl->co_tiles * pl->ci_tiles;
+    // pixel ranges per image: enough workgroups for ~2 per CU, at least 4 stages each, slabs within the workspace
+    int upi = 1;
+    while ((int64_t)batch * upi * tiles < 512 && pixels / (upi * 2) >= 4 * kp && (int64_t)batch * upi * 2 * tile_bytes <= workspace_bytes) upi *= 2;
+    pl->unit_len = sis_cdiv(sis_cdiv(pixels, upi), kp) * kp;
+    pl->units_per_image = sis_cdiv(pixels, pl->unit_len);
+    pl->units = batch * pl->units_per_image;
+    pl->slab_bytes = (int64_t)pl->units * tile_bytes;
+    return pl->slab_bytes <= workspace_bytes && (int64_t)batch * std::max(cin, cout) * pixels < (1LL << 31);
+}
+
+template <typename C>
+int launch_pw(const PwParams& p, int units, bool aligned, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_wgrad_bf16_kernel<C, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_wgrad_bf16_kernel<C, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        if (e != hipSuccess) return sis_fail("conv1x1_wgrad_bf16_kernel: cannot raise the LDS limit: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    dim3 grid(units, p.co_tiles * p.ci_tiles);
+    if (aligned) hipLaunchKernelGGL((conv1x1_wgrad_bf16_kernel<C, true>), grid, dim3(512), C::LDS, st, p);
+    else hipLaunchKernelGGL((conv1x1_wgrad_bf16_kernel<C, false>), grid, dim3(512), C::LDS, st, p);
+    SIS_CHECK_LAUNCH("conv1x1_wgrad_bf16_kernel");
+    sis_kernel_name = "conv1x1_wgrad_bf16_kernel";
+    return 0;
 }
 
 struct WgPlan { int wm, wn, ks, strips, row_blocks, rows_per_block, co_tiles, ci_tiles, units, partials; int64_t slab_bytes; };
@@ -365,10 +541,48 @@ extern "C" int sis_conv_bf16_wgrad(void* dw, int dw_dtype, const void* x, const 
     const int blocks = 9 * cout * sis_cdiv(cin, 64);
     if (dw_dtype == SIS_F32)
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (float*)dw, (const float*)workspace,
-                           pl.partials, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt);
+                           pl.partials, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt, 9);
     else
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel<__hip_bfloat16>, dim3(blocks), dim3(256), 0, st, (__hip_bfloat16*)dw,
-                           (const float*)workspace, pl.partials, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt);
+                           (const float*)workspace, pl.partials, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt, 9);
+    SIS_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
+    return 0;
+}
+
+/* 1x1 stride-1 layers: dW [Cout][Cin] (float32 or bfloat16) from bf16 NCHW x [B][Cin][pixels] and dL/dy [B][Cout][pixels]. */
+extern "C" int sis_conv1x1_bf16_wgrad_supported(int batch, int cin, int cout, int pixels, int64_t workspace_bytes) {
+    PwPlan pl;
+    return pw_plan(batch, cin, cout, pixels, workspace_bytes, &pl) ? 1 : 0;
+}
+
+extern "C" int sis_conv1x1_bf16_wgrad(void* dw, int dw_dtype, const void* x, const void* grad_y, int batch, int cin, int cout,
+                                      int pixels, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (batch <= 0) return 0;
+    SIS_REQUIRE(dw && x && grad_y && workspace, "sis_conv1x1_bf16_wgrad: null pointer");
+    SIS_REQUIRE(dw_dtype == SIS_F32 || dw_dtype == SIS_BF16, "sis_conv1x1_bf16_wgrad: dW must be float32 or bfloat16");
+    PwPlan pl;
+    SIS_REQUIRE(pw_plan(batch, cin, cout, pixels, workspace_bytes, &pl),
+                "sis_conv1x1_bf16_wgrad: no plan for %d->%d, %d pixels within %lld workspace bytes", cin, cout, pixels, (long long)workspace_bytes);
+    PwParams p;
+    p.x = (const u16*)x; p.gy = (const u16*)grad_y; p.slab = (float*)workspace;
+    p.N = batch; p.Cin = cin; p.Cout = cout; p.P = pixels;
+    p.units_per_image = pl.units_per_image; p.unit_len = pl.unit_len; p.co_tiles = pl.co_tiles; p.ci_tiles = pl.ci_tiles;
+    const bool aligned = (pixels % 8 == 0) && ((((uintptr_t)x) | ((uintptr_t)grad_y)) & 15) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (pl.wm == 2 && pl.wn == 2) rc = launch_pw<PwCfg<2, 2, 2>>(p, pl.units, aligned, st);
+    else if (pl.wm == 2) rc = launch_pw<PwCfg<2, 1, 1>>(p, pl.units, aligned, st);
+    else if (pl.wn == 2) rc = launch_pw<PwCfg<1, 2, 1>>(p, pl.units, aligned, st);
+    else rc = launch_pw<PwCfg<1, 1, 1>>(p, pl.units, aligned, st);
+    if (rc) return rc;
+    const int mt = 64 * pl.wm, nt = 64 * pl.wn;
+    const int blocks = cout * sis_cdiv(cin, 64);
+    if (dw_dtype == SIS_F32)
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (float*)dw, (const float*)workspace,
+                           pl.units, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt, 1);
+    else
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel<__hip_bfloat16>, dim3(blocks), dim3(256), 0, st, (__hip_bfloat16*)dw,
+                           (const float*)workspace, pl.units, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt, 1);
     SIS_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
     return 0;
 }

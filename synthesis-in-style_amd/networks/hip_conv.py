@@ -221,19 +221,41 @@ def pointwise_with_skip(conv, input):
 _FUSE_SKIP_GRAD = os.environ.get('SIS_FUSE_SKIP_GRAD', '1') != '0'
 
 
+_TAP_SELECT = {}  # device -> [3, 4] 0/1 matrix: row k selects the (u, u') pairs with u' - u + 1 == k
+
+
+def _tap_select(device):
+    sel = _TAP_SELECT.get(device)
+    if sel is None:
+        sel = torch.zeros(3, 4, device=device)
+        for u in (0, 1):
+            for u2 in (0, 1):
+                sel[u2 - u + 1, 2 * u + u2] = 1.0
+        _TAP_SELECT[device] = sel
+    return sel
+
+
 def conv3x3_half_image_dilation(input, weight):
     """3x3 convolution whose dilation is half the image side (padding = dilation): every output pixel (u*d + p,
     v*d + q) only sees the 2 x 2 pixels {(u'*d + p, v'*d + q)} -- EMANet's last bottleneck (dilation 16 on 32 x 32).
     That is one dense [4 Cin] -> [4 Cout] linear map per (p, q), a single GEMM with 4/9 of the multiplies a 9-tap
-    convolution spends (5 of its taps fall into the zero padding); autograd differentiates the composite."""
+    convolution spends (5 of its taps fall into the zero padding); autograd differentiates the composite.
+
+    The [4 Cout, 4 Cin] matrix holds tap (u' - u + 1, v' - v + 1) of the kernel in block ((u, v), (u', v')); it is gathered
+    with two multiplications by a 0/1 selection matrix (exact: every sum has one non-zero term), whose autograd backward
+    is the matching scatter-add -- 3 launches per direction where slicing and stacking the 16 blocks took 47 (16 zero
+    fills and 15 accumulations of the whole weight gradient among them: 0.5 ms of EMANet-50's step)."""
     b, cin, h, w = input.shape
     d = h // 2
     cout = weight.shape[0]
     x = input.view(b, cin, 2, d, 2, d).permute(0, 3, 5, 2, 4, 1).reshape(b * d * d, 4 * cin)  # rows (b,p,q), cols (u',v',ci)
-    taps = torch.stack([torch.stack([torch.stack([torch.stack([weight[:, :, u2 - u + 1, v2 - v + 1] for v2 in (0, 1)], 1)
-                                                  for u2 in (0, 1)], 1) for v in (0, 1)], 0) for u in (0, 1)], 0)
-    # taps [u, v, co, u', v', ci]
-    y = x @ taps.reshape(4 * cout, 4 * cin).t()
+    sel = _tap_select(weight.device)
+    # (two plain 2-D products with a transpose copy between them: a batched product of 262 144 3 x 4 matrices costs the
+    # library 2 ms per direction)
+    t = weight.reshape(cout * cin * 3, 3) @ sel                                     # [(co,ci,ky), (v,v')]
+    t = t.view(cout * cin, 3, 4).transpose(1, 2).reshape(cout * cin * 4, 3) @ sel   # [(co,ci,v,v'), (u,u')]
+    taps = t.view(cout, cin, 2, 2, 2, 2).permute(4, 2, 0, 5, 3, 1).reshape(4 * cout, 4 * cin)  # rows (u,v,co), cols (u',v',ci)
+    y = x @ taps.t()
     return y.view(b, d, d, 2, 2, cout).permute(0, 5, 3, 1, 4, 2).reshape(b, cout, h, w)
 
 
@@ -256,8 +278,8 @@ class _ConvBf16Function(Function):
     forward        sis_conv_bf16 on the packed weight
     dL/dx          the same kernel on the adjoint packing; 3x3 stride 2: on dL/dy zero-stuffed to the input's size
     dL/dw          3x3: sis_conv_bf16_wgrad where its tile plan applies (stride 2: on the zero-stuffed dL/dy), the library
-                   otherwise; 1x1 stride 1: one batched
-                   GEMM dy_b x_b^T on the NCHW tensors + sum over the batch
+                   otherwise; 1x1 stride 1: sis_conv1x1_bf16_wgrad (pixels are the contiguous reduction axis of both
+                   NCHW operands)
     dL/dbias       fp32 sum of dL/dy
     """
 
@@ -322,6 +344,8 @@ class _ConvBf16Function(Function):
         if ctx.needs_input_grad[1]:
             if k == 3 and s == 1 and sis_hip.conv_bf16_wgrad_supported(b, cin, cout, h, w):
                 grad_weight = sis_hip.conv_bf16_wgrad(input, gy, weight.dtype)
+            elif k == 1 and s == 1 and _PW_WGRAD_OWN and sis_hip.conv1x1_bf16_wgrad_supported(b, cin, cout, h * w):
+                grad_weight = sis_hip.conv1x1_bf16_wgrad(input, gy, weight.dtype)   # csrc/conv_bf16_wgrad.hip, any plane size
             elif k == 1 and s == 1:
                 grad_weight = torch.bmm(gy.view(b, cout, h * w), input.view(b, cin, h * w).transpose(1, 2)).sum(0, dtype=torch.float32)
                 grad_weight = grad_weight.view(cout, cin, 1, 1)
@@ -351,6 +375,7 @@ def conv_bf16(input, weight, bias=None, stride=1):
 
 
 _BF16_CONV = os.environ.get('SIS_BF16_CONV', '1') != '0'  # 0: bf16 convolutions stay on the library (A/B runs)
+_PW_WGRAD_OWN = os.environ.get('SIS_PW_WGRAD_OWN', '1') != '0'  # 0: the bf16 1x1 weight gradient as a library bmm + sum over the batch
 _STRIDE2_OWN = os.environ.get('SIS_STRIDE2_OWN', '1') != '0'  # 0: stride-2 layers (their backward under bf16) stay on the library
 
 

@@ -105,6 +105,8 @@ _SIGNATURES = {
     "sis_conv_bf16_pack_both": ([_vp, _vp, _vp, _i] + [_i] * 5 + [_vp], _i),
     "sis_conv_bf16_wgrad_supported": ([_i] * 5 + [_i64], _i),
     "sis_conv_bf16_wgrad": ([_vp, _i, _vp, _vp] + [_i] * 5 + [_vp, _i64, _vp], _i),
+    "sis_conv1x1_bf16_wgrad_supported": ([_i] * 4 + [_i64], _i),
+    "sis_conv1x1_bf16_wgrad": ([_vp, _i, _vp, _vp] + [_i] * 4 + [_vp, _i64, _vp], _i),
 }
 
 
@@ -735,6 +737,29 @@ def conv_bf16_wgrad(x, grad_output, out_dtype=torch.float32):
         _check(_launch(None, 2.0 * b * cout * cin * 9 * h * w, 2.0 * (x.numel() + grad_output.numel()) + 4.0 * dw.numel(),
                        lambda: lib().sis_conv_bf16_wgrad(_ptr(dw), _DTYPE_CODE[out_dtype], _ptr(x), _ptr(grad_output), b, cin, cout,
                                                          h, w, _ptr(ws), ws.numel(), _stream())), "sis_conv_bf16_wgrad")
+    return dw
+
+
+def conv1x1_bf16_wgrad_supported(batch, cin, cout, pixels):
+    return bool(lib().sis_conv1x1_bf16_wgrad_supported(batch, cin, cout, pixels, WORKSPACE_BYTES))
+
+
+def conv1x1_bf16_wgrad(x, grad_output, out_dtype=torch.float32):
+    """dL/dw [Cout,Cin,1,1] (float32 or bfloat16) of a stride-1 1x1 convolution from its bf16 NCHW input and dL/dy."""
+    require_device(x, "input")
+    if x.dtype != torch.bfloat16 or grad_output.dtype != torch.bfloat16 or not x.is_contiguous() or not grad_output.is_contiguous():
+        raise RuntimeError("conv1x1_bf16_wgrad: input and grad_output must be contiguous bfloat16 tensors")
+    b, cin = x.shape[0], x.shape[1]
+    cout = grad_output.shape[1]
+    pixels = x[0, 0].numel()
+    if grad_output.shape[0] != b or grad_output[0, 0].numel() != pixels:
+        raise RuntimeError("conv1x1_bf16_wgrad: input and grad_output disagree on batch / plane size")
+    dw = torch.empty((cout, cin, 1, 1), dtype=out_dtype, device=x.device)
+    ws = _workspace(x.device)
+    with torch.cuda.device(x.device):
+        _check(_launch(None, 2.0 * b * cout * cin * pixels, 2.0 * (x.numel() + grad_output.numel()) + 4.0 * dw.numel(),
+                       lambda: lib().sis_conv1x1_bf16_wgrad(_ptr(dw), _DTYPE_CODE[out_dtype], _ptr(x), _ptr(grad_output), b, cin, cout,
+                                                            pixels, _ptr(ws), ws.numel(), _stream())), "sis_conv1x1_bf16_wgrad")
     return dw
 
 

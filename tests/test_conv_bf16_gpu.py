@@ -92,6 +92,27 @@ def test_conv_bf16_weight_gradient(device, batch, cin, cout, h, w):
     assert torch.equal(again, sis_hip.conv_bf16_wgrad(x, gy, torch.float32))  # ordered slab reduction: bitwise reproducible
 
 
+@pytest.mark.parametrize("batch,cin,cout,h,w", [(8, 64, 256, 32, 32), (2, 256, 64, 127, 127), (1, 64, 64, 127, 127), (3, 1024, 256, 16, 16),
+                                                (2, 128, 512, 64, 64), (2, 72, 40, 20, 28), (1, 256, 1024, 32, 32), (2, 512, 128, 9, 7),
+                                                (8, 256, 64, 127, 127)])
+def test_conv1x1_bf16_weight_gradient(device, batch, cin, cout, h, w):
+    """dL/dw of the 1x1 layers (conv1x1_wgrad_bf16_kernel: all four wave layouts, aligned and odd planes, channel counts that
+    are not tile multiples, planes shorter than a stage) against the float64 contraction of the same bf16-rounded tensors on
+    the CPU; fp32 result |err| <= 2e-3 * max|ref| (fp32 accumulation), bf16 result 1e-2; bitwise repeatable."""
+    import sis_hip
+    gen = torch.Generator().manual_seed(cin + 3 * cout + h)
+    x = torch.randn(batch, cin, h, w, generator=gen).to(device).bfloat16()
+    gy = torch.randn(batch, cout, h, w, generator=gen).to(device).bfloat16()
+    ref = torch.einsum("bop,bip->oi", gy.cpu().double().flatten(2), x.cpu().double().flatten(2)).float().to(device)
+    assert sis_hip.conv1x1_bf16_wgrad_supported(batch, cin, cout, h * w)
+    for dtype, tol in ((torch.float32, 2e-3), (torch.bfloat16, 1e-2)):
+        dw = sis_hip.conv1x1_bf16_wgrad(x, gy, dtype)
+        assert dw.dtype == dtype and dw.shape == (cout, cin, 1, 1)
+        err = (dw.float().view(cout, cin) - ref).abs().max().item()
+        assert err <= tol * ref.abs().max().item(), (dtype, err, ref.abs().max().item())
+    assert torch.equal(sis_hip.conv1x1_bf16_wgrad(x, gy), sis_hip.conv1x1_bf16_wgrad(x, gy))
+
+
 def test_conv_bf16_autograd_function(device):
     """The autograd wrapper the networks call: forward, data and weight gradients, bias gradient in one graph."""
     from networks.hip_conv import conv_bf16, conv_bf16_applicable
