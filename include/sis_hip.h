@@ -384,6 +384,16 @@ int sis_conv_bf16_pack(void* packed, const void* weight, int weight_dtype, int c
                        int stride, int adjoint, void* stream);
 int sis_conv_bf16(void* y, const void* x, const void* packed, const float* bias, int batch, int cin, int cout, int h, int w,
                   int ksize, int stride, void* stream);
+/* All StdConv2d layers of a network in ONE launch: standardise every filter (as sis_weight_std_fwd, bf16 result) and write it
+ * into w_hat, into the forward image and (stride-1 layers) into the adjoint image of its layer
+ * (networks/trans_u_net/vit_seg_modeling_resnet_skip.py:20-27: the reference standardises every weight in every forward).
+ * `table`: device array of 13 int64 per layer -- pointers w (float32 [cout][cin][k][k]), w_hat (bf16), invstd (float32 [cout]),
+ * packed, adjoint (0 = none), then cout, cin, k, mt, kc, mt2 (from sis_weight_std_pack_plan), rows = ceil(cout / mt) * mt and
+ * row_begin = sum of the previous layers' rows; total_rows = sum of rows.  sis_weight_std_pack_plan returns 0 for a layer the
+ * bf16 convolution kernels have no plan for. */
+int sis_weight_std_pack_plan(int cin, int cout, int ksize, int stride, int* mt, int* kc, int* mt2, int64_t* packed_elems,
+                             int64_t* adjoint_elems);
+int sis_weight_std_pack_multi(const void* table, int n_layers, int total_rows, float eps, void* stream);
 /* forward and adjoint packing of a stride-1 layer's weight in one launch (training: both are needed every step) */
 int sis_conv_bf16_pack_both(void* packed, void* packed_adjoint, const void* weight, int weight_dtype, int cin, int cout, int h,
                             int w, int ksize, void* stream);

@@ -105,6 +105,81 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(u16* __restrict__ out, c
     out[e] = *reinterpret_cast<u16*>(&b);
 }
 
+// Weight standardisation of ALL the StdConv2d layers of a network and the packing of the results in ONE launch
+// (vit_seg_modeling_resnet_skip.py:20-27: every forward standardises every weight; 52 layers in R50-ViT-B/16 = 52
+// weight_std launches + 55 conv_pack launches per step before this).  Table of 13 int64 per layer:
+//   w (float32 [cout][cin][k][k]), w_hat (bf16, same shape), invstd (float32 [cout]), packed, adjoint (0 = none),
+//   cout, cin, k, mt, kc, mt2, rows (= M tiles * mt: workgroups of the layer), row_begin (prefix sum of rows).
+// One workgroup per packed row: two-pass mean / variance of filter `co` in fp32 (as weight_std_fwd_kernel), then the bf16
+// values go to w_hat (what the weight-gradient kernels and the backward read), to row `co` of the forward image and to
+// column `co` of the adjoint image (taps rotated by 180 degrees).  Rows beyond cout (tile padding) are written as zeros.
+constexpr int WSP_FIELDS = 13;
+
+__global__ __launch_bounds__(256) void weight_std_pack_multi_kernel(const long long* __restrict__ table, int n_layers, float eps) {
+    __shared__ float red[4];
+    int layer = 0;
+    while (layer + 1 < n_layers && (int)blockIdx.x >= (int)table[(layer + 1) * WSP_FIELDS + 12]) ++layer;
+    const long long* d = table + (int64_t)layer * WSP_FIELDS;
+    const float* w = reinterpret_cast<const float*>(d[0]);
+    u16* what = reinterpret_cast<u16*>(d[1]);
+    float* invstd = reinterpret_cast<float*>(d[2]);
+    u16* packed = reinterpret_cast<u16*>(d[3]);
+    u16* adj = reinterpret_cast<u16*>(d[4]);
+    const int Cout = (int)d[5], Cin = (int)d[6], KH = (int)d[7], MT = (int)d[8], KC = (int)d[9], MT2 = (int)d[10];
+    const int co = (int)blockIdx.x - (int)d[12];
+    const int taps = KH * KH, n = Cin * taps, units = KC / 8;
+    const int nchunks = Cin / KC;
+    const int mt = co / MT, row = co % MT;
+    auto fwd_pos = [&](int ci, int tap) {
+        const int chunk = ci / KC, unit = (ci % KC) >> 3, j = ci & 7;
+        return ((((int64_t)(mt * nchunks + chunk) * taps + tap) * MT + row) * units + swz(unit, row, units)) * 8 + j;
+    };
+    if (co >= Cout) {   // padding rows of the last M tile
+        for (int i = threadIdx.x; i < n; i += 256) packed[fwd_pos(i / taps, i % taps)] = 0;
+        return;
+    }
+    const float* src = w + (int64_t)co * n;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += src[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
+    __syncthreads();
+    float m2 = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { const float dd = src[i] - mean; m2 += dd * dd; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m2;
+    __syncthreads();
+    const float var = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
+    const float sd = sqrtf(var + eps);
+    if (threadIdx.x == 0) invstd[co] = 1.f / sd;
+    // adjoint image: M = Cin (row = ci), K = Cout (this filter is element k = co of every row)
+    const int nchunks2 = MT2 ? Cout / KC : 0, chunk2 = co / KC, unit2 = (co % KC) >> 3, j2 = co & 7;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        __hip_bfloat16 b = __float2bfloat16((src[i] - mean) / sd);
+        const u16 v = *reinterpret_cast<u16*>(&b);
+        what[(int64_t)co * n + i] = v;
+        const int ci = i / taps, tap = i - ci * taps;
+        packed[fwd_pos(ci, tap)] = v;
+        if (MT2) {
+            const int ky = tap / KH, kx = tap - ky * KH, tap2 = (KH - 1 - ky) * KH + (KH - 1 - kx);
+            const int mt2 = ci / MT2, row2 = ci % MT2;
+            adj[((((int64_t)(mt2 * nchunks2 + chunk2) * taps + tap2) * MT2 + row2) * units + swz(unit2, row2, units)) * 8 + j2] = v;
+        }
+    }
+    if (MT2 && Cin % MT2) {   // padding rows of the adjoint image's last M tile: zeros in this filter's column
+        const int pad0 = Cin, pad1 = (Cin + MT2 - 1) / MT2 * MT2;
+        for (int i = threadIdx.x; i < (pad1 - pad0) * taps; i += 256) {
+            const int ci = pad0 + i / taps, tap2 = i % taps;
+            const int mt2 = ci / MT2, row2 = ci % MT2;
+            adj[((((int64_t)(mt2 * nchunks2 + chunk2) * taps + tap2) * MT2 + row2) * units + swz(unit2, row2, units)) * 8 + j2] = 0;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- the convolution
 template <typename C, bool ALIGNED>
 __global__ __launch_bounds__(512, 2) void conv_bf16_kernel(ConvParams p) {
@@ -472,4 +547,29 @@ extern "C" int sis_conv_bf16(void* y, const void* x, const void* packed, const f
     CONV_CASE(128, 256, 16, 3, 2, 64) CONV_CASE(64, 256, 16, 3, 2, 64) CONV_CASE(128, 256, 16, 1, 2, 64) CONV_CASE(64, 256, 16, 1, 2, 64)
 #undef CONV_CASE
     return sis_fail("sis_conv_bf16: no kernel instance for tile plan mt=%d npix=%d kc=%d k=%d s=%d tw=%d", pl.mt, pl.npix, pl.kc, ksize, stride, pl.tw);
+}
+
+/* One launch for the standardised + packed weights of all StdConv2d layers (see weight_std_pack_multi_kernel).
+ * sis_weight_std_pack_plan: the packing parameters of a layer (they depend on cout, cin, ksize, stride only): mt, kc, mt2 (0: no
+ * adjoint image: stride 2, or cout not a multiple of kc) and the element counts of the two images; returns 0 when the layer
+ * has no plan (its weight then goes through sis_weight_std_fwd / sis_conv_bf16_pack as before). */
+extern "C" int sis_weight_std_pack_plan(int cin, int cout, int ksize, int stride, int* mt, int* kc, int* mt2, int64_t* packed_elems,
+                                        int64_t* adjoint_elems) {
+    Plan pf, pa;
+    if (!conv_plan(1, cin, cout, 64, 64, ksize, stride, &pf)) return 0;
+    *mt = pf.mt; *kc = pf.kc; *mt2 = 0; *adjoint_elems = 0;
+    *packed_elems = (int64_t)sis_cdiv(cout, pf.mt) * pf.mt * cin * ksize * ksize;
+    if (stride == 1 && conv_plan(1, cout, cin, 64, 64, ksize, 1, &pa) && pa.kc == pf.kc) {
+        *mt2 = pa.mt;
+        *adjoint_elems = (int64_t)sis_cdiv(cin, pa.mt) * pa.mt * cout * ksize * ksize;
+    }
+    return 1;
+}
+
+extern "C" int sis_weight_std_pack_multi(const void* table, int n_layers, int total_rows, float eps, void* stream) {
+    if (n_layers <= 0 || total_rows <= 0) return 0;
+    SIS_REQUIRE(table, "sis_weight_std_pack_multi: null table");
+    hipLaunchKernelGGL(weight_std_pack_multi_kernel, dim3(total_rows), dim3(256), 0, (hipStream_t)stream, (const long long*)table, n_layers, eps);
+    SIS_CHECK_LAUNCH("weight_std_pack_multi_kernel");
+    return 0;
 }

@@ -284,12 +284,15 @@ class _ConvBf16Function(Function):
     """
 
     @staticmethod
-    def forward(ctx, input, weight, bias, stride):
+    def forward(ctx, input, weight, bias, stride, packed=None, adjoint=None):
+        """``packed`` / ``adjoint``: the images of ``weight`` when the caller already has them (the trunk's weight bank writes
+        them for all layers in one launch)."""
         input = input.contiguous()
         cout, cin, k, _ = weight.shape
         h, w = input.shape[2], input.shape[3]
-        adjoint = None
-        if stride == 1 and ctx.needs_input_grad[0] and sis_hip.conv_bf16_supported(cout, cin, h, w, k, 1):
+        if packed is not None:
+            pass
+        elif stride == 1 and ctx.needs_input_grad[0] and sis_hip.conv_bf16_supported(cout, cin, h, w, k, 1):
             packed, adjoint = sis_hip.conv_bf16_pack_both(weight, h, w)  # one launch packs for forward AND data gradient
         else:
             packed = sis_hip.conv_bf16_pack(weight, h, w, stride)
@@ -365,12 +368,14 @@ class _ConvBf16Function(Function):
             full = grad_input.new_zeros((b, cin) + scatter)
             full[:, :, ::2, ::2] = grad_input
             grad_input = full
-        return grad_input, grad_weight, grad_bias, None
+        return grad_input, grad_weight, grad_bias, None, None, None
 
 
-def conv_bf16(input, weight, bias=None, stride=1):
+def conv_bf16(input, weight, bias=None, stride=1, prepacked=None):
     """Differentiable bf16 convolution (padding k // 2) on the matrix-core kernels; the caller checks
-    ``conv_bf16_applicable``."""
+    ``conv_bf16_applicable``.  ``prepacked``: (forward image, adjoint image or None) of ``weight``."""
+    if prepacked is not None:
+        return _ConvBf16Function.apply(input, weight, bias, stride, prepacked[0], prepacked[1])
     return _ConvBf16Function.apply(input, weight, bias, stride)
 
 

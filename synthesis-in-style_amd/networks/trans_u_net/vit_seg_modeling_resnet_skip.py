@@ -47,6 +47,28 @@ class _WeightStandardize(Function):
         return sis_hip.weight_std_bwd(grad, weight, invstd, ctx.eps), None, None
 
 
+class _BankStandardize(Function):
+    """All StdConv2d weights of the trunk at once: ``forward(bank, *weights) -> w_hat per layer`` runs ONE launch that also
+    writes every layer's packed images (``sis_hip.WeightStdPackBank``: 52 weight_std + 55 conv_pack launches per step before);
+    the backward is the per-layer standardisation backward."""
+
+    @staticmethod
+    def forward(ctx, bank, *weights):
+        bank.refresh()
+        ctx.bank = bank
+        ctx.save_for_backward(*weights)
+        return tuple(t.view_as(t) for t in bank.w_hat)   # fresh views of the persistent buffers
+
+    @staticmethod
+    def backward(ctx, *grads):
+        bank = ctx.bank
+        out = [None]
+        for g, w, invstd in zip(grads, ctx.saved_tensors, bank.invstd):
+            out.append(None if g is None else sis_hip.weight_std_bwd(g, w, invstd, bank.eps))
+        return tuple(out)
+
+
+_WS_BANK = os.environ.get('SIS_WS_BANK', '1') != '0'   # 0: every StdConv2d standardises and packs its own weight (A/B runs)
 _FUSE_RESIDUAL = os.environ.get('SIS_GN_RES', '1') != '0'
 _DUAL_STREAM = os.environ.get('SIS_GN_DUAL', '1') != '0'  # bottlenecks hand (fp32 residual stream, 16-bit copy) to the next one
 
@@ -110,8 +132,16 @@ class StdConv2d(nn.Conv2d):
         var, mean = torch.var_mean(w, dim=[1, 2, 3], keepdim=True, unbiased=False)
         return (w - mean) / torch.sqrt(var + self.EPS)
 
+    _banked = None   # (w_hat, packed, adjoint) of this forward when the trunk's weight bank produced them
+
     def forward(self, x):
-        w = self.standardized_weight()
+        if self._banked is not None:
+            w, packed, adjoint = self._banked
+            xb = x if x.dtype == torch.bfloat16 else x.bfloat16()
+            if conv_bf16_applicable(xb, w, self.stride, self.padding, self.dilation, self.groups):
+                return conv_bf16(xb, w, self.bias, self.stride[0], prepacked=(packed, adjoint))
+        else:
+            w = self.standardized_weight()
         if _BF16_CONV and w.dtype == torch.bfloat16 and self.padding_mode == 'zeros' and x.is_cuda and x.dim() == 4:
             xb = x if x.dtype == torch.bfloat16 else x.bfloat16()  # (the root convolution's fp32 image)
             if conv_bf16_applicable(xb, w, self.stride, self.padding, self.dilation, self.groups):
@@ -186,7 +216,43 @@ class ResNetV2(nn.Module):
             cin = cout
         self.body = nn.Sequential(stages)
 
+    _bank = None
+    _bank_list = None
+
+    def _bank_layers(self):
+        """The StdConv2d layers whose weights the bank can serve: float32 HIP weights under bf16 autocast with a packing plan
+        (all 1x1 / 3x3 layers of the trunk; the 7x7 root keeps its own launch)."""
+        return [m for m in self.modules() if isinstance(m, StdConv2d) and m.weight.is_cuda and m.groups == 1 and m.bias is None
+                and m.padding_mode == 'zeros' and m.dilation == (1, 1) and m.stride[0] == m.stride[1]
+                and m.kernel_size[0] == m.kernel_size[1] and m.padding == (m.kernel_size[0] // 2, m.kernel_size[0] // 2)
+                and sis_hip.WeightStdPackBank.supported(m.weight, m.stride[0])]
+
+    def _standardize_all(self):
+        if not (_WS_BANK and _BF16_CONV and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16):
+            return []
+        layers = self._bank_list
+        if layers is None:
+            layers = self._bank_list = self._bank_layers()   # (the module tree does not change after construction)
+        if not layers:
+            return []
+        bank = self._bank
+        if bank is None or len(bank.weights) != len(layers) or any(a is not m.weight for a, m in zip(bank.weights, layers)) \
+                or not bank.current():
+            bank = self._bank = sis_hip.WeightStdPackBank([m.weight for m in layers], [m.stride[0] for m in layers], StdConv2d.EPS)
+        w_hats = _BankStandardize.apply(bank, *bank.weights)
+        for m, w_hat, packed, adjoint in zip(layers, w_hats, bank.packed, bank.adjoint):
+            m._banked = (w_hat, packed, adjoint)
+        return layers
+
     def forward(self, x):
+        banked = self._standardize_all() if x.is_cuda else []
+        try:
+            return self._forward(x)
+        finally:
+            for m in banked:
+                m._banked = None
+
+    def _forward(self, x):
         in_size = x.size(2)
         x = self.root(x)
         skips = [x]

@@ -105,6 +105,8 @@ _SIGNATURES = {
     "sis_conv_bf16_pack_both": ([_vp, _vp, _vp, _i] + [_i] * 5 + [_vp], _i),
     "sis_conv_bf16_wgrad_supported": ([_i] * 5 + [_i64], _i),
     "sis_conv_bf16_wgrad": ([_vp, _i, _vp, _vp] + [_i] * 5 + [_vp, _i64, _vp], _i),
+    "sis_weight_std_pack_plan": ([_i] * 4 + [_vp] * 5, _i),
+    "sis_weight_std_pack_multi": ([_vp, _i, _i, _f, _vp], _i),
     "sis_conv1x1_bf16_wgrad_supported": ([_i] * 4 + [_i64], _i),
     "sis_conv1x1_bf16_wgrad": ([_vp, _i, _vp, _vp] + [_i] * 4 + [_vp, _i64, _vp], _i),
 }
@@ -738,6 +740,53 @@ def conv_bf16_wgrad(x, grad_output, out_dtype=torch.float32):
                        lambda: lib().sis_conv_bf16_wgrad(_ptr(dw), _DTYPE_CODE[out_dtype], _ptr(x), _ptr(grad_output), b, cin, cout,
                                                          h, w, _ptr(ws), ws.numel(), _stream())), "sis_conv_bf16_wgrad")
     return dw
+
+
+class WeightStdPackBank:
+    """Standardised + packed bf16 weights of a list of float32 convolution weights, refreshed by ONE launch
+    (``sis_weight_std_pack_multi``).  Output buffers are allocated once: ``w_hat[i]``, ``invstd[i]``, ``packed[i]``,
+    ``adjoint[i]`` (None for layers without an adjoint image) keep their addresses, ``refresh()`` rewrites their contents."""
+
+    def __init__(self, weights, strides, eps):
+        self.eps = float(eps)
+        self.weights = list(weights)
+        dev = self.weights[0].device
+        self.w_hat, self.invstd, self.packed, self.adjoint = [], [], [], []
+        rows, row_begin = [], 0
+        for w, stride in zip(self.weights, strides):
+            cout, cin, k, _ = w.shape
+            mt, kc, mt2 = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            pe, ae = ctypes.c_int64(), ctypes.c_int64()
+            if w.dtype != torch.float32 or not w.is_contiguous() or not lib().sis_weight_std_pack_plan(
+                    cin, cout, k, stride, ctypes.byref(mt), ctypes.byref(kc), ctypes.byref(mt2), ctypes.byref(pe), ctypes.byref(ae)):
+                raise RuntimeError(f"WeightStdPackBank: no plan for a {cin}->{cout} k{k} s{stride} layer")
+            self.w_hat.append(torch.empty(w.shape, dtype=torch.bfloat16, device=dev))
+            self.invstd.append(torch.empty(cout, dtype=torch.float32, device=dev))
+            self.packed.append(torch.empty(pe.value, dtype=torch.bfloat16, device=dev))
+            self.adjoint.append(torch.empty(ae.value, dtype=torch.bfloat16, device=dev) if mt2.value else None)
+            n_rows = -(-cout // mt.value) * mt.value
+            rows.append([w.data_ptr(), self.w_hat[-1].data_ptr(), self.invstd[-1].data_ptr(), self.packed[-1].data_ptr(),
+                         self.adjoint[-1].data_ptr() if mt2.value else 0, cout, cin, k, mt.value, kc.value, mt2.value, n_rows, row_begin])
+            row_begin += n_rows
+        self.total_rows = row_begin
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.source_ptrs = [w.data_ptr() for w in self.weights]
+
+    @staticmethod
+    def supported(weight, stride):
+        cout, cin, k, k2 = weight.shape
+        out = [ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int64(), ctypes.c_int64()]
+        return bool(k == k2 and weight.dtype == torch.float32 and weight.is_contiguous()
+                    and lib().sis_weight_std_pack_plan(cin, cout, k, stride, *[ctypes.byref(o) for o in out]))
+
+    def current(self):
+        """The table still points at the weights (a module moved / re-materialised since would have new storage)."""
+        return all(w.data_ptr() == ptr for w, ptr in zip(self.weights, self.source_ptrs))
+
+    def refresh(self):
+        with torch.cuda.device(self.table.device):
+            _check(lib().sis_weight_std_pack_multi(_ptr(self.table), len(self.weights), self.total_rows, self.eps, _stream()),
+                   "sis_weight_std_pack_multi")
 
 
 def conv1x1_bf16_wgrad_supported(batch, cin, cout, pixels):
