@@ -387,13 +387,18 @@ int sis_conv_bf16(void* y, const void* x, const void* packed, const float* bias,
 /* All StdConv2d layers of a network in ONE launch: standardise every filter (as sis_weight_std_fwd, bf16 result) and write it
  * into w_hat, into the forward image and (stride-1 layers) into the adjoint image of its layer
  * (networks/trans_u_net/vit_seg_modeling_resnet_skip.py:20-27: the reference standardises every weight in every forward).
- * `table`: device array of 13 int64 per layer -- pointers w (float32 [cout][cin][k][k]), w_hat (bf16), invstd (float32 [cout]),
- * packed, adjoint (0 = none), then cout, cin, k, mt, kc, mt2 (from sis_weight_std_pack_plan), rows = ceil(cout / mt) * mt and
- * row_begin = sum of the previous layers' rows; total_rows = sum of rows.  sis_weight_std_pack_plan returns 0 for a layer the
+ * `table`: device array of 14 int64 per layer -- pointers w (float32 [cout][cin][k][k]), w_hat (bf16), invstd (float32 [cout]),
+ * packed, adjoint (0 = none), then cout, cin, k, mt, kc, mt2 (from sis_weight_std_pack_plan), rows = ceil(cout / mt) * mt,
+ * row_begin = sum of the previous layers' rows, filter_begin = sum of the previous layers' cout; total_rows = sum of rows.  sis_weight_std_pack_plan returns 0 for a layer the
  * bf16 convolution kernels have no plan for. */
 int sis_weight_std_pack_plan(int cin, int cout, int ksize, int stride, int* mt, int* kc, int* mt2, int64_t* packed_elems,
                              int64_t* adjoint_elems);
 int sis_weight_std_pack_multi(const void* table, int n_layers, int total_rows, float eps, void* stream);
+/* ... and its backward for all layers in one launch (per 64 layers): grads[i] = dL/dw_hat of layer i (bf16, device pointer, NULL =
+ * no gradient for that layer), dw[i] = float32 result of the layer's weight shape; `grads`, `dw`, `couts` are HOST arrays of
+ * n_layers entries in the table's layer order. */
+int sis_weight_std_bwd_multi(const void* table, const void* const* grads, void* const* dw, const int* couts, int n_layers,
+                             void* stream);
 /* forward and adjoint packing of a stride-1 layer's weight in one launch (training: both are needed every step) */
 int sis_conv_bf16_pack_both(void* packed, void* packed_adjoint, const void* weight, int weight_dtype, int cin, int cout, int h,
                             int w, int ksize, void* stream);

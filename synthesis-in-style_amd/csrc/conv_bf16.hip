@@ -22,6 +22,7 @@
 //
 // The data gradient is the same kernel on adjoint-packed weights (channel roles swapped, taps rotated by 180 degrees);
 // stride-2 layers read their B fragments at a pixel stride of two units.
+#include <algorithm>
 #include <type_traits>
 #include "sis_common.h"
 
@@ -107,13 +108,14 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(u16* __restrict__ out, c
 
 // Weight standardisation of ALL the StdConv2d layers of a network and the packing of the results in ONE launch
 // (vit_seg_modeling_resnet_skip.py:20-27: every forward standardises every weight; 52 layers in R50-ViT-B/16 = 52
-// weight_std launches + 55 conv_pack launches per step before this).  Table of 13 int64 per layer:
+// weight_std launches + 55 conv_pack launches per step before this).  Table of 14 int64 per layer:
 //   w (float32 [cout][cin][k][k]), w_hat (bf16, same shape), invstd (float32 [cout]), packed, adjoint (0 = none),
-//   cout, cin, k, mt, kc, mt2, rows (= M tiles * mt: workgroups of the layer), row_begin (prefix sum of rows).
+//   cout, cin, k, mt, kc, mt2, rows (= M tiles * mt: workgroups of the layer), row_begin (prefix sum of rows),
+//   filter_begin (prefix sum of cout: the backward's workgroups).
 // One workgroup per packed row: two-pass mean / variance of filter `co` in fp32 (as weight_std_fwd_kernel), then the bf16
 // values go to w_hat (what the weight-gradient kernels and the backward read), to row `co` of the forward image and to
 // column `co` of the adjoint image (taps rotated by 180 degrees).  Rows beyond cout (tile padding) are written as zeros.
-constexpr int WSP_FIELDS = 13;
+constexpr int WSP_FIELDS = 14;
 
 __global__ __launch_bounds__(256) void weight_std_pack_multi_kernel(const long long* __restrict__ table, int n_layers, float eps) {
     __shared__ float red[4];
@@ -177,6 +179,51 @@ __global__ __launch_bounds__(256) void weight_std_pack_multi_kernel(const long l
             const int mt2 = ci / MT2, row2 = ci % MT2;
             adj[((((int64_t)(mt2 * nchunks2 + chunk2) * taps + tap2) * MT2 + row2) * units + swz(unit2, row2, units)) * 8 + j2] = 0;
         }
+    }
+}
+
+// Backward of the standardisation for all layers in one launch: dw = invstd * (g - mean(g) - w_hat * mean(g * w_hat)) per filter
+// (as weight_std_bwd_kernel, w_hat recomputed from the fp32 master weight).  The gradient / result pointers change from step
+// to step, so they travel as kernel arguments (<= 64 layers per launch); everything static comes from the forward's table.
+constexpr int WSB_MAX = 64;
+struct WsBwdPtrs { const u16* g[WSB_MAX]; float* dw[WSB_MAX]; };
+
+__global__ __launch_bounds__(256) void weight_std_bwd_multi_kernel(const long long* __restrict__ table, int layer0, int n_layers, WsBwdPtrs ptrs) {
+    __shared__ float red[4];
+    auto block_sum = [&](float v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    const int base = (int)table[(int64_t)layer0 * WSP_FIELDS + 13];
+    int layer = layer0;
+    while (layer + 1 < layer0 + n_layers && (int)blockIdx.x + base >= (int)table[(int64_t)(layer + 1) * WSP_FIELDS + 13]) ++layer;
+    const long long* d = table + (int64_t)layer * WSP_FIELDS;
+    const u16* g = ptrs.g[layer - layer0];
+    float* dw = ptrs.dw[layer - layer0];
+    if (!g) return;
+    const int co = (int)blockIdx.x + base - (int)d[13];
+    const int n = (int)d[6] * (int)d[7] * (int)d[7];
+    const float* row = reinterpret_cast<const float*>(d[0]) + (int64_t)co * n;
+    const u16* grow = g + (int64_t)co * n;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += row[i];
+    const float mean = block_sum(s) / (float)n;
+    const float is = reinterpret_cast<const float*>(d[2])[co];
+    float sg = 0.f, sgw = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float gi = __builtin_bit_cast(float, (unsigned)grow[i] << 16), wh = (row[i] - mean) * is;
+        sg += gi; sgw += gi * wh;
+    }
+    const float mg = block_sum(sg) / (float)n;
+    const float mgw = block_sum(sgw) / (float)n;
+    float* o = dw + (int64_t)co * n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float gi = __builtin_bit_cast(float, (unsigned)grow[i] << 16), wh = (row[i] - mean) * is;
+        o[i] = is * (gi - mg - wh * mgw);
     }
 }
 
@@ -571,5 +618,28 @@ extern "C" int sis_weight_std_pack_multi(const void* table, int n_layers, int to
     SIS_REQUIRE(table, "sis_weight_std_pack_multi: null table");
     hipLaunchKernelGGL(weight_std_pack_multi_kernel, dim3(total_rows), dim3(256), 0, (hipStream_t)stream, (const long long*)table, n_layers, eps);
     SIS_CHECK_LAUNCH("weight_std_pack_multi_kernel");
+    return 0;
+}
+
+/* Backward of sis_weight_std_pack_multi's standardisation: grads[i] (bf16, layer i's dL/dw_hat, NULL = layer skipped) ->
+ * dw[i] (float32, the layer's weight shape); `grads` / `dw` are HOST arrays of n_layers device pointers, `filters_total` =
+ * sum of cout over the layers (= the table's last filter_begin + cout). */
+extern "C" int sis_weight_std_bwd_multi(const void* table, const void* const* grads, void* const* dw, const int* couts, int n_layers,
+                                        void* stream) {
+    if (n_layers <= 0) return 0;
+    SIS_REQUIRE(table && grads && dw && couts, "sis_weight_std_bwd_multi: null pointer");
+    for (int l0 = 0; l0 < n_layers; l0 += WSB_MAX) {
+        const int nl = std::min(WSB_MAX, n_layers - l0);
+        WsBwdPtrs ptrs;
+        int rows = 0;
+        for (int i = 0; i < WSB_MAX; ++i) {
+            ptrs.g[i] = i < nl ? (const u16*)grads[l0 + i] : nullptr;
+            ptrs.dw[i] = i < nl ? (float*)dw[l0 + i] : nullptr;
+            SIS_REQUIRE(i >= nl || !ptrs.g[i] || ptrs.dw[i], "sis_weight_std_bwd_multi: layer %d has a gradient but no result", l0 + i);
+            if (i < nl) rows += couts[l0 + i];
+        }
+        hipLaunchKernelGGL(weight_std_bwd_multi_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const long long*)table, l0, nl, ptrs);
+        SIS_CHECK_LAUNCH("weight_std_bwd_multi_kernel");
+    }
     return 0;
 }

@@ -50,7 +50,7 @@ class _WeightStandardize(Function):
 class _BankStandardize(Function):
     """All StdConv2d weights of the trunk at once: ``forward(bank, *weights) -> w_hat per layer`` runs ONE launch that also
     writes every layer's packed images (``sis_hip.WeightStdPackBank``: 52 weight_std + 55 conv_pack launches per step before);
-    the backward is the per-layer standardisation backward."""
+    the backward likewise is one launch for all layers (``sis_weight_std_bwd_multi``)."""
 
     @staticmethod
     def forward(ctx, bank, *weights):
@@ -61,11 +61,7 @@ class _BankStandardize(Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        bank = ctx.bank
-        out = [None]
-        for g, w, invstd in zip(grads, ctx.saved_tensors, bank.invstd):
-            out.append(None if g is None else sis_hip.weight_std_bwd(g, w, invstd, bank.eps))
-        return tuple(out)
+        return (None,) + tuple(ctx.bank.backward(grads))
 
 
 _WS_BANK = os.environ.get('SIS_WS_BANK', '1') != '0'   # 0: every StdConv2d standardises and packs its own weight (A/B runs)

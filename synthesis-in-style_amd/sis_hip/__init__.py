@@ -107,6 +107,7 @@ _SIGNATURES = {
     "sis_conv_bf16_wgrad": ([_vp, _i, _vp, _vp] + [_i] * 5 + [_vp, _i64, _vp], _i),
     "sis_weight_std_pack_plan": ([_i] * 4 + [_vp] * 5, _i),
     "sis_weight_std_pack_multi": ([_vp, _i, _i, _f, _vp], _i),
+    "sis_weight_std_bwd_multi": ([_vp, _vp, _vp, _vp, _i, _vp], _i),
     "sis_conv1x1_bf16_wgrad_supported": ([_i] * 4 + [_i64], _i),
     "sis_conv1x1_bf16_wgrad": ([_vp, _i, _vp, _vp] + [_i] * 4 + [_vp, _i64, _vp], _i),
 }
@@ -752,7 +753,7 @@ class WeightStdPackBank:
         self.weights = list(weights)
         dev = self.weights[0].device
         self.w_hat, self.invstd, self.packed, self.adjoint = [], [], [], []
-        rows, row_begin = [], 0
+        rows, row_begin, filter_begin = [], 0, 0
         for w, stride in zip(self.weights, strides):
             cout, cin, k, _ = w.shape
             mt, kc, mt2 = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
@@ -766,8 +767,10 @@ class WeightStdPackBank:
             self.adjoint.append(torch.empty(ae.value, dtype=torch.bfloat16, device=dev) if mt2.value else None)
             n_rows = -(-cout // mt.value) * mt.value
             rows.append([w.data_ptr(), self.w_hat[-1].data_ptr(), self.invstd[-1].data_ptr(), self.packed[-1].data_ptr(),
-                         self.adjoint[-1].data_ptr() if mt2.value else 0, cout, cin, k, mt.value, kc.value, mt2.value, n_rows, row_begin])
+                         self.adjoint[-1].data_ptr() if mt2.value else 0, cout, cin, k, mt.value, kc.value, mt2.value, n_rows, row_begin,
+                         filter_begin])
             row_begin += n_rows
+            filter_begin += cout
         self.total_rows = row_begin
         self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
         self.source_ptrs = [w.data_ptr() for w in self.weights]
@@ -782,6 +785,20 @@ class WeightStdPackBank:
     def current(self):
         """The table still points at the weights (a module moved / re-materialised since would have new storage)."""
         return all(w.data_ptr() == ptr for w, ptr in zip(self.weights, self.source_ptrs))
+
+    def backward(self, grads):
+        """grads[i]: dL/dw_hat of layer i or None -> list of dL/dw (float32) or None, one launch for all layers (bf16
+        contiguous gradients; anything else goes layer by layer)."""
+        n = len(self.weights)
+        if any(g is not None and (g.dtype != torch.bfloat16 or not g.is_contiguous()) for g in grads):
+            return [None if g is None else weight_std_bwd(g, w, i, self.eps) for g, w, i in zip(grads, self.weights, self.invstd)]
+        out = [None if g is None else torch.empty(w.shape, dtype=torch.float32, device=w.device) for g, w in zip(grads, self.weights)]
+        g_ptrs = (ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in grads])
+        o_ptrs = (ctypes.c_void_p * n)(*[None if o is None else o.data_ptr() for o in out])
+        couts = (ctypes.c_int * n)(*[w.shape[0] for w in self.weights])
+        with torch.cuda.device(self.table.device):
+            _check(lib().sis_weight_std_bwd_multi(_ptr(self.table), g_ptrs, o_ptrs, couts, n, _stream()), "sis_weight_std_bwd_multi")
+        return out
 
     def refresh(self):
         with torch.cuda.device(self.table.device):
