@@ -6,12 +6,13 @@
 //
 // Two launches per direction, each fully parallel: (1) one workgroup per (sample, channel) plane reduces it -- mean /
 // M2 forward, sum(g') / sum(g' * xhat) backward (g' = g masked by the recomputed ReLU: nothing but x is saved); the
-// workgroup that completes a group (a device-scope counter per group, left at zero again) merges the group's planes
+// workgroup that completes a group (a device-scope counter per group, left at zero again: sis_xwg.h) merges the group's planes
 // (Chan's formula, in channel order whichever workgroup does it: deterministic) into per-plane scale / shift
 // coefficients; (2) a grid-strided element-wise kernel applies them (4 elements per lane when HW % 4 == 0), and its first
 // workgroup adds the plane sums over the batch in fixed order: d(gamma) / d(beta).  (Batch-norm mode and callers without a
 // counter buffer keep the merge as a launch of its own.)
 #include "sis_common.h"
+#include "sis_xwg.h"
 
 namespace {
 
@@ -83,16 +84,12 @@ __device__ __forceinline__ void gn_span(int64_t base, int lo, int hi, FS scalar,
 // planes of a group with Chan's formula in channel order (no E[x^2] - E[x]^2 cancellation, deterministic).
 // Planes are cut into S slices of `sl` elements (blockIdx.y) so that few-channel, high-resolution tensors (the decoder's
 // 16 x 512^2 maps) still fill the chip; part[plane][slice] = (count, mean, M2).
-__device__ __forceinline__ void gn_publish(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float gn_peek(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 __device__ __forceinline__ void gn_row_finish(int row, int lane, int lanes, float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                               float* __restrict__ ab, const float* __restrict__ part, const float* __restrict__ gamma,
                                               const float* __restrict__ beta, int groups, int cpg, int S, float eps);
 __device__ __forceinline__ void gn_bwd_row(int row, int lane, int lanes, float* __restrict__ coef, float* __restrict__ psum,
                                            const float* __restrict__ part, const float* __restrict__ rstd_in,
                                            const float* __restrict__ gamma, int groups, int cpg, int hw, int S);
-__device__ __forceinline__ bool gn_group_complete(int* counter, int count);
 
 struct GnFinish {   // counters == nullptr: no merge in the statistics kernel
     int* counters; float* mean; float* rstd; float* ab; const float* gamma; const float* beta; int groups, cpg; float eps;
@@ -124,11 +121,11 @@ __global__ __launch_bounds__(256) void gn_plane_stats_kernel(float* __restrict__
     m2 = gn_block_sum(m2, red);
     if (threadIdx.x == 0) {
         float* o = part + 3 * ((int64_t)blockIdx.x * gridDim.y + blockIdx.y);
-        gn_publish(o, cnt); gn_publish(o + 1, mean); gn_publish(o + 2, m2);
+        xwg_publish(o, cnt); xwg_publish(o + 1, mean); xwg_publish(o + 2, m2);
     }
     if (fin.counters) {
         const int row = blockIdx.x / fin.cpg;
-        if (gn_group_complete(fin.counters + row, fin.cpg * gridDim.y) && threadIdx.x < 64)
+        if (xwg_complete<false>(fin.counters + row, fin.cpg * gridDim.y) && threadIdx.x < 64)
             gn_row_finish(row, threadIdx.x, 64, fin.mean, fin.rstd, fin.ab, part, fin.gamma, fin.beta, fin.groups, fin.cpg, gridDim.y, fin.eps);
     }
 }
@@ -152,14 +149,14 @@ __device__ __forceinline__ void gn_row_finish(int row, int lane, int lanes, floa
             float pn = 0.f, pm = 0.f, p2 = 0.f;
             if (j < cpg * S) {
                 const float* p = part + 3 * ((int64_t)row * cpg * S + j);
-                pn = gn_peek(p); pm = gn_peek(p + 1); p2 = gn_peek(p + 2);
+                pn = xwg_peek(p); pm = xwg_peek(p + 1); p2 = xwg_peek(p + 2);
             }
             for (int t = 0; t < cnt; ++t) merge(__shfl(pn, t, 64), __shfl(pm, t, 64), __shfl(p2, t, 64));
         }
     } else {
         for (int j = 0; j < cpg * S; ++j) {
             const float* p = part + 3 * ((int64_t)row * cpg * S + j);
-            merge(gn_peek(p), gn_peek(p + 1), gn_peek(p + 2));
+            merge(xwg_peek(p), xwg_peek(p + 1), xwg_peek(p + 2));
         }
     }
     const float rstd = rsqrtf(m2 / n + eps);
@@ -179,24 +176,6 @@ __global__ __launch_bounds__(64) void gn_row_finish_kernel(float* __restrict__ m
     const int row = blockIdx.x * 64 + threadIdx.x;
     if (row >= rows) return;
     gn_row_finish(row, 0, 1, mean_out, rstd_out, ab, part, gamma, beta, groups, cpg, S, eps);
-}
-
-// The workgroup that finds a group's counter at `count - 1` is the one that completed it.  Partial results travel between
-// workgroups (possibly on different XCDs = different L2s) as device-scope relaxed atomics: gn_publish writes through to the
-// device's coherence point, the increment is issued once that store has completed, gn_peek reads past the non-coherent
-// caches.  No device-scope FENCE anywhere: a release / acquire fence writes back / invalidates the whole L2 of the XCD, and
-// with one per workgroup the trunk's norms ran 15 ms per step slower than with the merge as a launch of its own.
-// The completing workgroup puts the counter back to zero for the next launch on this stream.
-__device__ __forceinline__ bool gn_group_complete(int* counter, int count) {
-    __shared__ int last;
-    if (threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's gn_publish stores have completed; no cache maintenance
-        last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == count - 1;
-    }
-    __syncthreads();
-    if (!last) return false;
-    if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return true;
 }
 
 // y = relu?(x * a[plane] + b[plane] (+ residual)); VEC elements per lane.  FLAT: hw is not a multiple of VEC, a lane's
@@ -267,10 +246,10 @@ __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ p
     sgx = gn_block_sum(sgx, red);
     if (threadIdx.x == 0) {
         float* o = part + 2 * (plane * gridDim.y + blockIdx.y);
-        gn_publish(o, sg); gn_publish(o + 1, sgx);
+        xwg_publish(o, sg); xwg_publish(o + 1, sgx);
     }
     if (counters) {   // (group-norm mode only: cpg > 0)
-        if (gn_group_complete(counters + row, cpg * gridDim.y) && threadIdx.x < 64)
+        if (xwg_complete<false>(counters + row, cpg * gridDim.y) && threadIdx.x < 64)
             gn_bwd_row((int)row, threadIdx.x, 64, coef, psum, part, rstd_in, gamma, C / cpg, cpg, hw, gridDim.y);
     }
 }
@@ -289,7 +268,7 @@ __device__ __forceinline__ void gn_bwd_row(int row, int lane, int lanes, float* 
             if (c < cpg) {
                 for (int k = 0; k < S; ++k) {
                     const float* p = part + 2 * (((int64_t)row * cpg + c) * S + k);
-                    a += gn_peek(p); b += gn_peek(p + 1);
+                    a += xwg_peek(p); b += xwg_peek(p + 1);
                 }
                 psum[2 * ((int64_t)row * cpg + c)] = a; psum[2 * ((int64_t)row * cpg + c) + 1] = b;  // plane sums (for d gamma / beta)
                 gm = gamma[c0 + c];
@@ -301,7 +280,7 @@ __device__ __forceinline__ void gn_bwd_row(int row, int lane, int lanes, float* 
             float a = 0.f, b = 0.f;
             for (int k = 0; k < S; ++k) {
                 const float* p = part + 2 * (((int64_t)row * cpg + c) * S + k);
-                a += gn_peek(p); b += gn_peek(p + 1);
+                a += xwg_peek(p); b += xwg_peek(p + 1);
             }
             if (c % lanes == lane) {  // plane sums (for d gamma / beta)
                 psum[2 * ((int64_t)row * cpg + c)] = a; psum[2 * ((int64_t)row * cpg + c) + 1] = b;
