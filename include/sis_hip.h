@@ -329,6 +329,12 @@ int sis_layer_norm_bwd(void* dx, float* dgamma, float* dbeta, float* workspace, 
  * backward = 1: out = grad_x [planes][h][w] from x = grad_out [planes][out_h][out_w] (gather, deterministic). */
 int sis_upsample_bilinear(void* out, const void* x, int dtype, int64_t planes, int h, int w, int out_h, int out_w,
                           int backward, void* stream);
+/* The same with an image stride on the UPSAMPLED-size tensor (elements between consecutive images; >= channels*out_h*out_w):
+ * forward writes its result into the leading channels of a wider tensor, backward reads grad_out from there -- the decoder's
+ * torch.cat([up(x), skip], dim=1) (vit_seg_modeling.py:300-303) then costs one copy of the skip feature only.  Strided
+ * tensors need the x2 case (out_h = 2h, out_w = 2w). */
+int sis_upsample_bilinear_strided(void* out, const void* x, int dtype, int batch, int channels, int h, int w, int out_h, int out_w,
+                                  int64_t image_stride, int backward, void* stream);
 
 /* Weight gradient of the same 1x1 convolutions (networks/hip_conv.py::_Pointwise.backward; reference layers as for
  * sis_conv1x1_f32): dw[co][ci] = sum_{b, p} gy[b][co][p] * x[b][ci][p], fp32 on the matrix cores, NCHW rows straight from

@@ -1,8 +1,8 @@
 // Bilinear upsampling with align_corners=True (nn.UpsamplingBilinear2d), forward and backward -- the TransUNet decoder
 // (networks/trans_u_net/vit_seg_modeling.py:290-329: every DecoderBlock and the SegmentationHead upsample by 2).
 // ATen's kernel runs these four tensors at ~1/8 of the HBM roofline and its backward scatters with float atomics;
-// here the forward is one pass (each lane 4 consecutive outputs of a row: 16-byte stores, the two source rows come
-// from L2) and the backward is a gather (one lane per input pixel sums the <= 4 x 4 outputs whose footprint touches
+// here the forward is one pass (x2: source tile through LDS, 16-byte stores; other ratios: each lane 4 consecutive outputs
+// of a row, the two source rows come from L2) and the backward is a gather (one lane per input pixel sums the <= 4 x 4 outputs whose footprint touches
 // it): deterministic, no atomics.  Index rule = PyTorch's: src = dst * (in - 1) / (out - 1), i0 = (int) src,
 // i1 = i0 + (i0 < in - 1), lambda1 = src - i0.  Arithmetic in fp32 for f32 / bf16 / f16 tensors.
 #include "sis_common.h"
@@ -56,6 +56,72 @@ __global__ __launch_bounds__(256) void bilinear_up_fwd_kernel(T* __restrict__ ou
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (4 * c4 + e < ow) sis_st(o, e, v[e]);
+        }
+    }
+}
+
+// Forward of the x2 case (every call of the TransUNet decoder), tiled through LDS: a workgroup owns 16 output rows x <= 512
+// output columns of one plane.  The <= 10 x 258 source pixels they read arrive once (coalesced) and are kept as fp32; every
+// lane then produces 8 consecutive outputs per store (16 bytes of bf16) from LDS reads -- the kernel above issues 16
+// two-byte global loads per 4 outputs and ran at 1.2 TB/s of its traffic.  Same fp32 expression per output as above.
+// `out_image_stride`: elements between consecutive images of `out` (>= planes_per_image * oh * ow): the result can land in the
+// leading channels of a wider tensor (the decoder's concatenation with the skip feature needs no second copy of it).
+constexpr int UF_OR = 16, UF_OC = 512, UF_SR = UF_OR / 2 + 2, UF_SC = UF_OC / 2 + 2;
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_up2_fwd_tiled_kernel(T* __restrict__ out, const T* __restrict__ x, int h, int w,
+                                                                     int oh, int ow, float sy, float sx, int tiles_x, int tiles_y,
+                                                                     int planes_per_image, int64_t out_image_stride) {
+    __shared__ float tile[UF_SR][UF_SC + 1];
+    int b = blockIdx.x;
+    const int tx_i = b % tiles_x; b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int64_t plane = b / tiles_y;
+    const int oy0 = ty_i * UF_OR, ox0 = tx_i * UF_OC;
+    const int oy1 = min(oh, oy0 + UF_OR) - 1, ox1 = min(ow, ox0 + UF_OC) - 1;   // last output row / column of the tile
+    const int r_lo = lerp1(oy0, sy, h).i0, r_hi = lerp1(oy1, sy, h).i1;         // <= UF_SR rows: src advances < 1/2 per output
+    const int c_lo = lerp1(ox0, sx, w).i0, c_hi = lerp1(ox1, sx, w).i1;
+    const int nr = r_hi - r_lo + 1, nc = c_hi - c_lo + 1;
+    const T* src = x + plane * h * (int64_t)w;
+    for (int e = threadIdx.x; e < nr * nc; e += 256) {
+        const int r = e / nc, c = e - r * nc;
+        tile[r][c] = sis_ld(src, (int64_t)(r_lo + r) * w + c_lo + c);
+    }
+    __syncthreads();
+    const int64_t n = plane / planes_per_image, ch = plane - n * planes_per_image;
+    T* dst = out + n * out_image_stride + ch * oh * (int64_t)ow;
+    constexpr int GROUPS = UF_OC / 8;
+    for (int e = threadIdx.x; e < UF_OR * GROUPS; e += 256) {
+        const int ry = e / GROUPS, g = e % GROUPS;
+        const int oy = oy0 + ry, ox = ox0 + 8 * g;
+        if (oy >= oh || ox >= ow) continue;
+        const Lerp1 ly = lerp1(oy, sy, h);
+        const float* t0 = tile[ly.i0 - r_lo];
+        const float* t1 = tile[ly.i1 - r_lo];
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const Lerp1 lx = lerp1(min(ox + k, ow - 1), sx, w);
+            const int a = lx.i0 - c_lo, bq = lx.i1 - c_lo;
+            v[k] = ly.l0 * (lx.l0 * t0[a] + lx.l1 * t0[bq]) + ly.l1 * (lx.l0 * t1[a] + lx.l1 * t1[bq]);
+        }
+        T* o = dst + (int64_t)oy * ow + ox;
+        if (ox + 8 <= ow && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+            if constexpr (sizeof(T) == 2) {
+                T t[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sis_st(t, k, v[k]);
+                uint4 q;
+                __builtin_memcpy(&q, t, 16);
+                *reinterpret_cast<uint4*>(o) = q;
+            } else {
+                *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (ox + k < ow) sis_st(o, k, v[k]);
         }
     }
 }
@@ -140,7 +206,8 @@ constexpr int UB_TY = 8, UB_TX = 64, UB_OR = 2 * UB_TY + 6, UB_OC = 2 * UB_TX + 
 
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear_up2_bwd_tiled_kernel(T* __restrict__ gx, const T* __restrict__ gout, int h, int w,
-                                                                     int oh, int ow, float sy, float sx, int tiles_x, int tiles_y) {
+                                                                     int oh, int ow, float sy, float sx, int tiles_x, int tiles_y,
+                                                                     int planes_per_image, int64_t gout_image_stride) {
     __shared__ float tile[UB_OR][UB_OC + 1];
     __shared__ float tmp[UB_TY][UB_OC + 1];
     __shared__ float wrow[UB_TY][UB_OR];
@@ -150,7 +217,8 @@ __global__ __launch_bounds__(256) void bilinear_up2_bwd_tiled_kernel(T* __restri
     const int64_t plane = b / tiles_y;
     const int x0 = tx_i * UB_TX, y0 = ty_i * UB_TY;
     const int oy0 = 2 * y0 - 3, ox0 = 2 * x0 - 8;  // first window row / column (ox0 is a multiple of 8)
-    const T* g = gout + plane * oh * (int64_t)ow;
+    // (`gout_image_stride`: the gradient may be the leading channels of a wider tensor -- the concatenation's gradient)
+    const T* g = gout + (plane / planes_per_image) * gout_image_stride + (plane % planes_per_image) * oh * (int64_t)ow;
     // window -> LDS (fp32), zero outside the image
     constexpr int GROUPS = UB_OC / 8;
     for (int e = threadIdx.x; e < UB_OR * GROUPS; e += 256) {
@@ -226,22 +294,35 @@ __global__ __launch_bounds__(256) void bilinear_up2_bwd_tiled_kernel(T* __restri
 }
 
 template <typename T>
-int launch_up(void* out, const void* x, int64_t planes, int h, int w, int oh, int ow, int backward, hipStream_t st) {
+int launch_up(void* out, const void* x, int64_t planes, int h, int w, int oh, int ow, int backward, int planes_per_image,
+              int64_t image_stride, hipStream_t st) {
+    // image_stride: elements between the images of the UPSAMPLED-size tensor (forward: out, backward: grad_out = x)
     const float sy = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.f;
     const float sx = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.f;
+    const bool dense = image_stride == (int64_t)planes_per_image * oh * ow;
+    const bool x2 = oh == 2 * h && ow == 2 * w;
     if (!backward) {
+        const int tiles_x = sis_cdiv(ow, UF_OC), tiles_y = sis_cdiv(oh, UF_OR);
+        if (x2 && h >= 2 && w >= 2 && planes * tiles_x * tiles_y < ((int64_t)1 << 31)) {
+            hipLaunchKernelGGL(bilinear_up2_fwd_tiled_kernel<T>, dim3((unsigned)(planes * tiles_x * tiles_y)), dim3(256), 0, st,
+                               (T*)out, (const T*)x, h, w, oh, ow, sy, sx, tiles_x, tiles_y, planes_per_image, image_stride);
+            SIS_CHECK_LAUNCH("bilinear_up2_fwd_tiled_kernel");
+            return 0;
+        }
+        SIS_REQUIRE(dense, "sis_upsample_bilinear: a strided result needs the x2 case");
         const int64_t total4 = planes * oh * ((ow + 3) >> 2);
         const int64_t blocks = (total4 + 255) / 256;
         hipLaunchKernelGGL(bilinear_up_fwd_kernel<T>, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st,
                            (T*)out, (const T*)x, h, w, oh, ow, sy, sx, total4);
         SIS_CHECK_LAUNCH("bilinear_up_fwd_kernel");
-    } else if (oh == 2 * h && ow == 2 * w && ow % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+    } else if (x2 && ow % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && image_stride % 8 == 0 &&
                planes * sis_cdiv(w, UB_TX) * sis_cdiv(h, UB_TY) < ((int64_t)1 << 31)) {
         const int tiles_x = sis_cdiv(w, UB_TX), tiles_y = sis_cdiv(h, UB_TY);
         hipLaunchKernelGGL(bilinear_up2_bwd_tiled_kernel<T>, dim3((unsigned)(planes * tiles_x * tiles_y)), dim3(256), 0, st,
-                           (T*)out, (const T*)x, h, w, oh, ow, sy, sx, tiles_x, tiles_y);
+                           (T*)out, (const T*)x, h, w, oh, ow, sy, sx, tiles_x, tiles_y, planes_per_image, image_stride);
         SIS_CHECK_LAUNCH("bilinear_up2_bwd_tiled_kernel");
     } else {  // out = grad_x [planes][h][w], x = grad_out [planes][oh][ow]
+        SIS_REQUIRE(dense, "sis_upsample_bilinear: a strided gradient needs the aligned x2 case");
         const int64_t total = planes * h * w;
         hipLaunchKernelGGL(bilinear_up_bwd_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (T*)out,
                            (const T*)x, h, w, oh, ow, sy, sx, total);
@@ -252,17 +333,26 @@ int launch_up(void* out, const void* x, int64_t planes, int h, int w, int oh, in
 
 }  // namespace
 
+extern "C" int sis_upsample_bilinear_strided(void* out, const void* x, int dtype, int batch, int channels, int h, int w, int out_h,
+                                             int out_w, int64_t image_stride, int backward, void* stream) {
+    const int64_t planes = (int64_t)batch * channels;
+    if (planes == 0) return 0;
+    SIS_REQUIRE(out && x, "sis_upsample_bilinear: null pointer");
+    SIS_REQUIRE(batch > 0 && channels > 0 && h > 0 && w > 0 && out_h > 0 && out_w > 0, "sis_upsample_bilinear: non-positive size");
+    SIS_REQUIRE(planes * (int64_t)out_h * out_w < ((int64_t)1 << 40), "sis_upsample_bilinear: tensor too large");
+    SIS_REQUIRE(image_stride >= (int64_t)channels * out_h * out_w, "sis_upsample_bilinear: image stride below the size of an image");
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case SIS_F32: return launch_up<float>(out, x, planes, h, w, out_h, out_w, backward, channels, image_stride, st);
+        case SIS_F16: return launch_up<__half>(out, x, planes, h, w, out_h, out_w, backward, channels, image_stride, st);
+        case SIS_BF16: return launch_up<__hip_bfloat16>(out, x, planes, h, w, out_h, out_w, backward, channels, image_stride, st);
+        default: return sis_fail("sis_upsample_bilinear: dtype code %d not supported (f32, f16, bf16)", dtype);
+    }
+}
+
 extern "C" int sis_upsample_bilinear(void* out, const void* x, int dtype, int64_t planes, int h, int w, int out_h,
                                      int out_w, int backward, void* stream) {
     if (planes == 0) return 0;
-    SIS_REQUIRE(out && x, "sis_upsample_bilinear: null pointer");
-    SIS_REQUIRE(planes > 0 && h > 0 && w > 0 && out_h > 0 && out_w > 0, "sis_upsample_bilinear: non-positive size");
-    SIS_REQUIRE(planes * (int64_t)out_h * out_w < ((int64_t)1 << 40), "sis_upsample_bilinear: tensor too large");
-    hipStream_t st = (hipStream_t)stream;
-    switch (dtype) {
-        case SIS_F32: return launch_up<float>(out, x, planes, h, w, out_h, out_w, backward, st);
-        case SIS_F16: return launch_up<__half>(out, x, planes, h, w, out_h, out_w, backward, st);
-        case SIS_BF16: return launch_up<__hip_bfloat16>(out, x, planes, h, w, out_h, out_w, backward, st);
-        default: return sis_fail("sis_upsample_bilinear: dtype code %d not supported (f32, f16, bf16)", dtype);
-    }
+    SIS_REQUIRE(planes > 0 && planes < ((int64_t)1 << 31), "sis_upsample_bilinear: plane count");
+    return sis_upsample_bilinear_strided(out, x, dtype, 1, (int)planes, h, w, out_h, out_w, planes * (int64_t)out_h * out_w, backward, stream);
 }

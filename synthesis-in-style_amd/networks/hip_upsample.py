@@ -27,6 +27,39 @@ class _UpsampleBilinear(Function):
                                          grad_output=grad_output.to(like.dtype)), None, None
 
 
+class _UpsampleCat(Function):
+    """torch.cat([up2x(x), skip], dim=1) in one upsampling pass + one copy of ``skip``: the upsampled tensor is written straight
+    into the leading channels of the result, and the backward reads its share of the gradient from there (the reference's
+    DecoderBlock.forward, networks/trans_u_net/vit_seg_modeling.py:300-303; torch.cat copies BOTH parts, and its backward hands
+    the upsampling a non-contiguous slice that had to be copied once more)."""
+
+    @staticmethod
+    def forward(ctx, x, skip):
+        b, c, h, w = x.shape
+        out = torch.empty((b, c + skip.shape[1], 2 * h, 2 * w), dtype=x.dtype, device=x.device)
+        sis_hip.upsample2x_into(out, x)
+        out[:, c:].copy_(skip)
+        ctx.channels = c
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        grad = grad.contiguous()
+        c = ctx.channels
+        gx = sis_hip.upsample2x_grad_from(grad, c) if ctx.needs_input_grad[0] else None
+        return gx, (grad[:, c:] if ctx.needs_input_grad[1] else None)
+
+
+def upsample2x_cat(x, skip):
+    """``torch.cat([UpsamplingBilinear2d(2)(x), skip], 1)`` fused (``_UpsampleCat``) when the tensors allow it, None otherwise."""
+    if (x.is_cuda and skip.is_cuda and x.dim() == 4 and skip.dim() == 4 and x.dtype == skip.dtype
+            and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and skip.shape[0] == x.shape[0]
+            and skip.shape[2:] == (2 * x.shape[2], 2 * x.shape[3]) and x.shape[2] >= 2 and x.shape[3] >= 2
+            and (x.shape[3] * 2) % 8 == 0 and ((x.shape[1] + skip.shape[1]) * 4 * x.shape[2] * x.shape[3]) % 8 == 0):
+        return _UpsampleCat.apply(x, skip)
+    return None
+
+
 class HipUpsamplingBilinear2d(nn.Module):
     def __init__(self, size=None, scale_factor=None):
         super().__init__()

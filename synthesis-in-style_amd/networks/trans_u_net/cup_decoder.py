@@ -1,6 +1,8 @@
 """Cascaded-upsampling CNN decoder ("CUP") and segmentation head of TransUNet
 (reference: networks/trans_u_net/vit_seg_modeling.py:265-373): tokens -> [B, hidden, h, w] -> 3x3 conv to 512 ->
 four (bilinear x2, concat skip, 2 x conv-BN-ReLU) stages -> 3x3 head."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -10,7 +12,9 @@ from torch.autograd import Function
 import sis_hip
 
 from networks.hip_conv import HipConv2d
-from networks.hip_upsample import HipUpsamplingBilinear2d
+from networks.hip_upsample import HipUpsamplingBilinear2d, upsample2x_cat
+
+_FUSE_UP_CAT = os.environ.get('SIS_FUSE_UP_CAT', '1') != '0'  # 0: upsampling and torch.cat as two steps (A/B runs)
 
 
 class _BatchNormAct(Function):
@@ -64,9 +68,13 @@ class DecoderBlock(nn.Module):
         self.up = HipUpsamplingBilinear2d(scale_factor=2)
 
     def forward(self, x, skip=None):
-        x = self.up(x)
-        if skip is not None:
-            x = torch.cat([x, skip], dim=1)
+        fused = upsample2x_cat(x, skip) if (skip is not None and _FUSE_UP_CAT and self.up.scale_factor == 2) else None
+        if fused is not None:
+            x = fused   # upsampling written straight into the concatenated tensor
+        else:
+            x = self.up(x)
+            if skip is not None:
+                x = torch.cat([x, skip], dim=1)
         return self.conv2(self.conv1(x))
 
 

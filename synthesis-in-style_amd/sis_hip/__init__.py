@@ -46,6 +46,7 @@ _SIGNATURES = {
     "sis_conv3x3_prepack": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "sis_conv3x3_eligible": ([_i] * 5, _i),
     "sis_upsample_bilinear": ([_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp], _i),
+    "sis_upsample_bilinear_strided": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _i, _vp], _i),
     "sis_gemm_bf16_workspace_bytes": ([_i, _i, _i], _i64),
     "sis_gemm_bf16": ([_vp] * 4 + [_i] * 8 + [_vp] * 3 + [_i] + [_vp] * 3 + [_i, _f, _i, _vp, _i64, _i, _vp], _i),
     "sis_gemm_bf16_batched": ([_vp] * 3 + [_i] * 9 + [_i64] * 3 + [_i, _vp, _i64, _i, _vp], _i),
@@ -1262,6 +1263,33 @@ def upsample_bilinear(x, out_h, out_w, grad_output=None):
         _check(lib().sis_upsample_bilinear(_ptr(out), _ptr(src), _DTYPE_CODE[x.dtype], b * c, h, w, out_h, out_w, backward,
                                            _stream()), "sis_upsample_bilinear")
     return out
+
+
+def upsample2x_into(out, x):
+    """Bilinear x2 upsampling (align_corners=True) of x [B,C,H,W] into the leading C channels of ``out`` [B,C+S,2H,2W]
+    (contiguous; the remaining S channels are left alone)."""
+    require_device(x, "input")
+    b, c, h, w = x.shape
+    if out.shape[0] != b or out.shape[1] < c or out.shape[2:] != (2 * h, 2 * w) or out.dtype != x.dtype or not out.is_contiguous():
+        raise RuntimeError("upsample2x_into: out must be a contiguous [B, >= C, 2H, 2W] tensor of the input's dtype")
+    with torch.cuda.device(x.device):
+        _check(lib().sis_upsample_bilinear_strided(_ptr(out), _ptr(x.contiguous()), _DTYPE_CODE[x.dtype], b, c, h, w, 2 * h, 2 * w,
+                                                   out.stride(0), 0, _stream()), "sis_upsample_bilinear_strided")
+    return out
+
+
+def upsample2x_grad_from(grad_wide, channels):
+    """Gradient of ``upsample2x_into`` w.r.t. x from the gradient of the WIDE tensor [B,C+S,2H,2W] (contiguous; 16-byte aligned
+    images): reads its leading ``channels`` channels in place -> [B,channels,H,W]."""
+    require_device(grad_wide, "grad")
+    b, ct, oh, ow = grad_wide.shape
+    if not grad_wide.is_contiguous() or oh % 2 or ow % 2 or channels > ct:
+        raise RuntimeError("upsample2x_grad_from: a contiguous [B, >= C, 2H, 2W] gradient is required")
+    gx = torch.empty((b, channels, oh // 2, ow // 2), dtype=grad_wide.dtype, device=grad_wide.device)
+    with torch.cuda.device(grad_wide.device):
+        _check(lib().sis_upsample_bilinear_strided(_ptr(gx), _ptr(grad_wide), _DTYPE_CODE[grad_wide.dtype], b, channels, oh // 2, ow // 2,
+                                                   oh, ow, grad_wide.stride(0), 1, _stream()), "sis_upsample_bilinear_strided")
+    return gx
 
 
 def conv1x1_wgrad_f32_supported(grad_output, input):

@@ -44,6 +44,44 @@ def test_module_16bit_and_autograd(device, dtype, tol):
     assert list(up.state_dict().keys()) == []
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 300, 280), (1, 2, 2, 2), (3, 4, 17, 33)])
+def test_x2_forward_tiles(device, shape):
+    """The LDS-tiled x2 forward: several row / column tiles per plane (560 output columns > one 512-wide tile), the smallest
+    plane, odd sizes (scalar stores) -- against the float64 reference."""
+    import sis_hip
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(shape[2])).to(device)
+    size = (2 * shape[2], 2 * shape[3])
+    ref = F.interpolate(x.double(), size=size, mode="bilinear", align_corners=True)
+    # fp32 source coordinates (dst * scale, as ATen forms them) carry ~dst * 2^-24 of error: at 600 outputs the weights are off
+    # by up to ~4e-5, times the difference of two unit-variance neighbours -> atol 3e-4 against float64 (measured 7.3e-5 here,
+    # ATen's own fp32 kernel 1.3e-4 on the same input)
+    y = sis_hip.upsample_bilinear(x, *size)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-5, atol=3e-4)
+    yb = sis_hip.upsample_bilinear(x.bfloat16(), *size)
+    refb = F.interpolate(x.bfloat16().double(), size=size, mode="bilinear", align_corners=True)
+    np.testing.assert_allclose(yb.float().cpu().numpy(), refb.float().cpu().numpy(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("b,c,s,h,w", [(2, 16, 8, 16, 16), (3, 5, 3, 12, 20), (1, 64, 64, 64, 64)])
+def test_upsample_cat_fused(device, dtype, b, c, s, h, w):
+    """torch.cat([up2x(x), skip], 1) with the upsampling written straight into the wide tensor and its gradient read from the
+    wide gradient in place: bitwise the two-step result (same kernels, strided addressing), gradients of both inputs included."""
+    from networks.hip_upsample import HipUpsamplingBilinear2d, upsample2x_cat
+    g = torch.Generator().manual_seed(b + c + h)
+    x = torch.randn(b, c, h, w, generator=g).to(device).to(dtype).requires_grad_(True)
+    skip = torch.randn(b, s, 2 * h, 2 * w, generator=g).to(device).to(dtype).requires_grad_(True)
+    gy = torch.randn(b, c + s, 2 * h, 2 * w, generator=g).to(device).to(dtype)
+    fused = upsample2x_cat(x, skip)
+    assert fused is not None
+    fused.backward(gy)
+    gx, gs = x.grad.clone(), skip.grad.clone()
+    x.grad = skip.grad = None
+    two = torch.cat([HipUpsamplingBilinear2d(scale_factor=2)(x), skip], 1)
+    two.backward(gy)
+    assert torch.equal(fused, two) and torch.equal(gx, x.grad) and torch.equal(gs, skip.grad)
+
+
 @pytest.mark.parametrize("shape", [(64, 3, 7, 7), (256, 64, 1, 1), (128, 128, 3, 3), (1024, 1024, 1, 1), (5, 3, 3, 3)])
 def test_weight_standardisation(device, shape):
     """csrc/weight_std.hip against the reference formula (vit_seg_modeling_resnet_skip.py:22-27), both directions."""
