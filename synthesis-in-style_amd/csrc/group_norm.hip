@@ -11,6 +11,7 @@
 // coefficients; (2) a grid-strided element-wise kernel applies them (4 elements per lane when HW % 4 == 0), and its first
 // workgroup adds the plane sums over the batch in fixed order: d(gamma) / d(beta).  (Batch-norm mode and callers without a
 // counter buffer keep the merge as a launch of its own.)
+#include <cstdlib>
 #include "sis_common.h"
 #include "sis_xwg.h"
 
@@ -409,6 +410,192 @@ __global__ __launch_bounds__(64) void bn_bwd_chan_kernel(float* __restrict__ coe
     }
 }
 
+// ---- single-pass kernels for groups that fit the registers of one workgroup (16-bit x, hw % 8 == 0, <= 32 768 elements per
+// group: every norm of the trunk's blocks 2 and 3 at 512^2 input -- tensors of 2-17 MB whose four launches per step were
+// pure latency).  One workgroup per (sample, group) = one contiguous chunk of cpg * hw elements; wave w owns the vectors
+// (8 elements) [w * VW, (w + 1) * VW), 64 consecutive ones per iteration (NIT iterations, all in registers), so a wave's
+// vectors of one iteration lie in ONE channel (hw / 8 is a multiple of 64).  Statistics are the exact two-pass mean /
+// variance of the group (fp32).  Reductions across waves go through LDS and are summed by every thread in wave order:
+// deterministic.
+struct GnGroupArgs {
+    int hw, cpg, groups, relu; float eps;
+};
+
+template <typename TI>
+__device__ __forceinline__ void gn_load8(const TI* p, float* v) {   // 8 consecutive 16-bit elements: one 16-byte load
+    const uint4 q = *reinterpret_cast<const uint4*>(p);
+    TI t[8];
+    __builtin_memcpy(t, &q, 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = sis_ld(t, e);
+}
+template <typename TI>
+__device__ __forceinline__ void gn_store8(TI* p, const float* v) {
+    TI t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sis_st(t, e, v[e]);
+    uint4 q;
+    __builtin_memcpy(&q, t, 16);
+    *reinterpret_cast<uint4*>(p) = q;
+}
+__device__ __forceinline__ void gn_load8(const float* p, float* v) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void gn_store8(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// sum over the workgroup (<= 16 waves), the same value in every thread
+__device__ __forceinline__ float gn_group_sum(float v, float* red, int nw) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int w = 0; w < nw; ++w) s += red[w];
+    return s;
+}
+
+template <typename TI, typename TO, int NIT>
+__global__ __launch_bounds__(1024) void gn_group_fwd_kernel(TO* __restrict__ y, TI* __restrict__ y_lp, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out, const TI* __restrict__ x,
+                                                            const float* __restrict__ res, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, GnGroupArgs a) {
+    __shared__ float red[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int row = blockIdx.x;
+    const int64_t base = (int64_t)row * a.cpg * a.hw;
+    const int v0 = wave * (NIT * 64) + lane;       // this lane's vector of iteration 0 (+ 64 per iteration)
+    float xv[NIT][8];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        gn_load8(x + base + 8 * (int64_t)(v0 + it * 64), xv[it]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += xv[it][e];
+    }
+    const float n = (float)a.cpg * (float)a.hw;
+    const float mean = gn_group_sum(s, red, nw) / n;
+    float m2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = xv[it][e] - mean; m2 += d * d; }
+    const float rstd = rsqrtf(gn_group_sum(m2, red, nw) / n + a.eps);
+    if (threadIdx.x == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    const int c0 = (row % a.groups) * a.cpg;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int64_t off = 8 * (int64_t)(v0 + it * 64);
+        const int c = c0 + (int)(off / a.hw);
+        const float ga = rstd * gamma[c], gb = beta[c] - mean * ga;
+        float rv[8], out[8];
+        if (res) gn_load8(res + base + off, rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = xv[it][e] * ga + gb;
+            if (res) v += rv[e];
+            if (a.relu) v = fmaxf(v, 0.f);
+            out[e] = v;
+        }
+        gn_store8(y + base + off, out);
+        if (y_lp) gn_store8(y_lp + base + off, out);
+    }
+}
+
+// backward: g' = masked gradient, dx = k1 g' - k2 - k3 xhat (see gn_bwd_row); plane sums for d gamma / d beta go to
+// psum[plane] (published: the last workgroup of the launch adds them over the batch in sample order).
+template <typename TI, typename TG, int NIT, bool HAS_LP, bool HAS_MASK>
+__global__ __launch_bounds__(1024) void gn_group_bwd_kernel(TI* __restrict__ dx, float* __restrict__ dres, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ psum,
+                                                            int* __restrict__ counter, const TG* __restrict__ g,
+                                                            const TI* __restrict__ g_lp, const TI* __restrict__ x,
+                                                            const float* __restrict__ ymask, const float* __restrict__ mean_in,
+                                                            const float* __restrict__ rstd_in, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, GnGroupArgs a, int batch) {
+    __shared__ float part[16 * NIT][2];   // per (wave, iteration): sum g', sum g' xhat -- all of one channel
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int row = blockIdx.x;
+    const int64_t base = (int64_t)row * a.cpg * a.hw;
+    const int v0 = wave * (NIT * 64) + lane;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const int c0 = (row % a.groups) * a.cpg;
+    float xh[NIT][8], gi[NIT][8];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int64_t off = 8 * (int64_t)(v0 + it * 64);
+        const int c = c0 + (int)(off / a.hw);
+        float xv[8], g2[8], mv[8];
+        gn_load8(x + base + off, xv);
+        gn_load8(g + base + off, gi[it]);
+        if (HAS_LP) gn_load8(g_lp + base + off, g2);
+        if (HAS_MASK) gn_load8(ymask + base + off, mv);
+        const float gm = gamma[c], bt = beta[c];
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float h = (xv[e] - mean) * rstd;
+            float ge = gi[it][e] + (HAS_LP ? g2[e] : 0.f);
+            if (a.relu && (HAS_MASK ? mv[e] <= 0.f : h * gm + bt <= 0.f)) ge = 0.f;
+            xh[it][e] = h; gi[it][e] = ge;
+            sg += ge; sgx += ge * h;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sg += __shfl_xor(sg, o, 64); sgx += __shfl_xor(sgx, o, 64); }
+        if (lane == 0) { part[wave * NIT + it][0] = sg; part[wave * NIT + it][1] = sgx; }
+    }
+    __syncthreads();
+    // entries (wave, it) in vector order; entry j covers vectors [64 j, 64 j + 64): channel 512 j / hw of the group
+    const int entries = nw * NIT, per_chan = a.hw / 512;
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < entries; ++j) {
+        const float gm = gamma[c0 + j / per_chan];
+        s1 += gm * part[j][0]; s2 += gm * part[j][1];
+    }
+    if ((int)threadIdx.x < a.cpg) {   // plane sums of channel threadIdx.x of the group
+        float pa = 0.f, pb = 0.f;
+        for (int j = threadIdx.x * per_chan; j < (threadIdx.x + 1) * per_chan; ++j) { pa += part[j][0]; pb += part[j][1]; }
+        float* o = psum + 2 * ((int64_t)row * a.cpg + threadIdx.x);
+        xwg_publish(o, pa); xwg_publish(o + 1, pb);
+    }
+    const float n = (float)a.cpg * (float)a.hw;
+    const float k2 = rstd * s1 / n, k3 = rstd * s2 / n;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int64_t off = 8 * (int64_t)(v0 + it * 64);
+        const float k1 = rstd * gamma[c0 + (int)(off / a.hw)];
+        float out[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[e] = k1 * gi[it][e] - k2 - k3 * xh[it][e];
+        gn_store8(dx + base + off, out);
+        if (HAS_MASK && dres) gn_store8(dres + base + off, gi[it]);
+    }
+    // d gamma / d beta: the last workgroup of the launch adds the plane sums over the batch
+    if (xwg_complete<true>(counter, gridDim.x)) {
+        const int C = a.groups * a.cpg;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float da = 0.f, db = 0.f;
+            for (int b = 0; b < batch; ++b) { db += xwg_peek(psum + 2 * ((int64_t)b * C + c)); da += xwg_peek(psum + 2 * ((int64_t)b * C + c) + 1); }
+            dgamma[c] = da; dbeta[c] = db;
+        }
+    }
+}
+
+// launch geometry of the single-pass kernels: vectors per group V = cpg * hw / 8, NIT iterations of 64 vectors per wave
+inline bool gn_group_plan(int cpg, int hw, int* nit, int* nw) {
+    static const bool enabled = [] { const char* e = getenv("SIS_GN_SINGLE_PASS"); return !(e && e[0] == '0'); }();   // 0: A/B runs
+    if (!enabled || hw % 512) return false;           // a (wave, iteration) = 512 elements lies in one channel
+    const int64_t E = (int64_t)cpg * hw;
+    if (E > 32768) return false;
+    const int V = (int)(E / 8);
+    *nit = V <= 1024 ? 1 : V <= 2048 ? 2 : 4;
+    *nw = V / (64 * *nit);
+    return *nw >= 1 && *nw <= 16 && *nw * 64 * *nit == V;
+}
+
 constexpr int GN_SLICE = 16384;  // elements of a plane per statistics workgroup
 inline int gn_slices(int hw) { return (hw + GN_SLICE - 1) / GN_SLICE; }
 inline int gn_slice_len(int hw) { const int S = gn_slices(hw); return (((hw + S - 1) / S) + 3) & ~3; }
@@ -462,6 +649,17 @@ void gn_fwd_run(void* y, void* y_lp, float* mean, float* rstd, float* ws, const 
     const int S = gn_slices(hw);
     float* ab = ws;                // [planes][2]
     float* part = ws + 5 * planes; // [planes][S][3]
+    int nit, nw;
+    if constexpr (sizeof(TI) == 2) {
+        if (counters && gn_group_plan(cpg, hw, &nit, &nw) && gn_aligned(x) && gn_aligned(y) && gn_aligned(y_lp) && gn_aligned(res)) {
+            const GnGroupArgs a{hw, cpg, groups, relu, eps};
+#define GN_GROUP_FWD(N) hipLaunchKernelGGL((gn_group_fwd_kernel<TI, TO, N>), dim3(rows), dim3(64 * nw), 0, st, (TO*)y, (TI*)y_lp, mean, \
+                                           rstd, (const TI*)x, res, gamma, beta, a)
+            if (nit == 1) GN_GROUP_FWD(1); else if (nit == 2) GN_GROUP_FWD(2); else GN_GROUP_FWD(4);
+#undef GN_GROUP_FWD
+            return;
+        }
+    }
     if (counters) {
         gn_launch_stats<TI>(part, x, planes, hw, st, GnFinish{counters, mean, rstd, ab, gamma, beta, groups, cpg, eps});
     } else {
@@ -484,6 +682,24 @@ void gn_bwd_run(void* dx, float* dres, float* dgamma, float* dbeta, float* ws, c
     float* coef = ws + 2 * planes; // [planes][3]
     float* part = ws + 5 * planes; // [planes][S][2]
     float* no_param = nullptr;
+    int nit, nw;
+    if constexpr (sizeof(TI) == 2) {
+        if (counters && gn_group_plan(cpg, hw, &nit, &nw) && gn_aligned(dx) && gn_aligned(g) && gn_aligned(g_lp) && gn_aligned(x) &&
+            gn_aligned(ymask) && gn_aligned(dres) && (dres == nullptr || ymask != nullptr)) {
+            const GnGroupArgs a{hw, cpg, groups, relu, 0.f};
+#define GN_GROUP_BWD(N, LP, MK) hipLaunchKernelGGL((gn_group_bwd_kernel<TI, TG, N, LP, MK>), dim3(rows), dim3(64 * nw), 0, st, (TI*)dx, dres, \
+                                                   dgamma, dbeta, psum, counters, (const TG*)g, (const TI*)g_lp, (const TI*)x, ymask, mean,  \
+                                                   rstd, gamma, beta, a, batch)
+#define GN_GROUP_BWD_N(LP, MK) do { if (nit == 1) GN_GROUP_BWD(1, LP, MK); else if (nit == 2) GN_GROUP_BWD(2, LP, MK); else GN_GROUP_BWD(4, LP, MK); } while (0)
+            if (g_lp && ymask) GN_GROUP_BWD_N(true, true);
+            else if (g_lp) GN_GROUP_BWD_N(true, false);
+            else if (ymask) GN_GROUP_BWD_N(false, true);
+            else GN_GROUP_BWD_N(false, false);
+#undef GN_GROUP_BWD_N
+#undef GN_GROUP_BWD
+            return;
+        }
+    }
     if (counters) {
         gn_launch_bwd_plane<TI, TG>(part, g, g_lp, x, mean, rstd, gamma, beta, ymask, planes, C, cpg, hw, relu, st, counters, coef, psum);
     } else {

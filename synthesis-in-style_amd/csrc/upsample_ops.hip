@@ -91,20 +91,27 @@ __global__ __launch_bounds__(256) void bilinear_up2_fwd_tiled_kernel(T* __restri
     const int64_t n = plane / planes_per_image, ch = plane - n * planes_per_image;
     T* dst = out + n * out_image_stride + ch * oh * (int64_t)ow;
     constexpr int GROUPS = UF_OC / 8;
-    for (int e = threadIdx.x; e < UF_OR * GROUPS; e += 256) {
-        const int ry = e / GROUPS, g = e % GROUPS;
-        const int oy = oy0 + ry, ox = ox0 + 8 * g;
-        if (oy >= oh || ox >= ow) continue;
+    static_assert(256 % GROUPS == 0, "a thread keeps its column group over the rows it handles");
+    // a thread's 8 output columns are the same for all its rows: their source columns / weights are formed once
+    const int g = threadIdx.x % GROUPS, ox = ox0 + 8 * g;
+    if (ox >= ow) return;
+    int xa[8], xb[8];
+    float xl0[8], xl1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const Lerp1 lx = lerp1(min(ox + k, ow - 1), sx, w);
+        xa[k] = lx.i0 - c_lo; xb[k] = lx.i1 - c_lo; xl0[k] = lx.l0; xl1[k] = lx.l1;
+    }
+    for (int ry = threadIdx.x / GROUPS; ry < UF_OR; ry += 256 / GROUPS) {
+        const int oy = oy0 + ry;
+        if (oy >= oh) break;
         const Lerp1 ly = lerp1(oy, sy, h);
         const float* t0 = tile[ly.i0 - r_lo];
         const float* t1 = tile[ly.i1 - r_lo];
         float v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const Lerp1 lx = lerp1(min(ox + k, ow - 1), sx, w);
-            const int a = lx.i0 - c_lo, bq = lx.i1 - c_lo;
-            v[k] = ly.l0 * (lx.l0 * t0[a] + lx.l1 * t0[bq]) + ly.l1 * (lx.l0 * t1[a] + lx.l1 * t1[bq]);
-        }
+        for (int k = 0; k < 8; ++k)
+            v[k] = ly.l0 * (xl0[k] * t0[xa[k]] + xl1[k] * t0[xb[k]]) + ly.l1 * (xl0[k] * t1[xa[k]] + xl1[k] * t1[xb[k]]);
         T* o = dst + (int64_t)oy * ow + ox;
         if (ox + 8 <= ow && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
             if constexpr (sizeof(T) == 2) {

@@ -143,7 +143,7 @@ def test_group_norm_relu(device, shape, groups, relu):
     np.testing.assert_allclose(dxb.float().cpu().numpy(), xq.grad.float().cpu().numpy(), rtol=2e-2, atol=1e-2 * scale)
 
 
-@pytest.mark.parametrize("shape,groups", [((8, 256, 32, 32), 32), ((2, 64, 200, 200), 32), ((3, 96, 5, 5), 96), ((8, 1024, 8, 8), 32)])
+@pytest.mark.parametrize("shape,groups", [((8, 256, 24, 24), 32), ((2, 64, 200, 200), 32), ((3, 96, 5, 5), 96), ((8, 1024, 8, 8), 32)])
 def test_group_norm_merge_inside_the_statistics_launch(device, shape, groups, monkeypatch):
     """The per-group merge done by the workgroup that completes the group (device-scope counters, csrc/group_norm.hip) gives
     bitwise the results of the merge as a launch of its own, call after call (the counters are left at zero), incl. planes cut
@@ -168,6 +168,61 @@ def test_group_norm_merge_inside_the_statistics_launch(device, shape, groups, mo
             assert torch.equal(u, v)
     counters = sis_hip._group_counters(x.device, shape[0] * groups)
     assert int(counters.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("shape,groups,residual", [((2, 256, 32, 32), 32, False), ((3, 1024, 32, 32), 32, True), ((2, 128, 64, 64), 32, False),
+                                                   ((2, 64, 32, 32), 64, False), ((2, 32, 64, 64), 32, True), ((8, 256, 64, 64), 32, True)])
+def test_group_norm_single_pass_groups(device, shape, groups, residual, monkeypatch):
+    """Groups that fit one workgroup's registers (bf16 x, hw % 512 == 0, <= 32 768 elements: blocks 2 and 3 of the trunk) take
+    the single-pass kernels of csrc/group_norm.hip -- all three iteration counts, one-channel groups, the residual + dual
+    output form with fp32 gradients, the plain bf16 form: against F.group_norm in float64 on the same bf16-rounded input
+    (tolerances of test_group_norm_relu / _residual_relu) and against the two-launch kernels (fp32 results to 1e-5)."""
+    import sis_hip
+    g = torch.Generator().manual_seed(shape[1] + shape[2])
+    c = shape[1]
+    x = (torch.randn(*shape, generator=g) * 2 + 0.5).to(device).bfloat16()
+    gamma = (1 + 0.2 * torch.randn(c, generator=g)).to(device)
+    beta = (0.3 * torch.randn(c, generator=g)).to(device)
+    res = torch.randn(*shape, generator=g).to(device) if residual else None
+    gy = torch.randn(*shape, generator=g).to(device)
+    g_lp = torch.randn(*shape, generator=g).to(device).bfloat16() if residual else None
+    if not residual:
+        gy = gy.bfloat16()
+
+    def run():
+        if residual:
+            y, mean, rstd, y_lp = sis_hip.group_norm_fwd(x, gamma, beta, groups, 1e-6, True, residual=res, low_precision_copy=True)
+            assert torch.equal(y_lp, y.to(x.dtype))
+            dx, dg, db, dres = sis_hip.group_norm_bwd(gy, x, mean, rstd, gamma, beta, groups, True, y_mask=y, want_residual_grad=True,
+                                                      grad_y_lp=g_lp)
+            return y, mean, rstd, dx, dg, db, dres
+        y, mean, rstd = sis_hip.group_norm_fwd(x, gamma, beta, groups, 1e-6, True)
+        return (y, mean, rstd) + tuple(sis_hip.group_norm_bwd(gy, x, mean, rstd, gamma, beta, groups, True))
+
+    got = run()
+    assert all(torch.equal(u, v) for u, v in zip(got, run()))   # repeatable, counters left at zero
+    monkeypatch.setattr(sis_hip, "_GN_FUSED_FINISH", False)     # no counters: the two-launch kernels
+    two = run()
+    monkeypatch.setattr(sis_hip, "_GN_FUSED_FINISH", True)
+    for u, v in zip(got[1:3], two[1:3]):
+        np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-5, atol=1e-6)   # mean, rstd
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = F.group_norm(xr, groups, gr, br, 1e-6)
+    if residual:
+        rr = res.double().requires_grad_(True)
+        ref = F.relu(ref + rr)
+        ref.backward(gy.double() + g_lp.double())
+        np.testing.assert_allclose(got[0].cpu().numpy(), ref.detach().float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(got[6].cpu().numpy(), rr.grad.float().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    else:
+        ref = F.relu(ref)
+        ref.backward(gy.double())
+        np.testing.assert_allclose(got[0].float().cpu().numpy(), ref.detach().float().cpu().numpy(), rtol=1e-2, atol=1e-2)
+    scale = float(xr.grad.abs().max())
+    np.testing.assert_allclose(got[3].float().cpu().numpy(), xr.grad.float().cpu().numpy(), rtol=2e-2, atol=1e-2 * scale)
+    np.testing.assert_allclose(got[4].cpu().numpy(), gr.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-3 * float(gr.grad.abs().max()))
+    np.testing.assert_allclose(got[5].cpu().numpy(), br.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-3 * float(br.grad.abs().max()))
 
 
 @pytest.mark.parametrize("shape,relu", [((4, 16, 12, 12), True), ((2, 64, 33, 31), False), ((8, 256, 16, 16), True)])
