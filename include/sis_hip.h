@@ -219,6 +219,15 @@ int sis_bn_act_fwd(float* y, const float* x, const float* residual, const float*
 int sis_bn_act_bwd(float* dx, float* dresidual, float* dgamma, float* dbeta, const float* dy, const float* y,
                    const float* x, const float* mean, const float* invstd, const float* gamma, float* workspace,
                    int batch, int channels, int hw, int relu, const void* relu_mask, void* stream);
+/* Statistics + apply of the training-mode batch norm in ONE launch when a channel's batch * hw elements fit one workgroup's
+ * registers (sis_bn_fused_supported: batch * hw <= 16 384 and hw % 256 == 0 -- every 32 x 32 layer of EMANet at batch 16):
+ * x is read once instead of twice; mean / invstd / running statistics as sis_bn_stats, y (and relu_mask) as sis_bn_act_fwd,
+ * bitwise the same values.  sis_bn_act_bwd takes its single-pass form (dy and x read once; results to an ulp of the
+ * three-launch form) under the same condition. */
+int sis_bn_fused_supported(int batch, int channels, int hw);
+int sis_bn_fused_fwd(float* y, float* mean, float* invstd, float* running_mean, float* running_var, const float* x,
+                     const float* residual, const float* gamma, const float* beta, int batch, int channels, int hw, float eps,
+                     float momentum, int relu, void* relu_mask, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dataset-loop neighbours of Generator.forward (SURVEY.md §8f "next" rows 1 and 2).

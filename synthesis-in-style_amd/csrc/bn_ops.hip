@@ -18,6 +18,7 @@
 // ReLU gate as a bit mask: the backward needs y only for its sign.  The forward apply pass can leave one bit per element
 // (four 64-bit ballots per wave and float4 column: word (i / 64) * 4 + e, bit i % 64 for component e of float4 i), and both
 // backward passes then read 1/8 byte instead of 4 bytes per element for the gate: backward 4*(4 reads + 1 write) + 2/8.
+#include <cstdlib>
 #include "sis_common.h"
 
 namespace {
@@ -256,6 +257,144 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float4* __restrict__ 
     }
 }
 
+// ---- single-pass kernels for channels whose B * HW elements are ONE slice (<= 16 384: every 32 x 32 layer at batch 16 --
+// 42 of EMANet-50's norms): one workgroup per channel keeps its 64 values per thread in registers, so the forward reads x
+// once instead of twice (statistics + apply) and the backward reads dy and x once instead of twice; 1 launch instead of 3.
+// Same expressions in the same order as the kernels above (forward: bitwise the same results; backward: to an ulp).  (HW % 256 == 0: a wave's 64 float4s
+// stay inside one plane and fill one group of mask words.)
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_fused_fwd_kernel(float* __restrict__ y, float* __restrict__ mean_out,
+                                                           float* __restrict__ invstd_out, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, const float* __restrict__ x,
+                                                           const float* __restrict__ res, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int C, int HW, int64_t n, float eps,
+                                                           float momentum, unsigned long long* __restrict__ mask) {
+    __shared__ float red[4];
+    constexpr int PER = BN_SLICE / 1024;
+    const int c = blockIdx.x;
+    float4 v[PER];
+    int64_t addr[PER];
+    {
+        ChanWalk w(0, n, c, C, HW);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            addr[k] = w.valid() ? w.addr() : -1;
+            v[k] = w.valid() ? *reinterpret_cast<const float4*>(x + addr[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            w.next();
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    const float cnt = (float)n;
+    const float mean = block_sum(sum, red) / cnt;
+    float m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (addr[k] >= 0) {
+            const float d0 = v[k].x - mean, d1 = v[k].y - mean, d2 = v[k].z - mean, d3 = v[k].w - mean;
+            m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    }
+    m2 = block_sum(m2, red);
+    const float var = m2 / cnt;
+    const float is = rsqrtf(var + eps);
+    if (threadIdx.x == 0) {
+        mean_out[c] = mean; invstd_out[c] = is;
+        if (running_mean) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (cnt > 1.f ? m2 / (cnt - 1.f) : var);
+        }
+    }
+    const float a = (gamma ? gamma[c] : 1.f) * is;
+    const float b = (beta ? beta[c] : 0.f) - mean * a;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (addr[k] < 0) continue;   // (wave-uniform: n % 256 == 0)
+        float4 o = v[k];
+        o.x = o.x * a + b; o.y = o.y * a + b; o.z = o.z * a + b; o.w = o.w * a + b;
+        if (RES) { const float4 r = *reinterpret_cast<const float4*>(res + addr[k]); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+        if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *reinterpret_cast<float4*>(y + addr[k]) = o;
+        if (RELU && mask) {
+            const unsigned long long b0 = __ballot(o.x > 0.f), b1 = __ballot(o.y > 0.f), b2 = __ballot(o.z > 0.f), b3 = __ballot(o.w > 0.f);
+            if ((threadIdx.x & 63) == 0) {
+                unsigned long long* m = mask + ((addr[k] >> 2) >> 6) * 4;
+                m[0] = b0; m[1] = b1; m[2] = b2; m[3] = b3;
+            }
+        }
+    }
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_fused_bwd_kernel(float* __restrict__ dx, float* __restrict__ dres, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, const float* __restrict__ dy,
+                                                           const float* __restrict__ y, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, int C, int HW, int64_t n,
+                                                           const unsigned long long* __restrict__ mask) {
+    __shared__ float red[4];
+    constexpr int PER = BN_SLICE / 1024;
+    const int c = blockIdx.x;
+    const float mu = mean[c], is = invstd[c];
+    float4 g[PER], xv[PER];
+    int64_t addr[PER];
+    {
+        ChanWalk w(0, n, c, C, HW);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            addr[k] = w.valid() ? w.addr() : -1;
+            g[k] = w.valid() ? *reinterpret_cast<const float4*>(dy + addr[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[k] = w.valid() ? *reinterpret_cast<const float4*>(x + addr[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            w.next();
+        }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (addr[k] < 0) continue;
+        if (RELU) {
+            if (mask) {
+                const int64_t i4 = addr[k] >> 2;
+                if (!gate_bit(mask, i4, 0)) g[k].x = 0.f;
+                if (!gate_bit(mask, i4, 1)) g[k].y = 0.f;
+                if (!gate_bit(mask, i4, 2)) g[k].z = 0.f;
+                if (!gate_bit(mask, i4, 3)) g[k].w = 0.f;
+            } else {
+                const float4 o = *reinterpret_cast<const float4*>(y + addr[k]);
+                if (!(o.x > 0.f)) g[k].x = 0.f;
+                if (!(o.y > 0.f)) g[k].y = 0.f;
+                if (!(o.z > 0.f)) g[k].z = 0.f;
+                if (!(o.w > 0.f)) g[k].w = 0.f;
+            }
+        }
+        s1 += (g[k].x + g[k].y) + (g[k].z + g[k].w);
+        s2 += (g[k].x * ((xv[k].x - mu) * is) + g[k].y * ((xv[k].y - mu) * is)) + (g[k].z * ((xv[k].z - mu) * is) + g[k].w * ((xv[k].w - mu) * is));
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) { dbeta[c] = s1; dgamma[c] = s2; }
+    const float inv_n = 1.f / (float)n;
+    const float kk = (gamma ? gamma[c] : 1.f) * is;
+    const float m1 = s1 * inv_n, m2 = s2 * inv_n;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (addr[k] < 0) continue;
+        if (RES) *reinterpret_cast<float4*>(dres + addr[k]) = g[k];
+        float4 r;
+        r.x = kk * (g[k].x - m1 - (xv[k].x - mu) * is * m2);
+        r.y = kk * (g[k].y - m1 - (xv[k].y - mu) * is * m2);
+        r.z = kk * (g[k].z - m1 - (xv[k].z - mu) * is * m2);
+        r.w = kk * (g[k].w - m1 - (xv[k].w - mu) * is * m2);
+        *reinterpret_cast<float4*>(dx + addr[k]) = r;
+    }
+}
+
+bool bn_fused_ok(int batch, int hw) {
+    const char* e = getenv("SIS_BN_SINGLE_PASS");   // 0: the three-launch form (A/B runs, the equality test); read per call
+    return !(e && e[0] == '0') && (int64_t)batch * hw <= BN_SLICE && hw % 256 == 0;
+}
+
 int slices(int64_t n) { return (int)((n + BN_SLICE - 1) / BN_SLICE); }
 int ew_blocks(int64_t total4) { const int64_t b = (total4 + 255) / 256; return (int)(b < 4096 ? b : 4096); }
 
@@ -323,6 +462,18 @@ extern "C" int sis_bn_act_bwd(float* dx, float* dresidual, float* dgamma, float*
     const int64_t n = (int64_t)batch * hw;
     const int S = slices(n);
     hipStream_t st = (hipStream_t)stream;
+    if (bn_fused_ok(batch, hw)) {
+#define SIS_BN_FBWD(R, S_)                                                                                                  \
+    hipLaunchKernelGGL((bn_fused_bwd_kernel<R, S_>), dim3(channels), dim3(256), 0, st, dx, dresidual, dgamma, dbeta, dy, y, x, mean, \
+                       invstd, gamma, channels, hw, n, mk)
+        if (relu && dresidual) SIS_BN_FBWD(true, true);
+        else if (relu) SIS_BN_FBWD(true, false);
+        else if (dresidual) SIS_BN_FBWD(false, true);
+        else SIS_BN_FBWD(false, false);
+#undef SIS_BN_FBWD
+        SIS_CHECK_LAUNCH("bn_fused_bwd_kernel");
+        return 0;
+    }
     if (relu)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(channels * S), dim3(256), 0, st, workspace, dy, y, x, mean, invstd,
                            channels, hw, n, S, mk);
@@ -344,5 +495,34 @@ extern "C" int sis_bn_act_bwd(float* dx, float* dresidual, float* dgamma, float*
     else SIS_BN_BWD(false, false);
 #undef SIS_BN_BWD
     SIS_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return 0;
+}
+
+/* Statistics + apply of a training-mode batch norm in ONE launch when a channel's batch * hw elements fit one workgroup's
+ * registers (sis_bn_fused_supported: batch * hw <= 16 384 and hw % 256 == 0): mean / invstd / running statistics as
+ * sis_bn_stats, y (and relu_mask) as sis_bn_act_fwd, bitwise the same values.  (sis_bn_act_bwd takes its single-pass form
+ * under the same condition by itself.) */
+extern "C" int sis_bn_fused_supported(int batch, int channels, int hw) {
+    return (batch > 0 && channels > 0 && hw > 0 && bn_fused_ok(batch, hw)) ? 1 : 0;
+}
+
+extern "C" int sis_bn_fused_fwd(float* y, float* mean, float* invstd, float* running_mean, float* running_var, const float* x,
+                                const float* residual, const float* gamma, const float* beta, int batch, int channels, int hw,
+                                float eps, float momentum, int relu, void* relu_mask, void* stream) {
+    if (check_geom("sis_bn_fused_fwd", batch, channels, hw)) return 1;
+    SIS_REQUIRE(y && mean && invstd && x, "sis_bn_fused_fwd: null pointer");
+    SIS_REQUIRE(bn_fused_ok(batch, hw), "sis_bn_fused_fwd: batch * hw = %lld does not fit one slice / hw %% 256", (long long)batch * hw);
+    SIS_REQUIRE((((uintptr_t)y | (uintptr_t)x | (uintptr_t)residual) & 15) == 0, "sis_bn_fused_fwd: 16-byte alignment");
+    const int64_t n = (int64_t)batch * hw;
+    hipStream_t st = (hipStream_t)stream;
+#define SIS_BN_FFWD(R, S_)                                                                                              \
+    hipLaunchKernelGGL((bn_fused_fwd_kernel<R, S_>), dim3(channels), dim3(256), 0, st, y, mean, invstd, running_mean, running_var, \
+                       x, residual, gamma, beta, channels, hw, n, eps, momentum, (unsigned long long*)relu_mask)
+    if (relu && residual) SIS_BN_FFWD(true, true);
+    else if (relu) SIS_BN_FFWD(true, false);
+    else if (residual) SIS_BN_FFWD(false, true);
+    else SIS_BN_FFWD(false, false);
+#undef SIS_BN_FFWD
+    SIS_CHECK_LAUNCH("bn_fused_fwd_kernel");
     return 0;
 }

@@ -45,6 +45,13 @@ class _FusedBatchNormAct(Function):
 
     @staticmethod
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+        if training and sis_hip.bn_fused_supported(x):
+            # a channel's batch * H * W values fit one workgroup (the 32 x 32 layers): statistics and apply in one launch, x read once
+            y, mean, invstd, mask = sis_hip.bn_fused_fwd(x, residual, weight, bias, running_mean, running_var, eps, momentum, relu,
+                                                         want_mask=relu and _RELU_MASK)
+            ctx.save_for_backward(x, None if mask is not None else y, mean, invstd, weight, mask)
+            ctx.relu, ctx.training, ctx.has_residual = relu, training, residual is not None
+            return y
         if training:
             mean, invstd = sis_hip.bn_stats(x, running_mean, running_var, eps, momentum)
         else:

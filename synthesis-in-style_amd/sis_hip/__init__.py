@@ -91,6 +91,8 @@ _SIGNATURES = {
     "sis_bn_stats": ([_vp] * 6 + [_i, _i, _i, _f, _f, _vp], _i),
     "sis_bn_mask_words": ([_i, _i, _i], _i64),
     "sis_bn_act_fwd": ([_vp] * 7 + [_i, _i, _i, _i, _vp, _vp], _i),
+    "sis_bn_fused_supported": ([_i] * 3, _i),
+    "sis_bn_fused_fwd": ([_vp] * 9 + [_i, _i, _i, _f, _f, _i, _vp, _vp], _i),
     "sis_bn_act_bwd": ([_vp] * 11 + [_i, _i, _i, _i, _vp, _vp], _i),
     "sis_kmeans_assign": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "sis_make_image_u8": ([_vp, _vp, _i, _i, _i, _vp], _i),
@@ -1400,6 +1402,26 @@ def bn_stats(x, running_mean, running_var, eps, momentum):
         _check(lib().sis_bn_stats(_ptr(mean), _ptr(invstd), _ptr(running_mean), _ptr(running_var), _ptr(x), _ptr(ws), b, c,
                                   h * w, float(eps), float(momentum), _stream()), "sis_bn_stats")
     return mean, invstd
+
+
+def bn_fused_supported(x):
+    b, c, h, w = x.shape
+    return bool(lib().sis_bn_fused_supported(b, c, h * w))
+
+
+def bn_fused_fwd(x, residual, gamma, beta, running_mean, running_var, eps, momentum, relu, want_mask=False):
+    """``bn_stats`` + ``bn_act_fwd`` in one launch (a channel's batch * H * W values fit one workgroup: ``bn_fused_supported``)
+    -> (y, mean, invstd, mask or None)."""
+    b, c, h, w = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    mask = torch.empty(lib().sis_bn_mask_words(b, c, h * w), dtype=torch.int64, device=x.device) if (want_mask and relu) else None
+    with torch.cuda.device(x.device):
+        _check(lib().sis_bn_fused_fwd(_ptr(y), _ptr(mean), _ptr(invstd), _ptr(running_mean), _ptr(running_var), _ptr(x), _ptr(residual),
+                                      _ptr(gamma), _ptr(beta), b, c, h * w, float(eps), float(momentum), int(bool(relu)), _ptr(mask),
+                                      _stream()), "sis_bn_fused_fwd")
+    return y, mean, invstd, mask
 
 
 def bn_act_fwd(x, residual, mean, invstd, gamma, beta, relu, want_mask=False):

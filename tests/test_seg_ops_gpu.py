@@ -141,6 +141,45 @@ def test_fused_batch_norm_act(device, b, c, h, w, relu, use_res):
         assert torch.allclose(ye.cpu().double(), F.relu(re) if relu else re, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("b,c,h,w,relu,use_res", [(16, 64, 32, 32, True, True), (4, 37, 16, 16, True, False), (16, 24, 32, 32, False, True),
+                                                  (1, 8, 64, 64, False, False), (7, 16, 32, 32, True, True)])
+def test_batch_norm_single_pass_equals_three_launches(device, b, c, h, w, relu, use_res, monkeypatch):
+    """Channels whose batch * H * W values fit one workgroup (csrc/bn_ops.hip, bn_fused_*): statistics + apply in one launch and
+    the backward in one launch: the forward gives BITWISE the results of the three-launch form (sign mask and running
+    statistics included), the backward agrees to an ulp; batch sizes that leave the slice partly empty too."""
+    import sis_hip
+    gen = torch.Generator().manual_seed(b * 5 + c + h)
+    x = (torch.randn(b, c, h, w, generator=gen) * 2 + 0.5).to(device)
+    res = torch.randn(b, c, h, w, generator=gen).to(device) if use_res else None
+    dy = torch.randn(b, c, h, w, generator=gen).to(device)
+    gamma, beta = (1 + 0.1 * torch.randn(c, generator=gen)).to(device), (0.1 * torch.randn(c, generator=gen)).to(device)
+
+    def run(single):
+        monkeypatch.setenv("SIS_BN_SINGLE_PASS", "1" if single else "0")
+        rm, rv = torch.zeros(c, device=device), torch.ones(c, device=device)
+        if single:
+            assert sis_hip.bn_fused_supported(x)
+            y, mean, invstd, mask = sis_hip.bn_fused_fwd(x, res, gamma, beta, rm, rv, 1e-5, 3e-4, relu, want_mask=relu)
+        else:
+            assert not sis_hip.bn_fused_supported(x)
+            mean, invstd = sis_hip.bn_stats(x, rm, rv, 1e-5, 3e-4)
+            out = sis_hip.bn_act_fwd(x, res, mean, invstd, gamma, beta, relu, want_mask=relu)
+            y, mask = out if relu else (out, None)
+        grads = sis_hip.bn_act_bwd(dy, None if mask is not None else y, x, mean, invstd, gamma, relu, use_res, mask=mask)
+        return [y, mean, invstd, rm, rv] + ([mask] if mask is not None else []) + [t for t in grads if t is not None]
+
+    one, three = run(True), run(False)
+    assert len(one) == len(three)
+    n_fwd = 5 + (1 if relu else 0)
+    for u, v in zip(one[:n_fwd], three[:n_fwd]):
+        assert torch.equal(u, v)
+    # backward: the same sums in the same order, but the compiler contracts the multiply-adds of the two kernels differently:
+    # 1 ulp on the channel sums (measured 8e-8 relative), nothing else
+    for u, v in zip(one[n_fwd:], three[n_fwd:]):
+        assert (u - v).abs().max().item() <= 4e-7 * v.abs().max().item()
+    assert torch.equal(one[n_fwd:][-1], run(True)[n_fwd:][-1])   # and repeatable
+
+
 @pytest.mark.parametrize("b,c,h,w,use_res", [(2, 8, 16, 16, False), (3, 5, 12, 20, True), (16, 64, 32, 32, True), (1, 3, 6, 6, False)])
 def test_batch_norm_relu_sign_mask_equals_the_output_gate(device, b, c, h, w, use_res):
     """The 1-bit-per-element ReLU gate written by the forward apply pass gives bit-for-bit the backward that reads y itself
