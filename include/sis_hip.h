@@ -240,6 +240,12 @@ int sis_bn_fused_fwd(float* y, float* mean, float* invstd, float* running_mean, 
  * reference's evaluation); the order is written out in csrc/dataset_ops.hip and oracle/kmeans_ref.py. */
 int sis_kmeans_assign(int64_t* labels, const float* x, const float* centres, int batch, int channels,
                       int hw, int n_centres, void* stream);
+/* The same with a workspace of sis_kmeans_workspace_ints(batch, hw) ints: the pixels the fast first pass leaves open are
+ * listed there and the exact-order pass revisits exactly those, one per lane (without it: every 512-pixel workgroup that holds
+ * one).  Same labels either way. */
+int64_t sis_kmeans_workspace_ints(int batch, int hw);
+int sis_kmeans_assign_ws(int64_t* labels, const float* x, const float* centres, int batch, int channels, int hw, int n_centres,
+                         int* workspace, int64_t workspace_ints, void* stream);
 
 /* float32 NCHW image in [-1,1] -> uint8 NHWC: clamp, (x+1)/2*255, truncating cast (the third-party make_image
  * called at create_dataset_for_segmentation.py:135; its rounding is not pinned by the reference). */

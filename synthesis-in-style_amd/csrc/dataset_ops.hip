@@ -5,11 +5,14 @@
 //                        (segmentation/gan_local_edit/factor_catalog.py:47-62 of the reference, which ships the
 //                        activations to the CPU and materialises an N x K x C tensor there).  Direct
 //                        (x - c)^2 form in fp32 with the reference's own association of the adds (see the kernel):
-//                        label maps are bit-exact against the fp32 oracle.  Reads the activation exactly once:
-//                        HBM 4*C bytes per pixel, VALU 3*K flops per pixel-channel.
+//                        label maps are bit-exact against the fp32 oracle.  Two passes: a fast one (2 VALU operations per
+//                        term, free order) labels every pixel whose argmin provably does not depend on the association
+//                        of the adds, the exact-order one revisits the few workgroups with an undecided pixel.
 //  * sis_make_image_u8   float image in [-1,1] (NCHW) -> uint8 NHWC, the conversion in front of the PNG writer
 //                        (create_dataset_for_segmentation.py:135; third-party make_image: clamp, add 1, div 2, mul 255,
 //                        truncating cast; every step a separate fp32 operation as in the oracle: bytes are bit-exact).
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include "sis_common.h"
 
@@ -56,17 +59,36 @@ __device__ __forceinline__ km_f32x2 km_add(km_f32x2 a, km_f32x2 b) {
 template <int KMAX, int VEC, bool CASCADE>
 __global__ __launch_bounds__(256) void kmeans_assign_kernel(int64_t* __restrict__ labels, const float* __restrict__ x,
                                                             const float* __restrict__ centres, int C, int HW, int K,
-                                                            int groups) {
+                                                            int groups, int refine, const int* __restrict__ open_count,
+                                                            const int* __restrict__ open_list) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float cen[];  // [C][KMAX]
-    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    int b = blockIdx.x / groups;
+    const int g = blockIdx.x % groups;
+    int n_open = 0;
+    if (refine == 3) {   // second pass behind kmeans_fast_kernel, list form: lane i takes the i-th pixel it left open (VEC == 1)
+        n_open = *open_count;
+        if ((int)blockIdx.x * 256 >= n_open) return;
+    } else if (refine) {   // block form: only workgroups / waves with a pixel the fast pass could not decide (label -1)
+        const int pix0 = (g * 256 + threadIdx.x) * VEC;
+        bool open = false;
+        for (int v = 0; v < VEC; ++v) open = open || (pix0 + v < HW && labels[(int64_t)b * HW + pix0 + v] < 0);
+        if (!__syncthreads_or(open)) return;
+        refine = __any(open) ? 1 : 2;   // 2: this wave has nothing to do (it still helps staging the centres)
+    }
     for (int e = threadIdx.x; e < C * KMAX; e += 256) {
         const int c = e / KMAX, k = e - c * KMAX;
         cen[e] = k < K ? centres[(int64_t)k * C + c] : 0.f;
     }
     __syncthreads();
-    const int pix = (g * 256 + threadIdx.x) * VEC;
-    if (pix >= HW) return;
+    int pix = (g * 256 + threadIdx.x) * VEC;
+    if (refine == 3) {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= n_open) return;
+        const int q = open_list[i];
+        b = q / HW; pix = q - b * HW;
+    }
+    if (pix >= HW || refine == 2) return;
     constexpr int NA1 = CASCADE ? KMAX : 1;
     float fin[KMAX][VEC], lt[KMAX][VEC], acc0[KMAX][VEC], acc1[NA1][VEC];
     const float* xb = x + (int64_t)b * C * HW + pix;
@@ -245,6 +267,145 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(int64_t* __restrict_
     }
 }
 
+// First pass for the common shapes (two pixels per lane, K <= KMAX, C % 16 == 0): the same distances with one subtraction
+// and ONE fused multiply-add per term (2 VALU operations instead of the 3 separately rounded ones, no prescribed order),
+// accumulated in runs of 16 channels that are then added to a total -- every term passes through <= 16 + C / 16 additions, so
+//     |d_fast - D| <= (16 + C/16 + 3) u D,      |d_exact - D| <= (C/32 + 32) u D      (u = 2^-24, D the real distance:
+// sums of non-negative terms, standard recursive-summation bound per level; the exact-order kernel's cascade is no deeper
+// than C/32 + 27).  A pixel whose two smallest fast distances differ by more than `thr` * the second one (thr = 3 x the sum
+// of the two bounds) therefore has the same argmin under the exact association; it gets its label here.  Every other pixel
+// (near-ties, duplicate centres, NaN) gets -1 (and, given a workspace, an entry in the list of open pixels) and is decided
+// in exact order, add for add as before: the label map stays bit-exact.  Unit-variance data, 24 random centres: 0.05 % (128
+// channels) to 0.4 % (512) of the pixels stay open -- at least one in most 512-pixel workgroups, hence the list: the block
+// form of the refinement (no workspace) would redo almost everything.
+__device__ __forceinline__ km_f32x2 km_fma_sq(km_f32x2 d, km_f32x2 acc) {   // acc + d * d, one rounding per half
+    km_f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %1, %2" : "=v"(r) : "v"(d), "v"(acc));
+    return r;
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void kmeans_fast_kernel(int64_t* __restrict__ labels, const float* __restrict__ x,
+                                                          const float* __restrict__ centres, int C, int HW, int K, int groups,
+                                                          float thr, int* __restrict__ open_count, int* __restrict__ open_list) {
+    static_assert(KMAX % 4 == 0, "centres are read four at a time");
+    extern __shared__ __attribute__((aligned(16))) float cen[];  // [C][KMAX]
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    for (int e = threadIdx.x; e < C * KMAX; e += 256) {
+        const int c = e / KMAX, k = e - c * KMAX;
+        cen[e] = k < K ? centres[(int64_t)k * C + c] : 0.f;
+    }
+    __syncthreads();
+    const int pix = (g * 256 + threadIdx.x) * 2;
+    if (pix >= HW) return;
+    const float* xb = x + (int64_t)b * C * HW + pix;
+    km_f32x2 run[KMAX], tot[KMAX];   // (four pixels per lane -- a channel's centres read once per 96 operations -- measured slower: 400 vs 300 us)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { run[k] = km_f32x2{0.f, 0.f}; tot[k] = run[k]; }
+    float2 xs[2][16];
+    auto request = [&](auto setc, int c0) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) xs[S][u] = *reinterpret_cast<const float2*>(xb + (int64_t)(c0 + u) * HW);
+    };
+    auto block = [&](auto setc, int c0) {
+        constexpr int S = decltype(setc)::value;
+        request(std::integral_constant<int, S ^ 1>(), c0 + 16 < C ? c0 + 16 : c0);   // (past the end: this block again, unused)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const km_f32x2 xp = {xs[S][u].x, xs[S][u].y};
+            const float* cc = cen + (c0 + u) * KMAX;
+#pragma unroll
+            for (int k4 = 0; k4 < KMAX; k4 += 4) {
+                const km_f32x4 c4 = *reinterpret_cast<const km_f32x4*>(cc + k4);
+                const km_f32x2 c01 = {c4.x, c4.y}, c23 = {c4.z, c4.w};
+                run[k4 + 0] = km_fma_sq(km_sub_bcast<0>(xp, c01), run[k4 + 0]);
+                run[k4 + 1] = km_fma_sq(km_sub_bcast<1>(xp, c01), run[k4 + 1]);
+                run[k4 + 2] = km_fma_sq(km_sub_bcast<0>(xp, c23), run[k4 + 2]);
+                run[k4 + 3] = km_fma_sq(km_sub_bcast<1>(xp, c23), run[k4 + 3]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { tot[k] = km_add(tot[k], run[k]); run[k] = km_f32x2{0.f, 0.f}; }
+    };
+    request(std::integral_constant<int, 0>(), 0);
+    for (int c0 = 0; c0 < C; c0 += 32) {   // C % 16 == 0 (host-checked)
+        block(std::integral_constant<int, 0>(), c0);
+        if (c0 + 16 < C) block(std::integral_constant<int, 1>(), c0 + 16);
+        else break;
+    }
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        float d1 = v == 0 ? tot[0].x : tot[0].y, d2 = __builtin_inff();
+        int arg = 0;
+#pragma unroll
+        for (int k = 1; k < KMAX; ++k) {
+            if (k < K) {
+                const float d = v == 0 ? tot[k].x : tot[k].y;
+                if (d < d1) { d2 = d1; d1 = d; arg = k; }
+                else if (!(d >= d2)) d2 = d;   // (a NaN lands in d2: the pixel stays open)
+            }
+        }
+        const bool sure = K == 1 || (d2 - d1 > thr * d2);   // false for near-ties, exact ties and NaN
+        if (pix + v < HW) {
+            labels[(int64_t)b * HW + pix + v] = sure ? arg : -1;
+            if (!sure && open_list) open_list[atomicAdd(open_count, 1)] = b * HW + pix + v;   // (order irrelevant: one pixel per entry)
+        }
+    }
+}
+
+// Exact-order distances of the LISTED pixels (those kmeans_fast_kernel left open), 32 lanes per pixel: in the documented order
+// a pixel's sum is 8 x 4 independent running sums p[l][part] over the rows r (channel 32 r + 8 part + l), combined as
+// ((p0 + p1) + p2) + p3 per l and then over l = 0..7 in order -- so lane 8 part + l keeps one running sum per centre (C / 32
+// terms each, the same three roundings per term) and the combination is 11 shuffled adds per centre.  One lane per pixel, as
+// the kernel above would do it, is a serial chain of 3 K C operations: 60 us for a single open pixel at 512 channels.
+// C % 32 == 0, no second cascade level (C <= 512): the shapes the fast pass takes; same adds in the same order as above.
+template <int KMAX>
+__global__ __launch_bounds__(256) void kmeans_refine_kernel(int64_t* __restrict__ labels, const float* __restrict__ x,
+                                                            const float* __restrict__ centres, int C, int HW, int K,
+                                                            const int* __restrict__ open_count, const int* __restrict__ open_list) {
+#pragma clang fp contract(off)
+    const int n_open = *open_count;
+    for (int i = blockIdx.x * 8 + (threadIdx.x >> 5); i < n_open; i += gridDim.x * 8) {   // 8 pixels per workgroup and trip
+    const int q = open_list[i];
+    const int b = q / HW, pix = q - b * HW;
+    const int ln = threadIdx.x & 31;                      // = 8 part + l: channel 32 r + ln in row r
+    const float* xp = x + (int64_t)b * C * HW + pix;
+    float acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+    const int rows = C >> 5;
+    for (int r = 0; r < rows; ++r) {
+        const int c = (r << 5) + ln;
+        const float xv = xp[(int64_t)c * HW];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k < K) {
+                const float diff = xv - centres[(int64_t)k * C + c];
+                acc[k] = acc[k] + diff * diff;
+            }
+        }
+    }
+    float best = 0.f;
+    int arg = 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+            // lane total of position l (in lanes 0..7 of the pixel's 32): ((p0 + p1) + p2) + p3
+            float t = acc[k];
+            t = t + __shfl(acc[k], (threadIdx.x & 32) + 8 + (ln & 7), 64);
+            t = t + __shfl(acc[k], (threadIdx.x & 32) + 16 + (ln & 7), 64);
+            t = t + __shfl(acc[k], (threadIdx.x & 32) + 24 + (ln & 7), 64);
+            float fin = 0.f;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) fin = fin + __shfl(t, (threadIdx.x & 32) + l, 64);
+            if (k == 0 || fin < best) { best = fin; arg = k; }
+        }
+    }
+    if (ln == 0) labels[q] = arg;
+    }
+}
+
 __global__ __launch_bounds__(256) void make_image_kernel(uint8_t* __restrict__ out, const float* __restrict__ x,
                                                          int C, int HW, int64_t total) {
 #pragma clang fp contract(off)
@@ -290,28 +451,65 @@ __global__ __launch_bounds__(256) void make_image_rgb4_kernel(uint32_t* __restri
         out[3 * q + w] = (uint32_t)by[4 * w] | ((uint32_t)by[4 * w + 1] << 8) | ((uint32_t)by[4 * w + 2] << 16) | ((uint32_t)by[4 * w + 3] << 24);
 }
 
+constexpr int KM_LDS_MAX = 160 * 1024 - 256;   // dynamic LDS of the k-means kernels (the refine mode's block-wide OR keeps a static word)
+
 template <int KMAX, int VEC, bool CASCADE>
-int launch_kmeans(int64_t* labels, const float* x, const float* centres, int batch, int C, int HW, int K, hipStream_t st) {
+int launch_kmeans(int64_t* labels, const float* x, const float* centres, int batch, int C, int HW, int K, hipStream_t st, int refine = 0,
+                  const int* open_count = nullptr, const int* open_list = nullptr) {
     const int groups = sis_cdiv(HW, 256 * VEC);
     const size_t lds = (size_t)C * KMAX * sizeof(float);
-    SIS_REQUIRE(lds <= 160 * 1024, "sis_kmeans_assign: %d channels x %d centres do not fit in LDS", C, KMAX);
+    SIS_REQUIRE(lds <= KM_LDS_MAX, "sis_kmeans_assign: %d channels x %d centres do not fit in LDS", C, KMAX);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kmeans_assign_kernel<KMAX, VEC, CASCADE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, KM_LDS_MAX);
         if (e != hipSuccess) return sis_fail("sis_kmeans_assign: cannot raise the LDS limit: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((kmeans_assign_kernel<KMAX, VEC, CASCADE>), dim3(batch * groups), dim3(256), lds, st, labels, x, centres, C,
-                       HW, K, groups);
+    const int blocks = refine == 3 ? sis_cdiv((int64_t)batch * HW, 256) : batch * groups;
+    hipLaunchKernelGGL((kmeans_assign_kernel<KMAX, VEC, CASCADE>), dim3(blocks), dim3(256), lds, st, labels, x, centres, C,
+                       HW, K, groups, refine, open_count, open_list);
     SIS_CHECK_LAUNCH("kmeans_assign_kernel");
+    return 0;
+}
+
+template <int KMAX>
+int launch_kmeans_fast(int64_t* labels, const float* x, const float* centres, int batch, int C, int HW, int K, float thr, int* open_count,
+                       int* open_list, hipStream_t st) {
+    const int groups = sis_cdiv(HW, 512);
+    const size_t lds = (size_t)C * KMAX * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kmeans_fast_kernel<KMAX>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, KM_LDS_MAX);
+        if (e != hipSuccess) return sis_fail("sis_kmeans_assign: cannot raise the LDS limit: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((kmeans_fast_kernel<KMAX>), dim3(batch * groups), dim3(256), lds, st, labels, x, centres, C, HW, K, groups, thr,
+                       open_count, open_list);
+    SIS_CHECK_LAUNCH("kmeans_fast_kernel");
     return 0;
 }
 
 }  // namespace
 
+extern "C" int64_t sis_kmeans_workspace_ints(int batch, int hw) { return (int64_t)batch * hw + 1; }
+
+static int kmeans_assign_impl(int64_t* labels, const float* x, const float* centres, int batch, int channels, int hw, int n_centres,
+                              int* workspace, int64_t workspace_ints, void* stream);
+
 extern "C" int sis_kmeans_assign(int64_t* labels, const float* x, const float* centres, int batch, int channels,
                                  int hw, int n_centres, void* stream) {
+    return kmeans_assign_impl(labels, x, centres, batch, channels, hw, n_centres, nullptr, 0, stream);
+}
+
+extern "C" int sis_kmeans_assign_ws(int64_t* labels, const float* x, const float* centres, int batch, int channels, int hw,
+                                    int n_centres, int* workspace, int64_t workspace_ints, void* stream) {
+    return kmeans_assign_impl(labels, x, centres, batch, channels, hw, n_centres, workspace, workspace_ints, stream);
+}
+
+static int kmeans_assign_impl(int64_t* labels, const float* x, const float* centres, int batch, int channels, int hw, int n_centres,
+                              int* workspace, int64_t workspace_ints, void* stream) {
     if (batch <= 0 || hw <= 0) return 0;
     SIS_REQUIRE(labels && x && centres, "sis_kmeans_assign: null pointer");
     SIS_REQUIRE(n_centres >= 1 && n_centres <= 64, "sis_kmeans_assign: %d centres outside 1..64", n_centres);
@@ -321,11 +519,49 @@ extern "C" int sis_kmeans_assign(int64_t* labels, const float* x, const float* c
                 "sis_kmeans_assign: %d channels (the documented summation order covers 8 <= C < 8192)", channels);
     const bool vec = hw % 2 == 0 && (((uintptr_t)x) & 7) == 0;
     const bool cascade = (channels >> 5) > 16;  // more than 16 rows of 4 vectors: the second-level sums carry a rounding
+    // two passes where the fast kernel applies: it decides every pixel whose argmin cannot depend on the association of the adds,
+    // the exact-order kernel below then only visits the workgroups that still hold a -1 (SIS_KMEANS_FAST=0: exact order only)
+    const char* fast_env = getenv("SIS_KMEANS_FAST");
+    int refine = 0;
+    if (!(fast_env && fast_env[0] == '0') && vec && !cascade && channels % 16 == 0 && n_centres <= 32 &&
+        (size_t)channels * 32 * sizeof(float) <= (size_t)KM_LDS_MAX) {
+        const float u = 5.9604645e-8f;   // 2^-24
+        const float thr = 3.f * ((16.f + channels / 16.f + 3.f) + (channels / 32.f + 32.f)) * u;   // 2 (b_fast + b_exact), x 1.5
+        // with a workspace ([0]: counter, [1..]: pixel ids) the open pixels are listed and revisited one per lane
+        const bool listed = workspace && workspace_ints >= (int64_t)batch * hw + 1 && (int64_t)batch * hw < ((int64_t)1 << 31);
+        int* count = listed ? workspace : nullptr;
+        int* list = listed ? workspace + 1 : nullptr;
+        if (listed && hipMemsetAsync(count, 0, sizeof(int), st) != hipSuccess) return sis_fail("sis_kmeans_assign: cannot clear the counter");
+        int rc;
+        if (n_centres <= 8) rc = launch_kmeans_fast<8>(labels, x, centres, batch, channels, hw, n_centres, thr, count, list, st);
+        else if (n_centres <= 16) rc = launch_kmeans_fast<16>(labels, x, centres, batch, channels, hw, n_centres, thr, count, list, st);
+        else if (n_centres <= 24) rc = launch_kmeans_fast<24>(labels, x, centres, batch, channels, hw, n_centres, thr, count, list, st);
+        else rc = launch_kmeans_fast<32>(labels, x, centres, batch, channels, hw, n_centres, thr, count, list, st);
+        if (rc) return rc;
+        refine = listed ? 3 : 1;
+        if (listed && channels % 32 == 0) {   // 32 lanes per open pixel
+            const int blocks = (int)std::min<int64_t>(sis_cdiv((int64_t)batch * hw, 8), 1024);   // (the list is short: 262 144 empty workgroups took 170 us)
+#define KM_LIST(KM)                                                                                                              \
+    if (n_centres <= KM) {                                                                                                       \
+        hipLaunchKernelGGL(kmeans_refine_kernel<KM>, dim3(blocks), dim3(256), 0, st, labels, x, centres, channels, hw, n_centres, \
+                           (const int*)count, (const int*)list);                                                                 \
+        SIS_CHECK_LAUNCH("kmeans_refine_kernel");                                                                                \
+        return 0;                                                                                                                \
+    }
+            KM_LIST(8) KM_LIST(16) KM_LIST(24) KM_LIST(32)
+#undef KM_LIST
+        }
+        if (listed) {   // one lane per open pixel
+#define KM_LIST(KM) if (n_centres <= KM) return launch_kmeans<KM, 1, false>(labels, x, centres, batch, channels, hw, n_centres, st, 3, count, list);
+            KM_LIST(8) KM_LIST(16) KM_LIST(24) KM_LIST(32)
+#undef KM_LIST
+        }
+    }
     // accumulators for the centre count rounded up to a multiple of 8 (the reference config's 24 centres: no padded work)
 #define KM_CASE(KM)                                                                                                      \
     if (n_centres <= KM) {                                                                                               \
         if (cascade) return launch_kmeans<KM, 1, true>(labels, x, centres, batch, channels, hw, n_centres, st);           \
-        return vec ? launch_kmeans<KM, 2, false>(labels, x, centres, batch, channels, hw, n_centres, st)                  \
+        return vec ? launch_kmeans<KM, 2, false>(labels, x, centres, batch, channels, hw, n_centres, st, refine)          \
                    : launch_kmeans<KM, 1, false>(labels, x, centres, batch, channels, hw, n_centres, st);                 \
     }
     KM_CASE(8) KM_CASE(16) KM_CASE(24) KM_CASE(32) KM_CASE(64)

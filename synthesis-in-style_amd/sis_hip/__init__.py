@@ -95,6 +95,8 @@ _SIGNATURES = {
     "sis_bn_fused_fwd": ([_vp] * 9 + [_i, _i, _i, _f, _f, _i, _vp, _vp], _i),
     "sis_bn_act_bwd": ([_vp] * 11 + [_i, _i, _i, _i, _vp, _vp], _i),
     "sis_kmeans_assign": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "sis_kmeans_workspace_ints": ([_i, _i], _i64),
+    "sis_kmeans_assign_ws": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp], _i),
     "sis_make_image_u8": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "sis_crop_patches_u8": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "sis_assemble_max": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -598,10 +600,11 @@ def kmeans_assign(x, centres):
     if c.shape[1] != ch:
         raise RuntimeError(f"centres have {c.shape[1]} channels, activations {ch}")
     labels = torch.empty((b, h, w), dtype=torch.int64, device=x.device)
+    ws = torch.empty(lib().sis_kmeans_workspace_ints(b, h * w), dtype=torch.int32, device=x.device)   # list of the pixels the fast pass leaves open
     with torch.cuda.device(x.device):
         _check(_launch("kmeans_assign_kernel", 3.0 * b * ch * h * w * c.shape[0], 4.0 * x.numel() + 8.0 * labels.numel(),
-                       lambda: lib().sis_kmeans_assign(_ptr(labels), _ptr(x), _ptr(c), b, ch, h * w, c.shape[0],
-                                                       _stream())), "sis_kmeans_assign")
+                       lambda: lib().sis_kmeans_assign_ws(_ptr(labels), _ptr(x), _ptr(c), b, ch, h * w, c.shape[0], _ptr(ws), ws.numel(),
+                                                          _stream())), "sis_kmeans_assign")
     return labels
 
 

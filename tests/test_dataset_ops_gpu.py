@@ -55,6 +55,33 @@ def test_kmeans_assign_matches_reference_fixture(device, golden_dir):
         assert torch.equal(got, torch.from_numpy(g[f"labels{i}"].astype(np.int64))), f"case {i} {mk.CASES[i]}"
 
 
+@pytest.mark.parametrize("b,c,h,w,k", [(4, 512, 64, 64, 24), (2, 128, 256, 256, 24), (3, 48, 30, 34, 32), (2, 16, 64, 64, 8)])
+def test_kmeans_fast_pass_plus_exact_refinement(device, b, c, h, w, k, monkeypatch):
+    """The two-pass form (fast distances decide the pixels whose argmin cannot depend on the order of the adds, the exact-order
+    kernel revisits the rest) returns the label map of the exact-order kernel alone, bit for bit: unit-variance activations at
+    the generator's key shapes (few open pixels), plus pixels planted exactly between two centres and on top of a duplicated
+    centre (open by construction), plus a NaN pixel."""
+    import sis_hip
+    gen = torch.Generator().manual_seed(c + k + h)
+    x = torch.randn(b, c, h, w, generator=gen)
+    centres = torch.randn(k, c, generator=gen)
+    if k >= 4:
+        centres[3] = centres[1]                                   # exact duplicate: ties go to the lower index
+        x[0, :, 0, 0] = centres[1]
+        x[0, :, 0, 1] = (centres[0] + centres[2]) / 2             # equidistant up to rounding
+        x[-1, :, h - 1, w - 1] = centres[k - 1] * (1 + 1e-7)
+        x[0, 0, 1, 1] = float("nan")
+    xd, cd = x.to(device), centres.to(device)
+    monkeypatch.setenv("SIS_KMEANS_FAST", "0")
+    exact = sis_hip.kmeans_assign(xd, cd)
+    monkeypatch.setenv("SIS_KMEANS_FAST", "1")
+    two_pass = sis_hip.kmeans_assign(xd, cd)
+    assert torch.equal(two_pass, exact)
+    assert int(two_pass.min()) >= 0 and int(two_pass.max()) < k
+    if k >= 4:
+        assert int(exact[0, 0, 0]) == 1
+
+
 def test_kmeans_ties_go_to_lowest_index(device):
     import sis_hip
     x = torch.zeros(1, 8, 2, 2, device=device)
