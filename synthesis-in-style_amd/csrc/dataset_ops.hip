@@ -54,7 +54,7 @@ __device__ __forceinline__ km_f32x2 km_add(km_f32x2 a, km_f32x2 b) {
 //   * result = (((0 + scalar tail terms c >= 8*(C/8) in order) + lane 0) + lane 1) ... + lane 7;
 //   * every term is round(round(x - c) * round(x - c)): subtract, multiply and add are separate IEEE operations
 //     (no FMA contraction: #pragma clang fp contract(off)); ties go to the lowest centre index (torch.argmin).
-// 8 <= C < 8192 (below 8 ATen takes its scalar path, at 8192 a third cascade level starts).  The activations are
+// 8 <= C < 8192 here (below 8 ATen takes its scalar path: kmeans_small_c_kernel; at 8192 a third cascade level starts).  The activations are
 // still read exactly once, one channel plane row per step.
 template <int KMAX, int VEC, bool CASCADE>
 __global__ __launch_bounds__(256) void kmeans_assign_kernel(int64_t* __restrict__ labels, const float* __restrict__ x,
@@ -406,6 +406,30 @@ __global__ __launch_bounds__(256) void kmeans_refine_kernel(int64_t* __restrict_
     }
 }
 
+// Fewer than 8 channels: ATen sums the row with its scalar path (SumKernel.cpp scalar_inner_sum -> row_sum): four
+// interleaved partial sums p[j] = 0 + term_j (j < 4 when C >= 4), the remaining terms join p[0] in order, result
+// ((p0 + p1) + p2) + p3 (oracle/kmeans_ref.py::_row_sum).  One lane per pixel, centres straight from global memory.
+__global__ __launch_bounds__(256) void kmeans_small_c_kernel(int64_t* __restrict__ labels, const float* __restrict__ x,
+                                                             const float* __restrict__ centres, int C, int HW, int K, int64_t total) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int64_t b = i / HW, pix = i - b * HW;
+    float xv[7];
+    for (int c = 0; c < C; ++c) xv[c] = x[(b * C + c) * HW + pix];
+    const int lead = C >= 4 ? 4 : 0;
+    float best = 0.f;
+    int arg = 0;
+    for (int k = 0; k < K; ++k) {
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < lead; ++c) { const float d = xv[c] - centres[(int64_t)k * C + c]; p[c] = p[c] + d * d; }
+        for (int c = lead; c < C; ++c) { const float d = xv[c] - centres[(int64_t)k * C + c]; p[0] = p[0] + d * d; }
+        const float dist = ((p[0] + p[1]) + p[2]) + p[3];
+        if (k == 0 || dist < best) { best = dist; arg = k; }
+    }
+    labels[i] = arg;
+}
+
 __global__ __launch_bounds__(256) void make_image_kernel(uint8_t* __restrict__ out, const float* __restrict__ x,
                                                          int C, int HW, int64_t total) {
 #pragma clang fp contract(off)
@@ -515,8 +539,13 @@ static int kmeans_assign_impl(int64_t* labels, const float* x, const float* cent
     SIS_REQUIRE(n_centres >= 1 && n_centres <= 64, "sis_kmeans_assign: %d centres outside 1..64", n_centres);
     SIS_REQUIRE(channels >= 1, "sis_kmeans_assign: no channels");
     hipStream_t st = (hipStream_t)stream;
-    SIS_REQUIRE(channels >= 8 && channels < 8192,
-                "sis_kmeans_assign: %d channels (the documented summation order covers 8 <= C < 8192)", channels);
+    if (channels < 8) {
+        const int64_t total = (int64_t)batch * hw;
+        hipLaunchKernelGGL(kmeans_small_c_kernel, dim3(sis_cdiv(total, 256)), dim3(256), 0, st, labels, x, centres, channels, hw, n_centres, total);
+        SIS_CHECK_LAUNCH("kmeans_small_c_kernel");
+        return 0;
+    }
+    SIS_REQUIRE(channels < 8192, "sis_kmeans_assign: %d channels (the documented summation order covers C < 8192)", channels);
     const bool vec = hw % 2 == 0 && (((uintptr_t)x) & 7) == 0;
     const bool cascade = (channels >> 5) > 16;  // more than 16 rows of 4 vectors: the second-level sums carry a rounding
     // two passes where the fast kernel applies: it decides every pixel whose argmin cannot depend on the association of the adds,

@@ -26,7 +26,8 @@ def _kmeans_cases():
 
 @pytest.mark.parametrize("b,c,h,w,k", [(2, 128, 64, 64, 20), (1, 512, 16, 16, 7), (3, 32, 5, 7, 40), (2, 64, 32, 32, 16),
                                        (1, 16, 8, 8, 1), (1, 20, 3, 3, 5), (1, 1056, 6, 6, 9), (2, 40, 9, 8, 64),
-                                       (1, 256, 16, 16, 24), (1, 384, 8, 8, 12), (1, 128, 7, 7, 24)])  # (multiples of 128: the prefetching / packed path; odd HW: its one-pixel form)
+                                       (1, 256, 16, 16, 24), (1, 384, 8, 8, 12), (1, 128, 7, 7, 24),
+                                       (2, 1, 9, 9, 5), (1, 3, 16, 16, 24), (1, 4, 8, 8, 6), (2, 5, 7, 9, 16), (1, 7, 12, 12, 32)])  # (multiples of 128: the prefetching / packed path; odd HW: its one-pixel form)
 def test_kmeans_assign_matches_reference_rule(device, b, c, h, w, k):
     from segmentation.gan_local_edit.factor_catalog import FactorCatalog
     gen = torch.Generator().manual_seed(c + k)
