@@ -16,3 +16,9 @@ python tools/step_breakdown.py $O/prof_tu 90 130 > $O/transunet_step_breakdown.t
 cp $(find $O/prof_tu -name "*kernel_stats.csv" | head -1) $O/transunet_kernel_stats.csv
 rm -rf $O/prof_tu
 head -3 $O/emanet_step_breakdown.txt; head -3 $O/transunet_step_breakdown.txt; head -4 $O/step_timeline.txt
+python bench.py --workload dataset --steps 20 --warmup 5 --no-cpu-baseline 2> /dev/null | grep "^{" > $O/bench_dataset.json
+python bench.py --workload gan --steps 16 --warmup 2 --no-cpu-baseline 2> /dev/null | grep "^{" > $O/bench_gan.json
+PLAN=1 python tools/bench_gemm.py > $O/gemm_plan.txt 2>&1
+python tools/bench_attention.py > $O/attention.txt 2>&1
+python tools/bench_conv1x1_wgrad_bf16.py > $O/conv1x1_wgrad_bf16.txt 2>&1
+python -c "import json; [print(f, json.load(open('$O/'+f))['value']) for f in ('bench_dataset.json','bench_gan.json')]"
