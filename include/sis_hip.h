@@ -493,6 +493,13 @@ int sis_gemm_bf16(void* c, void* c2, const void* a, const void* b, int layout, i
                   int ldb, int ldc, const float* bias, const float* bias1, const float* bias2, int bias_seg, const float* resid,
                   const void* pre, const void* seed, int site, float drop_p, int splits, void* workspace,
                   int64_t workspace_bytes, int tile, void* stream);
+/* Weight gradient AND bias gradient of a Linear layer (what autograd computes as grad.t() @ x and grad.sum(0)) in the two
+ * launches of the split-K weight gradient: dw [m][n] float32 (TN layout: grad [k][m], x [k][n], splits > 1), db [m] float32 =
+ * column sums of grad by extra workgroups of the GEMM launch (dispatched last: they fill the slots its final, partly filled round
+ * of tiles leaves idle) and of the slab reduction; sis_column_sum's summation order.
+ * workspace: sis_gemm_bf16_workspace_bytes(m, n, splits) + 64 * m * 4 bytes; tile 0 or 4..6. */
+int sis_gemm_bf16_wgrad_bias(void* dw, float* db, const void* grad, const void* x, int m, int n, int k, int lda, int ldb, int splits,
+                             void* workspace, int64_t workspace_bytes, int tile, void* stream);
 
 /* The same kernel over `batches` problems (grid.y): A / B / C of entry i start i * {a,b,c}_batch_stride elements after the base
  * pointers (stride 0 = shared operand).  With sum_over_batches != 0 the entries are the K slices of ONE result instead

@@ -55,6 +55,11 @@ struct GemmParams {
     // (sum over the images of a convolution's weight gradient)
     int batch_k, grid_batches;
     long long a_bstride, b_bstride, c_bstride;
+    // Column sums of the A operand of a TN (weight-gradient) run = the bias gradient of the same Linear layer, computed by EXTRA
+    // workgroups of the same launch (block ids >= gemm_blocks): they are dispatched last, into the slots the final, partly
+    // filled round of tiles leaves idle, and stream the gradient once more while the tiles multiply.  cs_part [slices][M]
+    // partial rows; the slab-reduction launch that follows adds them in slice order (as column_sum.hip does).
+    float* cs_part; int gemm_blocks, cs_slices, cs_rows_per_slice;
 };
 
 template <int BM_, int BN_, bool AKM_, bool BKM_, int BK_ = 64, int NS_ = 2>
@@ -90,6 +95,46 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (C::AKM && C::BKM && C::THREADS == 256) {
+        if (p.cs_part && (int)blockIdx.x >= p.gemm_blocks) {
+            // column-sum role (see GemmParams): workgroup (column group of 256, row slice) exactly as column_sum_partial_kernel --
+            // lane l of every wave owns columns 4l..4l+3, the 4 waves take rows r, r+4, ..., combined through LDS in wave order
+            float* red = reinterpret_cast<float*>(lds);   // [4][256]
+            const int cs = (int)blockIdx.x - p.gemm_blocks;
+            const int groups = (p.M + 255) / 256;
+            const int cg = cs % groups, slice = cs / groups;
+            const int c = cg * 256 + 4 * lane;
+            const int r_lo = slice * p.cs_rows_per_slice, r_hi = min(p.K, r_lo + p.cs_rows_per_slice);
+            const u16* x = (const u16*)p.A;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            auto load4 = [&](int r, float* v) {
+                const uint2 q = *reinterpret_cast<const uint2*>(x + (long long)r * p.lda + c);
+                v[0] = __builtin_bit_cast(float, q.x << 16); v[1] = __builtin_bit_cast(float, q.x & 0xFFFF0000u);
+                v[2] = __builtin_bit_cast(float, q.y << 16); v[3] = __builtin_bit_cast(float, q.y & 0xFFFF0000u);
+            };
+            if (c < p.M) {
+                int r = r_lo + wave;
+                for (; r + 4 < r_hi; r += 8) {
+                    float a[4], b[4];
+                    load4(r, a); load4(r + 4, b);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += a[e] + b[e];
+                }
+                for (; r < r_hi; r += 4) {
+                    float a[4];
+                    load4(r, a);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += a[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wave * 256 + 4 * lane + e] = acc[e];
+            __syncthreads();
+            const int cc = cg * 256 + tid;
+            if (cc < p.M) p.cs_part[(long long)slice * p.M + cc] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+            return;
+        }
+    }
     const int i16 = lane & 15, g = lane >> 4;
     const int wm = wave % C::WM, wn = wave / C::WM;
 
@@ -372,7 +417,24 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
 
 // partial slabs of a split-K run -> result, added in slab order (deterministic)
 __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(float* __restrict__ out, const float* __restrict__ slabs, long long quads,
-                                                               int splits, long long slab_stride) {
+                                                               int splits, long long slab_stride, int reduce_blocks,
+                                                               float* __restrict__ cs_out, const float* __restrict__ cs_part, int cs_n,
+                                                               int cs_slices) {
+    if ((int)blockIdx.x >= reduce_blocks) {
+        // second stage of the bias column sums (blocks beyond the slab reduction): 64 columns per workgroup, wave q adds the
+        // slices q, q + 4, ... in order, then (s0 + s1) + (s2 + s3) -- column_sum_finish_kernel's order
+        __shared__ float red[4][64];
+        const int c = ((int)blockIdx.x - reduce_blocks) * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+        float sum = 0.f;
+        if (c < cs_n) {
+#pragma unroll 8
+            for (int k = q; k < cs_slices; k += 4) sum += cs_part[(long long)k * cs_n + c];
+        }
+        red[q][threadIdx.x & 63] = sum;
+        __syncthreads();
+        if (q == 0 && c < cs_n) cs_out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        return;
+    }
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= quads) return;
     float4 s = *reinterpret_cast<const float4*>(slabs + 4 * i);
@@ -397,7 +459,15 @@ int launch_gemm(const GemmParams& p, hipStream_t st, const char* name) {
     else if (p.splits >= 8) groups = p.m_tiles * p.n_tiles * (p.splits / 8);
     else groups = sis_cdiv((int64_t)p.m_tiles * p.n_tiles, 8 / p.splits);
     SIS_OCC_REPORT((gemm_bf16_kernel<C, EPI>), C::THREADS, C::LDS);
-    hipLaunchKernelGGL((gemm_bf16_kernel<C, EPI>), dim3(8 * groups, p.batch_k ? 1 : p.grid_batches), dim3(C::THREADS), C::LDS, st, p);
+    GemmParams q = p;
+    q.gemm_blocks = 8 * groups;
+    int extra = 0;
+    if (q.cs_part) {
+        if (!(C::AKM && C::BKM && C::THREADS == 256 && !p.batch_k && p.grid_batches == 1))
+            return sis_fail("%s: the bias column sums ride with the 4-wave TN tiles only", name);
+        extra = ((p.M + 255) / 256) * p.cs_slices;
+    }
+    hipLaunchKernelGGL((gemm_bf16_kernel<C, EPI>), dim3(8 * groups + extra, p.batch_k ? 1 : p.grid_batches), dim3(C::THREADS), C::LDS, st, q);
     SIS_CHECK_LAUNCH(name);
     sis_kernel_name = name;
     return 0;
@@ -458,7 +528,8 @@ static int gemm_impl(void* c, void* c2, const void* a, const void* b, int layout
                      int lda, int ldb, int ldc, const float* bias, const float* bias1, const float* bias2, int bias_seg,
                      const float* resid, const void* pre,
                      const void* seed, int site, float drop_p, int splits, void* workspace, int64_t workspace_bytes,
-                     int tile, int batches, int batch_k, int64_t a_bstride, int64_t b_bstride, int64_t c_bstride, void* stream) {
+                     int tile, int batches, int batch_k, int64_t a_bstride, int64_t b_bstride, int64_t c_bstride, void* stream,
+                     float* colsum_out = nullptr) {
     if (m <= 0 || n <= 0) return 0;
     SIS_REQUIRE(c && a && b, "sis_gemm_bf16: null pointer");
     SIS_REQUIRE(layout >= 0 && layout <= 2, "sis_gemm_bf16: layout %d (0 NT, 1 NN, 2 TN)", layout);
@@ -508,10 +579,25 @@ static int gemm_impl(void* c, void* c2, const void* a, const void* b, int layout
     }
     hipStream_t st = (hipStream_t)stream;
     float* result = (float*)c;
+    p.cs_part = nullptr; p.gemm_blocks = 0; p.cs_slices = 0; p.cs_rows_per_slice = 0;
     if (splits > 1) {
         SIS_REQUIRE(ldc == n, "sis_gemm_bf16: split-K writes a dense result (ldc == n)");
         SIS_REQUIRE(workspace && workspace_bytes >= sis_gemm_bf16_workspace_bytes(m, n, splits), "sis_gemm_bf16: workspace too small");
         p.C = workspace;
+    }
+    if (colsum_out) {   // bias gradient = column sums of the TN run's A operand, in the same two launches (see GemmParams)
+        SIS_REQUIRE(layout == LAYOUT_TN && epilogue == SIS_GEMM_EPI_F32 && splits > 1 && m % 4 == 0 && lda % 4 == 0,
+                    "sis_gemm_bf16_wgrad_bias: needs the TN layout with split-K and m, lda multiples of 4");
+        const int groups = sis_cdiv(m, 256);
+        int slices = sis_cdiv(1024, groups);
+        if (slices > 64) slices = 64;
+        if (slices > sis_cdiv(k, 8)) slices = sis_cdiv(k, 8);
+        if (slices < 1) slices = 1;
+        p.cs_rows_per_slice = sis_cdiv(k, slices);
+        p.cs_slices = sis_cdiv(k, p.cs_rows_per_slice);
+        const int64_t slab_bytes = sis_gemm_bf16_workspace_bytes(m, n, splits);
+        SIS_REQUIRE(workspace_bytes >= slab_bytes + (int64_t)p.cs_slices * m * 4, "sis_gemm_bf16_wgrad_bias: workspace too small");
+        p.cs_part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + slab_bytes);
     }
     int rc;
 switch (tile) {
@@ -531,8 +617,9 @@ switch (tile) {
     if (rc) return rc;
     if (splits > 1) {
         const long long quads = (long long)m * n / 4;
-        hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3(sis_cdiv(quads, 256)), dim3(256), 0, st, result, (const float*)workspace,
-                           quads, splits, p.slab_stride);
+        const int reduce_blocks = sis_cdiv(quads, 256), cs_blocks = p.cs_part ? sis_cdiv(m, 64) : 0;
+        hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3(reduce_blocks + cs_blocks), dim3(256), 0, st, result, (const float*)workspace,
+                           quads, splits, p.slab_stride, reduce_blocks, colsum_out, (const float*)p.cs_part, m, p.cs_slices);
         SIS_CHECK_LAUNCH("gemm_slab_reduce_kernel");
     }
     return 0;
@@ -557,4 +644,16 @@ extern "C" int sis_gemm_bf16_batched(void* c, const void* a, const void* b, int 
     SIS_REQUIRE(a_batch_stride % 8 == 0 && b_batch_stride % 8 == 0 && c_batch_stride % 4 == 0, "sis_gemm_bf16_batched: batch strides must keep 16-byte alignment");
     return gemm_impl(c, nullptr, a, b, layout, epilogue, m, n, k, lda, ldb, ldc, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0.f,
                      1, workspace, workspace_bytes, tile, batches, sum_over_batches ? 1 : 0, a_batch_stride, b_batch_stride, c_batch_stride, stream);
+}
+
+/* Weight gradient AND bias gradient of a Linear layer in the two launches of the split-K weight gradient: dw [m][n] float32 =
+ * grad^T x (TN layout: grad [k][m], x [k][n], as sis_gemm_bf16 with SIS_GEMM_EPI_F32, splits > 1) and db [m] float32 = column
+ * sums of grad, computed by extra workgroups of the GEMM launch (they land in the slots its last, partly filled round of tiles
+ * leaves idle) and finished by extra workgroups of the slab reduction; same summation order as sis_column_sum.
+ * workspace: sis_gemm_bf16_workspace_bytes(m, n, splits) + 64 * m * 4 bytes.  tile: 0 or 4..6 (the 4-wave tiles). */
+extern "C" int sis_gemm_bf16_wgrad_bias(void* dw, float* db, const void* grad, const void* x, int m, int n, int k, int lda, int ldb,
+                                        int splits, void* workspace, int64_t workspace_bytes, int tile, void* stream) {
+    SIS_REQUIRE(db, "sis_gemm_bf16_wgrad_bias: null pointer");
+    return gemm_impl(dw, nullptr, grad, x, LAYOUT_TN, SIS_GEMM_EPI_F32, m, n, k, lda, ldb, n, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                     nullptr, 0, 0.f, splits, workspace, workspace_bytes, tile, 1, 0, 0, 0, 0, stream, db);
 }

@@ -313,6 +313,7 @@ def _wgrad_plan(out_features, in_features):
     return splits, 0
 
 
+_FUSE_BIAS_GRAD = os.environ.get('SIS_FUSE_BIAS_GRAD', '1') != '0'   # 0: bias gradients as column-sum launches of their own (A/B runs)
 _WGRAD_STREAMS = {}  # device -> side stream of the weight-gradient GEMMs (process-wide, like the generator's ToRGB stream)
 _WGRAD_SIDE = int(os.environ.get('SIS_WGRAD_STREAM', '0'))   # 1: weight-gradient GEMMs + column sums on a side stream (measured 273 vs 277 images/s: off); 2: column sums only
 
@@ -343,6 +344,9 @@ class _SideWgrads:
         S = sis_hip
         splits, tile = _wgrad_plan(out_features, in_features)
         if self.side is None:
+            if _FUSE_BIAS_GRAD and splits > 1 and tile in (0, 4, 5, 6) and grad.shape[0] >= 64 * splits:   # (fewer tokens: the GEMM drops its split)
+                # the bias column sums ride in the weight-gradient launches (extra workgroups in the idle slots of the last round)
+                return S.gemm_bf16_wgrad_bias(grad, inp, splits, tile)
             return S.gemm_bf16(grad, inp, S.GEMM_TN, S.EPI_F32, splits=splits, tile=tile), S.column_sum(grad)
         self.side.wait_event(self.main.record_event())   # grad (and inp) are complete on the main stream
         grad.record_stream(self.side)

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "sis_upsample_bilinear_strided": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _i, _vp], _i),
     "sis_gemm_bf16_workspace_bytes": ([_i, _i, _i], _i64),
     "sis_gemm_bf16": ([_vp] * 4 + [_i] * 8 + [_vp] * 3 + [_i] + [_vp] * 3 + [_i, _f, _i, _vp, _i64, _i, _vp], _i),
+    "sis_gemm_bf16_wgrad_bias": ([_vp] * 4 + [_i] * 6 + [_vp, _i64, _i, _vp], _i),
     "sis_gemm_bf16_batched": ([_vp] * 3 + [_i] * 9 + [_i64] * 3 + [_i, _vp, _i64, _i, _vp], _i),
     "sis_layer_norm_bwd_fused": ([_vp] * 9 + [_i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp], _i),
     "sis_attention_fwd": ([_vp, _vp, _vp, _i, _i, _i, _vp], _i),
@@ -900,6 +901,37 @@ def gemm_bf16(a, b, layout, epilogue=EPI_NONE, bias=None, resid=None, pre=None, 
                                                    float(drop_p), int(splits), _ptr(ws), ws_bytes, int(tile), _stream())),
                "sis_gemm_bf16")
     return (c, c2) if c2 is not None else c
+
+
+def _stream_workspace(device):
+    """Split-K scratch of the current stream (the per-device buffer on the default stream)."""
+    stream = torch.cuda.current_stream(device)
+    if stream == torch.cuda.default_stream(device):
+        return _workspace(device)
+    ws = _workspaces.get((device, stream.cuda_stream))
+    if ws is None:
+        ws = _workspaces[(device, stream.cuda_stream)] = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+    return ws
+
+
+def gemm_bf16_wgrad_bias(grad, x, splits, tile=0):
+    """Weight and bias gradient of a Linear layer from dL/dy ``grad`` [tokens, out] and its input ``x`` [tokens, in] (bf16):
+    -> (dW [out, in] float32, db [out] float32) in the two launches of the split-K weight-gradient GEMM -- the column sums of
+    ``grad`` are computed by extra workgroups of those launches (``sis_gemm_bf16_wgrad_bias``)."""
+    require_device(grad, "grad")
+    grad, x = _rows2d(grad, "grad"), _rows2d(x, "x")
+    (k, m), (k2, n) = grad.shape, x.shape
+    if k != k2 or splits < 2 or m % 4:
+        raise RuntimeError("gemm_bf16_wgrad_bias: row counts differ, fewer than 2 splits, or an output width that is not a multiple of 4")
+    dw = torch.empty((m, n), dtype=torch.float32, device=grad.device)
+    db = torch.empty(m, dtype=torch.float32, device=grad.device)
+    ws = _stream_workspace(grad.device)
+    with torch.cuda.device(grad.device):
+        _check(_launch("gemm_bf16<TN,5>", 2.0 * m * n * k, 2.0 * (m * k + n * k) + 4.0 * m * n,
+                       lambda: lib().sis_gemm_bf16_wgrad_bias(_ptr(dw), _ptr(db), _ptr(grad), _ptr(x), m, n, k, grad.stride(0), x.stride(0),
+                                                              int(splits), _ptr(ws), ws.numel(), int(tile), _stream())),
+               "sis_gemm_bf16_wgrad_bias")
+    return dw, db
 
 
 def _batched_operand(t, name):

@@ -87,6 +87,23 @@ def test_gemm_tn_weight_gradient(device, m, n, k, splits, tile):
     assert torch.equal(got, again), "split-K partial sums are added in slab order: bitwise repeatable"
 
 
+@pytest.mark.parametrize("tile", [0, 4, 6])
+@pytest.mark.parametrize("m,n,k,splits", [(2304, 768, 8192, 4), (768, 768, 8192, 8), (3072, 768, 2048, 4), (136, 264, 200, 2), (264, 72, 1000, 2)])
+def test_gemm_weight_and_bias_gradient_in_one_pair_of_launches(device, m, n, k, splits, tile):
+    """sis_gemm_bf16_wgrad_bias: the weight gradient is bitwise the plain split-K TN run, the bias gradient (column sums of the
+    gradient, computed by extra workgroups of the same launches) bitwise sis_column_sum -- same summation orders -- incl. output
+    widths that are not multiples of 256 / of the tile and row counts that are not multiples of anything."""
+    import sis_hip as S
+    gen = torch.Generator().manual_seed(m + n + k + splits + tile)
+    g, x = _rand((k, m), gen).to(device), _rand((k, n), gen).to(device)
+    dw, db = S.gemm_bf16_wgrad_bias(g, x, splits, tile)
+    assert torch.equal(dw, S.gemm_bf16(g, x, S.GEMM_TN, S.EPI_F32, splits=splits, tile=tile))
+    assert torch.equal(db, S.column_sum(g))
+    _close(db, g.float().sum(0).cpu(), F32_TOL)
+    dw2, db2 = S.gemm_bf16_wgrad_bias(g, x, splits, tile)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
 def test_gemm_strided_views(device):
     """Operands are taken as row-strided views: q / k / v column blocks of the fused projection, no copies."""
     import sis_hip as S
