@@ -270,6 +270,9 @@ int sis_conv3x3_wgrad_eligible(int batch, int cin, int cout, int h, int w, int64
 int sis_conv3x3_wgrad(float* dw, const float* x, const float* gy, int batch, int cin, int cout, int h, int w,
                       void* workspace, int64_t workspace_bytes, void* stream);
 int sis_conv3x3_prepack(float* u, const float* w, int cout, int cin, int adjoint, void* stream);
+/* forward and adjoint images of w [cout][cin][3][3] from one launch (training: the backward of the same step needs the adjoint):
+ * u [cin][16][cout], u_adjoint [cout][16][cin]. */
+int sis_conv3x3_prepack_both(float* u, float* u_adjoint, const float* w, int cout, int cin, void* stream);
 int sis_conv3x3(float* out, const float* x, const float* u, int batch, int cin, int cout, int h, int w,
                 void* workspace, int64_t workspace_bytes, void* stream);
 

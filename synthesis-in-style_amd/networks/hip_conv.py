@@ -68,15 +68,19 @@ class _Conv3x3Function(Function):
     @staticmethod
     def forward(ctx, input, weight, dilation):
         input_s = _space_to_batch(input, dilation)
-        ctx.save_for_backward(input, weight, input_s if dilation > 1 and ctx.needs_input_grad[1] else None)
+        if ctx.needs_input_grad[0]:   # the data gradient of this step convolves with the adjoint image: both from one launch
+            u, u_adjoint = sis_hip.conv3x3_prepack_both(weight)
+        else:
+            u, u_adjoint = sis_hip.conv3x3_prepack(weight), None
+        ctx.save_for_backward(input, weight, input_s if dilation > 1 and ctx.needs_input_grad[1] else None, u_adjoint)
         ctx.dilation = dilation
-        return _batch_to_space(sis_hip.conv3x3(input_s, sis_hip.conv3x3_prepack(weight)), dilation)
+        return _batch_to_space(sis_hip.conv3x3(input_s, u), dilation)
 
     @staticmethod
     def backward(ctx, grad_output):
-        input, weight, input_s = ctx.saved_tensors
+        input, weight, input_s, u_adjoint = ctx.saved_tensors
         grad_input, grad_weight = _Conv3x3Backward.apply(grad_output.contiguous(), input, weight, ctx.dilation,
-                                                         ctx.needs_input_grad[0], ctx.needs_input_grad[1], input_s)
+                                                         ctx.needs_input_grad[0], ctx.needs_input_grad[1], input_s, u_adjoint)
         return grad_input, grad_weight, None
 
 
@@ -89,13 +93,15 @@ class _Conv3x3Backward(Function):
     all three on the same Winograd kernels as the first-order pass."""
 
     @staticmethod
-    def forward(ctx, grad_output, input, weight, dilation, want_input, want_weight, input_s=None):
+    def forward(ctx, grad_output, input, weight, dilation, want_input, want_weight, input_s=None, u_adjoint=None):
         ctx.save_for_backward(grad_output, input, weight)
         ctx.dilation = dilation
         grad_output_s = _space_to_batch(grad_output, dilation)  # once, for both gradients
         grad_input = grad_weight = None
         if want_input:
-            grad_input = _batch_to_space(sis_hip.conv3x3(grad_output_s, sis_hip.conv3x3_prepack(weight, adjoint=True)), dilation)
+            if u_adjoint is None:
+                u_adjoint = sis_hip.conv3x3_prepack(weight, adjoint=True)
+            grad_input = _batch_to_space(sis_hip.conv3x3(grad_output_s, u_adjoint), dilation)
         if want_weight:
             grad_weight = _conv3x3_wgrad(input, grad_output, weight.shape, dilation, input_s, grad_output_s)
         return grad_input, grad_weight
@@ -117,7 +123,7 @@ class _Conv3x3Backward(Function):
             d_x = _conv3x3_dgrad(grad_output, gg_weight.contiguous(), d)
         if need_w and gg_input is not None:
             d_w = _conv3x3_wgrad(gg_input.contiguous(), grad_output, weight.shape, d)
-        return d_gy, d_x, d_w, None, None, None, None
+        return d_gy, d_x, d_w, None, None, None, None, None
 
 
 def gan_winograd_enabled():

@@ -44,6 +44,7 @@ _SIGNATURES = {
     "sis_modconv_prepack_wino": ([_vp, _vp, _i, _i, _vp], _i),
     "sis_last_kernel": ([], ctypes.c_char_p),
     "sis_conv3x3_prepack": ([_vp, _vp, _i, _i, _i, _vp], _i),
+    "sis_conv3x3_prepack_both": ([_vp, _vp, _vp, _i, _i, _vp], _i),
     "sis_conv3x3_eligible": ([_i] * 5, _i),
     "sis_upsample_bilinear": ([_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp], _i),
     "sis_upsample_bilinear_strided": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _i, _vp], _i),
@@ -371,6 +372,17 @@ def conv3x3_prepack(weight, adjoint=False):
     with torch.cuda.device(w.device):
         _check(lib().sis_conv3x3_prepack(_ptr(u), _ptr(w), cout, cin, int(bool(adjoint)), _stream()), "sis_conv3x3_prepack")
     return u
+
+
+def conv3x3_prepack_both(weight):
+    """(forward image, adjoint image) of ``conv3x3_prepack`` from one launch."""
+    w = _f32(weight, "weight")
+    cout, cin = w.shape[0], w.shape[1]
+    u = torch.empty((cin, 16, cout), dtype=torch.float32, device=w.device)
+    ua = torch.empty((cout, 16, cin), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _check(lib().sis_conv3x3_prepack_both(_ptr(u), _ptr(ua), _ptr(w), cout, cin, _stream()), "sis_conv3x3_prepack_both")
+    return u, ua
 
 
 def conv3x3(x, u):
