@@ -301,15 +301,19 @@ int sis_weight_std_bwd(float* dw, const void* grad_w_hat, const float* w, const 
  *      counters (may be NULL): B*groups ints, ZERO on entry and left zero, private to the stream -- the per-group merge
  *      of the plane statistics then runs inside the statistics launch (the workgroup that completes a group does it, in
  *      channel order) and d(gamma) / d(beta) inside the apply launch: 2 launches per direction instead of 3 / 4; same
- *      values either way. */
+ *      values either way.
+ *      relu_bits (may be NULL; fwd: with relu; sis_group_norm_gate_bytes bytes, 8-byte aligned): the forward leaves one bit per
+ *      element ([y > 0], bit i of a flat bit array) and the backward gates on it instead of y_mask -- the residual form's
+ *      backward then reads 1/8 byte instead of 4 per element and pass for the gate. */
 int64_t sis_group_norm_workspace_floats(int batch, int channels, int hw);
 int sis_group_norm_fwd(void* y, void* y_lp, float* mean, float* rstd, float* workspace, const void* x, const float* residual,
                        const float* gamma, const float* beta, int x_dtype, int y_dtype, int batch, int channels, int hw,
-                       int groups, float eps, int relu, int* counters, void* stream);
+                       int groups, float eps, int relu, int* counters, void* relu_bits, void* stream);
 int sis_group_norm_bwd(void* dx, float* dresidual, float* dgamma, float* dbeta, float* workspace, const void* grad_y,
                        const void* grad_y_lp, const void* x, const float* y_mask, const float* mean, const float* rstd, const float* gamma,
                        const float* beta, int x_dtype, int g_dtype, int batch, int channels, int hw, int groups, int relu,
-                       int* counters, void* stream);
+                       int* counters, const void* relu_bits, void* stream);
+int64_t sis_group_norm_gate_bytes(int batch, int channels, int hw);
 /* nn.BatchNorm2d in training mode (+ optional ReLU) with 16-bit or fp32 tensors -- the TransUNet decoder's Conv2dReLU
  * blocks (networks/trans_u_net/vit_seg_modeling.py:265-287).  Arguments as for group norm; statistics per channel over
  * (B, hw); mean / rstd [C]; running_mean / running_var (float32 [C], may both be NULL) are updated with `momentum`

@@ -179,12 +179,20 @@ __global__ __launch_bounds__(64) void gn_row_finish_kernel(float* __restrict__ m
     gn_row_finish(row, 0, 1, mean_out, rstd_out, ab, part, gamma, beta, groups, cpg, S, eps);
 }
 
+// ReLU gate of the residual form as ONE BIT per element (bit i of a flat bit array, element i of the flat tensor): the forward's
+// apply pass writes it, both backward passes read 1/8 byte instead of the 4-byte output per element (the residual norms' outputs
+// are the trunk's fp32 stream: block 1's are 132 MB each).
+__device__ __forceinline__ float gn_gate(const unsigned char* __restrict__ bits, int64_t idx) {   // 1 = open, 0 = closed
+    return (float)((bits[idx >> 3] >> (idx & 7)) & 1);
+}
+
 // y = relu?(x * a[plane] + b[plane] (+ residual)); VEC elements per lane.  FLAT: hw is not a multiple of VEC, a lane's
 // vector may straddle two planes (VEC <= hw: at most one boundary) and picks its coefficients per element.
 template <typename TI, typename TO, int VEC, bool FLAT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(TO* __restrict__ y, TI* __restrict__ y_lp, const TI* __restrict__ x,
                                                        const float* __restrict__ ab, const float* __restrict__ res, int hw,
-                                                       int64_t total, int relu) {
+                                                       int64_t total, int relu, unsigned char* __restrict__ bits) {
+    static_assert(VEC == 4 || VEC == 1, "the gate bits are assembled from wave ballots for these two widths");
     const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < total; i += stride) {
         const int64_t plane = i / hw;
@@ -205,6 +213,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(TO* __restrict__ y, TI* _
         }
         gn_store<VEC>(y + i, out);
         if (y_lp) gn_store<VEC>(y_lp + i, out);  // the same values rounded to the convolutions' dtype (what autocast would cast to)
+        if (bits) {   // (a wave's lanes hold consecutive vectors; lanes past the end are not in the ballots)
+            const int ln = threadIdx.x & 63;
+            if constexpr (VEC == 4) {
+                unsigned long long bal[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bal[e] = __ballot(out[e] > 0.f);
+                if ((ln & 1) == 0) {   // an even lane and its neighbour share a byte (i % 8 == 0 here)
+                    unsigned byte = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) byte |= (unsigned)((bal[e] >> ln) & 1ull) << e | (unsigned)((bal[e] >> (ln + 1)) & 1ull) << (4 + e);
+                    bits[i >> 3] = (unsigned char)byte;
+                }
+            } else {
+                const unsigned long long bal = __ballot(out[0] > 0.f);
+                if (ln == 0) *reinterpret_cast<unsigned long long*>(bits + (i >> 3)) = bal;   // 64 elements = 8 bytes (i % 64 == 0)
+            }
+        }
     }
 }
 
@@ -215,7 +240,8 @@ __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ p
                                                            const float* __restrict__ rstd_in, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ ymask, int C,
                                                            int cpg, int hw, int sl, int relu, int* __restrict__ counters,
-                                                           float* __restrict__ coef, float* __restrict__ psum) {
+                                                           float* __restrict__ coef, float* __restrict__ psum,
+                                                           const unsigned char* __restrict__ bits) {
     __shared__ float red[4];
     const int64_t plane = blockIdx.x;
     const int c = (int)(plane % C);
@@ -227,21 +253,27 @@ __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ p
     const float* pm = ymask ? ymask + plane * hw : nullptr;
     const int lo = blockIdx.y * sl, hi = min(hw, lo + sl);
     float sg = 0.f, sgx = 0.f;
+    const bool gated = pm || bits;   // the gate comes from the saved output (its sign) or from the forward's bit per element
+    const int64_t flat0 = plane * hw;
     auto one = [&](float xe, float ge, float me) {
         const float xh = (xe - mean) * rstd;
-        if (relu && (pm ? me <= 0.f : xh * gm + bt <= 0.f)) ge = 0.f;
+        if (relu && (gated ? me <= 0.f : xh * gm + bt <= 0.f)) ge = 0.f;
         sg += ge; sgx += ge * xh;
     };
     gn_span<VEC>(plane * hw, lo, hi, [&](int i) {
-        one(sis_ld(px, i), sis_ld(pg, i) + (pg2 ? sis_ld(pg2, i) : 0.f), pm ? pm[i] : 1.f);
+        one(sis_ld(px, i), sis_ld(pg, i) + (pg2 ? sis_ld(pg2, i) : 0.f), pm ? pm[i] : bits ? gn_gate(bits, flat0 + i) : 1.f);
     }, [&](int i) {
         float xv[VEC], gv[VEC], g2[VEC], mv[VEC];
         gn_load<VEC>(px + i, xv);
         gn_load<VEC>(pg + i, gv);
         if (pg2) gn_load<VEC>(pg2 + i, g2);
         if (pm) gn_load<VEC>(pm + i, mv);
+        else if (bits) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) one(xv[e], gv[e] + (pg2 ? g2[e] : 0.f), pm ? mv[e] : 1.f);
+            for (int e = 0; e < VEC; ++e) mv[e] = gn_gate(bits, flat0 + i + e);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) one(xv[e], gv[e] + (pg2 ? g2[e] : 0.f), gated ? mv[e] : 1.f);
     });
     sg = gn_block_sum(sg, red);
     sgx = gn_block_sum(sgx, red);
@@ -321,7 +353,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(TI* __restrict__ dx, 
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ ymask, float* __restrict__ dres, int C,
                                                            int cpg, int hw, int64_t total, int relu, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, const float* __restrict__ psum, int batch) {
+                                                           float* __restrict__ dbeta, const float* __restrict__ psum, int batch,
+                                                           const unsigned char* __restrict__ bits) {
     if (dgamma && blockIdx.x == 0)   // the plane sums are complete since the previous launch
         for (int c = threadIdx.x; c < C; c += 256) gn_param_reduce(c, dgamma, dbeta, psum, batch, C);
     struct PlaneCoef { float mean, rstd, gm, bt, k1, k2, k3; };
@@ -342,12 +375,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(TI* __restrict__ dx, 
         gn_load<VEC>(g + i, gv);
         if (g_lp) gn_load<VEC>(g_lp + i, g2);
         if (ymask) gn_load<VEC>(ymask + i, mv);
+        else if (bits) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) mv[e] = gn_gate(bits, i + e);
+        }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const PlaneCoef& p = (FLAT && rem + e >= hw) ? p1 : p0;
             const float xh = (xv[e] - p.mean) * p.rstd;
             float gi = gv[e] + (g_lp ? g2[e] : 0.f);
-            if (relu && (ymask ? mv[e] <= 0.f : xh * p.gm + p.bt <= 0.f)) gi = 0.f;
+            if (relu && ((ymask || bits) ? mv[e] <= 0.f : xh * p.gm + p.bt <= 0.f)) gi = 0.f;
             drv[e] = gi;  // gradient of the residual branch = masked incoming gradient
             dxv[e] = p.k1 * gi - p.k2 - p.k3 * xh;
         }
@@ -463,7 +500,7 @@ template <typename TI, typename TO, int NIT>
 __global__ __launch_bounds__(1024) void gn_group_fwd_kernel(TO* __restrict__ y, TI* __restrict__ y_lp, float* __restrict__ mean_out,
                                                             float* __restrict__ rstd_out, const TI* __restrict__ x,
                                                             const float* __restrict__ res, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, GnGroupArgs a) {
+                                                            const float* __restrict__ beta, GnGroupArgs a, unsigned char* __restrict__ bits) {
     __shared__ float red[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int row = blockIdx.x;
@@ -503,6 +540,12 @@ __global__ __launch_bounds__(1024) void gn_group_fwd_kernel(TO* __restrict__ y, 
         }
         gn_store8(y + base + off, out);
         if (y_lp) gn_store8(y_lp + base + off, out);
+        if (bits) {   // this lane's 8 elements are one byte of the gate bits
+            unsigned byte = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) byte |= (out[e] > 0.f ? 1u : 0u) << e;
+            bits[(base + off) >> 3] = (unsigned char)byte;
+        }
     }
 }
 
@@ -515,7 +558,8 @@ __global__ __launch_bounds__(1024) void gn_group_bwd_kernel(TI* __restrict__ dx,
                                                             const TI* __restrict__ g_lp, const TI* __restrict__ x,
                                                             const float* __restrict__ ymask, const float* __restrict__ mean_in,
                                                             const float* __restrict__ rstd_in, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, GnGroupArgs a, int batch) {
+                                                            const float* __restrict__ beta, GnGroupArgs a, int batch,
+                                                            const unsigned char* __restrict__ bits) {
     __shared__ float part[16 * NIT][2];   // per (wave, iteration): sum g', sum g' xhat -- all of one channel
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int row = blockIdx.x;
@@ -532,7 +576,15 @@ __global__ __launch_bounds__(1024) void gn_group_bwd_kernel(TI* __restrict__ dx,
         gn_load8(x + base + off, xv);
         gn_load8(g + base + off, gi[it]);
         if (HAS_LP) gn_load8(g_lp + base + off, g2);
-        if (HAS_MASK) gn_load8(ymask + base + off, mv);
+        if (HAS_MASK) {
+            if (bits) {
+                const unsigned byte = bits[(base + off) >> 3];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) mv[e] = (float)((byte >> e) & 1u);
+            } else {
+                gn_load8(ymask + base + off, mv);
+            }
+        }
         const float gm = gamma[c], bt = beta[c];
         float sg = 0.f, sgx = 0.f;
 #pragma unroll
@@ -631,19 +683,20 @@ void gn_launch_stats(float* part, const void* x, int64_t planes, int hw, hipStre
 template <typename TI, typename TG>
 void gn_launch_bwd_plane(float* part, const void* g, const void* g_lp, const void* x, const float* mean, const float* rstd, const float* gamma,
                          const float* beta, const float* ymask, int64_t planes, int C, int cpg, int hw, int relu, hipStream_t st,
-                         int* counters = nullptr, float* coef = nullptr, float* psum = nullptr) {
+                         int* counters = nullptr, float* coef = nullptr, float* psum = nullptr, const unsigned char* bits = nullptr) {
     const int S = gn_slices(hw), sl = gn_slice_len(hw);
     if (gn_aligned(x) && gn_aligned(g) && gn_aligned(g_lp) && gn_aligned(ymask))
         hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
-                           (const TI*)g_lp, (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu, counters, coef, psum);
+                           (const TI*)g_lp, (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu, counters, coef, psum, bits);
     else
         hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
-                           (const TI*)g_lp, (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu, counters, coef, psum);
+                           (const TI*)g_lp, (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu, counters, coef, psum, bits);
 }
 
 template <typename TI, typename TO>
 void gn_fwd_run(void* y, void* y_lp, float* mean, float* rstd, float* ws, const void* x, const float* res, const float* gamma,
-                const float* beta, int batch, int C, int hw, int groups, float eps, int relu, int* counters, hipStream_t st) {
+                const float* beta, int batch, int C, int hw, int groups, float eps, int relu, int* counters, unsigned char* bits,
+                hipStream_t st) {
     const int cpg = C / groups, rows = batch * groups;
     const int64_t planes = (int64_t)batch * C, total = planes * hw;
     const int S = gn_slices(hw);
@@ -654,7 +707,7 @@ void gn_fwd_run(void* y, void* y_lp, float* mean, float* rstd, float* ws, const 
         if (counters && gn_group_plan(cpg, hw, &nit, &nw) && gn_aligned(x) && gn_aligned(y) && gn_aligned(y_lp) && gn_aligned(res)) {
             const GnGroupArgs a{hw, cpg, groups, relu, eps};
 #define GN_GROUP_FWD(N) hipLaunchKernelGGL((gn_group_fwd_kernel<TI, TO, N>), dim3(rows), dim3(64 * nw), 0, st, (TO*)y, (TI*)y_lp, mean, \
-                                           rstd, (const TI*)x, res, gamma, beta, a)
+                                           rstd, (const TI*)x, res, gamma, beta, a, bits)
             if (nit == 1) GN_GROUP_FWD(1); else if (nit == 2) GN_GROUP_FWD(2); else GN_GROUP_FWD(4);
 #undef GN_GROUP_FWD
             return;
@@ -668,13 +721,14 @@ void gn_fwd_run(void* y, void* y_lp, float* mean, float* rstd, float* ws, const 
                            groups, cpg, S, eps);
     }
     GN_DISPATCH_APPLY(gn_apply_kernel, TI, TO, gn_aligned(x) && gn_aligned(y) && gn_aligned(y_lp) && gn_aligned(res), (TO*)y,
-                      (TI*)y_lp, (const TI*)x, ab, res, hw, total, relu);
+                      (TI*)y_lp, (const TI*)x, ab, res, hw, total, relu, bits);
 }
 
 template <typename TI, typename TG>
 void gn_bwd_run(void* dx, float* dres, float* dgamma, float* dbeta, float* ws, const void* g, const void* g_lp, const void* x,
                 const float* ymask, const float* mean, const float* rstd, const float* gamma, const float* beta, int batch, int C,
-                int hw, int groups, int relu, int* counters, hipStream_t st) {
+                int hw, int groups, int relu, int* counters, const unsigned char* bits, hipStream_t st) {
+    const bool gated = ymask || bits;   // the ReLU gate of the residual form: the saved output or the forward's bit per element
     const int cpg = C / groups, rows = batch * groups;
     const int64_t planes = (int64_t)batch * C, total = planes * hw;
     const int S = gn_slices(hw);
@@ -685,15 +739,15 @@ void gn_bwd_run(void* dx, float* dres, float* dgamma, float* dbeta, float* ws, c
     int nit, nw;
     if constexpr (sizeof(TI) == 2) {
         if (counters && gn_group_plan(cpg, hw, &nit, &nw) && gn_aligned(dx) && gn_aligned(g) && gn_aligned(g_lp) && gn_aligned(x) &&
-            gn_aligned(ymask) && gn_aligned(dres) && (dres == nullptr || ymask != nullptr)) {
+            gn_aligned(ymask) && gn_aligned(dres) && (dres == nullptr || gated)) {
             const GnGroupArgs a{hw, cpg, groups, relu, 0.f};
 #define GN_GROUP_BWD(N, LP, MK) hipLaunchKernelGGL((gn_group_bwd_kernel<TI, TG, N, LP, MK>), dim3(rows), dim3(64 * nw), 0, st, (TI*)dx, dres, \
                                                    dgamma, dbeta, psum, counters, (const TG*)g, (const TI*)g_lp, (const TI*)x, ymask, mean,  \
-                                                   rstd, gamma, beta, a, batch)
+                                                   rstd, gamma, beta, a, batch, bits)
 #define GN_GROUP_BWD_N(LP, MK) do { if (nit == 1) GN_GROUP_BWD(1, LP, MK); else if (nit == 2) GN_GROUP_BWD(2, LP, MK); else GN_GROUP_BWD(4, LP, MK); } while (0)
-            if (g_lp && ymask) GN_GROUP_BWD_N(true, true);
+            if (g_lp && gated) GN_GROUP_BWD_N(true, true);
             else if (g_lp) GN_GROUP_BWD_N(true, false);
-            else if (ymask) GN_GROUP_BWD_N(false, true);
+            else if (gated) GN_GROUP_BWD_N(false, true);
             else GN_GROUP_BWD_N(false, false);
 #undef GN_GROUP_BWD_N
 #undef GN_GROUP_BWD
@@ -701,16 +755,16 @@ void gn_bwd_run(void* dx, float* dres, float* dgamma, float* dbeta, float* ws, c
         }
     }
     if (counters) {
-        gn_launch_bwd_plane<TI, TG>(part, g, g_lp, x, mean, rstd, gamma, beta, ymask, planes, C, cpg, hw, relu, st, counters, coef, psum);
+        gn_launch_bwd_plane<TI, TG>(part, g, g_lp, x, mean, rstd, gamma, beta, ymask, planes, C, cpg, hw, relu, st, counters, coef, psum, bits);
     } else {
-        gn_launch_bwd_plane<TI, TG>(part, g, g_lp, x, mean, rstd, gamma, beta, ymask, planes, C, cpg, hw, relu, st);
+        gn_launch_bwd_plane<TI, TG>(part, g, g_lp, x, mean, rstd, gamma, beta, ymask, planes, C, cpg, hw, relu, st, nullptr, nullptr, nullptr, bits);
         hipLaunchKernelGGL(gn_bwd_row_kernel, dim3(sis_cdiv(rows, 64)), dim3(64), 0, st, coef, psum, part, rstd, gamma, rows, groups,
                            cpg, hw, S);
     }
     GN_DISPATCH_APPLY(gn_bwd_apply_kernel, TI, TG,
                       gn_aligned(dx) && gn_aligned(g) && gn_aligned(g_lp) && gn_aligned(x) && gn_aligned(ymask) && gn_aligned(dres),
                       (TI*)dx, (const TG*)g, (const TI*)g_lp, (const TI*)x, coef, mean, rstd, gamma, beta, ymask, dres, C, cpg, hw, total, relu,
-                      counters ? dgamma : no_param, dbeta, (const float*)psum, batch);
+                      counters ? dgamma : no_param, dbeta, (const float*)psum, batch, bits);
     if (!counters) hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(sis_cdiv(C, 256)), dim3(256), 0, st, dgamma, dbeta, psum, batch, C);
 }
 
@@ -726,7 +780,7 @@ void bn_fwd_run(void* y, float* mean, float* rstd, float* rm, float* rv, float* 
     hipLaunchKernelGGL(bn_chan_finish_kernel, dim3(sis_cdiv(C, 64)), dim3(64), 0, st, mean, rstd, ab, rm, rv, part, gamma, beta,
                        batch, C, S, eps, momentum);
     GN_DISPATCH_APPLY(gn_apply_kernel, TI, TO, gn_aligned(x) && gn_aligned(y), (TO*)y, (TI*)nullptr, (const TI*)x, ab, res, hw, total,
-                      relu);
+                      relu, (unsigned char*)nullptr);
 }
 
 template <typename TI, typename TG>
@@ -743,7 +797,7 @@ void bn_bwd_run(void* dx, float* dgamma, float* dbeta, float* ws, const void* g,
                        C, hw, S);
     GN_DISPATCH_APPLY(gn_bwd_apply_kernel, TI, TG, gn_aligned(dx) && gn_aligned(g) && gn_aligned(x), (TI*)dx, (const TG*)g,
                       (const TI*)nullptr, (const TI*)x, coef, mean, rstd, gamma, beta, none, no_dres, C, 0, hw, total, relu, no_dres, no_dres,
-                      none, batch);
+                      none, batch, (const unsigned char*)nullptr);
 }
 
 }  // namespace
@@ -755,9 +809,11 @@ extern "C" int64_t sis_group_norm_workspace_floats(int batch, int channels, int 
 extern "C" int sis_group_norm_fwd(void* y, void* y_lp, float* mean, float* rstd, float* workspace, const void* x,
                                   const float* residual,
                                   const float* gamma, const float* beta, int x_dtype, int y_dtype, int batch, int channels,
-                                  int hw, int groups, float eps, int relu, int* counters, void* stream) {
+                                  int hw, int groups, float eps, int relu, int* counters, void* relu_bits, void* stream) {
     if (batch == 0) return 0;
     SIS_REQUIRE(y && mean && rstd && workspace && x && gamma && beta, "sis_group_norm_fwd: null pointer");
+    SIS_REQUIRE(!relu_bits || (relu && (reinterpret_cast<uintptr_t>(relu_bits) & 7) == 0), "sis_group_norm_fwd: the gate bits go with a ReLU (8-byte aligned buffer)");
+    unsigned char* bits = (unsigned char*)relu_bits;
     SIS_REQUIRE(batch > 0 && channels > 0 && hw > 0 && groups > 0 && channels % groups == 0,
                 "sis_group_norm_fwd: bad sizes (C %d, groups %d)", channels, groups);
     SIS_REQUIRE(y_dtype == x_dtype || y_dtype == SIS_F32, "sis_group_norm_fwd: output dtype must be the input's or f32");
@@ -766,8 +822,8 @@ extern "C" int sis_group_norm_fwd(void* y, void* y_lp, float* mean, float* rstd,
                 "sis_group_norm_fwd: the 16-bit copy goes with a float32 output of a 16-bit input");
     hipStream_t st = (hipStream_t)stream;
 #define GN_FWD(TI)                                                                                                       \
-    if (y_dtype == SIS_F32) gn_fwd_run<TI, float>(y, y_lp, mean, rstd, workspace, x, residual, gamma, beta, batch, channels, hw, groups, eps, relu, counters, st); \
-    else gn_fwd_run<TI, TI>(y, nullptr, mean, rstd, workspace, x, nullptr, gamma, beta, batch, channels, hw, groups, eps, relu, counters, st);
+    if (y_dtype == SIS_F32) gn_fwd_run<TI, float>(y, y_lp, mean, rstd, workspace, x, residual, gamma, beta, batch, channels, hw, groups, eps, relu, counters, bits, st); \
+    else gn_fwd_run<TI, TI>(y, nullptr, mean, rstd, workspace, x, nullptr, gamma, beta, batch, channels, hw, groups, eps, relu, counters, bits, st);
     switch (x_dtype) {
         case SIS_F32: GN_FWD(float) break;
         case SIS_F16: GN_FWD(__half) break;
@@ -782,10 +838,12 @@ extern "C" int sis_group_norm_fwd(void* y, void* y_lp, float* mean, float* rstd,
 extern "C" int sis_group_norm_bwd(void* dx, float* dresidual, float* dgamma, float* dbeta, float* workspace, const void* grad_y,
                                   const void* grad_y_lp, const void* x, const float* y_mask, const float* mean, const float* rstd, const float* gamma,
                                   const float* beta, int x_dtype, int g_dtype, int batch, int channels, int hw, int groups,
-                                  int relu, int* counters, void* stream) {
+                                  int relu, int* counters, const void* relu_bits, void* stream) {
     if (batch == 0) return 0;
     SIS_REQUIRE(dx && dgamma && dbeta && workspace && grad_y && x && mean && rstd && gamma && beta,
                 "sis_group_norm_bwd: null pointer");
+    SIS_REQUIRE(!(relu_bits && y_mask), "sis_group_norm_bwd: the ReLU gate comes from y_mask OR from relu_bits");
+    const unsigned char* bits = (const unsigned char*)relu_bits;
     SIS_REQUIRE(batch > 0 && channels > 0 && hw > 0 && groups > 0 && channels % groups == 0,
                 "sis_group_norm_bwd: bad sizes (C %d, groups %d)", channels, groups);
     SIS_REQUIRE(g_dtype == x_dtype || g_dtype == SIS_F32, "sis_group_norm_bwd: gradient dtype must be the input's or f32");
@@ -793,8 +851,8 @@ extern "C" int sis_group_norm_bwd(void* dx, float* dresidual, float* dgamma, flo
                 "sis_group_norm_bwd: the 16-bit gradient goes with a float32 gradient of a 16-bit input");
     hipStream_t st = (hipStream_t)stream;
 #define GN_BWD(TI)                                                                                                        \
-    if (g_dtype == SIS_F32) gn_bwd_run<TI, float>(dx, dresidual, dgamma, dbeta, workspace, grad_y, grad_y_lp, x, y_mask, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, counters, st); \
-    else gn_bwd_run<TI, TI>(dx, dresidual, dgamma, dbeta, workspace, grad_y, nullptr, x, y_mask, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, counters, st);
+    if (g_dtype == SIS_F32) gn_bwd_run<TI, float>(dx, dresidual, dgamma, dbeta, workspace, grad_y, grad_y_lp, x, y_mask, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, counters, bits, st); \
+    else gn_bwd_run<TI, TI>(dx, dresidual, dgamma, dbeta, workspace, grad_y, nullptr, x, y_mask, mean, rstd, gamma, beta, batch, channels, hw, groups, relu, counters, bits, st);
     switch (x_dtype) {
         case SIS_F32: GN_BWD(float) break;
         case SIS_F16: GN_BWD(__half) break;
@@ -853,4 +911,9 @@ extern "C" int sis_batch_norm_bwd(void* dx, float* dgamma, float* dbeta, float* 
 #undef BN_BWD
     SIS_CHECK_LAUNCH("bn_bwd");
     return 0;
+}
+
+/* bytes of the one-bit-per-element ReLU gate of sis_group_norm_fwd / _bwd (relu_bits), padded to whole 8-byte words */
+extern "C" int64_t sis_group_norm_gate_bytes(int batch, int channels, int hw) {
+    return (((int64_t)batch * channels * hw + 63) / 64) * 8;
 }

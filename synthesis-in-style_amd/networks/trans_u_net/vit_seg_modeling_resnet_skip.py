@@ -64,6 +64,7 @@ class _BankStandardize(Function):
         return (None,) + tuple(ctx.bank.backward(grads))
 
 
+_GN_GATE_BITS = os.environ.get('SIS_GN_GATE_BITS', '1') != '0'   # 0: the residual norms' backward gates on the saved fp32 output (A/B runs)
 _WS_BANK = os.environ.get('SIS_WS_BANK', '1') != '0'   # 0: every StdConv2d standardises and packs its own weight (A/B runs)
 _FUSE_RESIDUAL = os.environ.get('SIS_GN_RES', '1') != '0'
 _DUAL_STREAM = os.environ.get('SIS_GN_DUAL', '1') != '0'  # bottlenecks hand (fp32 residual stream, 16-bit copy) to the next one
@@ -72,22 +73,25 @@ _DUAL_STREAM = os.environ.get('SIS_GN_DUAL', '1') != '0'  # bottlenecks hand (fp
 class _GroupNormAct(Function):
     @staticmethod
     def forward(ctx, x, residual, weight, bias, groups, eps, relu, out_dtype, dual):
-        out = sis_hip.group_norm_fwd(x, weight, bias, groups, eps, relu, out_dtype, residual, low_precision_copy=dual)
-        y, mean, rstd = out[:3]
         ctx.has_residual = residual is not None
-        ctx.save_for_backward(x, mean, rstd, weight, bias, y if ctx.has_residual else None)
+        # residual form: the backward gates on [y > 0] -- one bit per element written by the forward instead of the fp32 output
+        want_gate = ctx.has_residual and relu and _GN_GATE_BITS
+        out = sis_hip.group_norm_fwd(x, weight, bias, groups, eps, relu, out_dtype, residual, low_precision_copy=dual, want_gate=want_gate)
+        y, mean, rstd = out[:3]
+        gate = out[-1] if want_gate else None
+        ctx.save_for_backward(x, mean, rstd, weight, bias, y if (ctx.has_residual and gate is None) else None, gate)
         ctx.groups, ctx.relu = groups, relu
         ctx.set_materialize_grads(False)  # an unused output of the pair arrives as None, not as a tensor of zeros
         return (y, out[3]) if dual else y
 
     @staticmethod
     def backward(ctx, grad, grad_lp=None):
-        x, mean, rstd, weight, bias, y = ctx.saved_tensors
+        x, mean, rstd, weight, bias, y, gate = ctx.saved_tensors
         if grad is None:  # only the 16-bit copy was used downstream
             grad, grad_lp = grad_lp, None
         if ctx.has_residual:
             dx, dgamma, dbeta, dres = sis_hip.group_norm_bwd(grad, x, mean, rstd, weight, bias, ctx.groups, ctx.relu, y_mask=y,
-                                                             want_residual_grad=True, grad_y_lp=grad_lp)
+                                                             want_residual_grad=True, grad_y_lp=grad_lp, gate=gate)
         else:
             (dx, dgamma, dbeta), dres = sis_hip.group_norm_bwd(grad, x, mean, rstd, weight, bias, ctx.groups, ctx.relu,
                                                                grad_y_lp=grad_lp), None

@@ -66,11 +66,12 @@ _SIGNATURES = {
     "sis_layer_norm_fwd": ([_vp] * 6 + [_i, _i, _i, _i, _f, _vp], _i),
     "sis_layer_norm_bwd": ([_vp] * 9 + [_i, _i, _i, _i, _vp], _i),
     "sis_weight_std_fwd": ([_vp, _vp, _vp, _i, _i, _i, _f, _vp], _i),
-    "sis_group_norm_fwd": ([_vp] * 9 + [_i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp], _i),
+    "sis_group_norm_fwd": ([_vp] * 9 + [_i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp], _i),
+    "sis_group_norm_gate_bytes": ([_i, _i, _i], _i64),
     "sis_group_norm_workspace_floats": ([_i, _i, _i], _i64),
     "sis_batch_norm_fwd": ([_vp] * 9 + [_i] * 5 + [_f, _f, _i, _vp], _i),
     "sis_batch_norm_bwd": ([_vp] * 10 + [_i] * 6 + [_vp], _i),
-    "sis_group_norm_bwd": ([_vp] * 13 + [_i] * 7 + [_vp, _vp], _i),
+    "sis_group_norm_bwd": ([_vp] * 13 + [_i] * 7 + [_vp, _vp, _vp], _i),
     "sis_weight_std_bwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp], _i),
     "sis_conv3x3_wgrad_eligible": ([_i] * 5 + [_i64], _i),
     "sis_conv3x3_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
@@ -1173,11 +1174,12 @@ def _group_counters(device, n):
     return buf
 
 
-def group_norm_fwd(x, gamma, beta, groups, eps, relu, out_dtype=None, residual=None, low_precision_copy=False):
+def group_norm_fwd(x, gamma, beta, groups, eps, relu, out_dtype=None, residual=None, low_precision_copy=False, want_gate=False):
     """x [B,C,...] (f32 / f16 / bf16) -> (y in ``out_dtype`` (default: x's), mean [B*groups], rstd [B*groups]).
     ``residual`` (float32, x's shape) is added before the ReLU; the output is then float32.
     ``low_precision_copy`` (16-bit x, float32 y): also returns y rounded to x's dtype, written in the same pass
-    -> (y, mean, rstd, y_lp)."""
+    -> (y, mean, rstd, y_lp).  ``want_gate`` (with relu): one more result, the ReLU gate [y > 0] as one bit per element (uint8
+    tensor) that ``group_norm_bwd(..., gate=...)`` reads instead of the saved output."""
     require_device(x, "input")
     x = x.contiguous()
     if residual is not None:
@@ -1195,16 +1197,18 @@ def group_norm_fwd(x, gamma, beta, groups, eps, relu, out_dtype=None, residual=N
     mean = torch.empty(b * groups, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
     ws = torch.empty(lib().sis_group_norm_workspace_floats(b, c, hw), dtype=torch.float32, device=x.device)
+    gate = torch.empty(lib().sis_group_norm_gate_bytes(b, c, hw), dtype=torch.uint8, device=x.device) if (want_gate and relu) else None
     with torch.cuda.device(x.device):
         _check(lib().sis_group_norm_fwd(_ptr(y), _ptr(y_lp), _ptr(mean), _ptr(rstd), _ptr(ws), _ptr(x), _ptr(residual),
                                         _ptr(_f32(gamma, "weight")), _ptr(_f32(beta, "bias")), _DTYPE_CODE[x.dtype],
                                         _DTYPE_CODE[out_dtype], b, c, hw, groups, float(eps), int(bool(relu)),
-                                        _ptr(_group_counters(x.device, b * groups)), _stream()),
+                                        _ptr(_group_counters(x.device, b * groups)), _ptr(gate), _stream()),
                "sis_group_norm_fwd")
-    return (y, mean, rstd, y_lp) if low_precision_copy else (y, mean, rstd)
+    out = (y, mean, rstd, y_lp) if low_precision_copy else (y, mean, rstd)
+    return out + (gate,) if want_gate else out
 
 
-def group_norm_bwd(grad_y, x, mean, rstd, gamma, beta, groups, relu, y_mask=None, want_residual_grad=False, grad_y_lp=None):
+def group_norm_bwd(grad_y, x, mean, rstd, gamma, beta, groups, relu, y_mask=None, want_residual_grad=False, grad_y_lp=None, gate=None):
     """-> (dx, dgamma, dbeta[, dresidual]).  ``y_mask``: the saved float32 output when a residual was added (its sign is
     the ReLU mask); ``want_residual_grad`` also returns the gradient of the residual branch; ``grad_y_lp`` (x's 16-bit
     dtype): the gradient that came back through the low-precision copy of the output, added to ``grad_y`` (float32) on load."""
@@ -1227,7 +1231,7 @@ def group_norm_bwd(grad_y, x, mean, rstd, gamma, beta, groups, relu, y_mask=None
         _check(lib().sis_group_norm_bwd(_ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _ptr(g), _ptr(grad_y_lp), _ptr(x),
                                         _ptr(y_mask), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _DTYPE_CODE[x.dtype],
                                         _DTYPE_CODE[g.dtype], b, c, hw, groups, int(bool(relu)),
-                                        _ptr(_group_counters(x.device, b * groups)), _stream()), "sis_group_norm_bwd")
+                                        _ptr(_group_counters(x.device, b * groups)), _ptr(gate), _stream()), "sis_group_norm_bwd")
     return (dx, dgamma, dbeta, dres) if want_residual_grad else (dx, dgamma, dbeta)
 
 

@@ -201,6 +201,14 @@ def test_group_norm_single_pass_groups(device, shape, groups, residual, monkeypa
 
     got = run()
     assert all(torch.equal(u, v) for u, v in zip(got, run()))   # repeatable, counters left at zero
+    if residual:   # gate bits instead of the saved output: same values
+        y, mean, rstd, y_lp, gate = sis_hip.group_norm_fwd(x, gamma, beta, groups, 1e-6, True, residual=res, low_precision_copy=True,
+                                                           want_gate=True)
+        bits = ((gate.cpu().numpy()[:, None] >> np.arange(8)) & 1).reshape(-1)[:y.numel()]
+        assert torch.equal(y, got[0]) and np.array_equal(bits.astype(bool), (y > 0).cpu().numpy().reshape(-1))
+        via = sis_hip.group_norm_bwd(gy, x, mean, rstd, gamma, beta, groups, True, want_residual_grad=True, grad_y_lp=g_lp, gate=gate)
+        for u, v in zip(via, (got[3], got[4], got[5], got[6])):
+            assert torch.equal(u, v)
     monkeypatch.setattr(sis_hip, "_GN_FUSED_FINISH", False)     # no counters: the two-launch kernels
     two = run()
     monkeypatch.setattr(sis_hip, "_GN_FUSED_FINISH", True)
@@ -280,6 +288,14 @@ def test_group_norm_residual_relu(device, shape):
     np.testing.assert_allclose(dx.float().cpu().numpy(), xr.grad.float().cpu().numpy(), rtol=2e-2, atol=1e-2 * scale)
     np.testing.assert_allclose(dg.cpu().numpy(), gr.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(db.cpu().numpy(), br.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-3)
+    # the ReLU gate as one bit per element written by the forward: bitwise the backward that reads the saved output's sign
+    y3, _, _, gate = sis_hip.group_norm_fwd(x, gamma, beta, groups, 1e-6, True, residual=res, want_gate=True)
+    assert torch.equal(y3, y) and gate.dtype == torch.uint8
+    bits = ((gate.cpu().numpy()[:, None] >> np.arange(8)) & 1).reshape(-1)[:y.numel()]
+    assert np.array_equal(bits.astype(bool), (y > 0).cpu().numpy().reshape(-1))
+    via_bits = sis_hip.group_norm_bwd(gy, x, mean, rstd, gamma, beta, groups, True, want_residual_grad=True, gate=gate)
+    for u, v in zip(via_bits, (dx, dg, db, dres)):
+        assert torch.equal(u, v)
     # dual output: the same pass also writes y rounded to x's dtype; the gradient arriving through that copy is added on load
     y2, _, _, y_lp = sis_hip.group_norm_fwd(x, gamma, beta, groups, 1e-6, True, residual=res, low_precision_copy=True)
     assert torch.equal(y2, y) and y_lp.dtype == x.dtype and torch.equal(y_lp, y.to(x.dtype))
