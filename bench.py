@@ -161,6 +161,88 @@ def cpu_baseline_training(workload, config):
                       f"{batch_size}, fp32, {threads} torch threads, median of 3 iterations after 1 warm-up ({sec:.2f} s)"}
 
 
+def _graph_expected(updater):
+    """The updater was built to replay its iteration as a hipGraph (single process, or a capturable gradient exchange)."""
+    graph = getattr(updater, "_step_graph", None)
+    return graph is not None and graph.requested
+
+
+def library_time(updater):
+    """Device time of ONE training iteration split into this library's kernels and everything else (ATen / MIOpen / hipBLASLt /
+    runtime copies), from the kernel records of torch.profiler (roctracer) around one more ``update()`` -- a graph replay when
+    the step is captured.  A kernel counts as own when its name contains a ``__global__`` function of csrc/*.hip
+    (sis_hip.own_kernel_names).  None when the profiler delivers no device records on this box."""
+    import sis_hip
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return {"skipped": "running under rocprofv3 (two tracers in one process); see profiles/ for the external breakdown"}
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+            updater.update()
+            torch.cuda.synchronize()
+        own_us = lib_us = 0.0
+        lib_names = {}
+        n = 0
+        for ev in prof.events():
+            if getattr(ev, "device_type", None) is None or "cuda" not in str(ev.device_type).lower():
+                continue
+            dur = float(getattr(ev, "device_time_total", 0.0) or getattr(ev, "cuda_time_total", 0.0) or 0.0)
+            if dur <= 0.0:
+                continue
+            n += 1
+            if sis_hip.is_own_kernel(ev.name):
+                own_us += dur
+            else:
+                lib_us += dur
+                lib_names[ev.name[:60]] = lib_names.get(ev.name[:60], 0.0) + dur
+        if n == 0:
+            return None
+        top = sorted(lib_names.items(), key=lambda kv: -kv[1])[:6]
+        return {"own_ms": round(own_us / 1e3, 3), "library_ms": round(lib_us / 1e3, 3), "device_records": n,
+                "top_library_kernels_ms": {k: round(v / 1e3, 3) for k, v in top}}
+    except Exception as err:   # the measurement must never take the bench line down
+        return {"error": repr(err)}
+
+
+def data_parallel_rehearsal(args, workload, config, device):
+    """What the N > 1 per-GPU step looks like, as far as ONE GPU can show it: the same training step with the network inside
+    the data-parallel wrap over a world-size-1 RCCL communicator (bucketed reduce-scatter + all-gather on RCCL's stream,
+    FusedSGD on the bucket views), once replayed as a hipGraph (collectives captured) and once eager.  No scaling claim: one
+    rank exchanges nothing; it shows that the path runs on RCCL and what the wrap costs per step."""
+    import gc
+    import torch.distributed as dist
+    from training_builder.train_builder_selection import get_train_builder_class
+    from utils.synthetic_data import SyntheticSegmentationLoader
+    if not dist.is_initialized():
+        return None
+    out = {"backend": dist.get_backend(), "world": dist.get_world_size(), "flavour": config.get("data_parallel", "buckets")}
+    for mode, hip_graph in (("graph", True), ("eager", False)):
+        gc.collect()
+        torch.cuda.empty_cache()
+        cfg = dict(config, force_data_parallel=True, hip_graph=hip_graph)
+        loader = SyntheticSegmentationLoader(cfg["batch_size"], cfg["image_size"], cfg["num_classes"], seed=1234, device=device)
+        torch.manual_seed(0)
+        builder = get_train_builder_class(cfg)(cfg, loader, None, rank=device.index, world_size=1)
+        updater = builder.get_updater()
+        if hip_graph:
+            updater._step_graph.strict = True
+        for _ in range(max(args.warmup, 4)):
+            updater.update()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            updater.update()
+        torch.cuda.synchronize()
+        out[f"{mode}_ms_per_step"] = round((time.perf_counter() - t0) / args.steps * 1e3, 3)
+        net = builder.get_network()
+        out["buckets"] = len(net.buckets or [])
+        out["collective"] = net.collective
+        if hip_graph:
+            out["hip_graph"] = updater._step_graph.graph is not None
+        del updater, builder, net
+    return out
+
+
 def bench_training(args, workload, world, rank, device, distributed):
     """Segmentation training images/s (BASELINE.json configs[3] / [4]): one step = one updater iteration
     (forward, loss, backward with bucketed RCCL all-reduce, fused SGD step) on a synthetic batch resident in HBM."""
@@ -184,6 +266,9 @@ def bench_training(args, workload, world, rank, device, distributed):
     torch.manual_seed(0)
     builder = get_train_builder_class(config)(config, loader, None, rank=device.index, world_size=world)
     updater = builder.get_updater()
+    graph = getattr(updater, "_step_graph", None)
+    if graph is not None and world == 1:
+        graph.strict = True   # a capture that fails must fail the bench, not pass as an eager measurement
 
     def fence():
         if distributed:
@@ -196,12 +281,14 @@ def bench_training(args, workload, world, rank, device, distributed):
     warmup = max(args.warmup, 4)  # two eager iterations, the capture, one replay before the clock starts
     updater.update()
     records = []
+    sis_hip.library_calls(reset=True)
     sis_hip.set_profiler(records)
     try:
         updater.update()
         torch.cuda.synchronize()
     finally:
         sis_hip.set_profiler(None)
+    library_calls = sis_hip.library_calls(reset=True)   # one whole iteration: what was handed to ATen / MIOpen / hipBLASLt
     own = {}
     for name, flops, nbytes, e0, e1 in records:
         a = own.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
@@ -220,6 +307,20 @@ def bench_training(args, workload, world, rank, device, distributed):
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    hip_graph = bool(graph is not None and graph.graph is not None)
+    if graph is not None and graph.requested and not hip_graph and world == 1 and _graph_expected(updater):
+        raise SystemExit(f"bench.py: the {workload} step was to be replayed as a hipGraph and was not captured "
+                         f"({graph.capture_error}); refusing to report an eager measurement as the graphed one")
+    baseline_config = not args.batch and ((workload == "emanet" and not config.get("amp")) or
+                                          (workload == "transunet" and config.get("amp") == "bf16"))
+    if baseline_config and library_calls["fallback"]:
+        raise SystemExit(f"bench.py: {workload} handed operators to the ROCm libraries that the BASELINE config is supposed to "
+                         f"run on libsis_hip.so: {library_calls['fallback']}")
+    library = library_time(updater) if rank == 0 else None
+    dp = None
+    if world == 1 and rank == 0 and args.dp_rehearsal:
+        del updater, builder
+        dp = data_parallel_rehearsal(args, workload, config, device)
     if rank != 0:
         return None
     images = config["batch_size"] * args.steps * world
@@ -233,7 +334,12 @@ def bench_training(args, workload, world, rank, device, distributed):
     step_s = elapsed / args.steps
     peak = PEAK_MFMA_BF16_TFLOPS if config.get("amp") else PEAK_MFMA_F32_TFLOPS
     nominal_tf, executed_tf = step_flops / step_s / 1e12, executed_flops / step_s / 1e12
-    dom = max(own, key=lambda k: own[k]["ms"]) if own else None
+    matrix = {k: v for k, v in own.items() if v["flops"]}
+    dom = max(matrix, key=lambda k: matrix[k]["ms"]) if matrix else None
+    traffic, traffic_src = measured_traffic(dom, workload) if dom else (None, None)
+
+    def kernel_peak(name):   # fp32 kernels (Winograd, fp32 1x1) inside an AMP step are priced against the fp32 peak
+        return PEAK_MFMA_F32_TFLOPS if ("wino" in name or "f32" in name or not config.get("amp")) else PEAK_MFMA_BF16_TFLOPS
     return {
         "metric": METRIC, "value": round(images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
@@ -241,21 +347,26 @@ def bench_training(args, workload, world, rank, device, distributed):
         "config": {"workload": f"{config['network']} training step, {config['image_size']}x{config['image_size']}, batch "
                                f"{config['batch_size']} per GPU (BASELINE.json configs[{3 if workload == 'emanet' else 4}])",
                    "batch_per_gpu": config["batch_size"], "image_size": config["image_size"],
-                   "parallelism": f"dp{world}, DDP bucketed all-reduce over RCCL",
-                   "hip_graph": bool(getattr(updater, "_step_graph", None) and updater._step_graph.graph is not None),
+                   "parallelism": f"dp{world}, bucketed reduce-scatter + all-gather over RCCL (training/grad_exchange.py)",
+                   "hip_graph": hip_graph, "graph_capture_error": None if graph is None else graph.capture_error,
                    "miopen_search": bool(config.get("miopen_search"))},
+        "library_calls_per_step": library_calls, "library_ms_per_step": library,
+        "data_parallel_rehearsal": dp,
         "roofline": {"kernel": "whole training step (forward, loss, backward, SGD)", "bound": "mfma",
                      "achieved": round(executed_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(executed_tf / peak, 4),
                      "note": "achieved / frac = EXECUTED matrix FLOPs of the hand-written kernels (recorded per launch; Winograd "
                              "launches at 16/36 of their direct-form count; library remainder excluded) / step time; "
                              "algorithmic_* use the nominal 2*MAC count of SURVEY.md 8(d)",
                      "algorithmic_tflops": round(nominal_tf, 2), "algorithmic_frac": round(nominal_tf / peak, 4),
-                     "flops_per_step_nominal": step_flops, "flops_per_step_executed": executed_flops, "traffic": None,
+                     "flops_per_step_nominal": step_flops, "flops_per_step_executed": executed_flops,
+                     "traffic": traffic, "traffic_unit": "HBM-side bytes per launch of dominant_own_kernel (PMC FETCH_SIZE x 2 + "
+                                                        "WRITE_SIZE, separate passes)", "traffic_source": traffic_src,
                      "dominant_own_kernel": dom,
                      "own_kernels_eager_iteration": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                                          "nominal_tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] else None,
                                                          "frac_of_peak": round(v["flops"] * (16.0 / 36.0 if "wino" in k else 1.0)
-                                                                               / (v["ms"] * 1e-3) / 1e12 / peak, 4) if v["ms"] else None}
+                                                                               / (v["ms"] * 1e-3) / 1e12 / kernel_peak(k), 4)
+                                                         if (v["ms"] and v["flops"]) else None}
                                                      for k, v in sorted(own.items(), key=lambda kv: -kv[1]["ms"])}},
         "cpu_baseline": None if (world > 1 or args.no_cpu_baseline) else cpu_baseline_training(workload, config),
     }
@@ -315,7 +426,7 @@ def bench_dataset(args, world, rank, device, distributed):
                 "frac": round(90.24e9 * images / elapsed / 1e12 / world / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None}}
 
 
-def measured_traffic(kernel):
+def measured_traffic(kernel, workload=None):
     """HBM bytes per launch of ``kernel`` from the committed PMC passes (profiles/*traffic*.json, written by
     tools/pmc_traffic.sh on the GPU box: counters cannot be collected from inside the timed process)."""
     import glob
@@ -324,7 +435,8 @@ def measured_traffic(kernel):
         return None, None
     with open(files[-1]) as f:
         data = json.load(f)
-    hits = [(v.get("launches", 0), v["traffic_bytes"]) for name, v in data.get("kernels", {}).items()
+    table = data.get("kernels", {}) if workload is None else data.get("training", {}).get(workload, {})
+    hits = [(v.get("launches", 0), v["traffic_bytes"]) for name, v in table.items()
             if name == kernel or name.startswith(kernel.rstrip(">") + ",") or name.startswith(kernel + "<")]
     if not hits:
         return None, None
@@ -498,18 +610,15 @@ def bench_synthesis(args, world, rank, device, distributed):
 
 def launch_ranks(n):
     """One child process group of ``n`` ranks through ``python -m torch.distributed.run`` (one rank per GPU, rendezvous on
-    127.0.0.1 at a free port), this script and its arguments unchanged.  The parent never initialises the GPU; the children's
+    127.0.0.1, port chosen by the launcher), this script and its arguments unchanged.  The parent never initialises the GPU; the children's
     stdout / stderr pass straight through (rank 0 prints the one JSON line).  Returns the launcher's exit code."""
-    import socket
     import subprocess
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher binds its own rendezvous port (no pick-then-release race, ADVICE r3)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
 
 
@@ -524,6 +633,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="training workloads: override the config's amp")
+    ap.add_argument("--no-dp-rehearsal", dest="dp_rehearsal", action="store_false",
+                    help="training workloads at N = 1: skip the data-parallel rehearsal over a world-size-1 RCCL communicator")
     ap.add_argument("--miopen-search", action="store_true",
                     help="training workloads: MIOpen solver search for the library convolutions (minutes at start-up)")
     args = ap.parse_args()
@@ -556,6 +667,18 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+    elif args.dp_rehearsal and args.workload in ("all", "emanet", "transunet"):
+        # N = 1: a one-rank RCCL communicator for the data-parallel rehearsal of the training workloads (bench_training)
+        import socket
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        try:
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
+        except Exception as err:   # no RCCL on this box: the rehearsal is skipped, the N = 1 measurements do not need it
+            print(f"bench.py: RCCL world-size-1 communicator unavailable ({err!r}); data-parallel rehearsal skipped", file=sys.stderr)
 
     if args.workload == "dataset":
         result = bench_dataset(args, world, rank, device, distributed)
@@ -574,21 +697,33 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             seg = {}
-            for key, workload, dtype in (("emanet", "emanet", "f32"), ("transunet_bf16", "transunet", "bf16")):
+            # (transunet_f32: SURVEY.md 8(d) config 5 asks for "bf16 and an fp32 parity run" -- the reference's own precision,
+            # fewer timed steps, no CPU baseline of its own: the oracle step is the bf16 entry's baseline too)
+            for key, workload, dtype in (("emanet", "emanet", "f32"), ("transunet_bf16", "transunet", "bf16"),
+                                         ("transunet_f32", "transunet", "f32")):
                 sub_args = copy.copy(args)
                 sub_args.batch, sub_args.dtype, sub_args.miopen_search = 0, dtype, False
+                if key == "transunet_f32":
+                    sub_args.steps, sub_args.no_cpu_baseline, sub_args.dp_rehearsal = max(4, args.steps // 2), True, False
                 sub = bench_training(sub_args, workload, world, rank, device, distributed)
                 gc.collect()
                 torch.cuda.empty_cache()
                 if sub is not None:
                     seg[key] = {"images_per_s": sub["value"], "ms_per_step": sub["ms_per_step"], "steps": sub["steps"],
                                 "warmup": sub["warmup"], "dtype": sub["dtype"], "scaling": sub["scaling"],
-                                "config": sub["config"], "roofline": sub["roofline"], "cpu_baseline": sub["cpu_baseline"]}
+                                "config": sub["config"], "roofline": sub["roofline"], "cpu_baseline": sub["cpu_baseline"],
+                                "library_calls_per_step": sub["library_calls_per_step"],
+                                "library_ms_per_step": sub["library_ms_per_step"],
+                                "data_parallel_rehearsal": sub["data_parallel_rehearsal"]}
             if result is not None:
                 result["seg_train"] = seg
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    else:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
     if result is not None:
         print(json.dumps(result))
 

@@ -472,6 +472,7 @@ extern "C" int sis_bn_act_bwd(float* dx, float* dresidual, float* dgamma, float*
         else SIS_BN_FBWD(false, false);
 #undef SIS_BN_FBWD
         SIS_CHECK_LAUNCH("bn_fused_bwd_kernel");
+        sis_kernel_name = "bn_fused_bwd_kernel";
         return 0;
     }
     if (relu)
@@ -495,6 +496,7 @@ extern "C" int sis_bn_act_bwd(float* dx, float* dresidual, float* dgamma, float*
     else SIS_BN_BWD(false, false);
 #undef SIS_BN_BWD
     SIS_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    sis_kernel_name = "bn_bwd_reduce_kernel+bn_bwd_apply_kernel";
     return 0;
 }
 
@@ -524,5 +526,6 @@ extern "C" int sis_bn_fused_fwd(float* y, float* mean, float* invstd, float* run
     else SIS_BN_FFWD(false, false);
 #undef SIS_BN_FFWD
     SIS_CHECK_LAUNCH("bn_fused_fwd_kernel");
+    sis_kernel_name = "bn_fused_fwd_kernel";
     return 0;
 }

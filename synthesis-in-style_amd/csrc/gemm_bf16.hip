@@ -567,8 +567,12 @@ static int gemm_impl(void* c, void* c2, const void* a, const void* b, int layout
     p.m_tiles = sis_cdiv(m, bm); p.n_tiles = sis_cdiv(n, bn);
     const int ksteps = sis_cdiv(k, bk);
     if (splits > ksteps && !batch_k) splits = 1;
+    // every slice must own at least one K step: with ceil(ksteps / splits) steps per slice the last slices can come out empty
+    // (8 slices of 13 steps: 7 x 2 covers them), so the count steps down through the values the workgroup order supports
+    // (multiples of 8, then 4, 2, 1) until none is -- any token count is a valid contraction length
+    while (!batch_k && splits > 1 && (int64_t)(splits - 1) * sis_cdiv(ksteps, splits) >= ksteps)
+        splits = splits > 8 ? splits - 8 : splits / 2;
     p.ksteps_per_split = sis_cdiv(ksteps, splits);
-    SIS_REQUIRE((splits - 1) * p.ksteps_per_split < ksteps, "sis_gemm_bf16: %d splits leave an empty slice of %d K steps", splits, ksteps);
     p.splits = splits; p.slab_stride = (long long)m * ldc;
     p.batch_k = batch_k; p.grid_batches = batches; p.a_bstride = a_bstride; p.b_bstride = b_bstride; p.c_bstride = c_bstride;
     if (batch_k) {   // one slice per batch entry, each over the whole K

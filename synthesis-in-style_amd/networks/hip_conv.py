@@ -153,6 +153,7 @@ class _Pointwise(Function):
         ctx.has_bias = bias is not None
         if _F32_POINTWISE and sis_hip.conv1x1_f32_supported(input, weight):
             return sis_hip.conv1x1_f32(input, weight, bias)  # fp32 MFMA kernel, csrc/conv1x1_f32.hip
+        sis_hip.library_call("hip_conv._Pointwise.forward")
         return F.conv2d(input, weight, bias)
 
     @staticmethod
@@ -166,6 +167,7 @@ class _Pointwise(Function):
             if _F32_POINTWISE and sis_hip.conv1x1_f32_supported(grad_output, weight):
                 grad_input = sis_hip.conv1x1_f32(grad_output, weight, data_gradient=True)
             else:
+                sis_hip.library_call("hip_conv._Pointwise.dgrad")
                 grad_input = torch.ops.aten.convolution_backward(grad_output, input, weight, None, (1, 1), (0, 0), (1, 1), False,
                                                                  (0, 0), 1, (True, False, False))[0]
         g = grad_output.view(b, cout, h * w)
@@ -173,6 +175,7 @@ class _Pointwise(Function):
             if _F32_POINTWISE and sis_hip.conv1x1_wgrad_f32_supported(grad_output, input):
                 grad_weight = sis_hip.conv1x1_wgrad_f32(grad_output, input)  # csrc/conv1x1_wgrad_f32.hip
             else:
+                sis_hip.library_call("hip_conv._Pointwise.wgrad")
                 grad_weight = torch.bmm(g, input.view(b, cin, h * w).transpose(1, 2)).sum(0).view(cout, cin, 1, 1)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = g.sum((0, 2))
@@ -208,6 +211,7 @@ class _PointwiseWithSkip(Function):
             if sis_hip.conv1x1_wgrad_f32_supported(grad_output, input):
                 grad_weight = sis_hip.conv1x1_wgrad_f32(grad_output, input)
             else:
+                sis_hip.library_call("hip_conv._PointwiseWithSkip.wgrad")
                 b, cin, h, w = input.shape
                 cout = weight.shape[0]
                 grad_weight = torch.bmm(grad_output.view(b, cout, h * w), input.view(b, cin, h * w).transpose(1, 2)).sum(0).view(cout, cin, 1, 1)
@@ -347,6 +351,7 @@ class _ConvBf16Function(Function):
                     adjoint = sis_hip.conv_bf16_pack(weight, h, w, 1, adjoint=True)
                 grad_input = sis_hip.conv_bf16(gy, adjoint, cin, k, 1)
             else:
+                sis_hip.library_call("hip_conv._ConvBf16Function.dgrad", intended=(cin <= 4))
                 lib_weight = weight if weight.dtype == torch.bfloat16 else weight.bfloat16()
                 grad_input = torch.ops.aten.convolution_backward(gy, input, lib_weight, None, (s, s), (k // 2, k // 2), (1, 1), False,
                                                                  (0, 0), 1, (True, False, False))[0]
@@ -356,9 +361,11 @@ class _ConvBf16Function(Function):
             elif k == 1 and s == 1 and _PW_WGRAD_OWN and sis_hip.conv1x1_bf16_wgrad_supported(b, cin, cout, h * w):
                 grad_weight = sis_hip.conv1x1_bf16_wgrad(input, gy, weight.dtype)   # csrc/conv_bf16_wgrad.hip, any plane size
             elif k == 1 and s == 1:
+                sis_hip.library_call("hip_conv._ConvBf16Function.wgrad_1x1")
                 grad_weight = torch.bmm(gy.view(b, cout, h * w), input.view(b, cin, h * w).transpose(1, 2)).sum(0, dtype=torch.float32)
                 grad_weight = grad_weight.view(cout, cin, 1, 1)
             else:
+                sis_hip.library_call("hip_conv._ConvBf16Function.wgrad", intended=(cin <= 4))
                 if lib_weight is None:
                     lib_weight = weight if weight.dtype == torch.bfloat16 else weight.bfloat16()
                 grad_weight = torch.ops.aten.convolution_backward(gy, input, lib_weight, None, (s, s), (k // 2, k // 2), (1, 1), False,
@@ -442,4 +449,6 @@ class HipConv2d(nn.Conv2d):
             return conv3x3_half_image_dilation(input, self.weight)
         if self._eligible(input):
             return conv3x3(input, self.weight, self.dilation[0])
+        if input.is_cuda:   # the 3-channel stems are the documented library layers; anything else is a fallback
+            sis_hip.library_call("hip_conv.HipConv2d.forward", intended=(self.in_channels <= 4))
         return super().forward(input)

@@ -38,6 +38,7 @@ def max_pool2d(input, kernel_size, stride=None, padding=0):
     if (input.is_cuda and input.dim() == 4 and input.dtype in (torch.float32, torch.float16, torch.bfloat16)
             and None not in (k, s, p) and 1 <= k <= 15 and 2 * p <= k and input.shape[2] + 2 * p >= k and input.shape[3] + 2 * p >= k):
         return _MaxPool2d.apply(input, k, s, p)
+    sis_hip.library_call("hip_pool.max_pool2d")
     return F.max_pool2d(input, kernel_size, stride, padding)
 
 

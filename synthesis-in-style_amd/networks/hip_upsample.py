@@ -75,6 +75,7 @@ class HipUpsamplingBilinear2d(nn.Module):
         oh, ow = self._out_size(input)
         if input.is_cuda and input.dim() == 4 and input.dtype in (torch.float32, torch.float16, torch.bfloat16):
             return _UpsampleBilinear.apply(input, oh, ow)
+        sis_hip.library_call("hip_upsample.HipUpsamplingBilinear2d")
         return F.interpolate(input, size=(oh, ow), mode='bilinear', align_corners=True)
 
     def extra_repr(self):

@@ -2,8 +2,13 @@
 transformer blocks, final LayerNorm.  Class names, constructor signatures and parameter names follow
 /root/reference/stylegan_code_finder/networks/trans_u_net/vit_seg_modeling.py:53-262 so checkpoints line up.
 
-Attention runs through ``scaled_dot_product_attention`` (no [B,12,N,N] score tensor in HBM; the reference's attention
-dropout rate is 0.0, so it is the same function) unless attention maps are requested (``vis``).
+Product path (HIP device, bf16 autocast, ``SIS_FUSED_VIT=1``): every transformer block is ONE autograd function,
+``_FusedBlockFn`` below -- own bf16 GEMMs with fused bias / GELU / dropout / residual epilogues (csrc/gemm_bf16.hip), own
+fused attention (csrc/attention_bf16.hip: online softmax, no [B,12,N,N] score tensor in HBM; the reference's attention
+dropout rate is 0.0, so it is the same function), own LayerNorm.  The module-by-module forward further down
+(``Attention.forward`` with ``F.scaled_dot_product_attention`` / ``torch.matmul``, ``Mlp.forward``) is what runs when the
+fused block declines -- fp32 (no autocast), ``vis`` attention maps, CPU tensors -- and every such use on a HIP device is
+counted by ``sis_hip.library_call`` (bench.py reports the counter and fails on it for the bf16 BASELINE config).
 """
 import copy
 import math
@@ -175,6 +180,8 @@ def linear(x, weight, bias):
             and x.dtype == torch.get_autocast_dtype('cuda') and weight.dtype == torch.float32 and weight.shape[0] % 4 == 0
             and x.is_contiguous()):
         return _AmpLinearFn.apply(x, weight, bias)
+    if x.is_cuda:
+        sis_hip.library_call("vit_encoder.linear")
     return F.linear(x, weight, bias)
 
 
@@ -189,6 +196,8 @@ class LayerNorm(nn.LayerNorm):
             out_dtype = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else x.dtype
             if out_dtype in (torch.float32, torch.bfloat16):
                 return _LayerNormFn.apply(x, self.weight, self.bias, self.eps, out_dtype)
+        if x.is_cuda:
+            sis_hip.library_call("vit_encoder.LayerNorm")
         return super().forward(x)
 
 
@@ -248,6 +257,8 @@ class Attention(nn.Module):
                          torch.cat([self.query.bias, self.key.bias, self.value.bias], 0))
         q, k, v = (self.transpose_for_scores(t) for t in qkv.split(self.all_head_size, dim=-1))
         weights = None
+        if hidden_states.is_cuda:
+            sis_hip.library_call("vit_encoder.Attention (module-by-module block)")
         if self.vis or (self.training and self.attn_dropout.p > 0):
             scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(self.attention_head_size)
             probs = self.softmax(scores)

@@ -114,6 +114,8 @@ class HipGroupNorm(nn.GroupNorm):
             out_dtype = torch.float32 if (keep_fp32 or residual is not None) else x.dtype
             dual = bool(dual) and out_dtype == torch.float32 and x.dtype != torch.float32
             return _GroupNormAct.apply(x, residual, self.weight, self.bias, self.num_groups, self.eps, relu, out_dtype, dual)
+        if x.is_cuda:
+            sis_hip.library_call("vit_seg_modeling_resnet_skip.HipGroupNorm")
         y = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
         if residual is not None:
             y = y + residual
@@ -149,6 +151,8 @@ class StdConv2d(nn.Conv2d):
         if (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.groups == 1
                 and x.is_cuda and x.dim() == 4 and x.is_contiguous() and x.dtype == w.dtype):
             return _Pointwise.apply(x, w, self.bias)  # weight gradient as a batched GEMM on the NCHW tensors
+        if x.is_cuda:   # the 7x7 stride-2 root on the 3-channel image is the documented library layer
+            sis_hip.library_call("vit_seg_modeling_resnet_skip.StdConv2d.forward", intended=(self.in_channels <= 4))
         return F.conv2d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
 

@@ -10,6 +10,7 @@ passes ``data_ptr()`` and the current HIP stream, and returns freshly allocated 
 the ownership rules of the reference extension (outputs owned by the caller, inputs borrowed and
 made contiguous, kernels enqueued on the current stream, no host sync).
 """
+import collections
 import ctypes
 import os
 
@@ -163,6 +164,57 @@ def _launch(kernel, flops, nbytes, call):
         kernel = lib().sis_last_kernel().decode()
     _prof.append((kernel, flops, nbytes, e0, e1))
     return rc
+
+
+# ---- audit of what does NOT run on this library: every place in the product that hands an operator to
+# ATen / MIOpen / hipBLASLt calls ``library_call(site)``.  ``intended=True`` marks the documented exceptions (the two 3-channel
+# stems); everything else is a shape the kernels declined and must stay at zero on the BASELINE configs --
+# bench.py reports both counters and fails on a non-zero fallback count.
+LIBRARY_CALLS = collections.Counter()
+_LIBRARY_STRICT = os.environ.get("SIS_NO_LIBRARY_FALLBACK", "0") == "1"
+
+
+def library_call(site, intended=False):
+    LIBRARY_CALLS[("intended:" if intended else "fallback:") + site] += 1
+    if _LIBRARY_STRICT and not intended:
+        raise RuntimeError(f"SIS_NO_LIBRARY_FALLBACK=1: {site} fell back to the ROCm libraries")
+
+
+def library_calls(reset=False):
+    """{"intended": {site: n}, "fallback": {site: n}} since the last reset."""
+    out = {"intended": {}, "fallback": {}}
+    for key, n in LIBRARY_CALLS.items():
+        kind, site = key.split(":", 1)
+        out[kind][site] = n
+    if reset:
+        LIBRARY_CALLS.clear()
+    return out
+
+
+_own_kernels = None
+
+
+def own_kernel_names():
+    """Names of every ``__global__`` function of csrc/*.hip (the library's own device symbols), for classifying profiler
+    records into own / vendor-library kernels."""
+    global _own_kernels
+    if _own_kernels is None:
+        import glob
+        import re
+        names = set()
+        for path in glob.glob(os.path.join(os.path.dirname(_HERE), "csrc", "*.hip")):
+            with open(path) as f:
+                text = f.read()
+            for m in re.finditer(r"__global__\s+(?:__launch_bounds__\s*\([^)]*\)\s*)?(?:static\s+)?void\s+"
+                                 r"(?:__launch_bounds__\s*\([^)]*\)\s*)?([A-Za-z_]\w*)\s*\(", text):
+                names.add(m.group(1))
+        _own_kernels = frozenset(names)
+    return _own_kernels
+
+
+def is_own_kernel(profiler_name):
+    import re
+    return any(tok in own_kernel_names() for tok in re.findall(r"[A-Za-z_][A-Za-z0-9_]*", profiler_name))
 
 
 def _check(rc, name):
@@ -1469,9 +1521,10 @@ def bn_fused_fwd(x, residual, gamma, beta, running_mean, running_var, eps, momen
     invstd = torch.empty(c, dtype=torch.float32, device=x.device)
     mask = torch.empty(lib().sis_bn_mask_words(b, c, h * w), dtype=torch.int64, device=x.device) if (want_mask and relu) else None
     with torch.cuda.device(x.device):
-        _check(lib().sis_bn_fused_fwd(_ptr(y), _ptr(mean), _ptr(invstd), _ptr(running_mean), _ptr(running_var), _ptr(x), _ptr(residual),
-                                      _ptr(gamma), _ptr(beta), b, c, h * w, float(eps), float(momentum), int(bool(relu)), _ptr(mask),
-                                      _stream()), "sis_bn_fused_fwd")
+        _check(_launch("bn_fused_fwd_kernel", 0.0, 4.0 * (2 + (residual is not None)) * x.numel(), lambda: lib().sis_bn_fused_fwd(
+            _ptr(y), _ptr(mean), _ptr(invstd), _ptr(running_mean), _ptr(running_var), _ptr(x), _ptr(residual),
+            _ptr(gamma), _ptr(beta), b, c, h * w, float(eps), float(momentum), int(bool(relu)), _ptr(mask),
+            _stream())), "sis_bn_fused_fwd")
     return y, mean, invstd, mask
 
 
@@ -1496,7 +1549,9 @@ def bn_act_bwd(dy, y, x, mean, invstd, gamma, relu, want_residual_grad, mask=Non
     dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
     ws = torch.empty(lib().sis_bn_workspace_floats(b, c, h * w), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(lib().sis_bn_act_bwd(_ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(dy), _ptr(y), _ptr(x), _ptr(mean),
-                                    _ptr(invstd), _ptr(gamma), _ptr(ws), b, c, h * w, int(bool(relu)), _ptr(mask), _stream()),
+        # (kernel name reported by the library: bn_fused_bwd_kernel where a channel fits one workgroup, else the three-launch form)
+        _check(_launch(None, 0.0, 4.0 * (3 + want_residual_grad) * x.numel(), lambda: lib().sis_bn_act_bwd(
+            _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(dy), _ptr(y), _ptr(x), _ptr(mean),
+            _ptr(invstd), _ptr(gamma), _ptr(ws), b, c, h * w, int(bool(relu)), _ptr(mask), _stream())),
                "sis_bn_act_bwd")
     return dx, dres, dgamma, dbeta

@@ -1,0 +1,238 @@
+"""Data-parallel gradient exchange for the segmentation training step: bucketed reduce-scatter + all-gather (or one
+all-reduce) over RCCL on a side stream, overlapped with backward, capturable inside the step's hipGraph.
+
+Role in the reference: ``DistributedDataParallel(network, device_ids=[rank], find_unused_parameters=...,
+broadcast_buffers=False)`` (training_builder/base_train_builder.py:40-43), whose C++ reducer all-reduces gradient buckets
+while backward runs.  torch's reducer stays available (``data_parallel: ddp`` in the config); this module is the default
+because three things of the MI355X step do not fit it:
+
+* **the whole iteration is one hipGraph** (training/graph_step.py).  DDP's reducer rebuilds its buckets on the second
+  iteration, copies a used-parameter bitmap to the host when ``find_unused_parameters`` is set (EMANet needs it:
+  ``emau.conv1`` never receives a gradient) and wants eleven eager iterations before a capture.  Here the bucket plan is
+  fixed after ONE discovery backward (the parameters that received a gradient, in the order they became ready: unused
+  parameters simply never appear, their ``.grad`` stays ``None`` and the optimizer skips them as ``torch.optim.SGD`` does),
+  every later backward issues the same launches in the same order, and the collectives are ordinary stream work that the
+  capture records like any kernel.
+* **gradients must sit at fixed addresses**: ``FusedSGD`` (training/fused_sgd.py) reads them through a device pointer
+  table.  Buckets are persistent flat fp32 buffers; when the last gradient of a bucket has been accumulated ONE fused copy
+  (``torch._foreach_copy_``) gathers the bucket and ``.grad`` is re-pointed at the bucket views, so the table is uploaded
+  once.
+* **xGMI is point-to-point** (7 links per GPU): by default a bucket is reduced as ``reduce_scatter`` (every
+  rank owns 1/N of the bucket) followed by ``all_gather``, each on the bucket's own slice of the flat buffer (in place);
+  ``collective: allreduce`` issues one ``all_reduce`` instead.  Averaging is the collective's own ``AVG`` on RCCL; gloo
+  (CPU rehearsals) sums and scales.
+
+Semantics kept from the reference wrap: parameters are broadcast from rank 0 at construction, buffers are NOT synchronised
+(``broadcast_buffers=False``: batch-norm statistics and EMANet's ``emau.mu`` stay per rank), gradients are the mean over
+ranks, ``.module`` is the wrapped network.
+"""
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+class _Bucket:
+    __slots__ = ("params", "views", "flat", "numel", "pending", "index")
+
+    def __init__(self, index: int, params: List[torch.Tensor], world: int, device, dtype):
+        self.index, self.params = index, params
+        numel = sum(p.numel() for p in params)
+        quantum = 4 * world                       # every rank's shard of the flat buffer starts 16-byte aligned
+        self.numel = (numel + quantum - 1) // quantum * quantum
+        self.flat = torch.zeros(self.numel, dtype=dtype, device=device)
+        self.views, at = [], 0
+        for p in params:
+            self.views.append(self.flat[at:at + p.numel()].view_as(p))
+            at += p.numel()
+        self.pending = len(params)
+
+
+class BucketedDataParallel(nn.Module):
+    """``BucketedDataParallel(network)``: same call surface as the wrapped network; gradients of every backward are averaged
+    over the process group's ranks before ``backward()`` returns (stream-ordered on a HIP device)."""
+
+    def __init__(self, module: nn.Module, process_group=None, bucket_cap_mb: float = 25.0, collective: Optional[str] = None):
+        super().__init__()
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("BucketedDataParallel needs an initialised torch.distributed process group")
+        self.module = module
+        self.process_group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        self.backend = dist.get_backend(process_group)
+        self.collective = collective or os.environ.get("SIS_GRAD_COLLECTIVE", "rs_ag")
+        if self.collective not in ("rs_ag", "allreduce"):
+            raise ValueError("collective must be 'rs_ag' (reduce-scatter + all-gather) or 'allreduce'")
+        self.bucket_bytes = int(bucket_cap_mb * (1 << 20))
+        self._params = [p for p in module.parameters() if p.requires_grad]
+        if not self._params:
+            raise RuntimeError("BucketedDataParallel: the network has no parameter that requires a gradient")
+        self.device = self._params[0].device
+        self._on_gpu = self.device.type == "cuda"
+        if self._on_gpu and self.backend == "gloo":
+            # gloo stages device tensors through the host and synchronises: correct (one-GPU rehearsals), never capturable
+            pass
+        self._comm_stream = torch.cuda.Stream(self.device) if self._on_gpu else None
+        self.buckets: Optional[List[_Bucket]] = None
+        self._bucket_of = {}
+        self._order: List[torch.Tensor] = []      # discovery: parameters in the order their gradients became ready
+        self._callback_queued = False
+        self._flushed = 0
+        self.stats = {"backwards": 0, "collectives": 0, "discovery_backwards": 0}
+        self._broadcast_parameters()
+        for p in self._params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    # ---- construction ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _broadcast_parameters(self):
+        """Rank 0's parameters everywhere (what DDP's constructor does); buffers stay as each rank made them."""
+        if self.world == 1:
+            return
+        chunk, size = [], 0
+        def send(tensors):
+            flat = torch.cat([t.detach().reshape(-1) for t in tensors])
+            dist.broadcast(flat, src=dist.get_global_rank(self.process_group, 0) if self.process_group is not None else 0,
+                           group=self.process_group)
+            at = 0
+            for t in tensors:
+                t.detach().copy_(flat[at:at + t.numel()].view_as(t))
+                at += t.numel()
+        for p in self.module.parameters():
+            if chunk and (p.dtype != chunk[0].dtype or size + p.numel() * p.element_size() > (64 << 20)):
+                send(chunk)
+                chunk, size = [], 0
+            chunk.append(p)
+            size += p.numel() * p.element_size()
+        if chunk:
+            send(chunk)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    # ---- backward ----------------------------------------------------------------------------------------------------
+    def _on_grad(self, param):
+        if not self._callback_queued:
+            # runs once the engine has finished THIS backward (the mechanism DDP's reducer and FSDP use)
+            torch.autograd.Variable._execution_engine.queue_callback(self._finish)
+            self._callback_queued = True
+        if self.buckets is None:
+            self._order.append(param)
+            return
+        bucket = self._bucket_of.get(id(param))
+        if bucket is None:
+            raise RuntimeError("BucketedDataParallel: a parameter that had no gradient in the first backward received one now; "
+                               "the bucket plan is fixed after the first iteration (rebuild the wrapper)")
+        bucket.pending -= 1
+        if bucket.pending == 0:
+            self._flush(bucket)
+
+    @torch.no_grad()
+    def _gather(self, bucket: _Bucket):
+        """Gradients of the bucket -> its flat buffer (one fused copy for those autograd allocated afresh), ``.grad`` -> views."""
+        src, dst = [], []
+        for p, view in zip(bucket.params, bucket.views):
+            g = p.grad
+            if g is None:
+                raise RuntimeError("BucketedDataParallel: a bucket was flushed before all of its gradients existed")
+            if g.data_ptr() != view.data_ptr():
+                src.append(g if g.dtype == view.dtype and g.is_contiguous() else g.to(view.dtype).contiguous())
+                dst.append(view)
+        if src:
+            torch._foreach_copy_(dst, src)
+            for p, view in zip(bucket.params, bucket.views):
+                p.grad = view
+
+    @torch.no_grad()
+    def _reduce(self, bucket: _Bucket):
+        flat, world = bucket.flat, self.world
+        self.stats["collectives"] += 1
+        if self.backend == "nccl":
+            avg = dist.ReduceOp.AVG
+            if self.collective == "rs_ag":
+                shard = flat[self.rank * (bucket.numel // world):(self.rank + 1) * (bucket.numel // world)]
+                dist.reduce_scatter_tensor(shard, flat, op=avg, group=self.process_group)
+                dist.all_gather_into_tensor(flat, shard, group=self.process_group)
+            else:
+                dist.all_reduce(flat, op=avg, group=self.process_group)
+        else:   # gloo: no AVG, no reduce_scatter_tensor
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
+            flat.mul_(1.0 / world)
+
+    def _flush(self, bucket: _Bucket):
+        self._gather(bucket)
+        if self._on_gpu:
+            current = torch.cuda.current_stream(self.device)
+            self._comm_stream.wait_stream(current)          # the gathered bucket is complete on the compute stream
+            with torch.cuda.stream(self._comm_stream):
+                self._reduce(bucket)                        # backward keeps running on the compute stream meanwhile
+        else:
+            self._reduce(bucket)
+        self._flushed += 1
+
+    @torch.no_grad()
+    def _finish(self):
+        """End of a backward: discovery -> fix the plan and reduce everything now; otherwise join the side stream."""
+        self._callback_queued = False
+        self.stats["backwards"] += 1
+        if self.buckets is None:
+            self.stats["discovery_backwards"] += 1
+            self._plan()
+            for bucket in self.buckets:
+                self._flush(bucket)
+        elif self._flushed != len(self.buckets):
+            missing = [b.index for b in self.buckets if b.pending != 0]
+            self._reset()
+            raise RuntimeError(f"BucketedDataParallel: buckets {missing} did not receive all of their gradients in this backward "
+                               "(a parameter used in the first iteration was unused now)")
+        if self._on_gpu:
+            torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)   # optimizer.step() reads the buckets
+        self._reset()
+
+    def _reset(self):
+        self._flushed = 0
+        if self.buckets is not None:
+            for b in self.buckets:
+                b.pending = len(b.params)
+
+    def _plan(self):
+        """Buckets of <= bucket_cap_mb in readiness order (the first bucket is the first to be complete in every later
+        backward).  Every rank runs the same graph, hence builds the same plan; checked by comparing a digest."""
+        seen, order = set(), []
+        for p in self._order:
+            if id(p) not in seen:
+                seen.add(id(p))
+                order.append(p)
+        self._order = []
+        if not order:
+            raise RuntimeError("BucketedDataParallel: backward produced no parameter gradient")
+        groups, cur, size = [], [], 0
+        for p in order:
+            nbytes = p.numel() * 4
+            if cur and size + nbytes > self.bucket_bytes:
+                groups.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nbytes
+        groups.append(cur)
+        self.buckets = [_Bucket(i, g, self.world, self.device, torch.float32) for i, g in enumerate(groups)]
+        self._bucket_of = {id(p): b for b in self.buckets for p in b.params}
+        if self.world > 1:
+            digest = torch.tensor([len(self.buckets), sum(b.numel for b in self.buckets), len(order)], dtype=torch.int64,
+                                  device=self.device if self.backend == "nccl" else "cpu")
+            lo, hi = digest.clone(), digest.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.process_group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.process_group)
+            if not torch.equal(lo, hi):
+                raise RuntimeError("BucketedDataParallel: ranks disagree on the bucket plan (different graphs per rank)")
+
+    # ---- introspection (tests, bench) --------------------------------------------------------------------------------
+    def bucket_spans(self):
+        return [(b.flat.data_ptr(), b.flat.data_ptr() + 4 * b.numel) for b in (self.buckets or [])]
+
+    def capturable(self) -> bool:
+        """The step hipGraph may include this exchange: RCCL collectives are stream work; gloo synchronises on the host."""
+        return self._on_gpu and self.backend == "nccl"

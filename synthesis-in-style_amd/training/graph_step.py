@@ -8,7 +8,13 @@ high-water mark, momentum buffers), then captures ONE iteration -- forward, loss
 graph's static inputs, refreshes the optimizer's device-side hyper-parameters (the LR schedule keeps running on the
 host) and launches the graph.
 
-Used only for single-process training: under DistributedDataParallel the bucketed all-reduce hooks are left eager.
+Data parallel: the bucketed gradient exchange of training/grad_exchange.py is stream work (RCCL collectives on a side
+stream forked from and joined to the step's stream), so the captured iteration contains it; its bucket plan is fixed in
+the first eager iteration, the second one rehearses the bucketed path, the third is captured.  torch's
+DistributedDataParallel flavour stays eager (its reducer synchronises with the host).
+
+A capture that fails leaves the step eager with a warning and ``capture_error`` set; ``strict=True`` (bench.py) or
+SIS_STEP_GRAPH_STRICT=1 re-raises instead, so that a silent regression to the eager path cannot pass as a measurement.
 """
 import os
 from typing import Callable, Dict, Iterable
@@ -17,9 +23,12 @@ import torch
 
 
 class StepGraph:
-    def __init__(self, warmup: int = 2, enabled: bool = True):
+    def __init__(self, warmup: int = 2, enabled: bool = True, strict: bool = False):
         self.warmup = max(int(warmup), 1)  # FusedSGD needs one eager step before capture
-        self.enabled = enabled and os.environ.get("SIS_STEP_GRAPH", "1") != "0"
+        self.requested = enabled and os.environ.get("SIS_STEP_GRAPH", "1") != "0"
+        self.enabled = self.requested
+        self.strict = strict or os.environ.get("SIS_STEP_GRAPH_STRICT", "0") == "1"
+        self.capture_error = None
         self.graph = None
         self.static_batch = None
         self.static_out = None
@@ -40,6 +49,9 @@ class StepGraph:
                 # No captured kernel has executed.  What _capture() did before the failure is harmless for an eager
                 # step: push_hyper() only refreshed the device copy of the hyper-parameters, and the gradients it set to
                 # None are re-created by the step's own zero_grad() / backward.
+                self.capture_error = repr(err)
+                if self.strict:
+                    raise
                 import warnings
                 warnings.warn(f"hipGraph capture of the training step failed ({err!r}); continuing eagerly")
                 self.enabled, self.graph = False, None

@@ -8,12 +8,15 @@ method names the reference's ``train.py`` calls (``get_updater``, ``get_optimize
 ``get_network``, ``get_evaluator``, ``get_image_plotter``) are kept.
 
 Multi-GPU: one process per GPU, ``torch.distributed`` backend "nccl" (= RCCL over xGMI on ROCm).  The wrap keeps the
-reference's semantics -- ``broadcast_buffers=False`` (batch-norm statistics and EMANet's ``emau.mu`` stay per-rank),
-``find_unused_parameters`` as the concrete builder declares -- and adds what suits the fabric: 25 MB buckets
-reduced while backward is still producing earlier layers' gradients (an EMANet-50 step has 139 MB of fp32
-gradients: ~6 buckets, each ~0.3 ms on one 153 GB/s xGMI link, hidden under >= 20 ms of backward) and
-``gradient_as_bucket_view=True``: gradients live in the buckets, no copy in or out, stable storage for the fused
-optimizer's pointer table.
+reference's semantics -- parameters broadcast from rank 0, ``broadcast_buffers=False`` (batch-norm statistics and EMANet's
+``emau.mu`` stay per-rank), parameters without a gradient tolerated where the concrete builder declares
+``find_unused_params`` -- and adds what suits the fabric: 25 MB buckets reduced while backward is still producing earlier
+layers' gradients (an EMANet-50 step has 139 MB of fp32 gradients: ~6 buckets, each ~0.3 ms on one 153 GB/s xGMI link,
+hidden under >= 20 ms of backward), gradients that LIVE in the buckets (stable storage for the fused optimizer's pointer
+table).  Two implementations, ``data_parallel`` in the config: ``buckets`` (default; training/grad_exchange.py: reduce-scatter
++ all-gather per bucket on a side stream, plan fixed after one backward, capturable in the step's hipGraph) and ``ddp``
+(torch's DistributedDataParallel with ``gradient_as_bucket_view=True``; eager only).  ``force_data_parallel: true`` wraps
+even a single rank (world_size 1 over RCCL: the rehearsal a one-GPU box allows).
 
 Reference quirk not reproduced: its ``get_optimizers()`` constructs a NEW optimizer on every call, so the LR
 scheduler built in train.py:39-56 schedules an optimizer that never trains.  Here the optimizer is created once.
@@ -25,10 +28,11 @@ import torch
 from torch.nn.parallel import DistributedDataParallel as DDP
 
 from training.fused_sgd import FusedSGD
+from training.grad_exchange import BucketedDataParallel
 
 
 def strip_parallel_module(network):
-    return network.module if isinstance(network, DDP) else network
+    return network.module if isinstance(network, (DDP, BucketedDataParallel)) else network
 
 
 def load_weights(network, checkpoint_path, key='segmentation_network', strict=True):
@@ -96,12 +100,19 @@ class BaseTrainBuilder:
         network.to(device)
         if self.fine_tune is not None:
             load_weights(network, self.fine_tune, key=network_name)
-        if self.world_size > 1:
-            kwargs = dict(find_unused_parameters=self.find_unused_params, broadcast_buffers=False,
-                          bucket_cap_mb=self.config.get('bucket_cap_mb', 25), gradient_as_bucket_view=True)
-            if device.type == 'cuda':
-                kwargs.update(device_ids=[device.index], output_device=device.index)
-            network = DDP(network, **kwargs)
+        if self.world_size > 1 or self.config.get('force_data_parallel'):
+            flavour = self.config.get('data_parallel', 'buckets')
+            if flavour == 'buckets':
+                network = BucketedDataParallel(network, bucket_cap_mb=self.config.get('bucket_cap_mb', 25),
+                                               collective=self.config.get('collective'))
+            elif flavour == 'ddp':
+                kwargs = dict(find_unused_parameters=self.find_unused_params, broadcast_buffers=False,
+                              bucket_cap_mb=self.config.get('bucket_cap_mb', 25), gradient_as_bucket_view=True)
+                if device.type == 'cuda':
+                    kwargs.update(device_ids=[device.index], output_device=device.index)
+                network = DDP(network, **kwargs)
+            else:
+                raise ValueError(f"data_parallel: '{flavour}' (buckets | ddp)")
         return network
 
     def get_network(self):

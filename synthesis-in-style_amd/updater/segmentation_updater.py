@@ -9,9 +9,10 @@ Mirrors updater/segmentation_updater.py:42-106 of the reference: same class name
 
 MI355X specifics: the bases update is one HIP kernel (``sis_ema_update``), the EMANet loss tail is fused inside
 the network (networks/ema_net/network.py), the optimizer step is the one-launch ``FusedSGD`` the builders
-create, gradients are all-reduced by DistributedDataParallel over RCCL while backward is still running.
-Single-process training replays the whole iteration as a hipGraph after two eager iterations
-(training/graph_step.py; keyword ``hip_graph=False`` or SIS_STEP_GRAPH=0 keeps it eager).
+create, gradients are averaged over the ranks bucket by bucket over RCCL while backward is still running
+(training/grad_exchange.py, or torch's DistributedDataParallel).  The whole iteration -- collectives included -- is replayed
+as a hipGraph after two eager iterations (training/graph_step.py; keyword ``hip_graph=False`` or SIS_STEP_GRAPH=0 keeps it
+eager, as does the DistributedDataParallel flavour).
 """
 import os
 
@@ -20,6 +21,7 @@ from torch import nn
 
 import sis_hip
 from networks.trans_u_net.utils import DiceLoss
+from training.grad_exchange import BucketedDataParallel
 from training.graph_step import StepGraph
 from training.loop import GradientApplier, Updater, get_current_reporter
 
@@ -33,8 +35,11 @@ def _unwrap(network):
 
 
 def _graphable(network, optimizer, device):
-    """Whole-iteration capture is used for single-process training on a HIP device with the fused optimizer."""
+    """Whole-iteration capture needs a HIP device and the fused optimizer; under data parallelism also an exchange whose
+    collectives are stream work (training/grad_exchange.py over RCCL) -- torch's DistributedDataParallel reducer stays eager."""
     if isinstance(network, nn.parallel.DistributedDataParallel) or not hasattr(optimizer, 'push_hyper'):
+        return False
+    if isinstance(network, BucketedDataParallel) and not network.capturable():
         return False
     return torch.device(device if not isinstance(device, int) else f'cuda:{device}').type == 'cuda'
 

@@ -48,18 +48,21 @@ class _TinySegmenter(nn.Module):
         return self.head(torch.relu(self.bn(self.conv(x))))
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, flavour):
     sys.path.insert(0, os.path.join(ROOT, "synthesis-in-style_amd"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        from training.grad_exchange import BucketedDataParallel
         from training_builder.base_train_builder import BaseSingleNetworkTrainBuilder, strip_parallel_module
-        torch.manual_seed(0)
-        builder = BaseSingleNetworkTrainBuilder({"fine_tune": None, "bucket_cap_mb": 1}, rank=rank, world_size=world, build=False)
+        torch.manual_seed(rank)  # DIFFERENT initial weights per rank: the wrap must broadcast rank 0's
+        builder = BaseSingleNetworkTrainBuilder({"fine_tune": None, "bucket_cap_mb": 1, "data_parallel": flavour}, rank=rank,
+                                                world_size=world, build=False)
         net = _TinySegmenter()
         with torch.no_grad():
             net.mu.fill_(float(rank))  # per-rank buffer must survive (broadcast_buffers=False)
         ddp = builder._prepare_segmentation_network(net)
+        assert isinstance(ddp, BucketedDataParallel if flavour == "buckets" else nn.parallel.DistributedDataParallel)
         assert strip_parallel_module(ddp) is net
         gen = torch.Generator().manual_seed(100 + rank)
         x = torch.randn(2, 3, 8, 8, generator=gen)
@@ -86,11 +89,12 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_ddp_wrap_world_size_2_gloo():
+@pytest.mark.parametrize("flavour", ["buckets", "ddp"])
+def test_ddp_wrap_world_size_2_gloo(flavour):
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, flavour), nprocs=world, join=True)
     assert len(out) == world
     for rank in range(world):
         grads_ok, params_ok, mu, bn_stat = out[rank]
@@ -130,7 +134,7 @@ def _host_sgd_kernel(table, n_chunks, lrs, wds, momentum, first_step):
         p -= np.float32(lrs[gi]) * b
 
 
-def _fused_sgd_worker(rank, world, port, out):
+def _fused_sgd_worker(rank, world, port, out, flavour="ddp"):
     sys.path.insert(0, os.path.join(ROOT, "synthesis-in-style_amd"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -159,12 +163,16 @@ def _fused_sgd_worker(rank, world, port, out):
             def optimizer_defaults(self):
                 return {'momentum': 0.9}
 
-        builder = Builder({"fine_tune": None, "bucket_cap_mb": 1}, rank=rank, world_size=world)
+        from training.grad_exchange import BucketedDataParallel
+        # buckets flavour: a 100-byte cap cuts the five live tensors (12, 96, 32 + 32, 864 bytes in readiness order) into four buckets
+        builder = Builder({"fine_tune": None, "bucket_cap_mb": 1 if flavour == "ddp" else 100 / (1 << 20), "data_parallel": flavour},
+                          rank=rank, world_size=world)
         ddp = builder.get_network()
         net = ddp.module
         opt = builder.get_optimizers()['main']
-        assert isinstance(opt, FusedSGD) and isinstance(ddp, nn.parallel.DistributedDataParallel)
-        graph_off = not _graphable(ddp, opt, 'cuda:0')   # the whole-iteration hipGraph must stay off under DDP
+        assert isinstance(opt, FusedSGD)
+        assert isinstance(ddp, nn.parallel.DistributedDataParallel if flavour == "ddp" else BucketedDataParallel)
+        graph_off = not _graphable(ddp, opt, 'cuda:0')   # eager under DDP, and under gloo (host-synchronising collectives)
         # reference run: same data, plain torch.optim.SGD on the hand-averaged gradients
         torch.manual_seed(0)
         solo = _TinyEmaShaped()
@@ -177,7 +185,8 @@ def _fused_sgd_worker(rank, world, port, out):
             fut = dist.all_reduce(buf.div_(world), async_op=True).get_future()
             return fut.then(lambda f: f.value()[0])
 
-        ddp.register_comm_hook(spans, recording_allreduce)
+        if flavour == "ddp":
+            ddp.register_comm_hook(spans, recording_allreduce)
         orig_upload = opt._upload
         opt._upload = lambda entries, capturing=False: (uploads.append(1), orig_upload(entries, capturing))[1]
         for it in range(3):
@@ -186,6 +195,9 @@ def _fused_sgd_worker(rank, world, port, out):
             opt.zero_grad()  # set_to_none: DDP re-points .grad at the bucket views during backward
             nn.functional.cross_entropy(ddp(x), y).backward()
             live = [p for p in net.parameters() if p.grad is not None]
+            if flavour == "buckets":
+                spans = ddp.bucket_spans()
+                assert len(spans) >= 3 and ddp.stats["discovery_backwards"] == 1
             assert net.unused.weight.grad is None and len(live) == 5 and spans
             alias_ok &= all(any(lo <= p.grad.data_ptr() < hi for lo, hi in spans) for p in live)
             ptrs.append(tuple(p.grad.data_ptr() for p in live))
@@ -217,8 +229,10 @@ def _TinyEmaShaped_init_unused():
     return _TinyEmaShaped().unused.weight.detach()
 
 
-def test_fused_sgd_on_ddp_bucket_views_world_size_2_gloo():
-    """EMANetTrainBuilder's shape under DistributedDataParallel(gradient_as_bucket_view=True, find_unused_parameters=True)
+@pytest.mark.parametrize("flavour", ["buckets", "ddp"])
+def test_fused_sgd_on_ddp_bucket_views_world_size_2_gloo(flavour):
+    """(``buckets``: the product's own exchange, training/grad_exchange.py -- plan fixed by the first backward, several buckets,
+    the unused parameter never enters a bucket; ``ddp``: torch's reducer.)  EMANetTrainBuilder's shape under DistributedDataParallel(gradient_as_bucket_view=True, find_unused_parameters=True)
     with the product's FusedSGD: gradients live in the all-reduce buckets at stable addresses (ONE pointer-table upload for
     three iterations), the table's gradient column points into the buckets, the update equals torch.optim.SGD on the
     rank-averaged gradients (3 groups: lr / 2 lr / weight decay), the gradient-less parameter is skipped like
@@ -227,7 +241,7 @@ def test_fused_sgd_on_ddp_bucket_views_world_size_2_gloo():
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_fused_sgd_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_fused_sgd_worker, args=(world, _free_port(), out, flavour), nprocs=world, join=True)
     assert len(out) == world
     for rank in range(world):
         r = out[rank]

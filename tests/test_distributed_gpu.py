@@ -73,3 +73,94 @@ def test_ema_net_ddp_two_ranks_share_one_gpu(device):
         assert lockstep, "replicas diverged: gradients were not averaged into the buckets FusedSGD reads"
         assert finite and iterations == 3
         assert mu_per_rank, "emau.mu is a per-rank buffer (broadcast_buffers=False): different data, different bases"
+
+
+def _rccl_worker(rank, world, port, out, golden_dir):
+    for p in (ROOT, os.path.join(ROOT, "synthesis-in-style_amd")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import numpy as np
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL communicator on the one GPU
+    try:
+        from oracle import ema_net_ref as E
+        from training.fused_sgd import FusedSGD
+        from training.grad_exchange import BucketedDataParallel
+        from training.loop import get_current_reporter
+        from training_builder.ema_net_train_builder import EMANetTrainBuilder
+        g = np.load(os.path.join(golden_dir, "ema_net_step_conditioned.npz"))
+        n_layers, classes, wseed, bseed, batch, size = g["cfg"].tolist()
+        batches = [E.seeded_batch(batch, size, classes, seed=bseed + i) for i in range(2)]
+        cfg = dict(network="EMANet", n_layers=50, num_classes=3, lr=0.009, lr_mom=0.9, weight_decay=1e-4, em_mom=0.9,
+                   fine_tune=None, batch_size=batch, image_size=size, use_pretrained_resnet=False, bucket_cap_mb=25)
+
+        def run(force, flavour="buckets", n_iter=6):
+            builder = EMANetTrainBuilder(dict(cfg, force_data_parallel=force, data_parallel=flavour), batches * 3, None, rank=0,
+                                         world_size=1)
+            net = builder.get_network()
+            bare = net.module if force else net
+            bare.load_state_dict(E.seeded_state_dict(50, 3, seed=wseed, residual_scale=0.1), strict=True)
+            bare.fc1[1].p = 0.0
+            upd = builder.get_updater()
+            losses = []
+            for _ in range(n_iter):
+                upd.update()
+                losses.append(float(get_current_reporter().scalars()["loss/softmax"]))
+            torch.cuda.synchronize()
+            return builder, net, upd, losses, {k: v.detach().cpu().clone() for k, v in bare.state_dict().items()}
+
+        builder, net, upd, losses, sd = run(True)
+        opt = builder.get_optimizers()["main"]
+        assert isinstance(net, BucketedDataParallel) and net.backend == "nccl" and isinstance(opt, FusedSGD)
+        spans = net.bucket_spans()
+        live = [p for p in net.module.parameters() if p.grad is not None]
+        rows = opt._table.cpu().numpy()
+        init = E.seeded_state_dict(50, 3, seed=wseed, residual_scale=0.1)
+        _, _, upd_plain, losses_plain, sd_plain = run(False)
+        _, net_ddp, upd_ddp, losses_ddp, _ = run(True, "ddp", n_iter=3)
+        out[rank] = dict(
+            graph=upd._step_graph.graph is not None, capture_error=upd._step_graph.capture_error,
+            n_buckets=len(spans), collectives=net.stats["collectives"], discovery=net.stats["discovery_backwards"],
+            backwards=net.stats["backwards"],
+            grads_in_buckets=all(any(lo <= p.grad.data_ptr() < hi for lo, hi in spans) for p in live),
+            table_in_buckets=all(any(lo <= int(r[1]) < hi for lo, hi in spans) for r in rows),
+            unused_none=net.module.emau.conv1.weight.grad is None,
+            losses=losses, losses_plain=losses_plain, losses_ddp=losses_ddp, golden=(float(g["loss_mean_0"]), float(g["loss_mean_1"])),
+            plain_graph=upd_plain._step_graph.graph is not None,
+            ddp_is_torch=isinstance(net_ddp, torch.nn.parallel.DistributedDataParallel), ddp_graph_off=not upd_ddp._step_graph.enabled,
+            delta_fc2=float(np.linalg.norm((sd["fc2.weight"] - sd_plain["fc2.weight"]).double().numpy())
+                            / np.linalg.norm((sd_plain["fc2.weight"] - init["fc2.weight"]).double().numpy())),
+            finite=all(bool(torch.isfinite(v).all()) for v in sd.values() if v.is_floating_point()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ema_net_rccl_world_size_1_bucketed_exchange_inside_the_step_graph(device, golden_dir):
+    """The data-parallel path on RCCL with the real kernels, as far as one GPU allows: a world-size-1 RCCL
+    communicator (HSA_ENABLE_IPC_MODE_LEGACY=0), EMANetTrainBuilder with a FORCED wrap -> BucketedDataParallel (several 25 MB
+    buckets, reduce-scatter + all-gather on RCCL's stream) -> FusedSGD reading the bucket views -> EMANetUpdater whose THIRD
+    iteration captures forward, backward, the collectives and the optimizer into one hipGraph and replays it.  Checked: the
+    two golden iterations of the conditioned reference fixture (shipped lr 0.009) at the tolerances of
+    test_ema_net_conditioned_fixture_tight, four more iterations (capture + replays) against the same run without the wrap
+    (a one-rank average is the identity), the unused ``emau.conv1`` stays gradient-less, and torch's DistributedDataParallel
+    flavour also runs over RCCL (eager)."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_worker, args=(1, _free_port(), out, golden_dir), nprocs=1, join=True)
+    r = out[0]
+    assert r["graph"] and r["capture_error"] is None, f"the data-parallel iteration was not captured: {r['capture_error']}"
+    assert r["plain_graph"]
+    assert r["n_buckets"] >= 5 and r["discovery"] == 1
+    # eager iterations 1-2 and the capture run the hooks (3 backwards seen by the wrapper); replays do not pass through Python
+    assert r["backwards"] == 3 and r["collectives"] == 3 * r["n_buckets"], r
+    assert r["grads_in_buckets"] and r["table_in_buckets"] and r["unused_none"] and r["finite"]
+    assert abs(r["losses"][0] - r["golden"][0]) <= 1e-5 * abs(r["golden"][0])
+    assert abs(r["losses"][1] - r["golden"][1]) <= 1e-3 * abs(r["golden"][1])
+    for a, b in zip(r["losses"], r["losses_plain"]):
+        assert abs(a - b) <= 2e-3 * abs(b), (r["losses"], r["losses_plain"])
+    for a, b in zip(r["losses_ddp"], r["losses_plain"]):
+        assert abs(a - b) <= 2e-3 * abs(b), (r["losses_ddp"], r["losses_plain"])
+    assert r["ddp_is_torch"] and r["ddp_graph_off"]
+    assert r["delta_fc2"] < 5e-2, r["delta_fc2"]   # six-step parameter change of the head, wrapped vs plain

@@ -1,9 +1,15 @@
 """GPU parity, part 4: the EMANet training step (product: networks/ema_net + updater + FusedSGD on MI355X)
 against the golden outputs of the reference (tests/golden/ema_net_step.npz) and the CPU oracle.
 
-Tolerances: convolutions go through the ROCm libraries in fp32, whose algorithms re-associate sums; the first
-iteration must agree to 1e-4 on the loss and 1 % on every gradient norm (measured: see DESIGN.md), label maps
-must be bit-exact wherever the reference's top-2 logit margin exceeds 5e-2 (twice the logit tolerance).
+Tolerances.  Every convolution of the step except the 3-channel stem runs on this repo's own fp32 kernels (Winograd
+F(2x2,3x3) forward / data / weight gradient, MFMA 1x1 kernels), which sum in a different order than the oracle's direct
+CPU convolution, and the Winograd transforms add ~1e-6 relative error per layer; on the plain random init of this fixture
+the 50-layer ReLU network amplifies such differences (a 1e-7 perturbation moves the stem gradient by 2-3 %
+between the CPU oracle and the CPU reference themselves).  Hence: first-iteration loss 1e-4, every gradient norm 2 %,
+label maps bit-exact wherever the reference's top-2 logit margin exceeds 5e-2 (twice the logit tolerance).  The
+well-conditioned fixture (``test_ema_net_conditioned_fixture_tight``) is where the bounds are tight: loss 1e-5, gradient
+norms 3e-3; the BASELINE batch size (B = 16, where the single-launch batch-norm kernels dispatch) is covered by
+``test_ema_net_step_at_baseline_batch_vs_oracle``.
 """
 import os
 
@@ -185,3 +191,57 @@ def test_ema_net_conditioned_fixture_tight(device, golden_dir):
     assert after["fc2.weight"] < 1e-2 and after["fc2.bias"] < 1e-2 and after["fc1.0.bn.weight"] < 2e-2, after  # momentum, wd, group lrs
     # the second step's gradients are taken at parameters that already differ by the first step's 3e-3: measured 3.0e-2 / 4.8e-2
     assert after["layer4_conv3"] < 6e-2 and after["stem0"] < 1e-1 and after["abs_sums"] < 1e-3, after
+
+
+def test_ema_net_step_at_baseline_batch_vs_oracle(device):
+    """BASELINE.json configs[3] at ITS batch: EMANet-50, 256 x 256, B = 16.  The batch decides the
+    dispatch -- at B = 16 a channel of a 32 x 32 layer is exactly one 16 384-element slice, so the single-launch
+    ``bn_fused_fwd/bwd_kernel`` replace the three-launch batch norm, the 1x1 / Winograd tile plans and split-K slabs change
+    -- and before this test that step was only ever run by bench.py, which checks nothing.  One forward + backward on the
+    conditioned seeded state (bn3 x 0.1, as ema_net_step_conditioned.npz) against the oracle run live on the host: per-sample
+    losses, the EM bases, every gradient norm, and a record that the B = 16-only kernels were the ones dispatched."""
+    import json
+    import sis_hip
+    from networks.ema_net.network import EMANet
+    sd = E.seeded_state_dict(50, 3, seed=41, residual_scale=0.1)
+    batch = E.seeded_batch(16, 256, 3, seed=42)
+    total, loss_o, mu_o, grads_o = E.train_step(dict(sd), {}, batch)
+    net = EMANet(3, 50, use_pretrained_resnet=False)
+    net.load_state_dict(sd, strict=True)
+    net.fc1[1].p = 0.0
+    net = net.to(device).train()
+    records = []
+    sis_hip.library_calls(reset=True)
+    sis_hip.set_profiler(records)
+    try:
+        loss, mu = net(batch["images"].to(device), batch["segmented"].squeeze(1).to(device))
+        loss.mean().backward()
+        torch.cuda.synchronize()
+    finally:
+        sis_hip.set_profiler(None)
+    launched = {}
+    for name, *_ in records:
+        launched[name] = launched.get(name, 0) + 1
+    calls = sis_hip.library_calls(reset=True)
+    # the single-pass batch norm takes every 32 x 32 layer (42 of the 55 norms, DESIGN.md §4.4) in both directions
+    assert launched.get("bn_fused_fwd_kernel", 0) >= 40 and launched.get("bn_fused_bwd_kernel", 0) >= 40, launched
+    assert calls["fallback"] == {}, calls       # nothing the kernels declined; the 3-channel stem is the one intended library layer
+    assert set(calls["intended"]) <= {"hip_conv.HipConv2d.forward"}, calls
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), loss_o.numpy(), rtol=1e-5)
+    mu_err = _rel_l2(mu.cpu().numpy(), mu_o.numpy())
+    norm_err = {}
+    for name, p in net.named_parameters():
+        if grads_o[name] is None:
+            assert p.grad is None, name
+        else:
+            ref = grads_o[name].double().norm().item()
+            norm_err[name] = abs(p.grad.double().norm().item() - ref) / (ref + 1e-30)
+    worst = max(norm_err.items(), key=lambda kv: kv[1])
+    measured = {"loss_rel": float(np.abs(loss.detach().cpu().numpy() / loss_o.numpy() - 1).max()), "mu_rel_l2": mu_err,
+                "worst_grad_norm": worst, "grad_fc2_rel_l2": _rel_l2(net.fc2.weight.grad.cpu().numpy(), grads_o["fc2.weight"].numpy()),
+                "launched": launched}
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "ema_net_b16_parity.json"), "w") as f:
+        json.dump(measured, f, indent=1)
+    # the bounds of the conditioned B = 2 fixture (test_ema_net_conditioned_fixture_tight): the floor of a ReLU network in fp32
+    assert mu_err < 1e-4 and worst[1] < 3e-3 and measured["grad_fc2_rel_l2"] < 1e-4, measured

@@ -72,7 +72,11 @@ def test_gemm_nn_data_gradient(device, m, n, k, tile):
 
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("m,n,k,splits", [(256, 256, 128, 1), (768, 768, 392, 1), (2304, 768, 2048, 4), (768, 3072, 1024, 8),
-                                          (136, 264, 200, 2), (768, 768, 8192, 16)])
+                                          (136, 264, 200, 2), (768, 768, 8192, 16),
+                                          # contraction lengths whose K steps 8 (4) slices cannot cover without an empty slice
+                                          # (12 / 13 / 20 / 28 steps of 64; 5 steps): the slice count steps down
+                                          (768, 768, 768, 8), (768, 768, 784, 8), (768, 768, 1280, 8), (2304, 768, 1792, 8),
+                                          (768, 768, 320, 4), (768, 768, 1100, 16)])
 def test_gemm_tn_weight_gradient(device, m, n, k, splits, tile):
     """dW[m = out][n = in] = sum_tokens g[token][m] x[token][n]: both operands K-major, fp32 result, split over the tokens;
     the token count need not be a multiple of the 64-deep K step (rows past the end read as zeros)."""
@@ -88,7 +92,8 @@ def test_gemm_tn_weight_gradient(device, m, n, k, splits, tile):
 
 
 @pytest.mark.parametrize("tile", [0, 4, 6])
-@pytest.mark.parametrize("m,n,k,splits", [(2304, 768, 8192, 4), (768, 768, 8192, 8), (3072, 768, 2048, 4), (136, 264, 200, 2), (264, 72, 1000, 2)])
+@pytest.mark.parametrize("m,n,k,splits", [(2304, 768, 8192, 4), (768, 768, 8192, 8), (3072, 768, 2048, 4), (136, 264, 200, 2), (264, 72, 1000, 2),
+                                          (768, 768, 784, 8)])
 def test_gemm_weight_and_bias_gradient_in_one_pair_of_launches(device, m, n, k, splits, tile):
     """sis_gemm_bf16_wgrad_bias: the weight gradient is bitwise the plain split-K TN run, the bias gradient (column sums of the
     gradient, computed by extra workgroups of the same launches) bitwise sis_column_sum -- same summation orders -- incl. output

@@ -204,6 +204,24 @@ def test_generator_batch32_properties(device):
         assert torch.equal(a, b)
 
 
+def test_generator_batch32_first_and_last_sample_vs_oracle(device):
+    """BASELINE.json configs[1] at its own batch size: ONE Generator.forward over 32 latents -- the tile plans, persistent
+    Winograd workgroups and multi-sample tiles the batch selects (a B = 4 forward takes other plans) -- with samples 0 and 31
+    compared in full (image and all 14 activations) against the oracle run live on those two latents.  Each image depends on
+    its own z row only (model.py:479-561), so the oracle needs just the two rows."""
+    g, sd = _build(256, 512, 8, 2, 0, device)
+    z = torch.randn(32, 512, generator=torch.Generator().manual_seed(5))
+    noise = R.seeded_inputs(256, 1, 512, seed=6)[1]
+    with torch.no_grad():
+        img, acts = g([z.to(device)], noise=[n.to(device) for n in noise], return_intermediate_activations=True)
+        torch.cuda.synchronize()
+        pick = torch.tensor([0, 31])
+        img_o, acts_o = R.generator_forward(sd, [z[pick]], noise=noise, return_intermediate_activations=True)
+    assert _rel(img[pick.to(device)], img_o) < 2e-4
+    for k in acts_o:
+        assert _rel(acts[k][pick.to(device)], acts_o[k]) < 1e-4, k
+
+
 def test_dataset_creation_driver(device):
     """utils/dataset_creation.py surface (reference :32-58): seeded latent stream + generate_images."""
     from latent_projecting import Latents

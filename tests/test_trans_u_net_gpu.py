@@ -119,12 +119,12 @@ FP32_CONTROL_REL_L2 = 1e-4     # the same product path in fp32 against the oracl
 HARSH_LOGITS_REL_L2, HARSH_LOGITS_MAX, HARSH_LABEL_AGREEMENT = 0.35, 0.40, 0.85
 
 
-def _bf16_two_iterations(device, size, batch, wseed, bseed, lr, linear_scale=1.0):
+def _bf16_two_iterations(device, size, batch, wseed, bseed, lr, linear_scale=1.0, iterations=2):
     from training.fused_sgd import FusedSGD
     from training.loop import get_current_reporter
     from updater.segmentation_updater import TransUNetUpdater
     classes = 3
-    batches = [E.seeded_batch(batch, size, classes, seed=bseed + i) for i in range(2)]
+    batches = [E.seeded_batch(batch, size, classes, seed=bseed + i) for i in range(iterations)]
     # fp32 oracle (CPU): two iterations from the seeded state
     sd = _vit_like(T.seeded_state_dict(size, classes, seed=wseed), linear_scale)
     bufs, oracle = {}, []
@@ -140,7 +140,7 @@ def _bf16_two_iterations(device, size, batch, wseed, bseed, lr, linear_scale=1.0
     report = {}
     with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.bfloat16):
         logits0 = net(batches[0]["images"].to(device)).float().cpu()
-    for it in range(2):
+    for it in range(iterations):
         upd.update()
         obs = get_current_reporter().scalars()
         got = (obs["loss/combined"], obs["loss/CE"], obs["loss/Dice"])
@@ -170,12 +170,12 @@ def _bf16_two_iterations(device, size, batch, wseed, bseed, lr, linear_scale=1.0
     return report
 
 
-def _check_bf16_report(report, tag):
+def _check_bf16_report(report, tag, iterations=2):
     import json
     os.makedirs("gpurun_out", exist_ok=True)
     with open(os.path.join("gpurun_out", f"transunet_bf16_parity_{tag}.json"), "w") as f:
         json.dump(report, f, indent=1)  # measured deviations, kept next to the stated tolerance
-    for it in range(2):
+    for it in range(iterations):
         assert max(report[f"loss{it}"]) < BF16_LOSS_RTOL, (it, report[f"loss{it}"])
     assert report["logits_rel_l2"] < BF16_LOGITS_REL_L2, report["logits_rel_l2"]
     assert report["logits_abs_over_max"] < BF16_LOGITS_MAX, report["logits_abs_over_max"]
@@ -202,6 +202,68 @@ def test_trans_u_net_bf16_512_two_iterations_vs_fp32_oracle(device):
     assert harsh["fp32_control_logits_rel_l2"] < FP32_CONTROL_REL_L2 and max(harsh["loss0"] + harsh["loss1"]) < BF16_LOSS_RTOL
     assert harsh["label_mismatches_where_decided"] == 0 and harsh["logits_rel_l2"] < HARSH_LOGITS_REL_L2
     _check_bf16_report(_bf16_two_iterations(device, 512, 2, wseed=3, bseed=40, lr=1e-4, linear_scale=0.1), "512")
+
+
+def test_trans_u_net_bf16_512_baseline_batch_vs_fp32_oracle(device):
+    """BASELINE.json configs[4] at ITS batch: 512^2, R50-ViT-B/16, bf16 autocast, B = 8 -- 8 192 tokens per
+    GEMM, the tile plans / split-K slab counts / GroupNorm dispatch of the benchmarked step -- one TransUNetUpdater iteration
+    against the fp32 oracle run live on the host (about 15 s of CPU), same stated bf16 tolerance as the B = 2 test."""
+    import sis_hip
+    sis_hip.library_calls(reset=True)
+    report = _bf16_two_iterations(device, 512, 8, wseed=3, bseed=60, lr=1e-4, linear_scale=0.1, iterations=1)
+    calls = sis_hip.library_calls(reset=True)
+    report["library_calls"] = calls
+    _check_bf16_report(report, "512_b8", iterations=1)
+    # (the fp32 control forward inside the helper runs the module-by-module encoder: its library calls are expected; the bf16
+    # iteration itself is audited by bench.py and by test_library_fallback_audit_on_baseline_configs)
+
+
+def test_decoder_layers_bf16_gradients_vs_fp32_on_the_same_inputs(device):
+    """Per-layer bf16 bounds for the decoder (replaces reading the cumulative 0.60 as a tolerance): every
+    decoder stage of configs[4] (``conv_more`` and the four ``DecoderBlock``s, B = 2) runs forward + backward ONCE under bf16
+    autocast and ONCE in fp32 on the SAME bf16-rounded inputs, skip features and incoming gradient, so that what is compared is
+    the stage's own rounding, not drift inherited from upstream.  Error model: operands and outputs rounded to 8 significant
+    bits (relative rms 2^-9 / sqrt 3 = 1.1e-3 each) -> outputs within ~3e-3 relative L2; every ReLU whose pre-activation sits
+    within that distance of zero (a fraction ~1e-3 of the units) flips a whole gradient element, which shows as
+    sqrt(fraction) ~ 3e-2 in the gradients below it -- one ReLU for conv2's weights, two for conv1's and for dL/dx."""
+    import json
+    from networks.trans_u_net.cup_decoder import Conv2dReLU, DecoderBlock
+    gen = torch.Generator().manual_seed(17)
+    stages = [("conv_more", Conv2dReLU(768, 512, kernel_size=3, padding=1), (2, 768, 32, 32), None),
+              ("blocks.0", DecoderBlock(512, 256, 512), (2, 512, 32, 32), (2, 512, 64, 64)),
+              ("blocks.1", DecoderBlock(256, 128, 256), (2, 256, 64, 64), (2, 256, 128, 128)),
+              ("blocks.2", DecoderBlock(128, 64, 64), (2, 128, 128, 128), (2, 64, 256, 256)),
+              ("blocks.3", DecoderBlock(64, 16, 0), (2, 64, 256, 256), None)]
+    measured = {}
+    for name, module, x_shape, skip_shape in stages:
+        torch.manual_seed(23)
+        module = module.to(device).train()
+        x = torch.randn(x_shape, generator=gen).relu().bfloat16().to(device)          # activations arrive behind a ReLU
+        skip = None if skip_shape is None else torch.randn(skip_shape, generator=gen).relu().bfloat16().to(device)
+
+        def run(amp):
+            module.zero_grad(set_to_none=True)
+            xi = (x if amp else x.float()).clone().requires_grad_(True)
+            si = None if skip is None else (skip if amp else skip.float()).clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                y = module(xi) if isinstance(module, Conv2dReLU) else module(xi, skip=si)
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(29)).bfloat16().to(device)
+            y.backward(gy.to(y.dtype))
+            return y.detach().float(), xi.grad.float(), {n: p.grad.float().clone() for n, p in module.named_parameters()}
+
+        y32, dx32, g32 = run(False)
+        y16, dx16, g16 = run(True)
+        rel = lambda a, b: ((a - b).norm() / (b.norm() + 1e-30)).item()  # noqa: E731
+        measured[name] = {"y": rel(y16, y32), "dx": rel(dx16, dx32), **{n: rel(g16[n], g32[n]) for n in g32 if n.endswith("0.weight")}}
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "transunet_bf16_decoder_per_layer.json"), "w") as f:
+        json.dump(measured, f, indent=1)
+    for name, m in measured.items():
+        assert m["y"] < 1e-2, (name, m)
+        assert m["dx"] < 0.08, (name, m)
+        for key, val in m.items():
+            if key.endswith("0.weight"):
+                assert val < (0.08 if key.startswith("conv1") else 0.06), (name, key, m)
 
 
 def test_trans_u_net_bf16_224_vs_golden(device, golden_dir):

@@ -22,7 +22,9 @@ def _config(dropout):
     return cfg
 
 
-@pytest.mark.parametrize("batch,tokens", [(2, 256), (1, 196), (3, 70)])
+# (3, 256) / (4, 196): 768 / 784 tokens = 12 / 13 K steps of the weight-gradient GEMMs, which 8 split-K slices cannot cover
+# without an empty slice -- gemm_impl steps the slice count down instead of failing
+@pytest.mark.parametrize("batch,tokens", [(2, 256), (1, 196), (3, 70), (3, 256), (4, 196)])
 def test_fused_block_matches_the_module_composition(device, batch, tokens):
     from networks.trans_u_net import vit_encoder as V
     torch.manual_seed(batch * 100 + tokens)
