@@ -198,6 +198,17 @@ int sis_sgd_momentum_dev(const int64_t* table, int n_chunks, const float* hyper,
 int sis_ema_update(float* mu, const float* mu_batch, float momentum, float one_minus_momentum,
                    int batch, int numel, void* stream);
 
+/* EMANet's Expectation-Maximisation Attention Unit between its two 1x1 convolutions (networks/ema_net/network.py:219-249,
+ * the no_grad block and the reconstruction):  mu <- mu0 (shared [channels][bases]) for every sample; `stages` rounds of
+ * z = softmax_k(x^T mu), z_ = z / (1e-6 + sum_n z), mu = l2norm_c(x z_) (eps 1e-6);  x_out = relu(mu z^T), mu_out = mu.
+ * x, x_out: [batch][channels][pixels] float32; mu_out: [batch][channels][bases].  fp32 MFMA products, 2 * stages + 1 launches,
+ * no atomics (csrc/emau.hip).  bases must be 64, channels % 64 == 0, pixels % 128 == 0 (sis_emau_supported);
+ * workspace: sis_emau_workspace_floats(...) floats (z, un-normalised bases, partial sums). */
+int sis_emau_supported(int batch, int channels, int pixels, int bases);
+int64_t sis_emau_workspace_floats(int batch, int channels, int pixels, int bases);
+int sis_emau_forward(float* x_out, float* mu_out, const float* x, const float* mu0, float* workspace, int batch, int channels,
+                     int pixels, int bases, int stages, void* stream);
+
 /* Batch normalisation (training: batch statistics; F.batch_norm semantics incl. the unbiased running_var update)
  * fused with an optional residual add and ReLU, fp32 NCHW with H*W % 4 == 0
  * (networks/ema_net/network.py:37-56 bottleneck tail, :169-184 ConvBNReLU; bn_lib/nn/modules/batchnorm.py:51-56).

@@ -35,6 +35,7 @@ from networks.hip_conv import HipConv2d, pointwise_with_skip
 from networks.hip_pool import HipMaxPool2d
 
 BN_MOM = 3e-4
+_HIP_EMAU = os.environ.get('SIS_HIP_EMAU', '1') != '0'   # 0: the EM rounds as torch.bmm / softmax launches (A/B runs)
 _RELU_MASK = os.environ.get('SIS_BN_RELU_MASK', '1') != '0'
 RESNET_BLOCKS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
 
@@ -238,6 +239,15 @@ class EMAU(nn.Module):
         idn = x
         x = self.conv1(x)
         b, c, h, w = x.size()
+        if _HIP_EMAU and sis_hip.emau_supported(x, self.mu):
+            # E / M rounds and the reconstruction on the fp32 matrix cores, 7 launches (csrc/emau.hip); like the reference's
+            # no_grad block the result carries no graph: conv1 receives no gradient, conv2 sees a constant input
+            with torch.no_grad():
+                x, mu = sis_hip.emau_forward(x.detach(), self.mu, self.stage_num)
+            x = self.conv2[1](self.conv2[0](x), residual=idn, relu=True)
+            return x, mu
+        if x.is_cuda:
+            sis_hip.library_call("ema_net.EMAU (bmm / softmax rounds)")
         x = x.view(b, c, h * w)
         mu = self.mu.repeat(b, 1, 1)
         with torch.no_grad():

@@ -91,6 +91,9 @@ _SIGNATURES = {
     "sis_sgd_momentum": ([_vp, _i, ctypes.POINTER(_f), ctypes.POINTER(_f), _i, _f, _i, _vp], _i),
     "sis_sgd_momentum_dev": ([_vp, _i, _vp, _vp], _i),
     "sis_ema_update": ([_vp, _vp, _f, _f, _i, _i, _vp], _i),
+    "sis_emau_supported": ([_i] * 4, _i),
+    "sis_emau_workspace_floats": ([_i] * 4, _i64),
+    "sis_emau_forward": ([_vp] * 5 + [_i] * 5 + [_vp], _i),
     "sis_bn_workspace_floats": ([_i, _i, _i], _i64),
     "sis_bn_stats": ([_vp] * 6 + [_i, _i, _i, _f, _f, _vp], _i),
     "sis_bn_mask_words": ([_i, _i, _i], _i64),
@@ -653,6 +656,33 @@ def ema_update(mu, mu_batch, momentum):
         _check(lib().sis_ema_update(_ptr(mu), _ptr(mb), float(momentum), float(1 - momentum), mb.numel() // n, n,
                                     _stream()), "sis_ema_update")
     return mu
+
+
+def emau_supported(x, mu):
+    """x [b, c, h, w] (or [b, c, n]) float32 on a HIP device, mu [1, c, 64]."""
+    if not (x.is_cuda and x.dtype == torch.float32 and mu.dtype == torch.float32 and x.dim() in (3, 4) and mu.dim() == 3):
+        return False
+    b, c = x.shape[0], x.shape[1]
+    n = x.numel() // max(b * c, 1)
+    return mu.shape[0] == 1 and mu.shape[1] == c and bool(lib().sis_emau_supported(b, c, n, mu.shape[2]))
+
+
+def emau_forward(x, mu, stages):
+    """The EM rounds + reconstruction of EMAU.forward (networks/ema_net/network.py:229-247) -> (relu(mu z^T) shaped like x,
+    mu [b, c, k]); no autograd graph (the reference runs the rounds under no_grad and the reconstruction only sees their
+    results)."""
+    require_device(x, "x")
+    x, m0 = _f32(x, "x"), _f32(mu, "mu")
+    b, c = x.shape[0], x.shape[1]
+    n, k = x.numel() // (b * c), m0.shape[2]
+    out = torch.empty_like(x)
+    mu_out = torch.empty((b, c, k), dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib().sis_emau_workspace_floats(b, c, n, k), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(_launch("emau_kernels", 2.0 * b * c * n * k * (2 * stages + 1), 4.0 * (2 * x.numel() + (2 * stages + 1) * (b * n * k + b * c * k)),
+                       lambda: lib().sis_emau_forward(_ptr(out), _ptr(mu_out), _ptr(x), _ptr(m0), _ptr(ws), b, c, n, k, int(stages),
+                                                      _stream())), "sis_emau_forward")
+    return out, mu_out
 
 
 # ------------------------------------------------------------------------------ dataset-loop neighbours

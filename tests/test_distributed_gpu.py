@@ -1,7 +1,8 @@
 """GPU: the data-parallel training path with more than one rank on real kernels.  One-GPU boxes only allow a rehearsal --
 two ranks SHARE cuda:0 and talk over gloo (RCCL refuses two ranks on one device) -- but everything else is the product
-path: EMANetTrainBuilder -> DistributedDataParallel(gradient_as_bucket_view, find_unused_parameters) -> FusedSGD on the
-bucket views (device kernel) -> EMANetUpdater with the step hipGraph off.  Multi-GPU throughput itself stays
+path: EMANetTrainBuilder -> BucketedDataParallel (training/grad_exchange.py) or DistributedDataParallel(gradient_as_bucket_view,
+find_unused_parameters) -> FusedSGD on the bucket views (device kernel) -> EMANetUpdater with the step hipGraph off (gloo).
+The RCCL path -- a world-size-1 communicator, collectives captured inside the step hipGraph -- is the last test of this file.  Multi-GPU throughput itself stays
 "unmeasured on hardware" until the driver's SCALE run."""
 import os
 import socket
@@ -25,7 +26,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, flavour):
     for p in (ROOT, os.path.join(ROOT, "synthesis-in-style_amd")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -37,16 +38,17 @@ def _worker(rank, world, port, out):
         from utils.synthetic_data import SyntheticSegmentationLoader
         torch.cuda.set_device(0)
         cfg = yaml.safe_load(open(os.path.join(ROOT, "synthesis-in-style_amd", "configs", "segmenter", "ema_net_resnet50_256.yaml")))
-        cfg.update(fine_tune=None, batch_size=2, image_size=64)
+        cfg.update(fine_tune=None, batch_size=2, image_size=64, data_parallel=flavour)
         loader = SyntheticSegmentationLoader(2, 64, 3, seed=1234 + rank, device=torch.device("cuda:0"))
         torch.manual_seed(0)  # identical initial weights on every rank
         builder = EMANetTrainBuilder(cfg, loader, None, rank=0, world_size=world)  # rank 0 -> cuda:0 on both (shared GPU)
         net = builder.get_network()
-        assert isinstance(net, torch.nn.parallel.DistributedDataParallel)
+        from training.grad_exchange import BucketedDataParallel
+        assert isinstance(net, BucketedDataParallel if flavour == "buckets" else torch.nn.parallel.DistributedDataParallel)
         opt = builder.get_optimizers()["main"]
         assert isinstance(opt, FusedSGD)
         upd = builder.get_updater()
-        assert not upd._step_graph.enabled  # whole-iteration capture stays off under DDP
+        assert not upd._step_graph.enabled  # capture stays off under torch's DDP and under gloo (host-synchronising collectives)
         for _ in range(3):
             upd.update()
         torch.cuda.synchronize()
@@ -62,11 +64,12 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_ema_net_ddp_two_ranks_share_one_gpu(device):
+@pytest.mark.parametrize("flavour", ["buckets", "ddp"])
+def test_ema_net_ddp_two_ranks_share_one_gpu(device, flavour):
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, flavour), nprocs=world, join=True)
     assert len(out) == world
     for rank in range(world):
         lockstep, finite, mu_per_rank, iterations = out[rank]
