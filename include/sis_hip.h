@@ -506,6 +506,12 @@ int sis_conv1x1_f32_dgrad_add(float* dx, const float* dy, const float* weight, c
 #define SIS_GEMM_EPI_BIAS_DROP_RESID 3
 #define SIS_GEMM_EPI_GELU_BWD 4
 #define SIS_GEMM_EPI_F32 5
+/* tile codes 9..11: 256 x 96 / 256 x 192 / 256 x 288 output tiles, one 8-wave workgroup per compute unit, register-double-
+ * buffered fragments over four LDS stages (csrc/gemm256_bf16.hip): layout NT only, splits == 1, k % 64 == 0, k >= 128, every
+ * epilogue except SIS_GEMM_EPI_F32.  8 192-token GEMMs of width 768 / 3072 / 2304 give 256 / 512 / 256 such tiles. */
+#define SIS_GEMM_TILE_256X96 9
+#define SIS_GEMM_TILE_256X192 10
+#define SIS_GEMM_TILE_256X288 11
 int64_t sis_gemm_bf16_workspace_bytes(int m, int n, int splits);
 int sis_gemm_bf16(void* c, void* c2, const void* a, const void* b, int layout, int epilogue, int m, int n, int k, int lda,
                   int ldb, int ldc, const float* bias, const float* bias1, const float* bias2, int bias_seg, const float* resid,
@@ -518,6 +524,12 @@ int sis_gemm_bf16(void* c, void* c2, const void* a, const void* b, int layout, i
  * workspace: sis_gemm_bf16_workspace_bytes(m, n, splits) + 64 * m * 4 bytes; tile 0 or 4..6. */
 int sis_gemm_bf16_wgrad_bias(void* dw, float* db, const void* grad, const void* x, int m, int n, int k, int lda, int ldb, int splits,
                              void* workspace, int64_t workspace_bytes, int tile, void* stream);
+
+/* Transposed bf16 copies of `n_tensors` matrices by one launch (csrc/vit_elementwise.hip): dst_i [cols_i][rows_i] =
+ * src_i [rows_i][cols_i]^T.  `table`: DEVICE array of n_tensors rows of 5 int64 {src, dst, rows, cols, first_tile} with
+ * first_tile = running sum of ceil(rows / 64) * ceil(cols / 64); total_tiles = the final sum.  Used for the transposed
+ * weight shadows that turn a Linear layer's data gradient into an NT product (sis_gemm_bf16 tiles 9..11). */
+int sis_transpose_bf16_multi(const void* table, int n_tensors, int total_tiles, void* stream);
 
 /* The same kernel over `batches` problems (grid.y): A / B / C of entry i start i * {a,b,c}_batch_stride elements after the base
  * pointers (stride 0 = shared operand).  With sum_over_batches != 0 the entries are the K slices of ONE result instead

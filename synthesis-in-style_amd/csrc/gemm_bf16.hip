@@ -28,6 +28,7 @@
 // slots of one group, so each A tile is fetched into one XCD's L2 once; the weights (<= 4.7 MB) stay L2 / MALL resident.
 #include <type_traits>
 #include "vit_common.h"
+#include "gemm256.h"
 
 namespace {
 
@@ -562,7 +563,20 @@ static int gemm_impl(void* c, void* c2, const void* a, const void* b, int layout
     p.drop_thr = sis_drop_thr16(drop_p);
     p.drop_scale = sis_drop_scale(p.drop_thr);
     SIS_REQUIRE(p.drop_thr == 0 || ((int64_t)n % 4 == 0), "sis_gemm_bf16: dropout quads need n % 4 == 0");
-    SIS_REQUIRE(tile >= 0 && tile < N_TILE_PLANS, "sis_gemm_bf16: tile code %d (0..%d)", tile, N_TILE_PLANS - 1);
+    if (tile >= SIS_GEMM_TILE_256X96 && tile <= SIS_GEMM_TILE_256X288) {
+        // 256-row tiles, one 8-wave workgroup per CU (gemm256_bf16.hip): NT layout, no split-K, K a multiple of 64 (>= 128)
+        SIS_REQUIRE(sis_gemm256_ok(layout, epilogue, k, splits) && batches == 1 && !batch_k && !colsum_out,
+                    "sis_gemm_bf16: tile %d (256 rows) serves the NT layout without split-K, k %% 64 == 0, k >= 128 (layout %d, k %d, splits %d)",
+                    tile, layout, k, splits);
+        G256Params g;
+        g.A = a; g.B = b; g.lda = lda; g.ldb = ldb; g.a_bytes = p.a_bytes; g.b_bytes = p.b_bytes; g.M = m; g.N = n; g.K = k;
+        g.C = c; g.C2 = c2; g.ldc = ldc; g.bias = bias; g.bias1 = bias1; g.bias2 = bias2; g.bias_seg = bias_seg; g.resid = resid;
+        g.pre = (const u16*)pre; g.seed = p.seed; g.site = p.site; g.drop_thr = p.drop_thr; g.drop_scale = p.drop_scale;
+        g.m_tiles = g.n_tiles = 0;
+        return sis_gemm256_dispatch(g, tile - SIS_GEMM_TILE_256X96 + 1, epilogue, (hipStream_t)stream);
+    }
+    SIS_REQUIRE(tile >= 0 && tile < N_TILE_PLANS, "sis_gemm_bf16: tile code %d (0..%d, or %d..%d for the 256-row tiles)", tile,
+                N_TILE_PLANS - 1, SIS_GEMM_TILE_256X96, SIS_GEMM_TILE_256X288);
     const int bm = TILE_PLANS[tile].bm, bn = TILE_PLANS[tile].bn, bk = TILE_PLANS[tile].bk;
     p.m_tiles = sis_cdiv(m, bm); p.n_tiles = sis_cdiv(n, bn);
     const int ksteps = sis_cdiv(k, bk);

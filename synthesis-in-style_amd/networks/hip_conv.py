@@ -151,9 +151,10 @@ class _Pointwise(Function):
     def _narrow(input, weight):
         """Output channels to append (zero filters) so that a layer with a handful of outputs -- EMANet's classifier fc2,
         256 -> num_classes -- runs on the MFMA kernels, whose forward wants Cout % 4 == 0 and whose data gradient contracts
-        over Cout in chunks of 32 (the bf16 path does the same for TransUNet's segmentation head); 0 when not applicable."""
+        over Cout in chunks of 32, and whose weight gradient takes 64 output channels per tile (the bf16 path does the same for
+        TransUNet's segmentation head); 0 when not applicable."""
         cout = weight.shape[0]
-        pad = (-cout) % 32
+        pad = (-cout) % 64
         if not (_F32_POINTWISE and pad and input.is_cuda and input.dtype == torch.float32 and weight.dtype == torch.float32):
             return 0
         return pad if sis_hip.conv1x1_f32_supported(input, weight.new_empty((cout + pad,) + tuple(weight.shape[1:]))) else 0

@@ -309,6 +309,7 @@ class Mlp(nn.Module):
 
 
 _FUSED_BLOCK = os.environ.get('SIS_FUSED_VIT', '1') != '0'  # 0: the module-by-module path (library GEMMs / attention)
+_GEMM256 = os.environ.get('SIS_GEMM256', '1') != '0'       # 0: forward / data-gradient GEMMs on the 128-wide tiles only (A/B runs)
 
 
 def _wgrad_plan(out_features, in_features):
@@ -399,32 +400,40 @@ class _FusedBlockFn(Function):
 
     @staticmethod
     def forward(ctx, x, cfg, wqkv, wo, w1, w2, ln1_w, ln1_b, q_w, k_w, v_w, q_b, k_b, v_b, o_w, o_b, ln2_w, ln2_b,
-                f1_w, f1_b, f2_w, f2_b):
+                f1_w, f1_b, f2_w, f2_b, wqkv_t=None, wo_t=None, w1_t=None, w2_t=None):
         S = sis_hip
         heads, eps, p_proj, p_mlp, site, seed = cfg
         b, n, hid = x.shape
         m = b * n
+        mlp = w1.shape[0]
         x2d = x.reshape(m, hid)
         h1, mean1, rstd1 = S.layer_norm_fwd(x2d, ln1_w, ln1_b, eps, torch.bfloat16)
-        # (128 x 96 tiles where the output width divides by 96: 768 -> 512 tiles, 2304 -> 1536 tiles at 8 192 tokens = whole
-        # rounds of 2 workgroups per CU; 128 x 128 leaves the last round a quarter full: 42.6 vs 46.3 us for the projection
-        # below, 46 vs 52 us for fc2, 21.7 vs 23.0 for the output projection)
+        # Tiles.  With >= ~200 of them (8 192 tokens) the 256-row tiles of csrc/gemm256_bf16.hip: 256 x 288 for the fused
+        # projection (256 tiles = one round of the chip), 256 x 96 for the 768-wide outputs (256 tiles), 256 x 192 for fc1
+        # (512).  Otherwise 128 x 96 where the output width divides by 96 (768 -> 512 tiles, 2304 -> 1536 tiles at 8 192
+        # tokens = whole rounds of 2 workgroups per CU; 128 x 128 leaves the last round a quarter full).
         t96 = 8 if hid % 96 == 0 else 0
-        qkv = S.gemm_bf16(h1, wqkv, S.GEMM_NT, S.EPI_BIAS, bias=(q_b, k_b, v_b), tile=t96)
+        pick = (lambda width, k, other: S.gemm_tile_256(m, width, k) or other) if _GEMM256 else (lambda width, k, other: other)
+        qkv = S.gemm_bf16(h1, wqkv, S.GEMM_NT, S.EPI_BIAS, bias=(q_b, k_b, v_b), tile=pick(3 * hid, hid, t96))
         att, lse = S.attention_fwd(qkv.view(b, n, 3 * hid), heads)
         att2d = att.view(m, hid)
-        x2 = S.gemm_bf16(att2d, wo, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=o_b, resid=x2d, seed=seed, site=site, drop_p=p_proj, tile=t96)
+        x2 = S.gemm_bf16(att2d, wo, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=o_b, resid=x2d, seed=seed, site=site, drop_p=p_proj,
+                         tile=pick(hid, hid, t96))
         h2, mean2, rstd2 = S.layer_norm_fwd(x2, ln2_w, ln2_b, eps, torch.bfloat16)
-        act, pre = S.gemm_bf16(h2, w1, S.GEMM_NT, S.EPI_BIAS_GELU_DROP, bias=f1_b, seed=seed, site=site + 1, drop_p=p_mlp)
-        x3 = S.gemm_bf16(act, w2, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=f2_b, resid=x2, seed=seed, site=site + 2, drop_p=p_mlp, tile=t96)
-        ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, pre, act, wqkv, wo, w1, w2, ln1_w, ln2_w)
+        act, pre = S.gemm_bf16(h2, w1, S.GEMM_NT, S.EPI_BIAS_GELU_DROP, bias=f1_b, seed=seed, site=site + 1, drop_p=p_mlp,
+                               tile=pick(mlp, hid, 0))
+        x3 = S.gemm_bf16(act, w2, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=f2_b, resid=x2, seed=seed, site=site + 2, drop_p=p_mlp,
+                         tile=pick(hid, mlp, t96))
+        ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, pre, act, wqkv, wo, w1, w2, ln1_w, ln2_w,
+                              wqkv_t, wo_t, w1_t, w2_t)
         ctx.cfg, ctx.shape = cfg, (b, n, hid)
         return x3.view(b, n, hid)
 
     @staticmethod
     def backward(ctx, grad):
         S = sis_hip
-        x2d, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, pre, act, wqkv, wo, w1, w2, ln1_w, ln2_w = ctx.saved_tensors
+        (x2d, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, pre, act, wqkv, wo, w1, w2, ln1_w, ln2_w,
+         wqkv_t, wo_t, w1_t, w2_t) = ctx.saved_tensors
         heads, eps, p_proj, p_mlp, site, seed = ctx.cfg
         b, n, hid = ctx.shape
         m = b * n
@@ -433,27 +442,36 @@ class _FusedBlockFn(Function):
             g3 = g3.float().contiguous()
         mlp = w1.shape[0]
         wg = _SideWgrads(g3.device)
+
+        def dgrad(g, w, w_t, epilogue=S.EPI_NONE, **kw):
+            """dL/dx = g W of a Linear layer y = x W^T: with the transposed weight shadow an NT product on the 256-row tiles
+            (the same kernel and tiles as the forward), otherwise the NN layout of csrc/gemm_bf16.hip."""
+            tile = S.gemm_tile_256(m, w.shape[1], w.shape[0]) if (w_t is not None and _GEMM256) else None
+            if tile is not None:
+                return S.gemm_bf16(g, w_t, S.GEMM_NT, epilogue, tile=tile, **kw)
+            return S.gemm_bf16(g, w, S.GEMM_NN, epilogue, **kw)
+
         # ---- MLP
         gl2 = S.dropout_bwd_cast(g3, seed, site + 2, p_mlp)                                   # d(fc2 output), bf16
         d_w2, d_b2 = wg.run(gl2, act, hid, mlp)
-        d_pre = S.gemm_bf16(gl2, w2, S.GEMM_NN, S.EPI_GELU_BWD, pre=pre, seed=seed, site=site + 1, drop_p=p_mlp)
+        d_pre = dgrad(gl2, w2, w2_t, S.EPI_GELU_BWD, pre=pre, seed=seed, site=site + 1, drop_p=p_mlp)
         d_w1, d_b1 = wg.run(d_pre, h2, mlp, hid)
-        d_h2 = S.gemm_bf16(d_pre, w1, S.GEMM_NN, S.EPI_NONE)
+        d_h2 = dgrad(d_pre, w1, w1_t)
         # LN2 backward + the skip connection's gradient, and d(out-projection output) = that sum through the proj dropout
         g2, d_ln2_w, d_ln2_b, gl1 = S.layer_norm_bwd_fused(d_h2, x2, mean2, rstd2, ln2_w, residual_grad=g3, cast_seed=seed,
                                                            cast_site=site, cast_p=p_proj)
         # ---- attention
         d_wo, d_bo = wg.run(gl1, att.view(m, hid), hid, hid)
-        d_att = S.gemm_bf16(gl1, wo, S.GEMM_NN, S.EPI_NONE)
+        d_att = dgrad(gl1, wo, wo_t)
         d_qkv = S.attention_bwd(d_att.view(b, n, hid), qkv.view(b, n, 3 * hid), att, lse, heads).view(m, 3 * hid)
         d_wqkv, d_bqkv = wg.run(d_qkv, h1, 3 * hid, hid)
-        d_h1 = S.gemm_bf16(d_qkv, wqkv, S.GEMM_NN, S.EPI_NONE)
+        d_h1 = dgrad(d_qkv, wqkv, wqkv_t)
         g1, d_ln1_w, d_ln1_b, _ = S.layer_norm_bwd_fused(d_h1, x2d, mean1, rstd1, ln1_w, residual_grad=g2)
         wg.join()
         d_q, d_k, d_v = d_wqkv.split(hid, 0)
         d_qb, d_kb, d_vb = d_bqkv.split(hid, 0)
         return (g1.view(b, n, hid), None, None, None, None, None, d_ln1_w, d_ln1_b, d_q, d_k, d_v, d_qb, d_kb, d_vb, d_wo, d_bo,
-                d_ln2_w, d_ln2_b, d_w1, d_b1, d_w2, d_b2)
+                d_ln2_w, d_ln2_b, d_w1, d_b1, d_w2, d_b2, None, None, None, None)
 
 
 class Embeddings(nn.Module):
@@ -505,6 +523,12 @@ class Block(nn.Module):
         self.attn = Attention(config, vis)
 
     block_index = 0   # set by the Encoder: numbers the block's three dropout sites (4 * index + 0 / 1 / 2)
+    _transposed = None   # set by the Encoder per training forward: transposed bf16 shadows (Wqkv^T, Wo^T, W1^T, W2^T) for the data gradients
+
+    def weight_shadow_tensors(self):
+        """The four bf16 weight shadows of the block, current (what _FusedBlockFn multiplies with)."""
+        la, lf = self.attn._shadows(), self.ffn._shadows()
+        return [la[0].tensor(), la[2].tensor(), lf[0].tensor(), lf[2].tensor()]
 
     def _fused_ok(self, x):
         a, f = self.attn, self.ffn
@@ -521,10 +545,11 @@ class Block(nn.Module):
             training = self.training
             cfg = (a.num_attention_heads, self.attention_norm.eps, a.proj_dropout.p if training else 0.0,
                    f.dropout.p if training else 0.0, 4 * self.block_index, sis_hip.dropout_seed(x.device))
+            wt = self._transposed if (self._transposed is not None and torch.is_grad_enabled()) else (None,) * 4
             y = _FusedBlockFn.apply(x, cfg, la[0].tensor(), la[2].tensor(), lf[0].tensor(), lf[2].tensor(),
                                     self.attention_norm.weight, self.attention_norm.bias, a.query.weight, a.key.weight,
                                     a.value.weight, a.query.bias, a.key.bias, a.value.bias, a.out.weight, a.out.bias,
-                                    self.ffn_norm.weight, self.ffn_norm.bias, f.fc1.weight, f.fc1.bias, f.fc2.weight, f.fc2.bias)
+                                    self.ffn_norm.weight, self.ffn_norm.bias, f.fc1.weight, f.fc1.bias, f.fc2.weight, f.fc2.bias, *wt)
             return y, None
         a, weights = self.attn(self.attention_norm(x))
         x = x + a
@@ -547,12 +572,34 @@ class Encoder(nn.Module):
             block.block_index = i
             self.layer.append(block)
 
+    _bank = None   # sis_hip.TransposeBank over every block's four weight shadows
+
+    def _refresh_transposed_shadows(self, hidden_states):
+        """Data gradients as NT products (csrc/gemm256_bf16.hip) need W^T: all 4 x 12 transposes by one launch per forward that
+        will be differentiated (the optimizer rewrites the shadows every step; inside a captured iteration the launch is
+        replayed with them)."""
+        use = (_GEMM256 and torch.is_grad_enabled() and len(self.layer) > 0 and self.layer[0]._fused_ok(hidden_states)
+               and sis_hip.gemm_tile_256(hidden_states.shape[0] * hidden_states.shape[1], self.layer[0].hidden_size,
+                                         self.layer[0].hidden_size) is not None)
+        if not use:
+            for block in self.layer:
+                block._transposed = None
+            return
+        sources = [t for block in self.layer for t in block.weight_shadow_tensors()]
+        if self._bank is None or not self._bank.current(sources):
+            self._bank = sis_hip.TransposeBank(sources)
+        self._bank.refresh()
+        for i, block in enumerate(self.layer):
+            block._transposed = tuple(self._bank.out[4 * i:4 * i + 4])
+
     def forward(self, hidden_states):
         attn_weights = []
         if self.training and hidden_states.is_cuda and _FUSED_BLOCK:
             # one step of the device seed word per forward: every dropout site of the fused blocks reads it (and their
             # backward reads it again); a captured hipGraph of the iteration replays this launch too
             sis_hip.dropout_advance(sis_hip.dropout_seed(hidden_states.device))
+        if hidden_states.is_cuda:
+            self._refresh_transposed_shadows(hidden_states)
         for block in self.layer:
             hidden_states, weights = block(hidden_states)
             if self.vis:

@@ -91,6 +91,7 @@ _SIGNATURES = {
     "sis_sgd_momentum": ([_vp, _i, ctypes.POINTER(_f), ctypes.POINTER(_f), _i, _f, _i, _vp], _i),
     "sis_sgd_momentum_dev": ([_vp, _i, _vp, _vp], _i),
     "sis_ema_update": ([_vp, _vp, _f, _f, _i, _i, _vp], _i),
+    "sis_transpose_bf16_multi": ([_vp, _i, _i, _vp], _i),
     "sis_emau_supported": ([_i] * 4, _i),
     "sis_emau_workspace_floats": ([_i] * 4, _i64),
     "sis_emau_forward": ([_vp] * 5 + [_i] * 5 + [_vp], _i),
@@ -908,6 +909,34 @@ class WeightStdPackBank:
                    "sis_weight_std_pack_multi")
 
 
+class TransposeBank:
+    """Transposed bf16 copies of a list of 2-D bf16 matrices, refreshed by ONE launch (``sis_transpose_bf16_multi``).
+    ``out[i]`` ([cols, rows]) keep their addresses; ``refresh()`` rewrites their contents from the sources."""
+
+    def __init__(self, sources):
+        self.sources = list(sources)
+        dev = self.sources[0].device
+        self.out, rows, first = [], [], 0
+        for s in self.sources:
+            if s.dtype != torch.bfloat16 or s.dim() != 2 or not s.is_contiguous():
+                raise RuntimeError("TransposeBank: sources must be contiguous 2-D bfloat16 tensors")
+            r, c = s.shape
+            self.out.append(torch.empty((c, r), dtype=torch.bfloat16, device=dev))
+            rows.append([s.data_ptr(), self.out[-1].data_ptr(), r, c, first])
+            first += -(-r // 64) * -(-c // 64)
+        self.total_tiles = first
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.source_ptrs = [s.data_ptr() for s in self.sources]
+
+    def current(self, sources):
+        return len(sources) == len(self.source_ptrs) and all(s.data_ptr() == p for s, p in zip(sources, self.source_ptrs))
+
+    def refresh(self):
+        with torch.cuda.device(self.table.device):
+            _check(lib().sis_transpose_bf16_multi(_ptr(self.table), len(self.sources), self.total_tiles, _stream()),
+                   "sis_transpose_bf16_multi")
+
+
 def conv1x1_bf16_wgrad_supported(batch, cin, cout, pixels):
     return bool(lib().sis_conv1x1_bf16_wgrad_supported(batch, cin, cout, pixels, WORKSPACE_BYTES))
 
@@ -934,6 +963,21 @@ def conv1x1_bf16_wgrad(x, grad_output, out_dtype=torch.float32):
 # ------------------------------------------------------------------------------ bf16 GEMM with fused epilogues (ViT encoder)
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+TILE_256X96, TILE_256X192, TILE_256X288 = 9, 10, 11   # 256-row tiles of csrc/gemm256_bf16.hip (NT layout, no split-K)
+
+
+def gemm_tile_256(m, n, k):
+    """Tile code of the 256-row GEMM kernel for an [m, n] output contracted over k, or None when the 128-wide tiles of
+    csrc/gemm_bf16.hip suit the shape better: the widest of 256 x 288 / 192 / 96 that divides n and still leaves at least
+    ~200 tiles for the 256 compute units (8 192 tokens: n = 2304 -> 256 tiles of 256 x 288, 3072 -> 512 of 256 x 192,
+    768 -> 256 of 256 x 96)."""
+    if k % 64 or k < 128 or n % 4:
+        return None
+    m_tiles = -(-m // 256)
+    for code, width in ((TILE_256X288, 288), (TILE_256X192, 192), (TILE_256X96, 96)):
+        if n % width == 0 and m_tiles * (n // width) >= 200:
+            return code
+    return None
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_DROP, EPI_BIAS_DROP_RESID, EPI_GELU_BWD, EPI_F32 = range(6)
 
 
@@ -988,7 +1032,7 @@ def gemm_bf16(a, b, layout, epilogue=EPI_NONE, bias=None, resid=None, pre=None, 
             if ws is None:
                 ws = _workspaces[(a.device, stream.cuda_stream)] = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=a.device)
         ws_bytes = ws.numel()
-    name = f"gemm_bf16<{('NT', 'NN', 'TN')[layout]},{epilogue}>"
+    name = f"gemm_bf16<{('NT', 'NN', 'TN')[layout]},{epilogue}>" if tile < TILE_256X96 else f"gemm256<{(96, 192, 288)[tile - TILE_256X96]},{epilogue}>"
     with torch.cuda.device(a.device):
         _check(_launch(name, 2.0 * m * n * k, 2.0 * (m * k + n * k) + c.element_size() * m * n,
                        lambda: lib().sis_gemm_bf16(_ptr(c), _ptr(c2), _ptr(a), _ptr(b), layout, epilogue, m, n, k, a.stride(0),

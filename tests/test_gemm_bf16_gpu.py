@@ -202,3 +202,82 @@ def test_gemm_batched_as_pointwise_convolution(device, batch, cin, cout, hw):
         assert dw.dtype == torch.float32 and tuple(dw.shape) == (cout, cin)
         _close(dw, wr.grad.view(cout, cin), F32_TOL)
         assert torch.equal(dw, S.gemm_bf16_batched(gd, xd, S.GEMM_NT, S.EPI_F32, sum_over_batches=True))
+
+
+# ---- the 256-row tiles (csrc/gemm256_bf16.hip): NT layout, every bf16 / fp32-residual epilogue, whole and ragged tiles
+G256_CASES = [(256, 96, 128), (512, 288, 768), (1024, 768, 768), (768, 2304, 768), (512, 3072, 768), (1024, 768, 3072),
+              (300, 100, 192), (8192, 768, 128), (260, 580, 2304), (64, 96, 256)]
+
+
+@pytest.mark.parametrize("tile", [9, 10, 11])
+@pytest.mark.parametrize("m,n,k", G256_CASES)
+def test_gemm256_nt_epilogues(device, m, n, k, tile):
+    """One 8-wave workgroup per 256 x 96 / 192 / 288 output tile, fragments double-buffered in registers over four LDS stages:
+    the same results as the 128-wide tiles (and the fp32 CPU product) for every epilogue the encoder uses, including ragged
+    row / column tiles (rows beyond M and N read as zeros through the buffer range check) and the shortest K loop (4 steps)."""
+    import sis_hip as S
+    gen = torch.Generator().manual_seed(m * 7 + n * 3 + k + tile)
+    x, w = _rand((m, k), gen), _rand((n, k), gen, k ** -0.5)
+    bias = torch.randn(n, generator=gen)
+    resid = torch.randn(m, n, generator=gen)
+    pre_in = _rand((m, n), gen)
+    xd, wd, bd, rd, pd = x.to(device), w.to(device), bias.to(device), resid.to(device), pre_in.to(device)
+    y = x.float() @ w.float().t()
+    _close(S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_NONE, tile=tile), y, BF16_TOL)
+    _close(S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS, bias=bd, tile=tile), y + bias, BF16_TOL)
+    out, pre = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_GELU_DROP, bias=bd, tile=tile)
+    _close(pre, y + bias, BF16_TOL)
+    _close(out, _gelu(pre.float().cpu()), BF16_TOL)
+    res = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=bd, resid=rd, tile=tile)
+    assert res.dtype == torch.float32
+    _close(res, resid + y + bias, F32_TOL * 4)
+    _close(S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_GELU_BWD, pre=pd, tile=tile), y * _gelu_grad(pre_in.float()), BF16_TOL)
+    # bitwise the 128-wide kernel's result: both accumulate the K steps in order in fp32 and round once
+    assert torch.equal(S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS, bias=bd, tile=tile), S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS, bias=bd, tile=0))
+    if n % 12 == 0:   # three bias segments (query | key | value)
+        seg = n // 3
+        b3 = (bd[:seg].contiguous(), bd[seg:2 * seg].contiguous(), bd[2 * seg:].contiguous())
+        _close(S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS, bias=b3, tile=tile), y + bias, BF16_TOL)
+
+
+def test_gemm256_dropout_masks_match_the_128_wide_kernel(device):
+    """The dropout stream is a function of (seed, site, element index): the 256-row tiles must draw the masks the other kernels
+    (and the backward's recomputation) draw."""
+    import sis_hip as S
+    gen = torch.Generator().manual_seed(9)
+    m, n, k = 512, 768, 768
+    x, w = _rand((m, k), gen).to(device), _rand((n, k), gen, k ** -0.5).to(device)
+    bias, resid = torch.randn(n, generator=gen).to(device), torch.randn(m, n, generator=gen).to(device)
+    seed = S.dropout_seed(device)
+    a = S.gemm_bf16(x, w, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=bias, resid=resid, seed=seed, site=5, drop_p=0.1, tile=9)
+    b = S.gemm_bf16(x, w, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=bias, resid=resid, seed=seed, site=5, drop_p=0.1, tile=0)
+    assert torch.equal(a, b)
+    o1, p1 = S.gemm_bf16(x, w, S.GEMM_NT, S.EPI_BIAS_GELU_DROP, bias=bias, seed=seed, site=6, drop_p=0.1, tile=9)
+    o0, p0 = S.gemm_bf16(x, w, S.GEMM_NT, S.EPI_BIAS_GELU_DROP, bias=bias, seed=seed, site=6, drop_p=0.1, tile=0)
+    assert torch.equal(o1, o0) and torch.equal(p1, p0)
+    dropped = (o1 == 0).float().mean().item()
+    assert 0.08 < dropped < 0.13
+
+
+def test_gemm256_rejects_what_it_does_not_serve(device):
+    import sis_hip as S
+    x, w = torch.zeros(256, 96, dtype=torch.bfloat16, device=device), torch.zeros(96, 96, dtype=torch.bfloat16, device=device)
+    with pytest.raises(RuntimeError, match="256 rows"):
+        S.gemm_bf16(x, w, S.GEMM_NT, S.EPI_NONE, tile=9)          # k = 96: not a multiple of 64
+    with pytest.raises(RuntimeError, match="256 rows"):
+        S.gemm_bf16(x[:, :64].contiguous(), w[:, :64].contiguous(), S.GEMM_NT, S.EPI_NONE, tile=10)   # k = 64 < 128
+    assert S.gemm_tile_256(8192, 2304, 768) == S.TILE_256X288 and S.gemm_tile_256(8192, 3072, 768) == S.TILE_256X192
+    assert S.gemm_tile_256(8192, 768, 3072) == S.TILE_256X96 and S.gemm_tile_256(2048, 768, 768) is None
+
+
+def test_transpose_bank(device):
+    import sis_hip as S
+    gen = torch.Generator().manual_seed(3)
+    mats = [_rand(s, gen).to(device) for s in ((2304, 768), (768, 768), (3072, 768), (768, 3072), (70, 130), (64, 64))]
+    bank = S.TransposeBank(mats)
+    bank.refresh()
+    for src, dst in zip(mats, bank.out):
+        assert torch.equal(dst, src.t().contiguous())
+    mats[1].mul_(2)
+    bank.refresh()
+    assert torch.equal(bank.out[1], mats[1].t().contiguous()) and bank.current(mats)
