@@ -262,10 +262,13 @@ def test_gemm256_dropout_masks_match_the_128_wide_kernel(device):
 def test_gemm256_rejects_what_it_does_not_serve(device):
     import sis_hip as S
     x, w = torch.zeros(256, 96, dtype=torch.bfloat16, device=device), torch.zeros(96, 96, dtype=torch.bfloat16, device=device)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        S.gemm_bf16(x, w, S.GEMM_NT, S.EPI_NONE, tile=9)          # k = 96: not a multiple of 64 (the layout's own rule)
     with pytest.raises(RuntimeError, match="256 rows"):
-        S.gemm_bf16(x, w, S.GEMM_NT, S.EPI_NONE, tile=9)          # k = 96: not a multiple of 64
+        S.gemm_bf16(x[:, :64].contiguous(), w[:, :64].contiguous(), S.GEMM_NT, S.EPI_NONE, tile=10)   # k = 64 < 128: fewer than 4 K steps
     with pytest.raises(RuntimeError, match="256 rows"):
-        S.gemm_bf16(x[:, :64].contiguous(), w[:, :64].contiguous(), S.GEMM_NT, S.EPI_NONE, tile=10)   # k = 64 < 128
+        S.gemm_bf16(torch.zeros(128, 256, dtype=torch.bfloat16, device=device), torch.zeros(128, 96, dtype=torch.bfloat16, device=device),
+                    S.GEMM_NN, S.EPI_NONE, tile=11)               # the NN layout stays on the 128-wide tiles
     assert S.gemm_tile_256(8192, 2304, 768) == S.TILE_256X288 and S.gemm_tile_256(8192, 3072, 768) == S.TILE_256X192
     assert S.gemm_tile_256(8192, 768, 3072) == S.TILE_256X96 and S.gemm_tile_256(2048, 768, 768) is None
 
