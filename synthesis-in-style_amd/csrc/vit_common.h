@@ -16,7 +16,7 @@ typedef __attribute__((ext_vector_type(16))) float sis_f32x16;
 // device memory (advanced once per training step by sis_dropout_advance), which keeps a captured hipGraph of the step
 // drawing fresh masks on every replay.
 // Reference: nn.Dropout(config.transformer["dropout_rate"]) in networks/trans_u_net/vit_seg_modeling.py:70-71,108,138
-// (torch's Philox stream there; any independent uniform stream is the same operator).
+// (torch's Philox stream there; another stream of independent uniforms is the same operator in distribution).
 struct SisDropKey { unsigned s0, s1; };
 
 __device__ __forceinline__ SisDropKey sis_drop_key(const unsigned long long* seed, unsigned site) {
@@ -34,8 +34,11 @@ __host__ __device__ __forceinline__ float sis_drop_scale(unsigned thr16) { retur
 __device__ __forceinline__ void sis_drop_quad(SisDropKey k, unsigned quad, unsigned thr16, float scale, float* f) {
     unsigned h = quad * 0x9E3779B1u + k.s0;
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;   // murmur3 finaliser: a bijection of quad
-    unsigned h2 = (h ^ k.s1) * 0x27D4EB2Fu;
-    h2 ^= h2 >> 15;
+    // the second pair of uniforms comes from an INDEPENDENT mix of (quad, s1) -- a second finaliser with other constants on
+    // another affine image of quad -- not from h: elements 2, 3 of a quad must not be functions of elements 0, 1 (ADVICE r3;
+    // tests/test_gemm_bf16_gpu.py::test_dropout_quads_are_pairwise_independent checks the joint drop frequencies)
+    unsigned h2 = quad * 0xC2B2AE3Du + k.s1;
+    h2 ^= h2 >> 15; h2 *= 0x2C1B3C6Du; h2 ^= h2 >> 12; h2 *= 0x297A2D39u; h2 ^= h2 >> 15;
     f[0] = (h & 0xFFFFu) < thr16 ? 0.f : scale;
     f[1] = (h >> 16) < thr16 ? 0.f : scale;
     f[2] = (h2 & 0xFFFFu) < thr16 ? 0.f : scale;

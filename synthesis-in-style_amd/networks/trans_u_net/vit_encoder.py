@@ -523,6 +523,7 @@ class Block(nn.Module):
         self.attn = Attention(config, vis)
 
     block_index = 0   # set by the Encoder: numbers the block's three dropout sites (4 * index + 0 / 1 / 2)
+    _seed = None         # set by the Encoder per training forward: THIS forward's snapshot of the dropout seed word
     _transposed = None   # set by the Encoder per training forward: transposed bf16 shadows (Wqkv^T, Wo^T, W1^T, W2^T) for the data gradients
 
     def weight_shadow_tensors(self):
@@ -543,8 +544,9 @@ class Block(nn.Module):
             a, f = self.attn, self.ffn
             la, lf = a._shadows(), f._shadows()
             training = self.training
+            seed = self._seed if self._seed is not None else sis_hip.dropout_seed(x.device)
             cfg = (a.num_attention_heads, self.attention_norm.eps, a.proj_dropout.p if training else 0.0,
-                   f.dropout.p if training else 0.0, 4 * self.block_index, sis_hip.dropout_seed(x.device))
+                   f.dropout.p if training else 0.0, 4 * self.block_index, seed)
             wt = self._transposed if (self._transposed is not None and torch.is_grad_enabled()) else (None,) * 4
             y = _FusedBlockFn.apply(x, cfg, la[0].tensor(), la[2].tensor(), lf[0].tensor(), lf[2].tensor(),
                                     self.attention_norm.weight, self.attention_norm.bias, a.query.weight, a.key.weight,
@@ -597,7 +599,17 @@ class Encoder(nn.Module):
         if self.training and hidden_states.is_cuda and _FUSED_BLOCK:
             # one step of the device seed word per forward: every dropout site of the fused blocks reads it (and their
             # backward reads it again); a captured hipGraph of the iteration replays this launch too
-            sis_hip.dropout_advance(sis_hip.dropout_seed(hidden_states.device))
+            word = sis_hip.dropout_seed(hidden_states.device)
+            sis_hip.dropout_advance(word)
+            # Snapshot per forward (one 8-byte device copy, a graph node like the advance): the backward recomputes the masks
+            # from the word its OWN forward read, also when another training forward ran in between (gradient accumulation,
+            # two forwards then two backwards, a second TransUNet on the device) -- ADVICE r3.
+            snapshot = word.clone()
+            for block in self.layer:
+                block._seed = snapshot
+        else:
+            for block in self.layer:
+                block._seed = None
         if hidden_states.is_cuda:
             self._refresh_transposed_shadows(hidden_states)
         for block in self.layer:

@@ -267,7 +267,7 @@ def test_gemm256_rejects_what_it_does_not_serve(device):
     with pytest.raises(RuntimeError, match="256 rows"):
         S.gemm_bf16(x[:, :64].contiguous(), w[:, :64].contiguous(), S.GEMM_NT, S.EPI_NONE, tile=10)   # k = 64 < 128: fewer than 4 K steps
     with pytest.raises(RuntimeError, match="256 rows"):
-        S.gemm_bf16(torch.zeros(128, 256, dtype=torch.bfloat16, device=device), torch.zeros(128, 96, dtype=torch.bfloat16, device=device),
+        S.gemm_bf16(torch.zeros(128, 256, dtype=torch.bfloat16, device=device), torch.zeros(256, 96, dtype=torch.bfloat16, device=device),
                     S.GEMM_NN, S.EPI_NONE, tile=11)               # the NN layout stays on the 128-wide tiles
     assert S.gemm_tile_256(8192, 2304, 768) == S.TILE_256X288 and S.gemm_tile_256(8192, 3072, 768) == S.TILE_256X192
     assert S.gemm_tile_256(8192, 768, 3072) == S.TILE_256X96 and S.gemm_tile_256(2048, 768, 768) is None
@@ -284,3 +284,22 @@ def test_transpose_bank(device):
     mats[1].mul_(2)
     bank.refresh()
     assert torch.equal(bank.out[1], mats[1].t().contiguous()) and bank.current(mats)
+
+
+def test_dropout_quads_are_pairwise_independent(device):
+    """the four uniforms of a quad must be independent -- the joint drop frequency of every element pair of a quad is
+    p^2 (here p = 0.3: 0.09 +- 3 sigma of 2 M quads), including the pairs (0, 2) and (1, 3) whose second member used to be a
+    function of the first."""
+    import sis_hip as S
+    m, n, p = 8192, 1024, 0.3
+    g = torch.ones(m, n, device=device)
+    seed = torch.tensor([2024], dtype=torch.int64, device=device)
+    dropped = (S.dropout_bwd_cast(g, seed, 7, p) == 0).view(-1, 4).float()
+    marg = dropped.mean(0)
+    assert (marg - p).abs().max().item() < 2e-3, marg
+    quads = dropped.shape[0]
+    tol = 4 * (p * p * (1 - p * p) / quads) ** 0.5
+    for i in range(4):
+        for j in range(i + 1, 4):
+            joint = (dropped[:, i] * dropped[:, j]).mean().item()
+            assert abs(joint - p * p) < tol, (i, j, joint)

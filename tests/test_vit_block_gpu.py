@@ -91,3 +91,33 @@ def test_wgrad_plan_and_sites():
     from networks.trans_u_net import vit_encoder as V
     assert V._wgrad_plan(2304, 768) == (4, 0) and V._wgrad_plan(768, 768) == (8, 0)
     assert V._wgrad_plan(3072, 768) == (4, 4) and V._wgrad_plan(768, 3072) == (4, 4)
+
+
+def test_two_forwards_then_two_backwards_use_their_own_dropout_masks(device):
+    """every training forward of the encoder snapshots the dropout seed word it read, so a backward that runs after
+    ANOTHER forward (gradient accumulation: forward, forward, backward, backward) still recomputes its own masks: the
+    gradients equal those of forward-backward, forward-backward on the same two seed words."""
+    import sis_hip
+    from networks.trans_u_net import vit_encoder as V
+    cfg = _config(0.1)
+    cfg.transformer["num_layers"] = 2
+    torch.manual_seed(7)
+    enc = V.Encoder(cfg, vis=False).to(device).train()
+    xa, xb = torch.randn(2, 128, 768, device=device), torch.randn(2, 128, 768, device=device)
+    word = sis_hip.dropout_seed(device)
+
+    def grads(interleaved):
+        word.fill_(4242)
+        enc.zero_grad(set_to_none=True)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            if interleaved:
+                ya, yb = enc(xa)[0], enc(xb)[0]
+                ya.square().mean().backward()
+                yb.square().mean().backward()
+            else:
+                enc(xa)[0].square().mean().backward()
+                enc(xb)[0].square().mean().backward()
+        return [p.grad.clone() for p in enc.parameters()]
+
+    for u, v in zip(grads(False), grads(True)):
+        assert torch.equal(u, v)
