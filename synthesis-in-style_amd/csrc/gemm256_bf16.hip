@@ -207,22 +207,107 @@ __global__ __launch_bounds__(C::THREADS) void gemm256_kernel(G256Params p) {
     constexpr bool HAS_DROP = EPI == SIS_GEMM_EPI_BIAS_GELU_DROP || EPI == SIS_GEMM_EPI_BIAS_DROP_RESID || EPI == SIS_GEMM_EPI_GELU_BWD;
     if constexpr (HAS_DROP)
         if (p.drop_thr) key = sis_drop_key(p.seed, p.site);
+    constexpr bool BF16_OUT = EPI != SIS_GEMM_EPI_BIAS_DROP_RESID;
+    auto bias_of = [&](int n, bool n_ok) {
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (HAS_BIAS)
+            if (n_ok) {
+                const float* bp = p.bias + n;
+                if (p.bias_seg) {   // query | key | value biases stay three parameters (a lane's 4 columns never straddle two)
+                    if (n >= 2 * p.bias_seg) bp = p.bias2 + (n - 2 * p.bias_seg);
+                    else if (n >= p.bias_seg) bp = p.bias1 + (n - p.bias_seg);
+                }
+                bq = *reinterpret_cast<const float4*>(bp);
+            }
+        return bq;
+    };
+    // bf16 results of one 16 x 16 block for this lane: o0 -> C (4 columns), o1 -> C2 (the pre-activation of BIAS_GELU_DROP)
+    auto block_bf16 = [&](int tn, int tm, int m, int n, const float4& bq, const uint2& hpre, uint2& o0, uint2& o1) {
+        float keep[4] = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (HAS_DROP)
+            if (p.drop_thr) sis_drop_quad(key, ((unsigned)m * (unsigned)p.N + (unsigned)n) >> 2, p.drop_thr, p.drop_scale, keep);
+        float v[4] = {acc[tn][tm][0] + bq.x, acc[tn][tm][1] + bq.y, acc[tn][tm][2] + bq.z, acc[tn][tm][3] + bq.w};
+        if constexpr (EPI == SIS_GEMM_EPI_NONE || EPI == SIS_GEMM_EPI_BIAS) {
+            o0 = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
+        } else if constexpr (EPI == SIS_GEMM_EPI_BIAS_GELU_DROP) {
+            o1 = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));   // the activation is evaluated AT the stored bf16 value
+            float y[4] = {sis_gelu(sis_bf16_lo(o1.x)), sis_gelu(sis_bf16_hi(o1.x)), sis_gelu(sis_bf16_lo(o1.y)), sis_gelu(sis_bf16_hi(o1.y))};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] *= keep[e];
+            o0 = make_uint2(sis_pack_bf16x2(y[0], y[1]), sis_pack_bf16x2(y[2], y[3]));
+        } else {   // SIS_GEMM_EPI_GELU_BWD: gradient w.r.t. the pre-activation: acc * dropout factor * gelu'(pre)
+            const float d[4] = {sis_gelu_grad(sis_bf16_lo(hpre.x)), sis_gelu_grad(sis_bf16_hi(hpre.x)),
+                                sis_gelu_grad(sis_bf16_lo(hpre.y)), sis_gelu_grad(sis_bf16_hi(hpre.y))};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= d[e] * keep[e];
+            o0 = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
+        }
+    };
     auto epilogue = [&](auto checked_t) {
         constexpr bool CHECKED = decltype(checked_t)::value;
+        if constexpr (BF16_OUT && !CHECKED) {
+            // Whole tiles, bf16 results: 16-byte stores.  A lane holds 4 consecutive columns of a block (8 bytes); the lanes of
+            // rows g and g ^ 1 (16 lanes apart) exchange halves of a PAIR of column blocks through v_permlane16_swap, after
+            // which an even-g lane holds 8 consecutive columns of the first block and an odd-g lane 8 of the second: half the
+            // store instructions, each twice as wide (a workgroup alone on its CU cannot hide its store tail behind another's
+            // matrix work: the epilogue's instruction count is wall time here).
+            if ((p.ldc & 7) == 0) {
+                const int colpair = 4 * (g & 2);   // 0, 0, 8, 8
+#pragma unroll
+                for (int tn = 0; tn + 1 < NB; tn += 2) {
+                    const int na = n0 + wn * C::WNC + 16 * tn + 4 * g, nb = na + 16;
+                    const float4 bqa = bias_of(na, true), bqb = bias_of(nb, true);
+                    uint2 ha[4], hb[4];
+#pragma unroll
+                    for (int tm = 0; tm < 4; ++tm) {
+                        const long long row = (long long)(m0 + wm * 64 + 16 * tm + i16) * p.ldc;
+                        if constexpr (EPI == SIS_GEMM_EPI_GELU_BWD) {
+                            ha[tm] = *reinterpret_cast<const uint2*>(p.pre + row + na);
+                            hb[tm] = *reinterpret_cast<const uint2*>(p.pre + row + nb);
+                        }
+                    }
+#pragma unroll
+                    for (int tm = 0; tm < 4; ++tm) {
+                        const int m = m0 + wm * 64 + 16 * tm + i16;
+                        uint2 a0, a1, b0, b1;
+                        block_bf16(tn, tm, m, na, bqa, ha[tm], a0, a1);
+                        block_bf16(tn + 1, tm, m, nb, bqb, hb[tm], b0, b1);
+                        const long long at = (long long)m * p.ldc + n0 + wn * C::WNC + 16 * (tn + (g & 1)) + colpair;
+                        {
+                            const auto sx = __builtin_amdgcn_permlane16_swap(a0.x, b0.x, false, false);
+                            const auto sy = __builtin_amdgcn_permlane16_swap(a0.y, b0.y, false, false);
+                            *reinterpret_cast<uint4*>((u16*)p.C + at) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                        }
+                        if constexpr (EPI == SIS_GEMM_EPI_BIAS_GELU_DROP) {
+                            const auto sx = __builtin_amdgcn_permlane16_swap(a1.x, b1.x, false, false);
+                            const auto sy = __builtin_amdgcn_permlane16_swap(a1.y, b1.y, false, false);
+                            *reinterpret_cast<uint4*>((u16*)p.C2 + at) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                        }
+                    }
+                }
+                if constexpr (NB & 1) {   // the unpaired last block: 8-byte stores
+                    constexpr int tn = NB - 1;
+                    const int n = n0 + wn * C::WNC + 16 * tn + 4 * g;
+                    const float4 bq = bias_of(n, true);
+#pragma unroll
+                    for (int tm = 0; tm < 4; ++tm) {
+                        const int m = m0 + wm * 64 + 16 * tm + i16;
+                        const long long at = (long long)m * p.ldc + n;
+                        uint2 hpre = make_uint2(0u, 0u), o0, o1;
+                        if constexpr (EPI == SIS_GEMM_EPI_GELU_BWD) hpre = *reinterpret_cast<const uint2*>(p.pre + at);
+                        block_bf16(tn, tm, m, n, bq, hpre, o0, o1);
+                        *reinterpret_cast<uint2*>((u16*)p.C + at) = o0;
+                        if constexpr (EPI == SIS_GEMM_EPI_BIAS_GELU_DROP) *reinterpret_cast<uint2*>((u16*)p.C2 + at) = o1;
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int tn = 0; tn < NB; ++tn) {
             const int n = n0 + wn * C::WNC + 16 * tn + 4 * g;
             const bool n_ok = !CHECKED || n < p.N;
-            float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (HAS_BIAS)
-                if (n_ok) {
-                    const float* bp = p.bias + n;
-                    if (p.bias_seg) {   // query | key | value biases stay three parameters (a lane's 4 columns never straddle two)
-                        if (n >= 2 * p.bias_seg) bp = p.bias2 + (n - 2 * p.bias_seg);
-                        else if (n >= p.bias_seg) bp = p.bias1 + (n - p.bias_seg);
-                    }
-                    bq = *reinterpret_cast<const float4*>(bp);
-                }
+            const float4 bq = bias_of(n, n_ok);
             float4 r[4];
             uint2 h[4];
 #pragma unroll
@@ -237,31 +322,19 @@ __global__ __launch_bounds__(C::THREADS) void gemm256_kernel(G256Params p) {
                 const int m = m0 + wm * 64 + 16 * tm + i16;
                 const bool ok = n_ok && (!CHECKED || m < p.M);
                 const long long at = (long long)m * p.ldc + n;
-                float keep[4] = {1.f, 1.f, 1.f, 1.f};
-                if constexpr (HAS_DROP)
-                    if (p.drop_thr) sis_drop_quad(key, ((unsigned)m * (unsigned)p.N + (unsigned)n) >> 2, p.drop_thr, p.drop_scale, keep);
-                float v[4] = {acc[tn][tm][0] + bq.x, acc[tn][tm][1] + bq.y, acc[tn][tm][2] + bq.z, acc[tn][tm][3] + bq.w};
-                if constexpr (EPI == SIS_GEMM_EPI_NONE || EPI == SIS_GEMM_EPI_BIAS) {
-                    if (ok) *reinterpret_cast<uint2*>((u16*)p.C + at) = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
-                } else if constexpr (EPI == SIS_GEMM_EPI_BIAS_GELU_DROP) {
-                    const uint2 hp = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
-                    float y[4] = {sis_gelu(sis_bf16_lo(hp.x)), sis_gelu(sis_bf16_hi(hp.x)), sis_gelu(sis_bf16_lo(hp.y)), sis_gelu(sis_bf16_hi(hp.y))};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] *= keep[e];
+                if constexpr (BF16_OUT) {
+                    uint2 o0, o1;
+                    block_bf16(tn, tm, m, n, bq, h[tm], o0, o1);
                     if (ok) {
-                        *reinterpret_cast<uint2*>((u16*)p.C2 + at) = hp;
-                        *reinterpret_cast<uint2*>((u16*)p.C + at) = make_uint2(sis_pack_bf16x2(y[0], y[1]), sis_pack_bf16x2(y[2], y[3]));
+                        *reinterpret_cast<uint2*>((u16*)p.C + at) = o0;
+                        if constexpr (EPI == SIS_GEMM_EPI_BIAS_GELU_DROP) *reinterpret_cast<uint2*>((u16*)p.C2 + at) = o1;
                     }
-                } else if constexpr (EPI == SIS_GEMM_EPI_BIAS_DROP_RESID) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= keep[e];
+                } else {   // SIS_GEMM_EPI_BIAS_DROP_RESID: fp32 residual stream, 16 bytes per lane and block already
+                    float keep[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (p.drop_thr) sis_drop_quad(key, ((unsigned)m * (unsigned)p.N + (unsigned)n) >> 2, p.drop_thr, p.drop_scale, keep);
+                    const float v[4] = {(acc[tn][tm][0] + bq.x) * keep[0], (acc[tn][tm][1] + bq.y) * keep[1],
+                                        (acc[tn][tm][2] + bq.z) * keep[2], (acc[tn][tm][3] + bq.w) * keep[3]};
                     if (ok) *reinterpret_cast<float4*>((float*)p.C + at) = make_float4(r[tm].x + v[0], r[tm].y + v[1], r[tm].z + v[2], r[tm].w + v[3]);
-                } else {   // SIS_GEMM_EPI_GELU_BWD: gradient w.r.t. the pre-activation: acc * dropout factor * gelu'(pre)
-                    const float d[4] = {sis_gelu_grad(sis_bf16_lo(h[tm].x)), sis_gelu_grad(sis_bf16_hi(h[tm].x)),
-                                        sis_gelu_grad(sis_bf16_lo(h[tm].y)), sis_gelu_grad(sis_bf16_hi(h[tm].y))};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= d[e] * keep[e];
-                    if (ok) *reinterpret_cast<uint2*>((u16*)p.C + at) = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
                 }
             }
         }

@@ -10,8 +10,18 @@
 // ran 15 ms per step slower than with the merge as a launch of its own.
 // Counters: ints, ZERO before the launch; the completing workgroup puts its counter back to zero, so a buffer private to the
 // stream can serve every launch on it without being cleared in between.
+//
+// Hardware assumption, stated because the HIP / LLVM memory model does not promise it: on gfx942 / gfx950 a relaxed AGENT-scope
+// atomic store is an `sc1` write-through store and a relaxed agent-scope atomic load an `sc1` load that bypasses the vector L1
+// (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": the `sc1` store / `sc1` load /
+// counter form, one lane signalling for its workgroup behind a barrier and a drained vmcnt).  Every handed-off word is
+// written by xwg_publish and read by xwg_peek -- no plain access touches it -- which is that table's condition.  This
+// library is built for gfx950 only (Makefile ARCH); the static_assert below keeps the file from compiling for anything else.
 #pragma once
 #include <hip/hip_runtime.h>
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "sis_xwg.h relies on gfx942 / gfx950 sc1 write-through semantics of agent-scope relaxed atomics"
+#endif
 
 __device__ __forceinline__ void xwg_publish(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float xwg_peek(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -310,6 +310,10 @@ class Mlp(nn.Module):
 
 _FUSED_BLOCK = os.environ.get('SIS_FUSED_VIT', '1') != '0'  # 0: the module-by-module path (library GEMMs / attention)
 _GEMM256 = os.environ.get('SIS_GEMM256', '1') != '0'       # 0: forward / data-gradient GEMMs on the 128-wide tiles only (A/B runs)
+# 1: data gradients as NT products on transposed weight shadows (one multi-tensor transpose per step) wherever a 256-row tile is
+# enabled for the shape.  Off: with the shipped tile set (256 x 288 only) no data gradient would take that path -- their
+# outputs are 768 / 3072 wide -- and the NN layout of csrc/gemm_bf16.hip measured faster on them (tools/bench_gemm256.py).
+_GEMM256_DGRAD = os.environ.get('SIS_GEMM256_DGRAD', '0') == '1'
 
 
 def _wgrad_plan(out_features, in_features):
@@ -580,7 +584,7 @@ class Encoder(nn.Module):
         """Data gradients as NT products (csrc/gemm256_bf16.hip) need W^T: all 4 x 12 transposes by one launch per forward that
         will be differentiated (the optimizer rewrites the shadows every step; inside a captured iteration the launch is
         replayed with them)."""
-        use = (_GEMM256 and torch.is_grad_enabled() and len(self.layer) > 0 and self.layer[0]._fused_ok(hidden_states)
+        use = (_GEMM256 and _GEMM256_DGRAD and torch.is_grad_enabled() and len(self.layer) > 0 and self.layer[0]._fused_ok(hidden_states)
                and sis_hip.gemm_tile_256(hidden_states.shape[0] * hidden_states.shape[1], self.layer[0].hidden_size,
                                          self.layer[0].hidden_size) is not None)
         if not use:

@@ -975,9 +975,16 @@ def gemm_tile_256(m, n, k):
         return None
     m_tiles = -(-m // 256)
     for code, width in ((TILE_256X288, 288), (TILE_256X192, 192), (TILE_256X96, 96)):
-        if n % width == 0 and m_tiles * (n // width) >= 200:
+        if width in _GEMM256_WIDTHS and n % width == 0 and m_tiles * (n // width) >= 200:
             return code
     return None
+
+
+# Widths of the 256-row tiles the encoder may pick (tools/bench_gemm256.py, 8 192 tokens, against the 128-wide tiles with the
+# same epilogues): 256 x 288 wins on the fused projection (48.6 -> 40.7 us); 256 x 96 loses on the 768-wide outputs (its
+# 58 B/clk of operand traffic per MFMA cycle is the load path's limit, and a single workgroup per CU cannot hide its
+# epilogue), 256 x 192 ties.  SIS_GEMM256_TILES=288,192,96 re-enables them for measurements.
+_GEMM256_WIDTHS = tuple(int(w) for w in os.environ.get("SIS_GEMM256_TILES", "288").split(",") if w)
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_DROP, EPI_BIAS_DROP_RESID, EPI_GELU_BWD, EPI_F32 = range(6)
 
 
@@ -1285,19 +1292,28 @@ def column_sum(x):
 # ------------------------------------------------------------------------------ group norm (+ ReLU)
 
 
-_GROUP_COUNTERS = {}  # device -> int32 zeros: completion counters of the norm kernels (each launch leaves them zero)
+_GROUP_COUNTERS = {}  # (device, stream) -> int32 zeros: completion counters of the norm kernels (each launch leaves them zero)
+_GROUP_COUNTER_ROWS = 1 << 16   # sized up front: a captured hipGraph holds the buffer's address, so it is never reallocated
 _GN_FUSED_FINISH = os.environ.get("SIS_GN_FUSED_FINISH", "1") != "0"  # 0: the per-group merges as launches of their own
 
 
 def _group_counters(device, n):
-    """One buffer per device, like the split-K scratch: the norm launches of a device are stream-ordered (eager steps and
-    graph replays of a training loop never overlap).  Launches on OTHER streams at the same time need SIS_GN_FUSED_FINISH=0."""
-    if not _GN_FUSED_FINISH:
+    """Completion counters of the in-launch hand-over (csrc/sis_xwg.h), one buffer per (device, stream) like the split-K
+    scratch: launches on one stream are ordered, and every launch leaves its counters at zero, so concurrent streams must not
+    share them.  The buffer has a fixed size -- pointers baked into a captured graph stay valid -- and a launch
+    that would need more rows falls back to the merge-as-its-own-launch form (returns None)."""
+    if not _GN_FUSED_FINISH or n > _GROUP_COUNTER_ROWS:
         return None
-    buf = _GROUP_COUNTERS.get(device)
-    if buf is None or buf.numel() < n:
-        buf = _GROUP_COUNTERS[device] = torch.zeros(max(n, 16384), dtype=torch.int32, device=device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _GROUP_COUNTERS.get(key)
+    if buf is None:
+        buf = _GROUP_COUNTERS[key] = torch.zeros(_GROUP_COUNTER_ROWS, dtype=torch.int32, device=device)
     return buf
+
+
+def group_counters_are_zero():
+    """Debug check (tests): every completion-counter buffer is back at zero, i.e. no launch left a hand-over half done."""
+    return all(int(buf.abs().max().item()) == 0 for buf in _GROUP_COUNTERS.values())
 
 
 def group_norm_fwd(x, gamma, beta, groups, eps, relu, out_dtype=None, residual=None, low_precision_copy=False, want_gate=False):

@@ -1,5 +1,5 @@
 """Data-parallel gradient exchange for the segmentation training step: bucketed reduce-scatter + all-gather (or one
-all-reduce) over RCCL on a side stream, overlapped with backward, capturable inside the step's hipGraph.
+all-reduce) on RCCL's stream, overlapped with backward, capturable inside the step's hipGraph.
 
 Role in the reference: ``DistributedDataParallel(network, device_ids=[rank], find_unused_parameters=...,
 broadcast_buffers=False)`` (training_builder/base_train_builder.py:40-43), whose C++ reducer all-reduces gradient buckets
@@ -18,7 +18,8 @@ because three things of the MI355X step do not fit it:
   (``torch._foreach_copy_``) gathers the bucket and ``.grad`` is re-pointed at the bucket views, so the table is uploaded
   once.
 * **xGMI is point-to-point** (7 links per GPU): by default a bucket is reduced as ``reduce_scatter`` (every
-  rank owns 1/N of the bucket) followed by ``all_gather``, each on the bucket's own slice of the flat buffer (in place);
+  rank owns 1/N of the bucket) followed by ``all_gather``, each on the bucket's own slice of the flat buffer (in place),
+  both asynchronous on the process group's RCCL stream;
   ``collective: allreduce`` issues one ``all_reduce`` instead.  Averaging is the collective's own ``AVG`` on RCCL; gloo
   (CPU rehearsals) sums and scales.
 
@@ -75,7 +76,7 @@ class BucketedDataParallel(nn.Module):
         if self._on_gpu and self.backend == "gloo":
             # gloo stages device tensors through the host and synchronises: correct (one-GPU rehearsals), never capturable
             pass
-        self._comm_stream = torch.cuda.Stream(self.device) if self._on_gpu else None
+        self._pending = []   # work handles of the collectives issued during the current backward
         self.buckets: Optional[List[_Bucket]] = None
         self._bucket_of = {}
         self._order: List[torch.Tensor] = []      # discovery: parameters in the order their gradients became ready
@@ -148,29 +149,29 @@ class BucketedDataParallel(nn.Module):
 
     @torch.no_grad()
     def _reduce(self, bucket: _Bucket):
+        """Issues the bucket's collective(s) asynchronously FROM the stream backward is running on: the process group's own
+        RCCL stream first waits for that stream (the gathered bucket is complete there), then runs the collective beside the
+        rest of backward; ``_finish`` makes the compute stream wait for the work handles.  Called from the capturing stream
+        during a hipGraph capture, so that the process group sees the capture and keeps these work objects away from its
+        watchdog thread (an event recorded in a capturing stream must not be queried; launching from a side stream of our own
+        let the watchdog do exactly that)."""
         flat, world = bucket.flat, self.world
         self.stats["collectives"] += 1
         if self.backend == "nccl":
             avg = dist.ReduceOp.AVG
             if self.collective == "rs_ag":
                 shard = flat[self.rank * (bucket.numel // world):(self.rank + 1) * (bucket.numel // world)]
-                dist.reduce_scatter_tensor(shard, flat, op=avg, group=self.process_group)
-                dist.all_gather_into_tensor(flat, shard, group=self.process_group)
+                self._pending.append(dist.reduce_scatter_tensor(shard, flat, op=avg, group=self.process_group, async_op=True))
+                self._pending.append(dist.all_gather_into_tensor(flat, shard, group=self.process_group, async_op=True))
             else:
-                dist.all_reduce(flat, op=avg, group=self.process_group)
+                self._pending.append(dist.all_reduce(flat, op=avg, group=self.process_group, async_op=True))
         else:   # gloo: no AVG, no reduce_scatter_tensor
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
             flat.mul_(1.0 / world)
 
     def _flush(self, bucket: _Bucket):
         self._gather(bucket)
-        if self._on_gpu:
-            current = torch.cuda.current_stream(self.device)
-            self._comm_stream.wait_stream(current)          # the gathered bucket is complete on the compute stream
-            with torch.cuda.stream(self._comm_stream):
-                self._reduce(bucket)                        # backward keeps running on the compute stream meanwhile
-        else:
-            self._reduce(bucket)
+        self._reduce(bucket)
         self._flushed += 1
 
     @torch.no_grad()
@@ -188,8 +189,9 @@ class BucketedDataParallel(nn.Module):
             self._reset()
             raise RuntimeError(f"BucketedDataParallel: buckets {missing} did not receive all of their gradients in this backward "
                                "(a parameter used in the first iteration was unused now)")
-        if self._on_gpu:
-            torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)   # optimizer.step() reads the buckets
+        for work in self._pending:
+            work.wait()        # stream-ordered on a HIP device: the compute stream waits for RCCL's; optimizer.step() reads the buckets
+        self._pending = []
         self._reset()
 
     def _reset(self):

@@ -99,7 +99,7 @@ def _rccl_worker(rank, world, port, out, golden_dir):
         cfg = dict(network="EMANet", n_layers=50, num_classes=3, lr=0.009, lr_mom=0.9, weight_decay=1e-4, em_mom=0.9,
                    fine_tune=None, batch_size=batch, image_size=size, use_pretrained_resnet=False, bucket_cap_mb=25)
 
-        def run(force, flavour="buckets", n_iter=3):
+        def run(force, flavour="buckets", n_iter=3):   # (batches * 3 = 6 batches: 3 compared iterations + 3 more replays)
             # (three iterations: two eager ones, then capture + first replay.  At the shipped lr 0.009 on batches of two random
             # label maps the loss climbs 4.9 -> 5.3 -> 14.7 and the trajectory is chaotic from the fourth iteration on, where
             # two runs of the SAME configuration part ways as well, so nothing later is compared.)
@@ -115,6 +115,16 @@ def _rccl_worker(rank, world, port, out, golden_dir):
                 upd.update()
                 losses.append(float(get_current_reporter().scalars()["loss/softmax"]))
             torch.cuda.synchronize()
+            if force and flavour == "buckets":
+                # the process group's watchdog thread polls its work list every ~100 ms: give it the chance to look at whatever
+                # the captured iteration left there (it must leave nothing: events recorded while capturing cannot be queried),
+                # then replay the graph a few more times
+                import time
+                time.sleep(1.5)
+                for _ in range(3):
+                    upd.update()
+                torch.cuda.synchronize()
+                time.sleep(0.5)
             return builder, net, upd, losses, {k: v.detach().cpu().clone() for k, v in bare.state_dict().items()}
 
         builder, net, upd, losses, sd = run(True)

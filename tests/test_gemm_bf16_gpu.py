@@ -269,8 +269,9 @@ def test_gemm256_rejects_what_it_does_not_serve(device):
     with pytest.raises(RuntimeError, match="256 rows"):
         S.gemm_bf16(torch.zeros(128, 256, dtype=torch.bfloat16, device=device), torch.zeros(256, 96, dtype=torch.bfloat16, device=device),
                     S.GEMM_NN, S.EPI_NONE, tile=11)               # the NN layout stays on the 128-wide tiles
-    assert S.gemm_tile_256(8192, 2304, 768) == S.TILE_256X288 and S.gemm_tile_256(8192, 3072, 768) == S.TILE_256X192
-    assert S.gemm_tile_256(8192, 768, 3072) == S.TILE_256X96 and S.gemm_tile_256(2048, 768, 768) is None
+    assert S.gemm_tile_256(8192, 2304, 768) == S.TILE_256X288 and S.gemm_tile_256(2048, 2304, 768) is None
+    if S._GEMM256_WIDTHS == (288,):   # the shipped set: the widths that measured slower than the 128-wide tiles stay off
+        assert S.gemm_tile_256(8192, 3072, 768) is None and S.gemm_tile_256(8192, 768, 3072) is None
 
 
 def test_transpose_bank(device):

@@ -380,3 +380,6 @@ def test_weight_bank_equals_per_layer_standardisation(device, monkeypatch):
     monkeypatch.setattr(R, "_WS_BANK", False)
     for u, v in zip(got, run()):
         assert torch.equal(u, v)
+    import sis_hip
+    torch.cuda.synchronize()
+    assert sis_hip.group_counters_are_zero(), "a GroupNorm launch left an in-launch hand-over counter non-zero (csrc/sis_xwg.h)"
