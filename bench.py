@@ -291,10 +291,11 @@ def bench_training(args, workload, world, rank, device, distributed):
     library_calls = sis_hip.library_calls(reset=True)   # one whole iteration: what was handed to ATen / MIOpen / hipBLASLt
     own = {}
     for name, flops, nbytes, e0, e1 in records:
-        a = own.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        a = own.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
         a["launches"] += 1
         a["ms"] += e0.elapsed_time(e1)
         a["flops"] += flops
+        a["bytes"] += nbytes
     for _ in range(warmup - 2):
         updater.update()
     fence()
@@ -340,6 +341,19 @@ def bench_training(args, workload, world, rank, device, distributed):
 
     def kernel_peak(name):   # fp32 kernels (Winograd, fp32 1x1) inside an AMP step are priced against the fp32 peak
         return PEAK_MFMA_F32_TFLOPS if ("wino" in name or "f32" in name or not config.get("amp")) else PEAK_MFMA_BF16_TFLOPS
+
+    def kernel_row(name, v):
+        if not v["ms"]:
+            return {"launches": v["launches"], "ms": 0.0}
+        sec = v["ms"] * 1e-3
+        executed = v["flops"] * (16.0 / 36.0 if "wino" in name else 1.0)
+        tf, gbs = executed / sec / 1e12, v["bytes"] / sec / 1e9
+        ridge = kernel_peak(name) * 1e12 / (PEAK_HBM_GBS * 1e9)      # FLOP per byte at which the two roofs meet
+        hbm_bound = v["bytes"] > 0 and (v["flops"] == 0 or executed / v["bytes"] < ridge)
+        return {"launches": v["launches"], "ms": round(v["ms"], 3),
+                "nominal_tflops": round(v["flops"] / sec / 1e12, 1), "gbs_algorithmic": round(gbs, 1),
+                "bound": "hbm" if hbm_bound else "mfma",
+                "frac_of_peak": round(gbs / PEAK_HBM_GBS, 4) if hbm_bound else (round(tf / kernel_peak(name), 4) if v["flops"] else None)}
     return {
         "metric": METRIC, "value": round(images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
@@ -362,12 +376,9 @@ def bench_training(args, workload, world, rank, device, distributed):
                      "traffic": traffic, "traffic_unit": "HBM-side bytes per launch of dominant_own_kernel (PMC FETCH_SIZE x 2 + "
                                                         "WRITE_SIZE, separate passes)", "traffic_source": traffic_src,
                      "dominant_own_kernel": dom,
-                     "own_kernels_eager_iteration": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                                                         "nominal_tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] else None,
-                                                         "frac_of_peak": round(v["flops"] * (16.0 / 36.0 if "wino" in k else 1.0)
-                                                                               / (v["ms"] * 1e-3) / 1e12 / kernel_peak(k), 4)
-                                                         if (v["ms"] and v["flops"]) else None}
-                                                     for k, v in sorted(own.items(), key=lambda kv: -kv[1]["ms"])}},
+                     # per kernel: the roofline that bounds it -- "hbm" when its algorithmic FLOP / byte sits below the ridge of
+                     # its matrix peak (1x1 convolutions on wide maps, norms), else "mfma" -- and its fraction of THAT peak
+                     "own_kernels_eager_iteration": {k: kernel_row(k, v) for k, v in sorted(own.items(), key=lambda kv: -kv[1]["ms"])}},
         "cpu_baseline": None if (world > 1 or args.no_cpu_baseline) else cpu_baseline_training(workload, config),
     }
 

@@ -981,10 +981,11 @@ def gemm_tile_256(m, n, k):
 
 
 # Widths of the 256-row tiles the encoder may pick (tools/bench_gemm256.py, 8 192 tokens, against the 128-wide tiles with the
-# same epilogues): 256 x 288 wins on the fused projection (48.6 -> 40.7 us); 256 x 96 loses on the 768-wide outputs (its
-# 58 B/clk of operand traffic per MFMA cycle is the load path's limit, and a single workgroup per CU cannot hide its
-# epilogue), 256 x 192 ties.  SIS_GEMM256_TILES=288,192,96 re-enables them for measurements.
-_GEMM256_WIDTHS = tuple(int(w) for w in os.environ.get("SIS_GEMM256_TILES", "288").split(",") if w)
+# same epilogues): 256 x 288 wins on the fused projection (46.2 -> 35.0 us), 256 x 192 on fc1 with its GELU + dropout
+# epilogue (72.8 -> 66.3 us); 256 x 96 loses on the 768-wide outputs (its 58 B/clk of operand traffic per MFMA cycle is the
+# load path's limit, and a single workgroup per CU cannot hide its epilogue: 47 -> 56 us for fc2).
+# SIS_GEMM256_TILES=288,192,96 enables all three for measurements.
+_GEMM256_WIDTHS = tuple(int(w) for w in os.environ.get("SIS_GEMM256_TILES", "288,192").split(",") if w)
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_DROP, EPI_BIAS_DROP_RESID, EPI_GELU_BWD, EPI_F32 = range(6)
 
 
@@ -1504,8 +1505,9 @@ def conv1x1_wgrad_f32(grad_output, input):
     ws_bytes = int(L.sis_conv1x1_wgrad_f32_workspace(b, cin, cout, h * w))
     ws = torch.empty(max(ws_bytes // 4, 4), dtype=torch.float32, device=input.device)
     with torch.cuda.device(input.device):
-        _check(L.sis_conv1x1_wgrad_f32(_ptr(dw), _ptr(grad_output), _ptr(input), b, cin, cout, h * w, _ptr(ws) if ws_bytes else None,
-                                       ws_bytes, _stream()), "sis_conv1x1_wgrad_f32")
+        _check(_launch("conv1x1_wgrad_f32_kernel", 2.0 * b * cout * cin * h * w, 4.0 * (grad_output.numel() + input.numel() + dw.numel()),
+                       lambda: L.sis_conv1x1_wgrad_f32(_ptr(dw), _ptr(grad_output), _ptr(input), b, cin, cout, h * w,
+                                                       _ptr(ws) if ws_bytes else None, ws_bytes, _stream())), "sis_conv1x1_wgrad_f32")
     return dw
 
 

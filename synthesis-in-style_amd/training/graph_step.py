@@ -84,6 +84,18 @@ class StepGraph:
             opt.zero_grad(set_to_none=True)  # gradients are re-created inside the graph's memory pool
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # With an RCCL process group in the process its watchdog thread polls the events of earlier (eager) collectives; under
+        # the default "global" capture mode an event query from ANY thread while a capture is open is an error
+        # (hipErrorStreamCaptureUnsupported) and the watchdog takes the process down.  "thread_local" restricts the check to
+        # the capturing thread, which is what the capture needs; work objects created DURING the capture are never handed to
+        # the watchdog (training/grad_exchange.py issues them from the capturing stream).
+        mode = "global"
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+                mode = "thread_local"
+        except Exception:
+            pass
+        with torch.cuda.graph(graph, capture_error_mode=mode):
             self.static_out = step_fn(self.static_batch)
         self.graph = graph

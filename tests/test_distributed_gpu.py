@@ -115,6 +115,7 @@ def _rccl_worker(rank, world, port, out, golden_dir):
                 upd.update()
                 losses.append(float(get_current_reporter().scalars()["loss/softmax"]))
             torch.cuda.synchronize()
+            state = {k: v.detach().cpu().clone() for k, v in bare.state_dict().items()}   # after the compared iterations
             if force and flavour == "buckets":
                 # the process group's watchdog thread polls its work list every ~100 ms: give it the chance to look at whatever
                 # the captured iteration left there (it must leave nothing: events recorded while capturing cannot be queried),
@@ -125,7 +126,7 @@ def _rccl_worker(rank, world, port, out, golden_dir):
                     upd.update()
                 torch.cuda.synchronize()
                 time.sleep(0.5)
-            return builder, net, upd, losses, {k: v.detach().cpu().clone() for k, v in bare.state_dict().items()}
+            return builder, net, upd, losses, state
 
         builder, net, upd, losses, sd = run(True)
         opt = builder.get_optimizers()["main"]
