@@ -19,7 +19,8 @@ because three things of the MI355X step do not fit it:
   once.
 * **xGMI is point-to-point** (7 links per GPU): by default a bucket is reduced as ``reduce_scatter`` (every
   rank owns 1/N of the bucket) followed by ``all_gather``, each on the bucket's own slice of the flat buffer (in place),
-  both asynchronous on the process group's RCCL stream;
+  issued straight into librccl.so (``ncclReduceScatter`` / ``ncclAllGather`` on the process group's communicator) on the
+  exchange's own HIP stream;
   ``collective: allreduce`` issues one ``all_reduce`` instead.  Averaging is the collective's own ``AVG`` on RCCL; gloo
   (CPU rehearsals) sums and scales.
 
@@ -33,6 +34,50 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 from torch import nn
+
+
+_DEBUG = os.environ.get("SIS_DP_DEBUG", "0") == "1"
+_DIRECT_RCCL = os.environ.get("SIS_DP_DIRECT_RCCL", "1") != "0"   # 0: the collectives through torch.distributed work objects
+
+
+class _Rccl:
+    """The RCCL entry points the exchange needs, called on the process group's own communicator (``ProcessGroupNCCL._comm_ptr``)
+    with plain pointers and a HIP stream -- the C ABI of librccl.so, the library torch itself links: no torch work objects, no
+    watchdog bookkeeping, nothing but stream work, which is what a hipGraph capture wants.  (Through torch.distributed the
+    collectives captured fine, but the process group's watchdog thread intermittently queried an event that had last been
+    recorded while capturing -- hipErrorCapturedEvent -- and took the process down.)"""
+    FLOAT32, SUM, AVG = 7, 0, 4   # ncclDataType_t / ncclRedOp_t values (nccl.h)
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            import ctypes
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            lib = ctypes.CDLL(path)   # already mapped by torch: the same instance
+            vp, sz, i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+            lib.ncclReduceScatter.argtypes, lib.ncclReduceScatter.restype = [vp, vp, sz, i, i, vp, vp], i
+            lib.ncclAllGather.argtypes, lib.ncclAllGather.restype = [vp, vp, sz, i, vp, vp], i
+            lib.ncclAllReduce.argtypes, lib.ncclAllReduce.restype = [vp, vp, sz, i, i, vp, vp], i
+            lib.ncclGetErrorString.argtypes, lib.ncclGetErrorString.restype = [i], ctypes.c_char_p
+            cls._lib = lib
+        return cls._lib
+
+    @classmethod
+    def check(cls, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"RCCL {what} failed: {cls.lib().ncclGetErrorString(rc).decode()}")
+
+    @staticmethod
+    def communicator(process_group, device):
+        """ncclComm_t of the group's RCCL backend on ``device`` as an integer, or None when torch does not expose it."""
+        try:
+            group = process_group if process_group is not None else dist.distributed_c10d._get_default_group()
+            backend = group._get_backend(device)
+            ptr = int(backend._comm_ptr())
+            return ptr or None
+        except Exception:
+            return None
 
 
 class _Bucket:
@@ -76,7 +121,17 @@ class BucketedDataParallel(nn.Module):
         if self._on_gpu and self.backend == "gloo":
             # gloo stages device tensors through the host and synchronises: correct (one-GPU rehearsals), never capturable
             pass
-        self._pending = []   # work handles of the collectives issued during the current backward
+        self._pending = []   # work handles of collectives issued through torch.distributed during the current backward
+        self._comm, self._comm_stream, self._joined = None, None, True
+        if self._on_gpu and self.backend == "nccl" and _DIRECT_RCCL:
+            self._comm = _Rccl.communicator(process_group, self.device)
+            if self._comm is None:   # the communicator is created lazily by the first collective
+                probe = torch.zeros(1, device=self.device)
+                dist.all_reduce(probe, group=process_group)
+                torch.cuda.synchronize(self.device)
+                self._comm = _Rccl.communicator(process_group, self.device)
+            if self._comm is not None:
+                self._comm_stream = torch.cuda.Stream(self.device)
         self.buckets: Optional[List[_Bucket]] = None
         self._bucket_of = {}
         self._order: List[torch.Tensor] = []      # discovery: parameters in the order their gradients became ready
@@ -157,7 +212,29 @@ class BucketedDataParallel(nn.Module):
         let the watchdog do exactly that)."""
         flat, world = bucket.flat, self.world
         self.stats["collectives"] += 1
-        if self.backend == "nccl":
+        if _DEBUG and self._on_gpu:
+            import threading
+            print(f"[grad_exchange] bucket {bucket.index}: thread {threading.current_thread().name}, stream "
+                  f"{torch.cuda.current_stream(self.device).cuda_stream:#x}, capturing {torch.cuda.is_current_stream_capturing()}", flush=True)
+        if self.backend == "nccl" and self._comm is not None:
+            # straight into RCCL on the exchange's own stream: the gathered bucket is complete on the compute stream (event),
+            # backward keeps running there meanwhile; ``_finish`` joins the streams
+            import ctypes
+            R = _Rccl
+            current = torch.cuda.current_stream(self.device)
+            self._comm_stream.wait_stream(current)
+            stream = ctypes.c_void_p(self._comm_stream.cuda_stream)
+            comm, base, n = ctypes.c_void_p(self._comm), flat.data_ptr(), bucket.numel
+            with torch.cuda.device(self.device):
+                if self.collective == "rs_ag":
+                    per = n // world
+                    mine = ctypes.c_void_p(base + 4 * per * self.rank)
+                    R.check(R.lib().ncclReduceScatter(ctypes.c_void_p(base), mine, per, R.FLOAT32, R.AVG, comm, stream), "ncclReduceScatter")
+                    R.check(R.lib().ncclAllGather(mine, ctypes.c_void_p(base), per, R.FLOAT32, comm, stream), "ncclAllGather")
+                else:
+                    R.check(R.lib().ncclAllReduce(ctypes.c_void_p(base), ctypes.c_void_p(base), n, R.FLOAT32, R.AVG, comm, stream), "ncclAllReduce")
+            self._joined = False
+        elif self.backend == "nccl":
             avg = dist.ReduceOp.AVG
             if self.collective == "rs_ag":
                 shard = flat[self.rank * (bucket.numel // world):(self.rank + 1) * (bucket.numel // world)]
@@ -192,6 +269,9 @@ class BucketedDataParallel(nn.Module):
         for work in self._pending:
             work.wait()        # stream-ordered on a HIP device: the compute stream waits for RCCL's; optimizer.step() reads the buckets
         self._pending = []
+        if not self._joined:
+            torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)   # optimizer.step() reads the buckets
+            self._joined = True
         self._reset()
 
     def _reset(self):
@@ -232,6 +312,10 @@ class BucketedDataParallel(nn.Module):
                 raise RuntimeError("BucketedDataParallel: ranks disagree on the bucket plan (different graphs per rank)")
 
     # ---- introspection (tests, bench) --------------------------------------------------------------------------------
+    def direct_rccl(self) -> bool:
+        """The collectives go straight into librccl.so on the group's communicator (no torch.distributed work objects)."""
+        return self._comm is not None
+
     def bucket_spans(self):
         return [(b.flat.data_ptr(), b.flat.data_ptr() + 4 * b.numel) for b in (self.buckets or [])]
 

@@ -138,7 +138,7 @@ def _rccl_worker(rank, world, port, out, golden_dir):
         _, _, upd_plain, losses_plain, sd_plain = run(False)
         _, net_ddp, upd_ddp, losses_ddp, _ = run(True, "ddp")
         out[rank] = dict(
-            graph=upd._step_graph.graph is not None, capture_error=upd._step_graph.capture_error,
+            graph=upd._step_graph.graph is not None, capture_error=upd._step_graph.capture_error, direct=net.direct_rccl(),
             n_buckets=len(spans), collectives=net.stats["collectives"], discovery=net.stats["discovery_backwards"],
             backwards=net.stats["backwards"],
             grads_in_buckets=all(any(lo <= p.grad.data_ptr() < hi for lo, hi in spans) for p in live),
@@ -168,7 +168,7 @@ def test_ema_net_rccl_world_size_1_bucketed_exchange_inside_the_step_graph(devic
     mp.spawn(_rccl_worker, args=(1, _free_port(), out, golden_dir), nprocs=1, join=True)
     r = out[0]
     assert r["graph"] and r["capture_error"] is None, f"the data-parallel iteration was not captured: {r['capture_error']}"
-    assert r["plain_graph"]
+    assert r["plain_graph"] and r["direct"], "the exchange did not reach librccl.so directly"
     assert r["n_buckets"] >= 5 and r["discovery"] == 1
     # eager iterations 1-2 and the capture run the hooks (3 backwards seen by the wrapper); replays do not pass through Python
     assert r["backwards"] == 3 and r["collectives"] == 3 * r["n_buckets"], r
