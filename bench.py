@@ -169,17 +169,23 @@ def _graph_expected(updater):
 
 def library_time(updater):
     """Device time of ONE training iteration split into this library's kernels and everything else (ATen / MIOpen / hipBLASLt /
-    runtime copies), from the kernel records of torch.profiler (roctracer) around one more ``update()`` -- a graph replay when
-    the step is captured.  A kernel counts as own when its name contains a ``__global__`` function of csrc/*.hip
+    runtime copies), from the kernel records of torch.profiler (roctracer) around one more EAGER ``update()`` (the same
+    kernels a graph replay runs; the tracer does not see inside a replay).  A kernel counts as own when its name contains a ``__global__`` function of csrc/*.hip
     (sis_hip.own_kernel_names).  None when the profiler delivers no device records on this box."""
     import sis_hip
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
         return {"skipped": "running under rocprofv3 (two tracers in one process); see profiles/ for the external breakdown"}
+    graph = getattr(updater, "_step_graph", None)
+    was_enabled = graph.enabled if graph is not None else None
     try:
         from torch.profiler import ProfilerActivity, profile
+        if graph is not None:
+            graph.enabled = False   # one EAGER iteration: the tracer does not see inside a graph replay; the kernels are the same
         with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
             updater.update()
             torch.cuda.synchronize()
+        if graph is not None:
+            graph.enabled = was_enabled
         own_us = lib_us = 0.0
         lib_names = {}
         n = 0
@@ -201,6 +207,8 @@ def library_time(updater):
         return {"own_ms": round(own_us / 1e3, 3), "library_ms": round(lib_us / 1e3, 3), "device_records": n,
                 "top_library_kernels_ms": {k: round(v / 1e3, 3) for k, v in top}}
     except Exception as err:   # the measurement must never take the bench line down
+        if graph is not None and was_enabled is not None:
+            graph.enabled = was_enabled
         return {"error": repr(err)}
 
 
