@@ -192,6 +192,8 @@ def library_time(updater):
         for ev in prof.events():
             if getattr(ev, "device_type", None) is None or "cuda" not in str(ev.device_type).lower():
                 continue
+            if getattr(ev, "is_user_annotation", False) or "#" in ev.name:   # annotation ranges mirrored onto the device timeline
+                continue
             dur = float(getattr(ev, "device_time_total", 0.0) or getattr(ev, "cuda_time_total", 0.0) or 0.0)
             if dur <= 0.0:
                 continue

@@ -198,6 +198,13 @@ int sis_sgd_momentum_dev(const int64_t* table, int n_chunks, const float* hyper,
 int sis_ema_update(float* mu, const float* mu_batch, float momentum, float one_minus_momentum,
                    int batch, int numel, void* stream);
 
+/* A 3x3 convolution whose dilation (= padding) is half the image side (EMANet's dilation-16 bottleneck on 32 x 32 maps,
+ * networks/ema_net/network.py:82-86) is one dense [4 Cin] -> [4 Cout] map per position of the half-size grid:
+ * taps [4 cout][4 cin], rows (u, v, co), columns (u', v', ci), = weight[co][ci][u' - u + 1][v' - v + 1] (csrc/dilation_taps.hip);
+ * the product itself runs on sis_conv1x1_f32*.  _bwd: dweight [cout][cin][3][3] from dtaps, fixed summation order. */
+int sis_half_dilation_taps(float* taps, const float* weight, int cout, int cin, void* stream);
+int sis_half_dilation_taps_bwd(float* dweight, const float* dtaps, int cout, int cin, void* stream);
+
 /* EMANet's Expectation-Maximisation Attention Unit between its two 1x1 convolutions (networks/ema_net/network.py:219-249,
  * the no_grad block and the reconstruction):  mu <- mu0 (shared [channels][bases]) for every sample; `stages` rounds of
  * z = softmax_k(x^T mu), z_ = z / (1e-6 + sum_n z), mu = l2norm_c(x z_) (eps 1e-6);  x_out = relu(mu z^T), mu_out = mu.

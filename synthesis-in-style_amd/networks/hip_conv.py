@@ -278,6 +278,20 @@ def _tap_select(device):
     return sel
 
 
+_HALF_DIL_OWN = os.environ.get('SIS_HALF_DIL_OWN', '1') != '0'   # 0: the half-image-dilation layer as library GEMMs (A/B runs)
+
+
+class _HalfDilationTaps(Function):
+    @staticmethod
+    def forward(ctx, weight):
+        ctx.shape = (weight.shape[0], weight.shape[1])
+        return sis_hip.half_dilation_taps(weight)
+
+    @staticmethod
+    def backward(ctx, grad_taps):
+        return sis_hip.half_dilation_taps_bwd(grad_taps.contiguous(), *ctx.shape)
+
+
 def conv3x3_half_image_dilation(input, weight):
     """3x3 convolution whose dilation is half the image side (padding = dilation): every output pixel (u*d + p,
     v*d + q) only sees the 2 x 2 pixels {(u'*d + p, v'*d + q)} -- EMANet's last bottleneck (dilation 16 on 32 x 32).
@@ -291,6 +305,17 @@ def conv3x3_half_image_dilation(input, weight):
     b, cin, h, w = input.shape
     d = h // 2
     cout = weight.shape[0]
+    if _HALF_DIL_OWN and input.is_cuda and input.dtype == torch.float32 and weight.dtype == torch.float32 and not torch.is_autocast_enabled():
+        # own kernels end to end: the [4 Cout, 4 Cin] matrix by a gather kernel (csrc/dilation_taps.hip), the product as a
+        # pointwise convolution of the [b, (u', v', ci), d x d] arrangement of the input on the fp32 MFMA kernels
+        # (csrc/conv1x1_f32.hip: forward, data gradient and weight gradient), no library GEMM left in the layer
+        xs = input.view(b, cin, 2, d, 2, d).permute(0, 2, 4, 1, 3, 5).reshape(b, 4 * cin, d, d)
+        taps = _HalfDilationTaps.apply(weight)
+        if sis_hip.conv1x1_f32_supported(xs, taps.view(4 * cout, 4 * cin, 1, 1)):
+            y = _Pointwise.apply(xs, taps.view(4 * cout, 4 * cin, 1, 1), None)                 # [b, (u, v, co), d, d]
+            return y.view(b, 2, 2, cout, d, d).permute(0, 3, 1, 4, 2, 5).reshape(b, cout, h, w)
+    if input.is_cuda:
+        sis_hip.library_call("hip_conv.conv3x3_half_image_dilation (library GEMMs)")
     x = input.view(b, cin, 2, d, 2, d).permute(0, 3, 5, 2, 4, 1).reshape(b * d * d, 4 * cin)  # rows (b,p,q), cols (u',v',ci)
     sel = _tap_select(weight.device)
     # (two plain 2-D products with a transpose copy between them: a batched product of 262 144 3 x 4 matrices costs the

@@ -92,6 +92,8 @@ _SIGNATURES = {
     "sis_sgd_momentum_dev": ([_vp, _i, _vp, _vp], _i),
     "sis_ema_update": ([_vp, _vp, _f, _f, _i, _i, _vp], _i),
     "sis_transpose_bf16_multi": ([_vp, _i, _i, _vp], _i),
+    "sis_half_dilation_taps": ([_vp, _vp, _i, _i, _vp], _i),
+    "sis_half_dilation_taps_bwd": ([_vp, _vp, _i, _i, _vp], _i),
     "sis_emau_supported": ([_i] * 4, _i),
     "sis_emau_workspace_floats": ([_i] * 4, _i64),
     "sis_emau_forward": ([_vp] * 5 + [_i] * 5 + [_vp], _i),
@@ -657,6 +659,25 @@ def ema_update(mu, mu_batch, momentum):
         _check(lib().sis_ema_update(_ptr(mu), _ptr(mb), float(momentum), float(1 - momentum), mb.numel() // n, n,
                                     _stream()), "sis_ema_update")
     return mu
+
+
+def half_dilation_taps(weight):
+    """[4 cout, 4 cin] matrix of a 3x3 convolution whose dilation is half the image side (see include/sis_hip.h)."""
+    require_device(weight, "weight")
+    w = _f32(weight, "weight")
+    cout, cin = w.shape[0], w.shape[1]
+    taps = torch.empty((4 * cout, 4 * cin), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _check(lib().sis_half_dilation_taps(_ptr(taps), _ptr(w), cout, cin, _stream()), "sis_half_dilation_taps")
+    return taps
+
+
+def half_dilation_taps_bwd(grad_taps, cout, cin):
+    g = _f32(grad_taps, "grad_taps")
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        _check(lib().sis_half_dilation_taps_bwd(_ptr(dw), _ptr(g), cout, cin, _stream()), "sis_half_dilation_taps_bwd")
+    return dw
 
 
 def emau_supported(x, mu):

@@ -84,23 +84,31 @@ def test_module_dispatch_and_fallback(device):
     assert sorted(HipConv2d(8, 8, 3).state_dict().keys()) == ["bias", "weight"]
 
 
-def test_half_image_dilation_is_the_dilated_convolution(device):
+@pytest.mark.parametrize("b,cin,cout", [(3, 16, 24), (2, 512, 512)])
+def test_half_image_dilation_is_the_dilated_convolution(device, b, cin, cout):
+    """(2, 512, 512): EMANet-50's layer -- gather kernel + fp32 MFMA pointwise kernels in all three directions, nothing handed
+    to the ROCm libraries; (3, 16, 24): a shape whose weight gradient has no tile plan (counted as a fallback)."""
+    import sis_hip
     from networks.hip_conv import HipConv2d, conv3x3_half_image_dilation
     g = torch.Generator().manual_seed(16)
-    x = torch.randn(3, 16, 32, 32, generator=g).to(device).requires_grad_(True)
-    conv = HipConv2d(16, 24, 3, 1, 16, 16, bias=False).to(device)
-    gy = torch.randn(3, 24, 32, 32, generator=g).to(device)
+    x = torch.randn(b, cin, 32, 32, generator=g).to(device).requires_grad_(True)
+    conv = HipConv2d(cin, cout, 3, 1, 16, 16, bias=False).to(device)
+    gy = torch.randn(b, cout, 32, 32, generator=g).to(device)
     assert conv._half_image_dilation(x)
+    sis_hip.library_calls(reset=True)
     y = conv(x)
     y.backward(gy)
+    calls = sis_hip.library_calls(reset=True)
+    if cin == 512:
+        assert calls["fallback"] == {}, calls
     got = (y.detach(), x.grad.clone(), conv.weight.grad.clone())
     x.grad = conv.weight.grad = None
     ref = F.conv2d(x.double(), conv.weight.double(), padding=16, dilation=16)
     ref.backward(gy.double())
-    for a, b in zip(got, (ref, x.grad, conv.weight.grad)):
-        b = b.detach().float()
-        assert (a - b).abs().max().item() < 1e-5 * b.abs().max().item()
-    assert not conv._half_image_dilation(torch.zeros(1, 16, 64, 64, device=device))
+    for a, r in zip(got, (ref, x.grad, conv.weight.grad)):
+        r = r.detach().float()
+        assert (a - r).abs().max().item() < 1e-5 * r.abs().max().item()
+    assert not conv._half_image_dilation(torch.zeros(1, cin, 64, 64, device=device))
 
 
 def test_pointwise_convolution_is_a_batched_gemm(device):
