@@ -25,9 +25,9 @@ def label(name):
     if m:
         layout = {("false", "false"): "NT", ("false", "true"): "NN", ("true", "true"): "TN"}.get((m.group(3), m.group(4)), "??")
         return f"gemm_bf16<{layout},{m.group(5)}>"
-    m = re.match(r"gemm256_kernel<G256Cfg<([^>]*)>, (\d+)>", name)
+    m = re.match(r"gemm256_kernel<G256Cfg<(\d+)>, (\d+)>", name)
     if m:
-        return f"gemm256<{m.group(1).replace(' ', '')},{m.group(2)}>"
+        return f"gemm256<{96 * int(m.group(1))},{m.group(2)}>"
     m = re.match(r"conv_bf16_kernel<ConvCfg<([^>]*)>", name)
     if m:
         return "conv_bf16_kernel<" + m.group(1).replace(" ", "") + ">"
