@@ -141,6 +141,17 @@ int sis_modconv2d_up(float* t, const float* x, const float* wpk, const float* s,
                      const float* dscale, int batch, int cin, int cout, int h, int w,
                      int t_row_stride, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The same transposed convolution in its fast-FIR form (csrc/modconv_upfir.hip): 25 instead of 36 multiplies per 2 x 2 input
+ * positions (F(2,2) of the 2-tap even phases per axis), on v_mfma_f32_16x16x4_f32.  `u` = the 16 transformed weight planes
+ * [cin][16][cout] written by sis_modconv_up_fir_prepack from the layer's weight [cout][cin][3][3] (once per checkpoint).
+ * t: [batch][cout][2h+1][t_row_stride] with t_row_stride % 4 == 0 and >= 2w + 4 (columns beyond 2w are padding and receive
+ * unspecified finite values).  sis_modconv_up_fir_supported: h, w >= 32, h even, w % 4 == 0, cin % 8 == 0, cout % 64 == 0,
+ * operands below 2 GiB. */
+int sis_modconv_up_fir_supported(int batch, int cin, int cout, int h, int w, int t_row_stride);
+int sis_modconv_up_fir_prepack(float* u, const float* w, int cout, int cin, void* stream);
+int sis_modconv2d_up_fir(float* t, const float* x, const float* u, const float* s, const float* dscale, int batch, int cin, int cout,
+                         int h, int w, int t_row_stride, void* stream);
+
 /* Blur (upfirdn2d up=1 down=1, model.py:89-92 / :262) fused with NoiseInjection + FusedLeakyReLU
  * (model.py:338-340): in [B,C,IH,IW] -> out [B,C,OH,OW], OH = IH + pad0 + pad1 - kh + 1.
  * fuse_act == 0 gives the plain blur. taps [kh,kw] float32 device pointer.  in_row_stride (floats, 0 = in_w)

@@ -1,0 +1,300 @@
+// Transposed stride-2 3x3 modulated convolution (StyleGAN2's up-convolutions, reference networks/stylegan2/model.py:251-262:
+// conv_transpose2d(stride 2) on per-sample weights) with 25 instead of 36 multiplies per 2 x 2 input positions: the fast-FIR
+// form of the four output phases.
+//
+// Per axis, position h contributes out[2h] = g0 x[h] + g2 x[h-1] (a 2-tap FIR over the positions) and out[2h+1] = g1 x[h]
+// (csrc/modconv_mfma2.hip computes exactly these, 3 multiplies per position and axis, 9 per position in 2-D).  For a PAIR of
+// positions 2b, 2b+1 with d0 = x[2b-1], d1 = x[2b], d2 = x[2b+1] the two even outputs are F(2,2) of a 2-tap filter:
+//     m0 = (d0 - d1) g2     m1 = d1 (g0 + g2)     m2 = (d2 - d1) g0        out[4b] = m0 + m1,  out[4b+2] = m1 + m2
+//     m3 = d1 g1            m4 = d2 g1                                     out[4b+1] = m3,     out[4b+3] = m4
+// 5 products instead of 6; in two dimensions 25 instead of 36 per 2 x 2 block of positions (-30.6 % matrix work), with
+// 4 x 4 = 16 distinct transformed weight planes U[u][v] = sum_{ky in K(u), kx in K(v)} W[ky][kx], K = ({2}, {0, 2}, {0}, {1}),
+// prepacked once per checkpoint, and a 4 x 4 data transform T = (row transform) (column transform) of the block's 3 x 3
+// input patch, transform t = (d0 - d1, d1, d2 - d1, d2): 14 subtractions, done per lane in registers on the way from the
+// LDS to the MFMA (no transformed image).  Product (p, q), p, q = 0..4, multiplies plane (pu[p], pu[q]) with
+// T[dp[p]][dp[q]], pu = (0, 1, 2, 3, 3), dp = (0, 1, 2, 1, 3); the 4 x 4 outputs of a block are
+// out[r][s] = sum_{p in R(r), q in R(s)} acc[p][q], R = ({0, 1}, {3}, {1, 2}, {4}).
+//
+// GEMM view: M = output channels, N = 2 x 2 position BLOCKS, K = input channels, 25 accumulator planes.  25 planes of a
+// 32 x 32 tile (400 registers) leave one wave per SIMD; on v_mfma_f32_16x16x4_f32 (same rate: 64 FLOP/clk/SIMD, exact fp32) a
+// wave holds 32 channels x 16 blocks x 25 planes in 200 registers and two waves share a SIMD.  Workgroup = 8 waves =
+// 64 channels x 64 blocks (256 positions); lane l of a wave: block l & 15, input channel (l >> 4) of the 4-deep MFMA step.
+//
+// Blocks are numbered row-major over (sample, block row, block column) -- (H/2 + 1) x (W/2 + 1) per sample: the transposed
+// convolution has H + 1 position rows, the last block row / column holds one valid position -- and a workgroup takes 64
+// CONSECUTIVE blocks (no tile classes: 0.2 % of the blocks of a 64 x 64 layer are padding).  Its input tile is the run of
+// image rows those blocks touch, each staged whole as [4 zeros | W pixels | 4 zeros] by LDS-DMA through a buffer descriptor
+// whose out-of-range lanes write the zeros (rows -1 and H, H + 1 and the pad columns alike); "virtual" row v of sample b,
+// v = h + 1 in [0, H + 3), has index b (H + 3) + v, so a run that crosses from one sample into the next is still one range.
+// Staging: 8 input channels per chunk, wave w moves channel w (4 pieces of weights: 16 planes x 64 channels, and <= 4 pieces
+// of input rows), double-buffered, one barrier per chunk (as modconv_mfma2.hip).  The style factor s[b, ci] multiplies the
+// raw patch values after their LDS read; demodulation in the epilogue; noise / bias / activation belong to the blur kernel
+// that reads this kernel's (2H+1) x (2W+4)-strided result.
+#include "modconv_common.h"
+
+namespace {
+
+typedef float uf_f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int UF_CC = 8;                              // input channels per chunk (= waves: one channel's DMA per wave)
+constexpr int UF_MBLK = 64;                           // output channels per workgroup
+constexpr int UF_NBLK = 64;                           // position blocks per workgroup
+constexpr int UF_PLANES = 16;
+constexpr int UF_WROW = UF_PLANES * UF_MBLK + 16;     // floats per channel row of the weight stage: +16 puts the 4 channels a
+                                                      // 32-lane read group touches 16 banks apart (conflict-free ds_read_b32)
+constexpr int UF_THREADS = 512;
+constexpr int UF_XP_MAX = 4;                          // 1 KiB pieces per channel of the input tile (xs <= 1024 floats)
+constexpr unsigned UF_OOB = 0x80000000u;
+
+struct UpFirParams {
+    const float* x; const float* u; const float* s; const float* dscale; float* out;
+    int B, Cin, Cout, H, W, OH, ORS;
+    int nbw, bps, total_blocks;    // block columns per row, blocks per sample, blocks in the batch
+    int vr;                        // virtual rows per sample = H + 3
+    int rw4;                       // float4 per staged row = W / 4 + 2
+    int xs;                        // floats per channel of the staged tile (multiple of 256)
+};
+
+__device__ __forceinline__ void uf_dma16(__amdgpu_buffer_rsrc_t r, float* l, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
+}
+
+__global__ __launch_bounds__(UF_THREADS) void modconv_upfir_kernel(const UpFirParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Wl = lds;                              // [2][CC][WROW]
+    float* Xl = Wl + 2 * UF_CC * UF_WROW;         // [2][CC][xs]
+    float* Sl = Xl + 2 * UF_CC * p.xs;            // [2 samples][Cin]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    // output-channel block fastest: the n_co workgroups that share an input tile run at the same time on different XCDs
+    const int n_co = p.Cout / UF_MBLK;
+    const int tile = blockIdx.x / n_co, o0 = (blockIdx.x % n_co) * UF_MBLK;
+    const int g0 = tile * UF_NBLK;
+    const int b_first = g0 / p.bps, bh_first = (g0 % p.bps) / p.nbw;
+    const int R0 = b_first * p.vr + 2 * bh_first;     // first virtual row of the tile (position row 2 bh - 1)
+    const int RW = 4 * p.rw4;
+    const int HW = p.H * p.W;
+
+    // ---- this lane's block
+    const int g = g0 + wn * 16 + l15;
+    const bool live = g < p.total_blocks;
+    const int gc = live ? g : p.total_blocks - 1;
+    const int b = gc / p.bps, rem = gc % p.bps, bh = rem / p.nbw, bw = rem % p.nbw;
+    const int xoff = (b * p.vr + 2 * bh - R0) * RW + 3 + 2 * bw;    // patch element (0, 0): row 2 bh - 1, column 2 bw - 1 (+ 4 pad)
+    const int soff = (b - b_first) * p.Cin;
+
+    // ---- style rows of the (at most two) samples of this tile
+    for (int e = tid; e < 2 * p.Cin; e += UF_THREADS) {
+        const int n = e / p.Cin, ci = e - n * p.Cin;
+        Sl[e] = p.s[(int64_t)min(b_first + n, p.B - 1) * p.Cin + ci];
+    }
+
+    // ---- DMA plan.  Weights: wave w moves channel ci0 + w, piece q = planes 4 q .. 4 q + 3 (lane >> 4) x 64 channels.
+    // Input: wave w moves channel ci0 + w, piece q = float4 q * 64 + lane of the [rows][rw4] tile.
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.u + o0), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x7FFFFFFF, 0x00020000);
+    const unsigned w_voff = (unsigned)((kq * p.Cout + 4 * l15) * 4);
+    const int xpieces = p.xs >> 8;
+    unsigned x_voff[UF_XP_MAX];
+#pragma unroll
+    for (int q = 0; q < UF_XP_MAX; ++q) {
+        const int i = q * 64 + lane;
+        const int row = i / p.rw4, c4 = i - row * p.rw4;
+        const int v = R0 + row;
+        const int bb = v / p.vr, h = v - bb * p.vr - 1, col = 4 * (c4 - 1);
+        const bool ok = q < xpieces && bb < p.B && h >= 0 && h < p.H && col >= 0 && col < p.W;
+        x_voff[q] = ok ? (unsigned)((bb * p.Cin * HW + h * p.W + col) * 4) : UF_OOB;
+    }
+    auto stage = [&](int ci0, int buf) {
+        float* wdst = Wl + (buf * UF_CC + wave) * UF_WROW;
+        const unsigned wbase = (unsigned)((ci0 + wave) * UF_PLANES * p.Cout * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) uf_dma16(w_rsrc, wdst + q * 256, w_voff, wbase + (unsigned)(q * 4 * p.Cout * 4));
+        float* xdst = Xl + (buf * UF_CC + wave) * p.xs;
+        const unsigned xbase = (unsigned)((ci0 + wave) * HW * 4);
+#pragma unroll
+        for (int q = 0; q < UF_XP_MAX; ++q)
+            if (q < xpieces) uf_dma16(x_rsrc, xdst + q * 256, x_voff[q], xbase);   // (wave-uniform)
+    };
+
+    uf_f32x4 acc[5][5][2];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[a][c][t] = uf_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();   // style rows
+    stage(0, 0);
+    __syncthreads();   // vmcnt(0) + barrier: chunk 0 landed
+
+    int buf = 0;
+    for (int ci0 = 0; ci0 < p.Cin; ci0 += UF_CC, buf ^= 1) {
+        if (ci0 + UF_CC < p.Cin) stage(ci0 + UF_CC, buf ^ 1);
+        const float* Wb = Wl + buf * UF_CC * UF_WROW;
+        const float* Xb = Xl + buf * UF_CC * p.xs;
+#pragma unroll
+        for (int ks = 0; ks < UF_CC / 4; ++ks) {
+            const int cl = 4 * ks + kq;                       // this lane's channel of the MFMA step
+            const float sv = Sl[soff + ci0 + cl];
+            const float* xb = Xb + cl * p.xs + xoff;
+            float c[3][4];                                    // column transform of the three patch rows
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float d0 = xb[r * RW] * sv, d1 = xb[r * RW + 1] * sv, d2 = xb[r * RW + 2] * sv;
+                c[r][0] = d0 - d1; c[r][1] = d1; c[r][2] = d2 - d1; c[r][3] = d2;
+            }
+            float t[4][4];                                    // row transform
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = c[0][j] - c[1][j]; t[1][j] = c[1][j]; t[2][j] = c[2][j] - c[1][j]; t[3][j] = c[2][j];
+            }
+            const float* wb = Wb + cl * UF_WROW + wm * 32 + l15;
+            // planes (u, v): one pair of A fragments each, used by every product (p, q) with pu[p] = u, pu[q] = v
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float a0 = wb[(u * 4 + v) * UF_MBLK], a1 = wb[(u * 4 + v) * UF_MBLK + 16];
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                        for (int qq = 0; qq < 2; ++qq) {
+                            if ((pp && u != 3) || (qq && v != 3)) continue;   // only plane row / column 3 serves two products (3 and 4)
+                            const int pi = u + pp, qi = v + qq;               // product indices: u (or 4 for the second use of row 3)
+                            const int di = pi == 3 ? 1 : (pi == 4 ? 3 : pi), dj = qi == 3 ? 1 : (qi == 4 ? 3 : qi);
+                            acc[pi][qi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, t[di][dj], acc[pi][qi][0], 0, 0, 0);
+                            acc[pi][qi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, t[di][dj], acc[pi][qi][1], 0, 0, 0);
+                        }
+                }
+        }
+        __syncthreads();   // next chunk's DMA retired (vmcnt 0) and everyone is done with this buffer
+    }
+
+    // ---- epilogue: output transform, demodulation, 16-byte stores of the block's 4 x 4 outputs per channel
+    if (!live) return;
+    const int OHW = p.OH * p.ORS;
+    const float* db = p.dscale + (int64_t)b * p.Cout;
+    float* ob = p.out + (int64_t)b * p.Cout * OHW + (int64_t)(4 * bh) * p.ORS + 4 * bw;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = o0 + wm * 32 + tt * 16 + 4 * kq + r;
+            const float d = db[co];
+            float cs[5][4];                                   // column sums per product row p
+#pragma unroll
+            for (int pi = 0; pi < 5; ++pi) {
+                cs[pi][0] = acc[pi][0][tt][r] + acc[pi][1][tt][r];
+                cs[pi][1] = acc[pi][3][tt][r];
+                cs[pi][2] = acc[pi][1][tt][r] + acc[pi][2][tt][r];
+                cs[pi][3] = acc[pi][4][tt][r];
+            }
+            float* oc = ob + (int64_t)co * OHW;
+#pragma unroll
+            for (int ro = 0; ro < 4; ++ro) {
+                if (4 * bh + ro >= p.OH) continue;
+                float4 v;
+                if (ro == 0) v = make_float4(cs[0][0] + cs[1][0], cs[0][1] + cs[1][1], cs[0][2] + cs[1][2], cs[0][3] + cs[1][3]);
+                else if (ro == 1) v = make_float4(cs[3][0], cs[3][1], cs[3][2], cs[3][3]);
+                else if (ro == 2) v = make_float4(cs[1][0] + cs[2][0], cs[1][1] + cs[2][1], cs[1][2] + cs[2][2], cs[1][3] + cs[2][3]);
+                else v = make_float4(cs[4][0], cs[4][1], cs[4][2], cs[4][3]);
+                *reinterpret_cast<float4*>(oc + ro * p.ORS) = make_float4(v.x * d, v.y * d, v.z * d, v.w * d);
+            }
+        }
+}
+
+// u[ci][4 pu + pv][co] = sum_{ky in K(pu), kx in K(pv)} w[co][ci][ky][kx]
+__global__ __launch_bounds__(256) void upfir_prepack_kernel(float* __restrict__ u, const float* __restrict__ w, int cout, int cin) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // i = ci * cout + co (co fastest: coalesced writes)
+    if (i >= (int64_t)cout * cin) return;
+    const int co = (int)(i % cout), ci = (int)(i / cout);
+    const float* src = w + ((int64_t)co * cin + ci) * 9;
+    float g[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = src[t];
+    // rows: K(0) = {2}, K(1) = {0, 2}, K(2) = {0}, K(3) = {1}
+    float rows[4][3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        rows[0][kx] = g[2][kx]; rows[1][kx] = g[0][kx] + g[2][kx]; rows[2][kx] = g[0][kx]; rows[3][kx] = g[1][kx];
+    }
+#pragma unroll
+    for (int pu = 0; pu < 4; ++pu) {
+        const float v4[4] = {rows[pu][2], rows[pu][0] + rows[pu][2], rows[pu][0], rows[pu][1]};
+#pragma unroll
+        for (int pv = 0; pv < 4; ++pv) u[((int64_t)ci * UF_PLANES + pu * 4 + pv) * cout + co] = v4[pv];
+    }
+}
+
+bool upfir_plan(UpFirParams& p, int batch, int cin, int cout, int h, int w, int row_stride, size_t* lds_bytes) {
+    if (batch <= 0 || h < 32 || w < 32 || (h & 1) || (w & 3) || cin % UF_CC || cout % UF_MBLK) return false;
+    if ((row_stride & 3) || row_stride < 2 * w + 4) return false;
+    if ((int64_t)batch * cin * h * w * 4 >= (1LL << 31) || (int64_t)cin * UF_PLANES * cout * 4 >= (1LL << 31)) return false;
+    p.B = batch; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w; p.OH = 2 * h + 1; p.ORS = row_stride;
+    p.nbw = w / 2 + 1;
+    const int nbh = h / 2 + 1;
+    p.bps = nbh * p.nbw;
+    if (p.bps < UF_NBLK) return false;      // a tile spans at most two samples
+    p.total_blocks = batch * p.bps;
+    p.vr = h + 3;
+    p.rw4 = w / 4 + 2;
+    const int n_tiles = sis_cdiv(p.total_blocks, UF_NBLK);
+    int rows_max = 0;
+    for (int t = 0; t < n_tiles; ++t) {
+        const int g0 = t * UF_NBLK, g1 = (g0 + UF_NBLK - 1 < p.total_blocks ? g0 + UF_NBLK - 1 : p.total_blocks - 1);
+        const int r0 = (g0 / p.bps) * p.vr + 2 * ((g0 % p.bps) / p.nbw);
+        const int r1 = (g1 / p.bps) * p.vr + 2 * ((g1 % p.bps) / p.nbw) + 2;
+        rows_max = r1 - r0 + 1 > rows_max ? r1 - r0 + 1 : rows_max;
+    }
+    p.xs = sis_cdiv(rows_max * 4 * p.rw4, 256) * 256;
+    if (p.xs > 256 * UF_XP_MAX) return false;
+    *lds_bytes = (size_t)(2 * UF_CC * UF_WROW + 2 * UF_CC * p.xs + 2 * cin) * sizeof(float);
+    return *lds_bytes <= 160 * 1024;
+}
+
+}  // namespace
+
+extern "C" int sis_modconv_up_fir_supported(int batch, int cin, int cout, int h, int w, int t_row_stride) {
+    UpFirParams p;
+    size_t lds;
+    return upfir_plan(p, batch, cin, cout, h, w, t_row_stride, &lds) ? 1 : 0;
+}
+
+extern "C" int sis_modconv_up_fir_prepack(float* u, const float* w, int cout, int cin, void* stream) {
+    SIS_REQUIRE(u && w, "sis_modconv_up_fir_prepack: null pointer");
+    SIS_REQUIRE(cout > 0 && cin > 0, "sis_modconv_up_fir_prepack: bad sizes");
+    const int64_t n = (int64_t)cout * cin;
+    hipLaunchKernelGGL(upfir_prepack_kernel, dim3(sis_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, u, w, cout, cin);
+    SIS_CHECK_LAUNCH("upfir_prepack_kernel");
+    return 0;
+}
+
+extern "C" int sis_modconv2d_up_fir(float* t, const float* x, const float* u, const float* s, const float* dscale, int batch,
+                                    int cin, int cout, int h, int w, int t_row_stride, void* stream) {
+    if (batch == 0) return 0;
+    SIS_REQUIRE(t && x && u && s && dscale, "sis_modconv2d_up_fir: null pointer");
+    SIS_REQUIRE((((uintptr_t)t | (uintptr_t)x | (uintptr_t)u) & 15) == 0, "sis_modconv2d_up_fir: pointers must be 16-byte aligned");
+    UpFirParams p;
+    size_t lds;
+    SIS_REQUIRE(upfir_plan(p, batch, cin, cout, h, w, t_row_stride, &lds),
+                "sis_modconv2d_up_fir: %d x (%d -> %d) on %d x %d with row stride %d is not supported (sis_modconv_up_fir_supported)", batch,
+                cin, cout, h, w, t_row_stride);
+    p.x = x; p.u = u; p.s = s; p.dscale = dscale; p.out = t;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return sis_fail("sis_modconv2d_up_fir: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int64_t grid = (int64_t)sis_cdiv(p.total_blocks, UF_NBLK) * (cout / UF_MBLK);
+    SIS_REQUIRE(grid > 0 && grid < ((int64_t)1 << 31), "sis_modconv2d_up_fir: bad grid");
+    SIS_OCC_REPORT(modconv_upfir_kernel, UF_THREADS, lds);
+    hipLaunchKernelGGL(modconv_upfir_kernel, dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
+    SIS_CHECK_LAUNCH("modconv_upfir_kernel");
+    sis_kernel_name = "modconv_upfir_kernel";
+    return 0;
+}

@@ -165,12 +165,21 @@ class ModulatedConv2d(nn.Module):
             if (self.kernel_size == 3 and not self.upsample and not self.downsample and self.in_channel % 8 == 0
                     and self.out_channel % 4 == 0 and os.environ.get("SIS_WINOGRAD", "1") != "0"):
                 self._wino = sis_hip.modconv_prepack_wino(w.detach())
+            # up-convolutions keep the 16 transformed planes of the fast-FIR kernel (25 instead of 36 multiplies per 2 x 2
+            # input positions, csrc/modconv_upfir.hip); the launch falls back to the 4-phase kernel below 32 x 32
+            self._fir = None
+            if self.kernel_size == 3 and self.upsample and self.in_channel % 8 == 0 and self.out_channel % 64 == 0:
+                self._fir = sis_hip.modconv_prepack_up_fir(w.detach())
             self._pack_key = key
         return self._pack
 
     def wino_weights(self):
         self.packed_weights()
         return self._wino
+
+    def fir_weights(self):
+        self.packed_weights()
+        return self._fir
 
     def hip_supported(self):
         return (not self.downsample) and (self.kernel_size == 3 or (self.kernel_size == 1 and not self.upsample))
@@ -289,7 +298,7 @@ class StyledConv(nn.Module):
         if conv.upsample:
             taps, pad = conv.blur.kernel, conv.blur.pad
             padded = tuple(taps.shape) == (4, 4) and pad[0] == 1  # row-streaming blur wants 16-byte aligned rows
-            t = sis_hip.modconv2d_up(input, wpk, s, dscale, padded_rows=padded)
+            t = sis_hip.modconv2d_up(input, wpk, s, dscale, padded_rows=padded, fir_u=conv.fir_weights())
             in_w = 2 * w + 1
             oh = t.shape[2] + pad[0] + pad[1] - taps.shape[0] + 1
             ow = in_w + pad[0] + pad[1] - taps.shape[1] + 1

@@ -78,6 +78,9 @@ _SIGNATURES = {
     "sis_conv3x3_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
     "sis_conv3x3": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
     "sis_modconv2d_up": ([_vp] * 5 + [_i] * 6 + [_vp, _i64, _vp], _i),
+    "sis_modconv_up_fir_supported": ([_i] * 6, _i),
+    "sis_modconv_up_fir_prepack": ([_vp, _vp, _i, _i, _vp], _i),
+    "sis_modconv2d_up_fir": ([_vp] * 5 + [_i] * 6 + [_vp], _i),
     "sis_blur_noise_act": ([_vp, _vp, _vp, _vp, _i64, _vp, _vp] + [_i] * 10 + [_vp], _i),
     "sis_to_rgb": ([_vp] * 7 + [_i] * 9 + [_f, _vp], _i),
     "sis_conv1x1_wgrad_f32_supported": ([_i] * 4, _i),
@@ -539,14 +542,37 @@ def modconv2d(x, wpk, s, dscale, ksize, noise=None, noise_weight=None, bias=None
     return out
 
 
-def modconv2d_up(x, wpk, s, dscale, padded_rows=False):
+_UP_FIR = os.environ.get("SIS_UP_FIR", "1") != "0"   # 0: up-convolutions on the 4-phase gather kernel only (A/B runs)
+
+
+def modconv_prepack_up_fir(weight):
+    """[1, Cout, Cin, 3, 3] parameter -> the 16 transformed planes [Cin, 16, Cout] of the fast-FIR up-convolution."""
+    w = _f32(weight, "weight")
+    if w.dim() == 5:
+        w = w[0]
+    cout, cin = w.shape[0], w.shape[1]
+    u = torch.empty((cin, 16, cout), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _check(lib().sis_modconv_up_fir_prepack(_ptr(u), _ptr(w), cout, cin, _stream()), "sis_modconv_up_fir_prepack")
+    return u
+
+
+def modconv2d_up(x, wpk, s, dscale, padded_rows=False, fir_u=None):
     """Transposed stride-2 modulated conv -> [B, Cout, 2H+1, 2W+1].  ``padded_rows=True`` returns the buffer with
-    rows padded to 2W+4 floats ([..., 2H+1, 2W+4], first 2W+1 columns meaningful) for sis_blur_noise_act."""
+    rows padded to 2W+4 floats ([..., 2H+1, 2W+4], first 2W+1 columns meaningful) for sis_blur_noise_act.  ``fir_u``
+    (modconv_prepack_up_fir) selects the fast-FIR kernel where it applies (padded rows, maps of 32 x 32 and larger)."""
     x = _f32(x, "input")
     batch, cin, h, w = x.shape
     cout = wpk.shape[2]
     row = 2 * w + 4 if padded_rows else 2 * w + 1
     out = torch.empty((batch, cout, 2 * h + 1, row), dtype=torch.float32, device=x.device)
+    if fir_u is not None and _UP_FIR and padded_rows and lib().sis_modconv_up_fir_supported(batch, cin, cout, h, w, row):
+        with torch.cuda.device(x.device):
+            # (FLOPs recorded in the direct 9-multiplies-per-position count of SURVEY.md 8(d); the kernel executes 25 / 36 of it)
+            _check(_launch(None, 2.0 * batch * cout * cin * 9 * h * w, 4.0 * (x.numel() + out.numel() + fir_u.numel()),
+                           lambda: lib().sis_modconv2d_up_fir(_ptr(out), _ptr(x), _ptr(fir_u), _ptr(s), _ptr(dscale), batch, cin, cout,
+                                                              h, w, row, _stream())), "sis_modconv2d_up_fir")
+        return out
     ws = _workspace(x.device)
     with torch.cuda.device(x.device):
         _check(_launch(None, 2.0 * batch * cout * cin * 9 * h * w,

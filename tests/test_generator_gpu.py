@@ -97,6 +97,63 @@ def test_modconv_up_vs_oracle(device, b, cin, cout, h, w):
         assert _rel(yp0, ref) < 2e-5
 
 
+@pytest.mark.parametrize("b,cin,cout,h,w", [(2, 16, 64, 32, 32), (3, 40, 128, 32, 32), (1, 8, 64, 64, 64), (2, 24, 64, 34, 40),
+                                             (5, 8, 64, 32, 32), (1, 8, 128, 128, 128), (2, 16, 64, 32, 64)])
+def test_modconv_up_fir_vs_oracle(device, b, cin, cout, h, w):
+    """The fast-FIR transposed convolution (csrc/modconv_upfir.hip: 25 products per 2 x 2 positions on
+    v_mfma_f32_16x16x4_f32) against the reference's formulation (per-sample weights, conv_transpose2d with B groups) at the
+    per-layer tolerance of every other generator kernel (2e-5 max|ref|), against the 4-phase kernel, and through the fused
+    blur + noise + bias + activation.  Shapes: tiles that cross from one sample into the next (3 x 289 blocks / 64), an odd
+    number of block rows, non-square maps, one to two workgroup columns."""
+    import sis_hip
+    gen = torch.Generator().manual_seed(b * 131 + cin + cout + h + w)
+    x, style = _mk(gen, b, cin, h, w), _mk(gen, b, 32)
+    weight, mod_w, mod_b = _mk(gen, 1, cout, cin, 3, 3), _mk(gen, cin, 32), 1 + 0.1 * _mk(gen, cin)
+    noise, nw, bias = _mk(gen, b, 1, 2 * h, 2 * w), 0.3 * _mk(gen, 1), 0.2 * _mk(gen, cout)
+    taps = ops_ref.make_kernel([1, 3, 3, 1]) * 4
+    with torch.no_grad():
+        s_ref = R.equal_linear(style, mod_w, mod_b).view(b, 1, cin, 1, 1)
+        wt = (1 / (cin * 9) ** 0.5) * weight * s_ref
+        wt = wt * torch.rsqrt(wt.pow(2).sum([2, 3, 4]) + 1e-8).view(b, cout, 1, 1, 1)
+        t_ref = torch.nn.functional.conv_transpose2d(x.reshape(1, b * cin, h, w),
+                                                     wt.transpose(1, 2).reshape(b * cin, cout, 3, 3), stride=2,
+                                                     groups=b).view(b, cout, 2 * h + 1, 2 * w + 1)
+        ref_act = ops_ref.fused_leaky_relu(R.modulated_conv2d(x, style, weight, mod_w, mod_b, True, True, taps) + nw * noise, bias)
+        d = lambda t: t.to(device)
+        wpk, wsq = sis_hip.modconv_prepack(d(weight))
+        fir_u = sis_hip.modconv_prepack_up_fir(d(weight))
+        assert tuple(fir_u.shape) == (cin, 16, cout)
+        s = sis_hip.equal_linear(d(style), d(mod_w), d(mod_b), 1 / 32 ** 0.5, 1.0, False)
+        ds = sis_hip.modconv_demod(s, wsq, 1 / (cin * 9) ** 0.5, True)
+        assert sis_hip.lib().sis_modconv_up_fir_supported(b, cin, cout, h, w, 2 * w + 4)
+        records = []
+        sis_hip.set_profiler(records)
+        try:
+            tp = sis_hip.modconv2d_up(d(x), wpk, s, ds, padded_rows=True, fir_u=fir_u)
+        finally:
+            sis_hip.set_profiler(None)
+        assert [r[0] for r in records] == ["modconv_upfir_kernel"]
+        assert tuple(tp.shape) == (b, cout, 2 * h + 1, 2 * w + 4)
+        assert _rel(tp[..., :2 * w + 1], t_ref) < 2e-5, _rel(tp[..., :2 * w + 1], t_ref)
+        t4 = sis_hip.modconv2d_up(d(x), wpk, s, ds, padded_rows=True)                     # the 4-phase gather kernel
+        assert _rel(tp[..., :2 * w + 1], t4[..., :2 * w + 1].cpu()) < 2e-5
+        assert torch.isfinite(tp).all()                                                   # padding columns: unspecified but finite
+        yp = sis_hip.blur_noise_act(tp, d(taps), (1, 1), d(noise), d(nw), d(bias), fuse_act=True, in_w=2 * w + 1)
+        assert _rel(yp, ref_act) < 2e-5
+        again = sis_hip.modconv2d_up(d(x), wpk, s, ds, padded_rows=True, fir_u=fir_u)
+        assert torch.equal(again[..., :2 * w + 1], tp[..., :2 * w + 1])
+
+
+def test_modconv_up_fir_declines_what_it_does_not_serve(device):
+    import sis_hip
+    L = sis_hip.lib()
+    assert not L.sis_modconv_up_fir_supported(2, 16, 64, 16, 16, 36)     # below 32 x 32: the 4-phase kernel (split-K there)
+    assert not L.sis_modconv_up_fir_supported(2, 16, 48, 32, 32, 68)     # output channels not a multiple of 64
+    assert not L.sis_modconv_up_fir_supported(2, 12, 64, 32, 32, 68)     # input channels not a multiple of 8
+    assert not L.sis_modconv_up_fir_supported(2, 16, 64, 32, 32, 65)     # un-padded rows
+    assert L.sis_modconv_up_fir_supported(32, 512, 512, 32, 32, 68) and L.sis_modconv_up_fir_supported(32, 256, 128, 128, 128, 260)
+
+
 @pytest.mark.parametrize("b,cin,h", [(2, 32, 4), (3, 64, 8), (2, 128, 32), (1, 16, 6)])
 def test_to_rgb_vs_oracle(device, b, cin, h):
     import sis_hip
