@@ -71,6 +71,17 @@ def step(g, z, noise):
         return g([z], noise=noise, return_intermediate_activations=True)
 
 
+def exec_ratio(kernel_name):
+    """Executed / direct-form matrix FLOPs of a kernel: Winograd F(2x2,3x3) runs 16 of the 36 multiplies of a 3x3 convolution,
+    the fast-FIR transposed convolution 25 of 36 (csrc/modconv_upfir.hip); launches are recorded in the direct-form count of
+    SURVEY.md 8(d)."""
+    if "wino" in kernel_name:
+        return 16.0 / 36.0
+    if "upfir" in kernel_name:
+        return 25.0 / 36.0
+    return 1.0
+
+
 def kernel_profile(g, z, noise, steps):
     """Per-kernel device time from HIP events recorded on the launch stream around every launch."""
     import sis_hip
@@ -341,7 +352,7 @@ def bench_training(args, workload, world, rank, device, distributed):
     # as dense stride-1 launches and dilated ones on sub-images are recorded (and counted) with the work they really do; the
     # attention backward is recorded with its 7 products (2 recomputed).  What still runs on vendor libraries (a 3-channel stem
     # convolution, a few small GEMMs) is NOT in this sum: the number is a lower bound of the executed rate.
-    executed_flops = sum(v["flops"] * (16.0 / 36.0 if "wino" in k else 1.0) for k, v in own.items())
+    executed_flops = sum(v["flops"] * exec_ratio(k) for k, v in own.items())
     step_s = elapsed / args.steps
     peak = PEAK_MFMA_BF16_TFLOPS if config.get("amp") else PEAK_MFMA_F32_TFLOPS
     nominal_tf, executed_tf = step_flops / step_s / 1e12, executed_flops / step_s / 1e12
@@ -356,7 +367,7 @@ def bench_training(args, workload, world, rank, device, distributed):
         if not v["ms"]:
             return {"launches": v["launches"], "ms": 0.0}
         sec = v["ms"] * 1e-3
-        executed = v["flops"] * (16.0 / 36.0 if "wino" in name else 1.0)
+        executed = v["flops"] * exec_ratio(name)
         tf, gbs = executed / sec / 1e12, v["bytes"] / sec / 1e9
         ridge = kernel_peak(name) * 1e12 / (PEAK_HBM_GBS * 1e9)      # FLOP per byte at which the two roofs meet
         hbm_bound = v["bytes"] > 0 and (v["flops"] == 0 or executed / v["bytes"] < ridge)
@@ -587,8 +598,8 @@ def bench_synthesis(args, world, rank, device, distributed):
     # The Winograd F(2x2,3x3) kernel executes 16 of the 36 multiplies of the direct form per 2x2 output tile.  SURVEY.md
     # §8(d) defines the unit work as direct-convolution FLOPs ("algorithmic_*" below, which can exceed the peak); the
     # roofline fraction proper is what the MFMA pipe EXECUTES: achieved = algorithmic * 16/36, frac = achieved / peak <= 1.
-    exec_ratio = 16.0 / 36.0 if "wino" in dom_name else 1.0
-    executed = algorithmic * exec_ratio
+    dom_ratio = exec_ratio(dom_name)
+    executed = algorithmic * dom_ratio
     traffic, traffic_src = measured_traffic(dom_name)
     roofline = {"kernel": dom_name, "bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_MFMA_F32_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(executed / PEAK_MFMA_F32_TFLOPS, 4),
@@ -601,11 +612,10 @@ def bench_synthesis(args, world, rank, device, distributed):
                 "launches_per_step": dom["launches"] // prof_steps,
                 "avg_launch_ms": round(per_launch_ms, 4),
                 "flops_per_launch": dom["flops"] / dom["launches"],
-                "executed_flops_per_launch": dom["flops"] / dom["launches"] * exec_ratio,
+                "executed_flops_per_launch": dom["flops"] / dom["launches"] * dom_ratio,
                 "kernels": {k: {"ms_per_step": round(v["ms"] / prof_steps, 4),
                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
-                                "executed_tflops": round(v["flops"] * (16.0 / 36.0 if "wino" in k else 1.0)
-                                                         / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                                "executed_tflops": round(v["flops"] * exec_ratio(k) / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
                                 "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
                             for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}}
     result = {

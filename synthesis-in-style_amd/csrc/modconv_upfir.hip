@@ -59,6 +59,7 @@ __device__ __forceinline__ void uf_dma16(__amdgpu_buffer_rsrc_t r, float* l, uns
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
 }
 
+template <int PIPE>
 __global__ __launch_bounds__(UF_THREADS) void modconv_upfir_kernel(const UpFirParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Wl = lds;                              // [2][CC][WROW]
@@ -132,13 +133,18 @@ __global__ __launch_bounds__(UF_THREADS) void modconv_upfir_kernel(const UpFirPa
     __syncthreads();   // vmcnt(0) + barrier: chunk 0 landed
 
     int buf = 0;
+    // PIPE == 3: the SIMD partners (waves w and w + 4) run out of step inside a chunk -- waves 0-3 issue their DMA for the next
+    // chunk at its start, waves 4-7 between their two MFMA steps -- so that one partner's staging / transform phase falls under
+    // the other's MFMAs instead of both idling the matrix pipe behind the barrier (MI355X_MICROARCH.md, two waves per SIMD,
+    // item 9: split roles by wave number >= 4).
+    const bool late_dma = PIPE == 3 && wave >= 4;
     for (int ci0 = 0; ci0 < p.Cin; ci0 += UF_CC, buf ^= 1) {
-        if (ci0 + UF_CC < p.Cin) stage(ci0 + UF_CC, buf ^ 1);
+        if (!late_dma && ci0 + UF_CC < p.Cin) stage(ci0 + UF_CC, buf ^ 1);
         const float* Wb = Wl + buf * UF_CC * UF_WROW;
         const float* Xb = Xl + buf * UF_CC * p.xs;
-#pragma unroll
-        for (int ks = 0; ks < UF_CC / 4; ++ks) {
-            const int cl = 4 * ks + kq;                       // this lane's channel of the MFMA step
+        // Transform of one MFMA step (4 channels: this lane's is 4 ks + kq): raw 3 x 3 patch x style -> t[4][4]
+        auto transform = [&](int ks, float (&t)[4][4]) {
+            const int cl = 4 * ks + kq;
             const float sv = Sl[soff + ci0 + cl];
             const float* xb = Xb + cl * p.xs + xoff;
             float c[3][4];                                    // column transform of the three patch rows
@@ -147,29 +153,57 @@ __global__ __launch_bounds__(UF_THREADS) void modconv_upfir_kernel(const UpFirPa
                 const float d0 = xb[r * RW] * sv, d1 = xb[r * RW + 1] * sv, d2 = xb[r * RW + 2] * sv;
                 c[r][0] = d0 - d1; c[r][1] = d1; c[r][2] = d2 - d1; c[r][3] = d2;
             }
-            float t[4][4];                                    // row transform
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; ++j) {                     // row transform
                 t[0][j] = c[0][j] - c[1][j]; t[1][j] = c[1][j]; t[2][j] = c[2][j] - c[1][j]; t[3][j] = c[2][j];
             }
-            const float* wb = Wb + cl * UF_WROW + wm * 32 + l15;
-            // planes (u, v): one pair of A fragments each, used by every product (p, q) with pu[p] = u, pu[q] = v
+        };
+        // The 50 MFMAs of one step.  Planes (u, v) in order, one pair of A fragments each, used by every product (p, q) with
+        // pu[p] = u, pu[q] = v (plane row / column 3 serves the products 3 and 4).  PIPE >= 1: the fragments of plane i + 2 are
+        // requested before the MFMAs of plane i (a ring of three register pairs, pinned with sched_group_barrier: left to
+        // itself the compiler reads each pair right in front of its MFMAs and waits for it -- 32 exposed LDS latencies per chunk).
+        auto multiply = [&](int ks, const float (&t)[4][4]) {
+            const float* wb = Wb + (4 * ks + kq) * UF_WROW + wm * 32 + l15;
+            float ra0[3], ra1[3];
+            auto fetch = [&](int i) { ra0[i % 3] = wb[i * UF_MBLK]; ra1[i % 3] = wb[i * UF_MBLK + 16]; };
+            if constexpr (PIPE >= 1) { fetch(0); fetch(1); }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int i = 0; i < 16; ++i) {
+                const int u = i >> 2, v = i & 3;
+                if constexpr (PIPE >= 1) { if (i + 2 < 16) fetch(i + 2); }
+                else fetch(i);
+                const float a0 = ra0[i % 3], a1 = ra1[i % 3];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float a0 = wb[(u * 4 + v) * UF_MBLK], a1 = wb[(u * 4 + v) * UF_MBLK + 16];
+                for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-                    for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-                        for (int qq = 0; qq < 2; ++qq) {
-                            if ((pp && u != 3) || (qq && v != 3)) continue;   // only plane row / column 3 serves two products (3 and 4)
-                            const int pi = u + pp, qi = v + qq;               // product indices: u (or 4 for the second use of row 3)
-                            const int di = pi == 3 ? 1 : (pi == 4 ? 3 : pi), dj = qi == 3 ? 1 : (qi == 4 ? 3 : qi);
-                            acc[pi][qi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, t[di][dj], acc[pi][qi][0], 0, 0, 0);
-                            acc[pi][qi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, t[di][dj], acc[pi][qi][1], 0, 0, 0);
-                        }
+                    for (int qq = 0; qq < 2; ++qq) {
+                        if ((pp && u != 3) || (qq && v != 3)) continue;
+                        const int pi = u + pp, qi = v + qq;               // product indices: u (or 4 for the second use of row 3)
+                        const int di = pi == 3 ? 1 : (pi == 4 ? 3 : pi), dj = qi == 3 ? 1 : (qi == 4 ? 3 : qi);
+                        acc[pi][qi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, t[di][dj], acc[pi][qi][0], 0, 0, 0);
+                        acc[pi][qi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, t[di][dj], acc[pi][qi][1], 0, 0, 0);
+                    }
+                if constexpr (PIPE >= 1) {
+                    if (i + 2 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the read of plane i + 2 ...
+                    // ... then the MFMAs of plane i: 2 (two channel tiles), 4 on the last plane row / column, 8 in the corner
+                    if (u == 3 && v == 3) __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                    else if (u == 3 || v == 3) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 }
+            }
+        };
+        float t0[4][4], t1[4][4];
+        if constexpr (PIPE == 2) {   // both steps' transforms first: the second one's loads and VALU go under the first step's MFMAs
+            transform(0, t0);
+            transform(1, t1);
+            multiply(0, t0);
+            multiply(1, t1);
+        } else {
+            transform(0, t0);
+            multiply(0, t0);
+            if (late_dma && ci0 + UF_CC < p.Cin) stage(ci0 + UF_CC, buf ^ 1);
+            transform(1, t1);
+            multiply(1, t1);
         }
         __syncthreads();   // next chunk's DMA retired (vmcnt 0) and everyone is done with this buffer
     }
@@ -286,14 +320,20 @@ extern "C" int sis_modconv2d_up_fir(float* t, const float* x, const float* u, co
     p.x = x; p.u = u; p.s = s; p.dscale = dscale; p.out = t;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return sis_fail("sis_modconv2d_up_fir: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int64_t grid = (int64_t)sis_cdiv(p.total_blocks, UF_NBLK) * (cout / UF_MBLK);
     SIS_REQUIRE(grid > 0 && grid < ((int64_t)1 << 31), "sis_modconv2d_up_fir: bad grid");
-    SIS_OCC_REPORT(modconv_upfir_kernel, UF_THREADS, lds);
-    hipLaunchKernelGGL(modconv_upfir_kernel, dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
+    static const int pipe = getenv("SIS_UPFIR_PIPE") ? atoi(getenv("SIS_UPFIR_PIPE")) : 1;   // software-pipelining variant (experiments)
+    if (pipe == 0) hipLaunchKernelGGL(modconv_upfir_kernel<0>, dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
+    else if (pipe == 2) hipLaunchKernelGGL(modconv_upfir_kernel<2>, dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
+    else if (pipe == 3) hipLaunchKernelGGL(modconv_upfir_kernel<3>, dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(modconv_upfir_kernel<1>, dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
     SIS_CHECK_LAUNCH("modconv_upfir_kernel");
     sis_kernel_name = "modconv_upfir_kernel";
     return 0;
