@@ -142,8 +142,9 @@ int sis_modconv2d_up(float* t, const float* x, const float* wpk, const float* s,
                      int t_row_stride, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* The same transposed convolution in its fast-FIR form (csrc/modconv_upfir.hip): 25 instead of 36 multiplies per 2 x 2 input
- * positions (F(2,2) of the 2-tap even phases per axis), on v_mfma_f32_16x16x4_f32.  `u` = the 16 transformed weight planes
- * [cin][16][cout] written by sis_modconv_up_fir_prepack from the layer's weight [cout][cin][3][3] (once per checkpoint).
+ * positions (F(2,2) of the 2-tap even phases per axis), on v_mfma_f32_16x16x4_f32.  `u` = the 16 transformed weight planes,
+ * [cin][8 plane pairs][cout][2], written by sis_modconv_up_fir_prepack from the layer's weight [cout][cin][3][3] (once per
+ * checkpoint).
  * t: [batch][cout][2h+1][t_row_stride] with t_row_stride % 4 == 0 and >= 2w + 4 (columns beyond 2w are padding and receive
  * unspecified finite values).  sis_modconv_up_fir_supported: h, w >= 32, h even, w % 4 == 0, cin % 8 == 0, cout % 64 == 0,
  * operands below 2 GiB. */

@@ -40,8 +40,9 @@ constexpr int UF_CC = 8;                              // input channels per chun
 constexpr int UF_MBLK = 64;                           // output channels per workgroup
 constexpr int UF_NBLK = 64;                           // position blocks per workgroup
 constexpr int UF_PLANES = 16;
-constexpr int UF_WROW = UF_PLANES * UF_MBLK + 16;     // floats per channel row of the weight stage: +16 puts the 4 channels a
-                                                      // 32-lane read group touches 16 banks apart (conflict-free ds_read_b32)
+constexpr int UF_WROW = UF_PLANES * UF_MBLK + 32;     // floats per channel row of the weight stage [8 plane pairs][64 co][2]:
+                                                      // +32 puts the two channels a 32-lane group of a ds_read_b64 touches 32
+                                                      // banks (of 64) apart: conflict-free
 constexpr int UF_THREADS = 512;
 constexpr int UF_XP_MAX = 4;                          // 1 KiB pieces per channel of the input tile (xs <= 1024 floats)
 constexpr unsigned UF_OOB = 0x80000000u;
@@ -59,7 +60,10 @@ __device__ __forceinline__ void uf_dma16(__amdgpu_buffer_rsrc_t r, float* l, uns
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
 }
 
-template <int PIPE>
+// ABL: timing ablations for development builds (tools/bench_upfir.py, SIS_UPFIR_ABL): bit 0 no barrier in the chunk loop, bit 1 no
+// DMA in the loop, bit 2 no patch reads / transform in the loop, bit 3 no weight-fragment reads in the loop.  Any non-zero value
+// computes WRONG results; the shipped kernel is ABL = 0.
+template <int PIPE, int ABL = 0>
 __global__ __launch_bounds__(UF_THREADS) void modconv_upfir_kernel(const UpFirParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Wl = lds;                              // [2][CC][WROW]
@@ -94,9 +98,10 @@ __global__ __launch_bounds__(UF_THREADS) void modconv_upfir_kernel(const UpFirPa
 
     // ---- DMA plan.  Weights: wave w moves channel ci0 + w, piece q = planes 4 q .. 4 q + 3 (lane >> 4) x 64 channels.
     // Input: wave w moves channel ci0 + w, piece q = float4 q * 64 + lane of the [rows][rw4] tile.
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.u + o0), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.u + 2 * o0), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x7FFFFFFF, 0x00020000);
-    const unsigned w_voff = (unsigned)((kq * p.Cout + 4 * l15) * 4);
+    // weight image of a channel: [plane pair 0..7][co][2 planes]; a 1 KiB piece = two pairs x 64 channels x 2
+    const unsigned w_voff = (unsigned)(((lane >> 5) * p.Cout * 2 + (lane & 31) * 4) * 4);
     const int xpieces = p.xs >> 8;
     unsigned x_voff[UF_XP_MAX];
 #pragma unroll
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(UF_THREADS) void modconv_upfir_kernel(const UpFirPa
         float* wdst = Wl + (buf * UF_CC + wave) * UF_WROW;
         const unsigned wbase = (unsigned)((ci0 + wave) * UF_PLANES * p.Cout * 4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) uf_dma16(w_rsrc, wdst + q * 256, w_voff, wbase + (unsigned)(q * 4 * p.Cout * 4));
+        for (int q = 0; q < 4; ++q) uf_dma16(w_rsrc, wdst + q * 256, w_voff, wbase + (unsigned)(q * 2 * p.Cout * 2 * 4));
         float* xdst = Xl + (buf * UF_CC + wave) * p.xs;
         const unsigned xbase = (unsigned)((ci0 + wave) * HW * 4);
 #pragma unroll
@@ -133,17 +138,21 @@ __global__ __launch_bounds__(UF_THREADS) void modconv_upfir_kernel(const UpFirPa
     __syncthreads();   // vmcnt(0) + barrier: chunk 0 landed
 
     int buf = 0;
+    float t0[4][4] = {}, t1[4][4] = {};
     // PIPE == 3: the SIMD partners (waves w and w + 4) run out of step inside a chunk -- waves 0-3 issue their DMA for the next
     // chunk at its start, waves 4-7 between their two MFMA steps -- so that one partner's staging / transform phase falls under
     // the other's MFMAs instead of both idling the matrix pipe behind the barrier (MI355X_MICROARCH.md, two waves per SIMD,
     // item 9: split roles by wave number >= 4).
     const bool late_dma = PIPE == 3 && wave >= 4;
     for (int ci0 = 0; ci0 < p.Cin; ci0 += UF_CC, buf ^= 1) {
-        if (!late_dma && ci0 + UF_CC < p.Cin) stage(ci0 + UF_CC, buf ^ 1);
+        if (!(ABL & 2) && !late_dma && ci0 + UF_CC < p.Cin) stage(ci0 + UF_CC, buf ^ 1);
         const float* Wb = Wl + buf * UF_CC * UF_WROW;
         const float* Xb = Xl + buf * UF_CC * p.xs;
         // Transform of one MFMA step (4 channels: this lane's is 4 ks + kq): raw 3 x 3 patch x style -> t[4][4]
         auto transform = [&](int ks, float (&t)[4][4]) {
+            if constexpr (ABL & 4) {
+                if (ci0 != 0) return;   // (the first chunk's values stay in the registers)
+            }
             const int cl = 4 * ks + kq;
             const float sv = Sl[soff + ci0 + cl];
             const float* xb = Xb + cl * p.xs + xoff;
@@ -163,36 +172,50 @@ __global__ __launch_bounds__(UF_THREADS) void modconv_upfir_kernel(const UpFirPa
         // requested before the MFMAs of plane i (a ring of three register pairs, pinned with sched_group_barrier: left to
         // itself the compiler reads each pair right in front of its MFMAs and waits for it -- 32 exposed LDS latencies per chunk).
         auto multiply = [&](int ks, const float (&t)[4][4]) {
-            const float* wb = Wb + (4 * ks + kq) * UF_WROW + wm * 32 + l15;
-            float ra0[3], ra1[3];
-            auto fetch = [&](int i) { ra0[i % 3] = wb[i * UF_MBLK]; ra1[i % 3] = wb[i * UF_MBLK + 16]; };
+            // A fragments: one ds_read2_b64 per PAIR of planes (u, 2 h) / (u, 2 h + 1) delivers both planes for both channel tiles
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const float* wb = Wb + (4 * ks + kq) * UF_WROW + (wm * 32 + l15) * 2;
+            f2 ra[3][2];   // ring of three pairs x two channel tiles
+            auto fetch = [&](int k) {
+                if constexpr (ABL & 8) {
+                    ra[k % 3][0] = f2{(float)(k + lane), (float)(k - lane)}; ra[k % 3][1] = f2{(float)lane, (float)k};
+                } else {
+                    ra[k % 3][0] = *reinterpret_cast<const f2*>(wb + k * 2 * UF_MBLK);
+                    ra[k % 3][1] = *reinterpret_cast<const f2*>(wb + k * 2 * UF_MBLK + 32);
+                }
+            };
             if constexpr (PIPE >= 1) { fetch(0); fetch(1); }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int u = i >> 2, v = i & 3;
-                if constexpr (PIPE >= 1) { if (i + 2 < 16) fetch(i + 2); }
-                else fetch(i);
-                const float a0 = ra0[i % 3], a1 = ra1[i % 3];
+            for (int k = 0; k < 8; ++k) {
+                if constexpr (PIPE >= 1) { if (k + 2 < 8) fetch(k + 2); }
+                else fetch(k);
 #pragma unroll
-                for (int pp = 0; pp < 2; ++pp)
+                for (int e = 0; e < 2; ++e) {
+                    const int i = 2 * k + e, u = i >> 2, v = i & 3;
+                    const float a0 = ra[k % 3][0][e], a1 = ra[k % 3][1][e];
 #pragma unroll
-                    for (int qq = 0; qq < 2; ++qq) {
-                        if ((pp && u != 3) || (qq && v != 3)) continue;
-                        const int pi = u + pp, qi = v + qq;               // product indices: u (or 4 for the second use of row 3)
-                        const int di = pi == 3 ? 1 : (pi == 4 ? 3 : pi), dj = qi == 3 ? 1 : (qi == 4 ? 3 : qi);
-                        acc[pi][qi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, t[di][dj], acc[pi][qi][0], 0, 0, 0);
-                        acc[pi][qi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, t[di][dj], acc[pi][qi][1], 0, 0, 0);
-                    }
+                    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                        for (int qq = 0; qq < 2; ++qq) {
+                            if ((pp && u != 3) || (qq && v != 3)) continue;
+                            const int pi = u + pp, qi = v + qq;               // product indices: u (or 4 for the second use of row 3)
+                            const int di = pi == 3 ? 1 : (pi == 4 ? 3 : pi), dj = qi == 3 ? 1 : (qi == 4 ? 3 : qi);
+                            acc[pi][qi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, t[di][dj], acc[pi][qi][0], 0, 0, 0);
+                            acc[pi][qi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, t[di][dj], acc[pi][qi][1], 0, 0, 0);
+                        }
+                }
                 if constexpr (PIPE >= 1) {
-                    if (i + 2 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the read of plane i + 2 ...
-                    // ... then the MFMAs of plane i: 2 (two channel tiles), 4 on the last plane row / column, 8 in the corner
-                    if (u == 3 && v == 3) __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-                    else if (u == 3 || v == 3) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                    else __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    if (k + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // the read of pair k + 2 ...
+                    // ... then the MFMAs of pair k: planes (u, v) and (u, v + 1) with v even: 2 + 2, on plane row 3: 4 + 4,
+                    // and with plane column 3 in the pair twice as many for that plane
+                    const int u = (2 * k) >> 2, vhi = ((2 * k) & 3) + 1;
+                    if (u == 3 && vhi == 3) __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                    else if (u == 3) __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                    else if (vhi == 3) __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 }
             }
         };
-        float t0[4][4], t1[4][4];
         if constexpr (PIPE == 2) {   // both steps' transforms first: the second one's loads and VALU go under the first step's MFMAs
             transform(0, t0);
             transform(1, t1);
@@ -205,7 +228,7 @@ __global__ __launch_bounds__(UF_THREADS) void modconv_upfir_kernel(const UpFirPa
             transform(1, t1);
             multiply(1, t1);
         }
-        __syncthreads();   // next chunk's DMA retired (vmcnt 0) and everyone is done with this buffer
+        if constexpr (!(ABL & 1)) __syncthreads();   // next chunk's DMA retired (vmcnt 0) and everyone is done with this buffer
     }
 
     // ---- epilogue: output transform, demodulation, 16-byte stores of the block's 4 x 4 outputs per channel
@@ -241,7 +264,7 @@ __global__ __launch_bounds__(UF_THREADS) void modconv_upfir_kernel(const UpFirPa
         }
 }
 
-// u[ci][4 pu + pv][co] = sum_{ky in K(pu), kx in K(pv)} w[co][ci][ky][kx]
+// u[ci][plane pair 2 pu + pv / 2][co][pv % 2] = sum_{ky in K(pu), kx in K(pv)} w[co][ci][ky][kx]
 __global__ __launch_bounds__(256) void upfir_prepack_kernel(float* __restrict__ u, const float* __restrict__ w, int cout, int cin) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // i = ci * cout + co (co fastest: coalesced writes)
     if (i >= (int64_t)cout * cin) return;
@@ -260,7 +283,8 @@ __global__ __launch_bounds__(256) void upfir_prepack_kernel(float* __restrict__ 
     for (int pu = 0; pu < 4; ++pu) {
         const float v4[4] = {rows[pu][2], rows[pu][0] + rows[pu][2], rows[pu][0], rows[pu][1]};
 #pragma unroll
-        for (int pv = 0; pv < 4; ++pv) u[((int64_t)ci * UF_PLANES + pu * 4 + pv) * cout + co] = v4[pv];
+        for (int h = 0; h < 2; ++h)   // plane pair (pu, 2 h), (pu, 2 h + 1): the two planes of a channel side by side
+            *reinterpret_cast<float2*>(u + (((int64_t)ci * 8 + pu * 2 + h) * cout + co) * 2) = make_float2(v4[2 * h], v4[2 * h + 1]);
     }
 }
 
@@ -330,6 +354,24 @@ extern "C" int sis_modconv2d_up_fir(float* t, const float* x, const float* u, co
     const int64_t grid = (int64_t)sis_cdiv(p.total_blocks, UF_NBLK) * (cout / UF_MBLK);
     SIS_REQUIRE(grid > 0 && grid < ((int64_t)1 << 31), "sis_modconv2d_up_fir: bad grid");
     static const int pipe = getenv("SIS_UPFIR_PIPE") ? atoi(getenv("SIS_UPFIR_PIPE")) : 1;   // software-pipelining variant (experiments)
+    static const int abl = getenv("SIS_UPFIR_ABL") ? atoi(getenv("SIS_UPFIR_ABL")) : 0;      // timing ablations: WRONG results
+    if (abl) {
+#define UF_ABL(A) hipLaunchKernelGGL((modconv_upfir_kernel<1, A>), dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p)
+        static bool abl_attr = false;
+        if (!abl_attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<1, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            abl_attr = true;
+        }
+        if (abl == 1) UF_ABL(1); else if (abl == 2) UF_ABL(2); else if (abl == 4) UF_ABL(4); else if (abl == 8) UF_ABL(8); else UF_ABL(15);
+#undef UF_ABL
+        SIS_CHECK_LAUNCH("modconv_upfir_kernel<ablation>");
+        sis_kernel_name = "modconv_upfir_kernel";
+        return 0;
+    }
     if (pipe == 0) hipLaunchKernelGGL(modconv_upfir_kernel<0>, dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
     else if (pipe == 2) hipLaunchKernelGGL(modconv_upfir_kernel<2>, dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
     else if (pipe == 3) hipLaunchKernelGGL(modconv_upfir_kernel<3>, dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);

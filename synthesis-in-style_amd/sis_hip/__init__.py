@@ -546,12 +546,12 @@ _UP_FIR = os.environ.get("SIS_UP_FIR", "1") != "0"   # 0: up-convolutions on the
 
 
 def modconv_prepack_up_fir(weight):
-    """[1, Cout, Cin, 3, 3] parameter -> the 16 transformed planes [Cin, 16, Cout] of the fast-FIR up-convolution."""
+    """[1, Cout, Cin, 3, 3] parameter -> the 16 transformed planes of the fast-FIR up-convolution, [Cin, 8 plane pairs, Cout, 2]."""
     w = _f32(weight, "weight")
     if w.dim() == 5:
         w = w[0]
     cout, cin = w.shape[0], w.shape[1]
-    u = torch.empty((cin, 16, cout), dtype=torch.float32, device=w.device)
+    u = torch.empty((cin, 8, cout, 2), dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
         _check(lib().sis_modconv_up_fir_prepack(_ptr(u), _ptr(w), cout, cin, _stream()), "sis_modconv_up_fir_prepack")
     return u

@@ -122,7 +122,7 @@ def test_modconv_up_fir_vs_oracle(device, b, cin, cout, h, w):
         d = lambda t: t.to(device)
         wpk, wsq = sis_hip.modconv_prepack(d(weight))
         fir_u = sis_hip.modconv_prepack_up_fir(d(weight))
-        assert tuple(fir_u.shape) == (cin, 16, cout)
+        assert tuple(fir_u.shape) == (cin, 8, cout, 2)
         s = sis_hip.equal_linear(d(style), d(mod_w), d(mod_b), 1 / 32 ** 0.5, 1.0, False)
         ds = sis_hip.modconv_demod(s, wsq, 1 / (cin * 9) ** 0.5, True)
         assert sis_hip.lib().sis_modconv_up_fir_supported(b, cin, cout, h, w, 2 * w + 4)
