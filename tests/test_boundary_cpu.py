@@ -83,3 +83,21 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_library_call_audit(monkeypatch):
+    """sis_hip.library_call: the per-site counters bench.py reports (library_calls_per_step) and the strict position
+    SIS_NO_LIBRARY_FALLBACK=1, in which a layer an own kernel should have taken raises instead of running on MIOpen / hipBLASLt;
+    layers that are MEANT to stay on the libraries (the 3-channel stem) never raise."""
+    import sis_hip
+    sis_hip.library_calls(reset=True)
+    sis_hip.library_call("unit.site")
+    sis_hip.library_call("unit.site")
+    sis_hip.library_call("unit.stem", intended=True)
+    assert sis_hip.library_calls(reset=True) == {"fallback": {"unit.site": 2}, "intended": {"unit.stem": 1}}
+    assert sis_hip.library_calls() == {"fallback": {}, "intended": {}}
+    monkeypatch.setattr(sis_hip, "_LIBRARY_STRICT", True)
+    sis_hip.library_call("unit.stem", intended=True)
+    with pytest.raises(RuntimeError, match="unit.site fell back"):
+        sis_hip.library_call("unit.site")
+    sis_hip.library_calls(reset=True)
