@@ -1,4 +1,4 @@
-"""One up-convolution on the fast-FIR kernel, a few launches (for rocprofv3 --pmc passes).  usage: bench_upfir_one.py cin cout h [batch]"""
+"""One up-convolution on the fast-FIR kernel, a few launches (for rocprofv3 --pmc passes).  usage: bench_upfir_one.py cin cout h [batch] [fir: 1 | 0 = the 4-phase gather kernel on the same layer]"""
 import os
 import sys
 
@@ -9,6 +9,7 @@ import sis_hip  # noqa: E402
 
 cin, cout, h = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+use_fir = (int(sys.argv[5]) if len(sys.argv) > 5 else 1) != 0
 dev = torch.device("cuda:0")
 x = torch.randn(B, cin, h, h, device=dev)
 w = torch.randn(1, cout, cin, 3, 3, device=dev)
@@ -17,5 +18,5 @@ wpk, wsq = sis_hip.modconv_prepack(w)
 fir = sis_hip.modconv_prepack_up_fir(w)
 ds = sis_hip.modconv_demod(s, wsq, 1 / (cin * 9) ** 0.5, True)
 for _ in range(6):
-    sis_hip.modconv2d_up(x, wpk, s, ds, padded_rows=True, fir_u=fir)
+    sis_hip.modconv2d_up(x, wpk, s, ds, padded_rows=True, fir_u=fir if use_fir else None)
 torch.cuda.synchronize()
