@@ -477,8 +477,11 @@ class HipConv2d(nn.Conv2d):
                 and input.shape[2] == 2 * d and input.shape[3] == 2 * d and input.is_cuda and input.is_contiguous())
 
     def _pointwise(self, input):
+        # (same dtype on both sides: under autocast with the bf16 kernels switched off the layer is the plain module, whose
+        # backward autograd derives -- _Pointwise.backward runs outside the autocast region and would see bf16 x fp32)
         return (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.groups == 1
-                and input.is_cuda and input.dim() == 4 and input.is_contiguous())
+                and input.is_cuda and input.dim() == 4 and input.is_contiguous() and input.dtype == self.weight.dtype
+                and not torch.is_autocast_enabled())
 
     def _stride2(self, input):
         """fp32 stride-2 layers (EMANet: layer2's 3x3 and its 1x1 shortcut) on the stride-1 kernels: a strided convolution
