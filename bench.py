@@ -237,7 +237,11 @@ def data_parallel_rehearsal(args, workload, config, device):
     if not dist.is_initialized():
         return None
     out = {"backend": dist.get_backend(), "world": dist.get_world_size(), "flavour": config.get("data_parallel", "buckets")}
-    for mode, hip_graph in (("graph", True), ("eager", False)):
+    import training.grad_exchange as grad_exchange
+    # "graph" / "eager": collectives issued straight into librccl.so (the default at world size 1, capturable);
+    # "torch_collectives_eager": the same buckets through torch.distributed's work objects -- the DEFAULT at world size > 1
+    for mode, hip_graph, direct in (("graph", True, "auto"), ("eager", False, "auto"), ("torch_collectives_eager", False, "0")):
+        grad_exchange._DIRECT_RCCL = direct
         gc.collect()
         torch.cuda.empty_cache()
         cfg = dict(config, force_data_parallel=True, hip_graph=hip_graph)
@@ -260,7 +264,10 @@ def data_parallel_rehearsal(args, workload, config, device):
         out["collective"] = net.collective
         if hip_graph:
             out["hip_graph"] = updater._step_graph.graph is not None
+            out["direct_rccl"] = net.direct_rccl()
         del updater, builder, net
+    grad_exchange._DIRECT_RCCL = "auto"
+    out["default_at_world_size_gt_1"] = "torch_collectives_eager (SIS_DP_DIRECT_RCCL=auto); SIS_DP_DIRECT_RCCL=1: graph"
     return out
 
 

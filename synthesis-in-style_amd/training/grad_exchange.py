@@ -37,7 +37,12 @@ from torch import nn
 
 
 _DEBUG = os.environ.get("SIS_DP_DEBUG", "0") == "1"
-_DIRECT_RCCL = os.environ.get("SIS_DP_DIRECT_RCCL", "1") != "0"   # 0: the collectives through torch.distributed work objects
+# Collectives straight into librccl.so (stream work only: capturable into the step hipGraph) or through torch.distributed work
+# objects (eager only).  "auto": direct at world size 1 -- the one configuration a 1-GPU box can run and
+# tests/test_distributed_gpu.py + bench.py's data_parallel_rehearsal verify -- and torch.distributed's own, long-proven
+# reduce_scatter_tensor / all_gather_into_tensor at world size > 1, where the direct path cannot be rehearsed here (RCCL refuses
+# two ranks on one device); "1" forces the direct path (and with it the captured step) at any world size, "0" never uses it.
+_DIRECT_RCCL = os.environ.get("SIS_DP_DIRECT_RCCL", "auto")
 
 
 class _Rccl:
@@ -123,7 +128,7 @@ class BucketedDataParallel(nn.Module):
             pass
         self._pending = []   # work handles of collectives issued through torch.distributed during the current backward
         self._comm, self._comm_stream, self._joined = None, None, True
-        if self._on_gpu and self.backend == "nccl" and _DIRECT_RCCL:
+        if self._on_gpu and self.backend == "nccl" and (_DIRECT_RCCL == "1" or (_DIRECT_RCCL == "auto" and self.world == 1)):
             self._comm = _Rccl.communicator(process_group, self.device)
             if self._comm is None:   # the communicator is created lazily by the first collective
                 probe = torch.zeros(1, device=self.device)
@@ -320,5 +325,6 @@ class BucketedDataParallel(nn.Module):
         return [(b.flat.data_ptr(), b.flat.data_ptr() + 4 * b.numel) for b in (self.buckets or [])]
 
     def capturable(self) -> bool:
-        """The step hipGraph may include this exchange: RCCL collectives are stream work; gloo synchronises on the host."""
-        return self._on_gpu and self.backend == "nccl"
+        """The step hipGraph may include this exchange: collectives issued straight into RCCL are stream work; torch.distributed's
+        work objects (watchdog events) and gloo (host synchronisation) are not."""
+        return self._on_gpu and self.backend == "nccl" and self._comm is not None

@@ -137,6 +137,14 @@ def _rccl_worker(rank, world, port, out, golden_dir):
         init = E.seeded_state_dict(50, 3, seed=wseed, residual_scale=0.1)
         _, _, upd_plain, losses_plain, sd_plain = run(False)
         _, net_ddp, upd_ddp, losses_ddp, _ = run(True, "ddp")
+        # the default at world size > 1 (SIS_DP_DIRECT_RCCL=auto): the same buckets, collectives through torch.distributed's
+        # reduce_scatter_tensor / all_gather_into_tensor work objects, iterations eager
+        import training.grad_exchange as GX
+        GX._DIRECT_RCCL = "0"
+        try:
+            _, net_torch, upd_torch, losses_torch, _ = run(True)
+        finally:
+            GX._DIRECT_RCCL = "auto"
         out[rank] = dict(
             graph=upd._step_graph.graph is not None, capture_error=upd._step_graph.capture_error, direct=net.direct_rccl(),
             n_buckets=len(spans), collectives=net.stats["collectives"], discovery=net.stats["discovery_backwards"],
@@ -147,6 +155,8 @@ def _rccl_worker(rank, world, port, out, golden_dir):
             losses=losses, losses_plain=losses_plain, losses_ddp=losses_ddp, golden=(float(g["loss_mean_0"]), float(g["loss_mean_1"])),
             plain_graph=upd_plain._step_graph.graph is not None,
             ddp_is_torch=isinstance(net_ddp, torch.nn.parallel.DistributedDataParallel), ddp_graph_off=not upd_ddp._step_graph.enabled,
+            losses_torch=losses_torch, torch_direct=net_torch.direct_rccl(), torch_graph_off=not upd_torch._step_graph.enabled,
+            torch_collectives=net_torch.stats["collectives"], torch_buckets=len(net_torch.bucket_spans()),
             delta_fc2=float(np.linalg.norm((sd["fc2.weight"] - sd_plain["fc2.weight"]).double().numpy())
                             / np.linalg.norm((sd_plain["fc2.weight"] - init["fc2.weight"]).double().numpy())),
             finite=all(bool(torch.isfinite(v).all()) for v in sd.values() if v.is_floating_point()))
@@ -161,8 +171,9 @@ def test_ema_net_rccl_world_size_1_bucketed_exchange_inside_the_step_graph(devic
     iteration captures forward, backward, the collectives and the optimizer into one hipGraph and replays it.  Checked: the
     two golden iterations of the conditioned reference fixture (shipped lr 0.009) at the tolerances of
     test_ema_net_conditioned_fixture_tight, the captured third iteration against the same run without the wrap
-    (a one-rank average is the identity), the unused ``emau.conv1`` stays gradient-less, and torch's DistributedDataParallel
-    flavour also runs over RCCL (eager)."""
+    (a one-rank average is the identity), the unused ``emau.conv1`` stays gradient-less, torch's DistributedDataParallel
+    flavour also runs over RCCL (eager), and so does the bucketed exchange with its collectives issued through
+    torch.distributed (the default at world size > 1, eager)."""
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_rccl_worker, args=(1, _free_port(), out, golden_dir), nprocs=1, join=True)
@@ -177,8 +188,10 @@ def test_ema_net_rccl_world_size_1_bucketed_exchange_inside_the_step_graph(devic
     assert abs(r["losses"][1] - r["golden"][1]) <= 1e-3 * abs(r["golden"][1])
     # wrapped (two eager iterations + the captured one replayed) against the same three iterations without the wrap, and
     # against torch's DistributedDataParallel over the same communicator (measured: identical, 5e-7, 6e-4)
-    for got in (r["losses"], r["losses_ddp"]):
+    for got in (r["losses"], r["losses_ddp"], r["losses_torch"]):
         for a, b, tol in zip(got, r["losses_plain"], (1e-5, 1e-4, 5e-3)):
             assert abs(a - b) <= tol * abs(b), (got, r["losses_plain"])
     assert r["ddp_is_torch"] and r["ddp_graph_off"]
+    # torch.distributed work objects: never captured, every one of the 6 iterations passes through the hooks
+    assert not r["torch_direct"] and r["torch_graph_off"] and r["torch_collectives"] == 6 * r["torch_buckets"], r
     assert r["delta_fc2"] < 5e-2, r["delta_fc2"]   # three-step parameter change of the head, wrapped vs plain
