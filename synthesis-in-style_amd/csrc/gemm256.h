@@ -12,6 +12,9 @@ struct G256Params {
     const float* resid; const unsigned short* pre;
     const unsigned long long* seed; unsigned site, drop_thr; float drop_scale;
     int m_tiles, n_tiles;
+#ifdef G256_TRACE   // development builds: per-workgroup cycle stamps (tools/trace_gemm256.py)
+    unsigned long long* trace;
+#endif
 };
 
 // np = 48-column panels per wave (1, 2, 3: workgroup tiles 256 x 96 / 192 / 288); epilogue: SIS_GEMM_EPI_* except F32

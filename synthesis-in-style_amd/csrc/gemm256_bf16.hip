@@ -75,6 +75,12 @@ __global__ __launch_bounds__(C::THREADS) void gemm256_kernel(G256Params p) {
     if (mt >= p.m_tiles) return;
     const int m0 = mt * C::BM, n0 = nt * C::BN;
     const int T = p.K / C::BK;   // K steps (host: K % 64 == 0, K >= 128: T even, >= 4)
+#ifdef G256_TRACE
+#define G256_STAMP(i) do { if (p.trace && tid == 0) p.trace[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define G256_STAMP(i) do {} while (0)
+#endif
+    G256_STAMP(0);
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
@@ -184,6 +190,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm256_kernel(G256Params p) {
     issue(1);
     issue(2);
     end_of_step(no);
+    G256_STAMP(1);
     read_early(fa0, fb0, 0);
     // ---- step 0 (peeled so that the pairs below start on the odd register set and the loop count is even: T is even)
     step(fa0, fb0, fa1, fb1, yes, yes, 0);
@@ -200,6 +207,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm256_kernel(G256Params p) {
     end_of_step(yes);
     step(fa0, fb0, fa1, fb1, no, yes, t + 1);   // (no barrier needed any more: nothing writes the LDS from here on)
     step(fa1, fb1, fa0, fb0, no, no, t + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    G256_STAMP(2);
 
     // ---- epilogue: lane = output row m (per m block), registers = 4 consecutive columns n (as gemm_bf16.hip)
     SisDropKey key{0u, 0u};
@@ -341,8 +350,17 @@ __global__ __launch_bounds__(C::THREADS) void gemm256_kernel(G256Params p) {
     };
     if (m0 + C::BM <= p.M && n0 + C::BN <= p.N) epilogue(std::false_type());
     else epilogue(std::true_type());
+#ifdef G256_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G256_STAMP(3);
+    if (p.trace && tid == 0) { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); p.trace[(size_t)blockIdx.x * 8 + 4] = ((unsigned long long)xcc << 32) | hw; }
+#endif
 #endif
 }
+
+#ifdef G256_TRACE
+unsigned long long* g256_trace = nullptr;
+#endif
 
 template <typename C, int EPI>
 int launch256(const G256Params& p, hipStream_t st, const char* name) {
@@ -365,6 +383,9 @@ template <int NP>
 int dispatch256(const G256Params& q, int epi, hipStream_t st) {
     typedef G256Cfg<NP> C;
     G256Params p = q;
+#ifdef G256_TRACE
+    p.trace = g256_trace;
+#endif
     p.m_tiles = sis_cdiv(p.M, C::BM);
     p.n_tiles = sis_cdiv(p.N, C::BN);
     switch (epi) {
@@ -378,6 +399,10 @@ int dispatch256(const G256Params& q, int epi, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef G256_TRACE
+extern "C" void sis_gemm256_set_trace(void* buffer) { g256_trace = (unsigned long long*)buffer; }
+#endif
 
 bool sis_gemm256_ok(int layout, int epilogue, int k, int splits) {
     return layout == 0 && epilogue != SIS_GEMM_EPI_F32 && splits == 1 && k % 64 == 0 && k >= 128;

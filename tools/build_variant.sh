@@ -6,9 +6,10 @@ set -e
 rev=$1; tag=$2; shift 2
 root=$(cd "$(dirname "$0")/.." && pwd)
 tmp=$(mktemp -d)
-if [ "$rev" = WORK ]; then cp -r "$root/synthesis-in-style_amd/csrc" "$tmp/csrc"; mkdir -p "$tmp/include"; cp "$root/include/sis_hip.h" "$tmp/include/";
-else git -C "$root" archive "$rev" synthesis-in-style_amd/csrc include | tar -x -C "$tmp"; mv "$tmp/synthesis-in-style_amd/csrc" "$tmp/csrc"; fi
-cd "$tmp/csrc"; rm -rf _obj _obj_trace
+# (the sources include "../../include/sis_hip.h": keep the tree's depth)
+if [ "$rev" = WORK ]; then mkdir -p "$tmp/synthesis-in-style_amd" "$tmp/include"; cp -r "$root/synthesis-in-style_amd/csrc" "$tmp/synthesis-in-style_amd/csrc"; cp "$root/include/sis_hip.h" "$tmp/include/";
+else git -C "$root" archive "$rev" synthesis-in-style_amd/csrc include | tar -x -C "$tmp"; fi
+cd "$tmp/synthesis-in-style_amd/csrc"; rm -rf _obj _obj_trace
 objs=""
 for f in *.hip; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -I"$tmp/include" "$@" -c "$f" -o "${f%.hip}.o" & objs="$objs ${f%.hip}.o"; done
 wait
