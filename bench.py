@@ -345,7 +345,8 @@ def bench_training(args, workload, world, rank, device, distributed):
     if baseline_config and library_calls["fallback"]:
         raise SystemExit(f"bench.py: {workload} handed operators to the ROCm libraries that the BASELINE config is supposed to "
                          f"run on libsis_hip.so: {library_calls['fallback']}")
-    library = library_time(updater) if rank == 0 else None
+    # (one more iteration on rank 0 alone: only where an iteration holds no collective, i.e. in a single process)
+    library = library_time(updater) if (rank == 0 and world == 1) else None
     dp = None
     if world == 1 and rank == 0 and args.dp_rehearsal:
         del updater, builder
