@@ -238,9 +238,9 @@ def data_parallel_rehearsal(args, workload, config, device):
         return None
     out = {"backend": dist.get_backend(), "world": dist.get_world_size(), "flavour": config.get("data_parallel", "buckets")}
     import training.grad_exchange as grad_exchange
-    # "graph" / "eager": collectives issued straight into librccl.so (the default at world size 1, capturable);
-    # "torch_collectives_eager": the same buckets through torch.distributed's work objects -- the DEFAULT at world size > 1
-    for mode, hip_graph, direct in (("graph", True, "auto"), ("eager", False, "auto"), ("torch_collectives_eager", False, "0")):
+    # "graph" / "eager": collectives issued straight into librccl.so ("eager" = the default at world size > 1, "graph" at 1);
+    # "torch_collectives_eager": the same buckets through torch.distributed's work objects (SIS_DP_DIRECT_RCCL=0)
+    for mode, hip_graph, direct in (("graph", True, "1"), ("eager", False, "1"), ("torch_collectives_eager", False, "0")):
         grad_exchange._DIRECT_RCCL = direct
         gc.collect()
         torch.cuda.empty_cache()
@@ -266,8 +266,8 @@ def data_parallel_rehearsal(args, workload, config, device):
             out["hip_graph"] = updater._step_graph.graph is not None
             out["direct_rccl"] = net.direct_rccl()
         del updater, builder, net
-    grad_exchange._DIRECT_RCCL = "auto"
-    out["default_at_world_size_gt_1"] = "torch_collectives_eager (SIS_DP_DIRECT_RCCL=auto); SIS_DP_DIRECT_RCCL=1: graph"
+    grad_exchange._DIRECT_RCCL = "1"
+    out["default_at_world_size_gt_1"] = "eager (direct RCCL calls; SIS_DP_GRAPH=1: graph)"
     return out
 
 

@@ -37,12 +37,16 @@ from torch import nn
 
 
 _DEBUG = os.environ.get("SIS_DP_DEBUG", "0") == "1"
-# Collectives straight into librccl.so (stream work only: capturable into the step hipGraph) or through torch.distributed work
-# objects (eager only).  "auto": direct at world size 1 -- the one configuration a 1-GPU box can run and
-# tests/test_distributed_gpu.py + bench.py's data_parallel_rehearsal verify -- and torch.distributed's own, long-proven
-# reduce_scatter_tensor / all_gather_into_tensor at world size > 1, where the direct path cannot be rehearsed here (RCCL refuses
-# two ranks on one device); "1" forces the direct path (and with it the captured step) at any world size, "0" never uses it.
-_DIRECT_RCCL = os.environ.get("SIS_DP_DIRECT_RCCL", "auto")
+# Collectives straight into librccl.so (ctypes on the communicator ProcessGroupNCCL owns: a few microseconds of host time each,
+# stream work only) or through torch.distributed's work objects (SIS_DP_DIRECT_RCCL=0).  Measured at world size 1, TransUNet,
+# 19 buckets = 38 collectives per iteration: 25.0 ms per eager iteration direct, 34.1 ms through torch.distributed (the host
+# cost of 38 c10d calls lands on an iteration whose 860 launches already keep the host busy); EMANet, 7 buckets: 28.4 / 28.5.
+# Capturing the collectives into the step hipGraph is a separate decision (``capturable``): by default only at world size 1 --
+# the one configuration a 1-GPU box can run (RCCL refuses two ranks on one device) and tests/test_distributed_gpu.py +
+# bench.py's data_parallel_rehearsal verify; SIS_DP_GRAPH=1 extends it to any world size.  Nothing is lost by staying eager
+# there: the wrapped iteration is as fast eager as captured (25.0 / 25.2 ms, 28.4 / 28.3 ms).
+_DIRECT_RCCL = os.environ.get("SIS_DP_DIRECT_RCCL", "1")
+_DP_GRAPH = os.environ.get("SIS_DP_GRAPH", "auto")
 
 
 class _Rccl:
@@ -128,7 +132,7 @@ class BucketedDataParallel(nn.Module):
             pass
         self._pending = []   # work handles of collectives issued through torch.distributed during the current backward
         self._comm, self._comm_stream, self._joined = None, None, True
-        if self._on_gpu and self.backend == "nccl" and (_DIRECT_RCCL == "1" or (_DIRECT_RCCL == "auto" and self.world == 1)):
+        if self._on_gpu and self.backend == "nccl" and _DIRECT_RCCL != "0":
             self._comm = _Rccl.communicator(process_group, self.device)
             if self._comm is None:   # the communicator is created lazily by the first collective
                 probe = torch.zeros(1, device=self.device)
@@ -326,5 +330,6 @@ class BucketedDataParallel(nn.Module):
 
     def capturable(self) -> bool:
         """The step hipGraph may include this exchange: collectives issued straight into RCCL are stream work; torch.distributed's
-        work objects (watchdog events) and gloo (host synchronisation) are not."""
-        return self._on_gpu and self.backend == "nccl" and self._comm is not None
+        work objects (watchdog events) and gloo (host synchronisation) are not.  At world size > 1 only with SIS_DP_GRAPH=1."""
+        return (self._on_gpu and self.backend == "nccl" and self._comm is not None
+                and (_DP_GRAPH == "1" or (_DP_GRAPH == "auto" and self.world == 1)))

@@ -137,14 +137,14 @@ def _rccl_worker(rank, world, port, out, golden_dir):
         init = E.seeded_state_dict(50, 3, seed=wseed, residual_scale=0.1)
         _, _, upd_plain, losses_plain, sd_plain = run(False)
         _, net_ddp, upd_ddp, losses_ddp, _ = run(True, "ddp")
-        # the default at world size > 1 (SIS_DP_DIRECT_RCCL=auto): the same buckets, collectives through torch.distributed's
-        # reduce_scatter_tensor / all_gather_into_tensor work objects, iterations eager
+        # SIS_DP_DIRECT_RCCL=0: the same buckets, collectives through torch.distributed's reduce_scatter_tensor /
+        # all_gather_into_tensor work objects, iterations eager
         import training.grad_exchange as GX
         GX._DIRECT_RCCL = "0"
         try:
             _, net_torch, upd_torch, losses_torch, _ = run(True)
         finally:
-            GX._DIRECT_RCCL = "auto"
+            GX._DIRECT_RCCL = "1"
         out[rank] = dict(
             graph=upd._step_graph.graph is not None, capture_error=upd._step_graph.capture_error, direct=net.direct_rccl(),
             n_buckets=len(spans), collectives=net.stats["collectives"], discovery=net.stats["discovery_backwards"],
@@ -173,7 +173,7 @@ def test_ema_net_rccl_world_size_1_bucketed_exchange_inside_the_step_graph(devic
     test_ema_net_conditioned_fixture_tight, the captured third iteration against the same run without the wrap
     (a one-rank average is the identity), the unused ``emau.conv1`` stays gradient-less, torch's DistributedDataParallel
     flavour also runs over RCCL (eager), and so does the bucketed exchange with its collectives issued through
-    torch.distributed (the default at world size > 1, eager)."""
+    torch.distributed (SIS_DP_DIRECT_RCCL=0, eager)."""
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_rccl_worker, args=(1, _free_port(), out, golden_dir), nprocs=1, join=True)
