@@ -15,7 +15,6 @@ reference's two native ops.
 Everything here is differentiable through stock autograd, which is what the
 tests use as the gradient oracle for the HIP backward kernels.
 """
-import math
 
 import numpy as np
 import torch

@@ -26,7 +26,7 @@ from pathlib import Path
 import numpy
 import torch
 
-import sis_hip
+import sis_hip  # noqa: F401  (fails loudly at import when libsis_hip.so is missing: there is no CPU path)
 from networks import get_stylegan2_generator
 from segmentation.gan_local_edit.factor_catalog import FactorCatalog
 from utils.dataset_creation import label_and_encode, shard_range

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch.autograd import Function
-from torch.nn import Conv2d, Dropout, Linear, Softmax
+from torch.nn import Dropout, Linear, Softmax
 
 import sis_hip
 from torch.nn.modules.utils import _pair

@@ -10,7 +10,7 @@ The constructor takes the network itself (the reference builds it from a checkpo
 builder -- `load_network`, :73-81 -- which is checkpoint / config-file IO outside the hot path).
 """
 import math
-from typing import Iterator, List, Optional, Sequence, Tuple
+from typing import Iterator, List, Sequence, Tuple
 
 import numpy as np
 import torch

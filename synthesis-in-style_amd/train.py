@@ -14,7 +14,6 @@ import json
 import logging
 import os
 import time
-from pathlib import Path
 
 import torch
 import torch.distributed as dist

@@ -89,7 +89,7 @@ def test_half_image_dilation_is_the_dilated_convolution(device, b, cin, cout):
     """(2, 512, 512): EMANet-50's layer -- gather kernel + fp32 MFMA pointwise kernels in all three directions, nothing handed
     to the ROCm libraries; (3, 16, 24): a shape whose weight gradient has no tile plan (counted as a fallback)."""
     import sis_hip
-    from networks.hip_conv import HipConv2d, conv3x3_half_image_dilation
+    from networks.hip_conv import HipConv2d
     g = torch.Generator().manual_seed(16)
     x = torch.randn(b, cin, 32, 32, generator=g).to(device).requires_grad_(True)
     conv = HipConv2d(cin, cout, 3, 1, 16, 16, bias=False).to(device)

@@ -1,6 +1,5 @@
 """GPU: the training entry point end to end (reference: train.py:69-147) -- ``train.main`` on synthetic batches for a
 few iterations across an epoch boundary: config file -> builder -> updater -> per-iteration LR schedule -> snapshot."""
-import argparse
 import math
 import os
 

@@ -1,5 +1,5 @@
 """EMANet 1x1 convolutions (B=16): ATen convolution (MIOpen) vs plain batched GEMMs on the NCHW tensors, per direction."""
-import sys, time
+import time
 import torch
 import torch.nn.functional as F
 

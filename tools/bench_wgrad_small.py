@@ -1,4 +1,4 @@
-import os, sys, time
+import sys, time
 sys.path.insert(0, "synthesis-in-style_amd")
 import torch, sis_hip
 dev = torch.device("cuda")

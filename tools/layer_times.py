@@ -3,7 +3,6 @@ kernel, algorithmic bytes, FLOPs, microseconds, GB/s, TFLOP/s -- for finding whi
 usage: layer_times.py emanet|transunet [substring filter]"""
 import os
 import sys
-import types
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
