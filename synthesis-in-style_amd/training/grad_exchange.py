@@ -39,8 +39,9 @@ from torch import nn
 _DEBUG = os.environ.get("SIS_DP_DEBUG", "0") == "1"
 # Collectives straight into librccl.so (ctypes on the communicator ProcessGroupNCCL owns: a few microseconds of host time each,
 # stream work only) or through torch.distributed's work objects (SIS_DP_DIRECT_RCCL=0).  Measured at world size 1, TransUNet,
-# 19 buckets = 38 collectives per iteration: 25.0 ms per eager iteration direct, 34.1 ms through torch.distributed (the host
-# cost of 38 c10d calls lands on an iteration whose 860 launches already keep the host busy); EMANet, 7 buckets: 28.4 / 28.5.
+# 19 buckets = 38 collectives per iteration: 25.4 ms per eager iteration direct against 25.9 ms through torch.distributed on
+# one box, 25.0 against 34.1 ms on another (the host cost of 38 c10d calls lands on an iteration whose 860 launches already keep
+# the host busy: a slower host falls behind); EMANet, 7 buckets: 28.3 / 28.3 and 28.4 / 28.5 ms.
 # Capturing the collectives into the step hipGraph is a separate decision (``capturable``): by default only at world size 1 --
 # the one configuration a 1-GPU box can run (RCCL refuses two ranks on one device) and tests/test_distributed_gpu.py +
 # bench.py's data_parallel_rehearsal verify; SIS_DP_GRAPH=1 extends it to any world size.  Nothing is lost by staying eager
