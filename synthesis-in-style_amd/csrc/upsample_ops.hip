@@ -300,6 +300,196 @@ __global__ __launch_bounds__(256) void bilinear_up2_bwd_tiled_kernel(T* __restri
     if (x0 + txl + 1 < w) sis_st(dst, 1, out[1]);
 }
 
+// ---- x2 without LDS (round 4).  For an exact doubling PyTorch's index rule is static: with s = (w - 1) / (2w - 1),
+// floor(s * 2j) = j - 1 (j >= 1) and floor(s * (2j + 1)) = j, so output columns 2j, 2j + 1 read sources (j - 1, j) and (j, j + 1)
+// -- no gather.  A lane owns 4 source columns of one source row i and produces the 2 x 8 outputs they centre: it loads its 4
+// values of rows i - 1, i, i + 1 (8 or 16 contiguous bytes each, fully coalesced over the wave), takes columns 4g - 1 and 4g + 4
+// from its neighbours by a wave shuffle, interpolates each row horizontally, then the two output rows vertically -- the same
+// fp32 expression, in the same association, as the kernels above (a weight pair (l0, l1) formed around the neighbouring index
+// where the fp32 floor lands on the other side gives the same value to 1e-7: linear interpolation is continuous there).
+// The tiled kernel ran the decoder's four stages at 0.7 / 1.3 / 2.0 / 2.7 TB/s (a workgroup per 16 x 512 outputs of ONE plane:
+// 7 of 8 lanes idle at 64 columns); backward likewise a gather of <= 4 x 4 outputs per source pixel with static candidates.
+template <typename T> struct Vec4Io;
+template <> struct Vec4Io<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { const float4 q = *reinterpret_cast<const float4*>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+    static __device__ __forceinline__ void store4(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec4Io<__hip_bfloat16> {
+    static __device__ __forceinline__ void load(const __hip_bfloat16* p, float (&v)[4]) {
+        const uint2 q = *reinterpret_cast<const uint2*>(p);
+        v[0] = __builtin_bit_cast(float, q.x << 16); v[1] = __builtin_bit_cast(float, q.x & 0xFFFF0000u);
+        v[2] = __builtin_bit_cast(float, q.y << 16); v[3] = __builtin_bit_cast(float, q.y & 0xFFFF0000u);
+    }
+    static __device__ __forceinline__ void store4(__hip_bfloat16* p, const float* v) {
+        __hip_bfloat16 t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = __float2bfloat16(v[k]);
+        uint2 q;
+        __builtin_memcpy(&q, t, 8);
+        *reinterpret_cast<uint2*>(p) = q;
+    }
+};
+template <> struct Vec4Io<__half> {
+    static __device__ __forceinline__ void load(const __half* p, float (&v)[4]) {
+        __half t[4];
+        const uint2 q = *reinterpret_cast<const uint2*>(p);
+        __builtin_memcpy(t, &q, 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = __half2float(t[k]);
+    }
+    static __device__ __forceinline__ void store4(__half* p, const float* v) {
+        __half t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = __float2half(v[k]);
+        uint2 q;
+        __builtin_memcpy(&q, t, 8);
+        *reinterpret_cast<uint2*>(p) = q;
+    }
+};
+
+// lanes_per_row = w / 4 divides 64 or is a multiple of it (host): a lane's left / right neighbour in the row is lane -/+ 1
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_up2_fwd_direct_kernel(T* __restrict__ out, const T* __restrict__ x, int h, int w,
+                                                                      float sy, float sx, int64_t total, int planes_per_image,
+                                                                      int64_t out_image_stride) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lpr = w >> 2;
+    const int64_t tc = t < total ? t : total - 1;   // (the grid is rounded up: surplus lanes recompute the last item, store nothing)
+    const int g = (int)(tc % lpr);
+    const int64_t rowi = tc / lpr;
+    const int i = (int)(rowi % h);
+    const int64_t plane = rowi / h;
+    const T* src = x + plane * h * (int64_t)w + 4 * g;
+    const int wl = threadIdx.x & 63;
+    const int rm = i > 0 ? i - 1 : 0, rp = i < h - 1 ? i + 1 : h - 1;
+    float a[3][4];
+    Vec4Io<T>::load(src + (int64_t)rm * w, a[0]);
+    Vec4Io<T>::load(src + (int64_t)i * w, a[1]);
+    Vec4Io<T>::load(src + (int64_t)rp * w, a[2]);
+    // horizontal weights of the 8 output columns 8g .. 8g + 7 (j = 4g + m: even output 2j from (j - 1, j), odd from (j, j + 1))
+    float e0[4], e1[4], o0[4], o1[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int j = 4 * g + m;
+        const float se = sx * (float)(2 * j), so = sx * (float)(2 * j + 1);
+        e1[m] = se - (float)(j - 1); e0[m] = 1.f - e1[m];
+        o1[m] = so - (float)j; o0[m] = 1.f - o1[m];
+    }
+    float hrow[3][8];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float left = __shfl_up(a[r][3], 1), right = __shfl_down(a[r][0], 1);
+        const T* rowp = src + (int64_t)(r == 0 ? rm : r == 1 ? i : rp) * w;
+        if (g == 0) left = a[r][0];            // column -1: weight e0 = 0 at j = 0; any finite value
+        else if (wl == 0) left = sis_ld(rowp, -1);     // rows wider than a wave: the neighbour sits in another wave
+        if (g == lpr - 1) right = a[r][3];     // column w: PyTorch clamps i1 to w - 1
+        else if (wl == 63) right = sis_ld(rowp, 4);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float sm1 = m == 0 ? left : a[r][m - 1], sp1 = m == 3 ? right : a[r][m + 1];
+            hrow[r][2 * m] = e0[m] * sm1 + e1[m] * a[r][m];
+            hrow[r][2 * m + 1] = o0[m] * a[r][m] + o1[m] * sp1;
+        }
+    }
+    if (t >= total) return;
+    // vertical: output row 2i from source rows (i - 1, i), row 2i + 1 from (i, i + 1)
+    const float ve1 = sy * (float)(2 * i) - (float)(i - 1), ve0 = 1.f - ve1;
+    const float vo1 = sy * (float)(2 * i + 1) - (float)i, vo0 = 1.f - vo1;
+    float r0[8], r1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        r0[k] = ve0 * hrow[0][k] + ve1 * hrow[1][k];
+        r1[k] = vo0 * hrow[1][k] + vo1 * hrow[2][k];
+    }
+    const int64_t n = plane / planes_per_image, ch = plane - n * planes_per_image;
+    const int ow = 2 * w;
+    T* dst = out + n * out_image_stride + (ch * (int64_t)(2 * h) + 2 * i) * ow + 8 * g;
+    Vec4Io<T>::store4(dst, r0); Vec4Io<T>::store4(dst + 4, r0 + 4);
+    Vec4Io<T>::store4(dst + ow, r1); Vec4Io<T>::store4(dst + ow + 4, r1 + 4);
+}
+
+// Backward of the same: a lane owns 4 source columns of RP consecutive source rows (RP = 2 when h is even: the 2 RP + 2 output rows
+// 2 i0 - 1 .. 2 i0 + 2 RP they gather from are loaded once for both -- 6 row loads per 2 source rows instead of 8); columns
+// 8g - 1 .. 8g + 8.  Weights by the index rule itself (lerp1 + comparison, as bilinear_up_bwd_kernel): a candidate that does not
+// reference the pixel gets weight 0, the clamped last column / row gets both of its weights.
+template <typename T, int RP>
+__global__ __launch_bounds__(256) void bilinear_up2_bwd_direct_kernel(T* __restrict__ gx, const T* __restrict__ gout, int h, int w,
+                                                                      float sy, float sx, int64_t total, int planes_per_image,
+                                                                      int64_t gout_image_stride) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lpr = w >> 2, oh = 2 * h, ow = 2 * w, hp = h / RP;
+    const int64_t tc = t < total ? t : total - 1;
+    const int g = (int)(tc % lpr);
+    const int64_t rowi = tc / lpr;
+    const int i0 = (int)(rowi % hp) * RP;
+    const int64_t plane = rowi / hp;
+    const int64_t n = plane / planes_per_image, ch = plane - n * planes_per_image;
+    const T* src = gout + n * gout_image_stride + ch * (int64_t)oh * ow + 8 * g;
+    // column weights: wx[m][k] = weight of output column 8g - 1 + 2m + k (k = 0..3: 2j - 1 .. 2j + 2) on source column j = 4g + m
+    float wx[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int j = 4 * g + m;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ox = 2 * j - 1 + k;
+            float wgt = 0.f;
+            if (ox >= 0 && ox < ow) {
+                const Lerp1 lx = lerp1(ox, sx, w);
+                if (lx.i0 == j) wgt += lx.l0;
+                if (lx.i1 == j) wgt += lx.l1;
+            }
+            wx[m][k] = wgt;
+        }
+    }
+    float acc[RP][4];
+#pragma unroll
+    for (int q = 0; q < RP; ++q)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[q][m] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 2 * RP + 2; ++r) {
+        const int oy = 2 * i0 - 1 + r;
+        const bool in = oy >= 0 && oy < oh;
+        const int oyc = in ? oy : (oy < 0 ? 0 : oh - 1);
+        float wy[RP];
+#pragma unroll
+        for (int q = 0; q < RP; ++q) {   // source row i0 + q gathers output rows 2 (i0 + q) - 1 .. + 2 = r in [2q, 2q + 3]
+            wy[q] = 0.f;
+            if (in && r >= 2 * q && r <= 2 * q + 3) {
+                const Lerp1 ly = lerp1(oy, sy, h);
+                if (ly.i0 == i0 + q) wy[q] += ly.l0;
+                if (ly.i1 == i0 + q) wy[q] += ly.l1;
+            }
+        }
+        float v[8];
+        {
+            float lo[4], hi[4];
+            Vec4Io<T>::load(src + (int64_t)oyc * ow, lo);
+            Vec4Io<T>::load(src + (int64_t)oyc * ow + 4, hi);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = lo[k]; v[4 + k] = hi[k]; }
+        }
+        float left = __shfl_up(v[7], 1), right = __shfl_down(v[0], 1);
+        if (g == 0) left = 0.f;               // output column -1 does not exist (its weight is 0 as well)
+        else if ((threadIdx.x & 63) == 0) left = sis_ld(src + (int64_t)oyc * ow, -1);
+        if (g == lpr - 1) right = 0.f;        // nor does column 2w
+        else if ((threadIdx.x & 63) == 63) right = sis_ld(src + (int64_t)oyc * ow, 8);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            // outputs 8g + 2m - 1 .. 8g + 2m + 2
+            const float c0 = m == 0 ? left : v[2 * m - 1], c1 = v[2 * m], c2 = v[2 * m + 1], c3 = m == 3 ? right : v[2 * m + 2];
+            const float hsum = ((wx[m][0] * c0 + wx[m][1] * c1) + wx[m][2] * c2) + wx[m][3] * c3;
+#pragma unroll
+            for (int q = 0; q < RP; ++q)
+                if (r >= 2 * q && r <= 2 * q + 3) acc[q][m] += wy[q] * hsum;
+        }
+    }
+    if (t >= total) return;
+#pragma unroll
+    for (int q = 0; q < RP; ++q) Vec4Io<T>::store4(gx + (plane * h + i0 + q) * (int64_t)w + 4 * g, acc[q]);
+}
+
 template <typename T>
 int launch_up(void* out, const void* x, int64_t planes, int h, int w, int oh, int ow, int backward, int planes_per_image,
               int64_t image_stride, hipStream_t st) {
@@ -308,6 +498,33 @@ int launch_up(void* out, const void* x, int64_t planes, int h, int w, int oh, in
     const float sx = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.f;
     const bool dense = image_stride == (int64_t)planes_per_image * oh * ow;
     const bool x2 = oh == 2 * h && ow == 2 * w;
+    // the LDS-free x2 kernels: 4 source columns per lane, whole rows per wave (w / 4 divides 64 or is a multiple of it), every
+    // vector access aligned (SIS_UP2_DIRECT=0: the tiled kernels, for A/B runs)
+    static const bool direct_on = !(getenv("SIS_UP2_DIRECT") && getenv("SIS_UP2_DIRECT")[0] == '0');
+    const int lpr = w / 4;
+    const int align = 16 / (int)sizeof(T);   // elements per 16 bytes
+    const bool direct = direct_on && x2 && h >= 2 && w % 4 == 0 && lpr > 0 && (64 % lpr == 0 || lpr % 64 == 0) && image_stride % align == 0 &&
+                        (reinterpret_cast<uintptr_t>(out) % 16) == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0 &&
+                        ((int64_t)oh * ow) % align == 0 && planes * (int64_t)h * lpr < ((int64_t)1 << 38);
+    if (direct) {
+        const int64_t total = planes * (int64_t)h * lpr;
+        const unsigned blocks = (unsigned)((total + 255) / 256);
+        if (!backward) {
+            hipLaunchKernelGGL(bilinear_up2_fwd_direct_kernel<T>, dim3(blocks), dim3(256), 0, st, (T*)out, (const T*)x, h, w, sy, sx, total,
+                               planes_per_image, image_stride);
+            SIS_CHECK_LAUNCH("bilinear_up2_fwd_direct_kernel");
+        } else if (h % 2 == 0) {
+            const int64_t total2 = total / 2;
+            hipLaunchKernelGGL((bilinear_up2_bwd_direct_kernel<T, 2>), dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, st, (T*)out,
+                               (const T*)x, h, w, sy, sx, total2, planes_per_image, image_stride);
+            SIS_CHECK_LAUNCH("bilinear_up2_bwd_direct_kernel");
+        } else {
+            hipLaunchKernelGGL((bilinear_up2_bwd_direct_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (T*)out, (const T*)x, h, w, sy, sx, total,
+                               planes_per_image, image_stride);
+            SIS_CHECK_LAUNCH("bilinear_up2_bwd_direct_kernel");
+        }
+        return 0;
+    }
     if (!backward) {
         const int tiles_x = sis_cdiv(ow, UF_OC), tiles_y = sis_cdiv(oh, UF_OR);
         if (x2 && h >= 2 && w >= 2 && planes * tiles_x * tiles_y < ((int64_t)1 << 31)) {

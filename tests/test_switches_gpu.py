@@ -165,6 +165,7 @@ _C_SIDE = [
     ("SIS_WINO_XCD_MB", "0", "tests/test_generator_gpu.py::test_generator_vs_golden_small"),
     ("SIS_UPFIR_PIPE", "0", "tests/test_generator_gpu.py::test_modconv_up_fir_vs_oracle"),
     ("SIS_GN_SINGLE_PASS", "0", "tests/test_upsample_gpu.py"),
+    ("SIS_UP2_DIRECT", "0", "tests/test_upsample_gpu.py"),
     ("SIS_PW_KC", "32", "tests/test_conv1x1_f32_gpu.py"),
     ("SIS_KMEANS_FAST", "0", "tests/test_dataset_ops_gpu.py"),
 ]

@@ -62,6 +62,34 @@ def test_x2_forward_tiles(device, shape):
     np.testing.assert_allclose(yb.float().cpu().numpy(), refb.float().cpu().numpy(), rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("shape", [(1, 2, 4, 512), (2, 3, 40, 256), (1, 4, 32, 32), (2, 2, 2, 4), (1, 1, 3, 1024), (8, 8, 64, 64), (2, 2, 5, 16)])
+def test_x2_direct_kernels(device, shape):
+    """The LDS-free x2 kernels (csrc/upsample_ops.hip, bilinear_up2_*_direct_kernel: static source indices, 4 source columns per
+    lane, neighbours by wave shuffle): rows narrower than a wave (several rows per wave), exactly a wave, wider than a wave (the
+    neighbour across the wave boundary is loaded), two-row planes -- forward and backward against float64, f32 and bf16."""
+    import sis_hip
+    g = torch.Generator().manual_seed(shape[2] + shape[3])
+    x = torch.randn(*shape, generator=g).to(device)
+    size = (2 * shape[2], 2 * shape[3])
+    gy = torch.randn(shape[0], shape[1], *size, generator=g).to(device)
+    xr = x.double().requires_grad_(True)
+    ref = F.interpolate(xr, size=size, mode="bilinear", align_corners=True)
+    ref.backward(gy.double())
+    y = sis_hip.upsample_bilinear(x, *size)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.detach().float().cpu().numpy(), rtol=1e-5, atol=3e-4)
+    gx = sis_hip.upsample_bilinear(x, *size, grad_output=gy)
+    np.testing.assert_allclose(gx.cpu().numpy(), xr.grad.float().cpu().numpy(), rtol=1e-5, atol=1e-3)
+    xb, gb = x.bfloat16(), gy.bfloat16()
+    xbr = xb.double().requires_grad_(True)
+    refb = F.interpolate(xbr, size=size, mode="bilinear", align_corners=True)
+    refb.backward(gb.double())
+    yb = sis_hip.upsample_bilinear(xb, *size)
+    np.testing.assert_allclose(yb.float().cpu().numpy(), refb.detach().float().cpu().numpy(), rtol=1e-2, atol=1e-2)
+    gxb = sis_hip.upsample_bilinear(xb, *size, grad_output=gb)
+    np.testing.assert_allclose(gxb.float().cpu().numpy(), xbr.grad.float().cpu().numpy(), rtol=1e-2, atol=4e-2)
+    assert torch.equal(y, sis_hip.upsample_bilinear(x, *size)) and torch.equal(gx, sis_hip.upsample_bilinear(x, *size, grad_output=gy))
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("b,c,s,h,w", [(2, 16, 8, 16, 16), (3, 5, 3, 12, 20), (1, 64, 64, 64, 64)])
 def test_upsample_cat_fused(device, dtype, b, c, s, h, w):
