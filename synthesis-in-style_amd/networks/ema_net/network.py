@@ -31,7 +31,7 @@ from torch.nn.modules.batchnorm import _BatchNorm
 
 import sis_hip
 from networks.base_segmenter import BaseSegmenter
-from networks.hip_conv import HipConv2d, pointwise_with_skip
+from networks.hip_conv import HipConv2d, _batch_to_space, _space_to_batch, conv3x3, pointwise_with_skip
 from networks.hip_pool import HipMaxPool2d
 
 BN_MOM = 3e-4
@@ -130,7 +130,10 @@ class Bottleneck(nn.Module):
         self.dilation = dilation
         self.stride = stride
 
-    def forward(self, x):
+    def forward(self, x, sub_images=False):
+        """``sub_images``: x is the space-to-batch arrangement [B d^2, C, H/d, W/d] of the unit's input for d = this unit's
+        dilation (``run_units``): the dilated 3x3 layer is then a plain one, every other layer of the unit is pointwise or a
+        per-channel statistic and does not see the difference."""
         fused = pointwise_with_skip(self.conv1, x) if self.downsample is None else None
         if fused is not None:
             y, shortcut = fused   # conv1(x) and the identity shortcut: their two gradients are summed in conv1's data-gradient kernel
@@ -138,8 +141,49 @@ class Bottleneck(nn.Module):
             shortcut = x if self.downsample is None else self.downsample(x)
             y = self.conv1(x)
         y = self.bn1(y, relu=True)
-        y = self.bn2(self.conv2(y), relu=True)
+        y = self.bn2(conv3x3(y, self.conv2.weight, 1) if sub_images else self.conv2(y), relu=True)
         return self.bn3(self.conv3(y), residual=shortcut, relu=True)
+
+    def sub_image_eligible(self, x):
+        """The unit can run on the sub-image arrangement of x: a stride-1 dilated fp32 unit whose 3x3 layer the Winograd kernel
+        takes at the sub-image size."""
+        d = self.dilation
+        if not (_SUB_IMAGE_UNITS and d > 1 and self.stride == 1 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                and not torch.is_autocast_enabled() and x.shape[2] % d == 0 and x.shape[3] % d == 0 and self.conv2.bias is None):
+            return False
+        b, _, h, w = x.shape
+        probe = x.new_empty((b * d * d, self.conv2.in_channels, h // d, w // d))
+        return bool(sis_hip.conv3x3_supported(probe, self.conv2.weight, 1))
+
+
+# Consecutive dilated units with the SAME dilation d (EMANet-50 at output stride 8: layer3's units 2-6 and layer4's first, d = 2)
+# run on the space-to-batch arrangement of their input: one rearrangement in, one out, instead of two around every 3x3 layer in
+# each direction (hip_conv._Conv3x3Function: 4 strided copies per dilated layer and iteration, 24 -> 4 for that run of six units;
+# SIS_SUB_IMAGE_UNITS=0: every unit on the plain arrangement, A/B runs).
+_SUB_IMAGE_UNITS = os.environ.get('SIS_SUB_IMAGE_UNITS', '1') != '0'
+
+
+def run_units(units, x):
+    """``units`` (Bottlenecks of one or several stages, in order) applied to x, runs of equal dilation on sub-images."""
+    units = list(units)
+    i = 0
+    while i < len(units):
+        unit = units[i]
+        d = getattr(unit, 'dilation', 1)
+        if d > 1 and unit.sub_image_eligible(x):
+            j = i
+            while j < len(units) and getattr(units[j], 'dilation', 1) == d and units[j].sub_image_eligible(x):
+                j += 1
+            if j - i >= 2:   # (a single unit gains nothing over the rearrangement inside its 3x3 layer)
+                xs = _space_to_batch(x, d).contiguous()
+                for u in units[i:j]:
+                    xs = u(xs, sub_images=True)
+                x = _batch_to_space(xs, d).contiguous()
+                i = j
+                continue
+        x = unit(x)
+        i += 1
+    return x
 
 
 class ResNet(nn.Module):
@@ -195,7 +239,7 @@ class ResNet(nn.Module):
 
     def forward(self, x):
         x = self.maxpool(self.stem(self.conv1, self.bn1, x))
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = run_units(list(self.layer3) + list(self.layer4), self.layer2(self.layer1(x)))
         x = self.avgpool(x)
         return self.fc(x.view(x.size(0), -1))
 
@@ -312,9 +356,8 @@ class EMANet(BaseSegmenter):
     def features(self, img):
         ex = self.extractor  # (stem convs, bn1, relu, maxpool, layer1..4): same modules, fused norm/activation calls
         x = ex[3](ResNet.stem(ex[0], ex[1], img))
-        for stage in (ex[4], ex[5], ex[6], ex[7]):
-            x = stage(x)
-        return x
+        x = ex[5](ex[4](x))
+        return run_units(list(ex[6]) + list(ex[7]), x)   # layer3 + layer4: runs of equal dilation on sub-images
 
     def logits(self, img):
         x = self.fc0(self.features(img))
