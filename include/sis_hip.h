@@ -549,6 +549,10 @@ int sis_gemm_bf16_wgrad_bias(void* dw, float* db, const void* grad, const void* 
  * first_tile = running sum of ceil(rows / 64) * ceil(cols / 64); total_tiles = the final sum.  Used for the transposed
  * weight shadows that turn a Linear layer's data gradient into an NT product (sis_gemm_bf16 tiles 9..11). */
 int sis_transpose_bf16_multi(const void* table, int n_tensors, int total_tiles, void* stream);
+/* dst[b][c][r] = src[b][r][c] for 2- or 4-byte elements: `x.flatten(2).transpose(-1, -2)` of the patch embeddings
+ * (networks/trans_u_net/vit_seg_modeling.py:151-153), `hidden_states.permute(0, 2, 1).contiguous()` of DecoderCup.forward
+ * (:341-344), and the gradients of both (the same operation). */
+int sis_transpose_batched(void* dst, const void* src, int elem_bytes, int batch, int rows, int cols, void* stream);
 
 /* The same kernel over `batches` problems (grid.y): A / B / C of entry i start i * {a,b,c}_batch_stride elements after the base
  * pointers (stride 0 = shared operand).  With sum_over_batches != 0 the entries are the K slices of ONE result instead

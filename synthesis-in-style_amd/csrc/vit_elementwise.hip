@@ -84,6 +84,48 @@ __global__ __launch_bounds__(256) void transpose_bf16_multi_kernel(const long lo
 }
 }  // namespace
 
+// [batch][rows][cols] -> [batch][cols][rows] for 2- and 4-byte elements: the patch embedding's NCHW feature map -> tokens
+// (networks/trans_u_net/vit_seg_modeling.py:151-153 `x.flatten(2).transpose(-1, -2)`), the decoder's tokens -> NCHW
+// (:341-344 `hidden_states.permute(0, 2, 1).contiguous().view(...)`) and their gradients.  64 x 64 tiles through LDS, 128- /
+// 256-byte runs per wave on both sides (the ATen strided copy these replace ran the 12.6 MB tensors at 0.8 TB/s).
+namespace {
+template <typename U>
+__global__ __launch_bounds__(256) void transpose_batched_kernel(U* __restrict__ dst, const U* __restrict__ src, int rows, int cols) {
+    __shared__ U tile[64][65 + (sizeof(U) == 2 ? 1 : 0)];
+    const int tiles_c = (cols + 63) / 64;
+    const int r0 = ((int)blockIdx.x / tiles_c) * 64, c0 = ((int)blockIdx.x % tiles_c) * 64;
+    const long long base = (long long)blockIdx.y * rows * cols;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty + 4 * i, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 4 * i][tx] = src[base + (long long)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i, r = r0 + tx;
+        if (c < cols && r < rows) dst[base + (long long)c * rows + r] = tile[tx][ty + 4 * i];
+    }
+}
+}  // namespace
+
+extern "C" int sis_transpose_batched(void* dst, const void* src, int elem_bytes, int batch, int rows, int cols, void* stream) {
+    if (batch <= 0 || rows <= 0 || cols <= 0) return 0;
+    SIS_REQUIRE(dst && src && dst != src, "sis_transpose_batched: null or aliased pointers");
+    SIS_REQUIRE(elem_bytes == 2 || elem_bytes == 4, "sis_transpose_batched: 2- or 4-byte elements, got %d", elem_bytes);
+    SIS_REQUIRE(batch <= 65535, "sis_transpose_batched: batch %d exceeds the grid's second dimension", batch);
+    const dim3 grid((unsigned)(((rows + 63) / 64) * ((cols + 63) / 64)), (unsigned)batch);
+    if (elem_bytes == 2)
+        hipLaunchKernelGGL(transpose_batched_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (unsigned short*)dst,
+                           (const unsigned short*)src, rows, cols);
+    else
+        hipLaunchKernelGGL(transpose_batched_kernel<unsigned int>, grid, dim3(256), 0, (hipStream_t)stream, (unsigned int*)dst,
+                           (const unsigned int*)src, rows, cols);
+    SIS_CHECK_LAUNCH("transpose_batched_kernel");
+    return 0;
+}
+
 extern "C" int sis_transpose_bf16_multi(const void* table, int n_tensors, int total_tiles, void* stream) {
     if (n_tensors <= 0 || total_tiles <= 0) return 0;
     SIS_REQUIRE(table, "sis_transpose_bf16_multi: null table");

@@ -104,7 +104,11 @@ class DecoderCup(nn.Module):
     def forward(self, hidden_states, features=None):
         b, n_patch, hidden = hidden_states.size()
         h = w = int(np.sqrt(n_patch))
-        x = self.conv_more(hidden_states.permute(0, 2, 1).contiguous().view(b, hidden, h, w))
+        if hidden_states.is_cuda and hidden_states.is_contiguous() and hidden_states.element_size() in (2, 4):
+            tokens_last = sis_hip.swap_last2(hidden_states)   # [B, hidden, n_patch]: one tiled transpose per direction
+        else:
+            tokens_last = hidden_states.permute(0, 2, 1).contiguous()
+        x = self.conv_more(tokens_last.view(b, hidden, h, w))
         for i, block in enumerate(self.blocks):
             skip = features[i] if (features is not None and i < self.config.n_skip) else None
             x = block(x, skip=skip)

@@ -513,7 +513,11 @@ class Embeddings(nn.Module):
         # [B, n_patches, hidden], made contiguous HERE: element-wise ops keep their first operand's strides, so a
         # transposed view would put the whole fp32 residual stream of the encoder in [B, hidden, n] memory order and
         # every LayerNorm / GEMM below (and their gradients) would start with a strided 25 MB copy
-        x = self.patch_embeddings(x).flatten(2).transpose(-1, -2).contiguous()
+        x = self.patch_embeddings(x).flatten(2)
+        if x.is_cuda and x.is_contiguous() and x.element_size() in (2, 4):
+            x = sis_hip.swap_last2(x)   # one tiled transpose (and one for its gradient) instead of ATen's strided copies
+        else:
+            x = x.transpose(-1, -2).contiguous()
         return self.dropout(x + self.position_embeddings), features
 
 

@@ -95,6 +95,7 @@ _SIGNATURES = {
     "sis_sgd_momentum_dev": ([_vp, _i, _vp, _vp], _i),
     "sis_ema_update": ([_vp, _vp, _f, _f, _i, _i, _vp], _i),
     "sis_transpose_bf16_multi": ([_vp, _i, _i, _vp], _i),
+    "sis_transpose_batched": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),
     "sis_half_dilation_taps": ([_vp, _vp, _i, _i, _vp], _i),
     "sis_half_dilation_taps_bwd": ([_vp, _vp, _i, _i, _vp], _i),
     "sis_emau_supported": ([_i] * 4, _i),
@@ -954,6 +955,32 @@ class WeightStdPackBank:
         with torch.cuda.device(self.table.device):
             _check(lib().sis_weight_std_pack_multi(_ptr(self.table), len(self.weights), self.total_rows, self.eps, _stream()),
                    "sis_weight_std_pack_multi")
+
+
+class _SwapLast2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _swap_last2(x)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return _swap_last2(grad.contiguous())
+
+
+def _swap_last2(x):
+    b, r, c = x.shape
+    out = torch.empty((b, c, r), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_transpose_batched(_ptr(out), _ptr(x), x.element_size(), b, r, c, _stream()), "sis_transpose_batched")
+    return out
+
+
+def swap_last2(x):
+    """Contiguous [B, R, C] -> contiguous [B, C, R] (differentiable): ``x.transpose(-1, -2).contiguous()`` as one tiled kernel."""
+    require_device(x, "input")
+    if x.dim() != 3 or x.element_size() not in (2, 4) or not x.is_contiguous():
+        raise RuntimeError("swap_last2: a contiguous 3-d tensor of 2- or 4-byte elements is required")
+    return _SwapLast2.apply(x)
 
 
 class TransposeBank:

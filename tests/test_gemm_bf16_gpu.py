@@ -304,3 +304,20 @@ def test_dropout_quads_are_pairwise_independent(device):
         for j in range(i + 1, 4):
             joint = (dropped[:, i] * dropped[:, j]).mean().item()
             assert abs(joint - p * p) < tol, (i, j, joint)
+
+
+@pytest.mark.parametrize("shape", [(8, 768, 1024), (2, 1024, 768), (3, 70, 33), (1, 1, 5), (2, 64, 64)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_swap_last2_is_the_contiguous_transpose(device, shape, dtype):
+    """sis_transpose_batched (csrc/vit_elementwise.hip): [B, R, C] -> [B, C, R], bitwise ``x.transpose(-1, -2).contiguous()``, and the
+    gradient is the same operation (TransUNet: patch embeddings -> tokens, tokens -> the decoder's feature map)."""
+    import sis_hip
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape))).to(device).to(dtype).requires_grad_(True)
+    y = sis_hip.swap_last2(x)
+    assert y.is_contiguous() and torch.equal(y, x.detach().transpose(-1, -2).contiguous())
+    g = torch.randn_like(y)
+    y.backward(g)
+    assert torch.equal(x.grad, g.transpose(-1, -2).contiguous())
+    if min(shape[1:]) > 1:   # (a transposed view with a size-1 axis is still contiguous)
+        with pytest.raises(RuntimeError, match="contiguous 3-d tensor"):
+            sis_hip.swap_last2(x.detach().transpose(-1, -2))
