@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r04ab
-timeout -k 10 300 python tools/find_copies.py transunet > gpurun_out/r04ab/copies_transunet.txt 2>&1
-head -120 gpurun_out/r04ab/copies_transunet.txt
+timeout -k 10 300 python tools/find_copies.py emanet > gpurun_out/r04ab/copies_emanet.txt 2>&1
+grep -v "^   \s" gpurun_out/r04ab/copies_emanet.txt | head -60
