@@ -380,6 +380,10 @@ class _ConvBf16Function(Function):
             gy = gy.bfloat16()
         grad_input = grad_weight = grad_bias = None
         lib_weight = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            # on dL/dy as it arrived: the zero-filled (stride 2) and zero-padded (narrow layer) forms below add nothing to the sums
+            # and are up to 5x the bytes (the segmentation head: 3 channels padded to 16)
+            grad_bias = gy.sum((0, 2, 3), dtype=torch.float32)
         if s == 2 and k == 3 and _STRIDE2_OWN and sis_hip.conv_bf16_supported(cout, cin, h, w, k, 1):
             # A stride-2 convolution is the stride-1 convolution sampled at the even pixels, so its gradients are the
             # stride-1 gradients of dL/dy written into a zero map of the input's size: 4x the multiplies of a dedicated
@@ -430,11 +434,8 @@ class _ConvBf16Function(Function):
                                                                   (0, 0), 1, (False, True, False))[1]
             if grad_weight.dtype != weight.dtype:
                 grad_weight = grad_weight.to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            grad_bias = gy.sum((0, 2, 3), dtype=torch.float32)
         if pad_out:
             grad_weight = None if grad_weight is None else grad_weight[:cout - pad_out]
-            grad_bias = None if grad_bias is None else grad_bias[:cout - pad_out]
         if scatter is not None and grad_input is not None:
             full = grad_input.new_zeros((b, cin) + scatter)
             full[:, :, ::2, ::2] = grad_input
