@@ -250,7 +250,8 @@ int sis_bn_act_bwd(float* dx, float* dresidual, float* dgamma, float* dbeta, con
                    const float* x, const float* mean, const float* invstd, const float* gamma, float* workspace,
                    int batch, int channels, int hw, int relu, const void* relu_mask, void* stream);
 /* Statistics + apply of the training-mode batch norm in ONE launch when a channel's batch * hw elements fit one workgroup's
- * registers (sis_bn_fused_supported: batch * hw <= 16 384 and hw % 256 == 0 -- every 32 x 32 layer of EMANet at batch 16):
+ * registers (sis_bn_fused_supported: batch * hw <= 16 384 and hw % 256 == 0 -- every 32 x 32 layer of EMANet at batch 16 -- or, with
+ * one workgroup of 1 024 threads per channel, batch * hw <= 65 536: the 64 x 64 layers; statistics then within 1e-6, not bitwise):
  * x is read once instead of twice; mean / invstd / running statistics as sis_bn_stats, y (and relu_mask) as sis_bn_act_fwd,
  * bitwise the same values.  sis_bn_act_bwd takes its single-pass form (dy and x read once; results to an ulp of the
  * three-launch form) under the same condition. */

@@ -390,6 +390,179 @@ __global__ __launch_bounds__(256) void bn_fused_bwd_kernel(float* __restrict__ d
     }
 }
 
+// ---- the same single-pass idea for channels of up to 65 536 values (EMANet's 64 x 64 layers at batch 16: layer1's ten norms,
+// 0.44 GB of activations that the three-launch form reads three times forward and five times backward): one workgroup of
+// 1 024 threads per channel, 64 values per thread.  Forward: the values stay in registers between the statistics and the apply
+// step (as above).  Backward: 1 024 threads have 128 registers each, not enough for dy AND x -- dy stays in registers, x is read
+// a second time for the apply step, out of the L2 this workgroup has just pulled its 256 KB through.  Statistics: the mean and the
+// centred second moment of the whole channel directly (no per-slice merge): within 1e-6 of the three-launch form, not bitwise.
+constexpr int BN_WIDE = 65536, BN_WIDE_THREADS = 1024, BN_WIDE_PER = BN_WIDE / (4 * BN_WIDE_THREADS);
+
+struct ChanWalkWide {   // ChanWalk with a step of 4 * 1024 elements
+    int64_t e, hi;
+    int b, r, C, HW, c;
+    __device__ __forceinline__ ChanWalkWide(int64_t hi_, int c_, int C_, int HW_) : hi(hi_), C(C_), HW(HW_), c(c_) {
+        e = (int64_t)threadIdx.x * 4;
+        b = (int)(e / HW);
+        r = (int)(e - (int64_t)b * HW);
+    }
+    __device__ __forceinline__ bool valid() const { return e < hi; }
+    __device__ __forceinline__ int64_t addr() const { return ((int64_t)b * C + c) * HW + r; }
+    __device__ __forceinline__ void next() {
+        e += 4 * BN_WIDE_THREADS; r += 4 * BN_WIDE_THREADS;
+        while (r >= HW) { r -= HW; ++b; }
+    }
+};
+
+__device__ __forceinline__ float block_sum_wide(float v, float* red) {   // 16 waves, fixed order
+    v = wsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < BN_WIDE_THREADS / 64; ++w) s += red[w];
+    return s;
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(BN_WIDE_THREADS) void bn_wide_fwd_kernel(float* __restrict__ y, float* __restrict__ mean_out,
+                                                                     float* __restrict__ invstd_out, float* __restrict__ running_mean,
+                                                                     float* __restrict__ running_var, const float* __restrict__ x,
+                                                                     const float* __restrict__ res, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, int C, int HW, int64_t n, float eps,
+                                                                     float momentum, unsigned long long* __restrict__ mask) {
+    __shared__ float red[BN_WIDE_THREADS / 64];
+    const int c = blockIdx.x;
+    float4 v[BN_WIDE_PER];
+    {
+        ChanWalkWide w(n, c, C, HW);
+#pragma unroll
+        for (int k = 0; k < BN_WIDE_PER; ++k) {
+            v[k] = w.valid() ? *reinterpret_cast<const float4*>(x + w.addr()) : make_float4(0.f, 0.f, 0.f, 0.f);
+            w.next();
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < BN_WIDE_PER; ++k) sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    const float cnt = (float)n;
+    const float mean = block_sum_wide(sum, red) / cnt;
+    float m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < BN_WIDE_PER; ++k) {
+        if ((int64_t)threadIdx.x * 4 + (int64_t)k * 4 * BN_WIDE_THREADS < n) {
+            const float d0 = v[k].x - mean, d1 = v[k].y - mean, d2 = v[k].z - mean, d3 = v[k].w - mean;
+            m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    }
+    m2 = block_sum_wide(m2, red);
+    const float var = m2 / cnt;
+    const float is = rsqrtf(var + eps);
+    if (threadIdx.x == 0) {
+        mean_out[c] = mean; invstd_out[c] = is;
+        if (running_mean) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (cnt > 1.f ? m2 / (cnt - 1.f) : var);
+        }
+    }
+    const float a = (gamma ? gamma[c] : 1.f) * is;
+    const float b = (beta ? beta[c] : 0.f) - mean * a;
+    ChanWalkWide w(n, c, C, HW);
+#pragma unroll
+    for (int k = 0; k < BN_WIDE_PER; ++k) {
+        if (w.valid()) {   // (wave-uniform: n % 256 == 0)
+            const int64_t ad = w.addr();
+            float4 o = v[k];
+            o.x = o.x * a + b; o.y = o.y * a + b; o.z = o.z * a + b; o.w = o.w * a + b;
+            if (RES) { const float4 r = *reinterpret_cast<const float4*>(res + ad); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+            if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            *reinterpret_cast<float4*>(y + ad) = o;
+            if (RELU && mask) {
+                const unsigned long long b0 = __ballot(o.x > 0.f), b1 = __ballot(o.y > 0.f), b2 = __ballot(o.z > 0.f), b3 = __ballot(o.w > 0.f);
+                if ((threadIdx.x & 63) == 0) {
+                    unsigned long long* m = mask + ((ad >> 2) >> 6) * 4;
+                    m[0] = b0; m[1] = b1; m[2] = b2; m[3] = b3;
+                }
+            }
+        }
+        w.next();
+    }
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(BN_WIDE_THREADS) void bn_wide_bwd_kernel(float* __restrict__ dx, float* __restrict__ dres,
+                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                     const float* __restrict__ dy, const float* __restrict__ y,
+                                                                     const float* __restrict__ x, const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                     int C, int HW, int64_t n, const unsigned long long* __restrict__ mask) {
+    __shared__ float red[BN_WIDE_THREADS / 64];
+    const int c = blockIdx.x;
+    const float mu = mean[c], is = invstd[c];
+    float4 g[BN_WIDE_PER];
+    float s1 = 0.f, s2 = 0.f;
+    {
+        ChanWalkWide w(n, c, C, HW);
+#pragma unroll
+        for (int k = 0; k < BN_WIDE_PER; ++k) {
+            g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (w.valid()) {
+                const int64_t ad = w.addr();
+                g[k] = *reinterpret_cast<const float4*>(dy + ad);
+                const float4 xv = *reinterpret_cast<const float4*>(x + ad);
+                if (RELU) {
+                    if (mask) {
+                        const int64_t i4 = ad >> 2;
+                        if (!gate_bit(mask, i4, 0)) g[k].x = 0.f;
+                        if (!gate_bit(mask, i4, 1)) g[k].y = 0.f;
+                        if (!gate_bit(mask, i4, 2)) g[k].z = 0.f;
+                        if (!gate_bit(mask, i4, 3)) g[k].w = 0.f;
+                    } else {
+                        const float4 o = *reinterpret_cast<const float4*>(y + ad);
+                        if (!(o.x > 0.f)) g[k].x = 0.f;
+                        if (!(o.y > 0.f)) g[k].y = 0.f;
+                        if (!(o.z > 0.f)) g[k].z = 0.f;
+                        if (!(o.w > 0.f)) g[k].w = 0.f;
+                    }
+                }
+                s1 += (g[k].x + g[k].y) + (g[k].z + g[k].w);
+                s2 += (g[k].x * ((xv.x - mu) * is) + g[k].y * ((xv.y - mu) * is)) + (g[k].z * ((xv.z - mu) * is) + g[k].w * ((xv.w - mu) * is));
+            }
+            w.next();
+        }
+    }
+    s1 = block_sum_wide(s1, red);
+    s2 = block_sum_wide(s2, red);
+    if (threadIdx.x == 0) { dbeta[c] = s1; dgamma[c] = s2; }
+    const float inv_n = 1.f / (float)n;
+    const float kk = (gamma ? gamma[c] : 1.f) * is;
+    const float m1 = s1 * inv_n, m2 = s2 * inv_n;
+    ChanWalkWide w(n, c, C, HW);
+#pragma unroll
+    for (int k = 0; k < BN_WIDE_PER; ++k) {
+        if (w.valid()) {
+            const int64_t ad = w.addr();
+            const float4 xv = *reinterpret_cast<const float4*>(x + ad);   // second read: L2
+            if (RES) *reinterpret_cast<float4*>(dres + ad) = g[k];
+            float4 r;
+            r.x = kk * (g[k].x - m1 - (xv.x - mu) * is * m2);
+            r.y = kk * (g[k].y - m1 - (xv.y - mu) * is * m2);
+            r.z = kk * (g[k].z - m1 - (xv.z - mu) * is * m2);
+            r.w = kk * (g[k].w - m1 - (xv.w - mu) * is * m2);
+            *reinterpret_cast<float4*>(dx + ad) = r;
+        }
+        w.next();
+    }
+}
+
+bool bn_wide_ok(int batch, int hw) {
+    const char* e = getenv("SIS_BN_SINGLE_PASS");   // (read per call, as bn_fused_ok)
+    const char* w = getenv("SIS_BN_WIDE");          // 0: channels above 16 384 values keep the three-launch form (A/B runs)
+    const int64_t n = (int64_t)batch * hw;
+    return !(e && e[0] == '0') && !(w && w[0] == '0') && n > BN_SLICE && n <= BN_WIDE && hw % 256 == 0;
+}
+
 bool bn_fused_ok(int batch, int hw) {
     const char* e = getenv("SIS_BN_SINGLE_PASS");   // 0: the three-launch form (A/B runs, the equality test); read per call
     return !(e && e[0] == '0') && (int64_t)batch * hw <= BN_SLICE && hw % 256 == 0;
@@ -462,6 +635,19 @@ extern "C" int sis_bn_act_bwd(float* dx, float* dresidual, float* dgamma, float*
     const int64_t n = (int64_t)batch * hw;
     const int S = slices(n);
     hipStream_t st = (hipStream_t)stream;
+    if (bn_wide_ok(batch, hw)) {
+#define SIS_BN_WBWD(R, S_)                                                                                                          \
+    hipLaunchKernelGGL((bn_wide_bwd_kernel<R, S_>), dim3(channels), dim3(BN_WIDE_THREADS), 0, st, dx, dresidual, dgamma, dbeta, dy, y, x, \
+                       mean, invstd, gamma, channels, hw, n, mk)
+        if (relu && dresidual) SIS_BN_WBWD(true, true);
+        else if (relu) SIS_BN_WBWD(true, false);
+        else if (dresidual) SIS_BN_WBWD(false, true);
+        else SIS_BN_WBWD(false, false);
+#undef SIS_BN_WBWD
+        SIS_CHECK_LAUNCH("bn_wide_bwd_kernel");
+        sis_kernel_name = "bn_wide_bwd_kernel";
+        return 0;
+    }
     if (bn_fused_ok(batch, hw)) {
 #define SIS_BN_FBWD(R, S_)                                                                                                  \
     hipLaunchKernelGGL((bn_fused_bwd_kernel<R, S_>), dim3(channels), dim3(256), 0, st, dx, dresidual, dgamma, dbeta, dy, y, x, mean, \
@@ -505,7 +691,7 @@ extern "C" int sis_bn_act_bwd(float* dx, float* dresidual, float* dgamma, float*
  * sis_bn_stats, y (and relu_mask) as sis_bn_act_fwd, bitwise the same values.  (sis_bn_act_bwd takes its single-pass form
  * under the same condition by itself.) */
 extern "C" int sis_bn_fused_supported(int batch, int channels, int hw) {
-    return (batch > 0 && channels > 0 && hw > 0 && bn_fused_ok(batch, hw)) ? 1 : 0;
+    return (batch > 0 && channels > 0 && hw > 0 && (bn_fused_ok(batch, hw) || bn_wide_ok(batch, hw))) ? 1 : 0;
 }
 
 extern "C" int sis_bn_fused_fwd(float* y, float* mean, float* invstd, float* running_mean, float* running_var, const float* x,
@@ -513,10 +699,24 @@ extern "C" int sis_bn_fused_fwd(float* y, float* mean, float* invstd, float* run
                                 float eps, float momentum, int relu, void* relu_mask, void* stream) {
     if (check_geom("sis_bn_fused_fwd", batch, channels, hw)) return 1;
     SIS_REQUIRE(y && mean && invstd && x, "sis_bn_fused_fwd: null pointer");
-    SIS_REQUIRE(bn_fused_ok(batch, hw), "sis_bn_fused_fwd: batch * hw = %lld does not fit one slice / hw %% 256", (long long)batch * hw);
+    SIS_REQUIRE(bn_fused_ok(batch, hw) || bn_wide_ok(batch, hw), "sis_bn_fused_fwd: batch * hw = %lld does not fit one workgroup / hw %% 256",
+                (long long)batch * hw);
     SIS_REQUIRE((((uintptr_t)y | (uintptr_t)x | (uintptr_t)residual) & 15) == 0, "sis_bn_fused_fwd: 16-byte alignment");
     const int64_t n = (int64_t)batch * hw;
     hipStream_t st = (hipStream_t)stream;
+    if (bn_wide_ok(batch, hw)) {
+#define SIS_BN_WFWD(R, S_)                                                                                                        \
+    hipLaunchKernelGGL((bn_wide_fwd_kernel<R, S_>), dim3(channels), dim3(BN_WIDE_THREADS), 0, st, y, mean, invstd, running_mean,     \
+                       running_var, x, residual, gamma, beta, channels, hw, n, eps, momentum, (unsigned long long*)relu_mask)
+        if (relu && residual) SIS_BN_WFWD(true, true);
+        else if (relu) SIS_BN_WFWD(true, false);
+        else if (residual) SIS_BN_WFWD(false, true);
+        else SIS_BN_WFWD(false, false);
+#undef SIS_BN_WFWD
+        SIS_CHECK_LAUNCH("bn_wide_fwd_kernel");
+        sis_kernel_name = "bn_fused_fwd_kernel";
+        return 0;
+    }
 #define SIS_BN_FFWD(R, S_)                                                                                              \
     hipLaunchKernelGGL((bn_fused_fwd_kernel<R, S_>), dim3(channels), dim3(256), 0, st, y, mean, invstd, running_mean, running_var, \
                        x, residual, gamma, beta, channels, hw, n, eps, momentum, (unsigned long long*)relu_mask)

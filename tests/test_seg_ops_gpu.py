@@ -180,6 +180,49 @@ def test_batch_norm_single_pass_equals_three_launches(device, b, c, h, w, relu, 
     assert torch.equal(one[n_fwd:][-1], run(True)[n_fwd:][-1])   # and repeatable
 
 
+@pytest.mark.parametrize("b,c,h,w,relu,use_res", [(16, 64, 64, 64, True, True), (8, 32, 64, 64, True, False), (5, 16, 64, 64, False, True),
+                                                  (2, 8, 128, 128, True, False), (16, 256, 64, 64, True, True)])
+def test_batch_norm_wide_single_pass(device, b, c, h, w, relu, use_res, monkeypatch):
+    """Channels of 16 385 ... 65 536 values (EMANet's 64 x 64 layers at batch 16; csrc/bn_ops.hip, bn_wide_*: one workgroup of 1 024
+    threads per channel, the backward reads x a second time out of L2) against the three-launch form: statistics within 1e-6, outputs
+    within 2e-6 of the largest value, gradients 2e-5, the ReLU gate identical except within rounding of zero; bitwise repeatable."""
+    import sis_hip
+    gen = torch.Generator().manual_seed(b * 3 + c + h)
+    x = (torch.randn(b, c, h, w, generator=gen) * 2 + 0.5).to(device)
+    res = torch.randn(b, c, h, w, generator=gen).to(device) if use_res else None
+    dy = torch.randn(b, c, h, w, generator=gen).to(device)
+    gamma, beta = (1 + 0.1 * torch.randn(c, generator=gen)).to(device), (0.1 * torch.randn(c, generator=gen)).to(device)
+
+    def run(single):
+        monkeypatch.setenv("SIS_BN_SINGLE_PASS", "1" if single else "0")
+        rm, rv = torch.zeros(c, device=device), torch.ones(c, device=device)
+        if single:
+            assert sis_hip.bn_fused_supported(x)
+            y, mean, invstd, mask = sis_hip.bn_fused_fwd(x, res, gamma, beta, rm, rv, 1e-5, 3e-4, relu, want_mask=relu)
+        else:
+            assert not sis_hip.bn_fused_supported(x)
+            mean, invstd = sis_hip.bn_stats(x, rm, rv, 1e-5, 3e-4)
+            out = sis_hip.bn_act_fwd(x, res, mean, invstd, gamma, beta, relu, want_mask=relu)
+            y, mask = out if relu else (out, None)
+        grads = sis_hip.bn_act_bwd(dy, None if mask is not None else y, x, mean, invstd, gamma, relu, use_res, mask=mask)
+        return dict(y=y, mean=mean, invstd=invstd, rm=rm, rv=rv, mask=mask, grads=[t for t in grads if t is not None])
+
+    one, three, again = run(True), run(False), run(True)
+    for k in ("mean", "invstd", "rm", "rv"):
+        assert (one[k] - three[k]).abs().max().item() <= 1e-6 * three[k].abs().max().item() + 1e-7, k
+    scale = three["y"].abs().max().item()
+    assert (one["y"] - three["y"]).abs().max().item() <= 2e-6 * scale
+    if relu:
+        flipped = sum(bin(int(v) & 0xFFFFFFFFFFFFFFFF).count("1") for v in (one["mask"] ^ three["mask"])[one["mask"] != three["mask"]].cpu().tolist())
+        assert flipped <= 8, flipped
+    for u, v in zip(one["grads"], three["grads"]):
+        assert (u - v).abs().max().item() <= 2e-5 * v.abs().max().item()
+    for k in ("y", "mean", "invstd", "rm", "rv"):
+        assert torch.equal(one[k], again[k]), k
+    for u, v in zip(one["grads"], again["grads"]):
+        assert torch.equal(u, v)
+
+
 @pytest.mark.parametrize("b,c,h,w,use_res", [(2, 8, 16, 16, False), (3, 5, 12, 20, True), (16, 64, 32, 32, True), (1, 3, 6, 6, False)])
 def test_batch_norm_relu_sign_mask_equals_the_output_gate(device, b, c, h, w, use_res):
     """The 1-bit-per-element ReLU gate written by the forward apply pass gives bit-for-bit the backward that reads y itself

@@ -149,6 +149,7 @@ _ENV_SWITCHES = [
     ("SIS_WINOGRAD", "0", "generator"),
     ("SIS_RGB_STREAM", "0", "generator"),
     ("SIS_BN_SINGLE_PASS", "0", "ema_net"),      # csrc/bn_ops.hip reads it per call
+    ("SIS_BN_WIDE", "0", "ema_net"),             # (the shapes it steers: tests/test_seg_ops_gpu.py::test_batch_norm_wide_single_pass)
 ]
 
 
