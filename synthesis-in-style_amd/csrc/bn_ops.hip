@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256) void bn_fused_bwd_kernel(float* __restrict__ d
 // centred second moment of the whole channel directly (no per-slice merge): within 1e-6 of the three-launch form, not bitwise.
 constexpr int BN_WIDE = 65536, BN_WIDE_THREADS = 1024, BN_WIDE_PER = BN_WIDE / (4 * BN_WIDE_THREADS);
 
-struct ChanWalkWide {   // ChanWalk with a step of 4 * 1024 elements
+template <int THREADS = BN_WIDE_THREADS>
+struct ChanWalkWide {   // ChanWalk with a step of 4 * THREADS elements
     int64_t e, hi;
     int b, r, C, HW, c;
     __device__ __forceinline__ ChanWalkWide(int64_t hi_, int c_, int C_, int HW_) : hi(hi_), C(C_), HW(HW_), c(c_) {
@@ -409,19 +410,20 @@ struct ChanWalkWide {   // ChanWalk with a step of 4 * 1024 elements
     __device__ __forceinline__ bool valid() const { return e < hi; }
     __device__ __forceinline__ int64_t addr() const { return ((int64_t)b * C + c) * HW + r; }
     __device__ __forceinline__ void next() {
-        e += 4 * BN_WIDE_THREADS; r += 4 * BN_WIDE_THREADS;
+        e += 4 * THREADS; r += 4 * THREADS;
         while (r >= HW) { r -= HW; ++b; }
     }
 };
 
-__device__ __forceinline__ float block_sum_wide(float v, float* red) {   // 16 waves, fixed order
+template <int THREADS = BN_WIDE_THREADS>
+__device__ __forceinline__ float block_sum_wide(float v, float* red) {   // THREADS / 64 waves, fixed order
     v = wsum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < BN_WIDE_THREADS / 64; ++w) s += red[w];
+    for (int w = 0; w < THREADS / 64; ++w) s += red[w];
     return s;
 }
 
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(BN_WIDE_THREADS) void bn_wide_fwd_kernel(float* __r
     const int c = blockIdx.x;
     float4 v[BN_WIDE_PER];
     {
-        ChanWalkWide w(n, c, C, HW);
+        ChanWalkWide<> w(n, c, C, HW);
 #pragma unroll
         for (int k = 0; k < BN_WIDE_PER; ++k) {
             v[k] = w.valid() ? *reinterpret_cast<const float4*>(x + w.addr()) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(BN_WIDE_THREADS) void bn_wide_fwd_kernel(float* __r
     }
     const float a = (gamma ? gamma[c] : 1.f) * is;
     const float b = (beta ? beta[c] : 0.f) - mean * a;
-    ChanWalkWide w(n, c, C, HW);
+    ChanWalkWide<> w(n, c, C, HW);
 #pragma unroll
     for (int k = 0; k < BN_WIDE_PER; ++k) {
         if (w.valid()) {   // (wave-uniform: n % 256 == 0)
@@ -490,27 +492,29 @@ __global__ __launch_bounds__(BN_WIDE_THREADS) void bn_wide_fwd_kernel(float* __r
     }
 }
 
-template <bool RELU, bool RES>
-__global__ __launch_bounds__(BN_WIDE_THREADS) void bn_wide_bwd_kernel(float* __restrict__ dx, float* __restrict__ dres,
+// THREADS x PER float4 = the channel's capacity (1 024 x 16: 65 536 values, x read twice; 512 x 8: 16 384 values, x kept in registers)
+template <bool RELU, bool RES, int THREADS, int PER, bool KEEP_X>
+__global__ __launch_bounds__(THREADS) void bn_wide_bwd_kernel(float* __restrict__ dx, float* __restrict__ dres,
                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                      const float* __restrict__ dy, const float* __restrict__ y,
                                                                      const float* __restrict__ x, const float* __restrict__ mean,
                                                                      const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                      int C, int HW, int64_t n, const unsigned long long* __restrict__ mask) {
-    __shared__ float red[BN_WIDE_THREADS / 64];
+    __shared__ float red[THREADS / 64];
     const int c = blockIdx.x;
     const float mu = mean[c], is = invstd[c];
-    float4 g[BN_WIDE_PER];
+    float4 g[PER], xk[KEEP_X ? PER : 1];
     float s1 = 0.f, s2 = 0.f;
     {
-        ChanWalkWide w(n, c, C, HW);
+        ChanWalkWide<THREADS> w(n, c, C, HW);
 #pragma unroll
-        for (int k = 0; k < BN_WIDE_PER; ++k) {
+        for (int k = 0; k < PER; ++k) {
             g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (w.valid()) {
                 const int64_t ad = w.addr();
                 g[k] = *reinterpret_cast<const float4*>(dy + ad);
                 const float4 xv = *reinterpret_cast<const float4*>(x + ad);
+                if (KEEP_X) xk[k] = xv;
                 if (RELU) {
                     if (mask) {
                         const int64_t i4 = ad >> 2;
@@ -532,18 +536,18 @@ __global__ __launch_bounds__(BN_WIDE_THREADS) void bn_wide_bwd_kernel(float* __r
             w.next();
         }
     }
-    s1 = block_sum_wide(s1, red);
-    s2 = block_sum_wide(s2, red);
+    s1 = block_sum_wide<THREADS>(s1, red);
+    s2 = block_sum_wide<THREADS>(s2, red);
     if (threadIdx.x == 0) { dbeta[c] = s1; dgamma[c] = s2; }
     const float inv_n = 1.f / (float)n;
     const float kk = (gamma ? gamma[c] : 1.f) * is;
     const float m1 = s1 * inv_n, m2 = s2 * inv_n;
-    ChanWalkWide w(n, c, C, HW);
+    ChanWalkWide<THREADS> w(n, c, C, HW);
 #pragma unroll
-    for (int k = 0; k < BN_WIDE_PER; ++k) {
+    for (int k = 0; k < PER; ++k) {
         if (w.valid()) {
             const int64_t ad = w.addr();
-            const float4 xv = *reinterpret_cast<const float4*>(x + ad);   // second read: L2
+            const float4 xv = KEEP_X ? xk[k] : *reinterpret_cast<const float4*>(x + ad);   // (second read: L2)
             if (RES) *reinterpret_cast<float4*>(dres + ad) = g[k];
             float4 r;
             r.x = kk * (g[k].x - m1 - (xv.x - mu) * is * m2);
@@ -637,7 +641,7 @@ extern "C" int sis_bn_act_bwd(float* dx, float* dresidual, float* dgamma, float*
     hipStream_t st = (hipStream_t)stream;
     if (bn_wide_ok(batch, hw)) {
 #define SIS_BN_WBWD(R, S_)                                                                                                          \
-    hipLaunchKernelGGL((bn_wide_bwd_kernel<R, S_>), dim3(channels), dim3(BN_WIDE_THREADS), 0, st, dx, dresidual, dgamma, dbeta, dy, y, x, \
+    hipLaunchKernelGGL((bn_wide_bwd_kernel<R, S_, BN_WIDE_THREADS, BN_WIDE_PER, false>), dim3(channels), dim3(BN_WIDE_THREADS), 0, st, dx, dresidual, dgamma, dbeta, dy, y, x, \
                        mean, invstd, gamma, channels, hw, n, mk)
         if (relu && dresidual) SIS_BN_WBWD(true, true);
         else if (relu) SIS_BN_WBWD(true, false);
@@ -646,6 +650,22 @@ extern "C" int sis_bn_act_bwd(float* dx, float* dresidual, float* dgamma, float*
 #undef SIS_BN_WBWD
         SIS_CHECK_LAUNCH("bn_wide_bwd_kernel");
         sis_kernel_name = "bn_wide_bwd_kernel";
+        return 0;
+    }
+    static const bool bwd512 = !(getenv("SIS_BN_BWD512") && getenv("SIS_BN_BWD512")[0] == '0');   // 0: the 256-thread form (A/B runs)
+    if (bn_fused_ok(batch, hw) && bwd512) {
+        // 512 threads x 8 float4 (dy and x in registers, ~100 VGPRs: 16 waves per CU instead of the 8 the 256-thread form's
+        // ~200 VGPRs allow) -- the same sums in a different association: to an ulp of the 256-thread form
+#define SIS_BN_MBWD(R, S_)                                                                                                   \
+    hipLaunchKernelGGL((bn_wide_bwd_kernel<R, S_, 512, BN_SLICE / 2048, true>), dim3(channels), dim3(512), 0, st, dx, dresidual, dgamma, \
+                       dbeta, dy, y, x, mean, invstd, gamma, channels, hw, n, mk)
+        if (relu && dresidual) SIS_BN_MBWD(true, true);
+        else if (relu) SIS_BN_MBWD(true, false);
+        else if (dresidual) SIS_BN_MBWD(false, true);
+        else SIS_BN_MBWD(false, false);
+#undef SIS_BN_MBWD
+        SIS_CHECK_LAUNCH("bn_fused_bwd_kernel");
+        sis_kernel_name = "bn_fused_bwd_kernel";
         return 0;
     }
     if (bn_fused_ok(batch, hw)) {

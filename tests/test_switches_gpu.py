@@ -169,6 +169,7 @@ _C_SIDE = [
     ("SIS_GN_SINGLE_PASS", "0", "tests/test_upsample_gpu.py"),
     ("SIS_UP2_DIRECT", "0", "tests/test_upsample_gpu.py"),
     ("SIS_PW_KC", "32", "tests/test_conv1x1_f32_gpu.py"),
+    ("SIS_BN_BWD512", "0", "tests/test_seg_ops_gpu.py"),
     ("SIS_KMEANS_FAST", "0", "tests/test_dataset_ops_gpu.py"),
 ]
 
