@@ -58,7 +58,9 @@ def test_bench_line_carries_the_contract_fields(device):
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
+    assert len(lines[0]) < 6144, f"the bench line is {len(lines[0])} bytes: per-kernel tables belong in the detail file"
     r = json.loads(lines[0])
+    assert "kernels" not in r["roofline"]
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in r, key

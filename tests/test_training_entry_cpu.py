@@ -207,3 +207,57 @@ def test_bench_gpus_flag_launches_ranks_or_rejects_a_mismatch():
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--workload", "synthesis"],
                            env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "local_rank: 1" in r.stderr  # two ranks were started, both failed loudly
+
+
+def test_bench_line_stays_compact_and_carries_the_training_legs(tmp_path, capsys, monkeypatch):
+    """bench.py's `--workload all` line (host logic only, no GPU): the driver's parsed record keeps `config`, `roofline` and
+    `cpu_baseline` as flat objects and the END of stdout, so the training legs must appear (1) as flat ``seg_<leg>_*`` keys in
+    those objects, (2) as the compact nested `seg_train` object at the very end of the line; per-kernel tables go to the
+    detail file and the whole line stays below 6 KB."""
+    import argparse
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    table = {f"kernel_{i}<128,256,{i}>": {"launches": i, "ms": 0.1 * i, "nominal_tflops": 1.0, "gbs_algorithmic": 2.0,
+                                          "bound": "mfma", "frac_of_peak": 0.5} for i in range(120)}
+
+    def leg(value, dtype, cpu):
+        return {"value": value, "ms_per_step": 27.0, "dtype": dtype, "steps": 20, "warmup": 5, "scaling": "weak",
+                "config": {"workload": "w" * 150, "batch_per_gpu": 16, "image_size": 256, "hip_graph": True},
+                "roofline": {"bound": "mfma", "achieved": 86.0, "peak": 157.3, "unit": "TFLOP/s", "frac": 0.55, "algorithmic_frac": 0.85,
+                             "dominant_own_kernel": "conv1x1_f32_kernel<128,256,16>", "traffic": 1.0e8,
+                             "own_kernels_eager_iteration": dict(table)},
+                "cpu_baseline": cpu and {"value": 1.5, "unit": "images/s", "cores": 16, "kind": "port", "batch": 4, "sample": "s" * 200},
+                "library_calls_per_step": {"fallback": {}, "intended": {"stem": 2}},
+                "library_ms_per_step": {"own_ms": 26.5, "library_ms": 0.34, "top_library_kernels_ms": {"x" * 60: 0.3}},
+                "data_parallel_rehearsal": {"graph_ms_per_step": 27.2, "eager_ms_per_step": 27.3, "direct_rccl": True}}
+
+    result = {"metric": bench.METRIC, "value": 2100.0, "unit": "images/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 15.2,
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+              "config": {"workload": "synthesis", "batch_per_gpu": 32},
+              "roofline": {"kernel": "modconv_wino2_kernel", "bound": "mfma", "achieved": 118.0, "peak": 157.3, "unit": "TFLOP/s",
+                           "frac": 0.75, "traffic": 1.7e9, "kernels": dict(table)},
+              "cpu_baseline": {"value": 2.2, "unit": "images/s", "cores": 16, "kind": "port", "sample": "b4"}}
+    seg = {"emanet": leg(600.0, "f32", True), "transunet_bf16": leg(370.0, "bf16", True), "transunet_f32": leg(94.0, "f32", False)}
+    bench.attach_seg_train(result, seg)
+    bench.emit(result, argparse.Namespace(workload="all"))
+    line = capsys.readouterr().out.strip()
+    assert "\n" not in line and len(line) < 6144, len(line)
+    r = json.loads(line)
+    assert list(r)[-1] == "seg_train"                      # the tail of stdout is the compact summary
+    assert r["value"] == 2100.0 and "kernels" not in r["roofline"]
+    assert r["config"]["seg_emanet_images_per_s"] == 600.0 and r["config"]["seg_transunet_bf16_images_per_s"] == 370.0
+    assert r["roofline"]["seg_transunet_bf16_frac"] == 0.55 and r["roofline"]["seg_emanet_dominant_own_kernel"].startswith("conv1x1")
+    assert r["cpu_baseline"]["seg_emanet_value"] == 1.5 and "seg_transunet_f32_value" not in r["cpu_baseline"]
+    for obj in (r["config"], r["roofline"], r["cpu_baseline"]):   # flat: nothing the driver's parser would drop
+        assert not any(isinstance(v, (dict, list)) for v in obj.values())
+    s = r["seg_train"]["transunet_bf16"]
+    assert s["images_per_s"] == 370.0 and s["roofline"]["frac"] == 0.55 and s["cpu_baseline"]["value"] == 1.5
+    assert s["library_ms_per_step"] == 0.34 and s["dp_rehearsal_graph_ms_per_step"] == 27.2 and s["hip_graph"] is True
+    detail = json.load(open(tmp_path / "gpurun_out" / "bench_detail_all.json"))
+    assert len(detail["seg_train"]["emanet"]["roofline"]["own_kernels_eager_iteration"]) == 120
+    assert len(detail["roofline_tables"]["kernels"]) == 120
