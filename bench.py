@@ -238,9 +238,13 @@ def data_parallel_rehearsal(args, workload, config, device):
         return None
     out = {"backend": dist.get_backend(), "world": dist.get_world_size(), "flavour": config.get("data_parallel", "buckets")}
     import training.grad_exchange as grad_exchange
-    # "graph" / "eager": collectives issued straight into librccl.so ("eager" = the default at world size > 1, "graph" at 1);
-    # "torch_collectives_eager": the same buckets through torch.distributed's work objects (SIS_DP_DIRECT_RCCL=0)
+    saved_direct = grad_exchange._DIRECT_RCCL
+    # "graph" / "eager": collectives issued straight into librccl.so (the default at world size 1; captured = "graph");
+    # "torch_collectives_eager": the same buckets through torch.distributed's work objects (the default at world size > 1)
+    only = os.environ.get("SIS_BENCH_DP_MODES")   # profiling: a comma-separated subset of the legs
     for mode, hip_graph, direct in (("graph", True, "1"), ("eager", False, "1"), ("torch_collectives_eager", False, "0")):
+        if only and mode not in only.split(","):
+            continue
         grad_exchange._DIRECT_RCCL = direct
         gc.collect()
         torch.cuda.empty_cache()
@@ -264,10 +268,17 @@ def data_parallel_rehearsal(args, workload, config, device):
         out["collective"] = net.collective
         if hip_graph:
             out["hip_graph"] = updater._step_graph.graph is not None
+        if direct == "1":
             out["direct_rccl"] = net.direct_rccl()
+            out["direct_rccl_note"] = net.direct_rccl_note
+            moved = net.stats["copied_elems"] + net.stats["in_place_elems"]
+            # share of the gradient elements the weight-gradient kernels wrote straight into the buckets (eager backwards
+            # after the discovery one; replays run the same launches)
+            per = moved / max(net.stats["backwards"], 1)
+            out["gradients_written_in_place"] = round(net.stats["in_place_elems"] / max(moved - per, 1), 4)
         del updater, builder, net
-    grad_exchange._DIRECT_RCCL = "1"
-    out["default_at_world_size_gt_1"] = "eager (direct RCCL calls; SIS_DP_GRAPH=1: graph)"
+    grad_exchange._DIRECT_RCCL = saved_direct
+    out["default_at_world_size_gt_1"] = "eager, torch.distributed collectives (SIS_DP_DIRECT_RCCL=1: direct RCCL calls behind a self-check)"
     return out
 
 
@@ -353,6 +364,11 @@ def bench_training(args, workload, world, rank, device, distributed):
         dp = data_parallel_rehearsal(args, workload, config, device)
     if rank != 0:
         return None
+    if dp is not None and baseline_config and dp.get("backend") == "nccl" and dp.get("direct_rccl") is False:
+        # the rehearsal's graph leg was to run on the direct librccl.so path: a torch build without _comm_ptr (or no mapped
+        # RCCL) silently measuring the work-object path would pass as the captured exchange
+        raise SystemExit(f"bench.py: {workload}: the data-parallel rehearsal did not reach librccl.so directly "
+                         f"(direct_rccl: false, {dp.get('direct_rccl_note')})")
     images = config["batch_size"] * args.steps * world
     step_flops = SEG_FLOPS_PER_IMAGE[workload] * config["batch_size"]           # nominal 2*MAC, SURVEY.md §8(d)
     # EXECUTED matrix FLOPs of the hand-written kernels, as recorded at their launches in the instrumented eager iteration:
@@ -665,7 +681,7 @@ def seg_summary(sub):
             "library_ms_per_step": lib.get("library_ms"), "own_ms_per_step": lib.get("own_ms"),
             "library_fallback_ops": sum((sub.get("library_calls_per_step") or {}).get("fallback", {}).values()),
             "dp_rehearsal_graph_ms_per_step": dp.get("graph_ms_per_step"), "dp_rehearsal_eager_ms_per_step": dp.get("eager_ms_per_step"),
-            "dp_direct_rccl": dp.get("direct_rccl")}
+            "dp_direct_rccl": dp.get("direct_rccl"), "dp_gradients_written_in_place": dp.get("gradients_written_in_place")}
 
 
 def attach_seg_train(result, seg):

@@ -21,6 +21,11 @@
 #include <type_traits>
 #include "sis_common.h"
 
+// Timing ablations (WRONG results): development builds only (-DSIS_ABLATIONS -DSIS_WG_NOLOAD ...), refused otherwise.
+#if !defined(SIS_ABLATIONS) && (defined(SIS_WG_NOTRANSFORM) || defined(SIS_WG_NOLOAD) || defined(SIS_WG_NOBARRIER))
+#error "SIS_WG_* ablation switches need -DSIS_ABLATIONS (development builds only)"
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -354,7 +354,7 @@ extern "C" int sis_modconv2d_up_fir(float* t, const float* x, const float* u, co
     const int64_t grid = (int64_t)sis_cdiv(p.total_blocks, UF_NBLK) * (cout / UF_MBLK);
     SIS_REQUIRE(grid > 0 && grid < ((int64_t)1 << 31), "sis_modconv2d_up_fir: bad grid");
     static const int pipe = getenv("SIS_UPFIR_PIPE") ? atoi(getenv("SIS_UPFIR_PIPE")) : 1;   // software-pipelining variant (experiments)
-#ifdef SIS_UPFIR_ABLATIONS   // development builds only (tools/build_variant.sh -DSIS_UPFIR_ABLATIONS): the shipped library has no wrong-result path
+#ifdef SIS_ABLATIONS   // development builds only (tools/build_variant.sh WORK <tag> -DSIS_ABLATIONS): the shipped library has no wrong-result path
     static const int abl = getenv("SIS_UPFIR_ABL") ? atoi(getenv("SIS_UPFIR_ABL")) : 0;      // timing ablations: WRONG results
     if (abl) {
 #define UF_ABL(A) hipLaunchKernelGGL((modconv_upfir_kernel<1, A>), dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p)

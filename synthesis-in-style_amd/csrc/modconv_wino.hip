@@ -23,6 +23,14 @@
 // 2e-5 per-layer bound as the direct kernel (tests/test_generator_gpu.py).
 #include "modconv_common.h"
 
+// Timing ablations (WRONG results) exist for development builds only: `tools/build_variant.sh WORK <tag> -DSIS_ABLATIONS
+// -DSIS_WINO_NOSTORE ...`.  Without -DSIS_ABLATIONS the switches are refused at compile time, so the shipped library cannot
+// contain a wrong-result path.
+#if !defined(SIS_ABLATIONS) && (defined(SIS_WINO_NODMA) || defined(SIS_WINO_NOTRANSFORM) || defined(SIS_WINO_NOBARRIER) || \
+                                defined(SIS_WINO_NOSTORE) || defined(SIS_WINO_STAGGER))
+#error "SIS_WINO_* ablation switches need -DSIS_ABLATIONS (development builds only)"
+#endif
+
 namespace {
 
 constexpr int WCC = 8;      // input channels per chunk

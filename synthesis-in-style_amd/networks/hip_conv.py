@@ -51,14 +51,14 @@ def _conv3x3_dgrad(grad_output, weight, d):
     return _batch_to_space(sis_hip.conv3x3(_space_to_batch(grad_output, d), sis_hip.conv3x3_prepack(weight, adjoint=True)), d)
 
 
-def _conv3x3_wgrad(input, grad_output, weight_shape, d, input_s=None, grad_output_s=None):
+def _conv3x3_wgrad(input, grad_output, weight_shape, d, input_s=None, grad_output_s=None, for_param=None):
     """``input_s`` / ``grad_output_s``: the sub-image forms of the two tensors when the caller already has them (a dilated
     layer's forward keeps its permuted input, its backward permutes dL/dy once for both gradients: 4 permute copies per
     layer and step instead of 6)."""
     b, cin, h, w = input.shape
     if sis_hip.conv3x3_wgrad_supported(b * d * d, cin, weight_shape[0], h // d, w // d):
         return sis_hip.conv3x3_wgrad(_space_to_batch(input, d) if input_s is None else input_s,
-                                     _space_to_batch(grad_output, d) if grad_output_s is None else grad_output_s)
+                                     _space_to_batch(grad_output, d) if grad_output_s is None else grad_output_s, for_param=for_param)
     # narrow sub-images / channel counts below a 64 x 64 tile / too little work: the library's kernel
     return torch.ops.aten.convolution_backward(grad_output, input, input.new_empty(weight_shape), None, (1, 1), (d, d), (d, d),
                                                False, (0, 0), 1, (False, True, False))[1]
@@ -103,7 +103,8 @@ class _Conv3x3Backward(Function):
                 u_adjoint = sis_hip.conv3x3_prepack(weight, adjoint=True)
             grad_input = _batch_to_space(sis_hip.conv3x3(grad_output_s, u_adjoint), dilation)
         if want_weight:
-            grad_weight = _conv3x3_wgrad(input, grad_output, weight.shape, dilation, input_s, grad_output_s)
+            # (for_param: under the data-parallel wrap the kernel writes into the parameter's bucket slice, sis_hip.grad_out)
+            grad_weight = _conv3x3_wgrad(input, grad_output, weight.shape, dilation, input_s, grad_output_s, for_param=weight.data_ptr())
         return grad_input, grad_weight
 
     @staticmethod
@@ -206,7 +207,7 @@ class _Pointwise(Function):
         g = grad_output.view(b, cout, h * w)
         if ctx.needs_input_grad[1]:
             if _F32_POINTWISE and sis_hip.conv1x1_wgrad_f32_supported(grad_output, input):
-                grad_weight = sis_hip.conv1x1_wgrad_f32(grad_output, input)  # csrc/conv1x1_wgrad_f32.hip
+                grad_weight = sis_hip.conv1x1_wgrad_f32(grad_output, input, for_param=weight.data_ptr())  # csrc/conv1x1_wgrad_f32.hip
             else:
                 sis_hip.library_call("hip_conv._Pointwise.wgrad")
                 grad_weight = torch.bmm(g, input.view(b, cin, h * w).transpose(1, 2)).sum(0).view(cout, cin, 1, 1)
@@ -242,7 +243,7 @@ class _PointwiseWithSkip(Function):
                 grad_input = sis_hip.conv1x1_f32(grad_output, weight, data_gradient=True)
         if ctx.needs_input_grad[1]:
             if sis_hip.conv1x1_wgrad_f32_supported(grad_output, input):
-                grad_weight = sis_hip.conv1x1_wgrad_f32(grad_output, input)
+                grad_weight = sis_hip.conv1x1_wgrad_f32(grad_output, input, for_param=weight.data_ptr())
             else:
                 sis_hip.library_call("hip_conv._PointwiseWithSkip.wgrad")
                 b, cin, h, w = input.shape
@@ -285,11 +286,12 @@ class _HalfDilationTaps(Function):
     @staticmethod
     def forward(ctx, weight):
         ctx.shape = (weight.shape[0], weight.shape[1])
+        ctx.key = weight.data_ptr()   # the parameter's gradient-arena slice (sis_hip.grad_out)
         return sis_hip.half_dilation_taps(weight)
 
     @staticmethod
     def backward(ctx, grad_taps):
-        return sis_hip.half_dilation_taps_bwd(grad_taps.contiguous(), *ctx.shape)
+        return sis_hip.half_dilation_taps_bwd(grad_taps.contiguous(), *ctx.shape, for_param=ctx.key)
 
 
 def conv3x3_half_image_dilation(input, weight):
@@ -418,10 +420,11 @@ class _ConvBf16Function(Function):
                 grad_input = torch.ops.aten.convolution_backward(gy, input, lib_weight, None, (s, s), (k // 2, k // 2), (1, 1), False,
                                                                  (0, 0), 1, (True, False, False))[0]
         if ctx.needs_input_grad[1]:
+            key = None if pad_out else weight.data_ptr()   # the parameter's arena slice (sis_hip.grad_out); a padded weight is a copy
             if k == 3 and s == 1 and sis_hip.conv_bf16_wgrad_supported(b, cin, cout, h, w):
-                grad_weight = sis_hip.conv_bf16_wgrad(input, gy, weight.dtype)
+                grad_weight = sis_hip.conv_bf16_wgrad(input, gy, weight.dtype, for_param=key)
             elif k == 1 and s == 1 and _PW_WGRAD_OWN and sis_hip.conv1x1_bf16_wgrad_supported(b, cin, cout, h * w):
-                grad_weight = sis_hip.conv1x1_bf16_wgrad(input, gy, weight.dtype)   # csrc/conv_bf16_wgrad.hip, any plane size
+                grad_weight = sis_hip.conv1x1_bf16_wgrad(input, gy, weight.dtype, for_param=key)   # csrc/conv_bf16_wgrad.hip, any plane size
             elif k == 1 and s == 1:
                 sis_hip.library_call("hip_conv._ConvBf16Function.wgrad_1x1")
                 grad_weight = torch.bmm(gy.view(b, cout, h * w), input.view(b, cin, h * w).transpose(1, 2)).sum(0, dtype=torch.float32)

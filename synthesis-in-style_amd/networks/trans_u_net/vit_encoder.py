@@ -217,6 +217,12 @@ class Attention(nn.Module):
         self.softmax = Softmax(dim=-1)
         self._lp = None  # bf16 shadows of (query | key | value) and out, built on first use (not part of the state_dict)
 
+    def grad_fusion_groups(self):
+        """Parameters whose gradients ONE kernel produces as one stacked tensor (the fused query | key | value weight-gradient
+        GEMM): the data-parallel wrap lays their bucket slices out back to back in this order, so that the GEMM can write
+        straight into the bucket (training/grad_exchange.py, sis_hip.grad_out_fused)."""
+        return [(self.query.weight, self.key.weight, self.value.weight)]
+
     def _shadows(self):
         if self._lp is None or self._lp[0].params[0] is not self.query.weight:
             self._lp = (_Bf16Shadow([self.query.weight, self.key.weight, self.value.weight]),
@@ -355,26 +361,32 @@ class _SideWgrads:
         self.side = _wgrad_stream(device)
         self.outputs = []
 
-    def run(self, grad, inp, out_features, in_features):
-        """(dW fp32 [out, in], db fp32 [out]) of y = inp W^T + b from grad = dL/dy (bf16 [tokens, out]), inp bf16 [tokens, in]."""
+    def run(self, grad, inp, out_features, in_features, keys=None):
+        """(dW fp32 [out, in], db fp32 [out]) of y = inp W^T + b from grad = dL/dy (bf16 [tokens, out]), inp bf16 [tokens, in].
+        ``keys``: storage addresses of the weight parameter(s) dW is the gradient of -- under the data-parallel wrap the GEMM
+        writes into their bucket slice (``sis_hip.grad_out_fused``; several parameters: query | key | value, stacked)."""
         S = sis_hip
         splits, tile = _wgrad_plan(out_features, in_features)
+        out = None
+        if keys:
+            rows = [out_features // len(keys)] * len(keys)
+            out = S.grad_out_fused(keys, rows, in_features, grad.device)
         if self.side is None:
             if _FUSE_BIAS_GRAD and splits > 1 and tile in (0, 4, 5, 6) and grad.shape[0] >= 64 * splits:   # (fewer tokens: the GEMM drops its split)
                 # the bias column sums ride in the weight-gradient launches (extra workgroups in the idle slots of the last round)
-                return S.gemm_bf16_wgrad_bias(grad, inp, splits, tile)
-            return S.gemm_bf16(grad, inp, S.GEMM_TN, S.EPI_F32, splits=splits, tile=tile), S.column_sum(grad)
+                return S.gemm_bf16_wgrad_bias(grad, inp, splits, tile, dw=out)
+            return S.gemm_bf16(grad, inp, S.GEMM_TN, S.EPI_F32, splits=splits, tile=tile, out=out), S.column_sum(grad)
         self.side.wait_event(self.main.record_event())   # grad (and inp) are complete on the main stream
         grad.record_stream(self.side)
         if _WGRAD_SIDE == 2:   # only the small column-sum kernels leave the main stream
-            dw = S.gemm_bf16(grad, inp, S.GEMM_TN, S.EPI_F32, splits=splits, tile=tile)
+            dw = S.gemm_bf16(grad, inp, S.GEMM_TN, S.EPI_F32, splits=splits, tile=tile, out=out)
             with torch.cuda.stream(self.side):
                 db = S.column_sum(grad)
             self.outputs += [db]
             return dw, db
         inp.record_stream(self.side)
         with torch.cuda.stream(self.side):
-            dw = S.gemm_bf16(grad, inp, S.GEMM_TN, S.EPI_F32, splits=splits, tile=tile)
+            dw = S.gemm_bf16(grad, inp, S.GEMM_TN, S.EPI_F32, splits=splits, tile=tile, out=out)
             db = S.column_sum(grad)
         self.outputs += [dw, db]
         return dw, db
@@ -431,6 +443,8 @@ class _FusedBlockFn(Function):
         ctx.save_for_backward(x2d, mean1, rstd1, h1, qkv, att, lse, x2, mean2, rstd2, h2, pre, act, wqkv, wo, w1, w2, ln1_w, ln2_w,
                               wqkv_t, wo_t, w1_t, w2_t)
         ctx.cfg, ctx.shape = cfg, (b, n, hid)
+        # storage addresses of the weight parameters: the backward's weight-gradient GEMMs write into their gradient-arena slices
+        ctx.weight_keys = ((q_w.data_ptr(), k_w.data_ptr(), v_w.data_ptr()), (o_w.data_ptr(),), (f1_w.data_ptr(),), (f2_w.data_ptr(),))
         return x3.view(b, n, hid)
 
     @staticmethod
@@ -457,18 +471,19 @@ class _FusedBlockFn(Function):
 
         # ---- MLP
         gl2 = S.dropout_bwd_cast(g3, seed, site + 2, p_mlp)                                   # d(fc2 output), bf16
-        d_w2, d_b2 = wg.run(gl2, act, hid, mlp)
+        k_qkv, k_o, k_f1, k_f2 = ctx.weight_keys
+        d_w2, d_b2 = wg.run(gl2, act, hid, mlp, k_f2)
         d_pre = dgrad(gl2, w2, w2_t, S.EPI_GELU_BWD, pre=pre, seed=seed, site=site + 1, drop_p=p_mlp)
-        d_w1, d_b1 = wg.run(d_pre, h2, mlp, hid)
+        d_w1, d_b1 = wg.run(d_pre, h2, mlp, hid, k_f1)
         d_h2 = dgrad(d_pre, w1, w1_t)
         # LN2 backward + the skip connection's gradient, and d(out-projection output) = that sum through the proj dropout
         g2, d_ln2_w, d_ln2_b, gl1 = S.layer_norm_bwd_fused(d_h2, x2, mean2, rstd2, ln2_w, residual_grad=g3, cast_seed=seed,
                                                            cast_site=site, cast_p=p_proj)
         # ---- attention
-        d_wo, d_bo = wg.run(gl1, att.view(m, hid), hid, hid)
+        d_wo, d_bo = wg.run(gl1, att.view(m, hid), hid, hid, k_o)
         d_att = dgrad(gl1, wo, wo_t)
         d_qkv = S.attention_bwd(d_att.view(b, n, hid), qkv.view(b, n, 3 * hid), att, lse, heads).view(m, 3 * hid)
-        d_wqkv, d_bqkv = wg.run(d_qkv, h1, 3 * hid, hid)
+        d_wqkv, d_bqkv = wg.run(d_qkv, h1, 3 * hid, hid, k_qkv)
         d_h1 = dgrad(d_qkv, wqkv, wqkv_t)
         g1, d_ln1_w, d_ln1_b, _ = S.layer_norm_bwd_fused(d_h1, x2d, mean1, rstd1, ln1_w, residual_grad=g2)
         wg.join()

@@ -475,13 +475,14 @@ def conv3x3_wgrad_supported(batch, cin, cout, h, w, min_work=0.0):
     return bool(lib().sis_conv3x3_wgrad_eligible(batch, cin, cout, h, w, WORKSPACE_BYTES))
 
 
-def conv3x3_wgrad(x, grad_output):
-    """dL/dw [Cout,Cin,3,3] of a stride-1, padding-1 3x3 convolution from its input x [B,Cin,H,W] and dL/dy."""
+def conv3x3_wgrad(x, grad_output, for_param=None):
+    """dL/dw [Cout,Cin,3,3] of a stride-1, padding-1 3x3 convolution from its input x [B,Cin,H,W] and dL/dy.  ``for_param``: storage
+    address of the parameter the result is the gradient of (``grad_out``)."""
     x = _f32(x, "input")
     gy = _f32(grad_output, "grad_output")
     batch, cin, h, w = x.shape
     cout = gy.shape[1]
-    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    dw = grad_out(for_param, (cout, cin, 3, 3), torch.float32, x.device)
     ws = _workspace(x.device)
     with torch.cuda.device(x.device):
         _check(_launch(None, 2.0 * batch * cout * cin * 9 * h * w, 4.0 * (x.numel() + gy.numel() + dw.numel()),
@@ -498,6 +499,70 @@ def modconv_demod(s, wsq, scale, demodulate):
         _check(lib().sis_modconv_demod(_ptr(out), _ptr(s), _ptr(wsq), s.shape[0], cin, cout, float(scale),
                                        int(bool(demodulate)), _stream()), "sis_modconv_demod")
     return out
+
+
+# ---- gradient arena: where a parameter's gradient is WRITTEN.  The data-parallel wrap (training/grad_exchange.py) keeps every
+# gradient in flat fp32 buckets that the collectives and the fused SGD read in place.  autograd assigns a gradient that arrives
+# for a parameter without one (no copy), so a weight-gradient kernel that writes its result straight into the parameter's
+# bucket slice -- and returns a fresh view of it -- puts the gradient where the exchange wants it with no gather copy at all
+# (the copy was 139 / 424 MB per EMANet / TransUNet iteration).  ``grad_arena_register`` maps a
+# parameter's storage address to its slice; ``grad_out(key, ...)`` is what the weight-gradient bindings allocate through.
+_GRAD_ARENA = {}   # parameter data_ptr -> (weakref to the parameter, flat fp32 buffer, element offset, numel, owner id)
+
+
+def grad_arena_register(owner, params, flats, offsets):
+    """``params[i]``'s gradient lives at ``flats[i][offsets[i] : offsets[i] + params[i].numel()]`` (fp32, contiguous)."""
+    import weakref
+    for prm, flat, off in zip(params, flats, offsets):
+        _GRAD_ARENA[prm.data_ptr()] = (weakref.ref(prm), flat, int(off), prm.numel(), id(owner))
+
+
+def grad_arena_release(owner):
+    for key in [k for k, v in _GRAD_ARENA.items() if v[4] == id(owner)]:
+        del _GRAD_ARENA[key]
+
+
+def grad_arena_slot(key):
+    """(flat buffer, element offset, numel) registered for the parameter whose storage starts at ``key``, provided that
+    parameter is alive and holds NO gradient yet (a second backward before the optimizer step must accumulate: its kernels get
+    fresh tensors and autograd adds them); None otherwise."""
+    ent = _GRAD_ARENA.get(key) if key is not None else None
+    if ent is None:
+        return None
+    prm = ent[0]()
+    if prm is None or prm.grad is not None or prm.data_ptr() != key:
+        return None
+    return ent[1], ent[2], ent[3]
+
+
+def grad_out(key, shape, dtype, device):
+    """Result tensor of a weight-gradient kernel for the parameter at storage address ``key`` (None / unknown: a fresh tensor):
+    a NEW view of the parameter's arena slice when one is registered, so that autograd takes it as ``.grad`` as it is."""
+    slot = grad_arena_slot(key)
+    if slot is not None:
+        flat, off, numel = slot
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if n == numel and dtype == flat.dtype and device == flat.device and (flat.data_ptr() + flat.element_size() * off) % 16 == 0:
+            return flat[off:off + numel].view(shape)
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
+def grad_out_fused(keys, rows, cols, device):
+    """One [sum(rows), cols] fp32 result covering SEVERAL parameters (the ViT encoder's query | key | value product): the
+    arena view when their slices lie back to back in that order, else a fresh tensor."""
+    slots = [grad_arena_slot(k) for k in keys]
+    if all(s is not None for s in slots):
+        flat, off, _ = slots[0]
+        at = off
+        ok = flat.dtype == torch.float32 and flat.device == device and (flat.data_ptr() + 4 * off) % 16 == 0
+        for (f, o, n), r in zip(slots, rows):
+            ok = ok and f is flat and o == at and n == r * cols
+            at += n
+        if ok:
+            return flat[off:at].view(sum(rows), cols)
+    return torch.empty((sum(rows), cols), dtype=torch.float32, device=device)
 
 
 WORKSPACE_BYTES = int(os.environ.get("SIS_WORKSPACE_MB", "128")) << 20  # split-K slabs (per device)
@@ -699,9 +764,9 @@ def half_dilation_taps(weight):
     return taps
 
 
-def half_dilation_taps_bwd(grad_taps, cout, cin):
+def half_dilation_taps_bwd(grad_taps, cout, cin, for_param=None):
     g = _f32(grad_taps, "grad_taps")
-    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=g.device)
+    dw = grad_out(for_param, (cout, cin, 3, 3), torch.float32, g.device)
     with torch.cuda.device(g.device):
         _check(lib().sis_half_dilation_taps_bwd(_ptr(dw), _ptr(g), cout, cin, _stream()), "sis_half_dilation_taps_bwd")
     return dw
@@ -878,14 +943,14 @@ def conv_bf16_wgrad_supported(batch, cin, cout, h, w):
     return bool(lib().sis_conv_bf16_wgrad_supported(batch, cin, cout, h, w, WORKSPACE_BYTES))
 
 
-def conv_bf16_wgrad(x, grad_output, out_dtype=torch.float32):
+def conv_bf16_wgrad(x, grad_output, out_dtype=torch.float32, for_param=None):
     """dL/dw [Cout,Cin,3,3] (float32 or bfloat16) of a stride-1, padding-1 3x3 convolution from its bf16 input and dL/dy."""
     require_device(x, "input")
     if x.dtype != torch.bfloat16 or grad_output.dtype != torch.bfloat16 or not x.is_contiguous() or not grad_output.is_contiguous():
         raise RuntimeError("conv_bf16_wgrad: input and grad_output must be contiguous bfloat16 tensors")
     b, cin, h, w = x.shape
     cout = grad_output.shape[1]
-    dw = torch.empty((cout, cin, 3, 3), dtype=out_dtype, device=x.device)
+    dw = grad_out(for_param, (cout, cin, 3, 3), out_dtype, x.device)
     ws = _workspace(x.device)
     with torch.cuda.device(x.device):
         _check(_launch(None, 2.0 * b * cout * cin * 9 * h * w, 2.0 * (x.numel() + grad_output.numel()) + 4.0 * dw.numel(),
@@ -943,7 +1008,7 @@ class WeightStdPackBank:
         n = len(self.weights)
         if any(g is not None and (g.dtype != torch.bfloat16 or not g.is_contiguous()) for g in grads):
             return [None if g is None else weight_std_bwd(g, w, i, self.eps) for g, w, i in zip(grads, self.weights, self.invstd)]
-        out = [None if g is None else torch.empty(w.shape, dtype=torch.float32, device=w.device) for g, w in zip(grads, self.weights)]
+        out = [None if g is None else grad_out(w.data_ptr(), tuple(w.shape), torch.float32, w.device) for g, w in zip(grads, self.weights)]
         g_ptrs = (ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in grads])
         o_ptrs = (ctypes.c_void_p * n)(*[None if o is None else o.data_ptr() for o in out])
         couts = (ctypes.c_int * n)(*[w.shape[0] for w in self.weights])
@@ -1015,7 +1080,7 @@ def conv1x1_bf16_wgrad_supported(batch, cin, cout, pixels):
     return bool(lib().sis_conv1x1_bf16_wgrad_supported(batch, cin, cout, pixels, WORKSPACE_BYTES))
 
 
-def conv1x1_bf16_wgrad(x, grad_output, out_dtype=torch.float32):
+def conv1x1_bf16_wgrad(x, grad_output, out_dtype=torch.float32, for_param=None):
     """dL/dw [Cout,Cin,1,1] (float32 or bfloat16) of a stride-1 1x1 convolution from its bf16 NCHW input and dL/dy."""
     require_device(x, "input")
     if x.dtype != torch.bfloat16 or grad_output.dtype != torch.bfloat16 or not x.is_contiguous() or not grad_output.is_contiguous():
@@ -1025,7 +1090,7 @@ def conv1x1_bf16_wgrad(x, grad_output, out_dtype=torch.float32):
     pixels = x[0, 0].numel()
     if grad_output.shape[0] != b or grad_output[0, 0].numel() != pixels:
         raise RuntimeError("conv1x1_bf16_wgrad: input and grad_output disagree on batch / plane size")
-    dw = torch.empty((cout, cin, 1, 1), dtype=out_dtype, device=x.device)
+    dw = grad_out(for_param, (cout, cin, 1, 1), out_dtype, x.device)
     ws = _workspace(x.device)
     with torch.cuda.device(x.device):
         _check(_launch(None, 2.0 * b * cout * cin * pixels, 2.0 * (x.numel() + grad_output.numel()) + 4.0 * dw.numel(),
@@ -1070,7 +1135,7 @@ def _rows2d(t, name):
     return t
 
 
-def gemm_bf16(a, b, layout, epilogue=EPI_NONE, bias=None, resid=None, pre=None, seed=None, site=0, drop_p=0.0, splits=1, tile=0):
+def gemm_bf16(a, b, layout, epilogue=EPI_NONE, bias=None, resid=None, pre=None, seed=None, site=0, drop_p=0.0, splits=1, tile=0, out=None):
     """C = epilogue(op(a) op(b)) on the bf16 matrix cores (csrc/gemm_bf16.hip), fp32 accumulation.
       GEMM_NT  a [m,k], b [n,k]   (forward of a Linear layer: x, weight)
       GEMM_NN  a [m,k], b [k,n]   (data gradient: grad, weight)
@@ -1088,7 +1153,12 @@ def gemm_bf16(a, b, layout, epilogue=EPI_NONE, bias=None, resid=None, pre=None, 
     if k != k2:
         raise RuntimeError(f"gemm_bf16: contraction lengths differ ({k} vs {k2})")
     f32_out = epilogue in (EPI_BIAS_DROP_RESID, EPI_F32)
-    c = torch.empty((m, n), dtype=torch.float32 if f32_out else torch.bfloat16, device=a.device)
+    if out is not None:   # (a weight gradient written into its parameter's arena slice: ``grad_out``)
+        if tuple(out.shape) != (m, n) or out.dtype != (torch.float32 if f32_out else torch.bfloat16) or not out.is_contiguous():
+            raise RuntimeError("gemm_bf16: out must be a contiguous [m, n] tensor of the result's dtype")
+        c = out
+    else:
+        c = torch.empty((m, n), dtype=torch.float32 if f32_out else torch.bfloat16, device=a.device)
     c2 = torch.empty((m, n), dtype=torch.bfloat16, device=a.device) if epilogue == EPI_BIAS_GELU_DROP else None
     b0, b1, b2, seg = bias, None, None, 0
     if isinstance(bias, (tuple, list)):   # query | key | value: three parameters, one fused projection
@@ -1135,7 +1205,7 @@ def _stream_workspace(device):
     return ws
 
 
-def gemm_bf16_wgrad_bias(grad, x, splits, tile=0):
+def gemm_bf16_wgrad_bias(grad, x, splits, tile=0, dw=None):
     """Weight and bias gradient of a Linear layer from dL/dy ``grad`` [tokens, out] and its input ``x`` [tokens, in] (bf16):
     -> (dW [out, in] float32, db [out] float32) in the two launches of the split-K weight-gradient GEMM -- the column sums of
     ``grad`` are computed by extra workgroups of those launches (``sis_gemm_bf16_wgrad_bias``)."""
@@ -1144,7 +1214,10 @@ def gemm_bf16_wgrad_bias(grad, x, splits, tile=0):
     (k, m), (k2, n) = grad.shape, x.shape
     if k != k2 or splits < 2 or m % 4:
         raise RuntimeError("gemm_bf16_wgrad_bias: row counts differ, fewer than 2 splits, or an output width that is not a multiple of 4")
-    dw = torch.empty((m, n), dtype=torch.float32, device=grad.device)
+    if dw is None:
+        dw = torch.empty((m, n), dtype=torch.float32, device=grad.device)
+    elif tuple(dw.shape) != (m, n) or dw.dtype != torch.float32 or not dw.is_contiguous():
+        raise RuntimeError("gemm_bf16_wgrad_bias: dw must be a contiguous float32 [out, in] tensor")
     db = torch.empty(m, dtype=torch.float32, device=grad.device)
     ws = _stream_workspace(grad.device)
     with torch.cuda.device(grad.device):
@@ -1386,6 +1459,26 @@ def _group_counters(device, n):
     return buf
 
 
+def prepare_capture(device):
+    """Called on the stream a hipGraph capture is about to run on, BEFORE the capture opens: creates (and zeroes, as ordinary
+    eager stream work) the per-stream state that captured launches will hold pointers to -- the completion counters and the
+    split-K scratch -- so that neither lives in the graph's private pool with its zero-fill as a captured node only (ADVICE r4:
+    a failed capture would leave a cached, never-zeroed counter buffer behind for the next capture on that stream).
+    Returns a snapshot for ``rollback_capture``."""
+    _group_counters(device, 1)
+    _stream_workspace(device)
+    return (set(_GROUP_COUNTERS), set(_workspaces))
+
+
+def rollback_capture(snapshot):
+    """After a FAILED capture: forget per-stream buffers that were first created while the capture was open."""
+    counters, workspaces = snapshot
+    for key in [k for k in _GROUP_COUNTERS if k not in counters]:
+        del _GROUP_COUNTERS[key]
+    for key in [k for k in _workspaces if k not in workspaces]:
+        del _workspaces[key]
+
+
 def group_counters_are_zero():
     """Debug check (tests): every completion-counter buffer is back at zero, i.e. no launch left a hand-over half done."""
     return all(int(buf.abs().max().item()) == 0 for buf in _GROUP_COUNTERS.values())
@@ -1569,13 +1662,13 @@ def conv1x1_wgrad_f32_supported(grad_output, input):
                                                          input.shape[2] * input.shape[3]))
 
 
-def conv1x1_wgrad_f32(grad_output, input):
+def conv1x1_wgrad_f32(grad_output, input, for_param=None):
     """dW [Cout, Cin, 1, 1] of a 1x1 stride-1 convolution from dL/dy [B,Cout,H,W] and x [B,Cin,H,W] (fp32, NCHW)."""
     require_device(input, "input")
     b, cin, h, w = input.shape
     cout = grad_output.shape[1]
     L = lib()
-    dw = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=input.device)
+    dw = grad_out(for_param, (cout, cin, 1, 1), torch.float32, input.device)
     ws_bytes = int(L.sis_conv1x1_wgrad_f32_workspace(b, cin, cout, h * w))
     ws = torch.empty(max(ws_bytes // 4, 4), dtype=torch.float32, device=input.device)
     with torch.cuda.device(input.device):
@@ -1687,7 +1780,8 @@ def bn_fused_fwd(x, residual, gamma, beta, running_mean, running_var, eps, momen
     invstd = torch.empty(c, dtype=torch.float32, device=x.device)
     mask = torch.empty(lib().sis_bn_mask_words(b, c, h * w), dtype=torch.int64, device=x.device) if (want_mask and relu) else None
     with torch.cuda.device(x.device):
-        _check(_launch("bn_fused_fwd_kernel", 0.0, 4.0 * (2 + (residual is not None)) * x.numel(), lambda: lib().sis_bn_fused_fwd(
+        # (kernel name reported by the library: bn_fused_fwd_kernel, or bn_wide_fwd_kernel for channels of 16 385 ... 65 536 values)
+        _check(_launch(None, 0.0, 4.0 * (2 + (residual is not None)) * x.numel(), lambda: lib().sis_bn_fused_fwd(
             _ptr(y), _ptr(mean), _ptr(invstd), _ptr(running_mean), _ptr(running_var), _ptr(x), _ptr(residual),
             _ptr(gamma), _ptr(beta), b, c, h * w, float(eps), float(momentum), int(bool(relu)), _ptr(mask),
             _stream())), "sis_bn_fused_fwd")
@@ -1715,7 +1809,8 @@ def bn_act_bwd(dy, y, x, mean, invstd, gamma, relu, want_residual_grad, mask=Non
     dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
     ws = torch.empty(lib().sis_bn_workspace_floats(b, c, h * w), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        # (kernel name reported by the library: bn_fused_bwd_kernel where a channel fits one workgroup, else the three-launch form)
+        # (kernel name reported by the library: bn_wide_bwd_kernel / bn_fused_bwd_kernel where a channel fits one workgroup, else the
+        # three-launch form)
         _check(_launch(None, 0.0, 4.0 * (3 + want_residual_grad) * x.numel(), lambda: lib().sis_bn_act_bwd(
             _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(dy), _ptr(y), _ptr(x), _ptr(mean),
             _ptr(invstd), _ptr(gamma), _ptr(ws), b, c, h * w, int(bool(relu)), _ptr(mask), _stream())),

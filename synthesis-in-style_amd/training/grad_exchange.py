@@ -14,13 +14,17 @@ because three things of the MI355X step do not fit it:
   every later backward issues the same launches in the same order, and the collectives are ordinary stream work that the
   capture records like any kernel.
 * **gradients must sit at fixed addresses**: ``FusedSGD`` (training/fused_sgd.py) reads them through a device pointer
-  table.  Buckets are persistent flat fp32 buffers; when the last gradient of a bucket has been accumulated ONE fused copy
-  (``torch._foreach_copy_``) gathers the bucket and ``.grad`` is re-pointed at the bucket views, so the table is uploaded
-  once.
+  table.  Buckets are persistent flat fp32 buffers, registered with ``sis_hip`` as the gradient arena: the weight-gradient
+  kernels (convolutions, Linear layers, the weight-standardisation bank: nearly all bytes) write their result INTO the
+  parameter's slice and hand autograd a view of it, so those gradients are born in place; when the last gradient of a
+  bucket has arrived ONE fused copy (``torch._foreach_copy_``) moves the small rest (norm parameters, biases) and
+  ``.grad`` is re-pointed at the bucket views, so the table is uploaded once.
 * **xGMI is point-to-point** (7 links per GPU): by default a bucket is reduced as ``reduce_scatter`` (every
   rank owns 1/N of the bucket) followed by ``all_gather``, each on the bucket's own slice of the flat buffer (in place),
   issued straight into librccl.so (``ncclReduceScatter`` / ``ncclAllGather`` on the process group's communicator) on the
-  exchange's own HIP stream;
+  exchange's own HIP stream at world size 1 (the only configuration a one-GPU box can run and verify) and, until a
+  multi-rank run has exercised it, through torch.distributed at world size > 1 unless SIS_DP_DIRECT_RCCL=1 (then behind a
+  start-up self-check against torch's all_reduce);
   ``collective: allreduce`` issues one ``all_reduce`` instead.  Averaging is the collective's own ``AVG`` on RCCL; gloo
   (CPU rehearsals) sums and scales.
 
@@ -46,8 +50,29 @@ _DEBUG = os.environ.get("SIS_DP_DEBUG", "0") == "1"
 # the one configuration a 1-GPU box can run (RCCL refuses two ranks on one device) and tests/test_distributed_gpu.py +
 # bench.py's data_parallel_rehearsal verify; SIS_DP_GRAPH=1 extends it to any world size.  Nothing is lost by staying eager
 # there: the wrapped iteration is as fast eager as captured (25.0 / 25.2 ms, 28.4 / 28.3 ms).
-_DIRECT_RCCL = os.environ.get("SIS_DP_DIRECT_RCCL", "1")
+# SIS_DP_DIRECT_RCCL: "auto" (default) = direct calls at world size 1 -- the configuration a one-GPU box runs, tests and
+# captures -- and torch.distributed's collectives at world size > 1, where the direct path (shard offsets, in-place
+# reduce-scatter / all-gather aliasing, RCCL enum values) has never executed on hardware; "1" = direct at any
+# world size, after a start-up self-check of one bucket-shaped exchange against torch's all_reduce (a failed check falls back
+# and says so); "0" = never.
+_DIRECT_RCCL = os.environ.get("SIS_DP_DIRECT_RCCL", "auto")
 _DP_GRAPH = os.environ.get("SIS_DP_GRAPH", "auto")
+
+
+def shard_plan(numel: int, world: int):
+    """Padded length and per-rank shard of a bucket holding ``numel`` gradient elements: the flat buffer is padded to a multiple
+    of 4 * world so that every rank's shard has the same length AND starts 16-byte aligned -> (padded_numel, per_rank)."""
+    if numel <= 0 or world <= 0:
+        raise ValueError("shard_plan needs a positive element count and world size")
+    quantum = 4 * world
+    padded = (numel + quantum - 1) // quantum * quantum
+    return padded, padded // world
+
+
+def shard_span(rank: int, per: int):
+    """Element range [begin, end) of ``rank``'s shard inside a bucket: the in-place convention of ncclReduceScatter
+    (recvbuff = sendbuff + rank * recvcount) and ncclAllGather (sendbuff = recvbuff + rank * sendcount)."""
+    return rank * per, (rank + 1) * per
 
 
 class _Rccl:
@@ -58,20 +83,40 @@ class _Rccl:
     recorded while capturing -- hipErrorCapturedEvent -- and took the process down.)"""
     FLOAT32, SUM, AVG = 7, 0, 4   # ncclDataType_t / ncclRedOp_t values (nccl.h)
     _lib = None
+    path = None
 
     @classmethod
     def lib(cls):
+        """The librccl.so instance ALREADY MAPPED into this process (the one torch's ProcessGroupNCCL created the communicator
+        with), found through /proc/self/maps and opened with RTLD_NOLOAD: handing torch's ncclComm_t to a second copy of the
+        library (a torch built against /opt/rocm's RCCL, say) would be undefined behaviour, and a missing file must not
+        surface as an OSError inside the first backward.  None when no mapped RCCL is found."""
         if cls._lib is None:
             import ctypes
-            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-            lib = ctypes.CDLL(path)   # already mapped by torch: the same instance
-            vp, sz, i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
-            lib.ncclReduceScatter.argtypes, lib.ncclReduceScatter.restype = [vp, vp, sz, i, i, vp, vp], i
-            lib.ncclAllGather.argtypes, lib.ncclAllGather.restype = [vp, vp, sz, i, vp, vp], i
-            lib.ncclAllReduce.argtypes, lib.ncclAllReduce.restype = [vp, vp, sz, i, i, vp, vp], i
-            lib.ncclGetErrorString.argtypes, lib.ncclGetErrorString.restype = [i], ctypes.c_char_p
-            cls._lib = lib
-        return cls._lib
+            path = None
+            try:
+                with open("/proc/self/maps") as maps:
+                    for line in maps:
+                        name = line.rsplit(" ", 1)[-1].strip()
+                        if "/" in name and os.path.basename(name).startswith(("librccl.so", "libnccl.so")):
+                            path = name
+                            break
+            except OSError:
+                path = None
+            if path is None:
+                cls._lib = False
+                return None
+            try:
+                lib = ctypes.CDLL(path, mode=getattr(os, "RTLD_NOLOAD", 4) | getattr(os, "RTLD_NOW", 2))
+                vp, sz, i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+                lib.ncclReduceScatter.argtypes, lib.ncclReduceScatter.restype = [vp, vp, sz, i, i, vp, vp], i
+                lib.ncclAllGather.argtypes, lib.ncclAllGather.restype = [vp, vp, sz, i, vp, vp], i
+                lib.ncclAllReduce.argtypes, lib.ncclAllReduce.restype = [vp, vp, sz, i, i, vp, vp], i
+                lib.ncclGetErrorString.argtypes, lib.ncclGetErrorString.restype = [i], ctypes.c_char_p
+                cls._lib, cls.path = lib, path
+            except (OSError, AttributeError):
+                cls._lib = False
+        return cls._lib or None
 
     @classmethod
     def check(cls, rc, what):
@@ -91,18 +136,19 @@ class _Rccl:
 
 
 class _Bucket:
-    __slots__ = ("params", "views", "flat", "numel", "pending", "index")
+    __slots__ = ("params", "views", "offsets", "flat", "numel", "per", "pending", "index")
 
     def __init__(self, index: int, params: List[torch.Tensor], world: int, device, dtype):
         self.index, self.params = index, params
-        numel = sum(p.numel() for p in params)
-        quantum = 4 * world                       # every rank's shard of the flat buffer starts 16-byte aligned
-        self.numel = (numel + quantum - 1) // quantum * quantum
-        self.flat = torch.zeros(self.numel, dtype=dtype, device=device)
-        self.views, at = [], 0
+        # every parameter's slice starts 16-byte aligned (4 fp32 elements): the weight-gradient kernels that write into the
+        # slices store 16 bytes per lane; the gaps stay zero on every rank and ride through the collectives as zeros
+        self.offsets, at = [], 0
         for p in params:
-            self.views.append(self.flat[at:at + p.numel()].view_as(p))
-            at += p.numel()
+            self.offsets.append(at)
+            at += (p.numel() + 3) // 4 * 4
+        self.numel, self.per = shard_plan(at, world)   # every rank's shard starts 16-byte aligned as well
+        self.flat = torch.zeros(self.numel, dtype=dtype, device=device)
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, params)]
         self.pending = len(params)
 
 
@@ -133,21 +179,35 @@ class BucketedDataParallel(nn.Module):
             pass
         self._pending = []   # work handles of collectives issued through torch.distributed during the current backward
         self._comm, self._comm_stream, self._joined = None, None, True
-        if self._on_gpu and self.backend == "nccl" and _DIRECT_RCCL != "0":
-            self._comm = _Rccl.communicator(process_group, self.device)
-            if self._comm is None:   # the communicator is created lazily by the first collective
-                probe = torch.zeros(1, device=self.device)
-                dist.all_reduce(probe, group=process_group)
-                torch.cuda.synchronize(self.device)
+        self.direct_rccl_note = None   # why the direct path is off when it was wanted (bench.py prints it)
+        want_direct = _DIRECT_RCCL == "1" or (_DIRECT_RCCL == "auto" and self.world == 1)
+        if self._on_gpu and self.backend == "nccl" and want_direct:
+            if _Rccl.lib() is None:
+                self.direct_rccl_note = "no librccl.so mapped into this process"
+            else:
                 self._comm = _Rccl.communicator(process_group, self.device)
-            if self._comm is not None:
-                self._comm_stream = torch.cuda.Stream(self.device)
+                if self._comm is None:   # the communicator is created lazily by the first collective
+                    probe = torch.zeros(1, device=self.device)
+                    dist.all_reduce(probe, group=process_group)
+                    torch.cuda.synchronize(self.device)
+                    self._comm = _Rccl.communicator(process_group, self.device)
+                if self._comm is None:
+                    self.direct_rccl_note = "this torch build does not expose ProcessGroupNCCL._comm_ptr"
+                else:
+                    self._comm_stream = torch.cuda.Stream(self.device)
+                    if self.world > 1 and not self._self_check():
+                        self.direct_rccl_note = "start-up self-check of the direct reduce-scatter + all-gather failed"
+                        self._comm, self._comm_stream = None, None
+            if self.direct_rccl_note and self.rank == 0:
+                import warnings
+                warnings.warn(f"BucketedDataParallel: collectives go through torch.distributed ({self.direct_rccl_note})")
         self.buckets: Optional[List[_Bucket]] = None
         self._bucket_of = {}
         self._order: List[torch.Tensor] = []      # discovery: parameters in the order their gradients became ready
         self._callback_queued = False
         self._flushed = 0
-        self.stats = {"backwards": 0, "collectives": 0, "discovery_backwards": 0}
+        # copied_elems / in_place_elems: gradient elements the gather had to copy / found already written into their bucket slice
+        self.stats = {"backwards": 0, "collectives": 0, "discovery_backwards": 0, "copied_elems": 0, "in_place_elems": 0}
         self._broadcast_parameters()
         for p in self._params:
             p.register_post_accumulate_grad_hook(self._on_grad)
@@ -179,6 +239,44 @@ class BucketedDataParallel(nn.Module):
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
+    def _rccl_exchange(self, flat: torch.Tensor, numel: int, per: int, stream):
+        """The direct form of one bucket's exchange on ``stream`` (a torch.cuda.Stream): in-place reduce-scatter into this rank's
+        shard followed by the all-gather of the shards, or one all-reduce; ``AVG`` on RCCL.  At world size 1 the mean of one
+        rank is that rank, and the reduction is issued as ``SUM``: RCCL's one-rank AVG is a pre-multiply kernel that reads and
+        rewrites the whole bucket (``oneRankReduce<FuncPreMulSum>``: 1.15 ms per TransUNet iteration at 0.74 TB/s,
+        profiles/r05_transunet_dp_step_breakdown.txt), its one-rank in-place SUM is nothing at all."""
+        import ctypes
+        R = _Rccl
+        lib = R.lib()
+        op = R.SUM if self.world == 1 else R.AVG
+        st = ctypes.c_void_p(stream.cuda_stream)
+        comm, base = ctypes.c_void_p(self._comm), flat.data_ptr()
+        with torch.cuda.device(self.device):
+            if self.collective == "rs_ag":
+                begin, _ = shard_span(self.rank, per)
+                mine = ctypes.c_void_p(base + 4 * begin)
+                R.check(lib.ncclReduceScatter(ctypes.c_void_p(base), mine, per, R.FLOAT32, op, comm, st), "ncclReduceScatter")
+                R.check(lib.ncclAllGather(mine, ctypes.c_void_p(base), per, R.FLOAT32, comm, st), "ncclAllGather")
+            else:
+                R.check(lib.ncclAllReduce(ctypes.c_void_p(base), ctypes.c_void_p(base), numel, R.FLOAT32, op, comm, st), "ncclAllReduce")
+
+    @torch.no_grad()
+    def _self_check(self) -> bool:
+        """World size > 1 with the direct path requested: one bucket-shaped exchange of rank-dependent values through the direct
+        calls must equal torch.distributed's all_reduce(AVG) of the same values on every rank -- shard offsets, in-place
+        aliasing and the enum values are then verified on THIS machine before any gradient depends on them."""
+        numel, per = shard_plan(4099, self.world)
+        gen = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
+        ref = torch.randn(numel, generator=gen).to(self.device)
+        got = ref.clone()
+        dist.all_reduce(ref, op=dist.ReduceOp.AVG, group=self.process_group)
+        self._comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._rccl_exchange(got, numel, per, self._comm_stream)
+        torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)
+        ok = torch.tensor([1.0 if torch.allclose(got, ref, rtol=1e-5, atol=1e-6) else 0.0], device=self.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.process_group)   # every rank takes the same branch
+        return bool(ok.item() == 1.0)
+
     # ---- backward ----------------------------------------------------------------------------------------------------
     def _on_grad(self, param):
         if not self._callback_queued:
@@ -198,7 +296,9 @@ class BucketedDataParallel(nn.Module):
 
     @torch.no_grad()
     def _gather(self, bucket: _Bucket):
-        """Gradients of the bucket -> its flat buffer (one fused copy for those autograd allocated afresh), ``.grad`` -> views."""
+        """Gradients of the bucket -> its flat buffer, ``.grad`` -> views.  Gradients the weight-gradient kernels wrote straight into
+        their slice (``sis_hip.grad_out``: the convolution / Linear weights, i.e. nearly all bytes) are already in place; one
+        fused copy moves the rest (norm parameters, biases, anything a library kernel produced)."""
         src, dst = [], []
         for p, view in zip(bucket.params, bucket.views):
             g = p.grad
@@ -207,6 +307,9 @@ class BucketedDataParallel(nn.Module):
             if g.data_ptr() != view.data_ptr():
                 src.append(g if g.dtype == view.dtype and g.is_contiguous() else g.to(view.dtype).contiguous())
                 dst.append(view)
+                self.stats["copied_elems"] += view.numel()
+            else:
+                self.stats["in_place_elems"] += view.numel()
         if src:
             torch._foreach_copy_(dst, src)
             for p, view in zip(bucket.params, bucket.views):
@@ -229,25 +332,14 @@ class BucketedDataParallel(nn.Module):
         if self.backend == "nccl" and self._comm is not None:
             # straight into RCCL on the exchange's own stream: the gathered bucket is complete on the compute stream (event),
             # backward keeps running there meanwhile; ``_finish`` joins the streams
-            import ctypes
-            R = _Rccl
-            current = torch.cuda.current_stream(self.device)
-            self._comm_stream.wait_stream(current)
-            stream = ctypes.c_void_p(self._comm_stream.cuda_stream)
-            comm, base, n = ctypes.c_void_p(self._comm), flat.data_ptr(), bucket.numel
-            with torch.cuda.device(self.device):
-                if self.collective == "rs_ag":
-                    per = n // world
-                    mine = ctypes.c_void_p(base + 4 * per * self.rank)
-                    R.check(R.lib().ncclReduceScatter(ctypes.c_void_p(base), mine, per, R.FLOAT32, R.AVG, comm, stream), "ncclReduceScatter")
-                    R.check(R.lib().ncclAllGather(mine, ctypes.c_void_p(base), per, R.FLOAT32, comm, stream), "ncclAllGather")
-                else:
-                    R.check(R.lib().ncclAllReduce(ctypes.c_void_p(base), ctypes.c_void_p(base), n, R.FLOAT32, R.AVG, comm, stream), "ncclAllReduce")
+            self._comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+            self._rccl_exchange(flat, bucket.numel, bucket.per, self._comm_stream)
             self._joined = False
         elif self.backend == "nccl":
             avg = dist.ReduceOp.AVG
             if self.collective == "rs_ag":
-                shard = flat[self.rank * (bucket.numel // world):(self.rank + 1) * (bucket.numel // world)]
+                begin, end = shard_span(self.rank, bucket.per)
+                shard = flat[begin:end]
                 self._pending.append(dist.reduce_scatter_tensor(shard, flat, op=avg, group=self.process_group, async_op=True))
                 self._pending.append(dist.all_gather_into_tensor(flat, shard, group=self.process_group, async_op=True))
             else:
@@ -273,6 +365,12 @@ class BucketedDataParallel(nn.Module):
                 self._flush(bucket)
         elif self._flushed != len(self.buckets):
             missing = [b.index for b in self.buckets if b.pending != 0]
+            for work in self._pending:       # leave no collective in flight behind the exception
+                work.wait()
+            self._pending = []
+            if not self._joined:
+                torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)
+                self._joined = True
             self._reset()
             raise RuntimeError(f"BucketedDataParallel: buckets {missing} did not receive all of their gradients in this backward "
                                "(a parameter used in the first iteration was unused now)")
@@ -301,25 +399,67 @@ class BucketedDataParallel(nn.Module):
         self._order = []
         if not order:
             raise RuntimeError("BucketedDataParallel: backward produced no parameter gradient")
-        groups, cur, size = [], [], 0
+        # Parameters whose gradients one kernel writes as ONE stacked tensor (modules announce them through
+        # ``grad_fusion_groups()``: the ViT encoder's query | key | value weights) are kept together, in the announced order, at
+        # the position of the first of them to become ready, and never split over two buckets.
+        fused = {}
+        for m in self.module.modules():
+            if hasattr(m, "grad_fusion_groups"):
+                for group in m.grad_fusion_groups():
+                    if all(id(p) in seen for p in group):
+                        for p in group:
+                            fused[id(p)] = group
+        units, placed = [], set()
         for p in order:
-            nbytes = p.numel() * 4
+            if id(p) in placed:
+                continue
+            unit = list(fused.get(id(p), (p,)))
+            placed.update(id(q) for q in unit)
+            units.append(unit)
+        groups, cur, size = [], [], 0
+        for unit in units:
+            nbytes = sum(p.numel() for p in unit) * 4
             if cur and size + nbytes > self.bucket_bytes:
                 groups.append(cur)
                 cur, size = [], 0
-            cur.append(p)
+            cur += unit
             size += nbytes
         groups.append(cur)
         self.buckets = [_Bucket(i, g, self.world, self.device, torch.float32) for i, g in enumerate(groups)]
         self._bucket_of = {id(p): b for b in self.buckets for p in b.params}
+        if self._on_gpu:
+            try:   # weight-gradient kernels write into the slices from now on (no gather copy for those parameters)
+                import sis_hip
+                for b in self.buckets:
+                    sis_hip.grad_arena_register(self, b.params, [b.flat] * len(b.params), b.offsets)
+            except ImportError:
+                pass
         if self.world > 1:
-            digest = torch.tensor([len(self.buckets), sum(b.numel for b in self.buckets), len(order)], dtype=torch.int64,
-                                  device=self.device if self.backend == "nccl" else "cpu")
+            # what must agree across ranks: bucket count and sizes, and WHICH parameter sits where (a rolling hash of the
+            # parameters' positions in module order and their element counts, bucket by bucket)
+            position = {id(p): i for i, p in enumerate(self.module.parameters())}
+            def folded(values):
+                h = 1469598103934665603
+                for v in values:
+                    h = ((h ^ int(v)) * 1099511628211) & 0x7FFFFFFFFFFFFFFF
+                return h
+            # a fixed-length record (ranks with different bucket counts must still be able to compare): counts, total padded
+            # length, a hash of the per-bucket lengths and a hash of (parameter position, element count) in bucket order
+            words = [len(self.buckets), len(order), sum(b.numel for b in self.buckets), folded(b.numel for b in self.buckets),
+                     folded(v for b in self.buckets for p in b.params for v in (position[id(p)], p.numel()))]
+            digest = torch.tensor(words, dtype=torch.int64, device=self.device if self.backend == "nccl" else "cpu")
             lo, hi = digest.clone(), digest.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.process_group)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.process_group)
             if not torch.equal(lo, hi):
                 raise RuntimeError("BucketedDataParallel: ranks disagree on the bucket plan (different graphs per rank)")
+
+    def __del__(self):
+        try:
+            import sis_hip
+            sis_hip.grad_arena_release(self)
+        except Exception:
+            pass
 
     # ---- introspection (tests, bench) --------------------------------------------------------------------------------
     def direct_rccl(self) -> bool:

@@ -32,6 +32,7 @@ class StepGraph:
         self.graph = None
         self.static_batch = None
         self.static_out = None
+        self._capture_stream = None
         self.seen = 0
 
     def run(self, batch: Dict[str, torch.Tensor], step_fn: Callable, optimizers: Iterable):
@@ -96,6 +97,20 @@ class StepGraph:
                 mode = "thread_local"
         except Exception:
             pass
-        with torch.cuda.graph(graph, capture_error_mode=mode):
-            self.static_out = step_fn(self.static_batch)
+        # Per-stream kernel state (completion counters, split-K scratch) is created and zeroed on the capture stream as EAGER
+        # work before the capture opens; buffers first created inside a capture that then fails are forgotten again.
+        import sis_hip
+        device = next(iter(self.static_batch.values())).device
+        if self._capture_stream is None:
+            self._capture_stream = torch.cuda.Stream(device)
+        self._capture_stream.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(self._capture_stream):
+            snapshot = sis_hip.prepare_capture(device)
+        self._capture_stream.synchronize()
+        try:
+            with torch.cuda.graph(graph, stream=self._capture_stream, capture_error_mode=mode):
+                self.static_out = step_fn(self.static_batch)
+        except Exception:
+            sis_hip.rollback_capture(snapshot)
+            raise
         self.graph = graph

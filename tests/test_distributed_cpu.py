@@ -333,3 +333,108 @@ def test_stylegan2_updater_world_size_2_gloo():
     assert all(out[r][0] for r in range(world)), "replicas diverged"
     assert out[0][1] == pytest.approx(out[1][1], rel=1e-6) and out[0][1] > 0, "mean path length is not the all-rank average"
     assert all(out[r][2] and out[r][3] for r in range(world))
+
+
+def test_shard_plan_matches_the_in_place_reduce_scatter_all_gather_convention():
+    """The shard arithmetic of the direct RCCL path (training/grad_exchange.py::shard_plan / shard_span) for world sizes 1..8,
+    checked against a host model of the two collectives as nccl.h defines their in-place forms: ncclReduceScatter(send, recv =
+    send + rank * count) leaves rank r with the reduction of everybody's elements [r * count, (r + 1) * count) at that offset;
+    ncclAllGather(send = recv + rank * count, recv) then gives every rank every shard.  A one-GPU box can never run this path
+    with more than one rank, so what CAN be pinned is: every rank's shard has the same length, starts 16-byte aligned, the
+    shards tile the padded bucket exactly, and the composition is the mean of the ranks' buckets (padding included)."""
+    import numpy as np
+    from training.grad_exchange import shard_plan, shard_span
+    rng = np.random.RandomState(5)
+    for world in range(1, 9):
+        for numel in (1, 3, 4 * world, 4 * world + 1, 4099, 6553601):
+            padded, per = shard_plan(numel, world)
+            assert padded >= numel and padded - numel < 4 * world and padded == per * world and per % 4 == 0
+            spans = [shard_span(r, per) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == padded
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])) and all((4 * b) % 16 == 0 for b, _ in spans)
+            if numel > 5000:
+                continue
+            send = [rng.randn(padded).astype(np.float32) for _ in range(world)]     # each rank's bucket before the exchange
+            mean = np.mean(np.stack(send).astype(np.float64), axis=0)
+            buf = [s.copy() for s in send]
+            for r in range(world):                                                  # reduce-scatter, in place
+                b, e = shard_span(r, per)
+                buf[r][b:e] = np.mean(np.stack([s[b:e] for s in send]).astype(np.float64), axis=0).astype(np.float32)
+            shards = [buf[r][slice(*shard_span(r, per))].copy() for r in range(world)]
+            for r in range(world):                                                  # all-gather, in place
+                for q in range(world):
+                    buf[r][slice(*shard_span(q, per))] = shards[q]
+            for r in range(world):
+                np.testing.assert_allclose(buf[r], mean, rtol=1e-6, atol=1e-7)
+    with pytest.raises(ValueError):
+        shard_plan(0, 2)
+
+
+def test_direct_rccl_switch_positions():
+    """Which configurations take the direct librccl.so path: by default world size 1 only (until a multi-rank run
+    has exercised it, world > 1 goes through torch.distributed); SIS_DP_DIRECT_RCCL=1 opts every world size in, 0 none; and a
+    capture of the exchange additionally needs SIS_DP_GRAPH (auto: world size 1) -- work objects (direct off) never are."""
+    import training.grad_exchange as GX
+
+    class Fake:
+        _on_gpu, backend = True, "nccl"
+        capturable = GX.BucketedDataParallel.capturable
+
+    fake = Fake()
+    saved = GX._DP_GRAPH
+    try:
+        for graph, world, comm, want in (("auto", 1, 1, True), ("auto", 2, 1, False), ("1", 2, 1, True), ("0", 1, 1, False),
+                                         ("1", 1, None, False), ("auto", 1, None, False)):
+            GX._DP_GRAPH, fake.world, fake._comm = graph, world, comm
+            assert fake.capturable() is want, (graph, world, comm)
+    finally:
+        GX._DP_GRAPH = saved
+    src = open(GX.__file__).read()
+    assert 'os.environ.get("SIS_DP_DIRECT_RCCL", "auto")' in src and '_DIRECT_RCCL == "auto" and self.world == 1' in src
+
+
+def test_gradient_arena_hands_out_bucket_slices():
+    """sis_hip's gradient arena (host logic, CPU tensors): after the data-parallel wrap has registered the bucket slices, a
+    weight-gradient binding asking ``grad_out(param.data_ptr(), ...)`` gets a NEW view of the parameter's slice (autograd then
+    takes it as ``.grad`` without a copy); it gets a fresh tensor when the parameter already holds a gradient (a second
+    backward must accumulate), when the shape / dtype does not match, or for an unknown address; the fused query | key | value
+    result is served only when the three slices lie back to back in that order; releasing the owner empties the registry."""
+    import sis_hip
+    owner = object()
+    flat = torch.zeros(64)
+    a, b, c = (nn.Parameter(torch.randn(2, 4)) for _ in range(3))
+    sis_hip.grad_arena_register(owner, [a, b, c], [flat, flat, flat], [8, 16, 24])
+    try:
+        g = sis_hip.grad_out(a.data_ptr(), (2, 4), torch.float32, flat.device)
+        assert g.data_ptr() == flat.data_ptr() + 4 * 8 and g.shape == (2, 4)
+        assert sis_hip.grad_out(a.data_ptr(), (2, 4), torch.float32, flat.device) is not g          # a new view object per call
+        g.fill_(3.0)
+        assert float(flat[8:16].sum()) == 24.0 and float(flat.sum()) == 24.0
+        for key, shape, dtype in ((a.data_ptr(), (4, 4), torch.float32), (a.data_ptr(), (2, 4), torch.float64),
+                                  (12345, (2, 4), torch.float32), (None, (2, 4), torch.float32)):
+            t = sis_hip.grad_out(key, shape, dtype, flat.device)
+            assert not (flat.data_ptr() <= t.data_ptr() < flat.data_ptr() + 4 * 64)
+        a.grad = torch.ones(2, 4)                                                                    # holds a gradient: accumulate
+        t = sis_hip.grad_out(a.data_ptr(), (2, 4), torch.float32, flat.device)
+        assert not (flat.data_ptr() <= t.data_ptr() < flat.data_ptr() + 4 * 64)
+        a.grad = None
+        fused = sis_hip.grad_out_fused((a.data_ptr(), b.data_ptr(), c.data_ptr()), [2, 2, 2], 4, flat.device)
+        assert fused.data_ptr() == flat.data_ptr() + 4 * 8 and fused.shape == (6, 4)
+        swapped = sis_hip.grad_out_fused((b.data_ptr(), a.data_ptr(), c.data_ptr()), [2, 2, 2], 4, flat.device)
+        assert not (flat.data_ptr() <= swapped.data_ptr() < flat.data_ptr() + 4 * 64)
+        # autograd's side of the contract: a gradient returned as such a view becomes .grad as it is (no clone)
+        class Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w):
+                ctx.key = w.data_ptr()
+                return x * w.sum()
+            @staticmethod
+            def backward(ctx, gy):
+                dw = sis_hip.grad_out(ctx.key, (2, 4), torch.float32, gy.device)
+                dw.fill_(float(gy.sum()))
+                return None, dw
+        Fn.apply(torch.ones(3), b).sum().backward()
+        assert b.grad.data_ptr() == flat.data_ptr() + 4 * 16 and float(flat[16:24].sum()) == 24.0
+    finally:
+        sis_hip.grad_arena_release(owner)
+    assert sis_hip.grad_arena_slot(a.data_ptr()) is None

@@ -139,12 +139,15 @@ def _rccl_worker(rank, world, port, out, golden_dir):
         _, net_ddp, upd_ddp, losses_ddp, _ = run(True, "ddp")
         # SIS_DP_DIRECT_RCCL=0: the same buckets, collectives through torch.distributed's reduce_scatter_tensor /
         # all_gather_into_tensor work objects, iterations eager
+        # -- with SIS_DP_GRAPH=1 on top: work objects are never captured, whatever the graph switch says
         import training.grad_exchange as GX
-        GX._DIRECT_RCCL = "0"
+        saved = GX._DIRECT_RCCL, GX._DP_GRAPH
+        GX._DIRECT_RCCL, GX._DP_GRAPH = "0", "1"
         try:
             _, net_torch, upd_torch, losses_torch, _ = run(True)
+            torch_capturable = net_torch.capturable()
         finally:
-            GX._DIRECT_RCCL = "1"
+            GX._DIRECT_RCCL, GX._DP_GRAPH = saved
         out[rank] = dict(
             graph=upd._step_graph.graph is not None, capture_error=upd._step_graph.capture_error, direct=net.direct_rccl(),
             n_buckets=len(spans), collectives=net.stats["collectives"], discovery=net.stats["discovery_backwards"],
@@ -157,6 +160,8 @@ def _rccl_worker(rank, world, port, out, golden_dir):
             ddp_is_torch=isinstance(net_ddp, torch.nn.parallel.DistributedDataParallel), ddp_graph_off=not upd_ddp._step_graph.enabled,
             losses_torch=losses_torch, torch_direct=net_torch.direct_rccl(), torch_graph_off=not upd_torch._step_graph.enabled,
             torch_collectives=net_torch.stats["collectives"], torch_buckets=len(net_torch.bucket_spans()),
+            torch_capturable=torch_capturable, rccl_path=GX._Rccl.path,
+            copied_elems=net.stats["copied_elems"], in_place_elems=net.stats["in_place_elems"],
             delta_fc2=float(np.linalg.norm((sd["fc2.weight"] - sd_plain["fc2.weight"]).double().numpy())
                             / np.linalg.norm((sd_plain["fc2.weight"] - init["fc2.weight"]).double().numpy())),
             finite=all(bool(torch.isfinite(v).all()) for v in sd.values() if v.is_floating_point()))
@@ -194,4 +199,10 @@ def test_ema_net_rccl_world_size_1_bucketed_exchange_inside_the_step_graph(devic
     assert r["ddp_is_torch"] and r["ddp_graph_off"]
     # torch.distributed work objects: never captured, every one of the 6 iterations passes through the hooks
     assert not r["torch_direct"] and r["torch_graph_off"] and r["torch_collectives"] == 6 * r["torch_buckets"], r
+    assert not r["torch_capturable"]   # SIS_DP_DIRECT_RCCL=0 + SIS_DP_GRAPH=1 stays eager
+    assert r["rccl_path"] and "rccl" in os.path.basename(r["rccl_path"])   # the library instance torch itself mapped
+    # the weight-gradient kernels write into the buckets: what the gather still copies (after the discovery backward, whose
+    # gradients predate the plan) is norm parameters and biases -- a few per cent of EMANet-50's 35 M gradient elements
+    per_backward = (r["copied_elems"] + r["in_place_elems"]) / r["backwards"]
+    assert r["in_place_elems"] >= 0.6 * (r["backwards"] - 1) * per_backward, r
     assert r["delta_fc2"] < 5e-2, r["delta_fc2"]   # three-step parameter change of the head, wrapped vs plain

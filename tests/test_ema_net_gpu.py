@@ -224,7 +224,9 @@ def test_ema_net_step_at_baseline_batch_vs_oracle(device):
         launched[name] = launched.get(name, 0) + 1
     calls = sis_hip.library_calls(reset=True)
     # the single-pass batch norm takes every 32 x 32 layer (42 of the 55 norms) in both directions
-    assert launched.get("bn_fused_fwd_kernel", 0) >= 40 and launched.get("bn_fused_bwd_kernel", 0) >= 40, launched
+    # (backward: the 512-thread instance of bn_wide_bwd_kernel -- the name the library reports is the kernel rocprof lists)
+    assert launched.get("bn_fused_fwd_kernel", 0) >= 40 and launched.get("bn_wide_bwd_kernel", 0) >= 40, launched
+    assert launched.get("bn_wide_fwd_kernel", 0) >= 8, launched   # layer1's 64 x 64 norms: one 1 024-thread workgroup per channel
     assert calls["fallback"] == {}, calls       # nothing the kernels declined; the 3-channel stem is the one intended library layer
     assert set(calls["intended"]) <= {"hip_conv.HipConv2d.forward"}, calls
     np.testing.assert_allclose(loss.detach().cpu().numpy(), loss_o.numpy(), rtol=1e-5)
