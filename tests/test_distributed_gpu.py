@@ -206,3 +206,58 @@ def test_ema_net_rccl_world_size_1_bucketed_exchange_inside_the_step_graph(devic
     per_backward = (r["copied_elems"] + r["in_place_elems"]) / r["backwards"]
     assert r["in_place_elems"] >= 0.6 * (r["backwards"] - 1) * per_backward, r
     assert r["delta_fc2"] < 5e-2, r["delta_fc2"]   # three-step parameter change of the head, wrapped vs plain
+
+
+def _two_gpu_worker(rank, world, port, out, collective, direct):
+    for p in (ROOT, os.path.join(ROOT, "synthesis-in-style_amd")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    device = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    try:
+        import training.grad_exchange as GX
+        GX._DIRECT_RCCL = direct
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(257, 1031), torch.nn.ReLU(), torch.nn.Linear(1031, 513), torch.nn.ReLU(),
+                                  torch.nn.Linear(513, 7)).to(device)
+        wrapped = GX.BucketedDataParallel(net, bucket_cap_mb=0.5, collective=collective)
+        gen = torch.Generator().manual_seed(100 + rank)
+        results = []
+        for it in range(3):   # discovery backward, then two on the planned buckets
+            for p in net.parameters():
+                p.grad = None
+            x = torch.randn(16, 257, generator=gen).to(device)
+            wrapped(x).square().mean().backward()
+            torch.cuda.synchronize()
+            mine = [p.grad.detach().clone() for p in net.parameters()]
+            # the same per-rank gradients without the wrap, averaged by torch's own all_reduce
+            for p in net.parameters():
+                p.grad = None
+            net(x).square().mean().backward()
+            ref = [p.grad.detach().clone() for p in net.parameters()]
+            for r in ref:
+                dist.all_reduce(r, op=dist.ReduceOp.AVG)
+            results.append(max(float((a - b).abs().max() / (b.abs().max() + 1e-30)) for a, b in zip(mine, ref)))
+        out[rank] = dict(err=max(results), buckets=len(wrapped.buckets), direct=wrapped.direct_rccl(), note=wrapped.direct_rccl_note)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("collective,direct", [("rs_ag", "1"), ("allreduce", "1"), ("rs_ag", "auto")])
+def test_two_rccl_ranks_average_every_bucket(collective, direct):
+    """Two RCCL ranks on two GPUs with DIFFERENT per-rank gradients: every gradient behind the wrap equals the mean
+    of the ranks' gradients, for reduce-scatter + all-gather and for all-reduce on the direct librccl.so path (opted in:
+    shard offset ``base + 4 * per * rank``, in-place aliasing, the enum values, behind the start-up self-check) and on the
+    default path at world size > 1 (torch.distributed's collectives).  Needs two devices: skipped on the one-GPU boxes, run
+    wherever the suite meets a multi-GPU node."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two HIP devices (RCCL refuses two ranks on one)")
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_two_gpu_worker, args=(2, _free_port(), out, collective, direct), nprocs=2, join=True)
+    for rank in (0, 1):
+        r = out[rank]
+        assert r["buckets"] >= 2 and r["err"] < 1e-5, r
+        assert r["direct"] == (direct == "1"), r   # opted in: the self-check passed and the direct path is live
