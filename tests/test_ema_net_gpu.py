@@ -247,3 +247,46 @@ def test_ema_net_step_at_baseline_batch_vs_oracle(device):
         json.dump(measured, f, indent=1)
     # the bounds of the conditioned B = 2 fixture (test_ema_net_conditioned_fixture_tight): the floor of a ReLU network in fp32
     assert mu_err < 1e-4 and worst[1] < 3e-3 and measured["grad_fc2_rel_l2"] < 1e-4, measured
+
+
+def test_ema_net_101_shipped_config_vs_oracle(device):
+    """The configuration the reference actually SHIPS (configs/segmenter/stylegan2_ema_net_segmenter.yaml:16-24: EMANet on a
+    ResNet-101 trunk, batch 8, 256 x 256; VERDICT r4 missing #4): one forward + backward on the conditioned seeded state against
+    the oracle run live on the host.  The 23 units of layer3 run on the same kernels and tile plans as EMANet-50's six, but
+    nothing had ever executed them: this pins losses, EM bases, every gradient norm and that no operator of the step falls
+    back to the ROCm libraries."""
+    import json
+    import sis_hip
+    from networks.ema_net.network import EMANet
+    sd = E.seeded_state_dict(101, 3, seed=51, residual_scale=0.1)
+    batch = E.seeded_batch(8, 256, 3, seed=52)
+    total, loss_o, mu_o, grads_o = E.train_step(dict(sd), {}, batch, n_layers=101)
+    net = EMANet(3, 101, use_pretrained_resnet=False)
+    net.load_state_dict(sd, strict=True)
+    net.fc1[1].p = 0.0
+    net = net.to(device).train()
+    sis_hip.library_calls(reset=True)
+    loss, mu = net(batch["images"].to(device), batch["segmented"].squeeze(1).to(device))
+    loss.mean().backward()
+    torch.cuda.synchronize()
+    calls = sis_hip.library_calls(reset=True)
+    assert calls["fallback"] == {}, calls
+    assert set(calls["intended"]) <= {"hip_conv.HipConv2d.forward"}, calls
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), loss_o.numpy(), rtol=2e-5)
+    mu_err = _rel_l2(mu.cpu().numpy(), mu_o.numpy())
+    norm_err = {}
+    for name, p in net.named_parameters():
+        if grads_o[name] is None:
+            assert p.grad is None, name
+        else:
+            ref = grads_o[name].double().norm().item()
+            norm_err[name] = abs(p.grad.double().norm().item() - ref) / (ref + 1e-30)
+    worst = max(norm_err.items(), key=lambda kv: kv[1])
+    measured = {"loss_rel": float(np.abs(loss.detach().cpu().numpy() / loss_o.numpy() - 1).max()), "mu_rel_l2": mu_err,
+                "worst_grad_norm": worst, "grad_fc2_rel_l2": _rel_l2(net.fc2.weight.grad.cpu().numpy(), grads_o["fc2.weight"].numpy()),
+                "parameters": len(norm_err)}
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "ema_net_101_b8_parity.json"), "w") as f:
+        json.dump(measured, f, indent=1)
+    # EMANet-50's bounds at B = 16 (test_ema_net_step_at_baseline_batch_vs_oracle), with twice the depth between loss and stem
+    assert mu_err < 1e-4 and worst[1] < 6e-3 and measured["grad_fc2_rel_l2"] < 1e-4, measured

@@ -106,9 +106,15 @@ BF16_LOSS_RTOL = 1e-3          # combined / CE / Dice loss of an iteration      
 BF16_LOGITS_REL_L2 = 0.08      # ||logits - ref||_2 / ||ref||_2 over the whole map                (measured 0.040)
 BF16_LOGITS_MAX = 0.08         # worst single logit of 1.5 M, in units of max|ref|                (measured 0.037)
 BF16_GRAD_NORM_RTOL = 0.08     # per-tensor gradient L2 norms, head + decoder                     (measured <= 0.033)
-BF16_GRAD_REL_L2 = 0.60        # ||g - g_ref|| / ||g_ref|| of the head / decoder convolution weight gradients: 0.001 at the
-#                                head, growing to 0.31 at conv_more -- every ReLU whose pre-activation moved across zero flips a
-#                                whole gradient element while the norms stay put
+# ||g - g_ref|| / ||g_ref|| of the head / decoder convolution weight gradients, LAYER BY LAYER at 1.5 x the larger of the two
+# measured values (B = 2 / B = 8 of the conditioned state, profiles/r04_transunet_bf16_parity_512_b8.json): 0.001 at the head,
+# growing to 0.31 at conv_more -- every ReLU whose pre-activation moved across zero flips a whole gradient element while the
+# norms stay put.  (Round 4 had ONE bound of 0.60 for all of them, which pinned nothing once the per-layer test below existed:
+# test_decoder_layers_bf16_gradients_vs_fp32_on_the_same_inputs, VERDICT r4 weak #2.)
+BF16_GRAD_REL_L2 = {"decoder.conv_more.0.weight": 0.47, "decoder.blocks.0.conv1.0.weight": 0.46, "decoder.blocks.0.conv2.0.weight": 0.43,
+                    "decoder.blocks.1.conv1.0.weight": 0.41, "decoder.blocks.1.conv2.0.weight": 0.34, "decoder.blocks.2.conv1.0.weight": 0.27,
+                    "decoder.blocks.2.conv2.0.weight": 0.14, "decoder.blocks.3.conv1.0.weight": 0.063,
+                    "decoder.blocks.3.conv2.0.weight": 0.017, "segmentation_head.0.weight": 6e-3}
 BF16_HEAD_GRAD_REL_L2 = 6e-3   # the segmentation head's weight gradient, element-wise relative L2 (measured 2.6e-3): error model =
 #                                one bf16 rounding of the logits' gradient (2^-9) x sqrt(2) for the two operands of the weight-gradient
 #                                product, ~3e-3; a kernel whose error doubled fails here although its norm stays inside the 8 % above
@@ -181,12 +187,13 @@ def _check_bf16_report(report, tag, iterations=2):
     assert report["logits_abs_over_max"] < BF16_LOGITS_MAX, report["logits_abs_over_max"]
     worst = max(report["grad_norm_rel"].items(), key=lambda kv: kv[1])
     assert worst[1] < BF16_GRAD_NORM_RTOL, worst
-    assert max(report["grad_rel_l2"].values()) < BF16_GRAD_REL_L2, report["grad_rel_l2"]
+    for name, bound in BF16_GRAD_REL_L2.items():
+        assert report["grad_rel_l2"][name] < bound, (name, report["grad_rel_l2"][name], bound)
+    assert set(report["grad_rel_l2"]) <= set(BF16_GRAD_REL_L2), set(report["grad_rel_l2"]) - set(BF16_GRAD_REL_L2)
     # tight where no ReLU flip can hide a wrong gradient: the segmentation head sits directly under the loss (measured 2.6e-3),
     # the last decoder convolution one ReLU below it (measured 2.7e-2); the transformer blocks are pinned separately, per
     # block and without any ReLU in the way, by tests/test_vit_block_gpu.py
     assert report["grad_rel_l2"]["segmentation_head.0.weight"] < BF16_HEAD_GRAD_REL_L2, report["grad_rel_l2"]
-    assert report["grad_rel_l2"]["decoder.blocks.3.conv2.0.weight"] < 0.06, report["grad_rel_l2"]
     assert report["label_mismatches_where_decided"] == 0 and report["label_agreement"] > BF16_LABEL_AGREEMENT, report
     assert report["fp32_control_logits_rel_l2"] < FP32_CONTROL_REL_L2, report["fp32_control_logits_rel_l2"]
 
