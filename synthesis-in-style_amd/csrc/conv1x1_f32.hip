@@ -139,18 +139,29 @@ __global__ __launch_bounds__(512, C::OCC) void conv1x1_f32_kernel(PwParams p) {
             else load_a(chunk + 1);
         }
         const float* st = lds + cur * C::STAGE;
+        // Fragments one k-pair ahead: the ds_reads of pair kp + 1 are issued BEFORE the MFMAs of pair kp, so the wait in front
+        // of a pair's MFMAs (a counted lgkmcnt) finds its operands already there.  As the compiler scheduled the plain loop,
+        // every 4 MFMAs were preceded by `ds_read x2; s_waitcnt lgkmcnt(0)`: a full LDS round trip exposed per 256 MFMA cycles.
+        float a[2][C::MB], b[2][C::NB];
+#pragma unroll
+        for (int mb = 0; mb < C::MB; ++mb) a[0][mb] = st[a_off + mb * 32];
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb) b[0][nb] = st[b_off + nb * 32];
 #pragma unroll
         for (int kp = 0; kp < C::KC / 2; ++kp) {
-            float a[C::MB], b[C::NB];
+            const int cb = kp & 1, nx = cb ^ 1;
+            if (kp + 1 < C::KC / 2) {
 #pragma unroll
-            for (int mb = 0; mb < C::MB; ++mb) a[mb] = st[a_off + kp * 2 * C::MT + mb * 32];
+                for (int mb = 0; mb < C::MB; ++mb) a[nx][mb] = st[a_off + (kp + 1) * 2 * C::MT + mb * 32];
 #pragma unroll
-            for (int nb = 0; nb < C::NB; ++nb) b[nb] = st[b_off + kp * 2 * C::NPIX + nb * 32];
+                for (int nb = 0; nb < C::NB; ++nb) b[nx][nb] = st[b_off + (kp + 1) * 2 * C::NPIX + nb * 32];
+            }
 #pragma unroll
             for (int mb = 0; mb < C::MB; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < C::NB; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb][mb], b[cb][nb], acc[mb][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);   // keep the pairs in program order: reads of kp + 1, then MFMAs of kp
         }
         if constexpr (!A_KMAJOR) {
             __builtin_amdgcn_sched_barrier(0);

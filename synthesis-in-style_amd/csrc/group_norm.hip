@@ -625,8 +625,9 @@ __global__ __launch_bounds__(1024) void gn_group_bwd_kernel(TI* __restrict__ dx,
         gn_store8(dx + base + off, out);
         if (HAS_MASK && dres) gn_store8(dres + base + off, gi[it]);
     }
-    // d gamma / d beta: the last workgroup of the launch adds the plane sums over the batch
-    if (xwg_complete<true>(counter, gridDim.x)) {
+    // d gamma / d beta: the last workgroup of the launch adds the plane sums over the batch (counter == nullptr: launches of
+    // thousands of workgroups leave that to gn_param_reduce_kernel -- see gn_bwd_run)
+    if (counter && xwg_complete<true>(counter, gridDim.x)) {
         const int C = a.groups * a.cpg;
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             float da = 0.f, db = 0.f;
@@ -741,8 +742,13 @@ void gn_bwd_run(void* dx, float* dres, float* dgamma, float* dbeta, float* ws, c
         if (counters && gn_group_plan(cpg, hw, &nit, &nw) && gn_aligned(dx) && gn_aligned(g) && gn_aligned(g_lp) && gn_aligned(x) &&
             gn_aligned(ymask) && gn_aligned(dres) && (dres == nullptr || gated)) {
             const GnGroupArgs a{hw, cpg, groups, relu, 0.f};
+            // The in-launch hand-over is ONE device-scope counter that every workgroup increments (after draining its stores):
+            // ~12 ns per arrival (MI355X_MICROARCH.md, "fanin"), i.e. 98 us for the 8 192 one-plane groups of block3's projection
+            // norm (measured 117 us for 67 MB; 59 us for block2's 4 096) against ~3 us for a launch of its own.  Beyond 1 024
+            // workgroups the plane sums are added by gn_param_reduce_kernel instead.
+            int* const done = rows <= 1024 ? counters : nullptr;
 #define GN_GROUP_BWD(N, LP, MK) hipLaunchKernelGGL((gn_group_bwd_kernel<TI, TG, N, LP, MK>), dim3(rows), dim3(64 * nw), 0, st, (TI*)dx, dres, \
-                                                   dgamma, dbeta, psum, counters, (const TG*)g, (const TI*)g_lp, (const TI*)x, ymask, mean,  \
+                                                   dgamma, dbeta, psum, done, (const TG*)g, (const TI*)g_lp, (const TI*)x, ymask, mean,  \
                                                    rstd, gamma, beta, a, batch, bits)
 #define GN_GROUP_BWD_N(LP, MK) do { if (nit == 1) GN_GROUP_BWD(1, LP, MK); else if (nit == 2) GN_GROUP_BWD(2, LP, MK); else GN_GROUP_BWD(4, LP, MK); } while (0)
             if (g_lp && gated) GN_GROUP_BWD_N(true, true);
@@ -751,6 +757,7 @@ void gn_bwd_run(void* dx, float* dres, float* dgamma, float* dbeta, float* ws, c
             else GN_GROUP_BWD_N(false, false);
 #undef GN_GROUP_BWD_N
 #undef GN_GROUP_BWD
+            if (!done) hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(sis_cdiv(C, 256)), dim3(256), 0, st, dgamma, dbeta, psum, batch, C);
             return;
         }
     }
