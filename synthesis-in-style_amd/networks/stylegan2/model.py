@@ -291,8 +291,9 @@ class StyledConv(nn.Module):
         wpk, s, dscale = conv.modulate(style)
         return self.forward_s(input, wpk, s, dscale, noise)
 
-    def forward_s(self, input, wpk, s, dscale, noise=None):
-        """Fused layer given the already computed style vector ``s`` [B,Cin] and epilogue factors [B,Cout]."""
+    def forward_s(self, input, wpk, s, dscale, noise=None, out=None):
+        """Fused layer given the already computed style vector ``s`` [B,Cin] and epilogue factors [B,Cout].  ``out`` (stride-1
+        layers): result tensor to write into."""
         conv, act = self.conv, self.activate
         b, _, h, w = input.shape
         if conv.upsample:
@@ -308,7 +309,7 @@ class StyledConv(nn.Module):
         if noise is None:
             noise = input.new_empty(b, 1, h, w).normal_()
         return sis_hip.modconv2d(input, wpk, s, dscale, conv.kernel_size, noise, self.noise.weight, act.bias,
-                                 fuse_act=True, wino_u=conv.wino_weights())
+                                 fuse_act=True, wino_u=conv.wino_weights(), out=out)
 
 
 class ToRGB(nn.Module):
@@ -327,14 +328,15 @@ class ToRGB(nn.Module):
         sis_hip.require_device(input, "input")
         return self.forward_s(input, conv.modulation(style), skip)
 
-    def forward_s(self, input, s, skip=None):
+    def forward_s(self, input, s, skip=None, out=None):
+        """``out``: result tensor to write into (a batch slice of the image: Generator.forward's tail)."""
         conv = self.conv
         if skip is None:
-            return sis_hip.to_rgb(input, conv.weight, s, self.bias, conv.scale)
+            return sis_hip.to_rgb(input, conv.weight, s, self.bias, conv.scale, out=out)
         up = self.upsample
         if up.factor != 2:
             return sis_hip.to_rgb(input, conv.weight, s, self.bias, conv.scale) + up(skip)
-        return sis_hip.to_rgb(input, conv.weight, s, self.bias, conv.scale, skip, up.kernel, up.pad)
+        return sis_hip.to_rgb(input, conv.weight, s, self.bias, conv.scale, skip, up.kernel, up.pad, out=out)
 
 
 def truncate_styles(style, truncation, truncation_latent):
@@ -474,6 +476,50 @@ class Generator(nn.Module):
             _RGB_STREAMS[device] = torch.cuda.Stream(device=device)
         return _RGB_STREAMS[device]
 
+    @staticmethod
+    def _tail_parts(x, rgb, skip):
+        """In how many batch parts the last resolution's convolution + ToRGB run (``_tail``): SIS_RGB_TAIL_SPLIT when the batch
+        divides and holds at least 4 samples per part, else 1.  Default 1 (off): measured on one box at B = 32, two alternating
+        rounds, 15.01-15.02 ms unsplit against 15.02-15.04 (2 parts) and 15.06-15.09 ms (4 parts) -- what the hidden ToRGB
+        saves, the convolution loses to the extra launch tails and to sharing HBM with it (profiles/r05_syn_tail_split.txt)."""
+        parts = int(os.environ.get("SIS_RGB_TAIL_SPLIT", "1"))
+        b = x.shape[0]
+        if parts < 2 or b % parts or b // parts < 4 or skip is None or rgb.upsample.factor != 2:
+            return 1
+        return parts
+
+    def _tail(self, x, conv, rgb, s_conv, d_conv, s_rgb, noise, skip, main, side):
+        """The last StyledConv and its ToRGB by batch parts.  The final ToRGB has no later convolution to hide behind (196 us of
+        a 14.9 ms step at B = 32: an HBM-bound pass over the 1 GB activation with the matrix cores idle), so the batch is cut
+        in parts: while the convolution of part k + 1 runs, the side stream converts part k; only the last part's ToRGB is
+        exposed.  Results are written into batch slices of ONE activation tensor and ONE image: same values, same layout."""
+        parts = self._tail_parts(x, rgb, skip)
+        b, _, h, w = x.shape
+        n = b // parts
+        cout = conv.conv.out_channel
+        act = x.new_empty((b, cout, h, w))
+        image = x.new_empty((b, 3, h, w))
+        wpk = conv.conv.packed_weights()[0]
+        per_sample_noise = noise is not None and noise.numel() == b * h * w
+        if noise is None:
+            noise = x.new_empty(b, 1, h, w).normal_()
+            per_sample_noise = True
+        for k in range(parts):
+            sl = slice(k * n, (k + 1) * n)
+            conv.forward_s(x[sl], wpk, s_conv[sl], d_conv[sl], noise[sl] if per_sample_noise else noise, out=act[sl])
+            if k + 1 < parts:
+                ready = main.record_event()
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    rgb.forward_s(act[sl], s_rgb[sl], skip[sl], out=image[sl])
+            else:   # behind the side chain, on the main stream (as rgb_branch's last=True)
+                main.wait_event(side.record_event())
+                rgb.forward_s(act[sl], s_rgb[sl], skip[sl], out=image[sl])
+        for t in (act, image):
+            t.record_stream(side)
+        skip.record_stream(main)
+        return act, image
+
     def _modulate_all(self, latent):
         """Every layer's s [B,Cin] (and scale*demod [B,Cout] for the styled convs): two launches in total."""
         latent = latent.contiguous()
@@ -528,9 +574,14 @@ class Generator(nn.Module):
                 up, conv, rgb = self.convs[2 * r], self.convs[2 * r + 1], self.to_rgbs[r]
                 out = up.forward_s(out, up.conv.packed_weights()[0], s[j], d[j], noise[1 + 2 * r])
                 tap(i + 1, out)
+                last = r == self.log_size - 3
+                if last and side is not None and self._tail_parts(out, rgb, skip) > 1:
+                    out, skip = self._tail(out, conv, rgb, s[j + 1], d[j + 1], s[j + 2], noise[2 + 2 * r], skip, main, side)
+                    tap(i + 2, out)
+                    continue
                 out = conv.forward_s(out, conv.conv.packed_weights()[0], s[j + 1], d[j + 1], noise[2 + 2 * r])
                 tap(i + 2, out)
-                skip = rgb_branch(rgb, out, s[j + 2], skip, last=r == self.log_size - 3)
+                skip = rgb_branch(rgb, out, s[j + 2], skip, last=last)
             if side is not None and self.log_size == 2:  # 4 x 4 generator: to_rgb1 is the only (side-stream) ToRGB
                 main.wait_event(side.record_event())
                 skip.record_stream(main)

@@ -589,12 +589,21 @@ def _noise_args(noise, batch, h, w):
     raise RuntimeError(f"noise shape {tuple(noise.shape)} does not broadcast over [{batch}, C, {h}, {w}]")
 
 
-def modconv2d(x, wpk, s, dscale, ksize, noise=None, noise_weight=None, bias=None, fuse_act=False, wino_u=None):
+def _out_or_new(out, shape, device, what):
+    """``out``: a caller-provided contiguous float32 result tensor (e.g. a batch slice of a larger one) or None."""
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != device:
+        raise RuntimeError(f"{what}: out must be a contiguous float32 tensor of shape {tuple(shape)} on {device}")
+    return out
+
+
+def modconv2d(x, wpk, s, dscale, ksize, noise=None, noise_weight=None, bias=None, fuse_act=False, wino_u=None, out=None):
     x = _f32(x, "input")
     batch, cin, h, w = x.shape
     cout = wpk.shape[2]
     noise, nbs = _noise_args(noise, batch, h, w)
-    out = torch.empty((batch, cout, h, w), dtype=torch.float32, device=x.device)
+    out = _out_or_new(out, (batch, cout, h, w), x.device, "modconv2d")
     ws = _workspace(x.device)
     wino = wino_u is not None and ksize == 3 and h % 2 == 0 and w % 2 == 0 and cin % 8 == 0 and cout % 4 == 0
     with torch.cuda.device(x.device):
@@ -668,7 +677,7 @@ def blur_noise_act(x, taps, pad, noise=None, noise_weight=None, bias=None, fuse_
     return out
 
 
-def to_rgb(x, weight, s, bias, scale, skip=None, taps=None, pad=(0, 0)):
+def to_rgb(x, weight, s, bias, scale, skip=None, taps=None, pad=(0, 0), out=None):
     x = _f32(x, "input")
     w = _f32(weight, "weight")
     batch, cin, h, wd = x.shape
@@ -678,7 +687,7 @@ def to_rgb(x, weight, s, bias, scale, skip=None, taps=None, pad=(0, 0)):
         skip = _f32(skip, "skip")
         taps = _f32(taps, "kernel")
         kh, kw = taps.shape
-    out = torch.empty((batch, cout, h, wd), dtype=torch.float32, device=x.device)
+    out = _out_or_new(out, (batch, cout, h, wd), x.device, "to_rgb")
     with torch.cuda.device(x.device):
         _check(_launch("to_rgb_kernel", 0.0, 4.0 * (x.numel() + out.numel() + (skip.numel() if skip is not None else 0)),
                        lambda: lib().sis_to_rgb(_ptr(out), _ptr(x), _ptr(w), _ptr(s), _ptr(bias), _ptr(skip),

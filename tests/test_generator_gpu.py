@@ -261,6 +261,35 @@ def test_generator_batch32_properties(device):
         assert torch.equal(a, b)
 
 
+def test_generator_tail_split_is_the_unsplit_forward(device, monkeypatch):
+    """SIS_RGB_TAIL_SPLIT: the last StyledConv + ToRGB run by batch parts so that the final ToRGB overlaps the convolution of
+    the next part (Generator._tail).  Whatever the number of parts -- 1 (off, the default), 2, 4 -- image and activations are
+    the same values in the same tensors (per-sample work, written into batch slices), with explicit shared noise, explicit
+    per-sample noise and fresh noise under a seeded device RNG."""
+    g, _ = _build(64, 512, 8, 2, 3, device)
+    z = torch.randn(16, 512, generator=torch.Generator().manual_seed(9)).to(device)
+    shared = [n.to(device) for n in R.seeded_inputs(64, 1, 512, seed=10)[1]]
+    per_sample = [torch.randn(16, 1, n.shape[2], n.shape[3], generator=torch.Generator().manual_seed(11 + i)).to(device)
+                  for i, n in enumerate(shared)]
+    results = {}
+    for parts in ("1", "2", "4"):
+        monkeypatch.setenv("SIS_RGB_TAIL_SPLIT", parts)
+        with torch.no_grad():
+            out = []
+            for noise in (shared, per_sample, None):
+                torch.manual_seed(77)
+                img, acts = g([z], noise=noise, return_intermediate_activations=True)
+                out += [img] + [acts[k] for k in sorted(acts)]
+            torch.cuda.synchronize()
+        results[parts] = out
+    for parts in ("2", "4"):
+        # the same per-sample arithmetic (a smaller batch may pick another tile / split plan for the convolution, hence a
+        # tolerance instead of bitwise equality); fresh noise: the tail draws the layer's noise for the whole batch in one call,
+        # exactly as the unsplit layer does
+        for a, b in zip(results["1"], results[parts]):
+            assert a.shape == b.shape and _rel(a, b.cpu()) < 1e-6, parts
+
+
 def test_generator_batch32_first_and_last_sample_vs_oracle(device):
     """BASELINE.json configs[1] at its own batch size: ONE Generator.forward over 32 latents -- the tile plans, persistent
     Winograd workgroups and multi-sample tiles the batch selects (a B = 4 forward takes other plans) -- with samples 0 and 31
