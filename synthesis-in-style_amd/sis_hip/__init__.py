@@ -507,14 +507,21 @@ def modconv_demod(s, wsq, scale, demodulate):
 # bucket slice -- and returns a fresh view of it -- puts the gradient where the exchange wants it with no gather copy at all
 # (the copy was 139 / 424 MB per EMANet / TransUNet iteration).  ``grad_arena_register`` maps a
 # parameter's storage address to its slice; ``grad_out(key, ...)`` is what the weight-gradient bindings allocate through.
-_GRAD_ARENA = {}   # parameter data_ptr -> (weakref to the parameter, flat fp32 buffer, element offset, numel, owner id)
+_GRAD_ARENA = {}   # parameter data_ptr -> [weakref to the parameter, flat fp32 buffer, element offset, numel, owner id, handed out]
 
 
 def grad_arena_register(owner, params, flats, offsets):
     """``params[i]``'s gradient lives at ``flats[i][offsets[i] : offsets[i] + params[i].numel()]`` (fp32, contiguous)."""
     import weakref
     for prm, flat, off in zip(params, flats, offsets):
-        _GRAD_ARENA[prm.data_ptr()] = (weakref.ref(prm), flat, int(off), prm.numel(), id(owner))
+        _GRAD_ARENA[prm.data_ptr()] = [weakref.ref(prm), flat, int(off), prm.numel(), id(owner), False]
+
+
+def grad_arena_reset(owner):
+    """End of a backward (the owner's ``_finish``): every slice may be handed out again in the next one."""
+    for ent in _GRAD_ARENA.values():
+        if ent[4] == id(owner):
+            ent[5] = False
 
 
 def grad_arena_release(owner):
@@ -524,15 +531,22 @@ def grad_arena_release(owner):
 
 def grad_arena_slot(key):
     """(flat buffer, element offset, numel) registered for the parameter whose storage starts at ``key``, provided that
-    parameter is alive and holds NO gradient yet (a second backward before the optimizer step must accumulate: its kernels get
-    fresh tensors and autograd adds them); None otherwise."""
+    parameter is alive, holds NO gradient yet (a second backward before the optimizer step must accumulate: its kernels get
+    fresh tensors and autograd adds them) and its slice has not been handed out already in this backward (a parameter used by
+    two nodes of the graph: the second kernel may run before autograd has accumulated the first result; it must not write
+    over it); None otherwise.  A successful call marks the slice as handed out until ``grad_arena_reset``."""
     ent = _GRAD_ARENA.get(key) if key is not None else None
-    if ent is None:
+    if ent is None or ent[5]:
         return None
     prm = ent[0]()
     if prm is None or prm.grad is not None or prm.data_ptr() != key:
         return None
     return ent[1], ent[2], ent[3]
+
+
+def _grad_arena_take(keys):
+    for key in keys:
+        _GRAD_ARENA[key][5] = True
 
 
 def grad_out(key, shape, dtype, device):
@@ -545,6 +559,7 @@ def grad_out(key, shape, dtype, device):
         for d in shape:
             n *= int(d)
         if n == numel and dtype == flat.dtype and device == flat.device and (flat.data_ptr() + flat.element_size() * off) % 16 == 0:
+            _grad_arena_take([key])
             return flat[off:off + numel].view(shape)
     return torch.empty(shape, dtype=dtype, device=device)
 
@@ -561,6 +576,7 @@ def grad_out_fused(keys, rows, cols, device):
             ok = ok and f is flat and o == at and n == r * cols
             at += n
         if ok:
+            _grad_arena_take(keys)
             return flat[off:at].view(sum(rows), cols)
     return torch.empty((sum(rows), cols), dtype=torch.float32, device=device)
 

@@ -384,6 +384,12 @@ class BucketedDataParallel(nn.Module):
 
     def _reset(self):
         self._flushed = 0
+        if self._on_gpu:
+            try:
+                import sis_hip
+                sis_hip.grad_arena_reset(self)   # every bucket slice may be handed to a weight-gradient kernel again
+            except ImportError:
+                pass
         if self.buckets is not None:
             for b in self.buckets:
                 b.pending = len(b.params)

@@ -407,7 +407,14 @@ def test_gradient_arena_hands_out_bucket_slices():
     try:
         g = sis_hip.grad_out(a.data_ptr(), (2, 4), torch.float32, flat.device)
         assert g.data_ptr() == flat.data_ptr() + 4 * 8 and g.shape == (2, 4)
-        assert sis_hip.grad_out(a.data_ptr(), (2, 4), torch.float32, flat.device) is not g          # a new view object per call
+        # handed out: a second request in the same backward (a parameter with two uses in the graph, whose second kernel may run
+        # before autograd has accumulated the first result) gets a FRESH tensor, never the same slice again
+        t = sis_hip.grad_out(a.data_ptr(), (2, 4), torch.float32, flat.device)
+        assert not (flat.data_ptr() <= t.data_ptr() < flat.data_ptr() + 4 * 64)
+        sis_hip.grad_arena_reset(owner)                                                               # next backward
+        g2 = sis_hip.grad_out(a.data_ptr(), (2, 4), torch.float32, flat.device)
+        assert g2.data_ptr() == g.data_ptr() and g2 is not g                                          # a new view object per call
+        sis_hip.grad_arena_reset(owner)
         g.fill_(3.0)
         assert float(flat[8:16].sum()) == 24.0 and float(flat.sum()) == 24.0
         for key, shape, dtype in ((a.data_ptr(), (4, 4), torch.float32), (a.data_ptr(), (2, 4), torch.float64),
@@ -420,8 +427,23 @@ def test_gradient_arena_hands_out_bucket_slices():
         a.grad = None
         fused = sis_hip.grad_out_fused((a.data_ptr(), b.data_ptr(), c.data_ptr()), [2, 2, 2], 4, flat.device)
         assert fused.data_ptr() == flat.data_ptr() + 4 * 8 and fused.shape == (6, 4)
+        sis_hip.grad_arena_reset(owner)
         swapped = sis_hip.grad_out_fused((b.data_ptr(), a.data_ptr(), c.data_ptr()), [2, 2, 2], 4, flat.device)
         assert not (flat.data_ptr() <= swapped.data_ptr() < flat.data_ptr() + 4 * 64)
+        # a parameter used TWICE in one graph: both results arrive, one through the slice, one fresh, and autograd adds them
+        class Twice(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w):
+                ctx.key = w.data_ptr()
+                return x * w.sum()
+            @staticmethod
+            def backward(ctx, gy):
+                dw = sis_hip.grad_out(ctx.key, (2, 4), torch.float32, gy.device)
+                dw.fill_(float(gy.sum()))
+                return None, dw
+        (Twice.apply(torch.ones(3), c).sum() + Twice.apply(2 * torch.ones(5), c).sum()).backward()
+        assert torch.equal(c.grad, torch.full((2, 4), 8.0))   # (the engine sums the two into a new tensor: the wrap's gather copies it)
+        sis_hip.grad_arena_reset(owner)
         # autograd's side of the contract: a gradient returned as such a view becomes .grad as it is (no clone)
         class Fn(torch.autograd.Function):
             @staticmethod
