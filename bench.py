@@ -435,7 +435,7 @@ def bench_dataset(args, world, rank, device, distributed):
     import torch.distributed as dist
     import sis_hip
     from segmentation.gan_local_edit.factor_catalog import FactorCatalog
-    from utils.dataset_creation import label_and_encode
+    from utils.dataset_creation import label_and_encode, seeded_latents
     batch = args.batch or BATCH
     g = build_generator(device)
     rng = np.random.RandomState(7)
@@ -445,7 +445,7 @@ def bench_dataset(args, world, rank, device, distributed):
 
     def one_batch():
         with torch.no_grad():
-            z = torch.randn(batch, g.style_dim).to(device, non_blocking=True)
+            z = seeded_latents(batch, g.style_dim, device).to(device, non_blocking=True)   # pinned: the host runs a batch ahead
             image, acts = g([z], noise=g.make_noise(), return_intermediate_activations=True)
             return label_and_encode(image, acts, catalogs)  # side stream: overlaps the next batch's first layers
 

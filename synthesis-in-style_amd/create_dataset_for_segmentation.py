@@ -29,7 +29,7 @@ import torch
 import sis_hip  # noqa: F401  (fails loudly at import when libsis_hip.so is missing: there is no CPU path)
 from networks import get_stylegan2_generator
 from segmentation.gan_local_edit.factor_catalog import FactorCatalog
-from utils.dataset_creation import label_and_encode, shard_range
+from utils.dataset_creation import label_and_encode, seeded_latents, shard_range
 
 
 def save_image(image: numpy.ndarray, image_id: int, base_dir: Path, name_format: str = "{id}.png"):
@@ -91,7 +91,7 @@ def build_dataset(args, creation_config, rank=0, world_size=1):
     with torch.no_grad():
         for first in range(0, args.num_images, args.batch_size):
             n = min(args.batch_size, args.num_images - first)
-            z = torch.randn(args.batch_size, g.style_dim)[:n]  # the whole stream is drawn on every rank ...
+            z = seeded_latents(args.batch_size, g.style_dim, device)[:n]  # the whole stream is drawn on every rank (pinned) ...
             noise = g.make_noise()  # ... and so are the batch's noise maps (device RNG, same seed on every rank)
             a, b = max(first, lo), min(first + n, hi)
             if a >= b:
@@ -99,7 +99,7 @@ def build_dataset(args, creation_config, rank=0, world_size=1):
             # A batch that straddles a shard boundary is synthesised WHOLE by both of its owners and then cut: the kernels'
             # split-K / tile plans follow the batch size, so only the same batch gives the same bits -- the bytes an image id
             # maps to must not depend on the world size (at most one redundant partial batch per shard boundary).
-            image, acts = g([z.to(device)], noise=noise, return_intermediate_activations=True,
+            image, acts = g([z.to(device, non_blocking=True)], noise=noise, return_intermediate_activations=True,
                             truncation=0.7 if mean_latent is not None else 1, truncation_latent=mean_latent)
             if (a, b) != (first, first + n):
                 image = image[a - first:b - first]

@@ -15,8 +15,9 @@ class Latents:
     noise: List[torch.Tensor]
 
     def to(self, device) -> Latents:
-        self.latent = self.latent.to(device)
-        self.noise = [n.to(device) for n in self.noise]
+        # (non_blocking: a latent drawn into pinned memory -- utils.dataset_creation.seeded_latents -- crosses asynchronously)
+        self.latent = self.latent.to(device, non_blocking=True)
+        self.noise = [n.to(device, non_blocking=True) for n in self.noise]
         return self
 
     def __getitem__(self, key: int) -> Latents:

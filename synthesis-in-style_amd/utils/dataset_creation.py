@@ -22,10 +22,23 @@ import sis_hip
 from latent_projecting import Latents
 
 
+def seeded_latents(batch: int, dim: int, device) -> torch.Tensor:
+    """``torch.randn(batch, dim)`` from the CPU generator (the reference's latent stream, same values) drawn into PINNED host
+    memory when it is headed for a HIP device: the copy that follows (``.to(device, non_blocking=True)``) is then a true
+    asynchronous transfer (from pageable memory the runtime stages it through a bounce buffer on the calling thread).  Measured
+    on the dataset loop: no difference (15.88 ms per batch of 32 either way, profiles/r05_dataset_vs_synthesis.txt) -- the loop's
+    0.9 ms over bare synthesis is the label pass itself: 2.7 GB of activations re-read while the next batch's convolutions
+    run, which slows those by what the pass would have cost alone (profiles/r05_dataset_timeline.txt)."""
+    device = torch.device(device)
+    return torch.randn(batch, dim, pin_memory=device.type == 'cuda' and torch.cuda.is_available())
+
+
 def build_latent_and_noise_generator(autoencoder, config: Dict, seed=1) -> Iterable:
     torch.random.manual_seed(seed)
+    decoder = autoencoder.decoder
     while True:
-        yield Latents(torch.randn(config['batch_size'], config['latent_size']), autoencoder.decoder.make_noise())
+        device = next(decoder.parameters()).device
+        yield Latents(seeded_latents(config['batch_size'], config['latent_size'], device), decoder.make_noise())
 
 
 def shard_range(num_images: int, rank: int, world_size: int) -> Tuple[int, int]:
