@@ -591,6 +591,17 @@ int sis_dropout_bwd_cast(void* out, const float* grad, int64_t numel, const void
 int sis_layer_norm_bwd_fused(void* dx, float* dgamma, float* dbeta, float* workspace, const void* grad_y, const void* x,
                              const float* mean, const float* rstd, const float* gamma, int x_dtype, int g_dtype, int rows, int n,
                              const float* residual_grad, void* cast_out, const void* seed, int site, float drop_p, void* stream);
+/* Deferred form of the LayerNorm parameter gradients (a ViT encoder has 25 norms; nothing reads d(gamma) / d(beta) before the
+ * optimizer or the gradient exchange): sis_layer_norm_bwd_fused_partial = sis_layer_norm_bwd_fused without its reduction launch
+ * (the sis_layer_norm_bwd_parts(rows) partial rows stay in `workspace`), sis_layer_norm_param_reduce_multi = the reductions of
+ * `count` such jobs in one launch per 32 jobs (HOST arrays of device pointers / ints), bitwise the results of the undeferred call. */
+int sis_layer_norm_bwd_fused_partial(void* dx, float* workspace, const void* grad_y, const void* x, const float* mean,
+                                     const float* rstd, const float* gamma, int x_dtype, int g_dtype, int rows, int n,
+                                     const float* residual_grad, void* cast_out, const void* seed, int site, float drop_p,
+                                     void* stream);
+int sis_layer_norm_bwd_parts(int rows);
+int sis_layer_norm_param_reduce_multi(void* const* dgamma, void* const* dbeta, const void* const* part, const int* n_part,
+                                      const int* n, int count, void* stream);
 int sis_attention_fwd(void* ctx, float* lse, const void* qkv, int batch, int n, int heads, void* stream);
 int sis_attention_bwd(void* d_qkv, float* delta, const void* d_ctx, const void* qkv, const void* ctx, const float* lse, int batch,
                       int n, int heads, void* stream);

@@ -6,6 +6,7 @@
 // Backward: dx per row as usual; d(gamma) / d(beta) are column sums over all rows -- every workgroup walks a strip
 // of rows, keeps its column sums in registers, writes one partial row per workgroup; ln_param_reduce adds the partials
 // in fixed order (deterministic, no atomics).
+#include <algorithm>
 #include "vit_common.h"
 
 namespace {
@@ -164,11 +165,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(TI* __restrict__ dx, float*
 // 64 columns per workgroup of 16 waves; wave w adds the partials k = w, w + 16, ... (fixed order, 8 loads requested per trip),
 // then the sixteen are combined in a fixed tree: deterministic, and ~3 us for 512 partial rows instead of one chain of
 // dependent-latency loads per wave
-__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               const float* __restrict__ part, int n_part, int n) {
+__device__ __forceinline__ void ln_param_reduce_body(float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     const float* __restrict__ part, int n_part, int n, int block) {
     __shared__ float red[2][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const int c = block * 64 + lane;
     float a = 0.f, b = 0.f;
     if (c < n) {
         int k = wave;
@@ -196,6 +197,25 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(float* __restrict
             for (int w = 0; w < 16; w += 2 * st) s[w] += s[w + st];
         (wave == 0 ? dgamma : dbeta)[c] = s[0];
     }
+}
+
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               const float* __restrict__ part, int n_part, int n) {
+    ln_param_reduce_body(dgamma, dbeta, part, n_part, n, blockIdx.x);
+}
+
+// The same reduction for SEVERAL LayerNorm backwards in one launch (their partial rows wait in their workspaces: nothing reads
+// d(gamma) / d(beta) before the optimizer or the gradient exchange).  A ViT-B/16 encoder has 25 norms: 25 launches of ~3 us of
+// work between ~2 us kernel boundaries become one.  Job descriptors travel as kernel arguments (hipGraph-capturable as they are).
+constexpr int LN_MULTI_MAX = 32;
+struct LnReduceJobs {
+    float* dgamma[LN_MULTI_MAX]; float* dbeta[LN_MULTI_MAX]; const float* part[LN_MULTI_MAX];
+    int n_part[LN_MULTI_MAX]; int n[LN_MULTI_MAX]; int first_block[LN_MULTI_MAX + 1]; int count;
+};
+__global__ __launch_bounds__(1024) void ln_param_reduce_multi_kernel(LnReduceJobs j) {
+    int job = 0;
+    while (job + 1 < j.count && (int)blockIdx.x >= j.first_block[job + 1]) ++job;
+    ln_param_reduce_body(j.dgamma[job], j.dbeta[job], j.part[job], j.n_part[job], j.n[job], (int)blockIdx.x - j.first_block[job]);
 }
 
 constexpr int LN_BWD_BLOCKS = 512;  // workgroups of the backward pass = partial rows to add afterwards
@@ -234,7 +254,7 @@ extern "C" int sis_layer_norm_fwd(void* y, float* mean, float* rstd, const void*
 
 static int ln_bwd_impl(void* dx, float* dgamma, float* dbeta, float* workspace, const void* grad_y, const void* x,
                        const float* mean, const float* rstd, const float* gamma, int x_dtype, int g_dtype, int rows,
-                       int n, LnBwdExtra ex, void* stream) {
+                       int n, LnBwdExtra ex, void* stream, bool reduce = true) {
     if (rows == 0) return 0;
     SIS_REQUIRE(dx && dgamma && dbeta && workspace && grad_y && x && mean && rstd && gamma, "sis_layer_norm_bwd: null pointer");
     SIS_REQUIRE(rows > 0 && n > 0 && n % 256 == 0, "sis_layer_norm_bwd: row length %d must be a multiple of 256", n);
@@ -251,6 +271,7 @@ static int ln_bwd_impl(void* dx, float* dgamma, float* dbeta, float* workspace, 
     else { LN_SWITCH_NJ(n / 256, LN_BWD(__hip_bfloat16, __hip_bfloat16)) }
 #undef LN_BWD
     SIS_CHECK_LAUNCH("ln_bwd_kernel");
+    if (!reduce) return 0;   // the partial rows stay in `workspace` for sis_layer_norm_param_reduce_multi
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(sis_cdiv(n, 64)), dim3(1024), 0, st, dgamma, dbeta, workspace, blocks, n);
     SIS_CHECK_LAUNCH("ln_param_reduce_kernel");
     return 0;
@@ -275,4 +296,52 @@ extern "C" int sis_layer_norm_bwd_fused(void* dx, float* dgamma, float* dbeta, f
     ex.thr = sis_drop_thr16(drop_p);
     ex.scale = sis_drop_scale(ex.thr);
     return ln_bwd_impl(dx, dgamma, dbeta, workspace, grad_y, x, mean, rstd, gamma, x_dtype, g_dtype, rows, n, ex, stream);
+}
+
+/* sis_layer_norm_bwd_fused without its second launch: dx (and the cast) are complete, d(gamma) / d(beta) are NOT written -- the
+ * sis_layer_norm_bwd_parts(rows) partial rows wait in `workspace` for sis_layer_norm_param_reduce_multi. */
+extern "C" int sis_layer_norm_bwd_fused_partial(void* dx, float* workspace, const void* grad_y, const void* x, const float* mean,
+                                                const float* rstd, const float* gamma, int x_dtype, int g_dtype, int rows, int n,
+                                                const float* residual_grad, void* cast_out, const void* seed, int site,
+                                                float drop_p, void* stream) {
+    SIS_REQUIRE(!(residual_grad || cast_out) || x_dtype == SIS_F32, "sis_layer_norm_bwd_fused_partial: the fusions are for an fp32 residual stream");
+    SIS_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sis_layer_norm_bwd_fused_partial: dropout probability %f / seed word", drop_p);
+    SIS_REQUIRE((int64_t)rows * n < (1LL << 32), "sis_layer_norm_bwd_fused_partial: more than 2^32 elements");
+    LnBwdExtra ex;
+    ex.radd = residual_grad; ex.cast_out = (unsigned short*)cast_out; ex.seed = (const unsigned long long*)seed; ex.site = (unsigned)site;
+    ex.thr = sis_drop_thr16(drop_p);
+    ex.scale = sis_drop_scale(ex.thr);
+    float dummy = 0.f;   // (ln_bwd_impl checks the pointers it will not use)
+    return ln_bwd_impl(dx, &dummy, &dummy, workspace, grad_y, x, mean, rstd, gamma, x_dtype, g_dtype, rows, n, ex, stream, false);
+}
+
+extern "C" int sis_layer_norm_bwd_parts(int rows) {
+    const int blocks = sis_cdiv(rows, 4);
+    return blocks > LN_BWD_BLOCKS ? LN_BWD_BLOCKS : blocks;
+}
+
+/* d(gamma) / d(beta) of `count` LayerNorm backwards from their partial rows: dgamma[i], dbeta[i] [n[i]] float32, part[i] the
+ * workspace of job i holding n_part[i] = sis_layer_norm_bwd_parts(rows_i) partial rows; HOST arrays of device pointers / ints.
+ * Same summation order as sis_layer_norm_bwd_fused's own reduction (bitwise the same results). */
+extern "C" int sis_layer_norm_param_reduce_multi(void* const* dgamma, void* const* dbeta, const void* const* part, const int* n_part,
+                                                 const int* n, int count, void* stream) {
+    if (count <= 0) return 0;
+    SIS_REQUIRE(dgamma && dbeta && part && n_part && n, "sis_layer_norm_param_reduce_multi: null pointer");
+    for (int j0 = 0; j0 < count; j0 += LN_MULTI_MAX) {
+        LnReduceJobs jobs;
+        jobs.count = std::min(LN_MULTI_MAX, count - j0);
+        int blocks = 0;
+        for (int i = 0; i < jobs.count; ++i) {
+            SIS_REQUIRE(dgamma[j0 + i] && dbeta[j0 + i] && part[j0 + i] && n_part[j0 + i] > 0 && n[j0 + i] > 0,
+                        "sis_layer_norm_param_reduce_multi: job %d is incomplete", j0 + i);
+            jobs.dgamma[i] = (float*)dgamma[j0 + i]; jobs.dbeta[i] = (float*)dbeta[j0 + i]; jobs.part[i] = (const float*)part[j0 + i];
+            jobs.n_part[i] = n_part[j0 + i]; jobs.n[i] = n[j0 + i];
+            jobs.first_block[i] = blocks;
+            blocks += sis_cdiv(n[j0 + i], 64);
+        }
+        jobs.first_block[jobs.count] = blocks;
+        hipLaunchKernelGGL(ln_param_reduce_multi_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, jobs);
+        SIS_CHECK_LAUNCH("ln_param_reduce_multi_kernel");
+    }
+    return 0;
 }

@@ -445,6 +445,7 @@ class _FusedBlockFn(Function):
         ctx.cfg, ctx.shape = cfg, (b, n, hid)
         # storage addresses of the weight parameters: the backward's weight-gradient GEMMs write into their gradient-arena slices
         ctx.weight_keys = ((q_w.data_ptr(), k_w.data_ptr(), v_w.data_ptr()), (o_w.data_ptr(),), (f1_w.data_ptr(),), (f2_w.data_ptr(),))
+        ctx.norm_params = ((ln1_w, ln1_b), (ln2_w, ln2_b))   # (leaves: their .grad state decides whether a reduction may be deferred)
         return x3.view(b, n, hid)
 
     @staticmethod
@@ -477,15 +478,16 @@ class _FusedBlockFn(Function):
         d_w1, d_b1 = wg.run(d_pre, h2, mlp, hid, k_f1)
         d_h2 = dgrad(d_pre, w1, w1_t)
         # LN2 backward + the skip connection's gradient, and d(out-projection output) = that sum through the proj dropout
+        fresh1, fresh2 = (all(p.grad is None for p in pair) for pair in ctx.norm_params)   # no gradient in place: deferrable
         g2, d_ln2_w, d_ln2_b, gl1 = S.layer_norm_bwd_fused(d_h2, x2, mean2, rstd2, ln2_w, residual_grad=g3, cast_seed=seed,
-                                                           cast_site=site, cast_p=p_proj)
+                                                           cast_site=site, cast_p=p_proj, defer=fresh2)
         # ---- attention
         d_wo, d_bo = wg.run(gl1, att.view(m, hid), hid, hid, k_o)
         d_att = dgrad(gl1, wo, wo_t)
         d_qkv = S.attention_bwd(d_att.view(b, n, hid), qkv.view(b, n, 3 * hid), att, lse, heads).view(m, 3 * hid)
         d_wqkv, d_bqkv = wg.run(d_qkv, h1, 3 * hid, hid, k_qkv)
         d_h1 = dgrad(d_qkv, wqkv, wqkv_t)
-        g1, d_ln1_w, d_ln1_b, _ = S.layer_norm_bwd_fused(d_h1, x2d, mean1, rstd1, ln1_w, residual_grad=g2)
+        g1, d_ln1_w, d_ln1_b, _ = S.layer_norm_bwd_fused(d_h1, x2d, mean1, rstd1, ln1_w, residual_grad=g2, defer=fresh1)
         wg.join()
         d_q, d_k, d_v = d_wqkv.split(hid, 0)
         d_qb, d_kb, d_vb = d_bqkv.split(hid, 0)

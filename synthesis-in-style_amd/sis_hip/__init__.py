@@ -62,6 +62,9 @@ _SIGNATURES = {
     "sis_dropout_advance": ([_vp, _vp], _i),
     "sis_dropout_bwd_cast": ([_vp, _vp, _i64, _vp, _i, _f, _vp], _i),
     "sis_layer_norm_workspace_floats": ([_i], _i),
+    "sis_layer_norm_bwd_fused_partial": ([_vp] * 7 + [_i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp], _i),
+    "sis_layer_norm_bwd_parts": ([_i], _i),
+    "sis_layer_norm_param_reduce_multi": ([_vp] * 5 + [_i, _vp], _i),
     "sis_column_sum_workspace_floats": ([_i], _i64),
     "sis_column_sum": ([_vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "sis_layer_norm_fwd": ([_vp] * 6 + [_i, _i, _i, _i, _f, _vp], _i),
@@ -579,6 +582,62 @@ def grad_out_fused(keys, rows, cols, device):
             _grad_arena_take(keys)
             return flat[off:at].view(sum(rows), cols)
     return torch.empty((sum(rows), cols), dtype=torch.float32, device=device)
+
+
+# ---- deferred reductions.  A training step is full of tiny second-stage launches (sums of split-K slabs, of per-workgroup partial
+# rows) whose results nothing reads before the optimizer or the gradient exchange: TransUNet's step had 169 of them, 1.6 ms of
+# 23.7 -- mostly kernel boundaries.  Inside an autograd backward a binding may therefore DEFER such a reduction: the
+# first-stage kernel runs, its partial results stay in their buffer, and the job joins a queue that ONE launch per kind drains
+# (``flush_deferred``) at the end of the backward (an engine callback), before a data-parallel bucket leaves, before the fused
+# SGD step, or on request.  Until the flush the result tensors (``.grad`` of the parameters) hold no valid data, so a call site
+# may only defer a gradient whose parameter has NO gradient yet (``defer=`` of the bindings: with one in place autograd adds the
+# new tensor to it immediately -- gradient accumulation over two backwards keeps the undeferred path).  Outside a backward (tests
+# calling a binding directly) nothing is deferred.  SIS_DEFER_REDUCES=0 switches it off (A/B runs).
+_DEFER = os.environ.get("SIS_DEFER_REDUCES", "1") != "0"
+_deferred = {"ln": []}
+_deferred_task = [None]         # the running backward has its end-of-backward callback queued (reset by the callback itself:
+                                # graph task ids are not unique across backwards)
+
+def deferring():
+    """True inside an autograd backward with deferral switched on; queues the end-of-backward flush on first use per backward."""
+    if not _DEFER:
+        return False
+    task = torch._C._current_graph_task_id()
+    if task < 0:
+        return False
+    if _deferred_task[0] != task:
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+        _deferred_task[0] = task
+    return True
+
+
+def _end_of_backward():
+    _deferred_task[0] = None
+    flush_deferred()
+
+
+def _hold(*tensors):
+    """What a queued job keeps of its tensors: their storages, not the tensors.  A result tensor that a job referenced would
+    reach autograd's AccumulateGrad with a use count of two, and a gradient that is not uniquely referenced is CLONED there --
+    before the flush has written it.  The storage keeps the memory alive without counting as a reference to the tensor."""
+    return tuple(t.untyped_storage() for t in tensors if t is not None)
+
+
+def deferred_pending():
+    return sum(len(v) for v in _deferred.values())
+
+
+def flush_deferred():
+    """Runs every queued reduction (one launch per 32 jobs).  Cheap when nothing is queued."""
+    jobs = _deferred["ln"]
+    if jobs:
+        _deferred["ln"] = []
+        n = len(jobs)
+        vp, ci = ctypes.c_void_p * n, ctypes.c_int * n
+        with torch.cuda.device(jobs[0][5]):
+            _check(lib().sis_layer_norm_param_reduce_multi(vp(*[j[0] for j in jobs]), vp(*[j[1] for j in jobs]), vp(*[j[2] for j in jobs]),
+                                                           ci(*[j[3] for j in jobs]), ci(*[j[4] for j in jobs]), n, _stream()),
+                   "sis_layer_norm_param_reduce_multi")
 
 
 WORKSPACE_BYTES = int(os.environ.get("SIS_WORKSPACE_MB", "128")) << 20  # split-K slabs (per device)
@@ -1201,13 +1260,7 @@ def gemm_bf16(a, b, layout, epilogue=EPI_NONE, bias=None, resid=None, pre=None, 
     if splits > 1:
         # split-K slabs: one scratch buffer per (device, stream) -- the encoder's weight gradients run on a side stream while
         # the main stream's convolution weight gradients use the per-device buffer
-        stream = torch.cuda.current_stream(a.device)
-        if stream == torch.cuda.default_stream(a.device):
-            ws = _workspace(a.device)
-        else:
-            ws = _workspaces.get((a.device, stream.cuda_stream))
-            if ws is None:
-                ws = _workspaces[(a.device, stream.cuda_stream)] = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=a.device)
+        ws = _stream_workspace(a.device)
         ws_bytes = ws.numel()
     name = f"gemm_bf16<{('NT', 'NN', 'TN')[layout]},{epilogue}>" if tile < TILE_256X96 else f"gemm256<{(96, 192, 288)[tile - TILE_256X96]},{epilogue}>"
     with torch.cuda.device(a.device):
@@ -1410,9 +1463,11 @@ def layer_norm_fwd(x, gamma, beta, eps, out_dtype=None):
     return y, mean, rstd
 
 
-def layer_norm_bwd_fused(grad_y, x, mean, rstd, gamma, residual_grad=None, cast_seed=None, cast_site=None, cast_p=0.0):
+def layer_norm_bwd_fused(grad_y, x, mean, rstd, gamma, residual_grad=None, cast_seed=None, cast_site=None, cast_p=0.0, defer=False):
     """LayerNorm backward of a pre-norm residual block: dx = residual_grad + LN'(grad_y); with ``cast_site`` also returns
-    bf16(dx * dropout factor of that site) -> (dx, dgamma, dbeta, cast or None)."""
+    bf16(dx * dropout factor of that site) -> (dx, dgamma, dbeta, cast or None).  ``defer``: the caller vouches that the two
+    parameters hold NO gradient yet (autograd will then take dgamma / dbeta as ``.grad`` as they are -- with a gradient in place it
+    would ADD them on the spot); inside a backward their reduction then joins the deferred queue (``flush_deferred``)."""
     x = x.contiguous()
     g = grad_y.contiguous()
     n = x.shape[-1]
@@ -1424,6 +1479,15 @@ def layer_norm_bwd_fused(grad_y, x, mean, rstd, gamma, residual_grad=None, cast_
     if residual_grad is not None:
         residual_grad = _f32(residual_grad, "residual_grad")
     ws = torch.empty(lib().sis_layer_norm_workspace_floats(n), dtype=torch.float32, device=x.device)
+    if defer and deferring():   # d(gamma) / d(beta) by the batched reduction at the end of the backward (flush_deferred)
+        with torch.cuda.device(x.device):
+            _check(lib().sis_layer_norm_bwd_fused_partial(_ptr(dx), _ptr(ws), _ptr(g), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma),
+                                                          _DTYPE_CODE[x.dtype], _DTYPE_CODE[g.dtype], rows, n, _ptr(residual_grad),
+                                                          _ptr(cast), _ptr(cast_seed), int(cast_site or 0), float(cast_p), _stream()),
+                   "sis_layer_norm_bwd_fused_partial")
+        _deferred["ln"].append((dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), int(lib().sis_layer_norm_bwd_parts(rows)), n, x.device,
+                                _hold(dgamma, dbeta, ws)))
+        return dx, dgamma, dbeta, cast
     with torch.cuda.device(x.device):
         _check(lib().sis_layer_norm_bwd_fused(_ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _ptr(g), _ptr(x), _ptr(mean), _ptr(rstd),
                                               _ptr(gamma), _DTYPE_CODE[x.dtype], _DTYPE_CODE[g.dtype], rows, n, _ptr(residual_grad),

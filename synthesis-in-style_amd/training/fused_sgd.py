@@ -129,6 +129,7 @@ class FusedSGD(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        sis_hip.flush_deferred()   # (normally drained at the end of the backward: a no-op then)
         entries, fresh = [], False
         for gi, group in enumerate(self.param_groups):
             for p in group['params']:

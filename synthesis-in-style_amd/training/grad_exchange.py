@@ -349,6 +349,9 @@ class BucketedDataParallel(nn.Module):
             flat.mul_(1.0 / world)
 
     def _flush(self, bucket: _Bucket):
+        if self._on_gpu:
+            import sis_hip
+            sis_hip.flush_deferred()   # gradients whose second-stage reduction was deferred are completed before they travel
         self._gather(bucket)
         self._reduce(bucket)
         self._flushed += 1
