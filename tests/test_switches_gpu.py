@@ -131,6 +131,7 @@ _MODULE_SWITCHES = [
     ("sis_hip", "_GN_FUSED_FINISH", False, "trans_u_net"),                                        # SIS_GN_FUSED_FINISH
     ("sis_hip", "_GEMM256_WIDTHS", (288, 192, 96), "trans_u_net"),                                # SIS_GEMM256_TILES
     ("sis_hip", "_UP_FIR", False, "generator"),                                                   # SIS_UP_FIR
+    ("sis_hip", "_DEFER", False, "trans_u_net"),                                                  # SIS_DEFER_REDUCES
 ]
 
 

@@ -121,3 +121,44 @@ def test_two_forwards_then_two_backwards_use_their_own_dropout_masks(device):
 
     for u, v in zip(grads(False), grads(True)):
         assert torch.equal(u, v)
+
+
+def test_deferred_layer_norm_reductions_are_the_undeferred_ones(device, monkeypatch):
+    """SIS_DEFER_REDUCES: inside a backward the encoder's LayerNorm parameter-gradient rows are summed by ONE batched launch at
+    the end of the backward (sis_hip.flush_deferred, an autograd-engine callback) instead of one launch per norm.  Same kernels
+    body, same order: every gradient is bitwise the undeferred one; the queue is empty when backward() returns; jobs were in fact
+    queued; and a direct call of the binding outside a backward is never deferred."""
+    import sis_hip
+    from networks.trans_u_net import vit_encoder as V
+    cfg = _config(0.0)
+    cfg.transformer["num_layers"] = 3
+    torch.manual_seed(11)
+    enc = V.Encoder(cfg, vis=False).to(device).train()
+    x = torch.randn(2, 128, 768, device=device)
+
+    def grads(defer):
+        monkeypatch.setattr(sis_hip, "_DEFER", defer)
+        enc.zero_grad(set_to_none=True)
+        queued = []
+        flush = sis_hip.flush_deferred
+        monkeypatch.setattr(sis_hip, "flush_deferred", lambda: (queued.append(sis_hip.deferred_pending()), flush())[1])
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            enc(x)[0].square().mean().backward()
+        monkeypatch.setattr(sis_hip, "flush_deferred", flush)
+        assert sis_hip.deferred_pending() == 0
+        return {n: p.grad.clone() for n, p in enc.named_parameters()}, max(queued, default=0)
+
+    plain, queued_off = grads(False)
+    deferred, queued_on = grads(True)
+    assert queued_off == 0 and queued_on >= 6, (queued_off, queued_on)   # two norms per block (+ the encoder's final norm undeferred or not)
+    for name in plain:
+        assert torch.equal(plain[name], deferred[name]), name
+    # outside a backward: complete results at once
+    n = 768
+    xs, g = torch.randn(64, n, device=device), torch.randn(64, n, device=device)
+    gamma, beta = torch.randn(n, device=device), torch.randn(n, device=device)
+    _, mean, rstd = sis_hip.layer_norm_fwd(xs, gamma, beta, 1e-6, torch.float32)
+    _, dg, db, _ = sis_hip.layer_norm_bwd_fused(g, xs, mean, rstd, gamma, defer=True)
+    assert sis_hip.deferred_pending() == 0
+    _, dg0, db0 = sis_hip.layer_norm_bwd(g, xs, mean, rstd, gamma)
+    assert torch.equal(dg, dg0) and torch.equal(db, db0)
