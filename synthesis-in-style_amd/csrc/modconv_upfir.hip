@@ -17,8 +17,11 @@
 //
 // GEMM view: M = output channels, N = 2 x 2 position BLOCKS, K = input channels, 25 accumulator planes.  25 planes of a
 // 32 x 32 tile (400 registers) leave one wave per SIMD; on v_mfma_f32_16x16x4_f32 (same rate: 64 FLOP/clk/SIMD, exact fp32) a
-// wave holds 32 channels x 16 blocks x 25 planes in 200 registers and two waves share a SIMD.  Workgroup = 8 waves =
-// 64 channels x 64 blocks (256 positions); lane l of a wave: block l & 15, input channel (l >> 4) of the 4-deep MFMA step.
+// wave holds 32 channels x 16 blocks x 25 planes in 200 registers and two waves share a SIMD.  Workgroup = 4 waves =
+// 64 channels x 32 blocks (128 positions), 4 input channels per chunk, 58 KB of LDS: TWO workgroups per CU, one wave of each
+// on every SIMD, so that one's barrier, patch transform, fragment reads, prologue and epilogue fall under the other's MFMAs
+// (the 8-wave / 64-block / 8-channel tile, SIS_UPFIR_WAVES=8, has both waves of a SIMD behind the same barrier: 5.22 -> 4.94 ms
+// on the three large layers).  Lane l of a wave: block l & 15, input channel (l >> 4) of the 4-deep MFMA step.
 //
 // Blocks are numbered row-major over (sample, block row, block column) -- (H/2 + 1) x (W/2 + 1) per sample: the transposed
 // convolution has H + 1 position rows, the last block row / column holds one valid position -- and a workgroup takes 64
@@ -26,8 +29,8 @@
 // image rows those blocks touch, each staged whole as [4 zeros | W pixels | 4 zeros] by LDS-DMA through a buffer descriptor
 // whose out-of-range lanes write the zeros (rows -1 and H, H + 1 and the pad columns alike); "virtual" row v of sample b,
 // v = h + 1 in [0, H + 3), has index b (H + 3) + v, so a run that crosses from one sample into the next is still one range.
-// Staging: 8 input channels per chunk, wave w moves channel w (4 pieces of weights: 16 planes x 64 channels, and <= 4 pieces
-// of input rows), double-buffered, one barrier per chunk (as modconv_mfma2.hip).  The style factor s[b, ci] multiplies the
+// Staging: one input channel per wave and chunk, wave w moves channel w (4 pieces of weights: 16 planes x 64 channels, and
+// <= 4 pieces of input rows), double-buffered, one barrier per chunk (as modconv_mfma2.hip).  The style factor s[b, ci] multiplies the
 // raw patch values after their LDS read; demodulation in the epilogue; noise / bias / activation belong to the blur kernel
 // that reads this kernel's (2H+1) x (2W+4)-strided result.
 #include "modconv_common.h"
@@ -36,14 +39,14 @@ namespace {
 
 typedef float uf_f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int UF_CC = 8;                              // input channels per chunk (= waves: one channel's DMA per wave)
 constexpr int UF_MBLK = 64;                           // output channels per workgroup
-constexpr int UF_NBLK = 64;                           // position blocks per workgroup
+// NW = waves per workgroup (8 or 4): NW input channels per chunk (one channel's DMA per wave) and 8 NW position blocks per
+// workgroup.  NW = 4 halves the tile and the chunk (58 KB of LDS): TWO workgroups share a CU, one wave of each per SIMD, and
+// one's barrier / transform / epilogue falls under the other's MFMAs.
 constexpr int UF_PLANES = 16;
 constexpr int UF_WROW = UF_PLANES * UF_MBLK + 32;     // floats per channel row of the weight stage [8 plane pairs][64 co][2]:
                                                       // +32 puts the two channels a 32-lane group of a ds_read_b64 touches 32
                                                       // banks (of 64) apart: conflict-free
-constexpr int UF_THREADS = 512;
 constexpr int UF_XP_MAX = 4;                          // 1 KiB pieces per channel of the input tile (xs <= 1024 floats)
 constexpr unsigned UF_OOB = 0x80000000u;
 
@@ -63,8 +66,9 @@ __device__ __forceinline__ void uf_dma16(__amdgpu_buffer_rsrc_t r, float* l, uns
 // ABL: timing ablations for development builds (tools/bench_upfir.py, SIS_UPFIR_ABL): bit 0 no barrier in the chunk loop, bit 1 no
 // DMA in the loop, bit 2 no patch reads / transform in the loop, bit 3 no weight-fragment reads in the loop.  Any non-zero value
 // computes WRONG results; the shipped kernel is ABL = 0.
-template <int PIPE, int ABL = 0>
-__global__ __launch_bounds__(UF_THREADS) void modconv_upfir_kernel(const UpFirParams p) {
+template <int PIPE, int ABL = 0, int NW = 8>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void modconv_upfir_kernel(const UpFirParams p) {
+    constexpr int UF_CC = NW, UF_NBLK = 8 * NW, UF_THREADS = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Wl = lds;                              // [2][CC][WROW]
     float* Xl = Wl + 2 * UF_CC * UF_WROW;         // [2][CC][xs]
@@ -216,7 +220,10 @@ __global__ __launch_bounds__(UF_THREADS) void modconv_upfir_kernel(const UpFirPa
                 }
             }
         };
-        if constexpr (PIPE == 2) {   // both steps' transforms first: the second one's loads and VALU go under the first step's MFMAs
+        if constexpr (NW == 4) {     // one MFMA step per chunk
+            transform(0, t0);
+            multiply(0, t0);
+        } else if constexpr (PIPE == 2) {   // both steps' transforms first: the second one's loads and VALU go under the first step's MFMAs
             transform(0, t0);
             transform(1, t1);
             multiply(0, t0);
@@ -288,7 +295,8 @@ __global__ __launch_bounds__(256) void upfir_prepack_kernel(float* __restrict__ 
     }
 }
 
-bool upfir_plan(UpFirParams& p, int batch, int cin, int cout, int h, int w, int row_stride, size_t* lds_bytes) {
+bool upfir_plan(UpFirParams& p, int batch, int cin, int cout, int h, int w, int row_stride, size_t* lds_bytes, int nw = 8) {
+    const int UF_CC = nw, UF_NBLK = 8 * nw;
     if (batch <= 0 || h < 32 || w < 32 || (h & 1) || (w & 3) || cin % UF_CC || cout % UF_MBLK) return false;
     if ((row_stride & 3) || row_stride < 2 * w + 4) return false;
     if ((int64_t)batch * cin * h * w * 4 >= (1LL << 31) || (int64_t)cin * UF_PLANES * cout * 4 >= (1LL << 31)) return false;
@@ -316,10 +324,17 @@ bool upfir_plan(UpFirParams& p, int batch, int cin, int cout, int h, int w, int 
 
 }  // namespace
 
+// SIS_UPFIR_WAVES: 4 (default) = half tiles, two workgroups per CU; 8 = the one-workgroup-per-CU tile (A/B runs, same results)
+static int upfir_waves() {
+    static const int nw = getenv("SIS_UPFIR_WAVES") ? atoi(getenv("SIS_UPFIR_WAVES")) : 4;
+    return nw;
+}
+
 extern "C" int sis_modconv_up_fir_supported(int batch, int cin, int cout, int h, int w, int t_row_stride) {
     UpFirParams p;
     size_t lds;
-    return upfir_plan(p, batch, cin, cout, h, w, t_row_stride, &lds) ? 1 : 0;
+    const int nw = upfir_waves();
+    return (nw == 4 || nw == 8) && upfir_plan(p, batch, cin, cout, h, w, t_row_stride, &lds, nw) ? 1 : 0;
 }
 
 extern "C" int sis_modconv_up_fir_prepack(float* u, const float* w, int cout, int cin, void* stream) {
@@ -338,7 +353,10 @@ extern "C" int sis_modconv2d_up_fir(float* t, const float* x, const float* u, co
     SIS_REQUIRE((((uintptr_t)t | (uintptr_t)x | (uintptr_t)u) & 15) == 0, "sis_modconv2d_up_fir: pointers must be 16-byte aligned");
     UpFirParams p;
     size_t lds;
-    SIS_REQUIRE(upfir_plan(p, batch, cin, cout, h, w, t_row_stride, &lds),
+    const int nw = upfir_waves();
+    SIS_REQUIRE(nw == 4 || nw == 8, "sis_modconv2d_up_fir: SIS_UPFIR_WAVES must be 4 or 8");
+    const int UF_NBLK = 8 * nw, UF_THREADS = 64 * nw;
+    SIS_REQUIRE(upfir_plan(p, batch, cin, cout, h, w, t_row_stride, &lds, nw),
                 "sis_modconv2d_up_fir: %d x (%d -> %d) on %d x %d with row stride %d is not supported (sis_modconv_up_fir_supported)", batch,
                 cin, cout, h, w, t_row_stride);
     p.x = x; p.u = u; p.s = s; p.dscale = dscale; p.out = t;
@@ -348,6 +366,8 @@ extern "C" int sis_modconv2d_up_fir(float* t, const float* x, const float* u, co
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<1, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<0, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e != hipSuccess) return sis_fail("sis_modconv2d_up_fir: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -357,6 +377,7 @@ extern "C" int sis_modconv2d_up_fir(float* t, const float* x, const float* u, co
 #ifdef SIS_ABLATIONS   // development builds only (tools/build_variant.sh WORK <tag> -DSIS_ABLATIONS): the shipped library has no wrong-result path
     static const int abl = getenv("SIS_UPFIR_ABL") ? atoi(getenv("SIS_UPFIR_ABL")) : 0;      // timing ablations: WRONG results
     if (abl) {
+        SIS_REQUIRE(nw == 8, "SIS_UPFIR_ABL: the ablations exist for SIS_UPFIR_WAVES=8 only");
 #define UF_ABL(A) hipLaunchKernelGGL((modconv_upfir_kernel<1, A>), dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p)
         static bool abl_attr = false;
         if (!abl_attr) {
@@ -374,7 +395,9 @@ extern "C" int sis_modconv2d_up_fir(float* t, const float* x, const float* u, co
         return 0;
     }
 #endif
-    if (pipe == 0) hipLaunchKernelGGL(modconv_upfir_kernel<0>, dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
+    if (nw == 4 && pipe == 0) hipLaunchKernelGGL((modconv_upfir_kernel<0, 0, 4>), dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
+    else if (nw == 4) hipLaunchKernelGGL((modconv_upfir_kernel<1, 0, 4>), dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
+    else if (pipe == 0) hipLaunchKernelGGL(modconv_upfir_kernel<0>, dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
     else if (pipe == 2) hipLaunchKernelGGL(modconv_upfir_kernel<2>, dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
     else if (pipe == 3) hipLaunchKernelGGL(modconv_upfir_kernel<3>, dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(modconv_upfir_kernel<1>, dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);

@@ -98,7 +98,7 @@ def test_modconv_up_vs_oracle(device, b, cin, cout, h, w):
 
 
 @pytest.mark.parametrize("b,cin,cout,h,w", [(2, 16, 64, 32, 32), (3, 40, 128, 32, 32), (1, 8, 64, 64, 64), (2, 24, 64, 34, 40),
-                                             (5, 8, 64, 32, 32), (1, 8, 128, 128, 128), (2, 16, 64, 32, 64)])
+                                             (5, 8, 64, 32, 32), (1, 8, 128, 128, 128), (2, 16, 64, 32, 64), (2, 12, 64, 32, 32)])
 def test_modconv_up_fir_vs_oracle(device, b, cin, cout, h, w):
     """The fast-FIR transposed convolution (csrc/modconv_upfir.hip: 25 products per 2 x 2 positions on
     v_mfma_f32_16x16x4_f32) against the reference's formulation (per-sample weights, conv_transpose2d with B groups) at the
@@ -106,6 +106,8 @@ def test_modconv_up_fir_vs_oracle(device, b, cin, cout, h, w):
     blur + noise + bias + activation.  Shapes: tiles that cross from one sample into the next (3 x 289 blocks / 64), an odd
     number of block rows, non-square maps, one to two workgroup columns."""
     import sis_hip
+    if cin % 8 and os.environ.get("SIS_UPFIR_WAVES") == "8":
+        pytest.skip("the one-workgroup-per-CU tile stages 8 input channels per chunk")
     gen = torch.Generator().manual_seed(b * 131 + cin + cout + h + w)
     x, style = _mk(gen, b, cin, h, w), _mk(gen, b, 32)
     weight, mod_w, mod_b = _mk(gen, 1, cout, cin, 3, 3), _mk(gen, cin, 32), 1 + 0.1 * _mk(gen, cin)
@@ -149,7 +151,7 @@ def test_modconv_up_fir_declines_what_it_does_not_serve(device):
     L = sis_hip.lib()
     assert not L.sis_modconv_up_fir_supported(2, 16, 64, 16, 16, 36)     # below 32 x 32: the 4-phase kernel (split-K there)
     assert not L.sis_modconv_up_fir_supported(2, 16, 48, 32, 32, 68)     # output channels not a multiple of 64
-    assert not L.sis_modconv_up_fir_supported(2, 12, 64, 32, 32, 68)     # input channels not a multiple of 8
+    assert not L.sis_modconv_up_fir_supported(2, 10, 64, 32, 32, 68)     # input channels not a multiple of the 4-channel chunk
     assert not L.sis_modconv_up_fir_supported(2, 16, 64, 32, 32, 65)     # un-padded rows
     assert L.sis_modconv_up_fir_supported(32, 512, 512, 32, 32, 68) and L.sis_modconv_up_fir_supported(32, 256, 128, 128, 128, 260)
 

@@ -166,7 +166,8 @@ _C_SIDE = [
     ("SIS_WINO_PIPE", "0", "tests/test_generator_gpu.py::test_generator_vs_golden_small"),
     ("SIS_WINO_TPW", "4", "tests/test_generator_gpu.py::test_generator_vs_golden_small"),
     ("SIS_WINO_XCD_MB", "0", "tests/test_generator_gpu.py::test_generator_vs_golden_small"),
-    ("SIS_UPFIR_PIPE", "0", "tests/test_generator_gpu.py::test_modconv_up_fir_vs_oracle"),
+    ("SIS_UPFIR_WAVES", "8", "tests/test_generator_gpu.py::test_modconv_up_fir_vs_oracle"),   # the one-workgroup-per-CU tile ...
+    ("SIS_UPFIR_PIPE", "0", "tests/test_generator_gpu.py::test_modconv_up_fir_vs_oracle"),    # ... and its unpipelined loop
     ("SIS_GN_SINGLE_PASS", "0", "tests/test_upsample_gpu.py"),
     ("SIS_UP2_DIRECT", "0", "tests/test_upsample_gpu.py"),
     ("SIS_PW_KC", "32", "tests/test_conv1x1_f32_gpu.py"),
