@@ -348,13 +348,15 @@ int64_t sis_group_norm_gate_bytes(int batch, int channels, int hw);
 /* nn.BatchNorm2d in training mode (+ optional ReLU) with 16-bit or fp32 tensors -- the TransUNet decoder's Conv2dReLU
  * blocks (networks/trans_u_net/vit_seg_modeling.py:265-287).  Arguments as for group norm; statistics per channel over
  * (B, hw); mean / rstd [C]; running_mean / running_var (float32 [C], may both be NULL) are updated with `momentum`
- * (unbiased variance).  Workspace: sis_group_norm_workspace_floats(B, C, hw) floats. */
+ * (unbiased variance).  Workspace: sis_group_norm_workspace_floats(B, C, hw) floats.  `counters`: NULL, or C ints that are
+ * zero before the call and zero again after it (private to the stream, as for group norm): the per-channel merge then
+ * happens inside the statistics launch, by the workgroup that completes the channel, instead of in a launch of its own. */
 int sis_batch_norm_fwd(void* y, float* mean, float* rstd, float* running_mean, float* running_var, float* workspace,
                        const void* x, const float* gamma, const float* beta, int x_dtype, int y_dtype, int batch,
-                       int channels, int hw, float eps, float momentum, int relu, void* stream);
+                       int channels, int hw, float eps, float momentum, int relu, int* counters, void* stream);
 int sis_batch_norm_bwd(void* dx, float* dgamma, float* dbeta, float* workspace, const void* grad_y, const void* x,
                        const float* mean, const float* rstd, const float* gamma, const float* beta, int x_dtype,
-                       int g_dtype, int batch, int channels, int hw, int relu, void* stream);
+                       int g_dtype, int batch, int channels, int hw, int relu, int* counters, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Column sums out[c] = sum_r x[r][c] of a [rows][n] matrix (n % 4 == 0; x SIS_F32 / SIS_F16 / SIS_BF16, out float32): the

@@ -141,29 +141,33 @@ __global__ __launch_bounds__(256) void weight_std_pack_multi_kernel(const long l
         return;
     }
     const float* src = w + (int64_t)co * n;
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += src[i];
+    const bool plain = what == nullptr;   // a layer without standardisation (the decoder's Conv2d): bf16 rounding + packing only
+    float mean = 0.f, sd = 1.f;
+    if (!plain) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n; i += 256) s += src[i];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
-    __syncthreads();
-    float m2 = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) { const float dd = src[i] - mean; m2 += dd * dd; }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
+        __syncthreads();
+        float m2 = 0.f;
+        for (int i = threadIdx.x; i < n; i += 256) { const float dd = src[i] - mean; m2 += dd * dd; }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m2;
-    __syncthreads();
-    const float var = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
-    const float sd = sqrtf(var + eps);
-    if (threadIdx.x == 0) invstd[co] = 1.f / sd;
+        for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m2;
+        __syncthreads();
+        const float var = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
+        sd = sqrtf(var + eps);
+        if (threadIdx.x == 0) invstd[co] = 1.f / sd;
+    }
     // adjoint image: M = Cin (row = ci), K = Cout (this filter is element k = co of every row)
     const int nchunks2 = MT2 ? Cout / KC : 0, chunk2 = co / KC, unit2 = (co % KC) >> 3, j2 = co & 7;
     for (int i = threadIdx.x; i < n; i += 256) {
-        __hip_bfloat16 b = __float2bfloat16((src[i] - mean) / sd);
+        __hip_bfloat16 b = __float2bfloat16(plain ? src[i] : (src[i] - mean) / sd);
         const u16 v = *reinterpret_cast<u16*>(&b);
-        what[(int64_t)co * n + i] = v;
+        if (!plain) what[(int64_t)co * n + i] = v;
         const int ci = i / taps, tap = i - ci * taps;
         packed[fwd_pos(ci, tap)] = v;
         if (MT2) {

@@ -28,12 +28,14 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef unsigned short u16;
 
-template <int WM_, int WN_, int KS_>
+template <int WM_, int WN_, int KS_, int NWV_ = 8>
 struct WgCfg {
     // waves along co / ci / K (the K waves split a row step's 16-pixel K-steps and write partial tiles of their own:
     // the narrow tail of the decoder, 16 or 3 output channels, has no other parallelism); K-steps per row step
-    static constexpr int WM = WM_, WN = WN_, WK = 8 / (WM_ * WN_), KS = KS_;
-    static_assert(WM * WN * WK == 8 && KS % WK == 0, "wave layout");
+    // NWV = waves per workgroup: 8, or 4 -- two workgroups per CU (the accumulators allow two waves per SIMD), one wave of each on
+    // every SIMD, so that one's barrier and staging fall under the other's MFMAs
+    static constexpr int WM = WM_, WN = WN_, NWV = NWV_, WK = NWV_ / (WM_ * WN_), KS = KS_, THREADS = 64 * NWV_;
+    static_assert(WM * WN * WK == NWV && KS % WK == 0, "wave layout");
     static constexpr int MT = 32 * WM, NT = 32 * WN;         // co x ci tile of the workgroup
     static constexpr int SW = 16 * KS;                       // strip width in pixels
     static constexpr int DY_UNITS = SW / 8 + 1;              // 16-byte units per dY row (one pad unit)
@@ -45,7 +47,7 @@ struct WgCfg {
     static constexpr int LDS = 2 * DY_BUF + X_BYTES;
     static constexpr int DY_CHUNKS = MT * (SW / 8);          // 16-byte loads per dY row
     static constexpr int X_CHUNKS = NT * (SW / 8 + 2);
-    static constexpr int NDY = (DY_CHUNKS + 511) / 512, NX = (X_CHUNKS + 511) / 512;
+    static constexpr int NDY = (DY_CHUNKS + THREADS - 1) / THREADS, NX = (X_CHUNKS + THREADS - 1) / THREADS;
     static_assert(LDS <= 160 * 1024, "LDS");
 };
 
@@ -96,7 +98,7 @@ __device__ __forceinline__ void tap_row(f32x16 (&acc)[9], int ky, bf16x8 a, uint
 }
 
 template <typename C, bool ALIGNED>
-__global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(WgParams p) {
+__global__ __launch_bounds__(C::THREADS, 2) void conv_wgrad_bf16_kernel(WgParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* const dy_lds = lds;
     unsigned char* const x_lds = lds + 2 * C::DY_BUF;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(WgParams p) {
     auto load_dy = [&](int y) {  // dY row y of the tile's channels, strip columns
 #pragma unroll
         for (int i = 0; i < C::NDY; ++i) {
-            const int c = tid + i * 512;
+            const int c = tid + i * C::THREADS;
             if (c < C::DY_CHUNKS) {
                 const int ch = c / (C::SW / 8), g = c % (C::SW / 8);
                 const bool ok = co_t * C::MT + ch < p.Cout;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(WgParams p) {
     auto store_dy = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < C::NDY; ++i) {
-            const int c = tid + i * 512;
+            const int c = tid + i * C::THREADS;
             if (c < C::DY_CHUNKS) {
                 const int ch = c / (C::SW / 8), g = c % (C::SW / 8);
                 *reinterpret_cast<uint4*>(dy_lds + buf * C::DY_BUF + ch * C::DY_ROW + g * 16) = dyr[i];
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(WgParams p) {
     auto load_x = [&](int y) {  // X row y (may be -1 or H: zeros), strip columns plus one group each side
 #pragma unroll
         for (int i = 0; i < C::NX; ++i) {
-            const int c = tid + i * 512;
+            const int c = tid + i * C::THREADS;
             if (c < C::X_CHUNKS) {
                 const int ch = c / (C::SW / 8 + 2), g = c % (C::SW / 8 + 2);
                 const bool ok = y >= 0 && y < p.H && ci_t * C::NT + ch < p.Cin;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(WgParams p) {
         const int slot = (y + 1) & 3;
 #pragma unroll
         for (int i = 0; i < C::NX; ++i) {
-            const int c = tid + i * 512;
+            const int c = tid + i * C::THREADS;
             if (c < C::X_CHUNKS) {
                 const int ch = c / (C::SW / 8 + 2), g = c % (C::SW / 8 + 2);
                 *reinterpret_cast<uint4*>(x_lds + ch * C::X_CI + (slot * C::XR_UNITS + g) * 16) = xr[i];
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_kernel(WgParams p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) red[((wk * NP + pair) * 16 + i) * 64 + lane] = acc[t][i];
             __syncthreads();
-            for (int e = tid; e < NP * 1024; e += 512) {
+            for (int e = tid; e < NP * 1024; e += C::THREADS) {
                 const int pr = e >> 10, i = (e >> 6) & 15, ln = e & 63;
                 float sum = 0.f;
 #pragma unroll
@@ -454,10 +456,15 @@ int launch_pw(const PwParams& p, int units, bool aligned, hipStream_t st) {
     return 0;
 }
 
-struct WgPlan { int wm, wn, ks, strips, row_blocks, rows_per_block, co_tiles, ci_tiles, units, partials; int64_t slab_bytes; };
+struct WgPlan { int wm, wn, ks, nwv, strips, row_blocks, rows_per_block, co_tiles, ci_tiles, units, partials; int64_t slab_bytes; };
 
 bool wgrad_plan(int batch, int cin, int cout, int h, int w, int64_t workspace_bytes, WgPlan* pl) {
     if (cin % 8 || cin < 16) return false;
+    // SIS_WGRAD_WAVES: 8 / 4 force the 8-wave tiles / the 4-wave 64 x 64 tile (two workgroups per CU) wherever it applies; default:
+    // the 4-wave tile only where the 8-wave one wastes half its 128 input channels (64 -> 64 layers on aligned maps: 114 -> 84 us
+    // at 256 x 256; every wider layer measured 5-20 % SLOWER on 64 x 64 tiles -- the X rows are staged twice as often)
+    static const int waves = getenv("SIS_WGRAD_WAVES") ? atoi(getenv("SIS_WGRAD_WAVES")) : 0;
+    pl->nwv = 8;
     if (cout <= 32) {                 // narrow tail of the decoder: one co block, the spare waves split K
         pl->wm = 1;
         pl->wn = cin > 32 ? 2 : 1;
@@ -466,6 +473,7 @@ bool wgrad_plan(int batch, int cin, int cout, int h, int w, int64_t workspace_by
         pl->wm = cout >= 128 ? 4 : 2;
         pl->wn = 8 / pl->wm;
         pl->ks = w <= 32 ? 2 : 4;
+        if (waves == 4 || (waves == 0 && pl->wm == 2 && cin <= 64 && w % 8 == 0)) { pl->wm = 2; pl->wn = 2; pl->nwv = 4; }
     }
     const int sw = 16 * pl->ks;
     const int mt = 32 * pl->wm, nt = 32 * pl->wn;
@@ -475,7 +483,8 @@ bool wgrad_plan(int batch, int cin, int cout, int h, int w, int64_t workspace_by
     const int tiles = pl->co_tiles * pl->ci_tiles;
     // row blocks: enough workgroups to fill the chip (~2 per CU), at least 8 rows each, slabs within the workspace
     int rbk = 1;
-    while (rbk < h / 8 && (int64_t)batch * pl->strips * rbk * tiles < 512 &&
+    static const int min_wg = getenv("SIS_WGRAD_MINWG") ? atoi(getenv("SIS_WGRAD_MINWG")) : 512;
+    while (rbk < h / 8 && (int64_t)batch * pl->strips * rbk * tiles < min_wg &&
            (int64_t)batch * pl->strips * (rbk * 2) * tile_bytes <= workspace_bytes) rbk *= 2;
     pl->rows_per_block = sis_cdiv(h, rbk);
     pl->row_blocks = sis_cdiv(h, pl->rows_per_block);
@@ -498,9 +507,9 @@ int launch_wgrad(const WgParams& p, int units, hipStream_t st, const char* name)
         attr_set = true;
     }
     dim3 grid(units, p.co_tiles * p.ci_tiles);
-    SIS_OCC_REPORT((conv_wgrad_bf16_kernel<C, true>), 512, C::LDS);
-    if (p.aligned) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<C, true>), grid, dim3(512), C::LDS, st, p);
-    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<C, false>), grid, dim3(512), C::LDS, st, p);
+    SIS_OCC_REPORT((conv_wgrad_bf16_kernel<C, true>), C::THREADS, C::LDS);
+    if (p.aligned) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<C, true>), grid, dim3(C::THREADS), C::LDS, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<C, false>), grid, dim3(C::THREADS), C::LDS, st, p);
     SIS_CHECK_LAUNCH(name);
     sis_kernel_name = name;
     return 0;
@@ -530,7 +539,9 @@ extern "C" int sis_conv_bf16_wgrad(void* dw, int dw_dtype, const void* x, const 
     p.aligned = (w % 8 == 0) && ((((uintptr_t)x) | ((uintptr_t)grad_y)) & 15) == 0;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (pl.wm == 4 && pl.ks == 4) rc = launch_wgrad<WgCfg<4, 2, 4>>(p, pl.units, st, "conv_wgrad_bf16_kernel<4,2,4>");
+    if (pl.nwv == 4 && pl.ks == 4) rc = launch_wgrad<WgCfg<2, 2, 4, 4>>(p, pl.units, st, "conv_wgrad_bf16_kernel<2,2,4,4>");
+    else if (pl.nwv == 4) rc = launch_wgrad<WgCfg<2, 2, 2, 4>>(p, pl.units, st, "conv_wgrad_bf16_kernel<2,2,2,4>");
+    else if (pl.wm == 4 && pl.ks == 4) rc = launch_wgrad<WgCfg<4, 2, 4>>(p, pl.units, st, "conv_wgrad_bf16_kernel<4,2,4>");
     else if (pl.wm == 4 && pl.ks == 2) rc = launch_wgrad<WgCfg<4, 2, 2>>(p, pl.units, st, "conv_wgrad_bf16_kernel<4,2,2>");
     else if (pl.wm == 2 && pl.ks == 4) rc = launch_wgrad<WgCfg<2, 4, 4>>(p, pl.units, st, "conv_wgrad_bf16_kernel<2,4,4>");
     else if (pl.wm == 2) rc = launch_wgrad<WgCfg<2, 4, 2>>(p, pl.units, st, "conv_wgrad_bf16_kernel<2,4,2>");

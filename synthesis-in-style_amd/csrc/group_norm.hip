@@ -94,7 +94,10 @@ __device__ __forceinline__ void gn_bwd_row(int row, int lane, int lanes, float* 
 
 struct GnFinish {   // counters == nullptr: no merge in the statistics kernel
     int* counters; float* mean; float* rstd; float* ab; const float* gamma; const float* beta; int groups, cpg; float eps;
+    // batch-norm mode (bn_batch > 0, groups = C): one counter per CHANNEL, bn_batch * slices arrivals
+    int bn_batch = 0; float* running_mean = nullptr; float* running_var = nullptr; float momentum = 0.f;
 };
+__device__ __forceinline__ void bn_chan_finish_wave(int c, int lane, const GnFinish& f, const float* __restrict__ part, int S);
 
 template <typename TI, int VEC>
 __global__ __launch_bounds__(256) void gn_plane_stats_kernel(float* __restrict__ part, const TI* __restrict__ x, int hw,
@@ -124,11 +127,48 @@ __global__ __launch_bounds__(256) void gn_plane_stats_kernel(float* __restrict__
         float* o = part + 3 * ((int64_t)blockIdx.x * gridDim.y + blockIdx.y);
         xwg_publish(o, cnt); xwg_publish(o + 1, mean); xwg_publish(o + 2, m2);
     }
-    if (fin.counters) {
+    if (fin.counters && fin.bn_batch) {   // batch norm: plane = sample * C + channel
+        const int c = (int)(blockIdx.x % fin.groups);
+        if (xwg_complete<false>(fin.counters + c, fin.bn_batch * gridDim.y) && threadIdx.x < 64)
+            bn_chan_finish_wave(c, threadIdx.x, fin, part, gridDim.y);
+    } else if (fin.counters) {
         const int row = blockIdx.x / fin.cpg;
         if (xwg_complete<false>(fin.counters + row, fin.cpg * gridDim.y) && threadIdx.x < 64)
             gn_row_finish(row, threadIdx.x, 64, fin.mean, fin.rstd, fin.ab, part, fin.gamma, fin.beta, fin.groups, fin.cpg, gridDim.y, fin.eps);
     }
+}
+
+// bn_chan_finish_kernel's work for ONE channel by the wave that completed it: 64 partial results per round trip to memory,
+// merged in the same (sample, slice) order as the kernel below.
+__device__ __forceinline__ void bn_chan_finish_wave(int c, int lane, const GnFinish& f, const float* __restrict__ part, int S) {
+    const int C = f.groups, total = f.bn_batch * S;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int j0 = 0; j0 < total; j0 += 64) {
+        const int j = j0 + lane, cnt = min(64, total - j0);
+        float pn = 0.f, pm = 0.f, p2 = 0.f;
+        if (j < total) {
+            const int b = j / S, k = j - b * S;
+            const float* p = part + 3 * (((int64_t)b * C + c) * S + k);
+            pn = xwg_peek(p); pm = xwg_peek(p + 1); p2 = xwg_peek(p + 2);
+        }
+        for (int t = 0; t < cnt; ++t) {
+            const float nb = __shfl(pn, t, 64), mb = __shfl(pm, t, 64), m2b = __shfl(p2, t, 64);
+            const float nt = n + nb, delta = mb - mean;
+            mean += delta * (nb / nt);
+            m2 += m2b + delta * delta * (n * nb / nt);
+            n = nt;
+        }
+    }
+    const float rstd = rsqrtf(m2 / n + f.eps);
+    if (lane == 0) {
+        f.mean[c] = mean; f.rstd[c] = rstd;
+        if (f.running_mean) {
+            f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * mean;
+            f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (n > 1.f ? m2 / (n - 1.f) : m2 / n);
+        }
+    }
+    const float a = rstd * f.gamma[c], sh = f.beta[c] - mean * a;
+    for (int b = lane; b < f.bn_batch; b += 64) { f.ab[2 * ((int64_t)b * C + c)] = a; f.ab[2 * ((int64_t)b * C + c) + 1] = sh; }
 }
 
 // per (sample, channel): a = rstd_row * gamma_c, b = beta_c - mean_row * a  (the apply kernel's scale / shift).
@@ -233,6 +273,31 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(TO* __restrict__ y, TI* _
     }
 }
 
+// bn_bwd_chan_kernel's work for ONE channel by the wave that completed it (same (sample, slice) order of the sums)
+__device__ __forceinline__ void bn_bwd_chan_wave(int c, int lane, float* __restrict__ coef, float* __restrict__ dgamma,
+                                                 float* __restrict__ dbeta, const float* __restrict__ part,
+                                                 const float* __restrict__ rstd_in, const float* __restrict__ gamma, int batch, int C,
+                                                 int hw, int S) {
+    const int total = batch * S;
+    float s1 = 0.f, s2 = 0.f;
+    for (int j0 = 0; j0 < total; j0 += 64) {
+        const int j = j0 + lane, cnt = min(64, total - j0);
+        float a = 0.f, b2 = 0.f;
+        if (j < total) {
+            const int b = j / S, k = j - b * S;
+            const float* p = part + 2 * (((int64_t)b * C + c) * S + k);
+            a = xwg_peek(p); b2 = xwg_peek(p + 1);
+        }
+        for (int t = 0; t < cnt; ++t) { s1 += __shfl(a, t, 64); s2 += __shfl(b2, t, 64); }
+    }
+    if (lane == 0) { dbeta[c] = s1; dgamma[c] = s2; }
+    const float n = (float)batch * (float)hw, k1 = rstd_in[c] * gamma[c];
+    for (int b = lane; b < batch; b += 64) {
+        float* k = coef + 3 * ((int64_t)b * C + c);
+        k[0] = k1; k[1] = k1 * s1 / n; k[2] = k1 * s2 / n;
+    }
+}
+
 // ---- backward.  g' = g * [y > 0] (mask recomputed: y = x*a + b).  Per plane: sum(g'), sum(g' * xhat).
 template <typename TI, typename TG, int VEC>
 __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ part, const TG* __restrict__ g,
@@ -241,7 +306,8 @@ __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ p
                                                            const float* __restrict__ beta, const float* __restrict__ ymask, int C,
                                                            int cpg, int hw, int sl, int relu, int* __restrict__ counters,
                                                            float* __restrict__ coef, float* __restrict__ psum,
-                                                           const unsigned char* __restrict__ bits) {
+                                                           const unsigned char* __restrict__ bits, int bn_batch = 0,
+                                                           float* __restrict__ bn_dgamma = nullptr, float* __restrict__ bn_dbeta = nullptr) {
     __shared__ float red[4];
     const int64_t plane = blockIdx.x;
     const int c = (int)(plane % C);
@@ -281,7 +347,10 @@ __global__ __launch_bounds__(256) void gn_bwd_plane_kernel(float* __restrict__ p
         float* o = part + 2 * (plane * gridDim.y + blockIdx.y);
         xwg_publish(o, sg); xwg_publish(o + 1, sgx);
     }
-    if (counters) {   // (group-norm mode only: cpg > 0)
+    if (counters && cpg == 0) {   // batch norm: the channel's last workgroup does bn_bwd_chan_kernel's work
+        if (xwg_complete<false>(counters + c, bn_batch * gridDim.y) && threadIdx.x < 64)
+            bn_bwd_chan_wave(c, threadIdx.x, coef, bn_dgamma, bn_dbeta, part, rstd_in, gamma, bn_batch, C, hw, gridDim.y);
+    } else if (counters) {
         if (xwg_complete<false>(counters + row, cpg * gridDim.y) && threadIdx.x < 64)
             gn_bwd_row((int)row, threadIdx.x, 64, coef, psum, part, rstd_in, gamma, C / cpg, cpg, hw, gridDim.y);
     }
@@ -684,14 +753,15 @@ void gn_launch_stats(float* part, const void* x, int64_t planes, int hw, hipStre
 template <typename TI, typename TG>
 void gn_launch_bwd_plane(float* part, const void* g, const void* g_lp, const void* x, const float* mean, const float* rstd, const float* gamma,
                          const float* beta, const float* ymask, int64_t planes, int C, int cpg, int hw, int relu, hipStream_t st,
-                         int* counters = nullptr, float* coef = nullptr, float* psum = nullptr, const unsigned char* bits = nullptr) {
+                         int* counters = nullptr, float* coef = nullptr, float* psum = nullptr, const unsigned char* bits = nullptr,
+                         int bn_batch = 0, float* bn_dgamma = nullptr, float* bn_dbeta = nullptr) {
     const int S = gn_slices(hw), sl = gn_slice_len(hw);
     if (gn_aligned(x) && gn_aligned(g) && gn_aligned(g_lp) && gn_aligned(ymask))
         hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 4>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
-                           (const TI*)g_lp, (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu, counters, coef, psum, bits);
+                           (const TI*)g_lp, (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu, counters, coef, psum, bits, bn_batch, bn_dgamma, bn_dbeta);
     else
         hipLaunchKernelGGL((gn_bwd_plane_kernel<TI, TG, 1>), dim3((unsigned)planes, S), dim3(256), 0, st, part, (const TG*)g,
-                           (const TI*)g_lp, (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu, counters, coef, psum, bits);
+                           (const TI*)g_lp, (const TI*)x, mean, rstd, gamma, beta, ymask, C, cpg, hw, sl, relu, counters, coef, psum, bits, bn_batch, bn_dgamma, bn_dbeta);
 }
 
 template <typename TI, typename TO>
@@ -777,31 +847,43 @@ void gn_bwd_run(void* dx, float* dres, float* dgamma, float* dbeta, float* ws, c
 
 template <typename TI, typename TO>
 void bn_fwd_run(void* y, float* mean, float* rstd, float* rm, float* rv, float* ws, const void* x, const float* gamma,
-                const float* beta, int batch, int C, int hw, float eps, float momentum, int relu, hipStream_t st) {
+                const float* beta, int batch, int C, int hw, float eps, float momentum, int relu, int* counters, hipStream_t st) {
     const float* res = nullptr;
     const int64_t planes = (int64_t)batch * C, total = planes * hw;
     const int S = gn_slices(hw);
     float* ab = ws;
     float* part = ws + 5 * planes;
-    gn_launch_stats<TI>(part, x, planes, hw, st);
-    hipLaunchKernelGGL(bn_chan_finish_kernel, dim3(sis_cdiv(C, 64)), dim3(64), 0, st, mean, rstd, ab, rm, rv, part, gamma, beta,
-                       batch, C, S, eps, momentum);
+    if (counters) {   // the workgroup that completes a channel merges it (no launch of its own for C threads of work)
+        GnFinish fin{counters, mean, rstd, ab, gamma, beta, C, 0, eps};
+        fin.bn_batch = batch; fin.running_mean = rm; fin.running_var = rv; fin.momentum = momentum;
+        gn_launch_stats<TI>(part, x, planes, hw, st, fin);
+    } else {
+        gn_launch_stats<TI>(part, x, planes, hw, st);
+        hipLaunchKernelGGL(bn_chan_finish_kernel, dim3(sis_cdiv(C, 64)), dim3(64), 0, st, mean, rstd, ab, rm, rv, part, gamma, beta,
+                           batch, C, S, eps, momentum);
+    }
     GN_DISPATCH_APPLY(gn_apply_kernel, TI, TO, gn_aligned(x) && gn_aligned(y), (TO*)y, (TI*)nullptr, (const TI*)x, ab, res, hw, total,
                       relu, (unsigned char*)nullptr);
 }
 
 template <typename TI, typename TG>
 void bn_bwd_run(void* dx, float* dgamma, float* dbeta, float* ws, const void* g, const void* x, const float* mean,
-                const float* rstd, const float* gamma, const float* beta, int batch, int C, int hw, int relu, hipStream_t st) {
+                const float* rstd, const float* gamma, const float* beta, int batch, int C, int hw, int relu, int* counters,
+                hipStream_t st) {
     const int64_t planes = (int64_t)batch * C, total = planes * hw;
     const int S = gn_slices(hw);
     float* coef = ws + 2 * planes;
     float* part = ws + 5 * planes;
     const float* none = nullptr;
     float* no_dres = nullptr;
-    gn_launch_bwd_plane<TI, TG>(part, g, nullptr, x, mean, rstd, gamma, beta, none, planes, C, 0, hw, relu, st);
-    hipLaunchKernelGGL(bn_bwd_chan_kernel, dim3(sis_cdiv(C, 64)), dim3(64), 0, st, coef, dgamma, dbeta, part, rstd, gamma, batch,
-                       C, hw, S);
+    if (counters) {
+        gn_launch_bwd_plane<TI, TG>(part, g, nullptr, x, mean, rstd, gamma, beta, none, planes, C, 0, hw, relu, st, counters, coef, nullptr,
+                                    nullptr, batch, dgamma, dbeta);
+    } else {
+        gn_launch_bwd_plane<TI, TG>(part, g, nullptr, x, mean, rstd, gamma, beta, none, planes, C, 0, hw, relu, st);
+        hipLaunchKernelGGL(bn_bwd_chan_kernel, dim3(sis_cdiv(C, 64)), dim3(64), 0, st, coef, dgamma, dbeta, part, rstd, gamma, batch,
+                           C, hw, S);
+    }
     GN_DISPATCH_APPLY(gn_bwd_apply_kernel, TI, TG, gn_aligned(dx) && gn_aligned(g) && gn_aligned(x), (TI*)dx, (const TG*)g,
                       (const TI*)nullptr, (const TI*)x, coef, mean, rstd, gamma, beta, none, no_dres, C, 0, hw, total, relu, no_dres, no_dres,
                       none, batch, (const unsigned char*)nullptr);
@@ -876,7 +958,7 @@ extern "C" int sis_group_norm_bwd(void* dx, float* dresidual, float* dgamma, flo
 // statistics updated with `momentum` (unbiased variance), may be NULL.  Workspace as for group norm.
 extern "C" int sis_batch_norm_fwd(void* y, float* mean, float* rstd, float* running_mean, float* running_var, float* workspace,
                                   const void* x, const float* gamma, const float* beta, int x_dtype, int y_dtype, int batch,
-                                  int channels, int hw, float eps, float momentum, int relu, void* stream) {
+                                  int channels, int hw, float eps, float momentum, int relu, int* counters, void* stream) {
     if (batch == 0) return 0;
     SIS_REQUIRE(y && mean && rstd && workspace && x && gamma && beta, "sis_batch_norm_fwd: null pointer");
     SIS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sis_batch_norm_fwd: running statistics come in pairs");
@@ -884,8 +966,8 @@ extern "C" int sis_batch_norm_fwd(void* y, float* mean, float* rstd, float* runn
     SIS_REQUIRE(y_dtype == x_dtype || y_dtype == SIS_F32, "sis_batch_norm_fwd: output dtype must be the input's or f32");
     hipStream_t st = (hipStream_t)stream;
 #define BN_FWD(TI)                                                                                                        \
-    if (y_dtype == SIS_F32) bn_fwd_run<TI, float>(y, mean, rstd, running_mean, running_var, workspace, x, gamma, beta, batch, channels, hw, eps, momentum, relu, st); \
-    else bn_fwd_run<TI, TI>(y, mean, rstd, running_mean, running_var, workspace, x, gamma, beta, batch, channels, hw, eps, momentum, relu, st);
+    if (y_dtype == SIS_F32) bn_fwd_run<TI, float>(y, mean, rstd, running_mean, running_var, workspace, x, gamma, beta, batch, channels, hw, eps, momentum, relu, counters, st); \
+    else bn_fwd_run<TI, TI>(y, mean, rstd, running_mean, running_var, workspace, x, gamma, beta, batch, channels, hw, eps, momentum, relu, counters, st);
     switch (x_dtype) {
         case SIS_F32: BN_FWD(float) break;
         case SIS_F16: BN_FWD(__half) break;
@@ -899,7 +981,7 @@ extern "C" int sis_batch_norm_fwd(void* y, float* mean, float* rstd, float* runn
 
 extern "C" int sis_batch_norm_bwd(void* dx, float* dgamma, float* dbeta, float* workspace, const void* grad_y, const void* x,
                                   const float* mean, const float* rstd, const float* gamma, const float* beta, int x_dtype,
-                                  int g_dtype, int batch, int channels, int hw, int relu, void* stream) {
+                                  int g_dtype, int batch, int channels, int hw, int relu, int* counters, void* stream) {
     if (batch == 0) return 0;
     SIS_REQUIRE(dx && dgamma && dbeta && workspace && grad_y && x && mean && rstd && gamma && beta,
                 "sis_batch_norm_bwd: null pointer");
@@ -907,8 +989,8 @@ extern "C" int sis_batch_norm_bwd(void* dx, float* dgamma, float* dbeta, float* 
     SIS_REQUIRE(g_dtype == x_dtype || g_dtype == SIS_F32, "sis_batch_norm_bwd: gradient dtype must be the input's or f32");
     hipStream_t st = (hipStream_t)stream;
 #define BN_BWD(TI)                                                                                                        \
-    if (g_dtype == SIS_F32) bn_bwd_run<TI, float>(dx, dgamma, dbeta, workspace, grad_y, x, mean, rstd, gamma, beta, batch, channels, hw, relu, st); \
-    else bn_bwd_run<TI, TI>(dx, dgamma, dbeta, workspace, grad_y, x, mean, rstd, gamma, beta, batch, channels, hw, relu, st);
+    if (g_dtype == SIS_F32) bn_bwd_run<TI, float>(dx, dgamma, dbeta, workspace, grad_y, x, mean, rstd, gamma, beta, batch, channels, hw, relu, counters, st); \
+    else bn_bwd_run<TI, TI>(dx, dgamma, dbeta, workspace, grad_y, x, mean, rstd, gamma, beta, batch, channels, hw, relu, counters, st);
     switch (x_dtype) {
         case SIS_F32: BN_BWD(float) break;
         case SIS_F16: BN_BWD(__half) break;

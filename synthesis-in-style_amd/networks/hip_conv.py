@@ -460,6 +460,8 @@ _STRIDE2_OWN = os.environ.get('SIS_STRIDE2_OWN', '1') != '0'  # 0: stride-2 laye
 
 
 class HipConv2d(nn.Conv2d):
+    _banked = None   # (forward image, adjoint image or None) of the weight when a pack bank wrote them for this forward
+
     def _bf16(self, input):
         """Under bf16 autocast: the input is already bf16 (norm kernels write it) or is cast here, as autocast would."""
         if not (_BF16_CONV and input.is_cuda and self.padding_mode == 'zeros' and torch.is_autocast_enabled()
@@ -504,7 +506,7 @@ class HipConv2d(nn.Conv2d):
     def forward(self, input):
         x = self._bf16(input)
         if x is not None:
-            return conv_bf16(x, self.weight, self.bias, self.stride[0])
+            return conv_bf16(x, self.weight, self.bias, self.stride[0], prepacked=self._banked)
         y = self._stride2(input)
         if y is not None:
             return y

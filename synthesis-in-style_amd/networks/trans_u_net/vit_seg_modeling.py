@@ -10,7 +10,7 @@ head), ``npz_import.py`` (ImageNet-21k ``.npz`` weight import), this file (the a
 import torch
 
 from . import vit_seg_configs as configs
-from .cup_decoder import Conv2dReLU, DecoderBlock, DecoderCup, SegmentationHead  # noqa: F401
+from .cup_decoder import Conv2dReLU, DecoderBlock, DecoderCup, SegmentationHead, decoder_step_state  # noqa: F401
 from .vit_encoder import ACT2FN, Attention, Block, Embeddings, Encoder, Mlp, Transformer, swish  # noqa: F401
 from .vit_seg_configs import ConfigDict
 from .vit_seg_modeling_resnet_skip import np2th  # noqa: F401
@@ -35,7 +35,8 @@ class VisionTransformer(BaseSegmenter):
         if x.size(1) == 1:
             x = x.repeat(1, 3, 1, 1)
         x, _, features = self.transformer(x)
-        return self.segmentation_head(self.decoder(x, features))
+        with decoder_step_state(self):   # one launch packs every decoder / head weight, one bumps every batch-norm counter
+            return self.segmentation_head(self.decoder(x, features))
 
     def predict_classes(self, x: torch.Tensor) -> torch.Tensor:
         return torch.argmax(self.forward(x), dim=1, keepdim=True)

@@ -73,8 +73,8 @@ _SIGNATURES = {
     "sis_group_norm_fwd": ([_vp] * 9 + [_i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp], _i),
     "sis_group_norm_gate_bytes": ([_i, _i, _i], _i64),
     "sis_group_norm_workspace_floats": ([_i, _i, _i], _i64),
-    "sis_batch_norm_fwd": ([_vp] * 9 + [_i] * 5 + [_f, _f, _i, _vp], _i),
-    "sis_batch_norm_bwd": ([_vp] * 10 + [_i] * 6 + [_vp], _i),
+    "sis_batch_norm_fwd": ([_vp] * 9 + [_i] * 5 + [_f, _f, _i, _vp, _vp], _i),
+    "sis_batch_norm_bwd": ([_vp] * 10 + [_i] * 6 + [_vp, _vp], _i),
     "sis_group_norm_bwd": ([_vp] * 13 + [_i] * 7 + [_vp, _vp, _vp], _i),
     "sis_weight_std_bwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp], _i),
     "sis_conv3x3_wgrad_eligible": ([_i] * 5 + [_i64], _i),
@@ -1048,8 +1048,11 @@ class WeightStdPackBank:
     (``sis_weight_std_pack_multi``).  Output buffers are allocated once: ``w_hat[i]``, ``invstd[i]``, ``packed[i]``,
     ``adjoint[i]`` (None for layers without an adjoint image) keep their addresses, ``refresh()`` rewrites their contents."""
 
-    def __init__(self, weights, strides, eps):
+    def __init__(self, weights, strides, eps, standardize=True):
+        """``standardize=False``: plain layers (``nn.Conv2d`` of the decoder) -- the launch only rounds to bf16 and packs; ``w_hat``
+        / ``invstd`` are lists of None."""
         self.eps = float(eps)
+        self.standardize = bool(standardize)
         self.weights = list(weights)
         dev = self.weights[0].device
         self.w_hat, self.invstd, self.packed, self.adjoint = [], [], [], []
@@ -1061,12 +1064,13 @@ class WeightStdPackBank:
             if w.dtype != torch.float32 or not w.is_contiguous() or not lib().sis_weight_std_pack_plan(
                     cin, cout, k, stride, ctypes.byref(mt), ctypes.byref(kc), ctypes.byref(mt2), ctypes.byref(pe), ctypes.byref(ae)):
                 raise RuntimeError(f"WeightStdPackBank: no plan for a {cin}->{cout} k{k} s{stride} layer")
-            self.w_hat.append(torch.empty(w.shape, dtype=torch.bfloat16, device=dev))
-            self.invstd.append(torch.empty(cout, dtype=torch.float32, device=dev))
+            self.w_hat.append(torch.empty(w.shape, dtype=torch.bfloat16, device=dev) if standardize else None)
+            self.invstd.append(torch.empty(cout, dtype=torch.float32, device=dev) if standardize else None)
             self.packed.append(torch.empty(pe.value, dtype=torch.bfloat16, device=dev))
             self.adjoint.append(torch.empty(ae.value, dtype=torch.bfloat16, device=dev) if mt2.value else None)
             n_rows = -(-cout // mt.value) * mt.value
-            rows.append([w.data_ptr(), self.w_hat[-1].data_ptr(), self.invstd[-1].data_ptr(), self.packed[-1].data_ptr(),
+            rows.append([w.data_ptr(), self.w_hat[-1].data_ptr() if standardize else 0, self.invstd[-1].data_ptr() if standardize else 0,
+                         self.packed[-1].data_ptr(),
                          self.adjoint[-1].data_ptr() if mt2.value else 0, cout, cin, k, mt.value, kc.value, mt2.value, n_rows, row_begin,
                          filter_begin])
             row_begin += n_rows
@@ -1649,7 +1653,7 @@ def batch_norm_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentu
         _check(lib().sis_batch_norm_fwd(_ptr(y), _ptr(mean), _ptr(rstd), _ptr(running_mean), _ptr(running_var), _ptr(ws), _ptr(x),
                                         _ptr(_f32(gamma, "weight")), _ptr(_f32(beta, "bias")), _DTYPE_CODE[x.dtype],
                                         _DTYPE_CODE[out_dtype], b, c, hw, float(eps), float(momentum), int(bool(relu)),
-                                        _stream()), "sis_batch_norm_fwd")
+                                        _ptr(_group_counters(x.device, c)), _stream()), "sis_batch_norm_fwd")
     return y, mean, rstd
 
 
@@ -1667,7 +1671,7 @@ def batch_norm_train_bwd(grad_y, x, mean, rstd, gamma, beta, relu):
     with torch.cuda.device(x.device):
         _check(lib().sis_batch_norm_bwd(_ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _ptr(g), _ptr(x), _ptr(mean), _ptr(rstd),
                                         _ptr(gamma), _ptr(beta), _DTYPE_CODE[x.dtype], _DTYPE_CODE[g.dtype], b, c, hw,
-                                        int(bool(relu)), _stream()), "sis_batch_norm_bwd")
+                                        int(bool(relu)), _ptr(_group_counters(x.device, c)), _stream()), "sis_batch_norm_bwd")
     return dx, dgamma, dbeta
 
 

@@ -70,7 +70,7 @@ def test_conv_bf16_data_gradient(device, batch, cin, cout, h, w, k):
 
 
 @pytest.mark.parametrize("batch,cin,cout,h,w", [(2, 64, 128, 32, 32), (2, 128, 64, 64, 64), (1, 192, 64, 48, 48), (3, 256, 256, 16, 16),
-                                                (1, 64, 64, 127, 127), (2, 96, 160, 24, 40), (8, 64, 64, 128, 128),
+                                                (1, 64, 64, 127, 127), (2, 96, 160, 24, 40), (8, 64, 64, 128, 128), (2, 64, 64, 32, 32),
                                                 (2, 64, 16, 64, 64), (2, 16, 16, 48, 80), (1, 16, 3, 64, 200), (2, 128, 24, 40, 40)])
 def test_conv_bf16_weight_gradient(device, batch, cin, cout, h, w):
     """dL/dw on the pixel-contraction kernel (csrc/conv_bf16_wgrad.hip) against autograd of the fp32 convolution on the
@@ -182,3 +182,26 @@ def test_narrow_output_layer_backward(device, cin, cout, h, w):
     for got, want, tol in ((x.grad, xr.grad, 1e-2), (wt.grad, wr.grad, 2e-3), (bias.grad, br.grad, 1e-3)):
         assert got.shape == want.shape
         assert (got.float() - want).abs().max().item() <= tol * want.abs().max().item()
+
+
+def test_plain_pack_bank_writes_the_images_of_the_single_layer_pack(device):
+    """``WeightStdPackBank(standardize=False)`` (the decoder's and the head's weights, one launch per forward): every layer's
+    forward / adjoint image is bit for bit what ``conv_bf16_pack`` writes for that layer alone; layers without an adjoint plan
+    (3 output channels) get none."""
+    import sis_hip
+    gen = torch.Generator().manual_seed(3)
+    shapes = [(512, 768, 3), (256, 1024, 3), (64, 64, 3), (16, 64, 3), (3, 16, 3), (96, 128, 1)]
+    weights = [torch.randn(co, ci, k, k, generator=gen).to(device) for co, ci, k in shapes]
+    assert all(sis_hip.WeightStdPackBank.supported(w, 1) for w in weights)
+    bank = sis_hip.WeightStdPackBank(weights, [1] * len(weights), 0.0, standardize=False)
+    bank.refresh()
+    assert all(t is None for t in bank.w_hat) and all(t is None for t in bank.invstd)
+    for w, packed, adjoint in zip(weights, bank.packed, bank.adjoint):
+        assert torch.equal(packed, sis_hip.conv_bf16_pack(w, 64, 64, 1))
+        if w.shape[0] % (16 if w.shape[2] == 3 else 64) == 0:   # the adjoint contracts over Cout in chunks of 16 (3x3) / 64 (1x1)
+            assert adjoint is not None and torch.equal(adjoint, sis_hip.conv_bf16_pack(w, 64, 64, 1, adjoint=True))
+        else:
+            assert adjoint is None
+    weights[2].mul_(2.0)
+    bank.refresh()   # same buffers, new contents
+    assert torch.equal(bank.packed[2], sis_hip.conv_bf16_pack(weights[2], 64, 64, 1))

@@ -114,6 +114,7 @@ _MODULE_SWITCHES = [
     ("networks.hip_conv", "_PW_WGRAD_OWN", False, "trans_u_net"),         # SIS_PW_WGRAD_OWN
     ("networks.hip_conv", "_STRIDE2_OWN", False, "trans_u_net"),
     ("networks.trans_u_net.cup_decoder", "_FUSE_UP_CAT", False, "trans_u_net"),                   # SIS_FUSE_UP_CAT
+    ("networks.trans_u_net.cup_decoder", "_DECODER_BANK", False, "trans_u_net"),                  # SIS_DECODER_BANK
     ("networks.trans_u_net.vit_encoder", "_HIP_LN", False, "trans_u_net"),                        # SIS_HIP_LN
     ("networks.trans_u_net.vit_encoder", "_AMP_LINEAR", False, "trans_u_net"),                    # SIS_AMP_LINEAR
     ("networks.trans_u_net.vit_encoder", "_SHADOW", False, "trans_u_net"),                        # SIS_LINEAR_SHADOW
@@ -168,6 +169,7 @@ _C_SIDE = [
     ("SIS_WINO_XCD_MB", "0", "tests/test_generator_gpu.py::test_generator_vs_golden_small"),
     ("SIS_UPFIR_WAVES", "8", "tests/test_generator_gpu.py::test_modconv_up_fir_vs_oracle"),   # the one-workgroup-per-CU tile ...
     ("SIS_UPFIR_PIPE", "0", "tests/test_generator_gpu.py::test_modconv_up_fir_vs_oracle"),    # ... and its unpipelined loop
+    ("SIS_WGRAD_WAVES", "4", "tests/test_conv_bf16_gpu.py::test_conv_bf16_weight_gradient"),   # 64 x 64 tiles, two workgroups per CU, everywhere
     ("SIS_GN_SINGLE_PASS", "0", "tests/test_upsample_gpu.py"),
     ("SIS_UP2_DIRECT", "0", "tests/test_upsample_gpu.py"),
     ("SIS_PW_KC", "32", "tests/test_conv1x1_f32_gpu.py"),

@@ -261,10 +261,15 @@ def test_group_norm_single_pass_groups(device, shape, groups, residual, monkeypa
     np.testing.assert_allclose(got[5].cpu().numpy(), br.grad.float().cpu().numpy(), rtol=1e-3, atol=1e-3 * float(br.grad.abs().max()))
 
 
-@pytest.mark.parametrize("shape,relu", [((4, 16, 12, 12), True), ((2, 64, 33, 31), False), ((8, 256, 16, 16), True)])
-def test_batch_norm_train_relu(device, shape, relu):
-    """Batch-norm mode of csrc/group_norm.hip against F.batch_norm(training=True) (+ relu), incl. running statistics."""
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("shape,relu", [((4, 16, 12, 12), True), ((2, 64, 33, 31), False), ((8, 256, 16, 16), True), ((3, 16, 128, 160), True),
+                                        ((70, 8, 64, 64), False)])
+def test_batch_norm_train_relu(device, monkeypatch, shape, relu, fused):
+    """Batch-norm mode of csrc/group_norm.hip against F.batch_norm(training=True) (+ relu), incl. running statistics; the
+    per-channel merges inside the statistics launches (``fused``: the workgroup that completes a channel, csrc/sis_xwg.h) or
+    as launches of their own -- planes cut into several slices, and more samples than the 64 lanes of the merging wave."""
     import sis_hip
+    monkeypatch.setattr(sis_hip, "_GN_FUSED_FINISH", fused)
     g = torch.Generator().manual_seed(shape[1] + shape[2])
     x = (torch.randn(*shape, generator=g) * 1.5 - 0.3).to(device)
     c = shape[1]
@@ -289,6 +294,7 @@ def test_batch_norm_train_relu(device, shape, relu):
     yb, _, _ = sis_hip.batch_norm_train_fwd(x.bfloat16(), gamma, beta, None, None, 1e-5, 0.1, relu)
     assert yb.dtype == torch.bfloat16
     np.testing.assert_allclose(yb.float().cpu().numpy(), ref.detach().float().cpu().numpy(), rtol=3e-2, atol=3e-2)
+    assert sis_hip.group_counters_are_zero()
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 12, 12), (2, 64, 9, 7), (1, 64, 3, 3)])

@@ -52,8 +52,8 @@ def main():
             gf = 2.0 * B * cout * cin * 9 * h * w / 1e9
             t_mine = timeit(lambda: sis_hip.conv_bf16_wgrad(x, gy, torch.float32))
             kern = sis_hip.lib().sis_last_kernel().decode()
-            t_lib = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, wt, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                                       (False, True, False)))
+            t_lib = float("nan") if os.environ.get("SIS_BENCH_NO_LIB") else timeit(
+                lambda: torch.ops.aten.convolution_backward(gy, x, wt, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False)))
             tot_mine += t_mine
             tot_lib += t_lib
             print(f"{name:18s} {gf:7.1f} {t_mine:8.3f} {gf / t_mine:7.1f} {t_lib:8.3f} {gf / t_lib:7.1f}  {kern}", flush=True)
