@@ -354,6 +354,127 @@ __global__ __launch_bounds__(256) void kmeans_fast_kernel(int64_t* __restrict__ 
     }
 }
 
+
+// First pass on the matrix cores (the shapes of the generator's catalogued layers: HW % 128 == 0, C % 16 == 0, K <= 32).
+// argmin_k |x - c_k|^2 = argmin_k (|c_k|^2 - 2 x.c_k): the dot products are a GEMM  S[k][pixel] = sum_c centres[k][c] x[c][pixel]
+// whose B operand is the NCHW activation as it lies in memory -- v_mfma_f32_32x32x2_f32 (exact fp32 products and sums) takes
+// B[k = channel][n = pixel] one float per lane, so a lane's 16-byte load of FOUR consecutive pixels of channel c0 + (lane >> 5)
+// feeds four 32-pixel column tiles (pixel 4 n + j of the wave's 128 in tile j).  The VALU pass above spends 2 K operations per
+// element (28 TF/s, 2.4 TB/s on 2.7 GB of activations per batch of 32); this one is bound by the read of x.
+// Decision rule: with S computed by a chain of C/2 MFMAs every product passes through at most C additions, so
+//     |d_fast_k - (D_k - |x|^2)| <= (C + 3) u (|x|^2 + 2 |c_k|^2)      (2 sum|x c| <= |x|^2 + |c_k|^2;  |c_k|^2 summed in fp32)
+// and the exact-order kernel's |d_exact - D| <= (C/32 + 32) u D <= (C/32 + 32) u 2 (|x|^2 + |c_k|^2).  A pixel whose two smallest
+// fast values differ by more than e_x |x|^2 + e_c max|c|^2 (twice the sum of both bounds, x 1.5) has the same argmin in exact
+// order and gets its label here; every other pixel (near-ties, NaN) is listed for kmeans_refine_kernel as before.
+typedef float km_f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void kmeans_mfma_kernel(int64_t* __restrict__ labels, const float* __restrict__ x,
+                                                          const float* __restrict__ centres, int C, int HW, int K, int tiles,
+                                                          float e_x, float e_c, int* __restrict__ open_count,
+                                                          int* __restrict__ open_list) {
+    extern __shared__ __attribute__((aligned(16))) float cen[];  // [C][32] centres (zero beyond K), [8][32] partial / [32] squared norms
+    float* ccp = cen + C * 32;
+    float* ccl = ccp + 8 * 32;
+    // Workgroups are persistent over the wave tiles (128 pixels each): the centres are staged and their norms summed once per
+    // workgroup, not once per 512 pixels (at 128 channels that prologue was a quarter of a workgroup's time).
+    for (int e = threadIdx.x; e < C * 32; e += 256) {
+        const int c = e >> 5, k = e & 31;
+        cen[e] = k < K ? centres[(int64_t)k * C + c] : 0.f;
+    }
+    __syncthreads();
+    {   // |c_k|^2: eight interleaved partial sums per centre, added in order
+        const int k = threadIdx.x & 31, part = threadIdx.x >> 5;
+        float s = 0.f;
+        for (int c = part; c < C; c += 8) s = fmaf(cen[c * 32 + k], cen[c * 32 + k], s);
+        ccp[part * 32 + k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float s = 0.f;
+        for (int p = 0; p < 8; ++p) s += ccp[p * 32 + threadIdx.x];
+        ccl[threadIdx.x] = s;
+    }
+    __syncthreads();
+    float ccmax = 0.f;
+    for (int k = 0; k < K; ++k) ccmax = fmaxf(ccmax, ccl[k]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+    const float* ab = cen + half * 32 + l31;
+    const int tiles_per_sample = HW >> 7;   // HW % 128 == 0: a wave tile lies inside one sample
+    constexpr int U = 16;   // MFMA steps (2 channels each) per register set: 16 KB of x in flight per wave
+    for (int t = blockIdx.x * 4 + wave; t < tiles; t += gridDim.x * 4) {
+        const int b = t / tiles_per_sample, pix0 = (t - b * tiles_per_sample) << 7;
+        const float* xb = x + ((int64_t)b * C + half) * HW + pix0 + 4 * l31;
+        km_f32x16 acc[4];
+        float xx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+        km_f32x4 xs[2][U];
+        auto request = [&](auto setc, int c0) {
+            constexpr int S = decltype(setc)::value;
+#pragma unroll
+            for (int s = 0; s < U; ++s) xs[S][s] = *reinterpret_cast<const km_f32x4*>(xb + (int64_t)(c0 + 2 * s) * HW);
+        };
+        auto block = [&](auto setc, int c0) {
+            constexpr int S = decltype(setc)::value;
+            request(std::integral_constant<int, S ^ 1>(), c0 + 2 * U < C ? c0 + 2 * U : c0);   // (past the end: this block again, unused)
+#pragma unroll
+            for (int s = 0; s < U; ++s) {
+                const float a = ab[(c0 + 2 * s) * 32];
+                const km_f32x4 v = xs[S][s];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v.y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v.z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v.w, acc[3], 0, 0, 0);
+                xx[0] = fmaf(v.x, v.x, xx[0]); xx[1] = fmaf(v.y, v.y, xx[1]); xx[2] = fmaf(v.z, v.z, xx[2]); xx[3] = fmaf(v.w, v.w, xx[3]);
+            }
+        };
+        request(std::integral_constant<int, 0>(), 0);
+        for (int c0 = 0; c0 < C; c0 += 4 * U) {   // C % 64 == 0 (host-checked)
+            block(std::integral_constant<int, 0>(), c0);
+            block(std::integral_constant<int, 1>(), c0 + 2 * U);
+        }
+        int64_t lab[4];
+        bool open[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xxj = xx[j] + __shfl_xor(xx[j], 32, 64);
+            float d1 = __builtin_inff(), d2 = __builtin_inff();
+            int arg = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = (i & 3) + 8 * (i >> 2) + 4 * half;   // this register's centre
+                if (k < K) {
+                    const float d = ccl[k] - 2.f * acc[j][i];
+                    if (d < d1) { d2 = d1; d1 = d; arg = k; }
+                    else if (!(d >= d2)) d2 = d;   // (a NaN lands in d2: the pixel stays open)
+                }
+            }
+            const float p1 = __shfl_xor(d1, 32, 64), p2 = __shfl_xor(d2, 32, 64);
+            const int pa = __shfl_xor(arg, 32, 64);
+            float best, second;
+            int narg;
+            if (p1 < d1) { best = p1; narg = pa; second = d1; if (!(p2 >= second)) second = p2; }
+            else { best = d1; narg = arg; second = p1; if (!(d2 >= second)) second = d2; }
+            const bool sure = K == 1 || (second - best > e_x * xxj + e_c * ccmax);   // false for near-ties, exact ties and NaN
+            lab[j] = sure ? narg : -1;
+            open[j] = !sure;
+        }
+        if (half == 0) {
+            int64_t* out = labels + (int64_t)b * HW + pix0 + 4 * l31;
+            typedef long long km_i64x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<km_i64x2*>(out) = km_i64x2{lab[0], lab[1]};
+            *reinterpret_cast<km_i64x2*>(out + 2) = km_i64x2{lab[2], lab[3]};
+            if (open_list) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (open[j]) open_list[atomicAdd(open_count, 1)] = b * HW + pix0 + 4 * l31 + j;   // (order irrelevant: one pixel per entry)
+            }
+        }
+    }
+}
+
 // Exact-order distances of the LISTED pixels (those kmeans_fast_kernel left open), 32 lanes per pixel: in the documented order
 // a pixel's sum is 8 x 4 independent running sums p[l][part] over the rows r (channel 32 r + 8 part + l), combined as
 // ((p0 + p1) + p2) + p3 per l and then over l = 0..7 in order -- so lane 8 part + l keeps one running sum per centre (C / 32
@@ -365,24 +486,39 @@ __global__ __launch_bounds__(256) void kmeans_refine_kernel(int64_t* __restrict_
                                                             const float* __restrict__ centres, int C, int HW, int K,
                                                             const int* __restrict__ open_count, const int* __restrict__ open_list) {
 #pragma clang fp contract(off)
+    // Latency, not work, is what this pass costs (a few hundred to a few thousand pixels per layer): a workgroup with pixels to
+    // visit copies the centres to LDS once (16-byte loads, all in flight together), and a pixel's C / 32 activation loads are all
+    // requested before the first subtraction -- two memory round trips per trip instead of one per row of 25 dependent loads
+    // (measured 31-113 us per layer before, with at most one trip per workgroup).
+    extern __shared__ __attribute__((aligned(16))) float cl[];   // [K][C]
     const int n_open = *open_count;
+    if ((int)blockIdx.x * 8 >= n_open) return;
+    for (int e = threadIdx.x * 4; e < K * C; e += 1024) *reinterpret_cast<float4*>(cl + e) = *reinterpret_cast<const float4*>(centres + e);
+    __syncthreads();
+    constexpr int RMAX = 16;   // rows of 32 channels held in registers (C <= 512: the shapes the first pass takes)
+    const int rows = C >> 5;
     for (int i = blockIdx.x * 8 + (threadIdx.x >> 5); i < n_open; i += gridDim.x * 8) {   // 8 pixels per workgroup and trip
     const int q = open_list[i];
     const int b = q / HW, pix = q - b * HW;
     const int ln = threadIdx.x & 31;                      // = 8 part + l: channel 32 r + ln in row r
     const float* xp = x + (int64_t)b * C * HW + pix;
+    float xr[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) xr[r] = r < rows ? xp[(int64_t)((r << 5) + ln) * HW] : 0.f;
     float acc[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
-    const int rows = C >> 5;
-    for (int r = 0; r < rows; ++r) {
-        const int c = (r << 5) + ln;
-        const float xv = xp[(int64_t)c * HW];
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            if (k < K) {
-                const float diff = xv - centres[(int64_t)k * C + c];
-                acc[k] = acc[k] + diff * diff;
+    for (int r = 0; r < RMAX; ++r) {
+        if (r < rows) {
+            const int c = (r << 5) + ln;
+            const float xv = xr[r];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                if (k < K) {
+                    const float diff = xv - cl[k * C + c];
+                    acc[k] = acc[k] + diff * diff;
+                }
             }
         }
     }
@@ -512,6 +648,7 @@ int launch_kmeans_fast(int64_t* labels, const float* x, const float* centres, in
     hipLaunchKernelGGL((kmeans_fast_kernel<KMAX>), dim3(batch * groups), dim3(256), lds, st, labels, x, centres, C, HW, K, groups, thr,
                        open_count, open_list);
     SIS_CHECK_LAUNCH("kmeans_fast_kernel");
+    sis_kernel_name = "kmeans_fast_kernel";
     return 0;
 }
 
@@ -562,18 +699,49 @@ static int kmeans_assign_impl(int64_t* labels, const float* x, const float* cent
         int* list = listed ? workspace + 1 : nullptr;
         if (listed && hipMemsetAsync(count, 0, sizeof(int), st) != hipSuccess) return sis_fail("sis_kmeans_assign: cannot clear the counter");
         int rc;
+        // matrix-core first pass where it applies (SIS_KMEANS_MFMA=0: the VALU first pass); it needs the list for its open pixels
+        const char* mfma_env = getenv("SIS_KMEANS_MFMA");   // (read per call, like SIS_KMEANS_FAST)
+        const bool mfma_on = !(mfma_env && mfma_env[0] == '0');
+        if (mfma_on && listed && hw % 128 == 0 && channels % 64 == 0 && (((uintptr_t)x) & 15) == 0 &&
+            (size_t)(channels + 9) * 32 * sizeof(float) <= (size_t)KM_LDS_MAX) {
+            const float b_fast = 1.01f * (channels + 3.f), b_exact = 2.f * (channels / 32.f + 32.f);
+            const float e_x = 1.5f * 2.f * (b_fast + b_exact) * u, e_c = 1.5f * 2.f * (2.f * b_fast + b_exact) * u;
+            static bool mfma_attr = false;
+            if (!mfma_attr) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&kmeans_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        KM_LDS_MAX) != hipSuccess)
+                    return sis_fail("sis_kmeans_assign: cannot raise the LDS limit");
+                mfma_attr = true;
+            }
+            const int64_t tiles = (int64_t)batch * (hw / 128);   // wave tiles of 128 pixels; workgroups persistent over them
+            SIS_REQUIRE(tiles < ((int64_t)1 << 31), "sis_kmeans_assign: too many pixels");
+            const int blocks = (int)std::min<int64_t>(sis_cdiv(tiles, 4), 512);
+            hipLaunchKernelGGL(kmeans_mfma_kernel, dim3(blocks), dim3(256), (size_t)(channels + 9) * 32 * sizeof(float), st, labels, x,
+                               centres, channels, hw, n_centres, (int)tiles, e_x, e_c, count, list);
+            SIS_CHECK_LAUNCH("kmeans_mfma_kernel");
+            sis_kernel_name = "kmeans_mfma_kernel";
+            rc = 0;
+        } else
         if (n_centres <= 8) rc = launch_kmeans_fast<8>(labels, x, centres, batch, channels, hw, n_centres, thr, count, list, st);
         else if (n_centres <= 16) rc = launch_kmeans_fast<16>(labels, x, centres, batch, channels, hw, n_centres, thr, count, list, st);
         else if (n_centres <= 24) rc = launch_kmeans_fast<24>(labels, x, centres, batch, channels, hw, n_centres, thr, count, list, st);
         else rc = launch_kmeans_fast<32>(labels, x, centres, batch, channels, hw, n_centres, thr, count, list, st);
         if (rc) return rc;
         refine = listed ? 3 : 1;
-        if (listed && channels % 32 == 0) {   // 32 lanes per open pixel
+        if (listed && channels % 32 == 0 && (((uintptr_t)centres) & 15) == 0) {   // 32 lanes per open pixel, centres in LDS
             const int blocks = (int)std::min<int64_t>(sis_cdiv((int64_t)batch * hw, 8), 1024);   // (the list is short: 262 144 empty workgroups took 170 us)
+            const size_t cl_bytes = (size_t)n_centres * channels * sizeof(float);   // <= 32 x 512 floats
 #define KM_LIST(KM)                                                                                                              \
     if (n_centres <= KM) {                                                                                                       \
-        hipLaunchKernelGGL(kmeans_refine_kernel<KM>, dim3(blocks), dim3(256), 0, st, labels, x, centres, channels, hw, n_centres, \
-                           (const int*)count, (const int*)list);                                                                 \
+        static bool attr = false;                                                                                                \
+        if (!attr) {                                                                                                             \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&kmeans_refine_kernel<KM>),                                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, KM_LDS_MAX) != hipSuccess)                       \
+                return sis_fail("sis_kmeans_assign: cannot raise the LDS limit");                                                \
+            attr = true;                                                                                                         \
+        }                                                                                                                        \
+        hipLaunchKernelGGL(kmeans_refine_kernel<KM>, dim3(blocks), dim3(256), cl_bytes, st, labels, x, centres, channels, hw,    \
+                           n_centres, (const int*)count, (const int*)list);                                                      \
         SIS_CHECK_LAUNCH("kmeans_refine_kernel");                                                                                \
         return 0;                                                                                                                \
     }

@@ -56,9 +56,12 @@ def test_kmeans_assign_matches_reference_fixture(device, golden_dir):
         assert torch.equal(got, torch.from_numpy(g[f"labels{i}"].astype(np.int64))), f"case {i} {mk.CASES[i]}"
 
 
-@pytest.mark.parametrize("b,c,h,w,k", [(4, 512, 64, 64, 24), (2, 128, 256, 256, 24), (3, 48, 30, 34, 32), (2, 16, 64, 64, 8)])
-def test_kmeans_fast_pass_plus_exact_refinement(device, b, c, h, w, k, monkeypatch):
-    """The two-pass form (fast distances decide the pixels whose argmin cannot depend on the order of the adds, the exact-order
+@pytest.mark.parametrize("mfma", ["1", "0"])
+@pytest.mark.parametrize("b,c,h,w,k", [(4, 512, 64, 64, 24), (2, 128, 256, 256, 24), (3, 48, 30, 34, 32), (2, 16, 64, 64, 8), (2, 64, 16, 24, 32),
+                                       (1, 512, 32, 32, 1), (2, 32, 16, 16, 3)])
+def test_kmeans_fast_pass_plus_exact_refinement(device, b, c, h, w, k, mfma, monkeypatch):
+    """(``mfma``: the first pass on the matrix cores -- csrc/dataset_ops.hip kmeans_mfma_kernel, HW % 128 == 0 and C % 32 == 0 -- or
+    the VALU one.)  The two-pass form (fast distances decide the pixels whose argmin cannot depend on the order of the adds, the exact-order
     kernel revisits the rest) returns the label map of the exact-order kernel alone, bit for bit: unit-variance activations at
     the generator's key shapes (few open pixels), plus pixels planted exactly between two centres and on top of a duplicated
     centre (open by construction), plus a NaN pixel."""
@@ -73,10 +76,14 @@ def test_kmeans_fast_pass_plus_exact_refinement(device, b, c, h, w, k, monkeypat
         x[-1, :, h - 1, w - 1] = centres[k - 1] * (1 + 1e-7)
         x[0, 0, 1, 1] = float("nan")
     xd, cd = x.to(device), centres.to(device)
+    monkeypatch.setenv("SIS_KMEANS_MFMA", mfma)
     monkeypatch.setenv("SIS_KMEANS_FAST", "0")
     exact = sis_hip.kmeans_assign(xd, cd)
     monkeypatch.setenv("SIS_KMEANS_FAST", "1")
     two_pass = sis_hip.kmeans_assign(xd, cd)
+    first_pass = sis_hip.lib().sis_last_kernel().decode()
+    takes_mfma = mfma == "1" and (h * w) % 128 == 0 and c % 64 == 0
+    assert first_pass == ("kmeans_mfma_kernel" if takes_mfma else "kmeans_fast_kernel"), first_pass
     assert torch.equal(two_pass, exact)
     assert int(two_pass.min()) >= 0 and int(two_pass.max()) < k
     if k >= 4:
