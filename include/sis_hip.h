@@ -304,6 +304,10 @@ int sis_conv3x3_prepack(float* u, const float* w, int cout, int cin, int adjoint
 /* forward and adjoint images of w [cout][cin][3][3] from one launch (training: the backward of the same step needs the adjoint):
  * u [cin][16][cout], u_adjoint [cout][16][cin]. */
 int sis_conv3x3_prepack_both(float* u, float* u_adjoint, const float* w, int cout, int cin, void* stream);
+/* Forward and adjoint images of SEVERAL layers from one launch.  `table`: device array of n_layers rows of 6 int64 --
+ * (w pointer [cout][cin][3][3] float32, u pointer, u_adjoint pointer, cout, cin, first block of the layer) with
+ * blocks per layer = ceil(cout * cin / 256); total_blocks = their sum. */
+int sis_conv3x3_prepack_multi(const void* table, int n_layers, int total_blocks, void* stream);
 int sis_conv3x3(float* out, const float* x, const float* u, int batch, int cin, int cout, int h, int w,
                 void* workspace, int64_t workspace_bytes, void* stream);
 

@@ -19,6 +19,7 @@ Differences in execution:
   profiles/r02_z_emanet_step_breakdown.txt).
 """
 import math
+import contextlib
 import os
 import pathlib
 from functools import partial
@@ -141,8 +142,12 @@ class Bottleneck(nn.Module):
             shortcut = x if self.downsample is None else self.downsample(x)
             y = self.conv1(x)
         y = self.bn1(y, relu=True)
-        y = self.bn2(conv3x3(y, self.conv2.weight, 1) if sub_images else self.conv2(y), relu=True)
+        y = self.bn2(self._conv2_on_sub_images(y) if sub_images else self.conv2(y), relu=True)
         return self.bn3(self.conv3(y), residual=shortcut, relu=True)
+
+    def _conv2_on_sub_images(self, y):
+        self.conv2._takes_wino = True
+        return conv3x3(y, self.conv2.weight, 1, self.conv2._wino_banked)
 
     def sub_image_eligible(self, x):
         """The unit can run on the sub-image arrangement of x: a stride-1 dilated fp32 unit whose 3x3 layer the Winograd kernel
@@ -337,6 +342,33 @@ class CrossEntropyLoss2d(nn.Module):
         return self.nll_loss(F.log_softmax(inputs, dim=1), targets).mean(dim=2).mean(dim=1)
 
 
+_WINO_BANK = os.environ.get('SIS_WINO_BANK', '1') != '0'  # 0: one Winograd weight-transform launch per 3x3 layer and step
+
+
+@contextlib.contextmanager
+def _winograd_bank(model):
+    """Forward / adjoint Winograd images of every 3x3 layer that takes the Winograd path (``HipConv2d._takes_wino``, set by the
+    layer's first forward), written by ONE launch per step (``sis_hip.WinogradPackBank``) and handed to the layers for the
+    duration of this forward."""
+    layers = []
+    if _WINO_BANK and torch.is_grad_enabled():
+        layers = [m for m in model.modules() if isinstance(m, HipConv2d) and m._takes_wino and m.weight.is_cuda
+                  and m.weight.dtype == torch.float32 and m.weight.is_contiguous() and m.kernel_size == (3, 3)]
+    if layers:
+        bank = getattr(model, '_wino_bank', None)
+        if bank is None or len(bank.weights) != len(layers) or any(a is not m.weight for a, m in zip(bank.weights, layers)) \
+                or not bank.current():
+            bank = model._wino_bank = sis_hip.WinogradPackBank([m.weight for m in layers])
+        bank.refresh()
+        for m, u, ua in zip(layers, bank.u, bank.u_adjoint):
+            m._wino_banked = (u, ua)
+    try:
+        yield
+    finally:
+        for m in layers:
+            m._wino_banked = None
+
+
 class EMANet(BaseSegmenter):
     def __init__(self, num_classes, n_layers, stride=8, stage_num=3, ignore_label=255, background_class_id: int = 0,
                  min_confidence: float = 0.0, min_contour_area: int = 0, use_pretrained_resnet=True,
@@ -365,7 +397,8 @@ class EMANet(BaseSegmenter):
         return self.fc2(self.fc1(x)), mu
 
     def forward(self, img, lbl=None, size=None):
-        x, mu = self.logits(img)
+        with _winograd_bank(self):   # one launch transforms the weights of every 3x3 layer (19 launches per step before)
+            x, mu = self.logits(img)
         if size is None:
             size = img.size()[-2:]
         if self.training and lbl is not None:

@@ -66,9 +66,12 @@ def _conv3x3_wgrad(input, grad_output, weight_shape, d, input_s=None, grad_outpu
 
 class _Conv3x3Function(Function):
     @staticmethod
-    def forward(ctx, input, weight, dilation):
+    def forward(ctx, input, weight, dilation, prepacked=None):
+        """``prepacked``: (forward image, adjoint image) of ``weight`` when a ``sis_hip.WinogradPackBank`` wrote them for this step."""
         input_s = _space_to_batch(input, dilation)
-        if ctx.needs_input_grad[0]:   # the data gradient of this step convolves with the adjoint image: both from one launch
+        if prepacked is not None:
+            u, u_adjoint = prepacked
+        elif ctx.needs_input_grad[0]:   # the data gradient of this step convolves with the adjoint image: both from one launch
             u, u_adjoint = sis_hip.conv3x3_prepack_both(weight)
         else:
             u, u_adjoint = sis_hip.conv3x3_prepack(weight), None
@@ -81,7 +84,7 @@ class _Conv3x3Function(Function):
         input, weight, input_s, u_adjoint = ctx.saved_tensors
         grad_input, grad_weight = _Conv3x3Backward.apply(grad_output.contiguous(), input, weight, ctx.dilation,
                                                          ctx.needs_input_grad[0], ctx.needs_input_grad[1], input_s, u_adjoint)
-        return grad_input, grad_weight, None
+        return grad_input, grad_weight, None, None
 
 
 class _Conv3x3Backward(Function):
@@ -133,10 +136,10 @@ def gan_winograd_enabled():
     return os.environ.get("SIS_GAN_WINOGRAD", "1") != "0"
 
 
-def conv3x3(input, weight, dilation=1):
+def conv3x3(input, weight, dilation=1, prepacked=None):
     """Differentiable stride-1 3x3 convolution with padding = dilation on the Winograd kernel (caller checks
     eligibility with ``sis_hip.conv3x3_supported``)."""
-    return _Conv3x3Function.apply(input, weight, dilation)
+    return _Conv3x3Function.apply(input, weight, dilation, prepacked)
 
 
 _F32_POINTWISE = os.environ.get('SIS_F32_POINTWISE', '1') != '0'  # 0: fp32 1x1 convolutions stay on the library (A/B runs)
@@ -461,6 +464,8 @@ _STRIDE2_OWN = os.environ.get('SIS_STRIDE2_OWN', '1') != '0'  # 0: stride-2 laye
 
 class HipConv2d(nn.Conv2d):
     _banked = None   # (forward image, adjoint image or None) of the weight when a pack bank wrote them for this forward
+    _wino_banked = None   # the same for the fp32 Winograd path (sis_hip.WinogradPackBank, networks/ema_net)
+    _takes_wino = False   # a forward of this layer went through conv3x3 (the bank packs these layers only)
 
     def _bf16(self, input):
         """Under bf16 autocast: the input is already bf16 (norm kernels write it) or is cast here, as autocast would."""
@@ -498,7 +503,8 @@ class HipConv2d(nn.Conv2d):
                 and input.dtype == torch.float32 and input.is_contiguous()):
             return None
         if self.kernel_size == (3, 3) and self.padding == (1, 1) and sis_hip.conv3x3_supported(input, self.weight, 1):
-            return conv3x3(input, self.weight, 1)[:, :, ::2, ::2].contiguous()
+            self._takes_wino = True
+            return conv3x3(input, self.weight, 1, self._wino_banked)[:, :, ::2, ::2].contiguous()
         if self.kernel_size == (1, 1) and self.padding == (0, 0):
             return _Pointwise.apply(input[:, :, ::2, ::2].contiguous(), self.weight, None)
         return None
@@ -515,7 +521,8 @@ class HipConv2d(nn.Conv2d):
         if self._half_image_dilation(input):
             return conv3x3_half_image_dilation(input, self.weight)
         if self._eligible(input):
-            return conv3x3(input, self.weight, self.dilation[0])
+            self._takes_wino = True
+            return conv3x3(input, self.weight, self.dilation[0], self._wino_banked)
         if input.is_cuda:   # the 3-channel stems are the documented library layers; anything else is a fallback
             sis_hip.library_call("hip_conv.HipConv2d.forward", intended=(self.in_channels <= 4))
         return super().forward(input)

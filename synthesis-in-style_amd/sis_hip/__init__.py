@@ -46,6 +46,7 @@ _SIGNATURES = {
     "sis_last_kernel": ([], ctypes.c_char_p),
     "sis_conv3x3_prepack": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "sis_conv3x3_prepack_both": ([_vp, _vp, _vp, _i, _i, _vp], _i),
+    "sis_conv3x3_prepack_multi": ([_vp, _i, _i, _vp], _i),
     "sis_conv3x3_eligible": ([_i] * 5, _i),
     "sis_upsample_bilinear": ([_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp], _i),
     "sis_upsample_bilinear_strided": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _i, _vp], _i),
@@ -449,6 +450,36 @@ def conv3x3_prepack_both(weight):
     with torch.cuda.device(w.device):
         _check(lib().sis_conv3x3_prepack_both(_ptr(u), _ptr(ua), _ptr(w), cout, cin, _stream()), "sis_conv3x3_prepack_both")
     return u, ua
+
+
+class WinogradPackBank:
+    """Forward and adjoint Winograd images of a list of float32 3x3 weights, refreshed by ONE launch
+    (``sis_conv3x3_prepack_multi``).  ``u[i]`` [Cin,16,Cout] / ``u_adjoint[i]`` [Cout,16,Cin] keep their addresses, ``refresh()``
+    rewrites their contents from the weights."""
+
+    def __init__(self, weights):
+        self.weights = [w for w in weights]
+        dev = self.weights[0].device
+        self.u, self.u_adjoint, rows, block = [], [], [], 0
+        for w in self.weights:
+            if w.dtype != torch.float32 or not w.is_contiguous() or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
+                raise RuntimeError("WinogradPackBank: contiguous float32 [Cout, Cin, 3, 3] weights only")
+            cout, cin = w.shape[0], w.shape[1]
+            self.u.append(torch.empty((cin, 16, cout), dtype=torch.float32, device=dev))
+            self.u_adjoint.append(torch.empty((cout, 16, cin), dtype=torch.float32, device=dev))
+            rows.append([w.data_ptr(), self.u[-1].data_ptr(), self.u_adjoint[-1].data_ptr(), cout, cin, block])
+            block += -(-cout * cin // 256)
+        self.total_blocks = block
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.source_ptrs = [w.data_ptr() for w in self.weights]
+
+    def current(self):
+        return all(w.data_ptr() == ptr for w, ptr in zip(self.weights, self.source_ptrs))
+
+    def refresh(self):
+        with torch.cuda.device(self.table.device):
+            _check(lib().sis_conv3x3_prepack_multi(_ptr(self.table), len(self.weights), self.total_blocks, _stream()),
+                   "sis_conv3x3_prepack_multi")
 
 
 def conv3x3(x, u):

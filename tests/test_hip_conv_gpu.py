@@ -194,3 +194,20 @@ def test_bottleneck_shortcut_gradient_is_summed_in_the_data_gradient_kernel(devi
     yr = ref(xr)
     yr.backward(gy.cpu().double())
     assert (dx1.cpu().double() - xr.grad).abs().max().item() <= 2e-4 * xr.grad.abs().max().item()
+
+
+def test_winograd_pack_bank_writes_the_images_of_the_single_layer_prepack(device):
+    """``sis_hip.WinogradPackBank`` (every 3x3 layer of EMANet, one launch per step): each layer's forward / adjoint image is bit
+    for bit what ``conv3x3_prepack_both`` writes for that layer alone, also after the weights changed in place."""
+    import sis_hip
+    gen = torch.Generator().manual_seed(11)
+    weights = [torch.randn(co, ci, 3, 3, generator=gen).to(device) for co, ci in ((64, 3), (64, 64), (128, 64), (512, 2048), (72, 40))]
+    bank = sis_hip.WinogradPackBank(weights)
+    for _ in range(2):
+        bank.refresh()
+        for w, u, ua in zip(weights, bank.u, bank.u_adjoint):
+            ref_u, ref_ua = sis_hip.conv3x3_prepack_both(w)
+            assert torch.equal(u, ref_u) and torch.equal(ua, ref_ua)
+        weights[1].mul_(-0.5)
+        weights[3].add_(1.0)
+    assert bank.current()

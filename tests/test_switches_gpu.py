@@ -110,6 +110,7 @@ _MODULE_SWITCHES = [
     ("networks.ema_net.network", "_HIP_EMAU", False, "ema_net"),          # SIS_HIP_EMAU
     ("networks.ema_net.network", "_RELU_MASK", False, "ema_net"),         # SIS_BN_RELU_MASK
     ("networks.ema_net.network", "_SUB_IMAGE_UNITS", False, "ema_net"),   # SIS_SUB_IMAGE_UNITS
+    ("networks.ema_net.network", "_WINO_BANK", False, "ema_net"),         # SIS_WINO_BANK
     ("networks.hip_conv", "_BF16_CONV", False, "trans_u_net"),            # SIS_BF16_CONV
     ("networks.hip_conv", "_PW_WGRAD_OWN", False, "trans_u_net"),         # SIS_PW_WGRAD_OWN
     ("networks.hip_conv", "_STRIDE2_OWN", False, "trans_u_net"),
