@@ -550,6 +550,14 @@ int sis_gemm_bf16(void* c, void* c2, const void* a, const void* b, int layout, i
  * workspace: sis_gemm_bf16_workspace_bytes(m, n, splits) + 64 * m * 4 bytes; tile 0 or 4..6. */
 int sis_gemm_bf16_wgrad_bias(void* dw, float* db, const void* grad, const void* x, int m, int n, int k, int lda, int ldb, int splits,
                              void* workspace, int64_t workspace_bytes, int tile, void* stream);
+/* The same for n_jobs Linear layers of ONE shape (the encoder's twelve blocks, queued during the backward): one launch for the
+ * n_jobs products -- every problem contracts its whole K per tile: no split-K, no slabs, no reduction launch -- and one for the
+ * column sums.  `dw`, `db`, `grad`, `x`: HOST arrays of n_jobs device pointers (dw[j] [m][n] float32, db[j] [m] float32, grad[j]
+ * bf16 [k][lda], x[j] bf16 [k][ldb]).  tile: a 128 x 128 four-wave tile code (0, 4, 5, 6).  workspace:
+ * sis_gemm_bf16_wgrad_multi_workspace_bytes(n_jobs, m, k) bytes. */
+int64_t sis_gemm_bf16_wgrad_multi_workspace_bytes(int n_jobs, int m, int k);
+int sis_gemm_bf16_wgrad_bias_multi(void* const* dw, float* const* db, const void* const* grad, const void* const* x, int n_jobs, int m,
+                                   int n, int k, int lda, int ldb, void* workspace, int64_t workspace_bytes, int tile, void* stream);
 
 /* Transposed bf16 copies of `n_tensors` matrices by one launch (csrc/vit_elementwise.hip): dst_i [cols_i][rows_i] =
  * src_i [rows_i][cols_i]^T.  `table`: DEVICE array of n_tensors rows of 5 int64 {src, dst, rows, cols, first_tile} with

@@ -40,6 +40,9 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 enum { LAYOUT_NT = 0, LAYOUT_NN = 1, LAYOUT_TN = 2 };
 
+constexpr int GEMM_TAB_MAX = 16;
+struct GemmColsumTab { float* db[GEMM_TAB_MAX]; };
+
 struct GemmParams {
     const void* A; const void* B;
     int lda, ldb;                 // elements
@@ -61,6 +64,12 @@ struct GemmParams {
     // filled round of tiles leaves idle, and stream the gradient once more while the tiles multiply.  cs_part [slices][M]
     // partial rows; the slab-reduction launch that follows adds them in slice order (as column_sum.hip does).
     float* cs_part; int gemm_blocks, cs_slices, cs_rows_per_slice;
+    // Pointer-table batches (grid.y = ptr_batches > 0): independent problems of ONE shape whose operands are separate allocations --
+    // the weight gradients of the encoder's twelve blocks, queued during the backward and multiplied by one launch per Linear
+    // shape at its end (no split-K: twelve problems fill the chip by themselves).  cs_part then holds ptr_batches consecutive
+    // [cs_slices][M] blocks of partial column sums.
+    int ptr_batches;
+    const void* tabA[GEMM_TAB_MAX]; const void* tabB[GEMM_TAB_MAX]; void* tabC[GEMM_TAB_MAX];
 };
 
 template <int BM_, int BN_, bool AKM_, bool BKM_, int BK_ = 64, int NS_ = 2>
@@ -106,7 +115,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
             const int cg = cs % groups, slice = cs / groups;
             const int c = cg * 256 + 4 * lane;
             const int r_lo = slice * p.cs_rows_per_slice, r_hi = min(p.K, r_lo + p.cs_rows_per_slice);
-            const u16* x = (const u16*)p.A;
+            const u16* x = (const u16*)(p.ptr_batches ? p.tabA[blockIdx.y] : p.A);
+            float* cs_out = p.cs_part + (p.ptr_batches ? (long long)blockIdx.y * p.cs_slices * p.M : 0);
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             auto load4 = [&](int r, float* v) {
                 const uint2 q = *reinterpret_cast<const uint2*>(x + (long long)r * p.lda + c);
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
             for (int e = 0; e < 4; ++e) red[wave * 256 + 4 * lane + e] = acc[e];
             __syncthreads();
             const int cc = cg * 256 + tid;
-            if (cc < p.M) p.cs_part[(long long)slice * p.M + cc] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+            if (cc < p.M) cs_out[(long long)slice * p.M + cc] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
             return;
         }
     }
@@ -167,9 +177,10 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
     const int T = min(p.ksteps_per_split, ks_total - ks_begin);   // K steps of this workgroup (>= 1 by construction)
 
     const long long bidx = p.batch_k ? split : (long long)blockIdx.y;
-    const u16* Ab = (const u16*)p.A + bidx * p.a_bstride;
-    const u16* Bb = (const u16*)p.B + bidx * p.b_bstride;
-    const long long c_batch = p.batch_k ? 0 : (long long)blockIdx.y * p.c_bstride;
+    const u16* Ab = p.ptr_batches ? (const u16*)p.tabA[blockIdx.y] : (const u16*)p.A + bidx * p.a_bstride;
+    const u16* Bb = p.ptr_batches ? (const u16*)p.tabB[blockIdx.y] : (const u16*)p.B + bidx * p.b_bstride;
+    void* const Cb = p.ptr_batches ? p.tabC[blockIdx.y] : p.C;
+    const long long c_batch = (p.batch_k || p.ptr_batches) ? 0 : (long long)blockIdx.y * p.c_bstride;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(Ab), 0, p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(Bb), 0, p.b_bytes, 0x00020000);
 
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
                     if (p.drop_thr) sis_drop_quad(key, ((unsigned)m * (unsigned)p.N + (unsigned)n) >> 2, p.drop_thr, p.drop_scale, keep);
                 float v[4] = {acc[tn][tm][0] + bq[tn].x, acc[tn][tm][1] + bq[tn].y, acc[tn][tm][2] + bq[tn].z, acc[tn][tm][3] + bq[tn].w};
                 if constexpr (EPI == SIS_GEMM_EPI_NONE || EPI == SIS_GEMM_EPI_BIAS) {
-                    if (ok) *reinterpret_cast<uint2*>((u16*)p.C + at) = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
+                    if (ok) *reinterpret_cast<uint2*>((u16*)Cb + at) = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
                 } else if constexpr (EPI == SIS_GEMM_EPI_BIAS_GELU_DROP) {
                     // pre-activation (bf16, what the backward differentiates at) and dropout(gelu(pre))
                     const uint2 hp = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
@@ -392,21 +403,21 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_bf16_kernel(GemmParams p) 
                     for (int e = 0; e < 4; ++e) y[e] *= keep[e];
                     if (ok) {
                         *reinterpret_cast<uint2*>((u16*)p.C2 + at) = hp;
-                        *reinterpret_cast<uint2*>((u16*)p.C + at) = make_uint2(sis_pack_bf16x2(y[0], y[1]), sis_pack_bf16x2(y[2], y[3]));
+                        *reinterpret_cast<uint2*>((u16*)Cb + at) = make_uint2(sis_pack_bf16x2(y[0], y[1]), sis_pack_bf16x2(y[2], y[3]));
                     }
                 } else if constexpr (EPI == SIS_GEMM_EPI_BIAS_DROP_RESID) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] *= keep[e];
-                    if (ok) *reinterpret_cast<float4*>((float*)p.C + at) = make_float4(r[tm].x + v[0], r[tm].y + v[1], r[tm].z + v[2], r[tm].w + v[3]);
+                    if (ok) *reinterpret_cast<float4*>((float*)Cb + at) = make_float4(r[tm].x + v[0], r[tm].y + v[1], r[tm].z + v[2], r[tm].w + v[3]);
                 } else if constexpr (EPI == SIS_GEMM_EPI_GELU_BWD) {
                     // gradient w.r.t. the pre-activation: acc * dropout factor * gelu'(pre)
                     const float d[4] = {sis_gelu_grad(sis_bf16_lo(h[tm].x)), sis_gelu_grad(sis_bf16_hi(h[tm].x)),
                                         sis_gelu_grad(sis_bf16_lo(h[tm].y)), sis_gelu_grad(sis_bf16_hi(h[tm].y))};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] *= d[e] * keep[e];
-                    if (ok) *reinterpret_cast<uint2*>((u16*)p.C + at) = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
+                    if (ok) *reinterpret_cast<uint2*>((u16*)Cb + at) = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
                 } else {  // SIS_GEMM_EPI_F32: fp32 result or partial slab of a split-K run
-                    if (ok) *reinterpret_cast<float4*>((float*)p.C + (long long)split * p.slab_stride + at) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (ok) *reinterpret_cast<float4*>((float*)Cb + (long long)split * p.slab_stride + at) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         }
@@ -464,7 +475,7 @@ int launch_gemm(const GemmParams& p, hipStream_t st, const char* name) {
     q.gemm_blocks = 8 * groups;
     int extra = 0;
     if (q.cs_part) {
-        if (!(C::AKM && C::BKM && C::THREADS == 256 && !p.batch_k && p.grid_batches == 1))
+        if (!(C::AKM && C::BKM && C::THREADS == 256 && !p.batch_k && (p.grid_batches == 1 || p.ptr_batches)))
             return sis_fail("%s: the bias column sums ride with the 4-wave TN tiles only", name);
         extra = ((p.M + 255) / 256) * p.cs_slices;
     }
@@ -551,6 +562,7 @@ static int gemm_impl(void* c, void* c2, const void* a, const void* b, int layout
     SIS_REQUIRE(splits == 1 || splits == 2 || splits == 4 || splits % 8 == 0, "sis_gemm_bf16: splits must be 1, 2, 4 or a multiple of 8");
 
     GemmParams p;
+    p.ptr_batches = 0;
     p.A = a; p.B = b; p.lda = lda; p.ldb = ldb; p.M = m; p.N = n; p.K = k;
     // operand extents: row operand [rows][k] -> (rows - 1) * ld + k elements; K-major [k][cols] -> (k - 1) * ld + cols
     const int64_t ae = layout == LAYOUT_TN ? (int64_t)(k - 1) * lda + m : (int64_t)(m - 1) * lda + k;
@@ -639,6 +651,82 @@ switch (tile) {
         hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3(reduce_blocks + cs_blocks), dim3(256), 0, st, result, (const float*)workspace,
                            quads, splits, p.slab_stride, reduce_blocks, colsum_out, (const float*)p.cs_part, m, p.cs_slices);
         SIS_CHECK_LAUNCH("gemm_slab_reduce_kernel");
+    }
+    return 0;
+}
+
+// second stage of the bias column sums of a pointer-table run: db[job][c] = sum over the row slices, in slice order
+static __global__ __launch_bounds__(256) void gemm_colsum_finish_multi_kernel(GemmColsumTab tab, const float* __restrict__ part, int m, int slices) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= m) return;
+    const float* p = part + (long long)blockIdx.y * slices * m + c;
+    float s = 0.f;
+    for (int k = 0; k < slices; ++k) s += p[(long long)k * m];
+    tab.db[blockIdx.y][c] = s;
+}
+
+/* Weight AND bias gradients of n_jobs Linear layers of ONE shape, one launch for the products and one for the column sums:
+ * dw[j] [m][n] float32 = grad[j]^T x[j], db[j] [m] = column sums of grad[j]; grad[j] bf16 [k][lda >= m], x[j] bf16 [k][ldb >= n].
+ * `dw`, `db`, `grad`, `x`: HOST arrays of n_jobs device pointers.  Every problem contracts its whole K in one workgroup per
+ * tile (no split-K, no slabs): n_jobs x (m / 128) x (n / 128) tiles fill the chip without it.  workspace:
+ * sis_gemm_bf16_wgrad_multi_workspace_bytes(n_jobs, m, k) bytes (partial column sums). */
+extern "C" int64_t sis_gemm_bf16_wgrad_multi_workspace_bytes(int n_jobs, int m, int k) {
+    const int groups = sis_cdiv(m, 256);
+    int slices = sis_cdiv(1024, groups * (n_jobs > 0 ? n_jobs : 1));
+    if (slices > 64) slices = 64;
+    if (slices > sis_cdiv(k, 8)) slices = sis_cdiv(k, 8);
+    if (slices < 1) slices = 1;
+    return (int64_t)n_jobs * slices * m * 4;
+}
+
+extern "C" int sis_gemm_bf16_wgrad_bias_multi(void* const* dw, float* const* db, const void* const* grad, const void* const* x,
+                                              int n_jobs, int m, int n, int k, int lda, int ldb, void* workspace,
+                                              int64_t workspace_bytes, int tile, void* stream) {
+    if (n_jobs <= 0 || m <= 0 || n <= 0) return 0;
+    SIS_REQUIRE(dw && db && grad && x && workspace, "sis_gemm_bf16_wgrad_bias_multi: null pointer");
+    SIS_REQUIRE(k > 0 && m % 4 == 0 && n % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0, "sis_gemm_bf16_wgrad_bias_multi: m, n multiples of 4, lda, ldb of 8");
+    SIS_REQUIRE(tile == 0 || tile == 4 || tile == 5 || tile == 6, "sis_gemm_bf16_wgrad_bias_multi: a 128 x 128 four-wave tile (0, 4, 5, 6)");
+    SIS_REQUIRE((int64_t)m * n < (1LL << 32), "sis_gemm_bf16_wgrad_bias_multi: more than 2^32 outputs");
+    const int64_t ae = (int64_t)(k - 1) * lda + m, be = (int64_t)(k - 1) * ldb + n;
+    SIS_REQUIRE(ae * 2 < (1LL << 31) && be * 2 < (1LL << 31), "sis_gemm_bf16_wgrad_bias_multi: operands above 2 GiB");
+    hipStream_t st = (hipStream_t)stream;
+    for (int j0 = 0; j0 < n_jobs; j0 += GEMM_TAB_MAX) {
+        const int nj = std::min(GEMM_TAB_MAX, n_jobs - j0);
+        GemmParams p = {};
+        GemmColsumTab ct = {};
+        for (int j = 0; j < nj; ++j) {
+            SIS_REQUIRE(dw[j0 + j] && db[j0 + j] && grad[j0 + j] && x[j0 + j], "sis_gemm_bf16_wgrad_bias_multi: null pointer in job %d", j0 + j);
+            SIS_REQUIRE((((uintptr_t)dw[j0 + j] | (uintptr_t)grad[j0 + j] | (uintptr_t)x[j0 + j]) & 15) == 0,
+                        "sis_gemm_bf16_wgrad_bias_multi: operands must be 16-byte aligned");
+            p.tabA[j] = grad[j0 + j]; p.tabB[j] = x[j0 + j]; p.tabC[j] = dw[j0 + j]; ct.db[j] = db[j0 + j];
+        }
+        p.ptr_batches = nj; p.grid_batches = nj;
+        p.A = p.tabA[0]; p.B = p.tabB[0]; p.C = p.tabC[0];
+        p.lda = lda; p.ldb = ldb; p.ldc = n; p.M = m; p.N = n; p.K = k;
+        p.a_bytes = (unsigned)(ae * 2); p.b_bytes = (unsigned)(be * 2);
+        const int bk = TILE_PLANS[tile].bk;
+        p.m_tiles = sis_cdiv(m, TILE_PLANS[tile].bm); p.n_tiles = sis_cdiv(n, TILE_PLANS[tile].bn);
+        p.splits = 1; p.ksteps_per_split = sis_cdiv(k, bk); p.slab_stride = (long long)m * n;
+        // bias column sums by extra workgroups of the same launch (as sis_gemm_bf16_wgrad_bias): ~1024 of them over all jobs
+        const int groups = sis_cdiv(m, 256);
+        int slices = sis_cdiv(1024, groups * nj);
+        if (slices > 64) slices = 64;
+        if (slices > sis_cdiv(k, 8)) slices = sis_cdiv(k, 8);
+        if (slices < 1) slices = 1;
+        p.cs_rows_per_slice = sis_cdiv(k, slices);
+        p.cs_slices = sis_cdiv(k, p.cs_rows_per_slice);
+        SIS_REQUIRE(workspace_bytes >= (int64_t)nj * p.cs_slices * m * 4, "sis_gemm_bf16_wgrad_bias_multi: workspace too small");
+        p.cs_part = (float*)workspace;
+        int rc;
+        switch (tile) {
+            case 0: rc = dispatch<128, 128, 64, 2>(p, LAYOUT_TN, SIS_GEMM_EPI_F32, st); break;
+            case 4: rc = dispatch<128, 128, 32, 3>(p, LAYOUT_TN, SIS_GEMM_EPI_F32, st); break;
+            case 5: rc = dispatch<128, 128, 32, 4>(p, LAYOUT_TN, SIS_GEMM_EPI_F32, st); break;
+            default: rc = dispatch<128, 128, 64, 3>(p, LAYOUT_TN, SIS_GEMM_EPI_F32, st); break;
+        }
+        if (rc) return rc;
+        hipLaunchKernelGGL(gemm_colsum_finish_multi_kernel, dim3(sis_cdiv(m, 256), nj), dim3(256), 0, st, ct, (const float*)workspace, m, p.cs_slices);
+        SIS_CHECK_LAUNCH("gemm_colsum_finish_multi_kernel");
     }
     return 0;
 }

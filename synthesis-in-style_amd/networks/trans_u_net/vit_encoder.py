@@ -361,7 +361,7 @@ class _SideWgrads:
         self.side = _wgrad_stream(device)
         self.outputs = []
 
-    def run(self, grad, inp, out_features, in_features, keys=None):
+    def run(self, grad, inp, out_features, in_features, keys=None, defer=False):
         """(dW fp32 [out, in], db fp32 [out]) of y = inp W^T + b from grad = dL/dy (bf16 [tokens, out]), inp bf16 [tokens, in].
         ``keys``: storage addresses of the weight parameter(s) dW is the gradient of -- under the data-parallel wrap the GEMM
         writes into their bucket slice (``sis_hip.grad_out_fused``; several parameters: query | key | value, stacked)."""
@@ -372,6 +372,10 @@ class _SideWgrads:
             rows = [out_features // len(keys)] * len(keys)
             out = S.grad_out_fused(keys, rows, in_features, grad.device)
         if self.side is None:
+            if defer:   # into the batched launch at the end of the backward (sis_hip.defer_wgrad_bias): results valid after the flush
+                queued = S.defer_wgrad_bias(grad, inp, dw=out)
+                if queued is not None:
+                    return queued
             if _FUSE_BIAS_GRAD and splits > 1 and tile in (0, 4, 5, 6) and grad.shape[0] >= 64 * splits:   # (fewer tokens: the GEMM drops its split)
                 # the bias column sums ride in the weight-gradient launches (extra workgroups in the idle slots of the last round)
                 return S.gemm_bf16_wgrad_bias(grad, inp, splits, tile, dw=out)
@@ -446,6 +450,7 @@ class _FusedBlockFn(Function):
         # storage addresses of the weight parameters: the backward's weight-gradient GEMMs write into their gradient-arena slices
         ctx.weight_keys = ((q_w.data_ptr(), k_w.data_ptr(), v_w.data_ptr()), (o_w.data_ptr(),), (f1_w.data_ptr(),), (f2_w.data_ptr(),))
         ctx.norm_params = ((ln1_w, ln1_b), (ln2_w, ln2_b))   # (leaves: their .grad state decides whether a reduction may be deferred)
+        ctx.linear_params = ((q_w, k_w, v_w, q_b, k_b, v_b), (o_w, o_b), (f1_w, f1_b), (f2_w, f2_b))
         return x3.view(b, n, hid)
 
     @staticmethod
@@ -473,19 +478,21 @@ class _FusedBlockFn(Function):
         # ---- MLP
         gl2 = S.dropout_bwd_cast(g3, seed, site + 2, p_mlp)                                   # d(fc2 output), bf16
         k_qkv, k_o, k_f1, k_f2 = ctx.weight_keys
-        d_w2, d_b2 = wg.run(gl2, act, hid, mlp, k_f2)
+        # (a gradient may only be deferred while its parameters hold none: autograd would add the unwritten tensor on the spot)
+        new_qkv, new_o, new_f1, new_f2 = (all(p.grad is None for p in group) for group in ctx.linear_params)
+        d_w2, d_b2 = wg.run(gl2, act, hid, mlp, k_f2, defer=new_f2)
         d_pre = dgrad(gl2, w2, w2_t, S.EPI_GELU_BWD, pre=pre, seed=seed, site=site + 1, drop_p=p_mlp)
-        d_w1, d_b1 = wg.run(d_pre, h2, mlp, hid, k_f1)
+        d_w1, d_b1 = wg.run(d_pre, h2, mlp, hid, k_f1, defer=new_f1)
         d_h2 = dgrad(d_pre, w1, w1_t)
         # LN2 backward + the skip connection's gradient, and d(out-projection output) = that sum through the proj dropout
         fresh1, fresh2 = (all(p.grad is None for p in pair) for pair in ctx.norm_params)   # no gradient in place: deferrable
         g2, d_ln2_w, d_ln2_b, gl1 = S.layer_norm_bwd_fused(d_h2, x2, mean2, rstd2, ln2_w, residual_grad=g3, cast_seed=seed,
                                                            cast_site=site, cast_p=p_proj, defer=fresh2)
         # ---- attention
-        d_wo, d_bo = wg.run(gl1, att.view(m, hid), hid, hid, k_o)
+        d_wo, d_bo = wg.run(gl1, att.view(m, hid), hid, hid, k_o, defer=new_o)
         d_att = dgrad(gl1, wo, wo_t)
         d_qkv = S.attention_bwd(d_att.view(b, n, hid), qkv.view(b, n, 3 * hid), att, lse, heads).view(m, 3 * hid)
-        d_wqkv, d_bqkv = wg.run(d_qkv, h1, 3 * hid, hid, k_qkv)
+        d_wqkv, d_bqkv = wg.run(d_qkv, h1, 3 * hid, hid, k_qkv, defer=new_qkv)
         d_h1 = dgrad(d_qkv, wqkv, wqkv_t)
         g1, d_ln1_w, d_ln1_b, _ = S.layer_norm_bwd_fused(d_h1, x2d, mean1, rstd1, ln1_w, residual_grad=g2, defer=fresh1)
         wg.join()

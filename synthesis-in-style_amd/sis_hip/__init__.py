@@ -53,6 +53,8 @@ _SIGNATURES = {
     "sis_gemm_bf16_workspace_bytes": ([_i, _i, _i], _i64),
     "sis_gemm_bf16": ([_vp] * 4 + [_i] * 8 + [_vp] * 3 + [_i] + [_vp] * 3 + [_i, _f, _i, _vp, _i64, _i, _vp], _i),
     "sis_gemm_bf16_wgrad_bias": ([_vp] * 4 + [_i] * 6 + [_vp, _i64, _i, _vp], _i),
+    "sis_gemm_bf16_wgrad_multi_workspace_bytes": ([_i, _i, _i], _i64),
+    "sis_gemm_bf16_wgrad_bias_multi": ([_vp] * 4 + [_i] * 6 + [_vp, _i64, _i, _vp], _i),
     "sis_gemm_bf16_batched": ([_vp] * 3 + [_i] * 9 + [_i64] * 3 + [_i, _vp, _i64, _i, _vp], _i),
     "sis_layer_norm_bwd_fused": ([_vp] * 9 + [_i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp], _i),
     "sis_attention_fwd": ([_vp, _vp, _vp, _i, _i, _i, _vp], _i),
@@ -625,13 +627,21 @@ def grad_out_fused(keys, rows, cols, device):
 # new tensor to it immediately -- gradient accumulation over two backwards keeps the undeferred path).  Outside a backward (tests
 # calling a binding directly) nothing is deferred.  SIS_DEFER_REDUCES=0 switches it off (A/B runs).
 _DEFER = os.environ.get("SIS_DEFER_REDUCES", "1") != "0"
-_deferred = {"ln": []}
+_deferred = {"ln": [], "wgrad": {}}   # wgrad: (tokens, out, in, lda, ldb, device) -> [(grad, x, dw, db addresses, storages)]
 _deferred_task = [None]         # the running backward has its end-of-backward callback queued (reset by the callback itself:
                                 # graph task ids are not unique across backwards)
 
+_defer_blockers = set()   # ids of wrappers that read a gradient the moment autograd hands it over (torch's DistributedDataParallel)
+
+
+def block_deferral(owner, blocked=True):
+    """No deferred completion of gradients while ``owner`` lives: for consumers that read ``.grad`` inside the backward."""
+    (_defer_blockers.add if blocked else _defer_blockers.discard)(id(owner))
+
+
 def deferring():
     """True inside an autograd backward with deferral switched on; queues the end-of-backward flush on first use per backward."""
-    if not _DEFER:
+    if not _DEFER or _defer_blockers:
         return False
     task = torch._C._current_graph_task_id()
     if task < 0:
@@ -655,11 +665,53 @@ def _hold(*tensors):
 
 
 def deferred_pending():
-    return sum(len(v) for v in _deferred.values())
+    return len(_deferred["ln"]) + sum(len(v) for v in _deferred["wgrad"].values())
+
+
+_DEFER_WGRAD = os.environ.get("SIS_DEFER_WGRAD", "1") != "0"   # 0: the encoder's weight-gradient GEMMs where their operands appear
+_defer_wgrad_blockers = set()   # ids of data-parallel wrappers with more than one rank: their buckets leave DURING the backward,
+                                # overlapped with it -- a gradient held back to its end would put the exchange behind it
+
+
+def block_wgrad_deferral(owner, blocked=True):
+    (_defer_wgrad_blockers.add if blocked else _defer_wgrad_blockers.discard)(id(owner))
+
+
+def deferred_wgrad_pending():
+    return any(_deferred["wgrad"].values())
+
+
+def defer_wgrad_bias(grad, x, dw=None):
+    """Queues the weight / bias gradient of a Linear layer (``gemm_bf16_wgrad_bias``'s operands) for the batched launch of
+    ``flush_deferred`` -- one pointer-table GEMM per Linear shape for all queued layers, each contracting its whole token axis per
+    tile (no split-K slabs, no reduction launches: 2.61 -> 2.02 ms for the twelve blocks of ViT-B at 8 192 tokens,
+    tools/bench_wgrad_multi.py).  Returns (dw, db): allocated now, VALID ONLY AFTER THE FLUSH (the caller checked that the
+    parameters hold no gradient yet, see the comment above).  None when the operands do not qualify (the caller then multiplies
+    on the spot)."""
+    if not (_DEFER_WGRAD and grad.dim() == 2 and x.dim() == 2 and grad.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+            and grad.stride(1) == 1 and x.stride(1) == 1 and grad.shape[0] == x.shape[0] and grad.stride(0) % 8 == 0
+            and x.stride(0) % 8 == 0 and grad.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and grad.shape[1] % 4 == 0
+            and x.shape[1] % 4 == 0 and not _defer_wgrad_blockers and deferring()):
+        return None
+    k, m = grad.shape
+    n = x.shape[1]
+    if dw is None:
+        dw = torch.empty((m, n), dtype=torch.float32, device=grad.device)
+    elif tuple(dw.shape) != (m, n) or dw.dtype != torch.float32 or not dw.is_contiguous():
+        raise RuntimeError("defer_wgrad_bias: dw must be a contiguous float32 [out, in] tensor")
+    db = torch.empty(m, dtype=torch.float32, device=grad.device)
+    key = (k, m, n, grad.stride(0), x.stride(0), grad.device)
+    _deferred["wgrad"].setdefault(key, []).append((grad.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), _hold(grad, x, dw, db)))
+    return dw, db
 
 
 def flush_deferred():
-    """Runs every queued reduction (one launch per 32 jobs).  Cheap when nothing is queued."""
+    """Runs every queued reduction (one launch per 32 jobs) and weight gradient (one launch per Linear shape and 16 jobs).
+    Cheap when nothing is queued."""
+    if _deferred["wgrad"]:
+        queued, _deferred["wgrad"] = _deferred["wgrad"], {}
+        for key, jobs in queued.items():
+            _wgrad_multi_raw([j[:4] for j in jobs], key)
     jobs = _deferred["ln"]
     if jobs:
         _deferred["ln"] = []
@@ -1339,6 +1391,45 @@ def gemm_bf16_wgrad_bias(grad, x, splits, tile=0, dw=None):
                                                               int(splits), _ptr(ws), ws.numel(), int(tile), _stream())),
                "sis_gemm_bf16_wgrad_bias")
     return dw, db
+
+
+_WGRAD_MULTI_TILE = int(os.environ.get("SIS_WGRAD_MULTI_TILE", "4"))   # 128 x 128 four-wave tile of the batched weight gradients
+
+
+def gemm_bf16_wgrad_bias_multi(jobs, tile=None):
+    """Weight and bias gradients of several Linear layers of ONE shape from one launch (+ one for the column sums):
+    ``jobs`` = [(grad [tokens, out] bf16, x [tokens, in] bf16, dw [out, in] float32, db [out] float32), ...] -- or the same as raw
+    addresses (grad_ptr, x_ptr, dw_ptr, db_ptr) with ``shape`` = (tokens, out, in, lda, ldb, device) given through ``tile``'s
+    sibling ``_wgrad_multi_raw`` (the deferred queue).  Every problem contracts all its tokens per tile: no split-K slabs."""
+    g0, x0 = jobs[0][0], jobs[0][1]
+    require_device(g0, "grad")
+    k, m = g0.shape
+    n = x0.shape[1]
+    for g, x, dw, db in jobs:
+        if (tuple(g.shape) != (k, m) or tuple(x.shape) != (k, n) or g.dtype != torch.bfloat16 or x.dtype != torch.bfloat16
+                or g.stride(1) != 1 or x.stride(1) != 1 or g.stride(0) != g0.stride(0) or x.stride(0) != x0.stride(0)
+                or tuple(dw.shape) != (m, n) or dw.dtype != torch.float32 or not dw.is_contiguous()
+                or tuple(db.shape) != (m,) or db.dtype != torch.float32):
+            raise RuntimeError("gemm_bf16_wgrad_bias_multi: every job must have the first job's shapes, strides and dtypes")
+    _wgrad_multi_raw([(g.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr()) for g, x, dw, db in jobs],
+                     (k, m, n, g0.stride(0), x0.stride(0), g0.device), tile)
+
+
+def _wgrad_multi_raw(ptrs, shape, tile=None):
+    k, m, n, lda, ldb, device = shape
+    nj = len(ptrs)
+    arr = ctypes.c_void_p * nj
+    ws = _stream_workspace(device)
+    need = lib().sis_gemm_bf16_wgrad_multi_workspace_bytes(min(nj, 16), m, k)
+    if need > ws.numel():
+        raise RuntimeError("gemm_bf16_wgrad_bias_multi: split-K workspace too small for the partial column sums")
+    with torch.cuda.device(device):
+        _check(_launch("gemm_bf16<TN,multi>", 2.0 * m * n * k * nj, (2.0 * (m * k + n * k) + 4.0 * m * n) * nj,
+                       lambda: lib().sis_gemm_bf16_wgrad_bias_multi(arr(*[p[2] for p in ptrs]), arr(*[p[3] for p in ptrs]),
+                                                                    arr(*[p[0] for p in ptrs]), arr(*[p[1] for p in ptrs]), nj, m, n, k,
+                                                                    lda, ldb, _ptr(ws), ws.numel(),
+                                                                    _WGRAD_MULTI_TILE if tile is None else int(tile), _stream())),
+               "sis_gemm_bf16_wgrad_bias_multi")
 
 
 def _batched_operand(t, name):

@@ -178,6 +178,10 @@ class BucketedDataParallel(nn.Module):
             # gloo stages device tensors through the host and synchronises: correct (one-GPU rehearsals), never capturable
             pass
         self._pending = []   # work handles of collectives issued through torch.distributed during the current backward
+        self._postponed = []   # (world size 1) buckets complete but for gradients still in sis_hip's deferred queue
+        if self._on_gpu and self.world > 1:
+            import sis_hip
+            sis_hip.block_wgrad_deferral(self)   # buckets leave during the backward: no gradient waits for its end
         self._comm, self._comm_stream, self._joined = None, None, True
         self.direct_rccl_note = None   # why the direct path is off when it was wanted (bench.py prints it)
         want_direct = _DIRECT_RCCL == "1" or (_DIRECT_RCCL == "auto" and self.world == 1)
@@ -348,9 +352,14 @@ class BucketedDataParallel(nn.Module):
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
             flat.mul_(1.0 / world)
 
-    def _flush(self, bucket: _Bucket):
+    def _flush(self, bucket: _Bucket, at_end=False):
         if self._on_gpu:
             import sis_hip
+            if self.world == 1 and not at_end and sis_hip.deferred_wgrad_pending():
+                # One rank has nobody to overlap with: the bucket waits for the end of the backward, where the queued weight
+                # gradients of ALL layers run as one launch per Linear shape (a flush here would multiply this bucket's layers alone).
+                self._postponed.append(bucket)
+                return
             sis_hip.flush_deferred()   # gradients whose second-stage reduction was deferred are completed before they travel
         self._gather(bucket)
         self._reduce(bucket)
@@ -366,7 +375,10 @@ class BucketedDataParallel(nn.Module):
             self._plan()
             for bucket in self.buckets:
                 self._flush(bucket)
-        elif self._flushed != len(self.buckets):
+        postponed, self._postponed = self._postponed, []
+        for bucket in postponed:
+            self._flush(bucket, at_end=True)
+        if self._flushed != len(self.buckets):
             missing = [b.index for b in self.buckets if b.pending != 0]
             for work in self._pending:       # leave no collective in flight behind the exception
                 work.wait()
@@ -467,6 +479,7 @@ class BucketedDataParallel(nn.Module):
         try:
             import sis_hip
             sis_hip.grad_arena_release(self)
+            sis_hip.block_wgrad_deferral(self, False)
         except Exception:
             pass
 

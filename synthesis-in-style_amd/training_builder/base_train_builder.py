@@ -111,6 +111,11 @@ class BaseTrainBuilder:
                 if device.type == 'cuda':
                     kwargs.update(device_ids=[device.index], output_device=device.index)
                 network = DDP(network, **kwargs)
+                if device.type == 'cuda':
+                    # torch's reducer copies a gradient into its bucket the moment autograd hands it over: nothing may be
+                    # completed later (sis_hip's deferred reductions / batched weight gradients fill their tensors at the end)
+                    import sis_hip
+                    sis_hip.block_deferral(network)
             else:
                 raise ValueError(f"data_parallel: '{flavour}' (buckets | ddp)")
         return network

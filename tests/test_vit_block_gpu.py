@@ -136,6 +136,8 @@ def test_deferred_layer_norm_reductions_are_the_undeferred_ones(device, monkeypa
     enc = V.Encoder(cfg, vis=False).to(device).train()
     x = torch.randn(2, 128, 768, device=device)
 
+    monkeypatch.setattr(sis_hip, "_DEFER_WGRAD", False)   # (the batched weight gradients have a test of their own below)
+
     def grads(defer):
         monkeypatch.setattr(sis_hip, "_DEFER", defer)
         enc.zero_grad(set_to_none=True)
@@ -162,3 +164,50 @@ def test_deferred_layer_norm_reductions_are_the_undeferred_ones(device, monkeypa
     assert sis_hip.deferred_pending() == 0
     _, dg0, db0 = sis_hip.layer_norm_bwd(g, xs, mean, rstd, gamma)
     assert torch.equal(dg, dg0) and torch.equal(db, db0)
+
+
+def test_deferred_weight_gradients_match_the_undeferred_ones(device, monkeypatch):
+    """SIS_DEFER_WGRAD: inside a backward the weight / bias gradients of the blocks' Linear layers are queued and multiplied by ONE
+    pointer-table launch per Linear shape at the end of the backward (sis_hip.defer_wgrad_bias / flush_deferred: every problem
+    contracts all its tokens per tile instead of split-K slabs).  Same products, another order of the fp32 sums: 1e-5 of the
+    largest entry; nothing is left queued; a second backward ON TOP of existing gradients (accumulation) takes the undeferred
+    path and adds up; under a blocker (a consumer that reads gradients inside the backward) nothing is queued at all."""
+    import sis_hip
+    from networks.trans_u_net import vit_encoder as V
+    cfg = _config(0.0)
+    cfg.transformer["num_layers"] = 3
+    torch.manual_seed(12)
+    enc = V.Encoder(cfg, vis=False).to(device).train()
+    x = torch.randn(2, 256, 768, device=device)
+
+    def backward_once(zero=True):
+        if zero:
+            enc.zero_grad(set_to_none=True)
+        queued = []
+        flush = sis_hip.flush_deferred
+        monkeypatch.setattr(sis_hip, "flush_deferred", lambda: (queued.append(sum(len(v) for v in sis_hip._deferred["wgrad"].values())), flush())[1])
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            enc(x)[0].square().mean().backward()
+        monkeypatch.setattr(sis_hip, "flush_deferred", flush)
+        assert sis_hip.deferred_pending() == 0
+        return {n: p.grad.clone() for n, p in enc.named_parameters()}, max(queued, default=0)
+
+    monkeypatch.setattr(sis_hip, "_DEFER_WGRAD", False)
+    plain, queued_off = backward_once()
+    monkeypatch.setattr(sis_hip, "_DEFER_WGRAD", True)
+    deferred, queued_on = backward_once()
+    assert queued_off == 0 and queued_on == 12, (queued_off, queued_on)   # four Linear layers per block, three blocks
+    for name in plain:
+        scale = float(plain[name].abs().max())
+        assert float((plain[name] - deferred[name]).abs().max()) <= 1e-5 * scale + 1e-12, name
+    twice, queued_acc = backward_once(zero=False)   # gradients in place: autograd adds on the spot, so nothing may be deferred
+    assert queued_acc == 0
+    for name in plain:
+        scale = float(plain[name].abs().max())
+        assert float((twice[name] - 2 * deferred[name]).abs().max()) <= 2e-5 * scale + 1e-12, name
+    sis_hip.block_wgrad_deferral(enc)
+    try:
+        _, queued_blocked = backward_once()
+    finally:
+        sis_hip.block_wgrad_deferral(enc, False)
+    assert queued_blocked == 0
