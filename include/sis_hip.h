@@ -482,6 +482,15 @@ int sis_conv_bf16_wgrad(void* dw, int dw_dtype, const void* x, const void* grad_
 int sis_conv1x1_bf16_wgrad_supported(int batch, int cin, int cout, int pixels, int64_t workspace_bytes);
 int sis_conv1x1_bf16_wgrad(void* dw, int dw_dtype, const void* x, const void* grad_y, int batch, int cin, int cout, int pixels,
                            void* workspace, int64_t workspace_bytes, void* stream);
+/* Both weight-gradient kernels for n_jobs layers of ONE shape (the trunk's repeated bottleneck units, queued during the
+ * backward): `dw`, `x`, `grad_y` are HOST arrays of n_jobs device pointers; one tile launch (grid.z = layer) and one reduction
+ * launch per <= 16 layers.  The tile plan counts the layers' workgroups together: each layer is cut into fewer, longer units than
+ * it would be alone (less slab traffic, fewer prologues).  Results are those of the single-layer calls up to the order of the
+ * fp32 partial sums. */
+int sis_conv_bf16_wgrad_multi(void* const* dw, int dw_dtype, const void* const* x, const void* const* grad_y, int n_jobs, int batch,
+                              int cin, int cout, int h, int w, void* workspace, int64_t workspace_bytes, void* stream);
+int sis_conv1x1_bf16_wgrad_multi(void* const* dw, int dw_dtype, const void* const* x, const void* const* grad_y, int n_jobs, int batch,
+                                 int cin, int cout, int pixels, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * fp32 pointwise (1x1, stride 1) convolution of the EMANet training step (csrc/conv1x1_f32.hip;

@@ -51,10 +51,15 @@ struct WgCfg {
     static_assert(LDS <= 160 * 1024, "LDS");
 };
 
+constexpr int WG_JOBS_MAX = 16;   // layers of one shape per launch (grid.z), operands through pointer tables
+
 struct WgParams {
     const u16* x;    // [N, Cin, H, W]
     const u16* gy;   // [N, Cout, H, W]
     float* slab;     // [units][9][co_pad][ci_pad]
+    int jobs;        // > 0: grid.z layers of this shape: x / gy from the tables, slab of layer z at slab + z * slab_job_stride
+    long long slab_job_stride;
+    const u16* xj[WG_JOBS_MAX]; const u16* gyj[WG_JOBS_MAX];
     int N, Cin, Cout, H, W;
     int strips, row_blocks, rows_per_block;
     int co_tiles, ci_tiles;
@@ -114,8 +119,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv_wgrad_bf16_kernel(WgParams
     const int x0 = strip * C::SW;
     const int y_begin = rb * p.rows_per_block, y_end = min(p.H, y_begin + p.rows_per_block);
     const int64_t plane = (int64_t)p.H * p.W;
-    const u16* gy_base = p.gy + ((int64_t)n * p.Cout + co_t * C::MT) * plane;
-    const u16* x_base = p.x + ((int64_t)n * p.Cin + ci_t * C::NT) * plane;
+    const u16* gy_base = (p.jobs ? p.gyj[blockIdx.z] : p.gy) + ((int64_t)n * p.Cout + co_t * C::MT) * plane;
+    const u16* x_base = (p.jobs ? p.xj[blockIdx.z] : p.x) + ((int64_t)n * p.Cin + ci_t * C::NT) * plane;
 
     uint4 dyr[C::NDY], xr[C::NX];
 
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv_wgrad_bf16_kernel(WgParams
 
     // ---- partial tile -> slab[unit][tap][co][ci] (ci on the lanes: 128-byte runs)
     const int co_pad = p.co_tiles * C::MT, ci_pad = p.ci_tiles * C::NT;
-    float* out = p.slab + (int64_t)blockIdx.x * 9 * co_pad * ci_pad;
+    float* out = p.slab + (p.jobs ? (int64_t)blockIdx.z * p.slab_job_stride : 0) + (int64_t)blockIdx.x * 9 * co_pad * ci_pad;
     if constexpr (C::WK == 1) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -259,10 +264,17 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv_wgrad_bf16_kernel(WgParams
 
 // dW[co][ci][tap] = sum over units of slab[unit][tap][co][ci].  One workgroup per (tap, co, 64 input channels): the
 // four waves add units w, w + 4, ... in order (coalesced 256-byte reads), then (s0 + s1) + (s2 + s3): a fixed order.
+struct WgDwTab { void* dw[WG_JOBS_MAX]; };
+
 template <typename T>
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(T* __restrict__ dw, const float* __restrict__ slab, int units,
-                                                                int Cout, int Cin, int co_pad, int ci_pad, int taps) {
+                                                                int Cout, int Cin, int co_pad, int ci_pad, int taps,
+                                                                long long slab_job_stride = 0, WgDwTab tab = WgDwTab{}) {
     __shared__ float red[4][64];
+    if (slab_job_stride) {   // grid.y layers of one shape
+        dw = reinterpret_cast<T*>(tab.dw[blockIdx.y]);
+        slab += (int64_t)blockIdx.y * slab_job_stride;
+    }
     const int cchunks = (Cin + 63) / 64;
     int b = blockIdx.x;
     const int cc = b % cchunks; b /= cchunks;
@@ -305,6 +317,8 @@ struct PwCfg {
 
 struct PwParams {
     const u16* x; const u16* gy; float* slab;
+    int jobs; long long slab_job_stride;   // as WgParams
+    const u16* xj[WG_JOBS_MAX]; const u16* gyj[WG_JOBS_MAX];
     int N, Cin, Cout, P;              // P = pixels per plane
     int units_per_image, unit_len;    // unit u: image u / units_per_image, pixels [k * unit_len, min(P, (k + 1) * unit_len))
     int co_tiles, ci_tiles;
@@ -319,8 +333,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wgrad_bf16_kernel(PwParams p) 
     const int n = blockIdx.x / p.units_per_image, uk = blockIdx.x % p.units_per_image;
     const int co_t = blockIdx.y % p.co_tiles, ci_t = blockIdx.y / p.co_tiles;
     const int p_begin = uk * p.unit_len, p_end = min(p.P, p_begin + p.unit_len);
-    const u16* gy_base = p.gy + ((int64_t)n * p.Cout + co_t * C::MT) * p.P;
-    const u16* x_base = p.x + ((int64_t)n * p.Cin + ci_t * C::NT) * p.P;
+    const u16* gy_base = (p.jobs ? p.gyj[blockIdx.z] : p.gy) + ((int64_t)n * p.Cout + co_t * C::MT) * p.P;
+    const u16* x_base = (p.jobs ? p.xj[blockIdx.z] : p.x) + ((int64_t)n * p.Cin + ci_t * C::NT) * p.P;
     const int stages = (p_end - p_begin + C::KP - 1) / C::KP;
 
     uint4 ar[C::NA], br[C::NB];
@@ -392,7 +406,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wgrad_bf16_kernel(PwParams p) 
 
     // ---- the K waves add their tiles through the staging LDS in wave order, block by block; one tile per unit reaches the slab
     const int co_pad = p.co_tiles * C::MT, ci_pad = p.ci_tiles * C::NT;
-    float* out = p.slab + (int64_t)blockIdx.x * co_pad * ci_pad;
+    float* out = p.slab + (p.jobs ? (int64_t)blockIdx.z * p.slab_job_stride : 0) + (int64_t)blockIdx.x * co_pad * ci_pad;
     constexpr int NP = C::WM * C::WN;
     float* red = reinterpret_cast<float*>(lds);  // [WK][NP][16][64]
     const int pair = wm + C::WM * wn;
@@ -417,7 +431,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wgrad_bf16_kernel(PwParams p) 
 
 struct PwPlan { int wm, wn, units_per_image, unit_len, co_tiles, ci_tiles, units; int64_t slab_bytes; };
 
-bool pw_plan(int batch, int cin, int cout, int pixels, int64_t workspace_bytes, PwPlan* pl) {
+bool pw_plan(int batch, int cin, int cout, int pixels, int64_t workspace_bytes, PwPlan* pl, int jobs = 1) {
+    workspace_bytes /= jobs;   // every layer of the launch has its own slabs
     if (cin < 8 || cout < 8 || pixels < 8 || batch < 1) return false;
     pl->wm = cout > 64 ? 2 : 1;
     pl->wn = cin > 64 ? 2 : 1;
@@ -428,7 +443,7 @@ bool pw_plan(int batch, int cin, int cout, int pixels, int64_t workspace_bytes, 
     const int tiles = pl->co_tiles * pl->ci_tiles;
     // pixel ranges per image: enough workgroups for ~2 per CU, at least 4 stages each, slabs within the workspace
     int upi = 1;
-    while ((int64_t)batch * upi * tiles < 512 && pixels / (upi * 2) >= 4 * kp && (int64_t)batch * upi * 2 * tile_bytes <= workspace_bytes) upi *= 2;
+    while ((int64_t)batch * upi * tiles * jobs < 512 && pixels / (upi * 2) >= 4 * kp && (int64_t)batch * upi * 2 * tile_bytes <= workspace_bytes) upi *= 2;
     pl->unit_len = sis_cdiv(sis_cdiv(pixels, upi), kp) * kp;
     pl->units_per_image = sis_cdiv(pixels, pl->unit_len);
     pl->units = batch * pl->units_per_image;
@@ -448,7 +463,7 @@ int launch_pw(const PwParams& p, int units, bool aligned, hipStream_t st) {
         if (e != hipSuccess) return sis_fail("conv1x1_wgrad_bf16_kernel: cannot raise the LDS limit: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    dim3 grid(units, p.co_tiles * p.ci_tiles);
+    dim3 grid(units, p.co_tiles * p.ci_tiles, p.jobs ? p.jobs : 1);
     if (aligned) hipLaunchKernelGGL((conv1x1_wgrad_bf16_kernel<C, true>), grid, dim3(512), C::LDS, st, p);
     else hipLaunchKernelGGL((conv1x1_wgrad_bf16_kernel<C, false>), grid, dim3(512), C::LDS, st, p);
     SIS_CHECK_LAUNCH("conv1x1_wgrad_bf16_kernel");
@@ -458,8 +473,9 @@ int launch_pw(const PwParams& p, int units, bool aligned, hipStream_t st) {
 
 struct WgPlan { int wm, wn, ks, nwv, strips, row_blocks, rows_per_block, co_tiles, ci_tiles, units, partials; int64_t slab_bytes; };
 
-bool wgrad_plan(int batch, int cin, int cout, int h, int w, int64_t workspace_bytes, WgPlan* pl) {
+bool wgrad_plan(int batch, int cin, int cout, int h, int w, int64_t workspace_bytes, WgPlan* pl, int jobs = 1) {
     if (cin % 8 || cin < 16) return false;
+    workspace_bytes /= jobs;   // every layer of the launch has its own slabs
     // SIS_WGRAD_WAVES: 8 / 4 force the 8-wave tiles / the 4-wave 64 x 64 tile (two workgroups per CU) wherever it applies; default:
     // the 4-wave tile only where the 8-wave one wastes half its 128 input channels (64 -> 64 layers on aligned maps: 114 -> 84 us
     // at 256 x 256; every wider layer measured 5-20 % SLOWER on 64 x 64 tiles -- the X rows are staged twice as often)
@@ -484,7 +500,7 @@ bool wgrad_plan(int batch, int cin, int cout, int h, int w, int64_t workspace_by
     // row blocks: enough workgroups to fill the chip (~2 per CU), at least 8 rows each, slabs within the workspace
     int rbk = 1;
     static const int min_wg = getenv("SIS_WGRAD_MINWG") ? atoi(getenv("SIS_WGRAD_MINWG")) : 512;
-    while (rbk < h / 8 && (int64_t)batch * pl->strips * rbk * tiles < min_wg &&
+    while (rbk < h / 8 && (int64_t)batch * pl->strips * rbk * tiles * jobs < min_wg &&
            (int64_t)batch * pl->strips * (rbk * 2) * tile_bytes <= workspace_bytes) rbk *= 2;
     pl->rows_per_block = sis_cdiv(h, rbk);
     pl->row_blocks = sis_cdiv(h, pl->rows_per_block);
@@ -506,7 +522,7 @@ int launch_wgrad(const WgParams& p, int units, hipStream_t st, const char* name)
         if (e != hipSuccess) return sis_fail("%s: cannot raise the LDS limit: %s", name, hipGetErrorString(e));
         attr_set = true;
     }
-    dim3 grid(units, p.co_tiles * p.ci_tiles);
+    dim3 grid(units, p.co_tiles * p.ci_tiles, p.jobs ? p.jobs : 1);
     SIS_OCC_REPORT((conv_wgrad_bf16_kernel<C, true>), C::THREADS, C::LDS);
     if (p.aligned) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<C, true>), grid, dim3(C::THREADS), C::LDS, st, p);
     else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<C, false>), grid, dim3(C::THREADS), C::LDS, st, p);
@@ -522,21 +538,27 @@ extern "C" int sis_conv_bf16_wgrad_supported(int batch, int cin, int cout, int h
     return wgrad_plan(batch, cin, cout, h, w, workspace_bytes, &pl) ? 1 : 0;
 }
 
-extern "C" int sis_conv_bf16_wgrad(void* dw, int dw_dtype, const void* x, const void* grad_y, int batch, int cin, int cout,
-                                   int h, int w, void* workspace, int64_t workspace_bytes, void* stream) {
-    if (batch <= 0) return 0;
-    SIS_REQUIRE(dw && x && grad_y && workspace, "sis_conv_bf16_wgrad: null pointer");
-    SIS_REQUIRE(dw_dtype == SIS_F32 || dw_dtype == SIS_BF16, "sis_conv_bf16_wgrad: dW must be float32 or bfloat16");
+// n_jobs layers of ONE shape: one launch of the tile kernel (grid.z = layer) and one of the reduction (grid.y = layer).
+static int conv_wgrad_jobs(void* const* dw, int dw_dtype, const void* const* x, const void* const* grad_y, int n_jobs, int batch, int cin,
+                           int cout, int h, int w, void* workspace, int64_t workspace_bytes, void* stream, const char* who) {
     WgPlan pl;
-    SIS_REQUIRE(wgrad_plan(batch, cin, cout, h, w, workspace_bytes, &pl),
-                "sis_conv_bf16_wgrad: no tile plan for %d->%d @%dx%d within %lld workspace bytes", cin, cout, h, w,
-                (long long)workspace_bytes);
+    SIS_REQUIRE(wgrad_plan(batch, cin, cout, h, w, workspace_bytes, &pl, n_jobs),
+                "%s: no tile plan for %d x (%d->%d @%dx%d) within %lld workspace bytes", who, n_jobs, cin, cout, h, w, (long long)workspace_bytes);
     WgParams p;
-    p.x = (const u16*)x; p.gy = (const u16*)grad_y; p.slab = (float*)workspace;
+    p.x = (const u16*)x[0]; p.gy = (const u16*)grad_y[0]; p.slab = (float*)workspace;
     p.N = batch; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w;
     p.strips = pl.strips; p.row_blocks = pl.row_blocks; p.rows_per_block = pl.rows_per_block;
     p.co_tiles = pl.co_tiles; p.ci_tiles = pl.ci_tiles;
-    p.aligned = (w % 8 == 0) && ((((uintptr_t)x) | ((uintptr_t)grad_y)) & 15) == 0;
+    p.jobs = n_jobs > 1 ? n_jobs : 0;
+    p.slab_job_stride = pl.slab_bytes / 4;
+    uintptr_t bits = 0;
+    WgDwTab tab = {};
+    for (int j = 0; j < n_jobs; ++j) {
+        SIS_REQUIRE(dw[j] && x[j] && grad_y[j], "%s: null pointer in layer %d", who, j);
+        p.xj[j] = (const u16*)x[j]; p.gyj[j] = (const u16*)grad_y[j]; tab.dw[j] = dw[j];
+        bits |= (uintptr_t)x[j] | (uintptr_t)grad_y[j];
+    }
+    p.aligned = (w % 8 == 0) && (bits & 15) == 0;
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (pl.nwv == 4 && pl.ks == 4) rc = launch_wgrad<WgCfg<2, 2, 4, 4>>(p, pl.units, st, "conv_wgrad_bf16_kernel<2,2,4,4>");
@@ -550,13 +572,49 @@ extern "C" int sis_conv_bf16_wgrad(void* dw, int dw_dtype, const void* x, const 
     if (rc) return rc;
     const int mt = 32 * pl.wm, nt = 32 * pl.wn;
     const int blocks = 9 * cout * sis_cdiv(cin, 64);
+    const long long stride = p.jobs ? p.slab_job_stride : 0;
     if (dw_dtype == SIS_F32)
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (float*)dw, (const float*)workspace,
-                           pl.partials, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt, 9);
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel<float>, dim3(blocks, n_jobs), dim3(256), 0, st, (float*)dw[0], (const float*)workspace,
+                           pl.partials, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt, 9, stride, tab);
     else
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel<__hip_bfloat16>, dim3(blocks), dim3(256), 0, st, (__hip_bfloat16*)dw,
-                           (const float*)workspace, pl.partials, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt, 9);
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel<__hip_bfloat16>, dim3(blocks, n_jobs), dim3(256), 0, st, (__hip_bfloat16*)dw[0],
+                           (const float*)workspace, pl.partials, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt, 9, stride, tab);
     SIS_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
+    return 0;
+}
+
+// layers per launch: at most WG_JOBS_MAX, and as many as leave every layer its slabs in the workspace
+template <typename PlanFits>
+static int jobs_per_launch(int n_jobs, PlanFits fits) {
+    int n = n_jobs < WG_JOBS_MAX ? n_jobs : WG_JOBS_MAX;
+    while (n > 1 && !fits(n)) n = (n + 1) / 2;
+    return n;
+}
+
+extern "C" int sis_conv_bf16_wgrad(void* dw, int dw_dtype, const void* x, const void* grad_y, int batch, int cin, int cout,
+                                   int h, int w, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (batch <= 0) return 0;
+    SIS_REQUIRE(dw && x && grad_y && workspace, "sis_conv_bf16_wgrad: null pointer");
+    SIS_REQUIRE(dw_dtype == SIS_F32 || dw_dtype == SIS_BF16, "sis_conv_bf16_wgrad: dW must be float32 or bfloat16");
+    return conv_wgrad_jobs(&dw, dw_dtype, &x, &grad_y, 1, batch, cin, cout, h, w, workspace, workspace_bytes, stream, "sis_conv_bf16_wgrad");
+}
+
+/* The same for n_jobs layers of ONE shape (the trunk's repeated bottleneck units, queued during the backward): `dw`, `x`,
+ * `grad_y` are HOST arrays of n_jobs device pointers.  One tile launch + one reduction launch per <= 16 layers; the tile plan
+ * counts the layers' workgroups together, so every layer is cut into fewer, longer units than it would be alone. */
+extern "C" int sis_conv_bf16_wgrad_multi(void* const* dw, int dw_dtype, const void* const* x, const void* const* grad_y, int n_jobs,
+                                         int batch, int cin, int cout, int h, int w, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (batch <= 0 || n_jobs <= 0) return 0;
+    SIS_REQUIRE(dw && x && grad_y && workspace, "sis_conv_bf16_wgrad_multi: null pointer");
+    SIS_REQUIRE(dw_dtype == SIS_F32 || dw_dtype == SIS_BF16, "sis_conv_bf16_wgrad_multi: dW must be float32 or bfloat16");
+    for (int j0 = 0; j0 < n_jobs;) {
+        const int left = n_jobs - j0;
+        const int n = jobs_per_launch(left, [&](int k) { WgPlan pl; return wgrad_plan(batch, cin, cout, h, w, workspace_bytes, &pl, k); });
+        const int rc = conv_wgrad_jobs(dw + j0, dw_dtype, x + j0, grad_y + j0, n, batch, cin, cout, h, w, workspace, workspace_bytes, stream,
+                                       "sis_conv_bf16_wgrad_multi");
+        if (rc) return rc;
+        j0 += n;
+    }
     return 0;
 }
 
@@ -566,19 +624,25 @@ extern "C" int sis_conv1x1_bf16_wgrad_supported(int batch, int cin, int cout, in
     return pw_plan(batch, cin, cout, pixels, workspace_bytes, &pl) ? 1 : 0;
 }
 
-extern "C" int sis_conv1x1_bf16_wgrad(void* dw, int dw_dtype, const void* x, const void* grad_y, int batch, int cin, int cout,
-                                      int pixels, void* workspace, int64_t workspace_bytes, void* stream) {
-    if (batch <= 0) return 0;
-    SIS_REQUIRE(dw && x && grad_y && workspace, "sis_conv1x1_bf16_wgrad: null pointer");
-    SIS_REQUIRE(dw_dtype == SIS_F32 || dw_dtype == SIS_BF16, "sis_conv1x1_bf16_wgrad: dW must be float32 or bfloat16");
+static int conv1x1_wgrad_jobs(void* const* dw, int dw_dtype, const void* const* x, const void* const* grad_y, int n_jobs, int batch, int cin,
+                              int cout, int pixels, void* workspace, int64_t workspace_bytes, void* stream, const char* who) {
     PwPlan pl;
-    SIS_REQUIRE(pw_plan(batch, cin, cout, pixels, workspace_bytes, &pl),
-                "sis_conv1x1_bf16_wgrad: no plan for %d->%d, %d pixels within %lld workspace bytes", cin, cout, pixels, (long long)workspace_bytes);
+    SIS_REQUIRE(pw_plan(batch, cin, cout, pixels, workspace_bytes, &pl, n_jobs),
+                "%s: no plan for %d x (%d->%d, %d pixels) within %lld workspace bytes", who, n_jobs, cin, cout, pixels, (long long)workspace_bytes);
     PwParams p;
-    p.x = (const u16*)x; p.gy = (const u16*)grad_y; p.slab = (float*)workspace;
+    p.x = (const u16*)x[0]; p.gy = (const u16*)grad_y[0]; p.slab = (float*)workspace;
     p.N = batch; p.Cin = cin; p.Cout = cout; p.P = pixels;
     p.units_per_image = pl.units_per_image; p.unit_len = pl.unit_len; p.co_tiles = pl.co_tiles; p.ci_tiles = pl.ci_tiles;
-    const bool aligned = (pixels % 8 == 0) && ((((uintptr_t)x) | ((uintptr_t)grad_y)) & 15) == 0;
+    p.jobs = n_jobs > 1 ? n_jobs : 0;
+    p.slab_job_stride = pl.slab_bytes / 4;
+    uintptr_t bits = 0;
+    WgDwTab tab = {};
+    for (int j = 0; j < n_jobs; ++j) {
+        SIS_REQUIRE(dw[j] && x[j] && grad_y[j], "%s: null pointer in layer %d", who, j);
+        p.xj[j] = (const u16*)x[j]; p.gyj[j] = (const u16*)grad_y[j]; tab.dw[j] = dw[j];
+        bits |= (uintptr_t)x[j] | (uintptr_t)grad_y[j];
+    }
+    const bool aligned = (pixels % 8 == 0) && (bits & 15) == 0;
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (pl.wm == 2 && pl.wn == 2) rc = launch_pw<PwCfg<2, 2, 2>>(p, pl.units, aligned, st);
@@ -588,12 +652,38 @@ extern "C" int sis_conv1x1_bf16_wgrad(void* dw, int dw_dtype, const void* x, con
     if (rc) return rc;
     const int mt = 64 * pl.wm, nt = 64 * pl.wn;
     const int blocks = cout * sis_cdiv(cin, 64);
+    const long long stride = p.jobs ? p.slab_job_stride : 0;
     if (dw_dtype == SIS_F32)
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (float*)dw, (const float*)workspace,
-                           pl.units, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt, 1);
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel<float>, dim3(blocks, n_jobs), dim3(256), 0, st, (float*)dw[0], (const float*)workspace,
+                           pl.units, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt, 1, stride, tab);
     else
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel<__hip_bfloat16>, dim3(blocks), dim3(256), 0, st, (__hip_bfloat16*)dw,
-                           (const float*)workspace, pl.units, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt, 1);
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel<__hip_bfloat16>, dim3(blocks, n_jobs), dim3(256), 0, st, (__hip_bfloat16*)dw[0],
+                           (const float*)workspace, pl.units, cout, cin, pl.co_tiles * mt, pl.ci_tiles * nt, 1, stride, tab);
     SIS_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
+    return 0;
+}
+
+extern "C" int sis_conv1x1_bf16_wgrad(void* dw, int dw_dtype, const void* x, const void* grad_y, int batch, int cin, int cout,
+                                      int pixels, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (batch <= 0) return 0;
+    SIS_REQUIRE(dw && x && grad_y && workspace, "sis_conv1x1_bf16_wgrad: null pointer");
+    SIS_REQUIRE(dw_dtype == SIS_F32 || dw_dtype == SIS_BF16, "sis_conv1x1_bf16_wgrad: dW must be float32 or bfloat16");
+    return conv1x1_wgrad_jobs(&dw, dw_dtype, &x, &grad_y, 1, batch, cin, cout, pixels, workspace, workspace_bytes, stream, "sis_conv1x1_bf16_wgrad");
+}
+
+extern "C" int sis_conv1x1_bf16_wgrad_multi(void* const* dw, int dw_dtype, const void* const* x, const void* const* grad_y, int n_jobs,
+                                            int batch, int cin, int cout, int pixels, void* workspace, int64_t workspace_bytes,
+                                            void* stream) {
+    if (batch <= 0 || n_jobs <= 0) return 0;
+    SIS_REQUIRE(dw && x && grad_y && workspace, "sis_conv1x1_bf16_wgrad_multi: null pointer");
+    SIS_REQUIRE(dw_dtype == SIS_F32 || dw_dtype == SIS_BF16, "sis_conv1x1_bf16_wgrad_multi: dW must be float32 or bfloat16");
+    for (int j0 = 0; j0 < n_jobs;) {
+        const int left = n_jobs - j0;
+        const int n = jobs_per_launch(left, [&](int k) { PwPlan pl; return pw_plan(batch, cin, cout, pixels, workspace_bytes, &pl, k); });
+        const int rc = conv1x1_wgrad_jobs(dw + j0, dw_dtype, x + j0, grad_y + j0, n, batch, cin, cout, pixels, workspace, workspace_bytes, stream,
+                                          "sis_conv1x1_bf16_wgrad_multi");
+        if (rc) return rc;
+        j0 += n;
+    }
     return 0;
 }

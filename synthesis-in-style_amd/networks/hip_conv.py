@@ -357,9 +357,11 @@ class _ConvBf16Function(Function):
     """
 
     @staticmethod
-    def forward(ctx, input, weight, bias, stride, packed=None, adjoint=None):
+    def forward(ctx, input, weight, bias, stride, packed=None, adjoint=None, defer_wgrad=False):
         """``packed`` / ``adjoint``: the images of ``weight`` when the caller already has them (the trunk's weight bank writes
-        them for all layers in one launch)."""
+        them for all layers in one launch).  ``defer_wgrad``: the weight gradient may be completed as late as
+        ``sis_hip.flush_deferred`` (batched with the other layers of its shape) -- only a caller whose consumer of that gradient
+        flushes first may say so (the trunk: ``_BankStandardize.backward``)."""
         input = input.contiguous()
         cout, cin, k, _ = weight.shape
         h, w = input.shape[2], input.shape[3]
@@ -371,6 +373,7 @@ class _ConvBf16Function(Function):
             packed = sis_hip.conv_bf16_pack(weight, h, w, stride)
         ctx.save_for_backward(input, weight, adjoint)
         ctx.stride, ctx.has_bias = stride, bias is not None
+        ctx.defer_wgrad = bool(defer_wgrad)
         return sis_hip.conv_bf16(input, packed, cout, k, stride, bias)
 
     @staticmethod
@@ -424,10 +427,13 @@ class _ConvBf16Function(Function):
                                                                  (0, 0), 1, (True, False, False))[0]
         if ctx.needs_input_grad[1]:
             key = None if pad_out else weight.data_ptr()   # the parameter's arena slice (sis_hip.grad_out); a padded weight is a copy
+            # (deferred: same-shape layers of the trunk in one launch at the end of its backward; plain stride-1 layers only --
+            # the zero-stuffed / sampled / padded operands above are temporaries of this call)
+            later = ctx.defer_wgrad and ctx.stride == 1 and not pad_out and scatter is None and grad_weight is None
             if k == 3 and s == 1 and sis_hip.conv_bf16_wgrad_supported(b, cin, cout, h, w):
-                grad_weight = sis_hip.conv_bf16_wgrad(input, gy, weight.dtype, for_param=key)
+                grad_weight = sis_hip.conv_bf16_wgrad(input, gy, weight.dtype, for_param=key, defer=later)
             elif k == 1 and s == 1 and _PW_WGRAD_OWN and sis_hip.conv1x1_bf16_wgrad_supported(b, cin, cout, h * w):
-                grad_weight = sis_hip.conv1x1_bf16_wgrad(input, gy, weight.dtype, for_param=key)   # csrc/conv_bf16_wgrad.hip, any plane size
+                grad_weight = sis_hip.conv1x1_bf16_wgrad(input, gy, weight.dtype, for_param=key, defer=later)   # csrc/conv_bf16_wgrad.hip, any plane size
             elif k == 1 and s == 1:
                 sis_hip.library_call("hip_conv._ConvBf16Function.wgrad_1x1")
                 grad_weight = torch.bmm(gy.view(b, cout, h * w), input.view(b, cin, h * w).transpose(1, 2)).sum(0, dtype=torch.float32)
@@ -446,15 +452,16 @@ class _ConvBf16Function(Function):
             full = grad_input.new_zeros((b, cin) + scatter)
             full[:, :, ::2, ::2] = grad_input
             grad_input = full
-        return grad_input, grad_weight, grad_bias, None, None, None
+        return grad_input, grad_weight, grad_bias, None, None, None, None
 
 
-def conv_bf16(input, weight, bias=None, stride=1, prepacked=None):
+def conv_bf16(input, weight, bias=None, stride=1, prepacked=None, defer_wgrad=False):
     """Differentiable bf16 convolution (padding k // 2) on the matrix-core kernels; the caller checks
-    ``conv_bf16_applicable``.  ``prepacked``: (forward image, adjoint image or None) of ``weight``."""
+    ``conv_bf16_applicable``.  ``prepacked``: (forward image, adjoint image or None) of ``weight``; ``defer_wgrad``: see
+    ``_ConvBf16Function.forward``."""
     if prepacked is not None:
-        return _ConvBf16Function.apply(input, weight, bias, stride, prepacked[0], prepacked[1])
-    return _ConvBf16Function.apply(input, weight, bias, stride)
+        return _ConvBf16Function.apply(input, weight, bias, stride, prepacked[0], prepacked[1], defer_wgrad)
+    return _ConvBf16Function.apply(input, weight, bias, stride, None, None, defer_wgrad)
 
 
 _BF16_CONV = os.environ.get('SIS_BF16_CONV', '1') != '0'  # 0: bf16 convolutions stay on the library (A/B runs)

@@ -61,6 +61,7 @@ class _BankStandardize(Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        sis_hip.flush_deferred()   # the layers' weight gradients were queued (conv_bf16(..., defer_wgrad=True)): complete them first
         return (None,) + tuple(ctx.bank.backward(grads))
 
 
@@ -141,7 +142,7 @@ class StdConv2d(nn.Conv2d):
             w, packed, adjoint = self._banked
             xb = x if x.dtype == torch.bfloat16 else x.bfloat16()
             if conv_bf16_applicable(xb, w, self.stride, self.padding, self.dilation, self.groups):
-                return conv_bf16(xb, w, self.bias, self.stride[0], prepacked=(packed, adjoint))
+                return conv_bf16(xb, w, self.bias, self.stride[0], prepacked=(packed, adjoint), defer_wgrad=True)
         else:
             w = self.standardized_weight()
         if _BF16_CONV and w.dtype == torch.bfloat16 and self.padding_mode == 'zeros' and x.is_cuda and x.dim() == 4:

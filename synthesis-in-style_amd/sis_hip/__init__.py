@@ -130,11 +130,13 @@ _SIGNATURES = {
     "sis_conv_bf16_pack_both": ([_vp, _vp, _vp, _i] + [_i] * 5 + [_vp], _i),
     "sis_conv_bf16_wgrad_supported": ([_i] * 5 + [_i64], _i),
     "sis_conv_bf16_wgrad": ([_vp, _i, _vp, _vp] + [_i] * 5 + [_vp, _i64, _vp], _i),
+    "sis_conv_bf16_wgrad_multi": ([_vp, _i, _vp, _vp] + [_i] * 6 + [_vp, _i64, _vp], _i),
     "sis_weight_std_pack_plan": ([_i] * 4 + [_vp] * 5, _i),
     "sis_weight_std_pack_multi": ([_vp, _i, _i, _f, _vp], _i),
     "sis_weight_std_bwd_multi": ([_vp, _vp, _vp, _vp, _i, _vp], _i),
     "sis_conv1x1_bf16_wgrad_supported": ([_i] * 4 + [_i64], _i),
     "sis_conv1x1_bf16_wgrad": ([_vp, _i, _vp, _vp] + [_i] * 4 + [_vp, _i64, _vp], _i),
+    "sis_conv1x1_bf16_wgrad_multi": ([_vp, _i, _vp, _vp] + [_i] * 5 + [_vp, _i64, _vp], _i),
 }
 
 
@@ -627,7 +629,7 @@ def grad_out_fused(keys, rows, cols, device):
 # new tensor to it immediately -- gradient accumulation over two backwards keeps the undeferred path).  Outside a backward (tests
 # calling a binding directly) nothing is deferred.  SIS_DEFER_REDUCES=0 switches it off (A/B runs).
 _DEFER = os.environ.get("SIS_DEFER_REDUCES", "1") != "0"
-_deferred = {"ln": [], "wgrad": {}}   # wgrad: (tokens, out, in, lda, ldb, device) -> [(grad, x, dw, db addresses, storages)]
+_deferred = {"ln": [], "wgrad": {}, "conv": {}}   # wgrad: (tokens, out, in, lda, ldb, device) -> [(grad, x, dw, db addresses, storages)]
 _deferred_task = [None]         # the running backward has its end-of-backward callback queued (reset by the callback itself:
                                 # graph task ids are not unique across backwards)
 
@@ -665,7 +667,7 @@ def _hold(*tensors):
 
 
 def deferred_pending():
-    return len(_deferred["ln"]) + sum(len(v) for v in _deferred["wgrad"].values())
+    return len(_deferred["ln"]) + sum(len(v) for v in _deferred["wgrad"].values()) + sum(len(v) for v in _deferred["conv"].values())
 
 
 _DEFER_WGRAD = os.environ.get("SIS_DEFER_WGRAD", "1") != "0"   # 0: the encoder's weight-gradient GEMMs where their operands appear
@@ -678,7 +680,40 @@ def block_wgrad_deferral(owner, blocked=True):
 
 
 def deferred_wgrad_pending():
-    return any(_deferred["wgrad"].values())
+    return any(_deferred["wgrad"].values()) or any(_deferred["conv"].values())
+
+
+def _defer_conv_wgrad(kind, x, grad_output, dw, dims):
+    """Queues a bf16 convolution's weight gradient (kind 3: 3x3, 1: 1x1) for the batched launch of ``flush_deferred``: layers of
+    one shape (the trunk's repeated bottleneck units) share one tile launch and one reduction launch, planned for their joint
+    workgroup count.  ``dw`` is valid after the flush only; the caller guarantees that nothing reads it before."""
+    key = (kind,) + tuple(dims) + (dw.dtype, x.device)
+    _deferred["conv"].setdefault(key, []).append((x.data_ptr(), grad_output.data_ptr(), dw.data_ptr(), _hold(x, grad_output, dw)))
+
+
+def _conv_wgrad_deferrable():
+    return _DEFER_WGRAD and not _defer_wgrad_blockers and deferring()
+
+
+def _flush_conv_wgrads():
+    queued, _deferred["conv"] = _deferred["conv"], {}
+    for key, jobs in queued.items():
+        kind, dims, dtype, device = key[0], key[1:-2], key[-2], key[-1]
+        n = len(jobs)
+        arr = ctypes.c_void_p * n
+        xs, gys, dws = arr(*[j[0] for j in jobs]), arr(*[j[1] for j in jobs]), arr(*[j[2] for j in jobs])
+        ws = _workspace(device)
+        with torch.cuda.device(device):
+            if kind == 3:
+                b, cin, cout, h, w = dims
+                _check(_launch(None, 2.0 * b * cout * cin * 9 * h * w * n, 0.0,
+                               lambda: lib().sis_conv_bf16_wgrad_multi(dws, _DTYPE_CODE[dtype], xs, gys, n, b, cin, cout, h, w, _ptr(ws),
+                                                                       ws.numel(), _stream())), "sis_conv_bf16_wgrad_multi")
+            else:
+                b, cin, cout, pixels = dims
+                _check(_launch(None, 2.0 * b * cout * cin * pixels * n, 0.0,
+                               lambda: lib().sis_conv1x1_bf16_wgrad_multi(dws, _DTYPE_CODE[dtype], xs, gys, n, b, cin, cout, pixels, _ptr(ws),
+                                                                          ws.numel(), _stream())), "sis_conv1x1_bf16_wgrad_multi")
 
 
 def defer_wgrad_bias(grad, x, dw=None):
@@ -708,6 +743,8 @@ def defer_wgrad_bias(grad, x, dw=None):
 def flush_deferred():
     """Runs every queued reduction (one launch per 32 jobs) and weight gradient (one launch per Linear shape and 16 jobs).
     Cheap when nothing is queued."""
+    if _deferred["conv"]:
+        _flush_conv_wgrads()
     if _deferred["wgrad"]:
         queued, _deferred["wgrad"] = _deferred["wgrad"], {}
         for key, jobs in queued.items():
@@ -1110,14 +1147,19 @@ def conv_bf16_wgrad_supported(batch, cin, cout, h, w):
     return bool(lib().sis_conv_bf16_wgrad_supported(batch, cin, cout, h, w, WORKSPACE_BYTES))
 
 
-def conv_bf16_wgrad(x, grad_output, out_dtype=torch.float32, for_param=None):
-    """dL/dw [Cout,Cin,3,3] (float32 or bfloat16) of a stride-1, padding-1 3x3 convolution from its bf16 input and dL/dy."""
+def conv_bf16_wgrad(x, grad_output, out_dtype=torch.float32, for_param=None, defer=False):
+    """dL/dw [Cout,Cin,3,3] (float32 or bfloat16) of a stride-1, padding-1 3x3 convolution from its bf16 input and dL/dy.
+    ``defer``: inside a backward the launch may wait for ``flush_deferred`` (batched with the other layers of its shape); the
+    caller then guarantees that nobody reads the result before the flush."""
     require_device(x, "input")
     if x.dtype != torch.bfloat16 or grad_output.dtype != torch.bfloat16 or not x.is_contiguous() or not grad_output.is_contiguous():
         raise RuntimeError("conv_bf16_wgrad: input and grad_output must be contiguous bfloat16 tensors")
     b, cin, h, w = x.shape
     cout = grad_output.shape[1]
     dw = grad_out(for_param, (cout, cin, 3, 3), out_dtype, x.device)
+    if defer and _conv_wgrad_deferrable():
+        _defer_conv_wgrad(3, x, grad_output, dw, (b, cin, cout, h, w))
+        return dw
     ws = _workspace(x.device)
     with torch.cuda.device(x.device):
         _check(_launch(None, 2.0 * b * cout * cin * 9 * h * w, 2.0 * (x.numel() + grad_output.numel()) + 4.0 * dw.numel(),
@@ -1251,7 +1293,7 @@ def conv1x1_bf16_wgrad_supported(batch, cin, cout, pixels):
     return bool(lib().sis_conv1x1_bf16_wgrad_supported(batch, cin, cout, pixels, WORKSPACE_BYTES))
 
 
-def conv1x1_bf16_wgrad(x, grad_output, out_dtype=torch.float32, for_param=None):
+def conv1x1_bf16_wgrad(x, grad_output, out_dtype=torch.float32, for_param=None, defer=False):
     """dL/dw [Cout,Cin,1,1] (float32 or bfloat16) of a stride-1 1x1 convolution from its bf16 NCHW input and dL/dy."""
     require_device(x, "input")
     if x.dtype != torch.bfloat16 or grad_output.dtype != torch.bfloat16 or not x.is_contiguous() or not grad_output.is_contiguous():
@@ -1262,6 +1304,9 @@ def conv1x1_bf16_wgrad(x, grad_output, out_dtype=torch.float32, for_param=None):
     if grad_output.shape[0] != b or grad_output[0, 0].numel() != pixels:
         raise RuntimeError("conv1x1_bf16_wgrad: input and grad_output disagree on batch / plane size")
     dw = grad_out(for_param, (cout, cin, 1, 1), out_dtype, x.device)
+    if defer and _conv_wgrad_deferrable():   # (as conv_bf16_wgrad)
+        _defer_conv_wgrad(1, x, grad_output, dw, (b, cin, cout, pixels))
+        return dw
     ws = _workspace(x.device)
     with torch.cuda.device(x.device):
         _check(_launch(None, 2.0 * b * cout * cin * pixels, 2.0 * (x.numel() + grad_output.numel()) + 4.0 * dw.numel(),

@@ -205,3 +205,35 @@ def test_plain_pack_bank_writes_the_images_of_the_single_layer_pack(device):
     weights[2].mul_(2.0)
     bank.refresh()   # same buffers, new contents
     assert torch.equal(bank.packed[2], sis_hip.conv_bf16_pack(weights[2], 64, 64, 1))
+
+
+@pytest.mark.parametrize("kind,jobs,batch,cin,cout,h,w", [(3, 8, 8, 256, 256, 32, 32), (3, 3, 2, 128, 128, 64, 64), (3, 20, 1, 64, 64, 16, 16),
+                                                          (3, 2, 1, 64, 64, 127, 127), (1, 8, 8, 1024, 256, 32, 32), (1, 5, 2, 256, 1024, 32, 32),
+                                                          (1, 2, 1, 64, 256, 127, 127), (1, 18, 2, 72, 40, 20, 28)])
+def test_batched_weight_gradients_of_one_shape(device, kind, jobs, batch, cin, cout, h, w):
+    """Several layers of ONE shape through one tile launch + one reduction launch (sis_conv_bf16_wgrad_multi /
+    sis_conv1x1_bf16_wgrad_multi, what ``sis_hip.flush_deferred`` runs for the trunk's repeated bottleneck units): every layer's
+    dW against its own single-layer call (same products; the joint tile plan cuts a layer into other units, so the fp32 partial
+    sums associate differently: 2e-3 of the largest entry for fp32 results, 1e-2 for bf16 ones), more layers than one launch
+    takes (16), unaligned planes, and bitwise repeatability of the batched form."""
+    import sis_hip
+    gen = torch.Generator().manual_seed(kind * 1000 + jobs * 10 + cin)
+    xs = [torch.randn(batch, cin, h, w, generator=gen).to(device).bfloat16() for _ in range(jobs)]
+    gys = [torch.randn(batch, cout, h, w, generator=gen).to(device).bfloat16() for _ in range(jobs)]
+    single = sis_hip.conv_bf16_wgrad if kind == 3 else sis_hip.conv1x1_bf16_wgrad
+    dims = (batch, cin, cout, h, w) if kind == 3 else (batch, cin, cout, h * w)
+    for dtype, tol in ((torch.float32, 2e-3), (torch.bfloat16, 1e-2)):
+        ref = [single(x, gy, dtype) for x, gy in zip(xs, gys)]
+        runs = []
+        for _ in range(2):
+            dws = [torch.empty_like(r) for r in ref]
+            for x, gy, dw in zip(xs, gys, dws):
+                sis_hip._defer_conv_wgrad(kind, x, gy, dw, dims)
+            assert sis_hip.deferred_pending() == jobs
+            sis_hip.flush_deferred()
+            assert sis_hip.deferred_pending() == 0
+            runs.append(dws)
+        for j in range(jobs):
+            scale = float(ref[j].float().abs().max())
+            assert float((runs[0][j].float() - ref[j].float()).abs().max()) <= tol * scale, (j, dtype)
+            assert torch.equal(runs[0][j], runs[1][j])
