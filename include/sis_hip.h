@@ -300,6 +300,10 @@ int sis_conv3x3_eligible(int batch, int cin, int cout, int h, int w); /* 1 if si
 int sis_conv3x3_wgrad_eligible(int batch, int cin, int cout, int h, int w, int64_t workspace_bytes);
 int sis_conv3x3_wgrad(float* dw, const float* x, const float* gy, int batch, int cin, int cout, int h, int w,
                       void* workspace, int64_t workspace_bytes, void* stream);
+/* n_jobs layers of ONE shape (EMANet's repeated bottleneck units) through one tile launch + one finish launch: `dw`, `x`, `gy` are
+ * HOST arrays of n_jobs device pointers; the K slices are planned for the layers' joint tile count. */
+int sis_conv3x3_wgrad_multi(float* const* dw, const float* const* x, const float* const* gy, int n_jobs, int batch, int cin, int cout,
+                            int h, int w, void* workspace, int64_t workspace_bytes, void* stream);
 int sis_conv3x3_prepack(float* u, const float* w, int cout, int cin, int adjoint, void* stream);
 /* forward and adjoint images of w [cout][cin][3][3] from one launch (training: the backward of the same step needs the adjoint):
  * u [cin][16][cout], u_adjoint [cout][16][cin]. */
@@ -404,6 +408,9 @@ int sis_conv1x1_wgrad_f32_supported(int batch, int cin, int cout, int hw);
 int64_t sis_conv1x1_wgrad_f32_workspace(int batch, int cin, int cout, int hw);
 int sis_conv1x1_wgrad_f32(float* dw, const float* gy, const float* x, int batch, int cin, int cout, int hw,
                           void* workspace, int64_t workspace_bytes, void* stream);
+/* (as sis_conv3x3_wgrad_multi; workspace: any size, the slices adapt -- sis_conv1x1_wgrad_f32_workspace x n_jobs is plenty) */
+int sis_conv1x1_wgrad_f32_multi(float* const* dw, const float* const* gy, const float* const* x, int n_jobs, int batch, int cin, int cout,
+                                int hw, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * nn.MaxPool2d / F.max_pool2d of the segmentation backbones (ceil_mode false, dilation 1): EMANet stem (3, 2, 1)

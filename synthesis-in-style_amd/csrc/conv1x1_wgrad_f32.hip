@@ -21,11 +21,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PK = 64;  // pixels per chunk (one 256-byte row piece per channel)
 
+constexpr int PWG_JOBS_MAX = 16;   // layers of one shape per launch (grid.z), operands through pointer tables
+
 struct PwgParams {
     const float* gy; const float* x; float* out;  // out: dW or the slab of slice 0
     int B, Cout, Cin, HW;
     int chunks_total, chunks_per_slice;
     int64_t slab_stride;  // floats between slices (0: single slice, out = dW)
+    int jobs;             // > 0: grid.z layers of this shape: gy / x / out from the tables (out of layer z: its dW or its first slab)
+    const float* gyj[PWG_JOBS_MAX]; const float* xj[PWG_JOBS_MAX]; float* outj[PWG_JOBS_MAX];
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t pwg_rsrc(const float* base) {
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wgrad_f32_kernel(const PwgPara
         const int row = 4 * v + (lane >> 4);
         voff[v] = (unsigned)(row * p.HW) * 4u + (unsigned)(((lane & 15) ^ (row & 15)) * 16);
     }
-    const __amdgpu_buffer_rsrc_t a_rsrc = pwg_rsrc(p.gy), b_rsrc = pwg_rsrc(p.x);
+    const __amdgpu_buffer_rsrc_t a_rsrc = pwg_rsrc(p.jobs ? p.gyj[blockIdx.z] : p.gy), b_rsrc = pwg_rsrc(p.jobs ? p.xj[blockIdx.z] : p.x);
     auto stage = [&](int chunk, int buf) {
         const int b = chunk / blocks_per_sample, p0 = (chunk - b * blocks_per_sample) * PK;
         float* al = lds + buf * STAGE;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wgrad_f32_kernel(const PwgPara
         __syncthreads();  // next chunk landed (vmcnt 0) and everyone is done with this buffer
     }
 
-    float* out = p.out + (int64_t)blockIdx.y * p.slab_stride;
+    float* out = (p.jobs ? p.outj[blockIdx.z] : p.out) + (int64_t)blockIdx.y * p.slab_stride;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -122,10 +126,17 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wgrad_f32_kernel(const PwgPara
 // dW[i] = sum over slices, in a fixed order (8 interleaved partial sums, then their fixed tree): deterministic.  One float
 // per lane and 8 independent loads in flight per trip: the sum is latency bound otherwise (a float4 per lane walking 64
 // slices one after the other took longer than the GEMM for the 128 -> 512 layers).
+struct PwgDwTab { float* dw[PWG_JOBS_MAX]; };
+
 __global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ slab,
-                                                                   int n_slices, int64_t n) {
+                                                                   int n_slices, int64_t n, int64_t slab_job_stride = 0,
+                                                                   PwgDwTab tab = PwgDwTab{}) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (slab_job_stride) {   // grid.y layers of one shape
+        dw = tab.dw[blockIdx.y];
+        slab += (int64_t)blockIdx.y * slab_job_stride;
+    }
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int k = 0;
     for (; k + 8 <= n_slices; k += 8) {
@@ -147,7 +158,7 @@ int launch_pwg(PwgParams& p, int tiles, int slices, hipStream_t st) {
         attr_set = true;
     }
     SIS_OCC_REPORT((conv1x1_wgrad_f32_kernel<WM, WN, MB>), 512, lds);
-    hipLaunchKernelGGL((conv1x1_wgrad_f32_kernel<WM, WN, MB>), dim3(tiles, slices), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((conv1x1_wgrad_f32_kernel<WM, WN, MB>), dim3(tiles, slices, p.jobs ? p.jobs : 1), dim3(512), lds, st, p);
     SIS_CHECK_LAUNCH("sis_conv1x1_wgrad_f32");
     return 0;
 }
@@ -164,10 +175,10 @@ int pwg_tile(int cout, int cin, int* tm, int* tn) {
 }
 
 // K slices: about 3 workgroups per compute unit in all, at least 2 chunks each, slabs of at most 32 MB, at most 256
-int pwg_slices(int batch, int cin, int cout, int hw) {
+int pwg_slices(int batch, int cin, int cout, int hw, int jobs = 1) {
     int tm, tn;
     pwg_tile(cout, cin, &tm, &tn);
-    const int tiles = (cout / tm) * (cin / tn), chunks = batch * (hw / PK);
+    const int tiles = (cout / tm) * (cin / tn) * jobs, chunks = batch * (hw / PK);   // (the layers of a launch fill the chip together)
     int slices = (768 + tiles - 1) / tiles;
     if (slices > chunks / 2) slices = chunks / 2;
     const int64_t by_bytes = ((int64_t)32 << 20) / ((int64_t)cout * cin * 4);
@@ -190,25 +201,32 @@ extern "C" int64_t sis_conv1x1_wgrad_f32_workspace(int batch, int cin, int cout,
     return slices > 1 ? (int64_t)slices * cout * cin * (int64_t)sizeof(float) : 0;
 }
 
-extern "C" int sis_conv1x1_wgrad_f32(float* dw, const float* gy, const float* x, int batch, int cin, int cout, int hw,
-                                     void* workspace, int64_t workspace_bytes, void* stream) {
-    SIS_REQUIRE(dw && gy && x, "sis_conv1x1_wgrad_f32: null pointer");
-    SIS_REQUIRE(sis_conv1x1_wgrad_f32_supported(batch, cin, cout, hw), "sis_conv1x1_wgrad_f32: %d x (%d -> %d) on %d pixels not supported", batch, cin, cout, hw);
-    SIS_REQUIRE((((uintptr_t)dw | (uintptr_t)gy | (uintptr_t)x | (uintptr_t)workspace) & 15) == 0, "sis_conv1x1_wgrad_f32: pointers must be 16-byte aligned");
+static int pwg_jobs(float* const* dw, const float* const* gy, const float* const* x, int n_jobs, int batch, int cin, int cout, int hw,
+                    void* workspace, int64_t workspace_bytes, void* stream, const char* who) {
+    SIS_REQUIRE(sis_conv1x1_wgrad_f32_supported(batch, cin, cout, hw), "%s: %d x (%d -> %d) on %d pixels not supported", who, batch, cin, cout, hw);
     int tm, tn;
     const int shape = pwg_tile(cout, cin, &tm, &tn);
     PwgParams p;
-    p.gy = gy; p.x = x; p.B = batch; p.Cout = cout; p.Cin = cin; p.HW = hw;
+    p.B = batch; p.Cout = cout; p.Cin = cin; p.HW = hw;
     p.chunks_total = batch * (hw / PK);
     const int tiles = (cout / tm) * (cin / tn);
-    int slices = pwg_slices(batch, cin, cout, hw);  // bounded by the workspace the caller brought
+    int slices = pwg_slices(batch, cin, cout, hw, n_jobs);  // bounded by the workspace the caller brought (every layer its own slabs)
     const int64_t n = (int64_t)cout * cin;
-    if (!workspace || (int64_t)slices * n * 4 > workspace_bytes) slices = workspace ? (int)(workspace_bytes / (n * 4)) : 1;
+    if (!workspace || (int64_t)slices * n * 4 * n_jobs > workspace_bytes) slices = workspace ? (int)(workspace_bytes / (n * 4 * n_jobs)) : 1;
     if (slices < 1) slices = 1;
     p.chunks_per_slice = (p.chunks_total + slices - 1) / slices;
     slices = (p.chunks_total + p.chunks_per_slice - 1) / p.chunks_per_slice;
-    p.out = slices > 1 ? (float*)workspace : dw;
     p.slab_stride = slices > 1 ? n : 0;
+    p.jobs = n_jobs > 1 ? n_jobs : 0;
+    const int64_t job_stride = (int64_t)slices * n;
+    PwgDwTab tab = {};
+    for (int j = 0; j < n_jobs; ++j) {
+        SIS_REQUIRE(dw[j] && gy[j] && x[j], "%s: null pointer in layer %d", who, j);
+        SIS_REQUIRE((((uintptr_t)dw[j] | (uintptr_t)gy[j] | (uintptr_t)x[j] | (uintptr_t)workspace) & 15) == 0, "%s: pointers must be 16-byte aligned", who);
+        p.gyj[j] = gy[j]; p.xj[j] = x[j]; tab.dw[j] = dw[j];
+        p.outj[j] = slices > 1 ? (float*)workspace + j * job_stride : dw[j];
+    }
+    p.gy = gy[0]; p.x = x[0]; p.out = p.outj[0];
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (shape == 3) rc = launch_pwg<2, 4, 2>(p, tiles, slices, st);
@@ -217,9 +235,31 @@ extern "C" int sis_conv1x1_wgrad_f32(float* dw, const float* gy, const float* x,
     else rc = launch_pwg<8, 1, 1>(p, tiles, slices, st);
     if (rc) return rc;
     if (slices > 1) {
-        hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3((unsigned)sis_cdiv(n, 256)), dim3(256), 0, st, dw, (const float*)workspace, slices, n);
+        hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3((unsigned)sis_cdiv(n, 256), n_jobs), dim3(256), 0, st, dw[0], (const float*)workspace,
+                           slices, n, p.jobs ? job_stride : 0, tab);
         SIS_CHECK_LAUNCH("sis_conv1x1_wgrad_f32 (reduce)");
     }
     sis_kernel_name = "conv1x1_wgrad_f32_kernel";
+    return 0;
+}
+
+extern "C" int sis_conv1x1_wgrad_f32(float* dw, const float* gy, const float* x, int batch, int cin, int cout, int hw,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+    SIS_REQUIRE(dw && gy && x, "sis_conv1x1_wgrad_f32: null pointer");
+    return pwg_jobs(&dw, &gy, &x, 1, batch, cin, cout, hw, workspace, workspace_bytes, stream, "sis_conv1x1_wgrad_f32");
+}
+
+/* The same for n_jobs layers of ONE shape (EMANet's repeated bottleneck units, queued during the backward): `dw`, `gy`, `x` are
+ * HOST arrays of n_jobs device pointers; one tile launch (grid.z = layer) + one reduction launch per <= 16 layers, the K slices
+ * planned for the layers' joint tile count (fewer, longer slices per layer: less slab traffic). */
+extern "C" int sis_conv1x1_wgrad_f32_multi(float* const* dw, const float* const* gy, const float* const* x, int n_jobs, int batch, int cin,
+                                           int cout, int hw, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (n_jobs <= 0) return 0;
+    SIS_REQUIRE(dw && gy && x, "sis_conv1x1_wgrad_f32_multi: null pointer");
+    for (int j0 = 0; j0 < n_jobs; j0 += PWG_JOBS_MAX) {
+        const int n = n_jobs - j0 < PWG_JOBS_MAX ? n_jobs - j0 : PWG_JOBS_MAX;
+        const int rc = pwg_jobs(dw + j0, gy + j0, x + j0, n, batch, cin, cout, hw, workspace, workspace_bytes, stream, "sis_conv1x1_wgrad_f32_multi");
+        if (rc) return rc;
+    }
     return 0;
 }

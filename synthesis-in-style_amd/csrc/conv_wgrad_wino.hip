@@ -36,8 +36,13 @@ constexpr int GK = 8;     // tiles per chunk (MFMA K = 2 per instruction: 4 inst
 constexpr int GBLK = 64;  // channels per workgroup on both GEMM axes
 constexpr int GTHR = 512;
 
+constexpr int GW_JOBS_MAX = 16;   // layers of one shape per launch (grid.z), operands through pointer tables
+
 struct WgradParams {
     const float* x; const float* gy; float* slab;
+    int jobs;                   // > 0: grid.z layers: x / gy from the tables, slabs of layer z at slab + z * slab_job_stride floats
+    long long slab_job_stride;
+    const float* xj[GW_JOBS_MAX]; const float* gyj[GW_JOBS_MAX];
     int B, Cin, Cout, H, W;
     int chunks_total, chunks_per_slice, tiles_per_row, tiles_per_sample;
 };
@@ -71,8 +76,8 @@ __global__ __launch_bounds__(GTHR, 2) void conv_wgrad_wino_kernel(const WgradPar
     // Loads go through buffer descriptors: a masked element gets an out-of-range offset and the hardware returns 0 -- the mask
     // selects an ADDRESS, so nothing waits for loaded data before the transform a chunk later (a select on the loaded value is
     // a wait for every load in flight, at the slot where the load was issued).
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.gy, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.jobs ? p.xj[blockIdx.z] : p.x), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.jobs ? p.gyj[blockIdx.z] : p.gy), 0, 0x7FFFFFFF, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     unsigned g_xo = 0, g_go = 0;  // byte offsets of (patch row 0, column 2tx) and of the dY tile
     bool g_left = false, g_right = false;
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(GTHR, 2) void conv_wgrad_wino_kernel(const WgradPar
     }
 
     // raw partial sums: slab[slice][xi][co][ci]
-    float* sb = p.slab + (int64_t)blockIdx.y * 16 * p.Cout * p.Cin;
+    float* sb = p.slab + (p.jobs ? (int64_t)blockIdx.z * p.slab_job_stride : 0) + (int64_t)blockIdx.y * 16 * p.Cout * p.Cin;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -254,10 +259,17 @@ __global__ __launch_bounds__(GTHR, 2) void conv_wgrad_wino_kernel(const WgradPar
 }
 
 // dW[co][ci][3][3] = G^T (sum over slices of S[.][co][ci]) G,  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+struct GwDwTab { float* dw[GW_JOBS_MAX]; };
+
 __global__ __launch_bounds__(256) void conv_wgrad_finish_kernel(float* __restrict__ dw, const float* __restrict__ slab,
-                                                                int n_slices, int64_t n_pairs) {
+                                                                int n_slices, int64_t n_pairs, long long slab_job_stride = 0,
+                                                                GwDwTab tab = GwDwTab{}) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // i = co * Cin + ci
     if (i >= n_pairs) return;
+    if (slab_job_stride) {   // grid.y layers of one shape
+        dw = tab.dw[blockIdx.y];
+        slab += (int64_t)blockIdx.y * slab_job_stride;
+    }
     float s[4][4];
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) {
@@ -283,9 +295,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_finish_kernel(float* __restric
 
 // slab[0][xi][pair] <- sum over slices (slice order: deterministic); one lane per (xi, pair), coalesced over pairs.
 // In place: element (0, xi, pair) is read and written by the same lane only.
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(float* __restrict__ slab, int n_slices, int64_t n_pairs) {
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(float* __restrict__ slab, int n_slices, int64_t n_pairs,
+                                                                long long slab_job_stride = 0) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pairs) return;
+    slab += (int64_t)blockIdx.z * slab_job_stride;   // (grid.z layers of one shape)
     const int64_t plane = 16 * n_pairs;
     float* p = slab + (int64_t)blockIdx.y * n_pairs + i;
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;  // four independent load chains, added back in slice order below
@@ -299,7 +313,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(float* __restric
     p[0] = sum;
 }
 
-int wgrad_plan(WgradParams& p, int* ksplit, int batch, int cin, int cout, int h, int w, int64_t workspace_bytes) {
+int wgrad_plan(WgradParams& p, int* ksplit, int batch, int cin, int cout, int h, int w, int64_t workspace_bytes, int jobs = 1) {
+    workspace_bytes /= jobs;   // every layer of the launch has its own slabs
     if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return -1;
     if (h % 2 || w % 2 || cin % GBLK || cout % GBLK) return -1;
     if (((int64_t)batch * (h / 2) * (w / 2)) % GK) return -1;  // whole chunks of GK tiles
@@ -309,7 +324,7 @@ int wgrad_plan(WgradParams& p, int* ksplit, int batch, int cin, int cout, int h,
     p.tiles_per_row = w / 2;
     p.tiles_per_sample = (h / 2) * (w / 2);
     p.chunks_total = (int)((int64_t)batch * p.tiles_per_sample / GK);
-    const int64_t blocks = (int64_t)(cin / GBLK) * (cout / GBLK);
+    const int64_t blocks = (int64_t)(cin / GBLK) * (cout / GBLK) * jobs;   // (the layers of a launch fill the chip together)
     const int64_t slab_bytes = (int64_t)16 * cin * cout * 4;
     // One workgroup per CU fits (128 KB of LDS): ONE round of workgroups over the 256 CUs.  (Two rounds, the round-1 plan, halve
     // every slice -- twice the slab traffic and twice the prologues for the same multiplies: 256 -> 256 channels on 16 x 16 sub-images
@@ -334,38 +349,72 @@ extern "C" int sis_conv3x3_wgrad_eligible(int batch, int cin, int cout, int h, i
     return wgrad_plan(p, &ks, batch, cin, cout, h, w, workspace_bytes) == 0 ? 1 : 0;
 }
 
-extern "C" int sis_conv3x3_wgrad(float* dw, const float* x, const float* gy, int batch, int cin, int cout, int h, int w,
-                                 void* workspace, int64_t workspace_bytes, void* stream) {
-    SIS_REQUIRE(dw && x && gy && workspace, "sis_conv3x3_wgrad: null pointer");
-    SIS_REQUIRE(((((uintptr_t)x | (uintptr_t)gy) & 7) == 0), "sis_conv3x3_wgrad: tensors must be 8-byte aligned");
+static int gw_jobs(float* const* dw, const float* const* x, const float* const* gy, int n_jobs, int batch, int cin, int cout, int h, int w,
+                   void* workspace, int64_t workspace_bytes, void* stream, const char* who) {
     WgradParams p;
     int ksplit = 1;
-    SIS_REQUIRE(wgrad_plan(p, &ksplit, batch, cin, cout, h, w, workspace_bytes) == 0,
-                "sis_conv3x3_wgrad: needs even H and W, B*H*W/4 %% 8 == 0, channels %% 64 == 0 and a workspace of at least "
-                "64 * Cin * Cout bytes (got %d x %dx%d, %d -> %d)", batch, h, w, cin, cout);
-    p.x = x; p.gy = gy; p.slab = (float*)workspace;
+    SIS_REQUIRE(wgrad_plan(p, &ksplit, batch, cin, cout, h, w, workspace_bytes, n_jobs) == 0,
+                "%s: needs even H and W, B*H*W/4 %% 8 == 0, channels %% 64 == 0 and a workspace of at least "
+                "64 * Cin * Cout bytes per layer (got %d x %d x %dx%d, %d -> %d)", who, n_jobs, batch, h, w, cin, cout);
+    const int64_t pairs = (int64_t)cin * cout;
+    p.slab = (float*)workspace;
+    p.jobs = n_jobs > 1 ? n_jobs : 0;
+    p.slab_job_stride = (long long)ksplit * 16 * pairs;
+    GwDwTab tab = {};
+    for (int j = 0; j < n_jobs; ++j) {
+        SIS_REQUIRE(dw[j] && x[j] && gy[j], "%s: null pointer in layer %d", who, j);
+        SIS_REQUIRE(((((uintptr_t)x[j] | (uintptr_t)gy[j]) & 7) == 0), "%s: tensors must be 8-byte aligned", who);
+        p.xj[j] = x[j]; p.gyj[j] = gy[j]; tab.dw[j] = dw[j];
+    }
+    p.x = x[0]; p.gy = gy[0];
     const size_t lds = (size_t)4 * 16 * 2 * GBLK * 4 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_wino_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return sis_fail("sis_conv3x3_wgrad: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        if (e != hipSuccess) return sis_fail("%s: cannot raise the dynamic LDS limit: %s", who, hipGetErrorString(e));
         attr_set = true;
     }
     sis_kernel_name = "conv_wgrad_wino_kernel";
     SIS_OCC_REPORT(conv_wgrad_wino_kernel, GTHR, lds);
-    hipLaunchKernelGGL(conv_wgrad_wino_kernel, dim3((cin / GBLK) * (cout / GBLK), ksplit), dim3(GTHR), lds,
-                       (hipStream_t)stream, p);
+    hipLaunchKernelGGL(conv_wgrad_wino_kernel, dim3((cin / GBLK) * (cout / GBLK), ksplit, n_jobs), dim3(GTHR), lds, (hipStream_t)stream, p);
     SIS_CHECK_LAUNCH("conv_wgrad_wino_kernel");
-    const int64_t pairs = (int64_t)cin * cout;
+    const long long stride = p.jobs ? p.slab_job_stride : 0;
     if (ksplit > 4) {  // many thin slices (few channel pairs): reduce them with one lane per (xi, pair) first
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(sis_cdiv(pairs, 256), 16), dim3(256), 0, (hipStream_t)stream,
-                           (float*)workspace, ksplit, pairs);
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(sis_cdiv(pairs, 256), 16, n_jobs), dim3(256), 0, (hipStream_t)stream,
+                           (float*)workspace, ksplit, pairs, stride);
         SIS_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
         ksplit = 1;
     }
-    hipLaunchKernelGGL(conv_wgrad_finish_kernel, dim3(sis_cdiv(pairs, 256)), dim3(256), 0, (hipStream_t)stream, dw,
-                       (const float*)workspace, ksplit, pairs);
+    hipLaunchKernelGGL(conv_wgrad_finish_kernel, dim3(sis_cdiv(pairs, 256), n_jobs), dim3(256), 0, (hipStream_t)stream, dw[0],
+                       (const float*)workspace, ksplit, pairs, stride, tab);
     SIS_CHECK_LAUNCH("conv_wgrad_finish_kernel");
+    return 0;
+}
+
+extern "C" int sis_conv3x3_wgrad(float* dw, const float* x, const float* gy, int batch, int cin, int cout, int h, int w,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+    SIS_REQUIRE(dw && x && gy && workspace, "sis_conv3x3_wgrad: null pointer");
+    return gw_jobs(&dw, &x, &gy, 1, batch, cin, cout, h, w, workspace, workspace_bytes, stream, "sis_conv3x3_wgrad");
+}
+
+/* The same for n_jobs layers of ONE shape (EMANet's repeated bottleneck units, queued during the backward): `dw`, `x`, `gy` are
+ * HOST arrays of n_jobs device pointers.  One tile launch (grid.z = layer), one finish launch (and one slice reduction where the
+ * plan has more than four slices) per <= 16 layers -- as few layers per launch as leave each its slabs in the workspace. */
+extern "C" int sis_conv3x3_wgrad_multi(float* const* dw, const float* const* x, const float* const* gy, int n_jobs, int batch, int cin,
+                                       int cout, int h, int w, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (n_jobs <= 0) return 0;
+    SIS_REQUIRE(dw && x && gy && workspace, "sis_conv3x3_wgrad_multi: null pointer");
+    for (int j0 = 0; j0 < n_jobs;) {
+        int n = n_jobs - j0 < GW_JOBS_MAX ? n_jobs - j0 : GW_JOBS_MAX;
+        for (; n > 1; n = (n + 1) / 2) {
+            WgradParams q;
+            int ks;
+            if (wgrad_plan(q, &ks, batch, cin, cout, h, w, workspace_bytes, n) == 0) break;
+        }
+        const int rc = gw_jobs(dw + j0, x + j0, gy + j0, n, batch, cin, cout, h, w, workspace, workspace_bytes, stream, "sis_conv3x3_wgrad_multi");
+        if (rc) return rc;
+        j0 += n;
+    }
     return 0;
 }

@@ -147,7 +147,7 @@ class Bottleneck(nn.Module):
 
     def _conv2_on_sub_images(self, y):
         self.conv2._takes_wino = True
-        return conv3x3(y, self.conv2.weight, 1, self.conv2._wino_banked)
+        return conv3x3(y, self.conv2.weight, 1, self.conv2._wino_banked, self.conv2._defer_wgrad)
 
     def sub_image_eligible(self, x):
         """The unit can run on the sub-image arrangement of x: a stride-1 dilated fp32 unit whose 3x3 layer the Winograd kernel
@@ -384,6 +384,9 @@ class EMANet(BaseSegmenter):
         self.fc2 = HipConv2d(256, num_classes, 1)
         self.crit = CrossEntropyLoss2d(ignore_index=ignore_label, reduction='none')
         self.ignore_label = ignore_label
+        for m in self.modules():   # every weight is used once per forward: weight gradients may be batched (hip_conv._may_defer)
+            if isinstance(m, HipConv2d):
+                m._defer_wgrad = True
 
     def features(self, img):
         ex = self.extractor  # (stem convs, bn1, relu, maxpool, layer1..4): same modules, fused norm/activation calls

@@ -51,23 +51,33 @@ def _conv3x3_dgrad(grad_output, weight, d):
     return _batch_to_space(sis_hip.conv3x3(_space_to_batch(grad_output, d), sis_hip.conv3x3_prepack(weight, adjoint=True)), d)
 
 
-def _conv3x3_wgrad(input, grad_output, weight_shape, d, input_s=None, grad_output_s=None, for_param=None):
+def _conv3x3_wgrad(input, grad_output, weight_shape, d, input_s=None, grad_output_s=None, for_param=None, defer=False):
     """``input_s`` / ``grad_output_s``: the sub-image forms of the two tensors when the caller already has them (a dilated
     layer's forward keeps its permuted input, its backward permutes dL/dy once for both gradients: 4 permute copies per
     layer and step instead of 6)."""
     b, cin, h, w = input.shape
     if sis_hip.conv3x3_wgrad_supported(b * d * d, cin, weight_shape[0], h // d, w // d):
         return sis_hip.conv3x3_wgrad(_space_to_batch(input, d) if input_s is None else input_s,
-                                     _space_to_batch(grad_output, d) if grad_output_s is None else grad_output_s, for_param=for_param)
+                                     _space_to_batch(grad_output, d) if grad_output_s is None else grad_output_s, for_param=for_param,
+                                     defer=defer)
     # narrow sub-images / channel counts below a 64 x 64 tile / too little work: the library's kernel
     return torch.ops.aten.convolution_backward(grad_output, input, input.new_empty(weight_shape), None, (1, 1), (d, d), (d, d),
                                                False, (0, 0), 1, (False, True, False))[1]
 
 
+def _may_defer(flag, weight):
+    """A layer's weight gradient may wait for ``sis_hip.flush_deferred`` (batched with the other layers of its shape) when the
+    owner of the layer said so (``HipConv2d._defer_wgrad``: its weight is used ONCE per forward) and the weight is a parameter
+    without a gradient in place -- autograd then takes the tensor as it is; with one in place it would add the unwritten result."""
+    return bool(flag) and weight.is_leaf and weight.grad is None
+
+
 class _Conv3x3Function(Function):
     @staticmethod
-    def forward(ctx, input, weight, dilation, prepacked=None):
-        """``prepacked``: (forward image, adjoint image) of ``weight`` when a ``sis_hip.WinogradPackBank`` wrote them for this step."""
+    def forward(ctx, input, weight, dilation, prepacked=None, defer=False):
+        """``prepacked``: (forward image, adjoint image) of ``weight`` when a ``sis_hip.WinogradPackBank`` wrote them for this step;
+        ``defer``: see ``_may_defer``."""
+        ctx.defer = defer
         input_s = _space_to_batch(input, dilation)
         if prepacked is not None:
             u, u_adjoint = prepacked
@@ -83,8 +93,9 @@ class _Conv3x3Function(Function):
     def backward(ctx, grad_output):
         input, weight, input_s, u_adjoint = ctx.saved_tensors
         grad_input, grad_weight = _Conv3x3Backward.apply(grad_output.contiguous(), input, weight, ctx.dilation,
-                                                         ctx.needs_input_grad[0], ctx.needs_input_grad[1], input_s, u_adjoint)
-        return grad_input, grad_weight, None, None
+                                                         ctx.needs_input_grad[0], ctx.needs_input_grad[1], input_s, u_adjoint,
+                                                         _may_defer(ctx.defer, weight) and not torch.is_grad_enabled())
+        return grad_input, grad_weight, None, None, None
 
 
 class _Conv3x3Backward(Function):
@@ -96,7 +107,7 @@ class _Conv3x3Backward(Function):
     all three on the same Winograd kernels as the first-order pass."""
 
     @staticmethod
-    def forward(ctx, grad_output, input, weight, dilation, want_input, want_weight, input_s=None, u_adjoint=None):
+    def forward(ctx, grad_output, input, weight, dilation, want_input, want_weight, input_s=None, u_adjoint=None, defer=False):
         ctx.save_for_backward(grad_output, input, weight)
         ctx.dilation = dilation
         grad_output_s = _space_to_batch(grad_output, dilation)  # once, for both gradients
@@ -107,7 +118,8 @@ class _Conv3x3Backward(Function):
             grad_input = _batch_to_space(sis_hip.conv3x3(grad_output_s, u_adjoint), dilation)
         if want_weight:
             # (for_param: under the data-parallel wrap the kernel writes into the parameter's bucket slice, sis_hip.grad_out)
-            grad_weight = _conv3x3_wgrad(input, grad_output, weight.shape, dilation, input_s, grad_output_s, for_param=weight.data_ptr())
+            grad_weight = _conv3x3_wgrad(input, grad_output, weight.shape, dilation, input_s, grad_output_s, for_param=weight.data_ptr(),
+                                         defer=defer)
         return grad_input, grad_weight
 
     @staticmethod
@@ -127,7 +139,7 @@ class _Conv3x3Backward(Function):
             d_x = _conv3x3_dgrad(grad_output, gg_weight.contiguous(), d)
         if need_w and gg_input is not None:
             d_w = _conv3x3_wgrad(gg_input.contiguous(), grad_output, weight.shape, d)
-        return d_gy, d_x, d_w, None, None, None, None, None
+        return d_gy, d_x, d_w, None, None, None, None, None, None
 
 
 def gan_winograd_enabled():
@@ -136,10 +148,10 @@ def gan_winograd_enabled():
     return os.environ.get("SIS_GAN_WINOGRAD", "1") != "0"
 
 
-def conv3x3(input, weight, dilation=1, prepacked=None):
+def conv3x3(input, weight, dilation=1, prepacked=None, defer_wgrad=False):
     """Differentiable stride-1 3x3 convolution with padding = dilation on the Winograd kernel (caller checks
     eligibility with ``sis_hip.conv3x3_supported``)."""
-    return _Conv3x3Function.apply(input, weight, dilation, prepacked)
+    return _Conv3x3Function.apply(input, weight, dilation, prepacked, defer_wgrad)
 
 
 _F32_POINTWISE = os.environ.get('SIS_F32_POINTWISE', '1') != '0'  # 0: fp32 1x1 convolutions stay on the library (A/B runs)
@@ -164,9 +176,10 @@ class _Pointwise(Function):
         return pad if sis_hip.conv1x1_f32_supported(input, weight.new_empty((cout + pad,) + tuple(weight.shape[1:]))) else 0
 
     @staticmethod
-    def forward(ctx, input, weight, bias):
+    def forward(ctx, input, weight, bias, defer=False):
         ctx.save_for_backward(input, weight)
         ctx.has_bias = bias is not None
+        ctx.defer = defer
         ctx.pad = 0
         if _F32_POINTWISE and sis_hip.conv1x1_f32_supported(input, weight):
             return sis_hip.conv1x1_f32(input, weight, bias)  # fp32 MFMA kernel, csrc/conv1x1_f32.hip
@@ -199,7 +212,7 @@ class _Pointwise(Function):
                     grad_weight = torch.bmm(grad_output.view(b, cout, h * w), input.view(b, cin, h * w).transpose(1, 2)).sum(0).view(cout, cin, 1, 1)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 grad_bias = grad_output.sum((0, 2, 3))
-            return grad_input, grad_weight, grad_bias
+            return grad_input, grad_weight, grad_bias, None
         if ctx.needs_input_grad[0]:
             if _F32_POINTWISE and sis_hip.conv1x1_f32_supported(grad_output, weight):
                 grad_input = sis_hip.conv1x1_f32(grad_output, weight, data_gradient=True)
@@ -210,13 +223,14 @@ class _Pointwise(Function):
         g = grad_output.view(b, cout, h * w)
         if ctx.needs_input_grad[1]:
             if _F32_POINTWISE and sis_hip.conv1x1_wgrad_f32_supported(grad_output, input):
-                grad_weight = sis_hip.conv1x1_wgrad_f32(grad_output, input, for_param=weight.data_ptr())  # csrc/conv1x1_wgrad_f32.hip
+                grad_weight = sis_hip.conv1x1_wgrad_f32(grad_output, input, for_param=weight.data_ptr(),   # csrc/conv1x1_wgrad_f32.hip
+                                                        defer=_may_defer(ctx.defer, weight) and not torch.is_grad_enabled())
             else:
                 sis_hip.library_call("hip_conv._Pointwise.wgrad")
                 grad_weight = torch.bmm(g, input.view(b, cin, h * w).transpose(1, 2)).sum(0).view(cout, cin, 1, 1)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = g.sum((0, 2))
-        return grad_input, grad_weight, grad_bias
+        return grad_input, grad_weight, grad_bias, None
 
 
 class _PointwiseWithSkip(Function):
@@ -227,9 +241,10 @@ class _PointwiseWithSkip(Function):
     bottlenecks; reference networks/ema_net/network.py:37-56)."""
 
     @staticmethod
-    def forward(ctx, input, weight):
+    def forward(ctx, input, weight, defer=False):
         ctx.save_for_backward(input, weight)
         ctx.set_materialize_grads(False)
+        ctx.defer = defer
         return sis_hip.conv1x1_f32(input, weight), input.view_as(input)
 
     @staticmethod
@@ -237,7 +252,7 @@ class _PointwiseWithSkip(Function):
         input, weight = ctx.saved_tensors
         grad_input = grad_weight = None
         if grad_output is None:
-            return grad_skip, None
+            return grad_skip, None, None
         grad_output = grad_output.contiguous()
         if ctx.needs_input_grad[0]:
             if grad_skip is not None:
@@ -246,13 +261,14 @@ class _PointwiseWithSkip(Function):
                 grad_input = sis_hip.conv1x1_f32(grad_output, weight, data_gradient=True)
         if ctx.needs_input_grad[1]:
             if sis_hip.conv1x1_wgrad_f32_supported(grad_output, input):
-                grad_weight = sis_hip.conv1x1_wgrad_f32(grad_output, input, for_param=weight.data_ptr())
+                grad_weight = sis_hip.conv1x1_wgrad_f32(grad_output, input, for_param=weight.data_ptr(),
+                                                        defer=_may_defer(ctx.defer, weight) and not torch.is_grad_enabled())
             else:
                 sis_hip.library_call("hip_conv._PointwiseWithSkip.wgrad")
                 b, cin, h, w = input.shape
                 cout = weight.shape[0]
                 grad_weight = torch.bmm(grad_output.view(b, cout, h * w), input.view(b, cin, h * w).transpose(1, 2)).sum(0).view(cout, cin, 1, 1)
-        return grad_input, grad_weight
+        return grad_input, grad_weight, None
 
 
 def pointwise_with_skip(conv, input):
@@ -261,7 +277,7 @@ def pointwise_with_skip(conv, input):
     if (_F32_POINTWISE and _FUSE_SKIP_GRAD and isinstance(conv, HipConv2d) and conv._pointwise(input) and conv.bias is None
             and not torch.is_autocast_enabled() and input.dtype == torch.float32 and torch.is_grad_enabled() and input.requires_grad
             and sis_hip.conv1x1_f32_supported(input, conv.weight)):
-        return _PointwiseWithSkip.apply(input, conv.weight)   # (the support check covers forward and data gradient)
+        return _PointwiseWithSkip.apply(input, conv.weight, conv._defer_wgrad)   # (the support check covers forward and data gradient)
     return None
 
 
@@ -473,6 +489,8 @@ class HipConv2d(nn.Conv2d):
     _banked = None   # (forward image, adjoint image or None) of the weight when a pack bank wrote them for this forward
     _wino_banked = None   # the same for the fp32 Winograd path (sis_hip.WinogradPackBank, networks/ema_net)
     _takes_wino = False   # a forward of this layer went through conv3x3 (the bank packs these layers only)
+    _defer_wgrad = False  # the owning network uses this layer's weight once per forward: its fp32 weight gradient may be queued and
+                          # batched with the other layers of its shape (sis_hip.flush_deferred; networks/ema_net sets it)
 
     def _bf16(self, input):
         """Under bf16 autocast: the input is already bf16 (norm kernels write it) or is cast here, as autocast would."""
@@ -511,9 +529,9 @@ class HipConv2d(nn.Conv2d):
             return None
         if self.kernel_size == (3, 3) and self.padding == (1, 1) and sis_hip.conv3x3_supported(input, self.weight, 1):
             self._takes_wino = True
-            return conv3x3(input, self.weight, 1, self._wino_banked)[:, :, ::2, ::2].contiguous()
+            return conv3x3(input, self.weight, 1, self._wino_banked, self._defer_wgrad)[:, :, ::2, ::2].contiguous()
         if self.kernel_size == (1, 1) and self.padding == (0, 0):
-            return _Pointwise.apply(input[:, :, ::2, ::2].contiguous(), self.weight, None)
+            return _Pointwise.apply(input[:, :, ::2, ::2].contiguous(), self.weight, None, self._defer_wgrad)
         return None
 
     def forward(self, input):
@@ -524,12 +542,12 @@ class HipConv2d(nn.Conv2d):
         if y is not None:
             return y
         if self._pointwise(input):
-            return _Pointwise.apply(input, self.weight, self.bias)
+            return _Pointwise.apply(input, self.weight, self.bias, self._defer_wgrad)
         if self._half_image_dilation(input):
             return conv3x3_half_image_dilation(input, self.weight)
         if self._eligible(input):
             self._takes_wino = True
-            return conv3x3(input, self.weight, self.dilation[0], self._wino_banked)
+            return conv3x3(input, self.weight, self.dilation[0], self._wino_banked, self._defer_wgrad)
         if input.is_cuda:   # the 3-channel stems are the documented library layers; anything else is a fallback
             sis_hip.library_call("hip_conv.HipConv2d.forward", intended=(self.in_channels <= 4))
         return super().forward(input)

@@ -82,6 +82,7 @@ _SIGNATURES = {
     "sis_weight_std_bwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp], _i),
     "sis_conv3x3_wgrad_eligible": ([_i] * 5 + [_i64], _i),
     "sis_conv3x3_wgrad": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
+    "sis_conv3x3_wgrad_multi": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
     "sis_conv3x3": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
     "sis_modconv2d_up": ([_vp] * 5 + [_i] * 6 + [_vp, _i64, _vp], _i),
     "sis_modconv_up_fir_supported": ([_i] * 6, _i),
@@ -92,6 +93,7 @@ _SIGNATURES = {
     "sis_conv1x1_wgrad_f32_supported": ([_i] * 4, _i),
     "sis_conv1x1_wgrad_f32_workspace": ([_i] * 4, _i64),
     "sis_conv1x1_wgrad_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp], _i),
+    "sis_conv1x1_wgrad_f32_multi": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp], _i),
     "sis_max_pool2d": ([_vp, _vp, _vp, _i, _i64] + [_i] * 8 + [_vp], _i),
     "sis_upsample_ce_workspace": ([_i] * 3, _i),
     "sis_upsample_ce_fwd": ([_vp] * 4 + [_i] * 6 + [_i64, _vp], _i),
@@ -513,14 +515,17 @@ def conv3x3_wgrad_supported(batch, cin, cout, h, w, min_work=0.0):
     return bool(lib().sis_conv3x3_wgrad_eligible(batch, cin, cout, h, w, WORKSPACE_BYTES))
 
 
-def conv3x3_wgrad(x, grad_output, for_param=None):
+def conv3x3_wgrad(x, grad_output, for_param=None, defer=False):
     """dL/dw [Cout,Cin,3,3] of a stride-1, padding-1 3x3 convolution from its input x [B,Cin,H,W] and dL/dy.  ``for_param``: storage
-    address of the parameter the result is the gradient of (``grad_out``)."""
+    address of the parameter the result is the gradient of (``grad_out``).  ``defer``: as ``conv_bf16_wgrad``."""
     x = _f32(x, "input")
     gy = _f32(grad_output, "grad_output")
     batch, cin, h, w = x.shape
     cout = gy.shape[1]
     dw = grad_out(for_param, (cout, cin, 3, 3), torch.float32, x.device)
+    if defer and _conv_wgrad_deferrable():
+        _defer_conv_wgrad("f3", x, gy, dw, (batch, cin, cout, h, w))
+        return dw
     ws = _workspace(x.device)
     with torch.cuda.device(x.device):
         _check(_launch(None, 2.0 * batch * cout * cin * 9 * h * w, 4.0 * (x.numel() + gy.numel() + dw.numel()),
@@ -692,7 +697,7 @@ def _defer_conv_wgrad(kind, x, grad_output, dw, dims):
 
 
 def _conv_wgrad_deferrable():
-    return _DEFER_WGRAD and not _defer_wgrad_blockers and deferring()
+    return _DEFER_WGRAD and not _defer_wgrad_blockers and not torch.is_grad_enabled() and deferring()
 
 
 def _flush_conv_wgrads():
@@ -704,7 +709,17 @@ def _flush_conv_wgrads():
         xs, gys, dws = arr(*[j[0] for j in jobs]), arr(*[j[1] for j in jobs]), arr(*[j[2] for j in jobs])
         ws = _workspace(device)
         with torch.cuda.device(device):
-            if kind == 3:
+            if kind == "f3":   # fp32 Winograd weight gradient (EMANet)
+                b, cin, cout, h, w = dims
+                _check(_launch(None, 2.0 * b * cout * cin * 9 * h * w * n, 0.0,
+                               lambda: lib().sis_conv3x3_wgrad_multi(dws, xs, gys, n, b, cin, cout, h, w, _ptr(ws), ws.numel(), _stream())),
+                       "sis_conv3x3_wgrad_multi")
+            elif kind == "f1":   # fp32 1x1 weight gradient (EMANet)
+                b, cin, cout, hw = dims
+                _check(_launch("conv1x1_wgrad_f32_kernel", 2.0 * b * cout * cin * hw * n, 0.0,
+                               lambda: lib().sis_conv1x1_wgrad_f32_multi(dws, gys, xs, n, b, cin, cout, hw, _ptr(ws), ws.numel(), _stream())),
+                       "sis_conv1x1_wgrad_f32_multi")
+            elif kind == 3:
                 b, cin, cout, h, w = dims
                 _check(_launch(None, 2.0 * b * cout * cin * 9 * h * w * n, 0.0,
                                lambda: lib().sis_conv_bf16_wgrad_multi(dws, _DTYPE_CODE[dtype], xs, gys, n, b, cin, cout, h, w, _ptr(ws),
@@ -1922,13 +1937,18 @@ def conv1x1_wgrad_f32_supported(grad_output, input):
                                                          input.shape[2] * input.shape[3]))
 
 
-def conv1x1_wgrad_f32(grad_output, input, for_param=None):
-    """dW [Cout, Cin, 1, 1] of a 1x1 stride-1 convolution from dL/dy [B,Cout,H,W] and x [B,Cin,H,W] (fp32, NCHW)."""
+def conv1x1_wgrad_f32(grad_output, input, for_param=None, defer=False):
+    """dW [Cout, Cin, 1, 1] of a 1x1 stride-1 convolution from dL/dy [B,Cout,H,W] and x [B,Cin,H,W] (fp32, NCHW).  ``defer``: as
+    ``conv_bf16_wgrad``."""
     require_device(input, "input")
     b, cin, h, w = input.shape
     cout = grad_output.shape[1]
     L = lib()
     dw = grad_out(for_param, (cout, cin, 1, 1), torch.float32, input.device)
+    if (defer and _conv_wgrad_deferrable() and grad_output.dtype == torch.float32 and input.dtype == torch.float32
+            and grad_output.is_contiguous() and input.is_contiguous() and grad_output.data_ptr() % 16 == 0 and input.data_ptr() % 16 == 0):
+        _defer_conv_wgrad("f1", input, grad_output, dw, (b, cin, cout, h * w))
+        return dw
     ws_bytes = int(L.sis_conv1x1_wgrad_f32_workspace(b, cin, cout, h * w))
     ws = torch.empty(max(ws_bytes // 4, 4), dtype=torch.float32, device=input.device)
     with torch.cuda.device(input.device):

@@ -211,3 +211,37 @@ def test_winograd_pack_bank_writes_the_images_of_the_single_layer_prepack(device
         weights[1].mul_(-0.5)
         weights[3].add_(1.0)
     assert bank.current()
+
+
+@pytest.mark.parametrize("kind,jobs,batch,cin,cout,h,w", [("f3", 5, 16, 256, 256, 16, 16), ("f3", 3, 4, 128, 128, 32, 32), ("f3", 18, 2, 64, 64, 16, 16),
+                                                          ("f1", 5, 8, 1024, 256, 32, 32), ("f1", 3, 2, 128, 512, 64, 64), ("f1", 17, 1, 64, 256, 16, 16),
+                                                          ("f1", 2, 4, 2048, 512, 16, 16)])
+def test_batched_fp32_weight_gradients_of_one_shape(device, kind, jobs, batch, cin, cout, h, w):
+    """EMANet's repeated bottleneck units: several fp32 layers of ONE shape through one tile launch + one finish / reduction launch
+    (sis_conv3x3_wgrad_multi / sis_conv1x1_wgrad_f32_multi, what ``sis_hip.flush_deferred`` runs).  Every layer's dW against its own
+    single-layer call: same products, K slices cut for the joint tile count -> another association of the fp32 partial sums
+    (1e-4 of the largest entry); more layers than one launch takes; bitwise repeatable."""
+    import sis_hip
+    gen = torch.Generator().manual_seed(len(kind) * 100 + jobs * 10 + cin)
+    xs = [torch.randn(batch, cin, h, w, generator=gen).to(device) for _ in range(jobs)]
+    gys = [torch.randn(batch, cout, h, w, generator=gen).to(device) for _ in range(jobs)]
+    if kind == "f3":
+        assert sis_hip.conv3x3_wgrad_supported(batch, cin, cout, h, w, min_work=0)
+        ref = [sis_hip.conv3x3_wgrad(x, gy) for x, gy in zip(xs, gys)]
+        dims = (batch, cin, cout, h, w)
+    else:
+        assert sis_hip.conv1x1_wgrad_f32_supported(gys[0], xs[0])
+        ref = [sis_hip.conv1x1_wgrad_f32(gy, x) for x, gy in zip(xs, gys)]
+        dims = (batch, cin, cout, h * w)
+    runs = []
+    for _ in range(2):
+        dws = [torch.empty_like(r) for r in ref]
+        for x, gy, dw in zip(xs, gys, dws):
+            sis_hip._defer_conv_wgrad(kind, x, gy, dw, dims)
+        sis_hip.flush_deferred()
+        assert sis_hip.deferred_pending() == 0
+        runs.append(dws)
+    for j in range(jobs):
+        scale = float(ref[j].abs().max())
+        assert float((runs[0][j] - ref[j]).abs().max()) <= 1e-4 * scale, j
+        assert torch.equal(runs[0][j], runs[1][j])

@@ -135,6 +135,7 @@ _MODULE_SWITCHES = [
     ("sis_hip", "_UP_FIR", False, "generator"),                                                   # SIS_UP_FIR
     ("sis_hip", "_DEFER", False, "trans_u_net"),                                                  # SIS_DEFER_REDUCES
     ("sis_hip", "_DEFER_WGRAD", False, "trans_u_net"),                                            # SIS_DEFER_WGRAD
+    ("sis_hip", "_DEFER_WGRAD", False, "ema_net"),
 ]
 
 
