@@ -297,7 +297,8 @@ __global__ __launch_bounds__(256) void upfir_prepack_kernel(float* __restrict__ 
 
 bool upfir_plan(UpFirParams& p, int batch, int cin, int cout, int h, int w, int row_stride, size_t* lds_bytes, int nw = 8) {
     const int UF_CC = nw, UF_NBLK = 8 * nw;
-    if (batch <= 0 || h < 32 || w < 32 || (h & 1) || (w & 3) || cin % UF_CC || cout % UF_MBLK) return false;
+    static const int min_side = getenv("SIS_UPFIR_MIN_SIDE") ? atoi(getenv("SIS_UPFIR_MIN_SIDE")) : 16;   // (32: the 16 x 16 layer on the 4-phase kernel)
+    if (batch <= 0 || h < min_side || w < min_side || (h & 1) || (w & 3) || cin % UF_CC || cout % UF_MBLK) return false;
     if ((row_stride & 3) || row_stride < 2 * w + 4) return false;
     if ((int64_t)batch * cin * h * w * 4 >= (1LL << 31) || (int64_t)cin * UF_PLANES * cout * 4 >= (1LL << 31)) return false;
     p.B = batch; p.Cin = cin; p.Cout = cout; p.H = h; p.W = w; p.OH = 2 * h + 1; p.ORS = row_stride;

@@ -98,7 +98,7 @@ def test_modconv_up_vs_oracle(device, b, cin, cout, h, w):
 
 
 @pytest.mark.parametrize("b,cin,cout,h,w", [(2, 16, 64, 32, 32), (3, 40, 128, 32, 32), (1, 8, 64, 64, 64), (2, 24, 64, 34, 40),
-                                             (5, 8, 64, 32, 32), (1, 8, 128, 128, 128), (2, 16, 64, 32, 64), (2, 12, 64, 32, 32)])
+                                             (5, 8, 64, 32, 32), (1, 8, 128, 128, 128), (2, 16, 64, 32, 64), (2, 12, 64, 32, 32), (2, 16, 64, 16, 16), (3, 32, 128, 16, 16)])
 def test_modconv_up_fir_vs_oracle(device, b, cin, cout, h, w):
     """The fast-FIR transposed convolution (csrc/modconv_upfir.hip: 25 products per 2 x 2 positions on
     v_mfma_f32_16x16x4_f32) against the reference's formulation (per-sample weights, conv_transpose2d with B groups) at the
@@ -149,7 +149,7 @@ def test_modconv_up_fir_vs_oracle(device, b, cin, cout, h, w):
 def test_modconv_up_fir_declines_what_it_does_not_serve(device):
     import sis_hip
     L = sis_hip.lib()
-    assert not L.sis_modconv_up_fir_supported(2, 16, 64, 16, 16, 36)     # below 32 x 32: the 4-phase kernel (split-K there)
+    assert not L.sis_modconv_up_fir_supported(2, 16, 64, 8, 8, 20)       # below 16 x 16: the 4-phase kernel (split-K there)
     assert not L.sis_modconv_up_fir_supported(2, 16, 48, 32, 32, 68)     # output channels not a multiple of 64
     assert not L.sis_modconv_up_fir_supported(2, 10, 64, 32, 32, 68)     # input channels not a multiple of the 4-channel chunk
     assert not L.sis_modconv_up_fir_supported(2, 16, 64, 32, 32, 65)     # un-padded rows
