@@ -225,7 +225,7 @@ def own_kernel_names():
         for path in glob.glob(os.path.join(os.path.dirname(_HERE), "csrc", "*.hip")):
             with open(path) as f:
                 text = f.read()
-            for m in re.finditer(r"__global__\s+(?:__launch_bounds__\s*\([^)]*\)\s*)?(?:static\s+)?void\s+"
+            for m in re.finditer(r"__global__\s+(?:__launch_bounds__\s*\([^)]*\)\s*)?(?:__attribute__\s*\(\(.*?\)\)\s*)?(?:static\s+)?void\s+"
                                  r"(?:__launch_bounds__\s*\([^)]*\)\s*)?([A-Za-z_]\w*)\s*\(", text):
                 names.add(m.group(1))
         _own_kernels = frozenset(names)

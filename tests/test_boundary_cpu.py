@@ -101,3 +101,25 @@ def test_library_call_audit(monkeypatch):
     with pytest.raises(RuntimeError, match="unit.site fell back"):
         sis_hip.library_call("unit.site")
     sis_hip.library_calls(reset=True)
+
+
+def test_every_kernel_of_the_sources_counts_as_own():
+    """bench.py's library-time audit and tools/pmc_traffic.py tell own kernels from library ones by the ``__global__`` function names
+    found in csrc/*.hip (``sis_hip.own_kernel_names``): the scan must see kernels declared with launch bounds, attributes
+    (``amdgpu_waves_per_eu``) or ``static`` in any order -- a missed name would book that kernel's time as library time."""
+    import re
+    import sis_hip
+    names = sis_hip.own_kernel_names()
+    for expect in ("modconv_upfir_kernel", "modconv_wino2_kernel", "kmeans_mfma_kernel", "gemm_bf16_kernel", "gemm_colsum_finish_multi_kernel",
+                   "wino_prepack_multi_kernel", "conv_wgrad_bf16_kernel", "conv1x1_wgrad_f32_kernel", "bn_wide_bwd_kernel"):
+        assert expect in names, expect
+    assert sis_hip.is_own_kernel("void (anonymous namespace)::modconv_upfir_kernel<1, 0, 4>((anonymous namespace)::UpFirParams)")
+    assert not sis_hip.is_own_kernel("Cijk_Alik_Bljk_BBS_BH_Bias_HA_S_SAV_UserArgs_MT256x256x64")
+    # every `__global__` in the sources is followed (eventually) by a function name the scan found
+    import glob
+    import os
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "synthesis-in-style_amd", "csrc")
+    for path in glob.glob(os.path.join(csrc, "*.hip")):
+        text = open(path).read()
+        for m in re.finditer(r"__global__[^;{]*?void\s+(?:__launch_bounds__\s*\([^)]*\)\s*)?([A-Za-z_]\w*)\s*\(", text):
+            assert m.group(1) in names, (os.path.basename(path), m.group(1))
