@@ -485,6 +485,10 @@ bool wgrad_plan(int batch, int cin, int cout, int h, int w, int64_t workspace_by
         pl->wm = 1;
         pl->wn = cin > 32 ? 2 : 1;
         pl->ks = cin > 32 ? 4 : 8;
+        // wide maps: strips twice as wide -- the K waves of these one-block layers then hold two K-steps (18 MFMAs) per barrier
+        // instead of one (SIS_WGRAD_NARROW_KS=0: the narrower strips)
+        static const bool wide = !(getenv("SIS_WGRAD_NARROW_KS") && getenv("SIS_WGRAD_NARROW_KS")[0] == '0');
+        if (wide && w >= 32 * pl->ks) pl->ks *= 2;
     } else {
         pl->wm = cout >= 128 ? 4 : 2;
         pl->wn = 8 / pl->wm;
@@ -567,7 +571,9 @@ static int conv_wgrad_jobs(void* const* dw, int dw_dtype, const void* const* x, 
     else if (pl.wm == 4 && pl.ks == 2) rc = launch_wgrad<WgCfg<4, 2, 2>>(p, pl.units, st, "conv_wgrad_bf16_kernel<4,2,2>");
     else if (pl.wm == 2 && pl.ks == 4) rc = launch_wgrad<WgCfg<2, 4, 4>>(p, pl.units, st, "conv_wgrad_bf16_kernel<2,4,4>");
     else if (pl.wm == 2) rc = launch_wgrad<WgCfg<2, 4, 2>>(p, pl.units, st, "conv_wgrad_bf16_kernel<2,4,2>");
+    else if (pl.wn == 2 && pl.ks == 8) rc = launch_wgrad<WgCfg<1, 2, 8>>(p, pl.units, st, "conv_wgrad_bf16_kernel<1,2,8>");
     else if (pl.wn == 2) rc = launch_wgrad<WgCfg<1, 2, 4>>(p, pl.units, st, "conv_wgrad_bf16_kernel<1,2,4>");
+    else if (pl.ks == 16) rc = launch_wgrad<WgCfg<1, 1, 16>>(p, pl.units, st, "conv_wgrad_bf16_kernel<1,1,16>");
     else rc = launch_wgrad<WgCfg<1, 1, 8>>(p, pl.units, st, "conv_wgrad_bf16_kernel<1,1,8>");
     if (rc) return rc;
     const int mt = 32 * pl.wm, nt = 32 * pl.wn;

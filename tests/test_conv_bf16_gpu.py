@@ -71,7 +71,8 @@ def test_conv_bf16_data_gradient(device, batch, cin, cout, h, w, k):
 
 @pytest.mark.parametrize("batch,cin,cout,h,w", [(2, 64, 128, 32, 32), (2, 128, 64, 64, 64), (1, 192, 64, 48, 48), (3, 256, 256, 16, 16),
                                                 (1, 64, 64, 127, 127), (2, 96, 160, 24, 40), (8, 64, 64, 128, 128), (2, 64, 64, 32, 32),
-                                                (2, 64, 16, 64, 64), (2, 16, 16, 48, 80), (1, 16, 3, 64, 200), (2, 128, 24, 40, 40)])
+                                                (2, 64, 16, 64, 64), (2, 16, 16, 48, 80), (1, 16, 3, 64, 200), (2, 128, 24, 40, 40),
+                                                (1, 64, 16, 16, 256), (1, 16, 16, 8, 256), (1, 16, 3, 8, 512), (1, 48, 16, 12, 136)])   # (wide maps: the double-width strips of the one-block layers)
 def test_conv_bf16_weight_gradient(device, batch, cin, cout, h, w):
     """dL/dw on the pixel-contraction kernel (csrc/conv_bf16_wgrad.hip) against autograd of the fp32 convolution on the
     same bf16-rounded tensors; fp32 result: |err| <= 2e-3 * max|ref| (fp32 accumulation in a different order), bf16

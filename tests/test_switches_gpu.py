@@ -173,6 +173,7 @@ _C_SIDE = [
     ("SIS_UPFIR_WAVES", "8", "tests/test_generator_gpu.py::test_modconv_up_fir_vs_oracle"),   # the one-workgroup-per-CU tile ...
     ("SIS_UPFIR_PIPE", "0", "tests/test_generator_gpu.py::test_modconv_up_fir_vs_oracle"),    # ... and its unpipelined loop
     ("SIS_WGRAD_WAVES", "4", "tests/test_conv_bf16_gpu.py::test_conv_bf16_weight_gradient"),   # 64 x 64 tiles, two workgroups per CU, everywhere
+    ("SIS_WGRAD_NARROW_KS", "0", "tests/test_conv_bf16_gpu.py::test_conv_bf16_weight_gradient"),   # (with SIS_WGRAD_WAVES=4 above: the narrow layers' single-width strips)
     ("SIS_GN_SINGLE_PASS", "0", "tests/test_upsample_gpu.py"),
     ("SIS_UP2_DIRECT", "0", "tests/test_upsample_gpu.py"),
     ("SIS_PW_KC", "32", "tests/test_conv1x1_f32_gpu.py"),
