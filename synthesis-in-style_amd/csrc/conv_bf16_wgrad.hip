@@ -503,7 +503,9 @@ bool wgrad_plan(int batch, int cin, int cout, int h, int w, int64_t workspace_by
     const int tiles = pl->co_tiles * pl->ci_tiles;
     // row blocks: enough workgroups to fill the chip (~2 per CU), at least 8 rows each, slabs within the workspace
     int rbk = 1;
-    static const int min_wg = getenv("SIS_WGRAD_MINWG") ? atoi(getenv("SIS_WGRAD_MINWG")) : 512;
+    // (the one-block layers of the decoder's tail are slab-bound: one round of workgroups, 127 / 71 / 67 us against 143 / 81 / 78 with two)
+    static const int min_wg_env = getenv("SIS_WGRAD_MINWG") ? atoi(getenv("SIS_WGRAD_MINWG")) : 0;
+    const int min_wg = min_wg_env ? min_wg_env : (cout <= 32 ? 256 : 512);
     while (rbk < h / 8 && (int64_t)batch * pl->strips * rbk * tiles * jobs < min_wg &&
            (int64_t)batch * pl->strips * (rbk * 2) * tile_bytes <= workspace_bytes) rbk *= 2;
     pl->rows_per_block = sis_cdiv(h, rbk);
