@@ -47,6 +47,13 @@ class _WeightStandardize(Function):
         return sis_hip.weight_std_bwd(grad, weight, invstd, ctx.eps), None, None
 
 
+_SAMPLE_POINTWISE = os.environ.get('SIS_SAMPLE_POINTWISE_S2', '1') != '0'   # 0: 1x1 stride-2 layers on the strided kernel (A/B runs)
+
+
+def _sampled_pointwise(m):
+    return _SAMPLE_POINTWISE and m.kernel_size == (1, 1) and m.stride == (2, 2) and m.padding == (0, 0)
+
+
 class _BankStandardize(Function):
     """All StdConv2d weights of the trunk at once: ``forward(bank, *weights) -> w_hat per layer`` runs ONE launch that also
     writes every layer's packed images (``sis_hip.WeightStdPackBank``: 52 weight_std + 55 conv_pack launches per step before);
@@ -141,8 +148,14 @@ class StdConv2d(nn.Conv2d):
         if self._banked is not None:
             w, packed, adjoint = self._banked
             xb = x if x.dtype == torch.bfloat16 else x.bfloat16()
-            if conv_bf16_applicable(xb, w, self.stride, self.padding, self.dilation, self.groups):
-                return conv_bf16(xb, w, self.bias, self.stride[0], prepacked=(packed, adjoint), defer_wgrad=True)
+            stride = self.stride
+            if _sampled_pointwise(self):
+                # 1x1 stride 2 (the projection shortcuts of block2 / block3) = the dense 1x1 layer on the even pixels: the strided
+                # kernel took 102 us for 8.6 GF at 127 x 127, the sampling copy + the pointwise kernel take 35; the bank packed the
+                # weight for stride 1 (with its adjoint image: no pack launch in the backward), autograd scatters dL/dx back
+                xb, stride = xb[:, :, ::2, ::2].contiguous(), (1, 1)
+            if conv_bf16_applicable(xb, w, stride, self.padding, self.dilation, self.groups):
+                return conv_bf16(xb, w, self.bias, stride[0], prepacked=(packed, adjoint), defer_wgrad=True)
         else:
             w = self.standardized_weight()
         if _BF16_CONV and w.dtype == torch.bfloat16 and self.padding_mode == 'zeros' and x.is_cuda and x.dim() == 4:
@@ -243,7 +256,8 @@ class ResNetV2(nn.Module):
         bank = self._bank
         if bank is None or len(bank.weights) != len(layers) or any(a is not m.weight for a, m in zip(bank.weights, layers)) \
                 or not bank.current():
-            bank = self._bank = sis_hip.WeightStdPackBank([m.weight for m in layers], [m.stride[0] for m in layers], StdConv2d.EPS)
+            bank = self._bank = sis_hip.WeightStdPackBank([m.weight for m in layers], [1 if _sampled_pointwise(m) else m.stride[0] for m in layers],
+                                                          StdConv2d.EPS)
         w_hats = _BankStandardize.apply(bank, *bank.weights)
         for m, w_hat, packed, adjoint in zip(layers, w_hats, bank.packed, bank.adjoint):
             m._banked = (w_hat, packed, adjoint)
