@@ -528,9 +528,12 @@ int sis_conv1x1_f32_dgrad_add(float* dx, const float* dy, const float* weight, c
  * epilogue:
  *   SIS_GEMM_EPI_NONE             C bf16 = acc
  *   SIS_GEMM_EPI_BIAS             C bf16 = acc + bias[n]
- *   SIS_GEMM_EPI_BIAS_GELU_DROP   C2 bf16 = h = acc + bias (the pre-activation);  C bf16 = dropout(gelu(h))     (erf GELU)
+ *   SIS_GEMM_EPI_BIAS_GELU_DROP   with h = acc + bias:  C bf16 = dropout(gelu(h))  (erf GELU);  C2 bf16 = d C / d h = gelu'(h) * the same
+ *                                 dropout factor -- what SIS_GEMM_EPI_GELU_BWD of the backward multiplies by (round 5: it was h, and the
+ *                                 backward recomputed erf, exp and the dropout hash per element)
  *   SIS_GEMM_EPI_BIAS_DROP_RESID  C fp32 = resid[m][n] + dropout(acc + bias)      (resid fp32, leading dim ldc)
- *   SIS_GEMM_EPI_GELU_BWD         C bf16 = acc * dropout_factor * gelu'(pre[m][n])  (pre bf16, leading dim ldc)
+ *   SIS_GEMM_EPI_GELU_BWD         C bf16 = acc * pre[m][n]   (pre bf16, leading dim ldc: the C2 of the forward's SIS_GEMM_EPI_BIAS_GELU_DROP;
+ *                                 seed / site / drop_p are not read)
  *   SIS_GEMM_EPI_F32              C fp32 = acc; with splits > 1 the K range is cut into `splits` slices whose partial results
  *                                 go through `workspace` and are added in slice order (deterministic)
  * dropout: element (m, n) of site `site` is dropped iff hash(seed word, site, m * n_cols + n) < drop_p * 2^32, else scaled by

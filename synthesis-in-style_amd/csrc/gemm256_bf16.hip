@@ -213,7 +213,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm256_kernel(G256Params p) {
     // ---- epilogue: lane = output row m (per m block), registers = 4 consecutive columns n (as gemm_bf16.hip)
     SisDropKey key{0u, 0u};
     constexpr bool HAS_BIAS = EPI == SIS_GEMM_EPI_BIAS || EPI == SIS_GEMM_EPI_BIAS_GELU_DROP || EPI == SIS_GEMM_EPI_BIAS_DROP_RESID;
-    constexpr bool HAS_DROP = EPI == SIS_GEMM_EPI_BIAS_GELU_DROP || EPI == SIS_GEMM_EPI_BIAS_DROP_RESID || EPI == SIS_GEMM_EPI_GELU_BWD;
+    constexpr bool HAS_DROP = EPI == SIS_GEMM_EPI_BIAS_GELU_DROP || EPI == SIS_GEMM_EPI_BIAS_DROP_RESID;   // (GELU_BWD: the factor it reads carries the mask)
     if constexpr (HAS_DROP)
         if (p.drop_thr) key = sis_drop_key(p.seed, p.site);
     constexpr bool BF16_OUT = EPI != SIS_GEMM_EPI_BIAS_DROP_RESID;
@@ -239,16 +239,20 @@ __global__ __launch_bounds__(C::THREADS) void gemm256_kernel(G256Params p) {
         if constexpr (EPI == SIS_GEMM_EPI_NONE || EPI == SIS_GEMM_EPI_BIAS) {
             o0 = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
         } else if constexpr (EPI == SIS_GEMM_EPI_BIAS_GELU_DROP) {
-            o1 = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));   // the activation is evaluated AT the stored bf16 value
-            float y[4] = {sis_gelu(sis_bf16_lo(o1.x)), sis_gelu(sis_bf16_hi(o1.x)), sis_gelu(sis_bf16_lo(o1.y)), sis_gelu(sis_bf16_hi(o1.y))};
+            float y[4], dd[4];   // dropout(gelu(pre)) and gelu'(pre) * the same dropout factor (what the backward multiplies by), one cdf / pdf evaluation
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] *= keep[e];
+            for (int e = 0; e < 4; ++e) {
+                float cdf, pdf;
+                sis_gelu_parts(v[e], cdf, pdf);
+                y[e] = v[e] * cdf * keep[e];
+                dd[e] = __builtin_fmaf(v[e], pdf, cdf) * keep[e];
+            }
+            o1 = make_uint2(sis_pack_bf16x2(dd[0], dd[1]), sis_pack_bf16x2(dd[2], dd[3]));
             o0 = make_uint2(sis_pack_bf16x2(y[0], y[1]), sis_pack_bf16x2(y[2], y[3]));
-        } else {   // SIS_GEMM_EPI_GELU_BWD: gradient w.r.t. the pre-activation: acc * dropout factor * gelu'(pre)
-            const float d[4] = {sis_gelu_grad(sis_bf16_lo(hpre.x)), sis_gelu_grad(sis_bf16_hi(hpre.x)),
-                                sis_gelu_grad(sis_bf16_lo(hpre.y)), sis_gelu_grad(sis_bf16_hi(hpre.y))};
+        } else {   // SIS_GEMM_EPI_GELU_BWD: gradient w.r.t. the pre-activation: acc * the factor the forward stored
+            const float d[4] = {sis_bf16_lo(hpre.x), sis_bf16_hi(hpre.x), sis_bf16_lo(hpre.y), sis_bf16_hi(hpre.y)};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= d[e] * keep[e];
+            for (int e = 0; e < 4; ++e) v[e] *= d[e];
             o0 = make_uint2(sis_pack_bf16x2(v[0], v[1]), sis_pack_bf16x2(v[2], v[3]));
         }
     };

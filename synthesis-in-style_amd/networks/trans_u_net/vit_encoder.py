@@ -481,7 +481,7 @@ class _FusedBlockFn(Function):
         # (a gradient may only be deferred while its parameters hold none: autograd would add the unwritten tensor on the spot)
         new_qkv, new_o, new_f1, new_f2 = (all(p.grad is None for p in group) for group in ctx.linear_params)
         d_w2, d_b2 = wg.run(gl2, act, hid, mlp, k_f2, defer=new_f2)
-        d_pre = dgrad(gl2, w2, w2_t, S.EPI_GELU_BWD, pre=pre, seed=seed, site=site + 1, drop_p=p_mlp)
+        d_pre = dgrad(gl2, w2, w2_t, S.EPI_GELU_BWD, pre=pre)   # pre = gelu'(h) * dropout factor, stored by fc1's forward epilogue
         d_w1, d_b1 = wg.run(d_pre, h2, mlp, hid, k_f1, defer=new_f1)
         d_h2 = dgrad(d_pre, w1, w1_t)
         # LN2 backward + the skip connection's gradient, and d(out-projection output) = that sum through the proj dropout

@@ -1372,7 +1372,7 @@ def gemm_bf16(a, b, layout, epilogue=EPI_NONE, bias=None, resid=None, pre=None, 
       GEMM_NN  a [m,k], b [k,n]   (data gradient: grad, weight)
       GEMM_TN  a [k,m], b [k,n]   (weight gradient: grad, x; EPI_F32, optionally split over k)
     Row-strided views are taken as they are (row stride % 8 == 0).  Returns C (bf16, or fp32 for EPI_BIAS_DROP_RESID /
-    EPI_F32); EPI_BIAS_GELU_DROP returns (dropout(gelu(h)), h)."""
+    EPI_F32); EPI_BIAS_GELU_DROP returns (dropout(gelu(h)), gelu'(h) * dropout factor) -- the second is the ``pre=`` of EPI_GELU_BWD."""
     require_device(a, "a")
     a, b = _rows2d(a, "a"), _rows2d(b, "b")
     if layout == GEMM_NT:

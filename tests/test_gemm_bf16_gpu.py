@@ -47,9 +47,9 @@ def test_gemm_nt_epilogues(device, m, n, k, tile):
     y = x.float() @ w.float().t()
     _close(S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_NONE, tile=tile), y, BF16_TOL)
     _close(S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS, bias=bd, tile=tile), y + bias, BF16_TOL)
-    out, pre = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_GELU_DROP, bias=bd, tile=tile)
-    _close(pre, y + bias, BF16_TOL)
-    _close(out, _gelu(pre.float().cpu()), BF16_TOL)            # the activation is evaluated AT the stored bf16 pre-activation
+    out, dact = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_GELU_DROP, bias=bd, tile=tile)
+    _close(out, _gelu(y + bias), BF16_TOL)
+    _close(dact, _gelu_grad(y + bias), BF16_TOL)               # the second output: d out / d (pre-activation), what EPI_GELU_BWD multiplies by
     res = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=bd, resid=rd, tile=tile)
     assert res.dtype == torch.float32
     _close(res, resid + y + bias, F32_TOL * 4)
@@ -67,7 +67,7 @@ def test_gemm_nn_data_gradient(device, m, n, k, tile):
     gd, wd, pd = g.to(device), w.to(device), pre.to(device)
     y = g.float() @ w.float()
     _close(S.gemm_bf16(gd, wd, S.GEMM_NN, S.EPI_NONE, tile=tile), y, BF16_TOL)
-    _close(S.gemm_bf16(gd, wd, S.GEMM_NN, S.EPI_GELU_BWD, pre=pd, tile=tile), y * _gelu_grad(pre.float()), BF16_TOL)
+    _close(S.gemm_bf16(gd, wd, S.GEMM_NN, S.EPI_GELU_BWD, pre=pd, tile=tile), y * pre.float(), BF16_TOL)   # (pre: the stored derivative factor)
 
 
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
@@ -154,14 +154,19 @@ def test_gemm_dropout_stream(device):
         assert abs(agree - (p * p + (1 - p) ** 2)) < 1e-2, agree    # independent masks agree on p^2 + (1-p)^2 of the elements
     # fc1 forward (GELU + dropout) and the fc2 data gradient's epilogue (dropout * gelu') share a site and a mask
     seed2 = torch.tensor([777], dtype=torch.int64, device=device)
-    out, pre = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_GELU_DROP, bias=zero_b, seed=seed2, site=9, drop_p=p)
+    out, dact = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_GELU_DROP, bias=zero_b, seed=seed2, site=9, drop_p=p)
+    out0, dact0 = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_GELU_DROP, bias=zero_b)
     gy, w2 = _rand((m, k), gen).to(device), _rand((k, n), gen, k ** -0.5).to(device)
-    dpre = S.gemm_bf16(gy, w2, S.GEMM_NN, S.EPI_GELU_BWD, pre=pre, seed=seed2, site=9, drop_p=p)
-    dpre0 = S.gemm_bf16(gy, w2, S.GEMM_NN, S.EPI_GELU_BWD, pre=pre)
-    fwd_dropped = (out == 0) & (_gelu(pre.float()).bfloat16() != 0)
+    dpre = S.gemm_bf16(gy, w2, S.GEMM_NN, S.EPI_GELU_BWD, pre=dact)
+    dpre0 = S.gemm_bf16(gy, w2, S.GEMM_NN, S.EPI_GELU_BWD, pre=dact0)
+    fwd_dropped = (out == 0) & (out0 != 0)
+    fac_dropped = (dact == 0) & (dact0 != 0)
     bwd_dropped = (dpre == 0) & (dpre0 != 0)
     assert fwd_dropped.float().mean().item() > 0.08
-    assert torch.equal(fwd_dropped & (dpre0 != 0), bwd_dropped & (_gelu(pre.float()).bfloat16() != 0))
+    assert torch.equal(fwd_dropped & (dact0 != 0), fac_dropped & (out0 != 0))       # one mask for the activation and its derivative factor ...
+    assert torch.equal(fac_dropped & (dpre0 != 0), bwd_dropped & (dact0 != 0))      # ... which is the mask of the data gradient
+    keep = ~fac_dropped & (dact0 != 0)
+    _close(dact[keep], (dact0[keep].float() * scale).cpu(), BF16_TOL)
 
 
 def test_gemm_full_size_qkv(device):
@@ -225,13 +230,13 @@ def test_gemm256_nt_epilogues(device, m, n, k, tile):
     y = x.float() @ w.float().t()
     _close(S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_NONE, tile=tile), y, BF16_TOL)
     _close(S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS, bias=bd, tile=tile), y + bias, BF16_TOL)
-    out, pre = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_GELU_DROP, bias=bd, tile=tile)
-    _close(pre, y + bias, BF16_TOL)
-    _close(out, _gelu(pre.float().cpu()), BF16_TOL)
+    out, dact = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_GELU_DROP, bias=bd, tile=tile)
+    _close(out, _gelu(y + bias), BF16_TOL)
+    _close(dact, _gelu_grad(y + bias), BF16_TOL)
     res = S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS_DROP_RESID, bias=bd, resid=rd, tile=tile)
     assert res.dtype == torch.float32
     _close(res, resid + y + bias, F32_TOL * 4)
-    _close(S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_GELU_BWD, pre=pd, tile=tile), y * _gelu_grad(pre_in.float()), BF16_TOL)
+    _close(S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_GELU_BWD, pre=pd, tile=tile), y * pre_in.float(), BF16_TOL)
     # bitwise the 128-wide kernel's result: both accumulate the K steps in order in fp32 and round once
     assert torch.equal(S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS, bias=bd, tile=tile), S.gemm_bf16(xd, wd, S.GEMM_NT, S.EPI_BIAS, bias=bd, tile=0))
     if n % 12 == 0:   # three bias segments (query | key | value)
