@@ -69,7 +69,7 @@ def _may_defer(flag, weight):
     """A layer's weight gradient may wait for ``sis_hip.flush_deferred`` (batched with the other layers of its shape) when the
     owner of the layer said so (``HipConv2d._defer_wgrad``: its weight is used ONCE per forward) and the weight is a parameter
     without a gradient in place -- autograd then takes the tensor as it is; with one in place it would add the unwritten result."""
-    return bool(flag) and weight.is_leaf and weight.grad is None
+    return bool(flag) and weight.is_leaf and weight.grad is None and not weight._backward_hooks   # (a tensor hook would read the unwritten gradient)
 
 
 class _Conv3x3Function(Function):

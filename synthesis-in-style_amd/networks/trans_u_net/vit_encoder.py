@@ -479,13 +479,13 @@ class _FusedBlockFn(Function):
         gl2 = S.dropout_bwd_cast(g3, seed, site + 2, p_mlp)                                   # d(fc2 output), bf16
         k_qkv, k_o, k_f1, k_f2 = ctx.weight_keys
         # (a gradient may only be deferred while its parameters hold none: autograd would add the unwritten tensor on the spot)
-        new_qkv, new_o, new_f1, new_f2 = (all(p.grad is None for p in group) for group in ctx.linear_params)
+        new_qkv, new_o, new_f1, new_f2 = (all(p.grad is None and not p._backward_hooks for p in group) for group in ctx.linear_params)   # (a tensor hook would read the unwritten gradient)
         d_w2, d_b2 = wg.run(gl2, act, hid, mlp, k_f2, defer=new_f2)
         d_pre = dgrad(gl2, w2, w2_t, S.EPI_GELU_BWD, pre=pre)   # pre = gelu'(h) * dropout factor, stored by fc1's forward epilogue
         d_w1, d_b1 = wg.run(d_pre, h2, mlp, hid, k_f1, defer=new_f1)
         d_h2 = dgrad(d_pre, w1, w1_t)
         # LN2 backward + the skip connection's gradient, and d(out-projection output) = that sum through the proj dropout
-        fresh1, fresh2 = (all(p.grad is None for p in pair) for pair in ctx.norm_params)   # no gradient in place: deferrable
+        fresh1, fresh2 = (all(p.grad is None and not p._backward_hooks for p in pair) for pair in ctx.norm_params)   # no gradient in place, no tensor hook: deferrable
         g2, d_ln2_w, d_ln2_b, gl1 = S.layer_norm_bwd_fused(d_h2, x2, mean2, rstd2, ln2_w, residual_grad=g3, cast_seed=seed,
                                                            cast_site=site, cast_p=p_proj, defer=fresh2)
         # ---- attention

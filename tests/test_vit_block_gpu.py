@@ -211,3 +211,14 @@ def test_deferred_weight_gradients_match_the_undeferred_ones(device, monkeypatch
     finally:
         sis_hip.block_wgrad_deferral(enc, False)
     assert queued_blocked == 0
+    # a tensor hook reads the gradient INSIDE the backward: that Linear layer is multiplied on the spot, the others stay queued
+    name, hooked = next((n, p) for n, p in enc.named_parameters() if n.endswith("ffn.fc1.weight"))
+    seen = []
+    handle = hooked.register_hook(lambda g: seen.append(g.clone()))
+    try:
+        with_hook, queued_hook = backward_once()
+    finally:
+        handle.remove()
+    assert queued_hook == 11 and len(seen) == 1
+    assert torch.equal(seen[0], with_hook[name])
+    assert float((with_hook[name] - plain[name]).abs().max()) <= 1e-5 * float(plain[name].abs().max())
