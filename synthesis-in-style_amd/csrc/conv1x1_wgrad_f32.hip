@@ -12,6 +12,7 @@
 // contraction order).  Each of the 8 waves owns MB 32 x 32 accumulator tiles stacked along the output channels (its B
 // operand read is shared by them); split-K over the pixel stream writes slabs that an ordered pass adds (deterministic,
 // no atomics).
+#include <cstdlib>
 #include "sis_common.h"
 
 namespace {
@@ -179,7 +180,8 @@ int pwg_slices(int batch, int cin, int cout, int hw, int jobs = 1) {
     int tm, tn;
     pwg_tile(cout, cin, &tm, &tn);
     const int tiles = (cout / tm) * (cin / tn) * jobs, chunks = batch * (hw / PK);   // (the layers of a launch fill the chip together)
-    int slices = (768 + tiles - 1) / tiles;
+    static const int target = getenv("SIS_PWG_TARGET") ? atoi(getenv("SIS_PWG_TARGET")) : 768;   // workgroups a launch is cut for (~3 per CU)
+    int slices = (target + tiles - 1) / tiles;
     if (slices > chunks / 2) slices = chunks / 2;
     const int64_t by_bytes = ((int64_t)32 << 20) / ((int64_t)cout * cin * 4);
     if (slices > by_bytes) slices = (int)by_bytes;
