@@ -335,6 +335,8 @@ def _wgrad_plan(out_features, in_features):
     return splits, 0
 
 
+_FUSE_BLOCK_CAST = os.environ.get('SIS_FUSE_BLOCK_CAST', '1') != '0'   # 0: every block casts its own output gradient (A/B runs)
+_NEXT_BLOCK_CAST = {}   # (gradient address, dropout site, backward id) -> its bf16 dropout-cast, handed from block i's backward to block i - 1's
 _FUSE_BIAS_GRAD = os.environ.get('SIS_FUSE_BIAS_GRAD', '1') != '0'   # 0: bias gradients as column-sum launches of their own (A/B runs)
 _WGRAD_STREAMS = {}  # device -> side stream of the weight-gradient GEMMs (process-wide, like the generator's ToRGB stream)
 _WGRAD_SIDE = int(os.environ.get('SIS_WGRAD_STREAM', '0'))   # 1: weight-gradient GEMMs + column sums on a side stream (measured 273 vs 277 images/s: off); 2: column sums only
@@ -476,7 +478,11 @@ class _FusedBlockFn(Function):
             return S.gemm_bf16(g, w, S.GEMM_NN, epilogue, **kw)
 
         # ---- MLP
-        gl2 = S.dropout_bwd_cast(g3, seed, site + 2, p_mlp)                                   # d(fc2 output), bf16
+        # d(fc2 output), bf16: written by the NEXT block's LayerNorm backward together with the gradient it was cast from (below);
+        # the last block -- or a gradient that did not come straight from there -- casts here
+        gl2 = _NEXT_BLOCK_CAST.pop((g3.data_ptr(), site + 2, torch._C._current_graph_task_id()), None) if _FUSE_BLOCK_CAST else None
+        if gl2 is None:
+            gl2 = S.dropout_bwd_cast(g3, seed, site + 2, p_mlp)
         k_qkv, k_o, k_f1, k_f2 = ctx.weight_keys
         # (a gradient may only be deferred while its parameters hold none: autograd would add the unwritten tensor on the spot)
         new_qkv, new_o, new_f1, new_f2 = (all(p.grad is None and not p._backward_hooks for p in group) for group in ctx.linear_params)   # (a tensor hook would read the unwritten gradient)
@@ -494,7 +500,15 @@ class _FusedBlockFn(Function):
         d_qkv = S.attention_bwd(d_att.view(b, n, hid), qkv.view(b, n, 3 * hid), att, lse, heads).view(m, 3 * hid)
         d_wqkv, d_bqkv = wg.run(d_qkv, h1, 3 * hid, hid, k_qkv, defer=new_qkv)
         d_h1 = dgrad(d_qkv, wqkv, wqkv_t)
-        g1, d_ln1_w, d_ln1_b, _ = S.layer_norm_bwd_fused(d_h1, x2d, mean1, rstd1, ln1_w, residual_grad=g2, defer=fresh1)
+        # (block i's input gradient IS block i - 1's output gradient: its bf16 cast through that block's fc2 dropout site -- 4 (i - 1) + 2 --
+        # rides in this launch instead of a launch of its own at the top of that block's backward: 11 launches per step)
+        prev_site = site - 2 if (_FUSE_BLOCK_CAST and site >= 4) else None
+        g1, d_ln1_w, d_ln1_b, cast_prev = S.layer_norm_bwd_fused(d_h1, x2d, mean1, rstd1, ln1_w, residual_grad=g2, cast_seed=seed,
+                                                                 cast_site=prev_site, cast_p=p_mlp, defer=fresh1)
+        if site == 0:
+            _NEXT_BLOCK_CAST.clear()
+        elif cast_prev is not None:
+            _NEXT_BLOCK_CAST[(g1.data_ptr(), prev_site, torch._C._current_graph_task_id())] = cast_prev
         wg.join()
         d_q, d_k, d_v = d_wqkv.split(hid, 0)
         d_qb, d_kb, d_vb = d_bqkv.split(hid, 0)

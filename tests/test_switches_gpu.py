@@ -123,6 +123,7 @@ _MODULE_SWITCHES = [
     ("networks.trans_u_net.vit_encoder", "_GEMM256", False, "trans_u_net"),                       # SIS_GEMM256
     ("networks.trans_u_net.vit_encoder", "_GEMM256_DGRAD", True, "trans_u_net"),                  # SIS_GEMM256_DGRAD
     ("networks.trans_u_net.vit_encoder", "_FUSE_BIAS_GRAD", False, "trans_u_net"),                # SIS_FUSE_BIAS_GRAD
+    ("networks.trans_u_net.vit_encoder", "_FUSE_BLOCK_CAST", False, "trans_u_net"),               # SIS_FUSE_BLOCK_CAST
     ("networks.trans_u_net.vit_encoder", "_WGRAD_SIDE", 1, "trans_u_net"),                        # SIS_WGRAD_STREAM
     ("networks.trans_u_net.vit_encoder", "_WGRAD_SIDE", 2, "trans_u_net"),
     ("networks.trans_u_net.vit_seg_modeling_resnet_skip", "_GN_GATE_BITS", False, "trans_u_net"),  # SIS_GN_GATE_BITS

@@ -222,3 +222,37 @@ def test_deferred_weight_gradients_match_the_undeferred_ones(device, monkeypatch
     assert queued_hook == 11 and len(seen) == 1
     assert torch.equal(seen[0], with_hook[name])
     assert float((with_hook[name] - plain[name]).abs().max()) <= 1e-5 * float(plain[name].abs().max())
+
+
+def test_block_output_gradient_cast_rides_in_the_next_blocks_layer_norm_backward(device, monkeypatch):
+    """SIS_FUSE_BLOCK_CAST: block i's LayerNorm-1 backward writes, next to the input gradient g, bf16(g * dropout factor of block
+    i - 1's fc2 site) -- what block i - 1's backward starts from -- instead of a cast launch at the top of that backward.  Same
+    values, same dropout mask: every gradient bitwise equal to the unfused form (dropout 0.1 on the MLP sites, one seed word)."""
+    import sis_hip
+    from networks.trans_u_net import vit_encoder as V
+    cfg = _config(0.1)
+    cfg.transformer["num_layers"] = 3
+    torch.manual_seed(21)
+    enc = V.Encoder(cfg, vis=False).to(device).train()
+    x = torch.randn(2, 128, 768, device=device, requires_grad=True)
+    word = sis_hip.dropout_seed(device)
+
+    def grads(fused):
+        monkeypatch.setattr(V, "_FUSE_BLOCK_CAST", fused)
+        word.fill_(777)
+        enc.zero_grad(set_to_none=True)
+        x.grad = None
+        casts = []
+        real = sis_hip.dropout_bwd_cast
+        monkeypatch.setattr(sis_hip, "dropout_bwd_cast", lambda *a, **k: (casts.append(1), real(*a, **k))[1])
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            enc(x)[0].square().mean().backward()
+        monkeypatch.setattr(sis_hip, "dropout_bwd_cast", real)
+        assert not V._NEXT_BLOCK_CAST
+        return [p.grad.clone() for p in enc.parameters()] + [x.grad.clone()], len(casts)
+
+    plain, n_plain = grads(False)
+    fused, n_fused = grads(True)
+    assert n_plain == 3 and n_fused == 1, (n_plain, n_fused)   # only the last block (its gradient comes from the final norm) casts by itself
+    for u, v in zip(plain, fused):
+        assert torch.equal(u, v)
