@@ -500,6 +500,21 @@ int sis_conv1x1_bf16_wgrad_multi(void* const* dw, int dw_dtype, const void* cons
                                  int cin, int cout, int pixels, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The root convolution of the hybrid trunk (networks/trans_u_net/vit_seg_modeling_resnet_skip.py:115-125: StdConv2d(3, 64,
+ * kernel_size=7, stride=2, padding=3) on the image) on the bf16 matrix cores: forward and weight gradient (the image needs no
+ * gradient).  x [B][3][h][w] float32 or bfloat16 (converted while staged), y / grad_y [B][64][ho][wo] bfloat16 with
+ * ho = (h - 1) / 2 + 1.  `packed`: sis_stem_conv_packed_elems() bf16 elements written by sis_stem_conv_pack from the
+ * (standardised) weight [64][3][7][7] (float32 or bfloat16).  dw [64][3][7][7] float32 or bfloat16; the partial sums of the
+ * workgroups go through `workspace` (sis_stem_conv_wgrad_workspace_bytes) and are added in a fixed order. */
+int sis_stem_conv_supported(int cin, int cout, int ksize, int stride, int padding, int h, int w);
+int64_t sis_stem_conv_packed_elems(void);
+int sis_stem_conv_pack(void* packed, const void* weight, int weight_dtype, void* stream);
+int sis_stem_conv_fwd(void* y, const void* x, int x_dtype, const void* packed, int batch, int h, int w, void* stream);
+int64_t sis_stem_conv_wgrad_workspace_bytes(int batch, int h, int w);
+int sis_stem_conv_wgrad(void* dw, int dw_dtype, const void* x, int x_dtype, const void* grad_y, int batch, int h, int w, void* workspace,
+                        int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * fp32 pointwise (1x1, stride 1) convolution of the EMANet training step (csrc/conv1x1_f32.hip;
  * networks/ema_net/network.py:24,29,106-107 Bottleneck conv1 / conv3 / downsample, :219-249 EMAU, :271-289 fc0 / fc1),
  * exact fp32 on v_mfma_f32_32x32x2_f32, NCHW in and out.

@@ -54,6 +54,23 @@ def _sampled_pointwise(m):
     return _SAMPLE_POINTWISE and m.kernel_size == (1, 1) and m.stride == (2, 2) and m.padding == (0, 0)
 
 
+_STEM_OWN = os.environ.get('SIS_STEM_OWN', '1') != '0'   # 0: the root convolution on the library (A/B runs)
+
+
+class _StemConv(Function):
+    """ResNetV2's root convolution (7x7, stride 2, padding 3, image -> 64 channels) on the matrix cores; the image gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return sis_hip.stem_conv_fwd(x, weight)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, weight = ctx.saved_tensors
+        return None, sis_hip.stem_conv_wgrad(x, grad, weight.dtype, for_param=weight.data_ptr())
+
+
 class _BankStandardize(Function):
     """All StdConv2d weights of the trunk at once: ``forward(bank, *weights) -> w_hat per layer`` runs ONE launch that also
     writes every layer's packed images (``sis_hip.WeightStdPackBank``: 52 weight_std + 55 conv_pack launches per step before);
@@ -165,7 +182,12 @@ class StdConv2d(nn.Conv2d):
         if (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.groups == 1
                 and x.is_cuda and x.dim() == 4 and x.is_contiguous() and x.dtype == w.dtype):
             return _Pointwise.apply(x, w, self.bias)  # weight gradient as a batched GEMM on the NCHW tensors
-        if x.is_cuda:   # the 7x7 stride-2 root on the 3-channel image is the documented library layer
+        if (_STEM_OWN and _BF16_CONV and x.is_cuda and w.dtype == torch.bfloat16 and self.bias is None and self.groups == 1
+                and self.padding_mode == 'zeros' and self.dilation == (1, 1) and self.stride[0] == self.stride[1]
+                and self.padding[0] == self.padding[1] and not x.requires_grad
+                and sis_hip.stem_conv_supported(x, w, self.stride[0], self.padding[0])):
+            return _StemConv.apply(x, w)   # the 7x7 stride-2 root on the 3-channel image: csrc/stem_conv.hip (round 5; the library before)
+        if x.is_cuda:   # (anything else of this kind is a library layer: counted)
             sis_hip.library_call("vit_seg_modeling_resnet_skip.StdConv2d.forward", intended=(self.in_channels <= 4))
         return F.conv2d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)
 

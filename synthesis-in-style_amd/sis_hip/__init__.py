@@ -133,6 +133,12 @@ _SIGNATURES = {
     "sis_conv_bf16_wgrad_supported": ([_i] * 5 + [_i64], _i),
     "sis_conv_bf16_wgrad": ([_vp, _i, _vp, _vp] + [_i] * 5 + [_vp, _i64, _vp], _i),
     "sis_conv_bf16_wgrad_multi": ([_vp, _i, _vp, _vp] + [_i] * 6 + [_vp, _i64, _vp], _i),
+    "sis_stem_conv_supported": ([_i] * 7, _i),
+    "sis_stem_conv_packed_elems": ([], _i64),
+    "sis_stem_conv_pack": ([_vp, _vp, _i, _vp], _i),
+    "sis_stem_conv_fwd": ([_vp, _vp, _i, _vp, _i, _i, _i, _vp], _i),
+    "sis_stem_conv_wgrad_workspace_bytes": ([_i, _i, _i], _i64),
+    "sis_stem_conv_wgrad": ([_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i64, _vp], _i),
     "sis_weight_std_pack_plan": ([_i] * 4 + [_vp] * 5, _i),
     "sis_weight_std_pack_multi": ([_vp, _i, _i, _f, _vp], _i),
     "sis_weight_std_bwd_multi": ([_vp, _vp, _vp, _vp, _i, _vp], _i),
@@ -1180,6 +1186,46 @@ def conv_bf16_wgrad(x, grad_output, out_dtype=torch.float32, for_param=None, def
         _check(_launch(None, 2.0 * b * cout * cin * 9 * h * w, 2.0 * (x.numel() + grad_output.numel()) + 4.0 * dw.numel(),
                        lambda: lib().sis_conv_bf16_wgrad(_ptr(dw), _DTYPE_CODE[out_dtype], _ptr(x), _ptr(grad_output), b, cin, cout,
                                                          h, w, _ptr(ws), ws.numel(), _stream())), "sis_conv_bf16_wgrad")
+    return dw
+
+
+def stem_conv_supported(x, weight, stride, padding):
+    """The 7x7 stride-2 padding-3 convolution of a 3-channel image to 64 channels (ResNetV2's root) on csrc/stem_conv.hip."""
+    return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and weight.dim() == 4
+            and weight.dtype in (torch.float32, torch.bfloat16) and weight.shape[2] == weight.shape[3]
+            and bool(lib().sis_stem_conv_supported(x.shape[1], weight.shape[0], weight.shape[2], int(stride), int(padding), x.shape[2], x.shape[3])))
+
+
+def stem_conv_fwd(x, weight):
+    """x [B,3,H,W] (float32 or bfloat16), weight [64,3,7,7] -> y [B,64,Ho,Wo] bfloat16 (bf16 products, fp32 sums)."""
+    require_device(x, "input")
+    x, w = x.contiguous(), weight.contiguous()
+    b, _, h, wd = x.shape
+    packed = torch.empty(lib().sis_stem_conv_packed_elems(), dtype=torch.bfloat16, device=x.device)
+    y = torch.empty((b, 64, (h - 1) // 2 + 1, (wd - 1) // 2 + 1), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().sis_stem_conv_pack(_ptr(packed), _ptr(w), _DTYPE_CODE[w.dtype], _stream()), "sis_stem_conv_pack")
+        _check(_launch(None, 2.0 * y.numel() * 147, 2.0 * y.numel() + x.numel() * x.element_size(),
+                       lambda: lib().sis_stem_conv_fwd(_ptr(y), _ptr(x), _DTYPE_CODE[x.dtype], _ptr(packed), b, h, wd, _stream())), "sis_stem_conv_fwd")
+    return y
+
+
+def stem_conv_wgrad(x, grad_y, out_dtype=torch.float32, for_param=None):
+    """dL/dw [64,3,7,7] of ``stem_conv_fwd`` from the image and dL/dy (bfloat16)."""
+    require_device(x, "input")
+    x = x.contiguous()
+    gy = grad_y.contiguous()
+    if gy.dtype != torch.bfloat16:
+        gy = gy.bfloat16()
+    b, _, h, wd = x.shape
+    dw = grad_out(for_param, (64, 3, 7, 7), out_dtype, x.device)
+    ws = _workspace(x.device)
+    if lib().sis_stem_conv_wgrad_workspace_bytes(b, h, wd) > ws.numel():
+        raise RuntimeError("stem_conv_wgrad: split-K workspace too small (SIS_WORKSPACE_MB)")
+    with torch.cuda.device(x.device):
+        _check(_launch(None, 2.0 * gy.numel() * 147, 2.0 * gy.numel() + x.numel() * x.element_size(),
+                       lambda: lib().sis_stem_conv_wgrad(_ptr(dw), _DTYPE_CODE[out_dtype], _ptr(x), _DTYPE_CODE[x.dtype], _ptr(gy), b, h, wd,
+                                                         _ptr(ws), ws.numel(), _stream())), "sis_stem_conv_wgrad")
     return dw
 
 

@@ -238,3 +238,31 @@ def test_batched_weight_gradients_of_one_shape(device, kind, jobs, batch, cin, c
             scale = float(ref[j].float().abs().max())
             assert float((runs[0][j].float() - ref[j].float()).abs().max()) <= tol * scale, (j, dtype)
             assert torch.equal(runs[0][j], runs[1][j])
+
+
+@pytest.mark.parametrize("image_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("batch,h,w", [(2, 64, 64), (1, 224, 224), (2, 50, 70), (1, 37, 129), (3, 128, 96)])
+def test_stem_conv_7x7_stride_2_on_the_image(device, batch, h, w, image_dtype):
+    """csrc/stem_conv.hip: ResNetV2's root convolution (3 -> 64, 7x7, stride 2, padding 3) forward and weight gradient on the matrix
+    cores against F.conv2d / autograd in fp32 on the same bf16-rounded tensors: output within bf16 rounding (1e-2 of the largest
+    entry), dW 2e-3 (fp32) / 1e-2 (bf16); output widths that are no multiple of the 32-pixel tile or the 16-pixel K-step, odd
+    sizes (unaligned dL/dy rows), float32 images converted while they are staged; bitwise repeatable."""
+    import sis_hip
+    gen = torch.Generator().manual_seed(h * 3 + w)
+    x = torch.randn(batch, 3, h, w, generator=gen).to(device).to(image_dtype)
+    wt = (torch.randn(64, 3, 7, 7, generator=gen) / 147 ** 0.5).to(device).bfloat16()
+    assert sis_hip.stem_conv_supported(x, wt, 2, 3)
+    wr = wt.float().requires_grad_(True)
+    ref = F.conv2d(x.bfloat16().float(), wr, stride=2, padding=3)
+    y = sis_hip.stem_conv_fwd(x, wt)
+    assert y.dtype == torch.bfloat16 and y.shape == ref.shape
+    assert float((y.float() - ref.detach()).abs().max()) <= 1e-2 * float(ref.detach().abs().max())
+    gy = torch.randn(*ref.shape, generator=gen).to(device).bfloat16()
+    ref.backward(gy.float())
+    for dtype, tol in ((torch.float32, 2e-3), (torch.bfloat16, 1e-2)):
+        dw = sis_hip.stem_conv_wgrad(x, gy, dtype)
+        assert dw.dtype == dtype and dw.shape == wt.shape
+        assert float((dw.float() - wr.grad).abs().max()) <= tol * float(wr.grad.abs().max()), dtype
+    assert torch.equal(sis_hip.stem_conv_wgrad(x, gy), sis_hip.stem_conv_wgrad(x, gy))
+    assert not sis_hip.stem_conv_supported(torch.empty(1, 4, 64, 64, device=device), wt, 2, 3)
+    assert not sis_hip.stem_conv_supported(x, wt, 1, 3)

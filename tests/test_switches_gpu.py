@@ -129,6 +129,7 @@ _MODULE_SWITCHES = [
     ("networks.trans_u_net.vit_seg_modeling_resnet_skip", "_GN_GATE_BITS", False, "trans_u_net"),  # SIS_GN_GATE_BITS
     ("networks.trans_u_net.vit_seg_modeling_resnet_skip", "_WS_BANK", False, "trans_u_net"),       # SIS_WS_BANK
     ("networks.trans_u_net.vit_seg_modeling_resnet_skip", "_SAMPLE_POINTWISE", False, "trans_u_net"),  # SIS_SAMPLE_POINTWISE_S2
+    ("networks.trans_u_net.vit_seg_modeling_resnet_skip", "_STEM_OWN", False, "trans_u_net"),          # SIS_STEM_OWN
     ("networks.trans_u_net.vit_seg_modeling_resnet_skip", "_FUSE_RESIDUAL", False, "trans_u_net"),  # SIS_GN_RES
     ("networks.trans_u_net.vit_seg_modeling_resnet_skip", "_DUAL_STREAM", False, "trans_u_net"),   # SIS_GN_DUAL
     ("updater.segmentation_updater", "_FUSED_LOSS", False, "trans_u_net"),                        # SIS_FUSED_LOSS
