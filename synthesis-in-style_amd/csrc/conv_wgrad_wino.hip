@@ -172,6 +172,9 @@ __global__ __launch_bounds__(GTHR, 2) void conv_wgrad_wino_kernel(const WgradPar
         load(set0, c_lo + 2, c_lo + 2 < c_hi);
     }
     __syncthreads();
+    // operand pair of the chunk's first Winograd point: carried from chunk to chunk (requested behind the previous chunk's barrier)
+    f32x4 a = *reinterpret_cast<const f32x4*>(El + aoff + 2 * q * XI_STRIDE);
+    f32x4 b = *reinterpret_cast<const f32x4*>(Vl + boff + 2 * q * XI_STRIDE);
 
     // One chunk: 32 MFMAs in eight groups (one Winograd point each: four steps from one float4 pair, the next group's pair
     // requested first), the side work of the chunk in the sixteen half-group slots between them: set P ^ 1 (chunk c + 1,
@@ -187,8 +190,6 @@ __global__ __launch_bounds__(GTHR, 2) void conv_wgrad_wino_kernel(const WgradPar
         const float* Eb = El + P * IMG + aoff;
         const float* Vb = Vl + P * IMG + boff;
         const int xi0 = 2 * q;
-        f32x4 a = *reinterpret_cast<const f32x4*>(Eb + xi0 * XI_STRIDE);
-        f32x4 b = *reinterpret_cast<const f32x4*>(Vb + xi0 * XI_STRIDE);
 #pragma unroll
         for (int g = 0; g < 8; ++g) {  // Winograd point xi = 4 (g >> 1) + 2 q + (g & 1)
             const int i = g >> 1, jj = g & 1;
@@ -197,6 +198,9 @@ __global__ __launch_bounds__(GTHR, 2) void conv_wgrad_wino_kernel(const WgradPar
                 const int xin = 4 * ((g + 1) >> 1) + 2 * q + ((g + 1) & 1);
                 an = *reinterpret_cast<const f32x4*>(Eb + xin * XI_STRIDE);
                 bn = *reinterpret_cast<const f32x4*>(Vb + xin * XI_STRIDE);
+            } else {  // behind the chunk's barrier (below, after group 6): the first pair of chunk c + 1, under this chunk's last MFMAs
+                an = *reinterpret_cast<const f32x4*>(El + (P ^ 1) * IMG + aoff + xi0 * XI_STRIDE);
+                bn = *reinterpret_cast<const f32x4*>(Vl + (P ^ 1) * IMG + boff + xi0 * XI_STRIDE);
             }
             acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[i][jj], 0, 0, 0);
             acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[i][jj], 0, 0, 0);
@@ -231,11 +235,14 @@ __global__ __launch_bounds__(GTHR, 2) void conv_wgrad_wino_kernel(const WgradPar
             if (g == 4) load_x(setT, 2);
 #endif
             __builtin_amdgcn_sched_barrier(0);
+#ifndef SIS_WG_NOBARRIER
+            // The chunk's barrier sits before its last group: the images of chunk c + 1 are written by group 5, the last operand pair
+            // of chunk c was requested in group 6 -- and what follows the barrier is the request for chunk c + 1's first pair, whose
+            // LDS latency (eight waves asking at once) then lies under group 7's MFMAs instead of in front of the next chunk's.
+            if (g == 6) __syncthreads();
+#endif
             a = an; b = bn;
         }
-#ifndef SIS_WG_NOBARRIER
-        __syncthreads();
-#endif
     };
     for (int chunk = c_lo; chunk < c_hi; chunk += 2) {
         chunk_body(set0, chunk);

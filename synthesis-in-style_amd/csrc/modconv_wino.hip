@@ -34,6 +34,10 @@
 namespace {
 
 constexpr int WCC = 8;      // input channels per chunk
+#ifndef SIS_WINO_BAR_SLOT
+#define SIS_WINO_BAR_SLOT 27
+#endif
+constexpr int S_BAR = SIS_WINO_BAR_SLOT;  // MFMA slot of a chunk behind which its barrier sits (32: at the chunk end, the form before r05)
 constexpr int WMBLK = 64;   // output channels per workgroup
 constexpr int WTILES = 64;  // 2x2 output tiles per workgroup (256 pixels)
 
@@ -710,6 +714,18 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
         // One slot after each of the 32 MFMAs.  Issue costs add up inside an MFMA gap and only ~48 cycles of them hide under a
         // 64-cycle MFMA (MI355X_MICROARCH.md, constants: an LDS-DMA piece costs 60-185 cycles to issue, a packed-f32 VALU
         // instruction ~3x a scalar one), so the side work is spread one expensive item per slot.
+        f32x4 ou[3], ov[3];
+        auto chunk_barrier = [&]() {
+#ifdef SIS_WINO_NOBARRIER  // timing experiment only (results are garbage): what does the per-chunk barrier cost?
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+            __syncthreads();  // V(c+1) written, DMA retired, everyone done with U(c) / V(c)
+#endif
+        };
+        if (S_BAR < 32) {  // a tile starts on parity 0
+            ou[0] = lds_ld4(Ul + aoff);
+            ov[0] = lds_ld4(Vl + voff);
+        }
         auto chunk = [&](auto parity, const int ci0, const int c) {
             constexpr int cur = decltype(parity)::value, nxt = cur ^ 1;
             WINO_TRACE(0);
@@ -723,7 +739,6 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
             const float* Ub = Ul + cur * WF + aoff;
             const float* Vb = Vl + cur * VF + voff;
             float* vw = Vl + nxt * VF + tvo;
-            f32x4 ou[3], ov[3];
             auto operands = [&](int g, int slot) {  // group g = (cp, ih): MFMA rows i = 2 ih, 2 ih + 1, both jj
                 ou[slot] = lds_ld4(Ub + (8 * (g >> 1) + (g & 1)) * WMBLK * 4);
                 ov[slot] = lds_ld4(Vb + (8 * (g >> 1) + (g & 1)) * WTILES * 4);
@@ -735,8 +750,11 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
             static_assert(S_UDMA + 2 * (WIT - 1) < S_XDMA && S_XDMA + X_STEP * (XI - 1) < 32, "DMA pieces must fit the 32 slots");
             constexpr int S_READ = 1, S_RSTEP = 2;  // patch rows: every second slot from slot 1
             constexpr int S_A = 11;                 // d B: 4 slots
+            static_assert(S_BAR >= 27 || S_BAR < 0, "slot 0 of the operand registers is in use until slot 27");
             constexpr int S_B = 15;                 // B^T (d B) and scale, column j: slots S_B + 2 j, S_B + 2 j + 1; writes follow
-            operands(0, 0);  // operands run two groups (four MFMA pairs) ahead
+            // operands run two groups (four MFMA pairs) ahead; group 0 of this chunk was requested behind the PREVIOUS chunk's
+            // barrier (or at the tile start), under that chunk's last MFMAs
+            if (S_BAR >= 32) operands(0, 0);
             operands(1, 1);
             __builtin_amdgcn_sched_barrier(0);
             WINO_TRACE(1);
@@ -784,15 +802,20 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
                     }
                 }
 #endif
+                if (sl == S_BAR) {
+                    // The chunk's barrier, BEFORE its last MFMAs: by this slot the wave has issued every DMA piece, written its
+                    // V(c+1) and read its last operands of U(c) / V(c) (slot 21), so the barrier means what it meant at the chunk
+                    // end -- and the first operand pair of chunk c + 1 is requested right behind it, its LDS latency (all eight
+                    // waves ask at once) under the MFMAs of slots S_BAR + 1 .. 31 instead of in front of the next chunk's first.
+                    chunk_barrier();
+                    ou[0] = lds_ld4(Ul + nxt * WF + aoff);
+                    ov[0] = lds_ld4(Vl + nxt * VF + voff);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             WINO_TRACE(2);
             WINO_TRACE(3);
-#ifdef SIS_WINO_NOBARRIER  // timing experiment only (results are garbage): what does the per-chunk barrier cost?
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-            __syncthreads();  // V(c+1) written, DMA retired, everyone done with U(c) / V(c)
-#endif
+            if (S_BAR >= 32) chunk_barrier();
         };
         // (A `late` placement for waves 4-7 -- their DMA in the second half of the chunk, while their SIMD partners are between
         // pieces -- measured 6-8 % SLOWER on the same device: the late pieces are not landed at the barrier.)
