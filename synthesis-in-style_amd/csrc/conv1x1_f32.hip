@@ -130,6 +130,11 @@ __global__ __launch_bounds__(512, C::OCC) void conv1x1_f32_kernel(PwParams p) {
     const int a_off = h * C::MT + wm * (C::MB * 32) + r;                       // + kp * 2 * MT + mb * 32
     const int b_off = C::A_FLOATS + h * C::NPIX + wn * (C::NB * 32) + r;       // + kp * 2 * NPIX + nb * 32
 
+    float a[2][C::MB], b[2][C::NB];   // fragments one k-pair ahead, carried from chunk to chunk
+#pragma unroll
+    for (int mb = 0; mb < C::MB; ++mb) a[0][mb] = lds[a_off + mb * 32];
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb) b[0][nb] = lds[b_off + nb * 32];
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int cur = chunk & 1;
         const bool more = chunk + 1 < nchunks;
@@ -142,11 +147,10 @@ __global__ __launch_bounds__(512, C::OCC) void conv1x1_f32_kernel(PwParams p) {
         // Fragments one k-pair ahead: the ds_reads of pair kp + 1 are issued BEFORE the MFMAs of pair kp, so the wait in front
         // of a pair's MFMAs (a counted lgkmcnt) finds its operands already there.  As the compiler scheduled the plain loop,
         // every 4 MFMAs were preceded by `ds_read x2; s_waitcnt lgkmcnt(0)`: a full LDS round trip exposed per 256 MFMA cycles.
-        float a[2][C::MB], b[2][C::NB];
-#pragma unroll
-        for (int mb = 0; mb < C::MB; ++mb) a[0][mb] = st[a_off + mb * 32];
-#pragma unroll
-        for (int nb = 0; nb < C::NB; ++nb) b[0][nb] = st[b_off + nb * 32];
+        // The chunk's barrier sits in front of its LAST pair's MFMAs (that pair's fragments are in registers by then, the weights
+        // of the next chunk are stored): the first fragments of chunk + 1 are requested right behind it, under those MFMAs, instead
+        // of in front of the next chunk's first.  (KC / 2 is even: the pair after the last one lands in register set 0 again.)
+        static_assert((C::KC / 2) % 2 == 0, "fragment sets alternate per pair and wrap to set 0 at the chunk end");
 #pragma unroll
         for (int kp = 0; kp < C::KC / 2; ++kp) {
             const int cb = kp & 1, nx = cb ^ 1;
@@ -155,6 +159,17 @@ __global__ __launch_bounds__(512, C::OCC) void conv1x1_f32_kernel(PwParams p) {
                 for (int mb = 0; mb < C::MB; ++mb) a[nx][mb] = st[a_off + (kp + 1) * 2 * C::MT + mb * 32];
 #pragma unroll
                 for (int nb = 0; nb < C::NB; ++nb) b[nx][nb] = st[b_off + (kp + 1) * 2 * C::NPIX + nb * 32];
+            } else {
+                if constexpr (!A_KMAJOR) {
+                    if (more) store_a(cur ^ 1);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of chunk + 1
+                __syncthreads();
+                const float* sn = lds + (cur ^ 1) * C::STAGE;
+#pragma unroll
+                for (int mb = 0; mb < C::MB; ++mb) a[nx][mb] = sn[a_off + mb * 32];
+#pragma unroll
+                for (int nb = 0; nb < C::NB; ++nb) b[nx][nb] = sn[b_off + nb * 32];
             }
 #pragma unroll
             for (int mb = 0; mb < C::MB; ++mb)
@@ -163,11 +178,6 @@ __global__ __launch_bounds__(512, C::OCC) void conv1x1_f32_kernel(PwParams p) {
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb][mb], b[cb][nb], acc[mb][nb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);   // keep the pairs in program order: reads of kp + 1, then MFMAs of kp
         }
-        if constexpr (!A_KMAJOR) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) store_a(cur ^ 1);
-        }
-        __syncthreads();
     }
 
     // ---- epilogue.  The bias of this wave's rows is fetched once (not per element), a row's address is the tile's base plus a

@@ -94,24 +94,41 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wgrad_f32_kernel(const PwgPara
         for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
 
     if (c_lo < c_hi) stage(c_lo, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // Operand quads one step ahead (two register sets; the step loop is unrolled), carried from chunk to chunk.  The chunk's barrier
+    // sits in front of its LAST step's MFMAs -- that step's quads are in registers by then, nobody reads this buffer any more --
+    // and the first quads of chunk + 1 are requested right behind it, under those MFMAs, instead of in front of the next chunk's
+    // first MFMA (one workgroup per CU: nothing else covers that LDS round trip, which all eight waves start at once).
+    f32x4 bq[2], aq[2][MB];
+    auto quads = [&](const float* st, int j, int set) {
+        bq[set] = *reinterpret_cast<const f32x4*>(st + b_base + ((2 * j) ^ b_hi) * 4);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) aq[set][mb] = *reinterpret_cast<const f32x4*>(st + a_base[mb] + ((2 * j) ^ a_hi[mb]) * 4);
+    };
+    quads(lds, 0, 0);
     int buf = 0;
     for (int chunk = c_lo; chunk < c_hi; ++chunk, buf ^= 1) {
         if (chunk + 1 < c_hi) stage(chunk + 1, buf ^ 1);
         const float* st = lds + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(st + b_base + ((2 * j) ^ b_hi) * 4);
+            const int cb = j & 1;
+            if (j < 7) quads(st, j + 1, cb ^ 1);
+            else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of chunk + 1 ...
+                __syncthreads();                                    // ... and everyone's
+                quads(lds + (buf ^ 1) * STAGE, 0, 0);
+            }
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(st + a_base[mb] + ((2 * j) ^ a_hi[mb]) * 4);
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[mb], 0, 0, 0);
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[mb], 0, 0, 0);
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[mb], 0, 0, 0);
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[mb], 0, 0, 0);
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cb][mb].x, bq[cb].x, acc[mb], 0, 0, 0);
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cb][mb].y, bq[cb].y, acc[mb], 0, 0, 0);
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cb][mb].z, bq[cb].z, acc[mb], 0, 0, 0);
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cb][mb].w, bq[cb].w, acc[mb], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);   // quads of step j + 1, then the MFMAs of step j: in program order
         }
-        __syncthreads();  // next chunk landed (vmcnt 0) and everyone is done with this buffer
     }
 
     float* out = (p.jobs ? p.outj[blockIdx.z] : p.out) + (int64_t)blockIdx.y * p.slab_stride;

@@ -33,6 +33,7 @@
 // <= 4 pieces of input rows), double-buffered, one barrier per chunk (as modconv_mfma2.hip).  The style factor s[b, ci] multiplies the
 // raw patch values after their LDS read; demodulation in the epilogue; noise / bias / activation belong to the blur kernel
 // that reads this kernel's (2H+1) x (2W+4)-strided result.
+#include <type_traits>
 #include "modconv_common.h"
 
 namespace {
@@ -141,6 +142,108 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     stage(0, 0);
     __syncthreads();   // vmcnt(0) + barrier: chunk 0 landed
 
+    if constexpr (PIPE == 4) {
+        // Chunks software-pipelined across the barrier (NW == 4, one MFMA step per chunk).  In the plain loop every chunk starts behind
+        // its barrier with 10 LDS reads and ~25 VALU of transform before its first MFMA.  Here the barrier of chunk c sits behind the
+        // request for its last fragment pair (pair 7, asked for in iteration 5): from there on nobody reads buffer c & 1 any more, chunk
+        // c + 1 has landed (its DMA was issued a whole chunk earlier) -- so the DMA of chunk c + 2 goes into the freed buffer and the
+        // transform of chunk c + 1 runs in slices between the 20 MFMAs of plane row 3, and the next chunk starts with MFMAs.
+        static_assert(NW == 4 && ABL == 0, "pipelined form: 4-wave workgroups, no ablations");
+        const int n_chunks = p.Cin / UF_CC;
+        if (n_chunks > 1) stage(UF_CC, 1);
+        __syncthreads();   // (chunk 1 landed as well: once per workgroup)
+        float tA[4][4], tB[4][4], cm0[4], raw[3][3], svn;
+        auto tr_read = [&](int c, int bufc) {   // patch and style of chunk c (clamped past the end: values unused)
+            const int cl = min(c, n_chunks - 1) * UF_CC + kq;
+            svn = Sl[soff + cl];
+            const float* xb = Xl + (bufc * UF_CC + kq) * p.xs + xoff;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) raw[r][j] = xb[r * RW + j];
+        };
+        // column transform of patch row r: rows 1 and 2 ARE rows 1 and 3 of t, row 0 waits in cm0 for the row transform
+        auto tr_col = [&](int r, float (&t)[4][4]) {
+            const float d0 = raw[r][0] * svn, d1 = raw[r][1] * svn, d2 = raw[r][2] * svn;
+            float* o = r == 0 ? cm0 : (r == 1 ? t[1] : t[3]);
+            o[0] = d0 - d1; o[1] = d1; o[2] = d2 - d1; o[3] = d2;
+            // (pinned where it stands: the results are used in the NEXT chunk only, and the compiler otherwise sinks the arithmetic
+            // into that chunk's block, in front of its first MFMA)
+            asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+        };
+        auto tr_row = [&](float (&t)[4][4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = cm0[j] - t[1][j]; t[2][j] = t[3][j] - t[1][j];
+                asm volatile("" : "+v"(t[0][j]), "+v"(t[2][j]));
+            }
+        };
+        tr_read(0, 0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) tr_col(r, tA);
+        tr_row(tA);
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const int woff = kq * UF_WROW + (wm * 32 + l15) * 2;
+        // ring of three fragment pairs, carried from chunk to chunk: pair 0 of chunk c + 1 takes pair 6's slot once that is used up
+        f2 ra[3][2];
+        ra[0][0] = *reinterpret_cast<const f2*>(Wl + woff); ra[0][1] = *reinterpret_cast<const f2*>(Wl + woff + 32);
+        auto chunk = [&](auto parity, int c, const float (&t)[4][4], float (&tn)[4][4]) {
+            constexpr int B = decltype(parity)::value;
+            const float* wb = Wl + B * UF_CC * UF_WROW + woff;
+            auto fetch = [&](int k) {
+                ra[k % 3][0] = *reinterpret_cast<const f2*>(wb + k * 2 * UF_MBLK);
+                ra[k % 3][1] = *reinterpret_cast<const f2*>(wb + k * 2 * UF_MBLK + 32);
+            };
+            fetch(1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k + 2 < 8) fetch(k + 2);
+                if (k == 7) {   // (behind the barrier: chunk c + 1 has landed)
+                    ra[0][0] = *reinterpret_cast<const f2*>(Wl + (B ^ 1) * UF_CC * UF_WROW + woff);
+                    ra[0][1] = *reinterpret_cast<const f2*>(Wl + (B ^ 1) * UF_CC * UF_WROW + woff + 32);
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int i = 2 * k + e, u = i >> 2, v = i & 3;
+                    const float a0 = ra[k % 3][0][e], a1 = ra[k % 3][1][e];
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                        for (int qq = 0; qq < 2; ++qq) {
+                            if ((pp && u != 3) || (qq && v != 3)) continue;
+                            const int pi = u + pp, qi = v + qq;
+                            const int di = pi == 3 ? 1 : (pi == 4 ? 3 : pi), dj = qi == 3 ? 1 : (qi == 4 ? 3 : qi);
+                            acc[pi][qi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, t[di][dj], acc[pi][qi][0], 0, 0, 0);
+                            acc[pi][qi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, t[di][dj], acc[pi][qi][1], 0, 0, 0);
+                        }
+                    if (k >= 5) {   // side work of the chunk's tail, one piece behind each MFMA group
+                        if (k == 5 && e == 1) {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk c + 1 (the compiler does not see them across the back edge)
+                            __syncthreads();
+                            if (c + 2 < n_chunks) stage((c + 2) * UF_CC, B);
+                            tr_read(c + 1, B ^ 1);
+                        }
+                        if (k == 6 && e == 0) { tr_col(0, tn); tr_col(1, tn); }
+                        if (k == 6 && e == 1) tr_col(2, tn);
+                        if (k == 7 && e == 0) tr_row(tn);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (k < 5) {
+                    if (k + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    const int u = (2 * k) >> 2, vhi = ((2 * k) & 3) + 1;
+                    if (u == 3 && vhi == 3) __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                    else if (u == 3) __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                    else if (vhi == 3) __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                }
+            }
+        };
+        for (int c = 0; c < n_chunks; c += 2) {
+            chunk(std::integral_constant<int, 0>(), c, tA, tB);
+            if (c + 1 < n_chunks) chunk(std::integral_constant<int, 1>(), c + 1, tB, tA);
+        }
+    } else {
     int buf = 0;
     float t0[4][4] = {}, t1[4][4] = {};
     // PIPE == 3: the SIMD partners (waves w and w + 4) run out of step inside a chunk -- waves 0-3 issue their DMA for the next
@@ -237,12 +340,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
         if constexpr (!(ABL & 1)) __syncthreads();   // next chunk's DMA retired (vmcnt 0) and everyone is done with this buffer
     }
+    }
 
     // ---- epilogue: output transform, demodulation, 16-byte stores of the block's 4 x 4 outputs per channel
-    if (!live) return;
+    // (PIPE == 4: the block's coordinates are worked out again from the lane number -- the loop has no register to carry them)
+    int eg = g;
+    if constexpr (PIPE == 4) { eg = g0 + wn * 16 + (int)(threadIdx.x & 15); asm volatile("" : "+v"(eg)); }
+    if (eg >= p.total_blocks) return;
+    int eb = b, ebh = bh, ebw = bw;
+    if constexpr (PIPE == 4) { eb = eg / p.bps; const int erem = eg % p.bps; ebh = erem / p.nbw; ebw = erem % p.nbw; }
     const int OHW = p.OH * p.ORS;
-    const float* db = p.dscale + (int64_t)b * p.Cout;
-    float* ob = p.out + (int64_t)b * p.Cout * OHW + (int64_t)(4 * bh) * p.ORS + 4 * bw;
+    const float* db = p.dscale + (int64_t)eb * p.Cout;
+    float* ob = p.out + (int64_t)eb * p.Cout * OHW + (int64_t)(4 * ebh) * p.ORS + 4 * ebw;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -260,7 +369,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             float* oc = ob + (int64_t)co * OHW;
 #pragma unroll
             for (int ro = 0; ro < 4; ++ro) {
-                if (4 * bh + ro >= p.OH) continue;
+                if (4 * ebh + ro >= p.OH) continue;
                 float4 v;
                 if (ro == 0) v = make_float4(cs[0][0] + cs[1][0], cs[0][1] + cs[1][1], cs[0][2] + cs[1][2], cs[0][3] + cs[1][3]);
                 else if (ro == 1) v = make_float4(cs[3][0], cs[3][1], cs[3][2], cs[3][3]);
@@ -369,12 +478,14 @@ extern "C" int sis_modconv2d_up_fir(float* t, const float* x, const float* u, co
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<1, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<0, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_upfir_kernel<4, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e != hipSuccess) return sis_fail("sis_modconv2d_up_fir: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int64_t grid = (int64_t)sis_cdiv(p.total_blocks, UF_NBLK) * (cout / UF_MBLK);
     SIS_REQUIRE(grid > 0 && grid < ((int64_t)1 << 31), "sis_modconv2d_up_fir: bad grid");
-    static const int pipe = getenv("SIS_UPFIR_PIPE") ? atoi(getenv("SIS_UPFIR_PIPE")) : 1;   // software-pipelining variant (experiments)
+    // chunk-loop form: 4 (4-wave workgroups only) = chunks pipelined across the barrier, 1 = fragments a pair ahead, 0 = plain; 2 / 3: 8-wave experiments
+    static const int pipe = getenv("SIS_UPFIR_PIPE") ? atoi(getenv("SIS_UPFIR_PIPE")) : 4;
 #ifdef SIS_ABLATIONS   // development builds only (tools/build_variant.sh WORK <tag> -DSIS_ABLATIONS): the shipped library has no wrong-result path
     static const int abl = getenv("SIS_UPFIR_ABL") ? atoi(getenv("SIS_UPFIR_ABL")) : 0;      // timing ablations: WRONG results
     if (abl) {
@@ -396,7 +507,8 @@ extern "C" int sis_modconv2d_up_fir(float* t, const float* x, const float* u, co
         return 0;
     }
 #endif
-    if (nw == 4 && pipe == 0) hipLaunchKernelGGL((modconv_upfir_kernel<0, 0, 4>), dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
+    if (nw == 4 && pipe == 4) hipLaunchKernelGGL((modconv_upfir_kernel<4, 0, 4>), dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
+    else if (nw == 4 && pipe == 0) hipLaunchKernelGGL((modconv_upfir_kernel<0, 0, 4>), dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
     else if (nw == 4) hipLaunchKernelGGL((modconv_upfir_kernel<1, 0, 4>), dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
     else if (pipe == 0) hipLaunchKernelGGL(modconv_upfir_kernel<0>, dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);
     else if (pipe == 2) hipLaunchKernelGGL(modconv_upfir_kernel<2>, dim3((unsigned)grid), dim3(UF_THREADS), lds, (hipStream_t)stream, p);

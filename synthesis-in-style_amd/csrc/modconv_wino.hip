@@ -676,6 +676,7 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
     tile_first_dma();
     tail_load(T);
     style_store();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // chunk 0 (and input chunk 1) landed, styles visible
     tail_store();
     transform(k_lo, 0, 0);
@@ -719,6 +720,9 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
 #ifdef SIS_WINO_NOBARRIER  // timing experiment only (results are garbage): what does the per-chunk barrier cost?
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
+            // (the wait for this wave's DMA pieces is spelled out: the compiler places its own where it sees an LDS read that may
+            // alias a DMA destination, which need not be in front of the barrier)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // V(c+1) written, DMA retired, everyone done with U(c) / V(c)
 #endif
         };

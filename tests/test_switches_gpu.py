@@ -185,13 +185,20 @@ _C_SIDE = [
 ]
 
 
-def test_c_side_switch_in_a_child_process(device):
+# a second value of a variable above (its own child): the 4-wave fast-FIR workgroups with the loop that is not pipelined across the barrier
+_C_SIDE_2 = [
+    ("SIS_UPFIR_PIPE", "1", "tests/test_generator_gpu.py::test_modconv_up_fir_vs_oracle"),
+]
+
+
+@pytest.mark.parametrize("switches", [_C_SIDE, _C_SIDE_2], ids=["set1", "set2"])
+def test_c_side_switch_in_a_child_process(device, switches):
     """One child process per switch would cost one GPU context each; the switches steer different kernels, so ONE child sets
     them all and reruns the parity tests of those kernels."""
     env = dict(os.environ)
-    for name, value, _ in _C_SIDE:
+    for name, value, _ in switches:
         env[name] = value
-    targets = sorted({t for _, _, t in _C_SIDE})
+    targets = sorted({t for _, _, t in switches})
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", *targets], cwd=_REPO, env=env,
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
