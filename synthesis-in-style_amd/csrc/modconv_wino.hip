@@ -749,9 +749,15 @@ __global__ __launch_bounds__(WNTHR, 2) void modconv_wino2_kernel(const ConvParam
             };
             float sv = 1.f, d[4][4], e[4][4], o[4][4];  // patch, d B, B^T (d B) scaled
             // slot tables: first slot of each kind of side work
-            constexpr int X_STEP = XI > 2 ? 1 : 2;  // input pieces every (second) slot, weight pieces every second slot
-            constexpr int S_UDMA = 0, S_XDMA = 8;
-            static_assert(S_UDMA + 2 * (WIT - 1) < S_XDMA && S_XDMA + X_STEP * (XI - 1) < 32, "DMA pieces must fit the 32 slots");
+#ifndef SIS_WINO_XDMA_EARLY
+#define SIS_WINO_XDMA_EARLY 0
+#endif
+            // input pieces every (second) slot, weight pieces every second slot; EARLY: up to four input pieces in the odd slots
+            // between the weight pieces (the barrier at slot S_BAR waits for all of them: 26 slots of cover instead of 19)
+            constexpr bool X_EARLY = SIS_WINO_XDMA_EARLY && XI <= 4;
+            constexpr int X_STEP = X_EARLY ? 2 : (XI > 2 ? 1 : 2);
+            constexpr int S_UDMA = 0, S_XDMA = X_EARLY ? 1 : 8;
+            static_assert((X_EARLY || S_UDMA + 2 * (WIT - 1) < S_XDMA) && S_XDMA + X_STEP * (XI - 1) < 27, "DMA pieces must fit in front of the barrier");
             constexpr int S_READ = 1, S_RSTEP = 2;  // patch rows: every second slot from slot 1
             constexpr int S_A = 11;                 // d B: 4 slots
             static_assert(S_BAR >= 27 || S_BAR < 0, "slot 0 of the operand registers is in use until slot 27");
