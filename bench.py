@@ -225,6 +225,39 @@ def library_time(updater):
         return {"error": repr(err)}
 
 
+class single_rank_communicator:
+    """N = 1 only: a world-size-1 RCCL communicator for the duration of the data-parallel rehearsal, and not a moment longer --
+    the bare steps (and the synthesis rate, which is timed first) are measured without it."""
+
+    def __init__(self, device):
+        self.device, self.created = device, False
+
+    def __enter__(self):
+        import socket
+        import torch.distributed as dist
+        if dist.is_initialized():
+            return self
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        try:
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=self.device)
+            self.created = True
+        except Exception as err:   # no RCCL on this box: the rehearsal is skipped, the N = 1 measurements do not need it
+            print(f"bench.py: RCCL world-size-1 communicator unavailable ({err!r}); data-parallel rehearsal skipped", file=sys.stderr)
+        return self
+
+    def __exit__(self, *exc):
+        import torch.distributed as dist
+        if self.created and dist.is_initialized():
+            import gc
+            gc.collect()   # (the rehearsal's captured step graphs hold the communicator's collectives: gone before it goes)
+            torch.cuda.synchronize()
+            dist.destroy_process_group()
+        return False
+
+
 def data_parallel_rehearsal(args, workload, config, device):
     """What the N > 1 per-GPU step looks like, as far as ONE GPU can show it: the same training step with the network inside
     the data-parallel wrap over a world-size-1 RCCL communicator (bucketed reduce-scatter + all-gather on RCCL's stream,
@@ -361,7 +394,8 @@ def bench_training(args, workload, world, rank, device, distributed):
     dp = None
     if world == 1 and rank == 0 and args.dp_rehearsal:
         del updater, builder
-        dp = data_parallel_rehearsal(args, workload, config, device)
+        with single_rank_communicator(device):
+            dp = data_parallel_rehearsal(args, workload, config, device)
     if rank != 0:
         return None
     if dp is not None and baseline_config and dp.get("backend") == "nccl" and dp.get("direct_rccl") is False:
@@ -790,18 +824,9 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
-    elif args.dp_rehearsal and args.workload in ("all", "emanet", "transunet"):
-        # N = 1: a one-rank RCCL communicator for the data-parallel rehearsal of the training workloads (bench_training)
-        import socket
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
-            sock.bind(("127.0.0.1", 0))
-            port = sock.getsockname()[1]
-        try:
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
-        except Exception as err:   # no RCCL on this box: the rehearsal is skipped, the N = 1 measurements do not need it
-            print(f"bench.py: RCCL world-size-1 communicator unavailable ({err!r}); data-parallel rehearsal skipped", file=sys.stderr)
+    # (N = 1: the one-rank RCCL communicator of the data-parallel rehearsal is created right before each rehearsal and destroyed
+    # right after it -- single_rank_communicator below.  With it alive from the start, every bare measurement of the process ran
+    # 0.5-1.3 % slower on the same box: synthesis 14.42 -> 14.61 ms per step, tools/ab_bench_modes.sh.)
 
     if args.workload == "dataset":
         result = bench_dataset(args, world, rank, device, distributed)
