@@ -261,3 +261,37 @@ def test_two_rccl_ranks_average_every_bucket(collective, direct):
         r = out[rank]
         assert r["buckets"] >= 2 and r["err"] < 1e-5, r
         assert r["direct"] == (direct == "1"), r   # opted in: the self-check passed and the direct path is live
+
+
+def _scoped_communicator_worker(rank, out):
+    import importlib.util
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    seen = []
+    for _ in range(2):   # (bench.py --workload all: one rehearsal per training workload, each with its own communicator)
+        before = dist.is_initialized()
+        with bench.single_rank_communicator(device) as comm:
+            t = torch.full((4,), 3.0, device=device)
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+            seen.append((before, comm.created, dist.is_initialized(), dist.get_backend(), dist.get_world_size(), float(t.sum())))
+        seen.append(dist.is_initialized())
+    out[rank] = seen
+
+
+def test_bench_rehearsal_communicator_lives_only_inside_the_rehearsal(device):
+    """bench.py at N = 1: the world-size-1 RCCL communicator of the data-parallel rehearsal exists between
+    ``single_rank_communicator.__enter__`` and ``__exit__`` only (alive from the start of the process it cost every bare
+    measurement 0.5-1.3 %), and a second one can be created after the first is gone."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_scoped_communicator_worker, args=(out,), nprocs=1, join=True)
+    first, after_first, second, after_second = out[0]
+    for inside in (first, second):
+        assert inside == (False, True, True, "nccl", 1, 12.0), inside
+    assert after_first is False and after_second is False
