@@ -473,7 +473,7 @@ class Generator(nn.Module):
         if os.environ.get("SIS_RGB_STREAM", "1") == "0":
             return None
         if device not in _RGB_STREAMS:
-            _RGB_STREAMS[device] = torch.cuda.Stream(device=device)
+            _RGB_STREAMS[device] = sis_hip.side_stream(device)   # (one that really runs beside the current stream)
         return _RGB_STREAMS[device]
 
     @staticmethod

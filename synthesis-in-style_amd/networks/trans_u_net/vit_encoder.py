@@ -347,7 +347,7 @@ def _wgrad_stream(device):
         return None
     st = _WGRAD_STREAMS.get(device)
     if st is None:
-        st = _WGRAD_STREAMS[device] = torch.cuda.Stream(device=device)
+        st = _WGRAD_STREAMS[device] = sis_hip.side_stream(device)
     return st
 
 

@@ -220,6 +220,66 @@ def library_calls(reset=False):
 _own_kernels = None
 
 
+# ---------------------------------------------------------------------------------------------------- side streams
+# HIP maps streams onto a handful of hardware queues (4 on this stack), and two streams on ONE queue run their kernels one after
+# the other.  Which pool stream lands beside the default stream's queue depends on what else created streams first: after an RCCL
+# communicator exists, the FIRST stream torch hands out shares the default stream's queue (tools/stream_probe.py: every fourth
+# one does) -- the generator's ToRGB chain then ran behind the convolutions instead of beside them (synthesis 14.29 -> 14.49 ms per
+# step, tools/rccl_alive_cost.py), and a gradient exchange on such a stream would not overlap the backward at all.  So a side
+# stream is CHOSEN: candidates are probed with a pair of spin kernels and the first that really runs beside its partner is kept.
+_SIDE_STREAM_REJECTS = []   # candidates found on the partner's queue: kept alive so that the pool moves on
+_SIDE_STREAM_LOG = []       # (device index, candidates tried, ratio of the chosen one): bench.py / tests read it
+
+
+def _spin_pair_ms(main, cand, cycles):
+    device = main.device
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    with torch.cuda.stream(main):
+        e0.record(main)
+        if cand is not None:
+            cand.wait_event(e0)
+        torch.cuda._sleep(cycles)
+        if cand is not None:
+            with torch.cuda.stream(cand):
+                torch.cuda._sleep(cycles)
+            main.wait_stream(cand)
+        e1.record(main)
+    torch.cuda.synchronize(device)
+    return e0.elapsed_time(e1)
+
+
+def runs_beside(main, cand, cycles=2_000_000):
+    """True when kernels on ``cand`` run concurrently with kernels on ``main`` (two spin kernels take the time of one)."""
+    alone = min(_spin_pair_ms(main, None, cycles) for _ in range(2))
+    both = min(_spin_pair_ms(main, cand, cycles) for _ in range(2))
+    return both < 1.5 * alone, both / max(alone, 1e-6)
+
+
+def side_stream(device, beside=None, tries=8):
+    """A stream of torch's pool whose kernels run CONCURRENTLY with those of ``beside`` (default: the current stream of
+    ``device``).  SIS_STREAM_PROBE=0, or a capture in progress: the first pool stream, unprobed."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise ValueError("side_stream: a HIP device is required")
+    if os.environ.get("SIS_STREAM_PROBE", "1") == "0" or torch.cuda.is_current_stream_capturing():
+        return torch.cuda.Stream(device=device)
+    main = beside if beside is not None else torch.cuda.current_stream(device)
+    cand, ratio = None, None
+    for n in range(1, tries + 1):
+        cand = torch.cuda.Stream(device=device)
+        ok, ratio = runs_beside(main, cand)
+        if ok:
+            _SIDE_STREAM_LOG.append((device.index, n, round(ratio, 2)))
+            return cand
+        _SIDE_STREAM_REJECTS.append(cand)
+    import warnings
+    warnings.warn(f"sis_hip.side_stream: none of {tries} pool streams ran beside the current stream (last ratio {ratio:.2f}); "
+                  f"side-stream work will run serially")
+    _SIDE_STREAM_LOG.append((device.index, tries, round(ratio, 2)))
+    return cand
+
+
 def own_kernel_names():
     """Names of every ``__global__`` function of csrc/*.hip (the library's own device symbols), for classifying profiler
     records into own / vendor-library kernels."""

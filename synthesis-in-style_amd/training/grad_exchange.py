@@ -198,7 +198,8 @@ class BucketedDataParallel(nn.Module):
                 if self._comm is None:
                     self.direct_rccl_note = "this torch build does not expose ProcessGroupNCCL._comm_ptr"
                 else:
-                    self._comm_stream = torch.cuda.Stream(self.device)
+                    import sis_hip
+                    self._comm_stream = sis_hip.side_stream(self.device)   # (on a hardware queue of its own: the exchange overlaps the backward)
                     if self.world > 1 and not self._self_check():
                         self.direct_rccl_note = "start-up self-check of the direct reduce-scatter + all-gather failed"
                         self._comm, self._comm_stream = None, None

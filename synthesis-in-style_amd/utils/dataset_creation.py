@@ -77,7 +77,7 @@ def label_and_encode(image: torch.Tensor, activations: Dict[int, torch.Tensor], 
     if os.environ.get("SIS_LABEL_STREAM", "1") == "0" or not image.is_cuda:
         return sis_hip.make_image_u8(image), {k: cat.predict(activations[k]) for k, cat in catalogs.items()}, None
     if device not in _LABEL_STREAMS:
-        _LABEL_STREAMS[device] = torch.cuda.Stream(device=device)
+        _LABEL_STREAMS[device] = sis_hip.side_stream(device)
     side, main = _LABEL_STREAMS[device], torch.cuda.current_stream(device)
     side.wait_event(main.record_event())
     with torch.cuda.stream(side):

@@ -13,6 +13,20 @@ import bench  # noqa: E402
 
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
+COMM_FIRST = len(sys.argv) > 1 and sys.argv[1] == "first"   # the communicator before the generator and its buffers exist (bench.py's old order)
+
+
+def make_comm():
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+
+
+if COMM_FIRST:
+    make_comm()
 g = bench.build_generator(dev)
 z, noise = bench.synth_inputs(g, bench.BATCH, dev, seed=1)
 
@@ -34,17 +48,21 @@ def phase(tag):
     del out
 
 
-phase("no communicator")
-import torch.distributed as dist  # noqa: E402
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
-phase("group initialised")
-t = torch.ones(1, device=dev)
-dist.all_reduce(t)
-torch.cuda.synchronize()
-phase("after one all_reduce")
-dist.destroy_process_group()
-phase("communicator destroyed")
+if COMM_FIRST:
+    phase("communicator made first")
+    phase("communicator made first (2)")
+    import torch.distributed as dist  # noqa: E402
+    dist.destroy_process_group()
+    phase("destroyed")
+else:
+    phase("no communicator")
+    phase("no communicator (2)")
+    make_comm()
+    import torch.distributed as dist  # noqa: E402
+    phase("group initialised")
+    t = torch.ones(1, device=dev)
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    phase("after one all_reduce")
+    dist.destroy_process_group()
+    phase("communicator destroyed")
