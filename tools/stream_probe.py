@@ -45,3 +45,7 @@ for i in range(10):
     s = torch.cuda.Stream(device=dev)
     both = min(timed(s) for _ in range(2))
     print(f"stream {i} (id {s.stream_id}, handle {s.cuda_stream:#x}): both {both:.3f} ms = {both / alone:.2f} x  ->  {'CONCURRENT' if both < 1.5 * alone else 'serial'}")
+for i in range(6):   # torch.distributed's ProcessGroupNCCL takes its stream from the HIGH-priority pool
+    s = torch.cuda.Stream(device=dev, priority=-1)
+    both = min(timed(s) for _ in range(2))
+    print(f"high-priority stream {i} (id {s.stream_id}): both {both:.3f} ms = {both / alone:.2f} x  ->  {'CONCURRENT' if both < 1.5 * alone else 'serial'}")
