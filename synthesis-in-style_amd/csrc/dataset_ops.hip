@@ -715,7 +715,10 @@ static int kmeans_assign_impl(int64_t* labels, const float* x, const float* cent
             }
             const int64_t tiles = (int64_t)batch * (hw / 128);   // wave tiles of 128 pixels; workgroups persistent over them
             SIS_REQUIRE(tiles < ((int64_t)1 << 31), "sis_kmeans_assign: too many pixels");
-            const int blocks = (int)std::min<int64_t>(sis_cdiv(tiles, 4), 512);
+            // (SIS_KMEANS_MAX_WG: fewer persistent workgroups leave compute units to whatever runs beside the pass; read per call)
+            const char* wg_env = getenv("SIS_KMEANS_MAX_WG");
+            const int max_wg = wg_env && atoi(wg_env) > 0 ? atoi(wg_env) : 512;
+            const int blocks = (int)std::min<int64_t>(sis_cdiv(tiles, 4), max_wg);
             hipLaunchKernelGGL(kmeans_mfma_kernel, dim3(blocks), dim3(256), (size_t)(channels + 9) * 32 * sizeof(float), st, labels, x,
                                centres, channels, hw, n_centres, (int)tiles, e_x, e_c, count, list);
             SIS_CHECK_LAUNCH("kmeans_mfma_kernel");

@@ -43,6 +43,7 @@ import sis_hip
 from networks import hip_conv
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 
+_NOISE_ONE_LAUNCH = os.environ.get('SIS_NOISE_ONE_LAUNCH', '1') != '0'   # make_noise(): all maps from one randn launch (device only)
 _RGB_STREAMS = {}  # device -> side stream of the ToRGB chain (process-wide: streams are not copyable module state)
 
 
@@ -409,6 +410,15 @@ class Generator(nn.Module):
     def make_noise(self) -> typing.List[torch.Tensor]:
         device = self.input.input.device
         sizes = [4] + [2 ** i for i in range(3, self.log_size + 1) for _ in range(2)]
+        if device.type == 'cuda' and _NOISE_ONE_LAUNCH:
+            # one generator launch for all maps (13 launches of 5-12 us each otherwise, on the critical path of the dataset loop):
+            # the maps are consecutive slices of one buffer (every offset a multiple of 16 floats)
+            flat = torch.randn(sum(s * s for s in sizes), device=device)
+            out, o = [], 0
+            for s in sizes:
+                out.append(flat[o:o + s * s].view(1, 1, s, s))
+                o += s * s
+            return out
         return [torch.randn(1, 1, s, s, device=device) for s in sizes]
 
     def mean_latent(self, n_latent):

@@ -280,3 +280,31 @@ def test_loader_leaves_grad_mode_on_and_feeds_an_updater(device):
     after = list(builder.get_network().parameters())[:4]
     assert all(torch.isfinite(a).all() for a in after)
     assert any(not torch.equal(a, b) for a, b in zip(after, before)), "the step fed by the loader did not train"
+
+
+def test_make_noise_on_the_device_is_one_launch_of_consecutive_maps(device, monkeypatch):
+    """``Generator.make_noise()`` on a HIP device draws all maps with ONE generator launch and returns them as consecutive
+    slices of that buffer (13 launches on the critical path of the dataset loop otherwise; SIS_NOISE_ONE_LAUNCH=0: one tensor
+    per map as in the reference, networks/stylegan2/model.py:443-452).  Same shapes, dense, 64-byte aligned, unit variance; the
+    generator takes either form and the same maps give the same image."""
+    import networks.stylegan2.model as M
+    g = M.Generator(64, 64, 2, channel_multiplier=1).to(device).eval()
+    want = [(1, 1, 4, 4)] + [(1, 1, 2 ** i, 2 ** i) for i in range(3, 7) for _ in range(2)]
+    torch.manual_seed(5)
+    one = g.make_noise()
+    assert [tuple(n.shape) for n in one] == want
+    assert all(n.is_contiguous() and n.data_ptr() % 64 == 0 for n in one)
+    base = one[0].untyped_storage().data_ptr()
+    assert all(n.untyped_storage().data_ptr() == base for n in one), "one buffer behind all maps"
+    ends = [n.data_ptr() + n.numel() * 4 for n in one]
+    assert all(a == b.data_ptr() for a, b in zip(ends[:-1], one[1:])), "consecutive slices"
+    flat = torch.cat([n.flatten() for n in one])
+    assert abs(float(flat.mean())) < 0.05 and abs(float(flat.std()) - 1) < 0.05
+    monkeypatch.setattr(M, "_NOISE_ONE_LAUNCH", False)
+    many = g.make_noise()
+    assert [tuple(n.shape) for n in many] == want and len({n.untyped_storage().data_ptr() for n in many}) == len(many)
+    z = torch.randn(2, 64, device=device)
+    with torch.no_grad():
+        img_views, _ = g([z], noise=one)
+        img_copies, _ = g([z], noise=[n.clone() for n in one])
+    assert torch.equal(img_views, img_copies)
